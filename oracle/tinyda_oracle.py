@@ -1,0 +1,327 @@
+"""CPU oracle for the tinyDA many-chain MH hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The shipped path (tinyda_amd/) never does; it fails loudly when the HIP library is missing.
+
+What this is: a NumPy restatement of the reference algorithm (mikkelbue/tinyDA, pure Python)
+for the path tda.sample() -> Chain.sample -> Proposal / Posterior / GaussianLogLike, written
+batch-of-chains (arrays are [chain, ...]) so that N chains advance in lock-step exactly like
+the device engine, but with every formula kept in the reference's own arithmetic form.
+Each function cites the reference file:line it follows (paths relative to /root/reference).
+
+Pinned: tests/test_oracle_golden.py checks this module against tests/golden/*.npz, which were
+produced by running the reference itself (tests/golden/gen_golden.py) on recorded variates.
+
+Random variates: the reference uses the global MT19937 stream; parity is defined on identical
+*variates* (SURVEY.md §7).  Every driver here takes explicit arrays z[chain, step, d] and
+u[chain, step]; `PhiloxStream` restates the engine's counter-based stream so the device RNG can
+be checked word for word.
+"""
+import math
+
+import numpy as np
+
+LOG_2PI = math.log(2.0 * math.pi)
+
+# ----------------------------------------------------------------------------------------
+# Philox4x32-10 stream (the engine's RNG contract, include/tinyda_amd.h "RNG stream")
+# ----------------------------------------------------------------------------------------
+_M0 = np.uint64(0xD2511F53)
+_M1 = np.uint64(0xCD9E8D57)
+_W0 = np.uint32(0x9E3779B9)
+_W1 = np.uint32(0xBB67AE85)
+_MASK = np.uint64(0xFFFFFFFF)
+
+STREAM_PROPOSAL = 0
+STREAM_ACCEPT = 1
+STREAM_INIT = 2
+STREAM_DREAM = 3
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox-4x32 with 10 rounds (Salmon et al. 2011), vectorised over equal-shaped counters."""
+    c0, c1, c2, c3 = [np.asarray(c, dtype=np.uint32).copy() for c in np.broadcast_arrays(c0, c1, c2, c3)]
+    k0 = np.uint32(k0)
+    k1 = np.uint32(k1)
+    with np.errstate(over="ignore"):
+        for _ in range(10):
+            p0 = c0.astype(np.uint64) * _M0
+            p1 = c2.astype(np.uint64) * _M1
+            hi0 = (p0 >> np.uint64(32)).astype(np.uint32)
+            lo0 = (p0 & _MASK).astype(np.uint32)
+            hi1 = (p1 >> np.uint64(32)).astype(np.uint32)
+            lo1 = (p1 & _MASK).astype(np.uint32)
+            c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+            k0 = np.uint32(k0 + _W0)
+            k1 = np.uint32(k1 + _W1)
+    return c0, c1, c2, c3
+
+
+def u53(xa, xb):
+    """53-bit uniform in [0, 1): ((xa >> 5) * 2^26 + (xb >> 6)) * 2^-53."""
+    return ((xa >> np.uint32(5)).astype(np.float64) * 67108864.0 + (xb >> np.uint32(6)).astype(np.float64)) * (
+        1.0 / 9007199254740992.0
+    )
+
+
+class PhiloxStream:
+    """key = (seed lo, seed hi); counter = (block, step, global chain id, stream tag)."""
+
+    def __init__(self, seed):
+        self.k0 = np.uint32(seed & 0xFFFFFFFF)
+        self.k1 = np.uint32((seed >> 32) & 0xFFFFFFFF)
+
+    def words(self, chain, step, stream, block):
+        return philox4x32_10(block, step, chain, stream, self.k0, self.k1)
+
+    def normals(self, chains, step, d, stream=STREAM_PROPOSAL):
+        """[len(chains), d] standard normals: block b -> (z[2b], z[2b+1]) by Box-Muller,
+        r = sqrt(-2 ln(1-u1)), angle = 2 pi u2."""
+        chains = np.asarray(chains, dtype=np.uint32)
+        nb = (d + 1) // 2
+        b = np.arange(nb, dtype=np.uint32)[None, :]
+        x0, x1, x2, x3 = self.words(chains[:, None], np.uint32(step), np.uint32(stream), b)
+        u1 = u53(x0, x1)
+        u2 = u53(x2, x3)
+        r = np.sqrt(-2.0 * np.log(1.0 - u1))
+        ang = 2.0 * np.pi * u2
+        z = np.empty((chains.shape[0], 2 * nb))
+        z[:, 0::2] = r * np.cos(ang)
+        z[:, 1::2] = r * np.sin(ang)
+        return z[:, :d]
+
+    def uniform(self, chains, step, level=0):
+        chains = np.asarray(chains, dtype=np.uint32)
+        x0, x1, _, _ = self.words(chains, np.uint32(step), np.uint32(STREAM_ACCEPT), np.uint32(level))
+        return u53(x0, x1)
+
+
+# ----------------------------------------------------------------------------------------
+# densities
+# ----------------------------------------------------------------------------------------
+class MVNPrior:
+    """scipy.stats.multivariate_normal(mean, cov).logpdf as called at posterior.py:92.
+
+    scipy (1.15, _multivariate.py `_logpdf` / `_PSD`) evaluates
+        -0.5 * (rank*log(2 pi) + log_pdet + || (x-mean) @ U ||^2),  U = eigvec / sqrt(eigval)
+    from a symmetric eigendecomposition; restated here with numpy.linalg.eigh.
+    """
+
+    def __init__(self, mean, cov):
+        self.mean = np.asarray(mean, dtype=float)
+        self.cov = np.asarray(cov, dtype=float)
+        s, v = np.linalg.eigh(self.cov)
+        self.U = v / np.sqrt(s)
+        self.log_pdet = float(np.sum(np.log(s)))
+        self.rank = self.mean.shape[0]
+
+    def logpdf(self, x):
+        dev = np.atleast_2d(x) - self.mean
+        maha = np.sum(np.square(dev @ self.U), axis=-1)
+        return -0.5 * (self.rank * LOG_2PI + self.log_pdet + maha)
+
+
+def loglike_isotropic(F, data, var):
+    """distributions.py:324-326  -0.5 * ||F - data||^2 / var  (norm, then squared)."""
+    return -0.5 * np.linalg.norm(F - data, axis=-1) ** 2 / var
+
+
+def loglike_diagonal(F, data, diag_cov):
+    """distributions.py:310-312  -0.5 * sum((F - data)^2 / diag)."""
+    return -0.5 * ((F - data) ** 2 / diag_cov).sum(axis=-1)
+
+
+def loglike_dense(F, data, cov_inverse, bias=0.0):
+    """distributions.py:295-298 (bias = 0) and :419-425 / :444-446 (bias-corrected)."""
+    r = F + bias - data
+    return -0.5 * np.einsum("...i,ij,...j->...", r, cov_inverse, r)
+
+
+def make_loglike(kind, data, noise):
+    """GaussianLogLike factory outcome (distributions.py:203-243) as a closure over F[chain, m].
+    kind: 'iso' (noise = variance), 'diag' (noise = diagonal), 'dense' (noise = covariance)."""
+    data = np.asarray(data, dtype=float)
+    if kind == "iso":
+        var = float(noise)
+        return lambda F: loglike_isotropic(F, data, var)
+    if kind == "diag":
+        dg = np.asarray(noise, dtype=float)
+        return lambda F: loglike_diagonal(F, data, dg)
+    if kind == "dense":
+        inv = np.linalg.inv(np.asarray(noise, dtype=float))  # distributions.py:280
+        return lambda F: loglike_dense(F, data, inv)
+    raise ValueError(kind)
+
+
+def classify_covariance(cov):
+    """Which class the factory returns (distributions.py:237-243)."""
+    cov = np.asarray(cov)
+    if np.count_nonzero(cov - np.diag(np.diag(cov))) == 0:
+        if np.all(np.diag(cov) == cov[0, 0]):
+            return "iso"
+        return "diag"
+    return "dense"
+
+
+class AdaptiveLogLike:
+    """AdaptiveGaussianLogLike (distributions.py:332-449), one instance per chain batch entry."""
+
+    def __init__(self, data, cov):
+        self.data = np.asarray(data, dtype=float)
+        self.cov = np.asarray(cov, dtype=float)
+        self.cov_inverse = np.linalg.inv(self.cov)
+        self.bias = np.zeros(self.data.shape[0])
+
+    def set_bias(self, mean_bias, cov_bias):
+        self.bias = mean_bias
+        if not np.all(cov_bias < 1e-9):  # distributions.py:399-402
+            self.cov_inverse = np.linalg.inv(self.cov + cov_bias)
+
+    def loglike(self, F):
+        return loglike_dense(F, self.data, self.cov_inverse, self.bias)
+
+    def loglike_custom_bias(self, F, bias):
+        return loglike_dense(F, self.data, self.cov_inverse, bias)
+
+
+# ----------------------------------------------------------------------------------------
+# running moments  (utils.py:104-124, :189-201)
+# ----------------------------------------------------------------------------------------
+def moments_update(mu, sigma, t, x, sd=1.0, epsilon=0.0):
+    """One RecursiveSampleMoments.update for a batch: mu[N,d], sigma[N,d,d], x[N,d]; t is the
+    recursion counter BEFORE the update (starts at 1).  Same operation order as utils.py:113-122."""
+    d = mu.shape[-1]
+    mu_prev = mu
+    mu_new = (1 / (t + 1)) * (t * mu_prev + x)
+    outer = lambda a: a[..., :, None] * a[..., None, :]
+    sigma_new = (t - 1) / t * sigma + sd / t * (
+        t * outer(mu_prev) - (t + 1) * outer(mu_new) + outer(x) + epsilon * np.eye(d)
+    )
+    return mu_new, sigma_new
+
+
+def zero_mean_moments_update(sigma, t, x):
+    """ZeroMeanRecursiveSampleMoments.update (utils.py:189-201)."""
+    return (t - 1) / t * sigma + 1 / t * (x[..., :, None] * x[..., None, :])
+
+
+# ----------------------------------------------------------------------------------------
+# single-level Metropolis-Hastings (chain.py:37-129) with GRW / pCN / AM proposals
+# ----------------------------------------------------------------------------------------
+class LinearGaussianLevel:
+    """Posterior.create_link (posterior.py:78-110) for model F = A theta (+ b)."""
+
+    def __init__(self, A, data, noise_kind, noise, prior, b=None):
+        self.A = np.asarray(A, dtype=float)
+        self.b = None if b is None else np.asarray(b, dtype=float)
+        self.prior = prior
+        self.loglike = make_loglike(noise_kind, data, noise)
+
+    def forward(self, theta):
+        F = theta @ self.A.T
+        return F if self.b is None else F + self.b
+
+    def evaluate(self, theta):
+        lp = self.prior.logpdf(theta)
+        F = self.forward(theta)
+        ll = self.loglike(F)
+        return lp, ll, F
+
+
+def _acceptance(kind, lp_new, ll_new, lp_old, ll_old):
+    """proposal.py:253-258 (GRW/AM/DREAMZ: posterior ratio) and :357-362 (pCN: likelihood ratio).
+    posterior = prior + likelihood as in link.py:48; NaN posterior -> 0."""
+    post_new = lp_new + ll_new
+    post_old = lp_old + ll_old
+    with np.errstate(over="ignore", invalid="ignore"):
+        if kind == "pcn":
+            alpha = np.exp(ll_new - ll_old)
+        else:
+            alpha = np.exp(post_new - post_old)
+    return np.where(np.isnan(post_new), 0.0, alpha)
+
+
+def run_mh(level, proposal, theta0, z, u):
+    """N chains x T steps of Chain.sample (chain.py:95-125) on recorded variates.
+
+    proposal: dict with 'kind' in {'grw','pcn','am'} and
+        grw: C[d,d], scaling, adaptive, gamma, period            (proposal.py:171-258)
+        pcn: scaling(beta), adaptive, gamma, period; C = prior covariance (proposal.py:302-362)
+        am : C0[d,d], sd, epsilon, t0, period, adaptive, gamma   (proposal.py:416-512)
+    theta0[N,d]; z[N,T,d] standard normals mapped through chol(C) (see gen_golden.py); u[N,T].
+    Returns dict of traces with the initial link at index 0, like tinyDA's chain lists.
+    """
+    theta0 = np.asarray(theta0, dtype=float)
+    N, d = theta0.shape
+    T = z.shape[1]
+    kind = proposal["kind"]
+    adaptive = bool(proposal.get("adaptive", False))
+    gamma = float(proposal.get("gamma", 1.01))
+    period = int(proposal.get("period", 100))
+    alpha_star = 0.24  # proposal.py:169
+
+    if kind == "grw":
+        C = np.broadcast_to(np.asarray(proposal["C"], dtype=float), (N, d, d)).copy()
+        scaling = np.full(N, float(proposal.get("scaling", 1.0)))
+    elif kind == "pcn":
+        C = np.broadcast_to(level.prior.cov, (N, d, d)).copy()  # proposal.py:336-341
+        scaling = np.full(N, float(proposal.get("scaling", 0.1)))
+    elif kind == "am":
+        C = np.broadcast_to(np.asarray(proposal["C0"], dtype=float), (N, d, d)).copy()
+        scaling = np.ones(N)  # proposal.py:462
+        sd = proposal.get("sd")
+        sd = min(1.0, 2.4 ** 2 / d) if sd is None else float(sd)  # proposal.py:465-468
+        eps = float(proposal.get("epsilon", 1e-6))
+        t0 = int(proposal.get("t0", 0))
+        am_mu = theta0.copy()  # proposal.py:495-500
+        am_sigma = np.zeros((N, d, d))
+    else:
+        raise ValueError(kind)
+    L = np.linalg.cholesky(C)
+
+    theta = theta0.copy()
+    lp, ll, _ = level.evaluate(theta)
+    out_theta = np.empty((N, T + 1, d))
+    out_lp = np.empty((N, T + 1))
+    out_ll = np.empty((N, T + 1))
+    out_acc = np.ones((N, T + 1), dtype=np.uint8)
+    out_theta[:, 0], out_lp[:, 0], out_ll[:, 0] = theta, lp, ll
+    scaling_hist, C_hist = [], []
+    t = 0  # proposal.t: number of adapt() calls
+    k = 0  # diminishing-adaptation counter
+
+    for s in range(T):
+        inc = np.einsum("nij,nj->ni", L, z[:, s])
+        if kind == "pcn":
+            prop = np.sqrt(1 - scaling ** 2)[:, None] * theta + scaling[:, None] * inc  # proposal.py:351-355
+        else:
+            prop = theta + scaling[:, None] * inc  # proposal.py:249-251
+        lp_n, ll_n, _ = level.evaluate(prop)
+        alpha = _acceptance(kind, lp_n, ll_n, lp, ll)
+        acc = u[:, s] < alpha  # chain.py:112
+        theta = np.where(acc[:, None], prop, theta)
+        lp = np.where(acc, lp_n, lp)
+        ll = np.where(acc, ll_n, ll)
+        out_theta[:, s + 1], out_lp[:, s + 1], out_ll[:, s + 1], out_acc[:, s + 1] = theta, lp, ll, acc
+
+        # ---- adapt (proposal.py:228-245; AM :502-512) ----
+        t += 1
+        if adaptive and t % period == 0:
+            rate = out_acc[:, : s + 2][:, -period:].mean(axis=1)
+            scaling = np.exp(np.log(scaling) + gamma ** -k * (rate - alpha_star))
+            k += 1
+        if kind == "am":
+            am_mu, am_sigma = moments_update(am_mu, am_sigma, t, theta, sd, eps)  # recursor.t == t here
+            if t >= t0 and t % period == 0:
+                C = am_sigma.copy()
+                L = np.linalg.cholesky(C)
+        if t % period == 0:
+            scaling_hist.append(scaling.copy())
+            C_hist.append(C.copy())
+
+    res = dict(theta=out_theta, logprior=out_lp, loglike=out_ll, logpost=out_lp + out_ll, accepted=out_acc,
+               scaling=scaling, scaling_hist=np.array(scaling_hist).T if scaling_hist else None,
+               C_hist=np.swapaxes(np.array(C_hist), 0, 1) if C_hist else None, C=C, L=L)
+    if kind == "am":
+        res.update(am_mu=am_mu, am_sigma=am_sigma)
+    return res

@@ -1,0 +1,349 @@
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE (tinyDA) itself.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/gen_golden.py            # all fixtures
+    python tests/golden/gen_golden.py g2_am_small  # one fixture
+
+Every fixture is plain data: the problem definition (A, data, noise, prior, proposal settings),
+the random variates the reference consumed, and what the reference produced (per-step
+parameters / log-prior / log-likelihood / accept flags / adaptation state).  No reference
+source text is stored.
+
+How variates are pinned (SURVEY.md §8(c), §7 "hard parts"): tinyDA looks up np.random.* at call
+time, so the functions it uses are replaced by a tap that
+  * draws d legacy standard normals `z` and returns `mean + chol(C) @ z` for
+    np.random.multivariate_normal (NumPy's own map is SVD based and not reproducible elsewhere;
+    the Cholesky map has the same law), recording z;
+  * records every np.random.random / uniform / normal / choice / randint result.
+Chains are run one after the other exactly as tinyDA's sequential sampler does
+(sampler.py:295-309, 335-368, 441-473) but each chain gets deep-copied posteriors so the
+sequential-mode likelihood leak is not baked into the vectors.
+"""
+import copy
+import os
+import sys
+
+import numpy as np
+import scipy.stats as stats
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from _refload import load_reference  # noqa: E402
+
+tda = load_reference()
+
+
+# --------------------------------------------------------------------------------------
+# variate tap
+# --------------------------------------------------------------------------------------
+class Tap:
+    """Replaces the np.random entry points tinyDA calls; records what was handed out."""
+
+    NAMES = ("multivariate_normal", "random", "uniform", "normal", "choice", "randint")
+
+    def __init__(self, seed):
+        self.rs = np.random.RandomState(seed)
+        self.log = []  # list of (kind, value)
+        self._saved = {}
+
+    # -- the replacement functions -------------------------------------------------
+    def multivariate_normal(self, mean, cov, size=None):
+        assert size is None
+        mean = np.asarray(mean, dtype=float)
+        z = self.rs.standard_normal(mean.shape[0])
+        L = np.linalg.cholesky(np.asarray(cov, dtype=float))
+        self.log.append(("z", z.copy()))
+        return mean + L @ z
+
+    def random(self, size=None):
+        assert size is None
+        u = self.rs.random_sample()
+        self.log.append(("u", u))
+        return u
+
+    def uniform(self, low=0.0, high=1.0, size=None):
+        x = self.rs.random_sample(size)
+        self.log.append(("uniform01", np.array(x, copy=True)))
+        return low + (high - low) * x
+
+    def normal(self, loc=0.0, scale=1.0, size=None):
+        x = self.rs.standard_normal(size)
+        self.log.append(("normal01", np.array(x, copy=True)))
+        return loc + scale * x
+
+    def choice(self, a, size=None, replace=True, p=None):
+        r = self.rs.choice(a, size=size, replace=replace, p=p)
+        self.log.append(("choice", np.array(r, copy=True)))
+        return r
+
+    def randint(self, low, high=None, size=None):
+        r = self.rs.randint(low, high, size)
+        self.log.append(("randint", np.array(r, copy=True)))
+        return r
+
+    # -- context manager -------------------------------------------------------------
+    def __enter__(self):
+        for n in self.NAMES:
+            self._saved[n] = getattr(np.random, n)
+            setattr(np.random, n, getattr(self, n))
+        return self
+
+    def __exit__(self, *exc):
+        for n, f in self._saved.items():
+            setattr(np.random, n, f)
+
+    def take(self, kind):
+        return [v for k, v in self.log if k == kind]
+
+
+# --------------------------------------------------------------------------------------
+# problem builders
+# --------------------------------------------------------------------------------------
+def linear_problem(seed, d, m, sigma=0.1, a_scale=None):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((m, d)) / (a_scale if a_scale else np.sqrt(d))
+    theta_true = rng.standard_normal(d)
+    y = A @ theta_true + sigma * rng.standard_normal(m)
+    return A, theta_true, y
+
+
+def make_model(A, b=None):
+    if b is None:
+        return lambda th: A @ th
+    return lambda th: A @ th + b
+
+
+def chain_trace(chain_links):
+    th = np.array([l.parameters for l in chain_links])
+    pr = np.array([l.prior for l in chain_links])
+    ll = np.array([l.likelihood for l in chain_links])
+    po = np.array([l.posterior for l in chain_links])
+    return th, pr, ll, po
+
+
+def run_mh(posterior, proposal, theta0, iterations, n_chains, seed, snapshot=None):
+    """Run tinyDA.Chain for each chain; returns stacked traces [chain][step]."""
+    out = {k: [] for k in ("theta", "logprior", "loglike", "logpost", "accepted", "z", "u")}
+    snaps = []
+    for c in range(n_chains):
+        post = copy.deepcopy(posterior)
+        prop = copy.deepcopy(proposal)
+        with Tap(seed + 1000 * c) as tap:
+            ch = tda.Chain(post, prop, theta0[c].copy())
+            if snapshot is None:
+                ch.sample(iterations, progressbar=False)
+            else:
+                period = snapshot["period"]
+                done = 0
+                snap_c = []
+                while done < iterations:
+                    n = min(period, iterations - done)
+                    ch.sample(n, progressbar=False)
+                    done += n
+                    snap_c.append(snapshot["fn"](ch.proposal))
+                snaps.append(snap_c)
+        th, pr, ll, po = chain_trace(ch.chain)
+        out["theta"].append(th)
+        out["logprior"].append(pr)
+        out["loglike"].append(ll)
+        out["logpost"].append(po)
+        out["accepted"].append(np.array(ch.accepted, dtype=np.uint8))
+        out["z"].append(np.array(tap.take("z")))
+        out["u"].append(np.array(tap.take("u")))
+    res = {k: np.array(v) for k, v in out.items()}
+    return res, snaps
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %-28s %7.1f KiB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+# --------------------------------------------------------------------------------------
+# fixtures
+# --------------------------------------------------------------------------------------
+def g1_basic_sampler():
+    """BASELINE config 1 (examples/Basic Sampler.ipynb): 2-parameter linear regression,
+    GaussianRandomWalk(C=I, scaling=0.1, adaptive=True), isotropic likelihood."""
+    rs = np.random.RandomState(0)
+    x = np.linspace(0, 1, 50)
+    y = 1.0 + 2.0 * x + rs.normal(0, 0.2, 50)
+    A = np.stack([np.ones_like(x), x], axis=1)
+    prior = stats.multivariate_normal(np.zeros(2), np.eye(2))
+    like = tda.GaussianLogLike(y, 0.04 * np.eye(50))
+    assert type(like).__name__ == "IsotropicGaussianLogLike"
+    post = tda.Posterior(prior, like, make_model(A))
+    prop = tda.GaussianRandomWalk(C=np.eye(2), scaling=0.1, adaptive=True, gamma=1.01, period=50)
+    theta0 = np.array([[0.3, -0.2], [1.5, 0.7]])
+    res, snaps = run_mh(post, prop, theta0, 300, 2, seed=11,
+                        snapshot={"period": 50, "fn": lambda p: (p.scaling, p.k, p.t)})
+    save("g1_basic_sampler", A=A, data=y, noise_var=np.array(0.04), prior_mean=np.zeros(2),
+         prior_cov=np.eye(2), C=np.eye(2), scaling0=np.array(0.1), gamma=np.array(1.01),
+         period=np.array(50), theta0=theta0, scaling_hist=np.array(snaps)[:, :, 0],
+         **res)
+
+
+def g2_am(name, d, m, n_chains, iters, t0, period, seed, c0=1e-2, adaptive=False,
+          noise="iso", prior_kind="identity", sd=None, eps=1e-6, sigma=0.1):
+    A, theta_true, y = linear_problem(seed, d, m, sigma=sigma)
+    rng = np.random.default_rng(seed + 7)
+    if prior_kind == "identity":
+        pm, pc = np.zeros(d), np.eye(d)
+    else:
+        B = rng.standard_normal((d, d)) / np.sqrt(d)
+        pc = B @ B.T + 0.5 * np.eye(d)
+        pm = 0.1 * rng.standard_normal(d)
+    prior = stats.multivariate_normal(pm, pc)
+    if noise == "iso":
+        cov = sigma ** 2 * np.eye(m)
+    elif noise == "diag":
+        cov = np.diag(sigma ** 2 * (0.5 + rng.random(m)))
+    else:
+        Lc = sigma * np.eye(m) + 0.01 * np.tril(rng.standard_normal((m, m)))
+        cov = Lc @ Lc.T
+    like = tda.GaussianLogLike(y, cov)
+    post = tda.Posterior(prior, like, make_model(A))
+    C0 = c0 * np.eye(d)
+    prop = tda.AdaptiveMetropolis(C0=C0, sd=sd, epsilon=eps, t0=t0, period=period,
+                                  adaptive=adaptive, gamma=1.01)
+    theta0 = theta_true[None, :] + 0.05 * rng.standard_normal((n_chains, d))
+
+    def snap(p):
+        return (p.C.copy(), p.AM_recursor.get_mu().copy(), p.AM_recursor.get_sigma().copy(),
+                float(p.scaling), int(p.t))
+
+    res, snaps = run_mh(post, prop, theta0, iters, n_chains, seed=seed + 100,
+                        snapshot={"period": period, "fn": snap})
+    C_hist = np.array([[s[0] for s in sc] for sc in snaps])
+    mu_hist = np.array([[s[1] for s in sc] for sc in snaps])
+    sig_hist = np.array([[s[2] for s in sc] for sc in snaps])
+    scal_hist = np.array([[s[3] for s in sc] for sc in snaps])
+    save(name, A=A, data=y, noise_kind=np.array(noise), noise_cov=cov if noise == "dense" else np.diag(cov),
+         prior_mean=pm, prior_cov=pc, C0=C0, sd=np.array(prop.sd), epsilon=np.array(eps),
+         t0=np.array(t0), period=np.array(period), adaptive=np.array(adaptive), gamma=np.array(1.01),
+         theta0=theta0, C_hist=C_hist, mu_hist=mu_hist, sigma_hist=sig_hist,
+         scaling_hist=scal_hist, like_class=np.array(type(like).__name__), **res)
+
+
+def g2b_pcn():
+    d, m, n_chains, iters = 8, 16, 4, 200
+    A, theta_true, y = linear_problem(21, d, m, sigma=0.2)
+    rng = np.random.default_rng(22)
+    B = rng.standard_normal((d, d)) / np.sqrt(d)
+    pc = B @ B.T + 0.5 * np.eye(d)
+    pm = np.zeros(d)
+    prior = stats.multivariate_normal(pm, pc)
+    like = tda.GaussianLogLike(y, 0.04 * np.eye(m))
+    post = tda.Posterior(prior, like, make_model(A))
+    prop = tda.CrankNicolson(scaling=0.15, adaptive=True, gamma=1.02, period=40)
+    theta0 = 0.3 * rng.standard_normal((n_chains, d))
+    res, snaps = run_mh(post, prop, theta0, iters, n_chains, seed=230,
+                        snapshot={"period": 40, "fn": lambda p: float(p.scaling)})
+    save("g2b_pcn", A=A, data=y, noise_var=np.array(0.04), prior_mean=pm, prior_cov=pc,
+         scaling0=np.array(0.15), gamma=np.array(1.02), period=np.array(40), theta0=theta0,
+         scaling_hist=np.array(snaps), **res)
+
+
+def g3_loglike_kats():
+    rng = np.random.default_rng(31)
+    m = 12
+    data = rng.standard_normal(m)
+    X = rng.standard_normal((6, m))
+    iso = tda.GaussianLogLike(data, 0.3 * np.eye(m))
+    dg = np.diag(0.1 + rng.random(m))
+    diag = tda.GaussianLogLike(data, dg)
+    Lc = 0.5 * np.eye(m) + 0.2 * np.tril(rng.standard_normal((m, m)))
+    dense_cov = Lc @ Lc.T
+    dense = tda.GaussianLogLike(data, dense_cov)
+    names = np.array([type(o).__name__ for o in (iso, diag, dense)])
+    ada = tda.AdaptiveGaussianLogLike(data, dense_cov)
+    out_ada0 = np.array([ada.loglike(x) for x in X])
+    bias = 0.1 * rng.standard_normal(m)
+    Bc = 0.05 * rng.standard_normal((m, m))
+    bias_cov = Bc @ Bc.T
+    ada.set_bias(bias, bias_cov)
+    out_ada1 = np.array([ada.loglike(x) for x in X])
+    custom = 0.2 * rng.standard_normal(m)
+    out_ada_custom = np.array([ada.loglike_custom_bias(x, custom) for x in X])
+    # threshold case: every entry < 1e-9 -> inverse NOT refreshed (distributions.py:399-402)
+    ada2 = tda.AdaptiveGaussianLogLike(data, dense_cov)
+    tiny_cov = 1e-10 * np.ones((m, m))
+    ada2.set_bias(bias, tiny_cov)
+    out_ada_tiny = np.array([ada2.loglike(x) for x in X])
+    # mixed case: one entry above threshold -> refreshed
+    mixed_cov = tiny_cov.copy()
+    mixed_cov[0, 0] = 1e-3
+    ada2.set_bias(bias, mixed_cov)
+    out_ada_mixed = np.array([ada2.loglike(x) for x in X])
+    save("g3_loglike_kats", data=data, X=X, iso_var=np.array(0.3), diag_cov=dg, dense_cov=dense_cov,
+         class_names=names,
+         out_iso=np.array([iso.loglike(x) for x in X]),
+         out_diag=np.array([diag.loglike(x) for x in X]),
+         out_dense=np.array([dense.loglike(x) for x in X]),
+         grad_iso=np.array([iso.grad_loglike(x) for x in X]),
+         grad_diag=np.array([diag.grad_loglike(x) for x in X]),
+         grad_dense=np.array([dense.grad_loglike(x) for x in X]),
+         bias=bias, bias_cov=bias_cov, custom_bias=custom, tiny_cov=tiny_cov, mixed_cov=mixed_cov,
+         out_ada0=out_ada0, out_ada1=out_ada1, out_ada_custom=out_ada_custom,
+         out_ada_tiny=out_ada_tiny, out_ada_mixed=out_ada_mixed)
+
+
+def g7_moments():
+    rng = np.random.default_rng(71)
+    d, n = 5, 40
+    X = rng.standard_normal((n, d)) * np.array([1.0, 0.5, 2.0, 0.1, 1.5]) + 0.3
+    r = tda.RecursiveSampleMoments(X[0].copy(), np.zeros((d, d)), sd=0.7, epsilon=1e-6)
+    mus, sigs = [], []
+    for x in X[1:]:
+        r.update(x)
+        mus.append(r.get_mu().copy())
+        sigs.append(r.get_sigma().copy())
+    r0 = tda.RecursiveSampleMoments(X[0].copy(), np.zeros((d, d)))
+    for x in X[1:]:
+        r0.update(x)
+    z = tda.chain.ZeroMeanRecursiveSampleMoments(np.zeros((d, d)))
+    zs = []
+    for x in X:
+        z.update(x)
+        zs.append(z.get_sigma().copy())
+    save("g7_moments", X=X, sd=np.array(0.7), epsilon=np.array(1e-6), mu_hist=np.array(mus),
+         sigma_hist=np.array(sigs), plain_mu=r0.get_mu(), plain_sigma=r0.get_sigma(),
+         np_cov=np.cov(X.T), zero_mean_hist=np.array(zs))
+
+
+def g9_mvn_logpdf():
+    rng = np.random.default_rng(91)
+    d = 7
+    B = rng.standard_normal((d, d))
+    cov = B @ B.T / d + 0.2 * np.eye(d)
+    mean = rng.standard_normal(d)
+    X = rng.standard_normal((9, d))
+    frozen = stats.multivariate_normal(mean, cov)
+    ident = stats.multivariate_normal(np.zeros(d), np.eye(d))
+    save("g9_mvn_logpdf", mean=mean, cov=cov, X=X, logpdf=frozen.logpdf(X),
+         logpdf_identity=ident.logpdf(X))
+
+
+FIXTURES = {
+    "g1_basic_sampler": g1_basic_sampler,
+    "g2_am_small": lambda: g2_am("g2_am_small", d=8, m=16, n_chains=8, iters=128, t0=16, period=16, seed=201),
+    "g2_am_small_adaptive": lambda: g2_am("g2_am_small_adaptive", d=8, m=16, n_chains=4, iters=128,
+                                          t0=0, period=16, seed=202, adaptive=True),
+    "g2_am_diag_genprior": lambda: g2_am("g2_am_diag_genprior", d=6, m=20, n_chains=4, iters=96, t0=16,
+                                         period=16, seed=203, noise="diag", prior_kind="general"),
+    "g2_am_dense": lambda: g2_am("g2_am_dense", d=6, m=20, n_chains=4, iters=96, t0=16, period=16,
+                                 seed=204, noise="dense", prior_kind="general"),
+    "g2_am_c2": lambda: g2_am("g2_am_c2", d=64, m=1024, n_chains=2, iters=300, t0=100, period=100,
+                              seed=1, c0=1e-4),
+    "g2b_pcn": g2b_pcn,
+    "g3_loglike_kats": g3_loglike_kats,
+    "g7_moments": g7_moments,
+    "g9_mvn_logpdf": g9_mvn_logpdf,
+}
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(FIXTURES)
+    for n in names:
+        FIXTURES[n]()
