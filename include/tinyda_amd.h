@@ -1,0 +1,172 @@
+/*
+ * tinyda_amd.h  --  C-ABI of the MI355X many-chain MH / DA / MLDA engine (libtinyda_hip.so).
+ *
+ * The reference (mikkelbue/tinyDA) has NO native boundary: its hot path is the Python loop
+ *   tda.sample()            tinyDA/sampler.py:21-292
+ *     Chain.sample          tinyDA/chain.py:78-129       (one Python iteration per MH step per chain)
+ *       Proposal.*          tinyDA/proposal.py:171-512   (GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis)
+ *       Posterior.create_link  tinyDA/posterior.py:78-110
+ *       GaussianLogLike     tinyDA/distributions.py:203-329
+ *       RecursiveSampleMoments tinyDA/utils.py:104-124
+ * This header is the boundary a maintainer would bind with ctypes from sampler.py (see
+ * INTEGRATION.md): plain pointers and sizes, no torch / numpy types.  The Python mirror of the
+ * reference API (tinyda_amd/) is a thin layer over exactly these entry points.
+ *
+ * Conventions
+ *   - every function returns TDA_OK (0) or a negative tda_status; tda_last_error() gives the message
+ *     (thread local);
+ *   - the caller owns every buffer it passes; the engine owns its internal device state;
+ *   - data pointers may be HOST or DEVICE memory (detected with hipPointerGetAttributes) unless a
+ *     parameter says "host";  all matrices are row-major fp64;
+ *   - one engine per GPU; calls on one engine are not thread-safe; different engines may be driven
+ *     from different threads / processes (one process per GPU under torch.distributed);
+ *   - chains are rows of device matrices: chain c of this engine has global id chain_offset + c, and
+ *     the global id (not the GPU count) keys its random stream, so results do not depend on sharding.
+ *
+ * RNG stream (part of the contract; restated independently in oracle/tinyda_oracle.py)
+ *   Philox4x32-10, key = (seed & 0xffffffff, seed >> 32), counter = (block, step, global chain, stream).
+ *   u53(a, b) = ((a >> 5) * 2^26 + (b >> 6)) * 2^-53.
+ *   stream 0, block b of step t : x0..x3 -> u1 = u53(x0,x1), u2 = u53(x2,x3),
+ *        r = sqrt(-2 ln(1 - u1));  z[2b] = r cos(2 pi u2), z[2b+1] = r sin(2 pi u2)   (proposal normals)
+ *   stream 1, block = level    : u = u53(x0,x1)                                       (accept uniform)
+ *   stream 2, block b          : as stream 0, step = 0                                (theta0 ~ prior)
+ *   "step" is the count of base-level proposals made so far on the chain (proposal.t in
+ *   tinyDA/proposal.py:223,229).
+ */
+#ifndef TINYDA_AMD_H
+#define TINYDA_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tda_engine tda_engine;
+
+typedef enum tda_status {
+  TDA_OK = 0,
+  TDA_ERR_INVALID = -1,     /* bad argument / shape */
+  TDA_ERR_HIP = -2,         /* a HIP runtime call failed */
+  TDA_ERR_STATE = -3,       /* call order (e.g. run before init) */
+  TDA_ERR_UNSUPPORTED = -4, /* configuration outside what the device engine lowers */
+  TDA_ERR_NUMERIC = -5      /* e.g. covariance not positive definite */
+} tda_status;
+
+/* GaussianLogLike factory outcome, tinyDA/distributions.py:237-243 */
+typedef enum tda_noise_kind { TDA_NOISE_ISO = 0, TDA_NOISE_DIAG = 1, TDA_NOISE_DENSE = 2 } tda_noise_kind;
+
+/* tinyDA/proposal.py: GaussianRandomWalk :132, CrankNicolson :261, AdaptiveMetropolis :372 */
+typedef enum tda_proposal_kind { TDA_PROP_GRW = 0, TDA_PROP_PCN = 1, TDA_PROP_AM = 2 } tda_proposal_kind;
+
+typedef struct tda_config {
+  uint32_t struct_size;  /* sizeof(tda_config) */
+  int32_t device;        /* HIP device ordinal */
+  int64_t n_chains;      /* chains held by this engine (rows of the state matrix) */
+  int64_t chain_offset;  /* global id of local chain 0 */
+  int32_t dim;           /* parameter dimension d (1..64) */
+  int32_t n_levels;      /* 1 = single-level MH (sampler.py:213); >1 reserved for DA / MLDA */
+  uint64_t seed;
+  void* stream;          /* hipStream_t to run on, or NULL for an engine-owned stream */
+  int32_t block_steps;   /* max MH steps fused per launch group (0 = default 128) */
+  int32_t reserved;
+} tda_config;
+
+/* Proposal constructor arguments, same meaning and defaults as the reference constructors
+ * (proposal.py:171, :302, :416). */
+typedef struct tda_proposal_params {
+  uint32_t struct_size;
+  int32_t kind;      /* tda_proposal_kind */
+  double scaling;    /* GRW: scaling (default 1); pCN: beta (default 0.1); AM: ignored (1, proposal.py:462) */
+  int32_t adaptive;  /* global scaling adaptation towards 0.24 acceptance (proposal.py:228-245) */
+  int32_t period;    /* adaptation period (default 100) */
+  double gamma;      /* adaptivity coefficient (default 1.01) */
+  const double* C;   /* HOST d x d: GRW covariance / AM initial covariance C0; NULL for pCN (prior cov) */
+  double sd;         /* AM scaling; <= 0 means min(1, 2.4^2/d) (proposal.py:465-468) */
+  double epsilon;    /* AM regulariser (default 1e-6) */
+  int32_t t0;        /* AM: first adapt() count at which C may be swapped (default 0) */
+  int32_t reserved;
+} tda_proposal_params;
+
+/* Per-step records of one run() call; any pointer may be NULL (that record is then not produced).
+ * Record r (0-based within this call) of chain c:
+ *   params  [(r * n_chains + c) * dim + j]       chain state after the accept/reject decision
+ *   stats   [(r * n_chains + c) * 3 + {0,1,2}]   log-prior, log-likelihood, log-posterior (link.py:41-48)
+ *   accepted[ r * n_chains + c]                  1 if the proposal of that step was accepted */
+typedef struct tda_outputs {
+  uint32_t struct_size;
+  uint32_t reserved;
+  double* params;
+  double* stats;
+  uint8_t* accepted;
+} tda_outputs;
+
+/* Wall-clock-free device timing of the last run() (HIP events on the engine's stream). */
+typedef struct tda_profile {
+  uint32_t struct_size;
+  uint32_t n_launch_propose, n_launch_steps, n_launch_adapt;
+  double ms_propose, ms_steps, ms_adapt; /* summed kernel durations */
+  double ms_total;                        /* first launch -> last completion */
+} tda_profile;
+
+const char* tda_last_error(void);
+const char* tda_version(void);
+
+int tda_engine_create(const tda_config* cfg, tda_engine** out);
+void tda_engine_destroy(tda_engine* e);
+
+/* Prior = scipy.stats.multivariate_normal(mean, cov) (posterior.py:92; normalised logpdf). HOST pointers. */
+int tda_engine_set_prior(tda_engine* e, const double* mean, const double* cov);
+
+/* Level `level` posterior: forward model F(theta) = A theta + b (A is m x d, b may be NULL), data y,
+ * Gaussian noise of the given kind: ISO noise[0] = variance; DIAG noise[m] = diagonal;
+ * DENSE noise[m*m] = covariance (distributions.py:246-329). HOST pointers. */
+int tda_engine_set_level(tda_engine* e, int level, int m, const double* A, const double* b,
+                         const double* data, int noise_kind, const double* noise);
+
+int tda_engine_set_proposal(tda_engine* e, const tda_proposal_params* p);
+
+/* Start the chains: theta0 is n_chains x dim, or NULL to draw theta0 ~ prior from RNG stream 2
+ * (sampler.py:209).  Evaluates the initial links (chain.py:70) and sets up the proposal
+ * (chain.py:74-76, proposal.py:492-500). */
+int tda_engine_init(tda_engine* e, const double* theta0);
+
+/* Current state of every chain: theta [n_chains*dim], stats [n_chains*3]; either may be NULL. */
+int tda_engine_get_current(tda_engine* e, double* theta, double* stats);
+
+/* Parity mode: consume caller-supplied variates instead of Philox.  z is [n_steps][n_chains][dim]
+ * standard normals (mapped through chol(C) like tests/golden/gen_golden.py), u is [n_steps][n_chains]
+ * uniforms; step index counts from the engine's current step.  NULL/0 switches replay off. */
+int tda_engine_set_replay(tda_engine* e, const double* z, const double* u, int64_t n_steps);
+
+/* Export mode: the engine writes the variates it generated into z / u (same layout as replay),
+ * so the CPU oracle can be driven with the identical stream.  NULL/0 switches export off. */
+int tda_engine_set_export(tda_engine* e, double* z, double* u, int64_t n_steps);
+
+/* Advance every chain by n_iterations MH steps (Chain.sample, chain.py:95-125).  Asynchronous on the
+ * engine's stream when all outputs are device pointers; tda_engine_sync() waits. */
+int tda_engine_run(tda_engine* e, int64_t n_iterations, const tda_outputs* out);
+int tda_engine_sync(tda_engine* e);
+
+/* Proposal state, HOST pointers, any may be NULL: scaling[n_chains], C[n_chains*d*d] (covariance in use),
+ * am_mu[n_chains*d], am_sigma[n_chains*d*d] (RecursiveSampleMoments), counters[2] = {t, k}. */
+int tda_engine_get_proposal_state(tda_engine* e, double* scaling, double* C, double* am_mu,
+                                  double* am_sigma, int64_t* counters);
+
+/* Per-chain error flags (bit 0: Cholesky of an adapted covariance failed, previous factor kept). HOST. */
+int tda_engine_get_flags(tda_engine* e, int32_t* flags);
+
+/* Evaluate log-prior / log-likelihood of arbitrary states with the level-evaluation kernel only
+ * (Posterior.create_link without the chain): theta [n][dim] -> stats [n][3].  n <= n_chains. */
+int tda_engine_evaluate(tda_engine* e, int level, const double* theta, int64_t n, double* stats);
+
+/* Device RNG probe: fills z [n_chains][dim] and u [n_chains] for the given step from streams 0 / 1. HOST. */
+int tda_engine_rng_probe(tda_engine* e, int64_t step, double* z, double* u);
+
+int tda_engine_set_profiling(tda_engine* e, int enable);
+int tda_engine_get_profile(tda_engine* e, tda_profile* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TINYDA_AMD_H */

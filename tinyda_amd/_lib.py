@@ -1,0 +1,149 @@
+"""ctypes binding of libtinyda_hip.so (C-ABI: include/tinyda_amd.h).
+
+There is no CPU compute fallback behind this module: if the shared library is missing or cannot be
+loaded, `load()` raises and every device code path of the package raises with it.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtinyda_hip.so")
+
+TDA_OK = 0
+NOISE_ISO, NOISE_DIAG, NOISE_DENSE = 0, 1, 2
+PROP_GRW, PROP_PCN, PROP_AM = 0, 1, 2
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class tda_config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("device", C.c_int32),
+        ("n_chains", C.c_int64),
+        ("chain_offset", C.c_int64),
+        ("dim", C.c_int32),
+        ("n_levels", C.c_int32),
+        ("seed", C.c_uint64),
+        ("stream", C.c_void_p),
+        ("block_steps", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class tda_proposal_params(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("kind", C.c_int32),
+        ("scaling", C.c_double),
+        ("adaptive", C.c_int32),
+        ("period", C.c_int32),
+        ("gamma", C.c_double),
+        ("C", C.c_void_p),
+        ("sd", C.c_double),
+        ("epsilon", C.c_double),
+        ("t0", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class tda_outputs(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("params", C.c_void_p),
+        ("stats", C.c_void_p),
+        ("accepted", C.c_void_p),
+    ]
+
+
+class tda_profile(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("n_launch_propose", C.c_uint32),
+        ("n_launch_steps", C.c_uint32),
+        ("n_launch_adapt", C.c_uint32),
+        ("ms_propose", C.c_double),
+        ("ms_steps", C.c_double),
+        ("ms_adapt", C.c_double),
+        ("ms_total", C.c_double),
+    ]
+
+
+# every symbol include/tinyda_amd.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "tda_last_error": (C.c_char_p, []),
+    "tda_version": (C.c_char_p, []),
+    "tda_engine_create": (C.c_int, [C.POINTER(tda_config), C.POINTER(_P)]),
+    "tda_engine_destroy": (None, [_P]),
+    "tda_engine_set_prior": (C.c_int, [_P, _P, _P]),
+    "tda_engine_set_level": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P]),
+    "tda_engine_set_proposal": (C.c_int, [_P, C.POINTER(tda_proposal_params)]),
+    "tda_engine_init": (C.c_int, [_P, _P]),
+    "tda_engine_get_current": (C.c_int, [_P, _P, _P]),
+    "tda_engine_set_replay": (C.c_int, [_P, _P, _P, C.c_int64]),
+    "tda_engine_set_export": (C.c_int, [_P, _P, _P, C.c_int64]),
+    "tda_engine_run": (C.c_int, [_P, C.c_int64, C.POINTER(tda_outputs)]),
+    "tda_engine_sync": (C.c_int, [_P]),
+    "tda_engine_get_proposal_state": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "tda_engine_get_flags": (C.c_int, [_P, _P]),
+    "tda_engine_evaluate": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P]),
+    "tda_engine_rng_probe": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "tda_engine_set_profiling": (C.c_int, [_P, C.c_int]),
+    "tda_engine_get_profile": (C.c_int, [_P, C.POINTER(tda_profile)]),
+}
+
+_lib = None
+
+
+def _bind_single_hip_runtime():
+    """One HIP runtime per process.  The PyTorch-ROCm wheel bundles its own libamdhip64 (SONAME
+    libamdhip64.so.7, the same as /opt/rocm's).  If this library pulled in /opt/rocm's copy first and torch
+    loaded its own afterwards, the second runtime would find no GPU.  So when torch is installed, its copy is
+    mapped first and libtinyda_hip.so binds to it by SONAME; torch later re-uses the same mapping."""
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:  # fall back to the system runtime named in the library's RUNPATH
+        pass
+
+
+def load():
+    """Load the HIP engine library; raises EngineError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(
+            "libtinyda_hip.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(the MH engine has no CPU fallback)" % LIB_PATH
+        )
+    _bind_single_hip_runtime()
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as exc:  # missing ROCm runtime etc.
+        raise EngineError("cannot load %s: %s" % (LIB_PATH, exc)) from exc
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != TDA_OK:
+        raise EngineError("tinyda_amd engine error %d: %s" % (rc, load().tda_last_error().decode()))

@@ -1,0 +1,922 @@
+// libtinyda_hip.so : C-ABI (include/tinyda_amd.h) over the gfx950 kernels in tda_kernels.h.
+// Host side = problem lowering (fragment packing, Cholesky of shared covariances), block scheduling and
+// record plumbing.  No CPU compute fallback exists: every entry point that advances chains launches HIP
+// kernels or fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "tda_kernels.h"
+#include "tinyda_amd.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) return fail(TDA_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+bool is_device_ptr(const void* p) {
+  if (!p) return false;
+  hipPointerAttribute_t at;
+  hipError_t e = hipPointerGetAttributes(&at, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
+
+int dpad_for(int d) { return d <= 8 ? 8 : d <= 16 ? 16 : d <= 32 ? 32 : 64; }
+
+// lower Cholesky of a d x d row-major SPD matrix; returns false if not positive definite
+bool cholesky_host(const double* C, int d, std::vector<double>& L) {
+  L.assign((size_t)d * d, 0.0);
+  for (int k = 0; k < d; ++k) {
+    for (int i = k; i < d; ++i) {
+      double s = C[(size_t)i * d + k];
+      for (int p = 0; p < k; ++p) s = std::fma(-L[(size_t)i * d + p], L[(size_t)k * d + p], s);
+      if (i == k) {
+        if (!(s > 0.0)) return false;
+        L[(size_t)k * d + k] = std::sqrt(s);
+      } else {
+        L[(size_t)i * d + k] = s / L[(size_t)k * d + k];
+      }
+    }
+  }
+  return true;
+}
+
+// inverse of a lower-triangular matrix
+void tri_inverse_host(const std::vector<double>& L, int d, std::vector<double>& W) {
+  W.assign((size_t)d * d, 0.0);
+  for (int j = 0; j < d; ++j) {
+    W[(size_t)j * d + j] = 1.0 / L[(size_t)j * d + j];
+    for (int i = j + 1; i < d; ++i) {
+      double s = 0.0;
+      for (int p = j; p < i; ++p) s += L[(size_t)i * d + p] * W[(size_t)p * d + j];
+      W[(size_t)i * d + j] = -s / L[(size_t)i * d + i];
+    }
+  }
+}
+
+// pack an (rows x cols) row-major matrix into MFMA A-operand fragments, see LevelDev::Apk
+void pack_fragments(const double* A, int rows, int cols, int dpad, std::vector<double>& out, int& ncb) {
+  ncb = (rows + 15) / 16;
+  const int K2 = dpad / 8;
+  out.assign((size_t)ncb * K2 * 64 * 2, 0.0);
+  for (int cb = 0; cb < ncb; ++cb)
+    for (int k2 = 0; k2 < K2; ++k2)
+      for (int l = 0; l < 64; ++l)
+        for (int e = 0; e < 2; ++e) {
+          const int r = cb * 16 + (l & 15), cidx = 4 * (2 * k2 + e) + (l >> 4);
+          if (r < rows && cidx < cols)
+            out[(((size_t)cb * K2 + k2) * 64 + l) * 2 + e] = A[(size_t)r * cols + cidx];
+        }
+}
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) return TDA_OK;
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e != hipSuccess) return fail(TDA_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    return TDA_OK;
+  }
+  int upload(const std::vector<T>& h) {
+    int rc = alloc(h.size());
+    if (rc) return rc;
+    if (!h.empty()) HIP_TRY(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return TDA_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  ~DevBuf() { release(); }
+};
+
+struct Level {
+  bool set = false;
+  int m = 0, m_pad = 0, ncb = 0, noise_kind = 0;
+  double var = 1.0;
+  DevBuf<double> Apk, ytil, w;
+};
+
+struct TimedLaunch {
+  hipEvent_t a, b;
+  int kind;
+};
+
+}  // namespace
+
+struct tda_engine {
+  tda_config cfg{};
+  int d = 0, DP = 0;
+  int64_t N = 0, NP = 0;
+  int SMAX = 128;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+
+  // prior
+  bool prior_set = false;
+  int prior_kind = tda::PRIOR_DIAG;
+  double prior_logconst = 0.0;
+  std::vector<double> prior_mean_h, prior_cov_h, prior_L_h;
+  DevBuf<double> prior_mean, prior_pinv, prior_Wpk, prior_wmu;
+  int prior_ncb = 0;
+
+  std::vector<Level> levels;
+
+  // proposal
+  bool prop_set = false;
+  tda_proposal_params pp{};
+  std::vector<double> prop_C_h;
+  double am_sd = 1.0;
+  bool L_shared = true;
+  DevBuf<double> Lk, am_mu, am_sigma, scaling;
+  DevBuf<int32_t> acc_count, flags;
+
+  // chain state
+  bool inited = false;
+  DevBuf<double> theta, lp, ll;
+  DevBuf<double> theta_s, lp_s, ll_s;  // scratch state for tda_engine_evaluate
+  int64_t t = 0;                        // proposal.t : adapt() calls so far
+  int64_t k_adapt = 0;                  // diminishing-adaptation counter
+
+  // block buffers
+  DevBuf<double> inc, ublk, rec_params, rec_stats;
+  DevBuf<uint8_t> rec_acc;
+
+  // replay / export
+  DevBuf<double> z_rep, u_rep;
+  int64_t rep_steps = 0, rep_pos = 0;
+  double *z_exp = nullptr, *u_exp = nullptr;  // caller pointers
+  bool exp_dev = false;
+  DevBuf<double> z_exp_d, u_exp_d;
+  int64_t exp_steps = 0, exp_pos = 0;
+
+  // profiling
+  bool profiling = false;
+  std::vector<TimedLaunch> timed;
+};
+
+namespace {
+
+using namespace tda;
+
+template <int DPAD>
+void launch_steps(const StepArgs& a, int64_t tiles, size_t lds, hipStream_t st) {
+  hipLaunchKernelGGL(k_mh_steps<DPAD>, dim3((unsigned)tiles), dim3(256), lds, st, a);
+}
+template <int DPAD>
+void launch_propose(const ProposeArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_propose<DPAD>, dim3((unsigned)a.NP), dim3(64), 0, st, a);
+}
+template <int DPAD>
+void launch_adapt(const AdaptArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_adapt<DPAD>, dim3((unsigned)a.N), dim3(64), 0, st, a);
+}
+
+#define DISPATCH_DPAD(dp, CALL)                  \
+  switch (dp) {                                  \
+    case 8: { constexpr int DPAD = 8; CALL; } break;   \
+    case 16: { constexpr int DPAD = 16; CALL; } break; \
+    case 32: { constexpr int DPAD = 32; CALL; } break; \
+    default: { constexpr int DPAD = 64; CALL; } break; \
+  }
+
+struct ScopedTimer {
+  tda_engine* e;
+  TimedLaunch tl{};
+  bool on;
+  ScopedTimer(tda_engine* e_, int kind) : e(e_), on(e_->profiling) {
+    if (on) {
+      (void)hipEventCreate(&tl.a);
+      (void)hipEventCreate(&tl.b);
+      tl.kind = kind;
+      (void)hipEventRecord(tl.a, e->stream);
+    }
+  }
+  ~ScopedTimer() {
+    if (on) {
+      (void)hipEventRecord(tl.b, e->stream);
+      e->timed.push_back(tl);
+    }
+  }
+};
+
+size_t steps_lds_bytes(const tda_engine* e, const Level& lv) {
+  const bool diag = lv.noise_kind == TDA_NOISE_DIAG;
+  const int prow = e->prior_kind == PRIOR_DENSE ? e->prior_ncb * 16 : 0;
+  size_t nd = (size_t)16 * (e->DP + 2) + 128 + lv.m_pad + (diag ? lv.m_pad : 0) + prow;
+  return nd * sizeof(double);
+}
+
+void fill_level(const tda_engine* e, const Level& lv, StepArgs& a) {
+  a.lv.Apk = lv.Apk.p;
+  a.lv.ytil = lv.ytil.p;
+  a.lv.w = lv.w.p;
+  a.lv.ncb = lv.ncb;
+  a.lv.m_pad = lv.m_pad;
+  a.lv.noise_kind = lv.noise_kind;
+  a.lv.var = lv.var;
+  a.pr.mean = e->prior_mean.p;
+  a.pr.pinv = e->prior_pinv.p;
+  a.pr.Wpk = e->prior_Wpk.p;
+  a.pr.wmu = e->prior_wmu.p;
+  a.pr.ncb = e->prior_ncb;
+  a.pr.kind = e->prior_kind;
+  a.pr.logconst = e->prior_logconst;
+  a.N = e->N;
+  a.NP = e->NP;
+  a.d = e->d;
+}
+
+int launch_eval(tda_engine* e, int level, double* theta, double* lp, double* ll) {
+  StepArgs a{};
+  fill_level(e, e->levels[level], a);
+  a.S = 1;
+  a.mode = MODE_EVAL;
+  a.prop_kind = TDA_PROP_GRW;
+  a.theta = theta;
+  a.lp = lp;
+  a.ll = ll;
+  a.scaling = e->scaling.p;
+  const size_t lds = steps_lds_bytes(e, e->levels[level]);
+  DISPATCH_DPAD(e->DP, launch_steps<DPAD>(a, e->NP / 16, lds, e->stream));
+  HIP_TRY(hipGetLastError());
+  return TDA_OK;
+}
+
+// copy [n][d] caller layout -> [NP][DP] padded device layout
+int upload_states(tda_engine* e, const double* src, int64_t n, double* dst) {
+  std::vector<double> h((size_t)e->NP * e->DP, 0.0);
+  std::vector<double> tmp;
+  const double* hs = src;
+  if (is_device_ptr(src)) {
+    tmp.resize((size_t)n * e->d);
+    HIP_TRY(hipMemcpy(tmp.data(), src, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    hs = tmp.data();
+  }
+  for (int64_t c = 0; c < n; ++c)
+    for (int j = 0; j < e->d; ++j) h[(size_t)c * e->DP + j] = hs[(size_t)c * e->d + j];
+  HIP_TRY(hipMemcpyAsync(dst, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return TDA_OK;
+}
+
+int copy_out(tda_engine* e, void* dst, const void* src_dev, size_t bytes) {
+  if (!dst || bytes == 0) return TDA_OK;
+  HIP_TRY(hipMemcpyAsync(dst, src_dev, bytes, is_device_ptr(dst) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                         e->stream));
+  return TDA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* tda_last_error(void) { return g_err.c_str(); }
+const char* tda_version(void) { return "tinyda_amd 0.1 (gfx950)"; }
+
+int tda_engine_create(const tda_config* cfg, tda_engine** out) {
+  if (!cfg || !out) return fail(TDA_ERR_INVALID, "null argument");
+  if (cfg->struct_size != sizeof(tda_config)) return fail(TDA_ERR_INVALID, "tda_config.struct_size mismatch");
+  if (cfg->dim < 1 || cfg->dim > 64)
+    return fail(TDA_ERR_UNSUPPORTED, "dim=%d outside the device engine's range 1..64", cfg->dim);
+  if (cfg->n_chains < 1) return fail(TDA_ERR_INVALID, "n_chains must be >= 1");
+  if (cfg->n_levels != 1) return fail(TDA_ERR_UNSUPPORTED, "n_levels=%d: only single-level MH is lowered so far", cfg->n_levels);
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (ndev < 1) return fail(TDA_ERR_HIP, "no HIP device visible: the MH engine has no CPU fallback");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(TDA_ERR_INVALID, "device %d of %d", cfg->device, ndev);
+  HIP_TRY(hipSetDevice(cfg->device));
+  tda_engine* e = new tda_engine();
+  e->cfg = *cfg;
+  e->d = cfg->dim;
+  e->DP = dpad_for(cfg->dim);
+  e->N = cfg->n_chains;
+  e->NP = (cfg->n_chains + 15) / 16 * 16;
+  e->SMAX = cfg->block_steps > 0 ? cfg->block_steps : 128;
+  e->levels.resize(cfg->n_levels);
+  if (cfg->stream) {
+    e->stream = (hipStream_t)cfg->stream;
+  } else {
+    hipError_t er = hipStreamCreate(&e->stream);
+    if (er != hipSuccess) {
+      delete e;
+      return fail(TDA_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(er));
+    }
+    e->own_stream = true;
+  }
+  *out = e;
+  return TDA_OK;
+}
+
+void tda_engine_destroy(tda_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->cfg.device);
+  (void)hipStreamSynchronize(e->stream);
+  for (auto& t : e->timed) {
+    (void)hipEventDestroy(t.a);
+    (void)hipEventDestroy(t.b);
+  }
+  if (e->own_stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int tda_engine_set_prior(tda_engine* e, const double* mean, const double* cov) {
+  if (!e || !mean || !cov) return fail(TDA_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const int d = e->d, DP = e->DP;
+  e->prior_mean_h.assign(mean, mean + d);
+  e->prior_cov_h.assign(cov, cov + (size_t)d * d);
+  if (!cholesky_host(cov, d, e->prior_L_h))
+    return fail(TDA_ERR_NUMERIC, "prior covariance is not positive definite");
+  double logdet = 0.0;
+  for (int j = 0; j < d; ++j) logdet += 2.0 * std::log(e->prior_L_h[(size_t)j * d + j]);
+  bool diag = true;
+  for (int i = 0; i < d && diag; ++i)
+    for (int j = 0; j < d; ++j)
+      if (i != j && cov[(size_t)i * d + j] != 0.0) {
+        diag = false;
+        break;
+      }
+  std::vector<double> mh(DP, 0.0), ph(DP, 0.0);
+  for (int j = 0; j < d; ++j) mh[j] = mean[j];
+  int rc;
+  if ((rc = e->prior_mean.upload(mh))) return rc;
+  if (diag) {
+    e->prior_kind = PRIOR_DIAG;
+    logdet = 0.0;
+    for (int j = 0; j < d; ++j) {
+      ph[j] = 1.0 / cov[(size_t)j * d + j];
+      logdet += std::log(cov[(size_t)j * d + j]);
+    }
+    e->prior_ncb = 0;
+  } else {
+    e->prior_kind = PRIOR_DENSE;
+    std::vector<double> W, Wpk;
+    tri_inverse_host(e->prior_L_h, d, W);
+    pack_fragments(W.data(), d, d, DP, Wpk, e->prior_ncb);
+    std::vector<double> wmu((size_t)e->prior_ncb * 16, 0.0);
+    for (int i = 0; i < d; ++i) {
+      double s = 0.0;
+      for (int j = 0; j < d; ++j) s += W[(size_t)i * d + j] * mean[j];
+      wmu[i] = s;
+    }
+    if ((rc = e->prior_Wpk.upload(Wpk))) return rc;
+    if ((rc = e->prior_wmu.upload(wmu))) return rc;
+  }
+  if ((rc = e->prior_pinv.upload(ph))) return rc;
+  e->prior_logconst = d * std::log(2.0 * M_PI) + logdet;
+  e->prior_set = true;
+  return TDA_OK;
+}
+
+int tda_engine_set_level(tda_engine* e, int level, int m, const double* A, const double* b, const double* data,
+                         int noise_kind, const double* noise) {
+  if (!e || !A || !data || !noise) return fail(TDA_ERR_INVALID, "null argument");
+  if (level < 0 || level >= (int)e->levels.size()) return fail(TDA_ERR_INVALID, "level %d out of range", level);
+  if (m < 1) return fail(TDA_ERR_INVALID, "m must be >= 1");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  Level& lv = e->levels[level];
+  if (noise_kind == TDA_NOISE_DENSE)
+    return fail(TDA_ERR_UNSUPPORTED, "dense noise covariance (DefaultGaussianLogLike) is not lowered to the device yet");
+  if (noise_kind != TDA_NOISE_ISO && noise_kind != TDA_NOISE_DIAG) return fail(TDA_ERR_INVALID, "noise_kind %d", noise_kind);
+  std::vector<double> Apk;
+  pack_fragments(A, m, e->d, e->DP, Apk, lv.ncb);
+  lv.m = m;
+  lv.m_pad = lv.ncb * 16;
+  lv.noise_kind = noise_kind;
+  std::vector<double> yt(lv.m_pad, 0.0), w;
+  for (int i = 0; i < m; ++i) yt[i] = data[i] - (b ? b[i] : 0.0);
+  if (noise_kind == TDA_NOISE_ISO) {
+    if (!(noise[0] > 0.0)) return fail(TDA_ERR_NUMERIC, "noise variance must be positive");
+    lv.var = noise[0];
+  } else {
+    w.assign(lv.m_pad, 0.0);
+    for (int i = 0; i < m; ++i) {
+      if (!(noise[i] > 0.0)) return fail(TDA_ERR_NUMERIC, "noise variance must be positive");
+      w[i] = 1.0 / noise[i];
+    }
+    lv.var = 1.0;
+  }
+  const size_t lds = ((size_t)16 * (e->DP + 2) + 128 + (size_t)lv.m_pad * 2 + 64) * sizeof(double);
+  if (lds > 150 * 1024) return fail(TDA_ERR_UNSUPPORTED, "m=%d observations exceed the LDS staging budget", m);
+  int rc;
+  if ((rc = lv.Apk.upload(Apk))) return rc;
+  if ((rc = lv.ytil.upload(yt))) return rc;
+  if ((rc = lv.w.upload(w))) return rc;
+  lv.set = true;
+  return TDA_OK;
+}
+
+int tda_engine_set_proposal(tda_engine* e, const tda_proposal_params* p) {
+  if (!e || !p) return fail(TDA_ERR_INVALID, "null argument");
+  if (p->struct_size != sizeof(tda_proposal_params)) return fail(TDA_ERR_INVALID, "tda_proposal_params.struct_size mismatch");
+  if (p->kind < TDA_PROP_GRW || p->kind > TDA_PROP_AM) return fail(TDA_ERR_UNSUPPORTED, "proposal kind %d", p->kind);
+  if ((p->kind == TDA_PROP_GRW || p->kind == TDA_PROP_AM) && !p->C) return fail(TDA_ERR_INVALID, "proposal covariance missing");
+  if (p->period < 1) return fail(TDA_ERR_INVALID, "period must be >= 1");
+  e->pp = *p;
+  if (p->C) e->prop_C_h.assign(p->C, p->C + (size_t)e->d * e->d);
+  e->pp.C = nullptr;
+  e->am_sd = p->sd > 0.0 ? p->sd : std::min(1.0, 2.4 * 2.4 / e->d);
+  e->prop_set = true;
+  e->inited = false;
+  return TDA_OK;
+}
+
+int tda_engine_init(tda_engine* e, const double* theta0) {
+  if (!e) return fail(TDA_ERR_INVALID, "null engine");
+  if (!e->prior_set || !e->prop_set) return fail(TDA_ERR_STATE, "set_prior and set_proposal must precede init");
+  for (auto& lv : e->levels)
+    if (!lv.set) return fail(TDA_ERR_STATE, "set_level missing");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const int d = e->d, DP = e->DP;
+  const int64_t N = e->N, NP = e->NP;
+  int rc;
+  if ((rc = e->theta.alloc((size_t)NP * DP))) return rc;
+  if ((rc = e->lp.alloc(NP))) return rc;
+  if ((rc = e->ll.alloc(NP))) return rc;
+  if ((rc = e->acc_count.alloc(NP))) return rc;
+  if ((rc = e->flags.alloc(NP))) return rc;
+  HIP_TRY(hipMemsetAsync(e->acc_count.p, 0, NP * sizeof(int32_t), e->stream));
+  HIP_TRY(hipMemsetAsync(e->flags.p, 0, NP * sizeof(int32_t), e->stream));
+  HIP_TRY(hipMemsetAsync(e->lp.p, 0, NP * sizeof(double), e->stream));
+  HIP_TRY(hipMemsetAsync(e->ll.p, 0, NP * sizeof(double), e->stream));
+
+  // initial parameters
+  std::vector<double> th0;
+  if (!theta0) {  // theta0 ~ prior (sampler.py:209) from RNG stream 2
+    th0.resize((size_t)N * d);
+    std::vector<double> z(d + 1);
+    for (int64_t c = 0; c < N; ++c) {
+      for (int b = 0; b < (d + 1) / 2; ++b)
+        normal_pair(e->cfg.seed, (uint32_t)(e->cfg.chain_offset + c), 0u, STREAM_INIT, (uint32_t)b, z[2 * b], z[2 * b + 1]);
+      for (int i = 0; i < d; ++i) {
+        double s = 0.0;
+        for (int k = 0; k <= i; ++k) s = std::fma(e->prior_L_h[(size_t)i * d + k], z[k], s);
+        th0[(size_t)c * d + i] = e->prior_mean_h[i] + s;
+      }
+    }
+    theta0 = th0.data();
+  }
+  if ((rc = upload_states(e, theta0, N, e->theta.p))) return rc;
+
+  // proposal state (chain.py:74-76)
+  std::vector<double> sc(NP, e->pp.kind == TDA_PROP_AM ? 1.0 : e->pp.scaling);
+  if ((rc = e->scaling.upload(sc))) return rc;
+  std::vector<double> L;
+  const double* Cuse = e->pp.kind == TDA_PROP_PCN ? e->prior_cov_h.data() : e->prop_C_h.data();  // proposal.py:336-341
+  if (!cholesky_host(Cuse, d, L)) return fail(TDA_ERR_NUMERIC, "proposal covariance is not positive definite");
+  std::vector<double> Lk((size_t)DP * DP, 0.0);
+  for (int j = 0; j < d; ++j)
+    for (int k = 0; k <= j; ++k) Lk[(size_t)k * DP + j] = L[(size_t)j * d + k];
+  if (e->pp.kind == TDA_PROP_AM) {
+    e->L_shared = false;
+    if ((rc = e->Lk.alloc((size_t)NP * DP * DP))) return rc;
+    std::vector<double> rep((size_t)std::min<int64_t>(NP, 256) * DP * DP);
+    for (size_t i = 0; i < rep.size(); ++i) rep[i] = Lk[i % ((size_t)DP * DP)];
+    for (int64_t c0 = 0; c0 < NP; c0 += 256) {
+      const int64_t n = std::min<int64_t>(256, NP - c0);
+      HIP_TRY(hipMemcpy(e->Lk.p + (size_t)c0 * DP * DP, rep.data(), (size_t)n * DP * DP * sizeof(double), hipMemcpyHostToDevice));
+    }
+    // RecursiveSampleMoments(mu0 = theta0, sigma0 = 0) (proposal.py:495-500)
+    if ((rc = e->am_mu.alloc((size_t)NP * DP))) return rc;
+    if ((rc = e->am_sigma.alloc((size_t)NP * DP * DP))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->am_mu.p, e->theta.p, (size_t)NP * DP * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    HIP_TRY(hipMemsetAsync(e->am_sigma.p, 0, (size_t)NP * DP * DP * sizeof(double), e->stream));
+  } else {
+    e->L_shared = true;
+    if ((rc = e->Lk.upload(Lk))) return rc;
+  }
+
+  // block buffers
+  if ((rc = e->inc.alloc((size_t)e->SMAX * NP * DP))) return rc;
+  if ((rc = e->ublk.alloc((size_t)e->SMAX * NP))) return rc;
+  if ((rc = e->rec_params.alloc((size_t)e->SMAX * N * d))) return rc;
+  if ((rc = e->rec_stats.alloc((size_t)e->SMAX * N * 3))) return rc;
+  if ((rc = e->rec_acc.alloc((size_t)e->SMAX * N))) return rc;
+
+  e->t = 0;
+  e->k_adapt = 0;
+  e->rep_pos = 0;
+  e->exp_pos = 0;
+  // initial links (chain.py:70)
+  if ((rc = launch_eval(e, 0, e->theta.p, e->lp.p, e->ll.p))) return rc;
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->inited = true;
+  return TDA_OK;
+}
+
+int tda_engine_get_current(tda_engine* e, double* theta, double* stats) {
+  if (!e || !e->inited) return fail(TDA_ERR_STATE, "engine not initialised");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  const int64_t N = e->N, NP = e->NP;
+  if (theta) {
+    std::vector<double> h((size_t)NP * e->DP), o((size_t)N * e->d);
+    HIP_TRY(hipMemcpy(h.data(), e->theta.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int64_t c = 0; c < N; ++c)
+      for (int j = 0; j < e->d; ++j) o[(size_t)c * e->d + j] = h[(size_t)c * e->DP + j];
+    HIP_TRY(hipMemcpy(theta, o.data(), o.size() * sizeof(double), is_device_ptr(theta) ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
+  }
+  if (stats) {
+    std::vector<double> a(NP), b(NP), o((size_t)N * 3);
+    HIP_TRY(hipMemcpy(a.data(), e->lp.p, NP * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(b.data(), e->ll.p, NP * sizeof(double), hipMemcpyDeviceToHost));
+    for (int64_t c = 0; c < N; ++c) {
+      o[c * 3] = a[c];
+      o[c * 3 + 1] = b[c];
+      o[c * 3 + 2] = a[c] + b[c];
+    }
+    HIP_TRY(hipMemcpy(stats, o.data(), o.size() * sizeof(double), is_device_ptr(stats) ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
+  }
+  return TDA_OK;
+}
+
+int tda_engine_set_replay(tda_engine* e, const double* z, const double* u, int64_t n_steps) {
+  if (!e) return fail(TDA_ERR_INVALID, "null engine");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  e->rep_steps = 0;
+  e->rep_pos = 0;
+  e->z_rep.release();
+  e->u_rep.release();
+  if (!z || !u || n_steps <= 0) return TDA_OK;
+  int rc;
+  const size_t nz = (size_t)n_steps * e->N * e->d, nu = (size_t)n_steps * e->N;
+  if ((rc = e->z_rep.alloc(nz))) return rc;
+  if ((rc = e->u_rep.alloc(nu))) return rc;
+  HIP_TRY(hipMemcpy(e->z_rep.p, z, nz * sizeof(double), is_device_ptr(z) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->u_rep.p, u, nu * sizeof(double), is_device_ptr(u) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  e->rep_steps = n_steps;
+  return TDA_OK;
+}
+
+int tda_engine_set_export(tda_engine* e, double* z, double* u, int64_t n_steps) {
+  if (!e) return fail(TDA_ERR_INVALID, "null engine");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  e->z_exp = e->u_exp = nullptr;
+  e->exp_steps = 0;
+  e->exp_pos = 0;
+  e->z_exp_d.release();
+  e->u_exp_d.release();
+  if (!z || !u || n_steps <= 0) return TDA_OK;
+  if (is_device_ptr(z) != is_device_ptr(u)) return fail(TDA_ERR_INVALID, "export buffers must both be host or both be device");
+  e->exp_dev = is_device_ptr(z);
+  if (!e->exp_dev) {
+    int rc;
+    if ((rc = e->z_exp_d.alloc((size_t)n_steps * e->N * e->d))) return rc;
+    if ((rc = e->u_exp_d.alloc((size_t)n_steps * e->N))) return rc;
+  }
+  e->z_exp = z;
+  e->u_exp = u;
+  e->exp_steps = n_steps;
+  return TDA_OK;
+}
+
+int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
+  if (!e || !e->inited) return fail(TDA_ERR_STATE, "engine not initialised");
+  if (n_iter < 0) return fail(TDA_ERR_INVALID, "n_iterations < 0");
+  if (out && out->struct_size != sizeof(tda_outputs)) return fail(TDA_ERR_INVALID, "tda_outputs.struct_size mismatch");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  if (e->rep_steps && e->rep_pos + n_iter > e->rep_steps)
+    return fail(TDA_ERR_INVALID, "replay buffer holds %lld steps, %lld requested", (long long)(e->rep_steps - e->rep_pos), (long long)n_iter);
+  if (e->exp_steps && e->exp_pos + n_iter > e->exp_steps)
+    return fail(TDA_ERR_INVALID, "export buffer too small");
+
+  const int d = e->d;
+  const int64_t N = e->N, NP = e->NP;
+  double* o_params = out ? out->params : nullptr;
+  double* o_stats = out ? out->stats : nullptr;
+  uint8_t* o_acc = out ? out->accepted : nullptr;
+  const bool p_dev = is_device_ptr(o_params), s_dev = is_device_ptr(o_stats), a_dev = is_device_ptr(o_acc);
+  const bool is_am = e->pp.kind == TDA_PROP_AM;
+  const bool adaptive = e->pp.adaptive != 0;
+  const bool periodic = is_am || adaptive;
+  const int period = e->pp.period;
+  const Level& lv = e->levels[0];
+  const size_t lds = steps_lds_bytes(e, lv);
+  bool host_copies = false;
+
+  if (e->profiling) {
+    for (auto& t : e->timed) {
+      (void)hipEventDestroy(t.a);
+      (void)hipEventDestroy(t.b);
+    }
+    e->timed.clear();
+  }
+
+  int64_t done = 0;
+  while (done < n_iter) {
+    int64_t S = std::min<int64_t>(n_iter - done, e->SMAX);
+    if (periodic) S = std::min<int64_t>(S, period - (e->t % period));
+
+    // ---- proposal increments + uniforms ----
+    ProposeArgs pa{};
+    pa.N = N;
+    pa.NP = NP;
+    pa.chain_offset = e->cfg.chain_offset;
+    pa.d = d;
+    pa.S = (int)S;
+    pa.step0 = e->t;
+    pa.seed = e->cfg.seed;
+    pa.Lk = e->Lk.p;
+    pa.L_stride = e->L_shared ? 0 : (int64_t)e->DP * e->DP;
+    pa.inc = e->inc.p;
+    pa.u = e->ublk.p;
+    if (e->rep_steps) {
+      pa.z_replay = e->z_rep.p + (size_t)e->rep_pos * N * d;
+      pa.u_replay = e->u_rep.p + (size_t)e->rep_pos * N;
+    }
+    if (e->exp_steps) {
+      pa.z_export = (e->exp_dev ? e->z_exp : e->z_exp_d.p) + (size_t)e->exp_pos * N * d;
+      pa.u_export = (e->exp_dev ? e->u_exp : e->u_exp_d.p) + (size_t)e->exp_pos * N;
+    }
+    {
+      ScopedTimer tm(e, 0);
+      DISPATCH_DPAD(e->DP, launch_propose<DPAD>(pa, e->stream));
+    }
+
+    // ---- fused MH steps ----
+    StepArgs sa{};
+    fill_level(e, lv, sa);
+    sa.S = (int)S;
+    sa.mode = MODE_STEP;
+    sa.prop_kind = e->pp.kind;
+    sa.theta = e->theta.p;
+    sa.lp = e->lp.p;
+    sa.ll = e->ll.p;
+    sa.scaling = e->scaling.p;
+    sa.acc_count = e->acc_count.p;
+    sa.inc = e->inc.p;
+    sa.u = e->ublk.p;
+    // records go straight into caller memory when it is device memory; AM needs the states either way
+    sa.rec_params = p_dev ? o_params + (size_t)done * N * d : ((o_params || is_am) ? e->rec_params.p : nullptr);
+    sa.rec_stats = s_dev ? o_stats + (size_t)done * N * 3 : (o_stats ? e->rec_stats.p : nullptr);
+    sa.rec_acc = a_dev ? o_acc + (size_t)done * N : (o_acc ? e->rec_acc.p : nullptr);
+    {
+      ScopedTimer tm(e, 1);
+      DISPATCH_DPAD(e->DP, launch_steps<DPAD>(sa, NP / 16, lds, e->stream));
+    }
+
+    // ---- adaptation (proposal.py:228-245, :502-512) ----
+    const bool boundary = periodic && ((e->t + S) % period == 0);
+    if (is_am || (boundary && adaptive)) {
+      AdaptArgs aa{};
+      aa.N = N;
+      aa.NP = NP;
+      aa.d = d;
+      aa.S = (int)S;
+      aa.t_base = e->t;
+      aa.do_am = is_am;
+      aa.boundary = boundary;
+      aa.do_scale = adaptive;
+      aa.do_swap = is_am && boundary && (e->t + S >= e->pp.t0);
+      aa.period = period;
+      aa.gamma_pow = std::pow(e->pp.gamma, -(double)e->k_adapt);
+      aa.sd = e->am_sd;
+      aa.eps = e->pp.epsilon;
+      aa.rec_params = sa.rec_params;
+      aa.am_mu = e->am_mu.p;
+      aa.am_sigma = e->am_sigma.p;
+      aa.Lk = e->Lk.p;
+      aa.scaling = e->scaling.p;
+      aa.acc_count = e->acc_count.p;
+      aa.flags = e->flags.p;
+      ScopedTimer tm(e, 2);
+      DISPATCH_DPAD(e->DP, launch_adapt<DPAD>(aa, e->stream));
+    } else if (boundary) {
+      HIP_TRY(hipMemsetAsync(e->acc_count.p, 0, NP * sizeof(int32_t), e->stream));
+    }
+    HIP_TRY(hipGetLastError());
+    if (boundary && adaptive) e->k_adapt += 1;
+
+    // ---- host-side records ----
+    int rc;
+    if (o_params && !p_dev) {
+      if ((rc = copy_out(e, o_params + (size_t)done * N * d, e->rec_params.p, (size_t)S * N * d * sizeof(double)))) return rc;
+      host_copies = true;
+    }
+    if (o_stats && !s_dev) {
+      if ((rc = copy_out(e, o_stats + (size_t)done * N * 3, e->rec_stats.p, (size_t)S * N * 3 * sizeof(double)))) return rc;
+      host_copies = true;
+    }
+    if (o_acc && !a_dev) {
+      if ((rc = copy_out(e, o_acc + (size_t)done * N, e->rec_acc.p, (size_t)S * N))) return rc;
+      host_copies = true;
+    }
+    if (host_copies) HIP_TRY(hipStreamSynchronize(e->stream));  // block buffers are reused next iteration
+
+    e->t += S;
+    done += S;
+    if (e->rep_steps) e->rep_pos += S;
+    if (e->exp_steps) e->exp_pos += S;
+  }
+
+  if (e->exp_steps && !e->exp_dev) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(e->z_exp, e->z_exp_d.p, (size_t)e->exp_pos * N * d * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(e->u_exp, e->u_exp_d.p, (size_t)e->exp_pos * N * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  return TDA_OK;
+}
+
+int tda_engine_sync(tda_engine* e) {
+  if (!e) return fail(TDA_ERR_INVALID, "null engine");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return TDA_OK;
+}
+
+int tda_engine_get_proposal_state(tda_engine* e, double* scaling, double* C, double* am_mu, double* am_sigma,
+                                  int64_t* counters) {
+  if (!e || !e->inited) return fail(TDA_ERR_STATE, "engine not initialised");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  const int d = e->d, DP = e->DP;
+  const int64_t N = e->N, NP = e->NP;
+  if (scaling) {
+    std::vector<double> h(NP);
+    HIP_TRY(hipMemcpy(h.data(), e->scaling.p, NP * sizeof(double), hipMemcpyDeviceToHost));
+    std::copy(h.begin(), h.begin() + N, scaling);
+  }
+  if (C) {  // C = L L^T from the factor in use
+    const int64_t nL = e->L_shared ? 1 : NP;
+    std::vector<double> h((size_t)nL * DP * DP);
+    HIP_TRY(hipMemcpy(h.data(), e->Lk.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int64_t c = 0; c < N; ++c) {
+      const double* Lc = h.data() + (e->L_shared ? 0 : (size_t)c * DP * DP);
+      for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) {
+          double s = 0.0;
+          for (int k = 0; k <= std::min(i, j); ++k) s += Lc[(size_t)k * DP + i] * Lc[(size_t)k * DP + j];
+          C[((size_t)c * d + i) * d + j] = s;
+        }
+    }
+  }
+  if (am_mu || am_sigma) {
+    if (e->pp.kind != TDA_PROP_AM) return fail(TDA_ERR_STATE, "proposal has no running moments");
+    if (am_mu) {
+      std::vector<double> h((size_t)NP * DP);
+      HIP_TRY(hipMemcpy(h.data(), e->am_mu.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+      for (int64_t c = 0; c < N; ++c)
+        for (int j = 0; j < d; ++j) am_mu[(size_t)c * d + j] = h[(size_t)c * DP + j];
+    }
+    if (am_sigma) {
+      std::vector<double> h((size_t)DP * DP);
+      for (int64_t c = 0; c < N; ++c) {
+        HIP_TRY(hipMemcpy(h.data(), e->am_sigma.p + (size_t)c * DP * DP, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int i = 0; i < d; ++i)
+          for (int j = 0; j < d; ++j) am_sigma[((size_t)c * d + i) * d + j] = h[(size_t)i * DP + j];
+      }
+    }
+  }
+  if (counters) {
+    counters[0] = e->t;
+    counters[1] = e->k_adapt;
+  }
+  return TDA_OK;
+}
+
+int tda_engine_get_flags(tda_engine* e, int32_t* flags) {
+  if (!e || !e->inited || !flags) return fail(TDA_ERR_STATE, "engine not initialised");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  std::vector<int32_t> h(e->NP);
+  HIP_TRY(hipMemcpy(h.data(), e->flags.p, e->NP * sizeof(int32_t), hipMemcpyDeviceToHost));
+  std::copy(h.begin(), h.begin() + e->N, flags);
+  return TDA_OK;
+}
+
+int tda_engine_evaluate(tda_engine* e, int level, const double* theta, int64_t n, double* stats) {
+  if (!e || !theta || !stats) return fail(TDA_ERR_INVALID, "null argument");
+  if (!e->prior_set) return fail(TDA_ERR_STATE, "set_prior missing");
+  if (level < 0 || level >= (int)e->levels.size() || !e->levels[level].set) return fail(TDA_ERR_STATE, "level %d not set", level);
+  if (n < 1 || n > e->N) return fail(TDA_ERR_INVALID, "n must be in 1..n_chains");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  int rc;
+  const int64_t NP = e->NP;
+  if (!e->theta_s.p) {
+    if ((rc = e->theta_s.alloc((size_t)NP * e->DP))) return rc;
+    if ((rc = e->lp_s.alloc(NP))) return rc;
+    if ((rc = e->ll_s.alloc(NP))) return rc;
+  }
+  if (!e->scaling.p) {
+    std::vector<double> sc(NP, 1.0);
+    if ((rc = e->scaling.upload(sc))) return rc;
+  }
+  if ((rc = upload_states(e, theta, n, e->theta_s.p))) return rc;
+  if ((rc = launch_eval(e, level, e->theta_s.p, e->lp_s.p, e->ll_s.p))) return rc;
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  std::vector<double> a(NP), b(NP), o((size_t)n * 3);
+  HIP_TRY(hipMemcpy(a.data(), e->lp_s.p, NP * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(b.data(), e->ll_s.p, NP * sizeof(double), hipMemcpyDeviceToHost));
+  for (int64_t c = 0; c < n; ++c) {
+    o[c * 3] = a[c];
+    o[c * 3 + 1] = b[c];
+    o[c * 3 + 2] = a[c] + b[c];
+  }
+  HIP_TRY(hipMemcpy(stats, o.data(), o.size() * sizeof(double), is_device_ptr(stats) ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
+  return TDA_OK;
+}
+
+int tda_engine_rng_probe(tda_engine* e, int64_t step, double* z, double* u) {
+  if (!e || !z || !u) return fail(TDA_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const int d = e->d, DP = e->DP;
+  const int64_t N = e->N, NP = e->NP;
+  DevBuf<double> Lid, inc, ub, zd, ud;
+  std::vector<double> I((size_t)DP * DP, 0.0);
+  for (int j = 0; j < DP; ++j) I[(size_t)j * DP + j] = 1.0;
+  int rc;
+  if ((rc = Lid.upload(I))) return rc;
+  if ((rc = inc.alloc((size_t)NP * DP))) return rc;
+  if ((rc = ub.alloc(NP))) return rc;
+  if ((rc = zd.alloc((size_t)N * d))) return rc;
+  if ((rc = ud.alloc(N))) return rc;
+  ProposeArgs pa{};
+  pa.N = N;
+  pa.NP = NP;
+  pa.chain_offset = e->cfg.chain_offset;
+  pa.d = d;
+  pa.S = 1;
+  pa.step0 = step;
+  pa.seed = e->cfg.seed;
+  pa.Lk = Lid.p;
+  pa.L_stride = 0;
+  pa.inc = inc.p;
+  pa.u = ub.p;
+  pa.z_export = zd.p;
+  pa.u_export = ud.p;
+  DISPATCH_DPAD(DP, launch_propose<DPAD>(pa, e->stream));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipMemcpy(z, zd.p, (size_t)N * d * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(u, ud.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+  return TDA_OK;
+}
+
+int tda_engine_set_profiling(tda_engine* e, int enable) {
+  if (!e) return fail(TDA_ERR_INVALID, "null engine");
+  e->profiling = enable != 0;
+  return TDA_OK;
+}
+
+int tda_engine_get_profile(tda_engine* e, tda_profile* p) {
+  if (!e || !p) return fail(TDA_ERR_INVALID, "null argument");
+  if (p->struct_size != sizeof(tda_profile)) return fail(TDA_ERR_INVALID, "tda_profile.struct_size mismatch");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  const uint32_t ss = p->struct_size;
+  memset(p, 0, sizeof *p);
+  p->struct_size = ss;
+  for (auto& t : e->timed) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b));
+    if (t.kind == 0) {
+      p->ms_propose += ms;
+      p->n_launch_propose++;
+    } else if (t.kind == 1) {
+      p->ms_steps += ms;
+      p->n_launch_steps++;
+    } else {
+      p->ms_adapt += ms;
+      p->n_launch_adapt++;
+    }
+  }
+  if (!e->timed.empty()) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e->timed.front().a, e->timed.back().b));
+    p->ms_total = ms;
+  }
+  return TDA_OK;
+}
+
+}  // extern "C"

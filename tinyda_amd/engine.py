@@ -1,0 +1,148 @@
+"""Thin object wrapper over the C-ABI (include/tinyda_amd.h); numpy / torch arrays in, arrays out."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+
+def _ptr(a):
+    """Pointer of a numpy array (host) or a torch tensor (device or host)."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return a.ctypes.data_as(C.c_void_p)
+    if hasattr(a, "data_ptr"):
+        assert a.is_contiguous()
+        return C.c_void_p(a.data_ptr())
+    raise TypeError("expected numpy array or torch tensor")
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+class Engine:
+    """One many-chain MH engine on one GPU (one per process under torch.distributed)."""
+
+    def __init__(self, n_chains, dim, seed=0, device=0, chain_offset=0, n_levels=1, block_steps=0, stream=None):
+        self.lib = _lib.load()
+        self.n_chains, self.dim = int(n_chains), int(dim)
+        cfg = _lib.tda_config(C.sizeof(_lib.tda_config), device, n_chains, chain_offset, dim, n_levels, seed,
+                              stream, block_steps, 0)
+        h = C.c_void_p()
+        check(self.lib.tda_engine_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tda_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- problem ------------------------------------------------------------------------
+    def set_prior(self, mean, cov):
+        mean, cov = _f64(mean), _f64(cov)
+        assert mean.shape == (self.dim,) and cov.shape == (self.dim, self.dim)
+        check(self.lib.tda_engine_set_prior(self.h, _ptr(mean), _ptr(cov)))
+
+    def set_level(self, level, A, data, noise_kind, noise, b=None):
+        A, data, noise = _f64(A), _f64(data), _f64(np.atleast_1d(noise))
+        m = A.shape[0]
+        assert A.shape == (m, self.dim) and data.shape == (m,)
+        b = None if b is None else _f64(b)
+        check(self.lib.tda_engine_set_level(self.h, level, m, _ptr(A), _ptr(b), _ptr(data), noise_kind, _ptr(noise)))
+
+    def set_proposal(self, kind, C_=None, scaling=1.0, adaptive=False, gamma=1.01, period=100, sd=None,
+                     epsilon=1e-6, t0=0):
+        Cm = None if C_ is None else _f64(C_)
+        p = _lib.tda_proposal_params(C.sizeof(_lib.tda_proposal_params), kind, scaling, int(adaptive), period, gamma,
+                                     _ptr(Cm), -1.0 if sd is None else sd, epsilon, t0, 0)
+        check(self.lib.tda_engine_set_proposal(self.h, C.byref(p)))
+
+    def init(self, theta0=None):
+        if theta0 is not None and isinstance(theta0, np.ndarray):
+            theta0 = _f64(theta0)
+            assert theta0.shape == (self.n_chains, self.dim)
+        check(self.lib.tda_engine_init(self.h, _ptr(theta0)))
+
+    # -- variates -----------------------------------------------------------------------
+    def set_replay(self, z, u):
+        """z [steps, chains, dim], u [steps, chains]"""
+        if z is None:
+            check(self.lib.tda_engine_set_replay(self.h, None, None, 0))
+            return
+        z, u = _f64(z), _f64(u)
+        assert z.shape[1:] == (self.n_chains, self.dim) and u.shape == z.shape[:2]
+        check(self.lib.tda_engine_set_replay(self.h, _ptr(z), _ptr(u), z.shape[0]))
+
+    def set_export(self, n_steps):
+        z = np.zeros((n_steps, self.n_chains, self.dim))
+        u = np.zeros((n_steps, self.n_chains))
+        self._keep = [z, u]
+        check(self.lib.tda_engine_set_export(self.h, _ptr(z), _ptr(u), n_steps))
+        return z, u
+
+    # -- running ------------------------------------------------------------------------
+    def run(self, n_iterations, params=None, stats=None, accepted=None, sync=True):
+        out = _lib.tda_outputs(C.sizeof(_lib.tda_outputs), 0, _ptr(params), _ptr(stats), _ptr(accepted))
+        check(self.lib.tda_engine_run(self.h, n_iterations, C.byref(out)))
+        if sync:
+            self.sync()
+
+    def run_host(self, n_iterations):
+        """Convenience: run and return numpy records (params [T,N,d], stats [T,N,3], accepted [T,N])."""
+        T, N, d = n_iterations, self.n_chains, self.dim
+        params, stats = np.empty((T, N, d)), np.empty((T, N, 3))
+        acc = np.empty((T, N), dtype=np.uint8)
+        self.run(T, params, stats, acc)
+        return params, stats, acc
+
+    def sync(self):
+        check(self.lib.tda_engine_sync(self.h))
+
+    def current(self):
+        th, st = np.empty((self.n_chains, self.dim)), np.empty((self.n_chains, 3))
+        check(self.lib.tda_engine_get_current(self.h, _ptr(th), _ptr(st)))
+        return th, st
+
+    def proposal_state(self, want_am=False):
+        N, d = self.n_chains, self.dim
+        sc, Cm, cnt = np.empty(N), np.empty((N, d, d)), np.zeros(2, dtype=np.int64)
+        mu = np.empty((N, d)) if want_am else None
+        sg = np.empty((N, d, d)) if want_am else None
+        check(self.lib.tda_engine_get_proposal_state(self.h, _ptr(sc), _ptr(Cm), _ptr(mu), _ptr(sg), _ptr(cnt)))
+        return dict(scaling=sc, C=Cm, am_mu=mu, am_sigma=sg, t=int(cnt[0]), k=int(cnt[1]))
+
+    def flags(self):
+        f = np.zeros(self.n_chains, dtype=np.int32)
+        check(self.lib.tda_engine_get_flags(self.h, _ptr(f)))
+        return f
+
+    def evaluate(self, theta, level=0):
+        theta = _f64(theta)
+        n = theta.shape[0]
+        st = np.empty((n, 3))
+        check(self.lib.tda_engine_evaluate(self.h, level, _ptr(theta), n, _ptr(st)))
+        return st
+
+    def rng_probe(self, step):
+        z, u = np.empty((self.n_chains, self.dim)), np.empty(self.n_chains)
+        check(self.lib.tda_engine_rng_probe(self.h, step, _ptr(z), _ptr(u)))
+        return z, u
+
+    def set_profiling(self, on):
+        check(self.lib.tda_engine_set_profiling(self.h, int(on)))
+
+    def profile(self):
+        p = _lib.tda_profile(C.sizeof(_lib.tda_profile))
+        check(self.lib.tda_engine_get_profile(self.h, C.byref(p)))
+        return {k: getattr(p, k) for k, _ in p._fields_ if k != "struct_size"}
