@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Headline benchmark: proposal evaluations / s of the many-chain MH hot path (BASELINE.json configs[1]):
+64-dim Gaussian-linear posterior, 1024 observations, isotropic noise, AdaptiveMetropolis(t0=100, period=100),
+4096 chains per GPU, synthetic data of SURVEY.md §8(d) "C2 synthetic input".
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" = one Metropolis-Hastings step of every chain on the GPU (propose -> forward model -> log-likelihood
+-> log alpha -> accept -> record, with the AdaptiveMetropolis recursion and covariance swaps included).
+For N > 1 launch under torch.distributed.run; chains are sharded by global id, no data-path collective.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+D, M, SIGMA = 64, 1024, 0.1
+CHAINS_PER_GPU = 4096
+HBM_PEAK = 8.0e12        # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
+FP64_MFMA_PEAK = 78.6e12  # FLOP/s dense fp64 matrix (AMD MI355X spec; tools/mfma_probe measures 75-77 on the box)
+B_ALG_STEP_SYNC = 40 * D + 25 + 24 * D * D + 8 * (M * D + M) / CHAINS_PER_GPU  # 101 019 B / eval
+FLOPS_STEPS_KERNEL = 2 * M * D + 3 * M + 2 * D  # forward + isotropic log-like + identity prior
+
+
+def c2_problem(seed=1):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((M, D)) / 8
+    theta_true = rng.standard_normal(D)
+    y = A @ theta_true + SIGMA * rng.standard_normal(M)
+    return A, theta_true, y
+
+
+def cpu_baseline(A, y, target_seconds=12.0):
+    """The C oracle (oracle/oracle_mh.c, kind 'port') on all host cores, bounded sample of the same workload."""
+    from oracle import oracle_c
+
+    oracle_c.load()
+    cores = os.cpu_count() or 1
+    rng = np.random.default_rng(7)
+
+    def run(n_chains, T):
+        theta0 = rng.standard_normal((n_chains, D))
+        z = rng.standard_normal((T, n_chains, D))
+        u = rng.random((T, n_chains))
+        t0 = time.perf_counter()
+        oracle_c.run_mh(A, y, SIGMA ** 2, np.zeros(D), np.ones(D), 2, 1e-4 * np.eye(D), theta0, z, u, period=100, t0=100,
+                        n_threads=cores, want_records=False)
+        return time.perf_counter() - t0
+
+    T = 250
+    t_cal = run(cores, 50)
+    rate = cores * 50 / t_cal
+    n_chains = int(max(cores, min(4096, round(rate * target_seconds / T / cores) * cores)))
+    dt = run(n_chains, T)
+    return {"value": n_chains * T / dt, "unit": "evals/s", "cores": cores, "kind": "port",
+            "sample": "%d chains x %d steps of the same workload (C oracle, OpenMP over chains, %.1f s)" % (n_chains, T, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ess", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    from tinyda_amd import diagnostics
+    from tinyda_amd import distributed as tdist
+    from tinyda_amd.engine import Engine
+
+    rank, local_rank, world = tdist.init_process_group()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    N, K, W = args.chains, args.steps, args.warmup
+
+    A, _, y = c2_problem()
+    eng = Engine(N, D, seed=2026, device=local_rank, chain_offset=rank * N)  # weak scaling: N chains per GPU
+    eng.set_prior(np.zeros(D), np.eye(D))
+    eng.set_level(0, A, y, 0, SIGMA ** 2)
+    eng.set_proposal(2, 1e-4 * np.eye(D), t0=100, period=100, sd=None, epsilon=1e-6)
+    eng.init(None)  # theta0 ~ prior, Philox stream 2 keyed by global chain id
+
+    params = torch.empty((max(K, W), N, D), dtype=torch.float64, device=dev)
+    stats = torch.empty((max(K, W), N, 3), dtype=torch.float64, device=dev)
+    acc = torch.empty((max(K, W), N), dtype=torch.uint8, device=dev)
+    if W > 0:
+        eng.run(W, params[:W], stats[:W], acc[:W])
+    eng.set_profiling(True)  # HIP events around every kernel launch, on the engine's stream
+    torch.cuda.synchronize()
+    tdist.barrier()
+    t0 = time.perf_counter()
+    eng.run(K, params[:K], stats[:K], acc[:K], sync=True)
+    torch.cuda.synchronize()
+    tdist.barrier()
+    dt = tdist.reduce_scalar(time.perf_counter() - t0, "max", dev)
+    prof = eng.profile()
+
+    evals = world * N * K
+    out = {
+        "metric": "proposal evals/sec (node), 64-dim AdaptiveMetropolis, 4096 chains/GPU",
+        "value": evals / dt,
+        "unit": "evals/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": dt / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1] / SURVEY C2a: d=64 Gaussian-linear posterior, m=1024 obs, isotropic noise, "
+                               "prior N(0,I), AdaptiveMetropolis(C0=1e-4 I, t0=100, period=100), theta0 ~ prior",
+                   "chains_per_gpu": N, "dim": D, "observations": M, "records": "params+stats+accepted to HBM every step"},
+    }
+    if rank == 0:
+        ev_rank = N * K
+        kern = {"k_mh_steps": (prof["ms_steps"], prof["n_launch_steps"]),
+                "k_adapt": (prof["ms_adapt"], prof["n_launch_adapt"]),
+                "k_propose": (prof["ms_propose"], prof["n_launch_propose"])}
+        ms_st, n_st = kern["k_mh_steps"]
+        avg_launch_s = ms_st * 1e-3 / max(n_st, 1)
+        evals_per_launch = ev_rank / max(n_st, 1)
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("k_mh_steps_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        achieved = FLOPS_STEPS_KERNEL * evals_per_launch / avg_launch_s
+        out["roofline"] = {"kernel": "k_mh_steps", "bound": "mfma", "achieved": achieved / 1e12, "peak": FP64_MFMA_PEAK / 1e12,
+                           "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK, "traffic": traffic,
+                           "flops_per_eval": FLOPS_STEPS_KERNEL, "evals_per_launch": evals_per_launch,
+                           "avg_launch_ms": avg_launch_s * 1e3}
+        # the figure north_star quotes: step-synchronous algorithmic bytes against HBM peak, whole pipeline
+        rate_gpu = ev_rank / dt
+        out["roofline_hbm_step_synchronous"] = {"bound": "hbm", "bytes_per_eval": B_ALG_STEP_SYNC,
+                                                "achieved": rate_gpu * B_ALG_STEP_SYNC / 1e9, "peak": HBM_PEAK / 1e9,
+                                                "unit": "GB/s", "frac": rate_gpu * B_ALG_STEP_SYNC / HBM_PEAK,
+                                                "note": "period-blocked pipeline keeps Sigma/L traffic off the per-step path; >1 means the "
+                                                        "step-synchronous HBM model no longer binds"}
+        out["kernel_ms"] = {k: {"total_ms": v[0], "launches": v[1], "ns_per_eval": v[0] * 1e6 / ev_rank} for k, v in kern.items()}
+        out["acceptance_rate"] = float(acc[:K].float().mean().item())
+        if not args.no_ess:
+            # ESS/s: min-over-parameters bulk ESS of the second half of the timed draws.  Chains are independent, so the
+            # ESS of a 512-chain subset is scaled to all chains of the node.
+            sub = min(N, 512)
+            draws = params[K // 2:K, :sub].cpu().numpy()
+            ess = diagnostics.ess_summary(draws)
+            scale = world * N / sub
+            out["ess_per_sec"] = ess["ess_min"] * scale / dt
+            out["ess"] = {"min_bulk_ess_node": ess["ess_min"] * scale, "median_bulk_ess_node": ess["ess_median"] * scale,
+                          "chains_used": sub, "draws_per_chain": draws.shape[0]}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(A, y)
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

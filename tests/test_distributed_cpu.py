@@ -1,0 +1,56 @@
+"""The N>1 plumbing on CPU: world_size-2 gloo process group (sharding, barrier, max-over-ranks, pooled moments)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from tinyda_amd import distributed as tdist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, %(root)r)
+import torch
+from tinyda_amd import distributed as tdist
+rank, local_rank, world = tdist.init_process_group("gloo")
+off, cnt = tdist.shard_chains(10, rank, world)
+tdist.barrier()
+mx = tdist.reduce_scalar(1.0 + rank, "max")
+sm = tdist.reduce_scalar(cnt, "sum")
+g = torch.Generator().manual_seed(5)
+x = torch.randn(10, 3, generator=g, dtype=torch.float64)[off:off + cnt]
+mean = x.mean(0)
+m2 = (x - mean).T @ (x - mean)
+n, mu, M2 = tdist.gather_moments(cnt, mean, m2)
+print("RESULT" + json.dumps(dict(rank=rank, off=off, cnt=cnt, mx=mx, sm=sm, n=n, mu=mu.tolist(), M2=M2.tolist())))
+"""
+
+
+def test_shard_chains_partition():
+    for n, w in ((4096, 8), (10, 3), (5, 8), (65536, 8)):
+        parts = [tdist.shard_chains(n, r, w) for r in range(w)]
+        assert sum(c for _, c in parts) == n
+        assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+        assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+
+
+def test_world_size_2_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29617", str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    import json
+
+    res = sorted((json.loads(l.split("RESULT", 1)[1]) for l in r.stdout.splitlines() if "RESULT" in l), key=lambda d: d["rank"])
+    assert [d["off"] for d in res] == [0, 5] and [d["cnt"] for d in res] == [5, 5]
+    assert all(d["mx"] == 2.0 and d["sm"] == 10.0 and d["n"] == 10.0 for d in res)
+    import torch
+
+    x = torch.randn(10, 3, generator=torch.Generator().manual_seed(5), dtype=torch.float64).numpy()
+    np.testing.assert_allclose(res[0]["mu"], x.mean(0), rtol=1e-12)
+    np.testing.assert_allclose(res[1]["M2"], (x - x.mean(0)).T @ (x - x.mean(0)), rtol=1e-10)

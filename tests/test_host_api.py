@@ -1,0 +1,163 @@
+"""Host mirror of the reference API: classes, factory dispatch, error behaviour, result layout, and the
+host chain driver replaying the reference's golden variates."""
+import numpy as np
+import pytest
+import scipy.stats as stats
+
+import tinyda_amd as tda
+
+
+def test_factory_dispatch_and_errors(golden):
+    g = golden("g3_loglike_kats")
+    data, X = g["data"], g["X"]
+    m = len(data)
+    iso = tda.GaussianLogLike(data, float(g["iso_var"]) * np.eye(m))
+    diag = tda.GaussianLogLike(data, g["diag_cov"])
+    dense = tda.GaussianLogLike(data, g["dense_cov"])
+    assert [type(o).__name__ for o in (iso, diag, dense)] == list(g["class_names"])
+    for obj, key in ((iso, "iso"), (diag, "diag"), (dense, "dense")):
+        np.testing.assert_allclose([obj.loglike(x) for x in X], g["out_" + key], rtol=1e-12)
+        np.testing.assert_allclose([obj.grad_loglike(x) for x in X], g["grad_" + key], rtol=1e-11, atol=1e-13)
+    with pytest.raises(TypeError):
+        tda.GaussianLogLike(data, [[1.0]])
+    with pytest.raises(TypeError):
+        tda.GaussianLogLike(data, np.ones(m))
+    with pytest.raises(ValueError):
+        tda.GaussianLogLike(data, np.eye(m + 1))
+    with pytest.raises(ValueError):
+        tda.GaussianLogLike(data, np.ones((m, m + 1)))
+    ada = tda.AdaptiveGaussianLogLike(data, g["dense_cov"])
+    np.testing.assert_allclose([ada.loglike(x) for x in X], g["out_ada0"], rtol=1e-12)
+    ada.set_bias(g["bias"], g["bias_cov"])
+    np.testing.assert_allclose([ada.loglike(x) for x in X], g["out_ada1"], rtol=1e-12)
+    np.testing.assert_allclose([ada.loglike_custom_bias(x, g["custom_bias"]) for x in X], g["out_ada_custom"], rtol=1e-12)
+    ada2 = tda.AdaptiveGaussianLogLike(data, g["dense_cov"])
+    ada2.set_bias(g["bias"], g["tiny_cov"])
+    np.testing.assert_allclose([ada2.loglike(x) for x in X], g["out_ada_tiny"], rtol=1e-12)
+    ada2.set_bias(g["bias"], g["mixed_cov"])
+    np.testing.assert_allclose([ada2.loglike(x) for x in X], g["out_ada_mixed"], rtol=1e-12)
+
+
+def test_recursive_moments_bit_identical(golden):
+    g = golden("g7_moments")
+    X = g["X"]
+    r = tda.RecursiveSampleMoments(X[0].copy(), np.zeros((X.shape[1],) * 2), sd=float(g["sd"]), epsilon=float(g["epsilon"]))
+    for i, x in enumerate(X[1:]):
+        r.update(x)
+        assert np.array_equal(r.get_mu(), g["mu_hist"][i]) and np.array_equal(r.get_sigma(), g["sigma_hist"][i])
+    z = tda.ZeroMeanRecursiveSampleMoments(np.zeros((X.shape[1],) * 2))
+    for i, x in enumerate(X):
+        z.update(x)
+        assert np.array_equal(z.get_sigma(), g["zero_mean_hist"][i])
+
+
+def test_posterior_and_link_protocol():
+    A = np.array([[1.0, 2.0], [0.5, -1.0], [0.0, 3.0]])
+    prior = stats.multivariate_normal(np.zeros(2), np.eye(2))
+    post = tda.Posterior(prior, tda.GaussianLogLike(np.ones(3), 0.5 * np.eye(3)), lambda th: (A @ th, th.sum()))
+    link = post.create_link(np.array([0.2, -0.1]))
+    assert link.qoi == pytest.approx(0.1) and link.posterior == link.prior + link.likelihood
+    assert post(np.array([0.2, -0.1])) == link.posterior == post.logpdf(np.array([0.2, -0.1]))
+    with pytest.raises(TypeError):
+        tda.Posterior(prior, tda.GaussianLogLike(np.ones(3), np.eye(3)), lambda th: [1, 2, 3]).create_link(np.zeros(2))
+    with pytest.raises(TypeError):
+        tda.GaussianRandomWalk([[1.0]])
+    with pytest.raises(ValueError):
+        tda.AdaptiveMetropolis(np.ones((2, 3)))
+    assert tda.AdaptiveMetropolis(np.eye(64)).sd == pytest.approx(2.4 ** 2 / 64)
+    with pytest.raises(TypeError):  # pCN needs a scipy multivariate normal prior (sampler.py:138-143)
+        tda.sample(tda.Posterior(stats.norm(), tda.GaussianLogLike(np.ones(3), np.eye(3)), lambda th: A @ th),
+                   tda.CrankNicolson(), 5, backend="host")
+
+
+class _Replay:
+    """Feeds recorded variates to the host proposals / chain (np.random.standard_normal, np.random.random)."""
+
+    def __init__(self, z, u):
+        self.z, self.u, self.iz, self.iu = z, u, 0, 0
+
+    def __enter__(self):
+        self.saved = (np.random.standard_normal, np.random.random)
+        np.random.standard_normal = self._normal
+        np.random.random = self._uniform
+        return self
+
+    def __exit__(self, *a):
+        np.random.standard_normal, np.random.random = self.saved
+
+    def _normal(self, n):
+        self.iz += 1
+        return self.z[self.iz - 1]
+
+    def _uniform(self):
+        self.iu += 1
+        return self.u[self.iu - 1]
+
+
+@pytest.mark.parametrize("name", ["g1_basic_sampler", "g2_am_small_adaptive", "g2b_pcn"])
+def test_host_chain_replays_reference(golden, name):
+    g = golden(name)
+    prior = stats.multivariate_normal(g["prior_mean"], g["prior_cov"])
+    if "noise_var" in g.files:
+        cov = float(g["noise_var"]) * np.eye(len(g["data"]))
+    else:
+        cov = np.diag(g["noise_cov"])
+    A = g["A"]
+    post = tda.Posterior(prior, tda.GaussianLogLike(g["data"], cov), lambda th: A @ th)
+    for c in range(g["theta"].shape[0]):
+        if name.startswith("g1"):
+            prop = tda.GaussianRandomWalk(g["C"], scaling=float(g["scaling0"]), adaptive=True, gamma=float(g["gamma"]),
+                                          period=int(g["period"]))
+        elif name.startswith("g2b"):
+            prop = tda.CrankNicolson(scaling=float(g["scaling0"]), adaptive=True, gamma=float(g["gamma"]),
+                                     period=int(g["period"]))
+        else:
+            prop = tda.AdaptiveMetropolis(g["C0"], sd=float(g["sd"]), epsilon=float(g["epsilon"]), t0=int(g["t0"]),
+                                          period=int(g["period"]), adaptive=bool(g["adaptive"]), gamma=float(g["gamma"]))
+        with _Replay(g["z"][c], g["u"][c]):
+            ch = tda.Chain(post, prop, g["theta0"][c].copy())
+            ch.sample(g["z"].shape[1], progressbar=False)
+        assert np.array_equal(np.array(ch.accepted, dtype=np.uint8), g["accepted"][c])
+        np.testing.assert_allclose([l.posterior for l in ch.chain], g["logpost"][c], rtol=1e-10)
+
+
+def test_config1_basic_sampler_host_path():
+    """BASELINE config 1: opaque Python model, 2 chains x 2000 iterations, result layout of sampler.py:305-309."""
+    rs = np.random.RandomState(0)
+    x = np.linspace(0, 1, 50)
+    y = 1 + 2 * x + rs.normal(0, 0.2, 50)
+    model = lambda th: th[0] + th[1] * x  # noqa: E731  (opaque closure -> host protocol)
+    post = tda.Posterior(stats.multivariate_normal(np.zeros(2), np.eye(2)), tda.GaussianLogLike(y, 0.04 * np.eye(50)), model)
+    np.random.seed(3)
+    res = tda.sample(post, tda.GaussianRandomWalk(np.eye(2), scaling=0.1, adaptive=True), 2000, n_chains=2,
+                     force_sequential=True)
+    assert res["sampler"] == "MH" and res["n_chains"] == 2 and res["iterations"] == 2001 and res["backend"] == "host"
+    assert len(res["chain_0"]) == 2001 and isinstance(res["chain_1"][5], tda.Link)
+    s = tda.get_samples(res, burnin=500)
+    assert s["iterations"] == 1501 and s["dimension"] == 2 and s["chain_1"].shape == (1501, 2)
+    st = tda.get_samples(res, "stats")
+    np.testing.assert_allclose(st["chain_0"][:, 2], st["chain_0"][:, 0] + st["chain_0"][:, 1])
+    mo = tda.get_samples(res, "model_output")
+    assert mo["dimension"] == 50
+    pooled = np.concatenate([s["chain_0"], s["chain_1"]])
+    # conjugate posterior mean of the linear-Gaussian problem
+    Ad = np.stack([np.ones_like(x), x], axis=1)
+    cov = np.linalg.inv(Ad.T @ Ad / 0.04 + np.eye(2))
+    mean = cov @ (Ad.T @ y / 0.04)
+    assert np.all(np.abs(pooled.mean(axis=0) - mean) < 5 * np.sqrt(np.diag(cov)) / np.sqrt(30)), (pooled.mean(axis=0), mean)
+
+
+def test_lowering_pass():
+    from tinyda_amd.sampler import _device_plan
+
+    A = np.random.default_rng(0).standard_normal((10, 4))
+    prior = stats.multivariate_normal(np.zeros(4), np.eye(4))
+    like = tda.GaussianLogLike(np.zeros(10), 0.1 * np.eye(10))
+    assert _device_plan([tda.Posterior(prior, like, tda.LinearModel(A))], tda.AdaptiveMetropolis(np.eye(4))) is not None
+    assert _device_plan([tda.Posterior(prior, like, lambda th: A @ th)], tda.AdaptiveMetropolis(np.eye(4))) is None
+    assert _device_plan([tda.Posterior(stats.norm(), like, tda.LinearModel(A))], tda.GaussianRandomWalk(np.eye(4))) is None
+
+    class Custom(tda.GaussianRandomWalk):
+        pass
+
+    assert _device_plan([tda.Posterior(prior, like, tda.LinearModel(A))], Custom(np.eye(4))) is None

@@ -1,8 +1,25 @@
-"""tinyda_amd: MI355X-native many-chain MH / DA / MLDA engine behind tinyDA's sampling API.
+"""tinyda_amd: MI355X-native many-chain MH engine behind tinyDA's sampling API.
 
-Drop-in for the hot path tda.sample() -> Chain.sample (tinyDA/sampler.py, chain.py); see DESIGN.md.
+Drop-in for the hot path tda.sample() -> Chain.sample -> Proposal / Posterior / GaussianLogLike
+(tinyDA/sampler.py, chain.py, proposal.py, posterior.py, distributions.py); see DESIGN.md for the scope.
 """
 __version__ = "0.1.0"
 
 from ._lib import EngineError  # noqa: F401
+from .chain import Chain  # noqa: F401
+from .diagnostics import ess_bulk, ess_summary, get_samples, rhat, to_inference_data  # noqa: F401
+from .distributions import (  # noqa: F401
+    AdaptiveGaussianLogLike,
+    DefaultGaussianLogLike,
+    DiagonalGaussianLogLike,
+    GaussianLogLike,
+    IsotropicGaussianLogLike,
+)
 from .engine import Engine  # noqa: F401
+from .link import Link  # noqa: F401
+from .models import LinearModel  # noqa: F401
+from .posterior import Posterior  # noqa: F401
+from .proposal import AdaptiveMetropolis, CrankNicolson, GaussianRandomWalk, Proposal  # noqa: F401
+from .results import DeviceChain  # noqa: F401
+from .sampler import sample  # noqa: F401
+from .utils import RecursiveSampleMoments, ZeroMeanRecursiveSampleMoments  # noqa: F401

@@ -1,0 +1,73 @@
+"""Multi-GPU plumbing: one process per GPU, chains sharded by global id, no data-path collective.
+
+tinyDA's only parallelism is one Ray actor per chain (tinyDA/ray.py:12-91); chains never interact for
+GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis (sampler.py:176 deep-copies the proposal per chain),
+so MH shards trivially: rank r owns global chains [offset_r, offset_r + n_r) and the RNG is keyed by the
+global id.  torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" on CPU) is used only for the barrier /
+max-over-ranks timing and for gathering summary statistics.
+"""
+import os
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def shard_chains(n_total, rank, world):
+    """Contiguous block partition: returns (offset, count) with counts differing by at most one."""
+    base, extra = divmod(int(n_total), int(world))
+    count = base + (1 if rank < extra else 0)
+    offset = rank * base + min(rank, extra)
+    return offset, count
+
+
+def init_process_group(backend=None):
+    import torch
+    import torch.distributed as dist
+
+    rank, local_rank, world = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def barrier():
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def reduce_scalar(value, op="max", device=None):
+    """max / sum of a Python float over ranks (identity when not distributed)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def gather_moments(count, mean, m2):
+    """Pool per-rank sample moments (n, mean [d], centred second moment [d,d]) with one all_reduce each
+    (Chan et al. parallel update expressed through sums); used for pooled summaries across GPUs."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return count, mean, m2
+    dev = mean.device
+    n = torch.tensor([float(count)], dtype=torch.float64, device=dev)
+    s1 = mean * count
+    s2 = m2 + count * torch.outer(mean, mean)
+    for t in (n, s1, s2):
+        dist.all_reduce(t)
+    tot = float(n.item())
+    mu = s1 / tot
+    return tot, mu, s2 - tot * torch.outer(mu, mu)

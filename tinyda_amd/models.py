@@ -1,0 +1,22 @@
+"""Forward models the device engine can run fused (declared, not opaque Python).
+
+tinyDA's model protocol is "callable theta -> ndarray or (ndarray, qoi)" (posterior.py:95-101).
+These classes honour it on the host and additionally expose what the HIP kernels need.
+"""
+import numpy as np
+
+
+class LinearModel:
+    """F(theta) = A theta (+ b).  All BASELINE.json configurations use linear forward models."""
+
+    def __init__(self, A, b=None):
+        self.A = np.ascontiguousarray(np.asarray(A, dtype=np.float64))
+        if self.A.ndim != 2:
+            raise ValueError("A must be a 2-D array (observations x parameters)")
+        self.b = None if b is None else np.ascontiguousarray(np.asarray(b, dtype=np.float64))
+        if self.b is not None and self.b.shape != (self.A.shape[0],):
+            raise ValueError("b must have one entry per observation")
+
+    def __call__(self, parameters):
+        out = self.A @ np.asarray(parameters, dtype=np.float64)
+        return out if self.b is None else out + self.b

@@ -1,0 +1,153 @@
+"""Transition kernels with the reference's constructor signatures and proposal protocol
+(tinyDA/proposal.py:17-41): setup_proposal / adapt / make_proposal / get_acceptance / get_q.
+
+On the device path `sample()` never calls these methods per step: `_lowering()` hands the constructor
+arguments to the HIP engine, which runs propose -> evaluate -> accept -> adapt fused.  The methods exist so
+that the same objects also drive the host loop for opaque Python models (BASELINE config 1), and so user
+code written against tinyDA keeps working.
+"""
+import numpy as np
+import scipy.stats as stats
+
+from . import _lib
+from .utils import RecursiveSampleMoments
+
+
+class Proposal:
+    is_symmetric = False
+
+    def setup_proposal(self, **kwargs):
+        pass
+
+    def adapt(self, **kwargs):
+        pass
+
+    def make_proposal(self, link):
+        pass
+
+    def get_acceptance(self, proposal_link, previous_link):
+        pass
+
+    def get_q(self, x_link, y_link):
+        pass
+
+
+def _require_square(C, name):
+    # same checks and messages as proposal.py:189-196 / :443-450
+    if not isinstance(C, np.ndarray):
+        raise TypeError("%s must be a numpy array" % name)
+    if C.ndim == 1:
+        if C.shape[0] != 1:
+            raise ValueError("%s must be an NxN array" % name)
+    elif C.shape[0] != C.shape[1]:
+        raise ValueError("%s must be an NxN array" % name)
+
+
+class GaussianRandomWalk(Proposal):
+    """theta' = theta + scaling * N(0, C), optional global scaling adaptation (proposal.py:132-258)."""
+
+    is_symmetric = True
+    alpha_star = 0.24
+
+    def __init__(self, C, scaling=1, adaptive=False, gamma=1.01, period=100):
+        _require_square(C, "C")
+        self.C = C
+        self.d = C.shape[0]
+        self._init_scaling(scaling, adaptive, gamma, period)
+
+    def _init_scaling(self, scaling, adaptive, gamma, period):
+        self.scaling = scaling
+        self.adaptive = adaptive
+        self.gamma = gamma
+        self.period = period
+        self.k = 0  # completed scaling adaptations (diminishing adaptation)
+        self.t = 0  # adapt() calls
+        self._factor_of = None
+
+    def _draw(self):
+        """N(0, C) as chol(C) z.  (The reference asks NumPy, which re-runs an SVD of C on every call;
+        the law is the same.)"""
+        if self._factor_of is not self.C:
+            self._L = np.linalg.cholesky(np.atleast_2d(self.C))
+            self._factor_of = self.C
+        return self._L @ np.random.standard_normal(self.d)
+
+    def adapt(self, **kwargs):
+        self.t += 1
+        if self.adaptive and self.t % self.period == 0:
+            rate = np.mean(kwargs["accepted"][-self.period:])
+            self.scaling = np.exp(np.log(self.scaling) + self.gamma ** -self.k * (rate - self.alpha_star))
+            self.k += 1
+
+    def make_proposal(self, link):
+        return link.parameters + self.scaling * self._draw()
+
+    def get_acceptance(self, proposal_link, previous_link):
+        if np.isnan(proposal_link.posterior):
+            return 0
+        return np.exp(proposal_link.posterior - previous_link.posterior)
+
+    def _lowering(self):
+        return dict(kind=_lib.PROP_GRW, C_=np.atleast_2d(self.C), scaling=float(self.scaling),
+                    adaptive=bool(self.adaptive), gamma=float(self.gamma), period=int(self.period))
+
+
+class CrankNicolson(GaussianRandomWalk):
+    """pCN: theta' = sqrt(1 - beta^2) theta + beta N(0, C_prior); acceptance on the likelihood ratio
+    (proposal.py:261-369).  The prior mean is ignored, as in the reference."""
+
+    is_symmetric = False
+
+    def __init__(self, scaling=0.1, adaptive=False, gamma=1.01, period=100):
+        self._init_scaling(scaling, adaptive, gamma, period)
+
+    def setup_proposal(self, **kwargs):
+        prior = kwargs["posterior"].prior
+        self.C = prior.cov if hasattr(prior, "cov") else prior.cov_object.covariance
+        self.d = self.C.shape[0]
+
+    def make_proposal(self, link):
+        return np.sqrt(1 - self.scaling ** 2) * link.parameters + self.scaling * self._draw()
+
+    def get_acceptance(self, proposal_link, previous_link):
+        if np.isnan(proposal_link.posterior):
+            return 0
+        return np.exp(proposal_link.likelihood - previous_link.likelihood)
+
+    def get_q(self, x_link, y_link):
+        return stats.multivariate_normal.logpdf(
+            y_link.parameters, mean=np.sqrt(1 - self.scaling ** 2) * x_link.parameters, cov=self.scaling ** 2 * self.C
+        )
+
+    def _lowering(self):
+        return dict(kind=_lib.PROP_PCN, C_=None, scaling=float(self.scaling), adaptive=bool(self.adaptive),
+                    gamma=float(self.gamma), period=int(self.period))
+
+
+class AdaptiveMetropolis(GaussianRandomWalk):
+    """Haario et al. (2001): proposal covariance <- running sample covariance every `period` adapt calls
+    once t >= t0 (proposal.py:372-512)."""
+
+    def __init__(self, C0, sd=None, epsilon=1e-6, t0=0, period=100, adaptive=False, gamma=1.01):
+        _require_square(C0, "C0")
+        self.C = C0
+        self.d = C0.shape[0]
+        self._init_scaling(1, adaptive, gamma, period)
+        self.sd = sd if sd is not None else min(1, 2.4 ** 2 / self.d)
+        self.epsilon = epsilon
+        self.t0 = t0
+
+    def setup_proposal(self, **kwargs):
+        self.AM_recursor = RecursiveSampleMoments(
+            kwargs["parameters"], np.zeros((self.d, self.d)), sd=self.sd, epsilon=self.epsilon
+        )
+
+    def adapt(self, **kwargs):
+        super().adapt(**kwargs)
+        self.AM_recursor.update(kwargs["parameters"])
+        if self.t >= self.t0 and self.t % self.period == 0:
+            self.C = self.AM_recursor.get_sigma()
+
+    def _lowering(self):
+        return dict(kind=_lib.PROP_AM, C_=np.atleast_2d(self.C), adaptive=bool(self.adaptive), gamma=float(self.gamma),
+                    period=int(self.period), sd=float(self.sd), epsilon=float(self.epsilon), t0=int(self.t0))

@@ -1,0 +1,118 @@
+"""tinyda_amd.sample(): same call signature and result dict as tinyDA.sample (tinyDA/sampler.py:21-292),
+with the per-chain Python loop replaced by the HIP engine for every configuration it can lower.
+
+Extra keyword-only arguments (not in the reference): seed, backend, device, chain_offset.
+"""
+import copy
+import warnings
+
+import numpy as np
+import scipy.stats as stats
+
+from . import _lib
+from .chain import Chain
+from .proposal import AdaptiveMetropolis, CrankNicolson, GaussianRandomWalk
+from .results import DeviceChain
+
+_DEVICE_PROPOSALS = (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis)
+
+
+def _device_plan(posteriors, proposal):
+    """Lowering pass: returns (level description, proposal description) or None."""
+    if len(posteriors) != 1 or type(proposal) not in _DEVICE_PROPOSALS:
+        return None
+    low = getattr(posteriors[0], "_lowering", lambda: None)()
+    if low is None or low["prior_mean"].shape[0] > 64:
+        return None
+    if low["noise_kind"] == _lib.NOISE_DENSE:
+        return None  # dense data covariance is evaluated on the host protocol for now
+    return low, proposal._lowering()
+
+
+def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None, subchain_length=1,
+           randomize_subchain_length=False, adaptive_error_model=None, store_coarse_chain=True,
+           force_sequential=False, force_progress_bar=False, subsampling_rate=None, *, seed=None,
+           backend="auto", device=0, chain_offset=0):
+    if subsampling_rate is not None:  # deprecated alias, sampler.py:113-115
+        warnings.warn(" subsampling_rate has been deprecated in favour of subchain_length.")
+        subchain_length = subsampling_rate
+    if not isinstance(posteriors, list):
+        posteriors = [posteriors]
+    if backend not in ("auto", "hip", "host"):
+        raise ValueError("backend must be 'auto', 'hip' or 'host'")
+
+    # pCN needs a Gaussian prior (sampler.py:138-143)
+    if isinstance(proposal, CrankNicolson) and not isinstance(
+        posteriors[0].prior, stats._multivariate.multivariate_normal_frozen
+    ):
+        raise TypeError("Prior must be of type scipy.stats.multivariate_normal for pCN proposal")
+
+    if len(posteriors) > 1:
+        raise NotImplementedError(
+            "Delayed Acceptance / MLDA (len(posteriors) > 1) is not built yet in tinyda_amd; see DESIGN.md scope table"
+        )
+
+    # initial parameters (sampler.py:196-209)
+    if initial_parameters is not None:
+        if type(initial_parameters) == list:
+            assert len(initial_parameters) == n_chains, \
+                "If list of initial parameters is provided, it must have length n_chains"
+        elif type(initial_parameters) == np.ndarray:
+            assert posteriors[0].prior.rvs().size == initial_parameters.size, \
+                "If an array of initial parameters is provided, it must have the same dimension as the prior"
+            initial_parameters = [initial_parameters] * n_chains
+        else:
+            raise TypeError("Initial paramaters must be list, numpy array or None")
+
+    plan = None if backend == "host" else _device_plan(posteriors, proposal)
+    if backend == "hip" and plan is None:
+        raise _lib.EngineError("this posterior / proposal combination cannot be lowered to the HIP engine")
+    if plan is not None:
+        return _sample_device(plan, posteriors[0], iterations, n_chains, initial_parameters, seed, device,
+                              chain_offset)
+    return _sample_host(posteriors[0], proposal, iterations, n_chains, initial_parameters)
+
+
+def _sample_host(posterior, proposal, iterations, n_chains, initial_parameters):
+    """Opaque-model path: one Python chain after the other (sampler.py:295-309)."""
+    proposals = [copy.deepcopy(proposal) for _ in range(n_chains)]
+    if initial_parameters is None:
+        initial_parameters = [posterior.prior.rvs() for _ in range(n_chains)]
+    result = {"sampler": "MH", "n_chains": n_chains, "iterations": iterations + 1, "backend": "host"}
+    for i in range(n_chains):
+        print("Sampling chain {}/{}".format(i + 1, n_chains))
+        chain = Chain(posterior, proposals[i], initial_parameters[i])
+        chain.sample(iterations)
+        result["chain_{}".format(i)] = chain.chain
+    return result
+
+
+def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, seed, device, chain_offset):
+    from .engine import Engine  # raises EngineError when libtinyda_hip.so is missing: no CPU fallback
+
+    low, prop = plan
+    d = low["prior_mean"].shape[0]
+    if seed is None:
+        seed = int(np.random.randint(0, 2 ** 31 - 1))
+    eng = Engine(n_chains, d, seed=seed, device=device, chain_offset=chain_offset)
+    try:
+        eng.set_prior(low["prior_mean"], low["prior_cov"])
+        eng.set_level(0, low["A"], low["data"], low["noise_kind"], low["noise"], b=low["b"])
+        eng.set_proposal(**prop)
+        theta0 = None if initial_parameters is None else np.stack([np.asarray(p, float) for p in initial_parameters])
+        eng.init(theta0)
+        T, N = iterations, n_chains
+        params = np.empty((T + 1, N, d))
+        stat = np.empty((T + 1, N, 3))
+        acc = np.ones((T + 1, N), dtype=np.uint8)
+        params[0], stat[0] = eng.current()
+        if T > 0:
+            eng.run(T, params[1:], stat[1:], acc[1:])
+        state = eng.proposal_state(want_am=prop["kind"] == _lib.PROP_AM)
+    finally:
+        eng.close()
+    result = {"sampler": "MH", "n_chains": n_chains, "iterations": iterations + 1, "backend": "hip",
+              "seed": seed, "proposal_state": state}
+    for i in range(n_chains):
+        result["chain_{}".format(i)] = DeviceChain(params[:, i], stat[:, i], acc[:, i], posterior.model)
+    return result
