@@ -201,6 +201,10 @@ template <int DPAD>
 void launch_adapt(const AdaptArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_adapt<DPAD>, dim3((unsigned)a.N), dim3(64), 0, st, a);
 }
+template <int DPAD>
+void launch_chol(const CholArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_chol<DPAD>, dim3((unsigned)a.N), dim3(64), 0, st, a);
+}
 
 #define DISPATCH_DPAD(dp, CALL)                  \
   switch (dp) {                                  \
@@ -509,9 +513,10 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
     }
     // RecursiveSampleMoments(mu0 = theta0, sigma0 = 0) (proposal.py:495-500)
     if ((rc = e->am_mu.alloc((size_t)NP * DP))) return rc;
-    if ((rc = e->am_sigma.alloc((size_t)NP * DP * DP))) return rc;
+    const size_t nsig = (size_t)NP * (DP / 2 + 1) * DP;  // circulant-folded symmetric storage
+    if ((rc = e->am_sigma.alloc(nsig))) return rc;
     HIP_TRY(hipMemcpyAsync(e->am_mu.p, e->theta.p, (size_t)NP * DP * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-    HIP_TRY(hipMemsetAsync(e->am_sigma.p, 0, (size_t)NP * DP * DP * sizeof(double), e->stream));
+    HIP_TRY(hipMemsetAsync(e->am_sigma.p, 0, nsig * sizeof(double), e->stream));
   } else {
     e->L_shared = true;
     if ((rc = e->Lk.upload(Lk))) return rc;
@@ -698,7 +703,8 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
       aa.do_am = is_am;
       aa.boundary = boundary;
       aa.do_scale = adaptive;
-      aa.do_swap = is_am && boundary && (e->t + S >= e->pp.t0);
+      const bool do_swap = is_am && boundary && (e->t + S >= e->pp.t0);
+      aa.do_swap = do_swap;
       aa.period = period;
       aa.gamma_pow = std::pow(e->pp.gamma, -(double)e->k_adapt);
       aa.sd = e->am_sd;
@@ -706,12 +712,20 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
       aa.rec_params = sa.rec_params;
       aa.am_mu = e->am_mu.p;
       aa.am_sigma = e->am_sigma.p;
-      aa.Lk = e->Lk.p;
       aa.scaling = e->scaling.p;
       aa.acc_count = e->acc_count.p;
       aa.flags = e->flags.p;
       ScopedTimer tm(e, 2);
       DISPATCH_DPAD(e->DP, launch_adapt<DPAD>(aa, e->stream));
+      if (do_swap) {  // C <- Sigma (proposal.py:509-510)
+        CholArgs ca{};
+        ca.N = N;
+        ca.d = d;
+        ca.am_sigma = e->am_sigma.p;
+        ca.Lk = e->Lk.p;
+        ca.flags = e->flags.p;
+        DISPATCH_DPAD(e->DP, launch_chol<DPAD>(ca, e->stream));
+      }
     } else if (boundary) {
       HIP_TRY(hipMemsetAsync(e->acc_count.p, 0, NP * sizeof(int32_t), e->stream));
     }
@@ -789,12 +803,17 @@ int tda_engine_get_proposal_state(tda_engine* e, double* scaling, double* C, dou
       for (int64_t c = 0; c < N; ++c)
         for (int j = 0; j < d; ++j) am_mu[(size_t)c * d + j] = h[(size_t)c * DP + j];
     }
-    if (am_sigma) {
-      std::vector<double> h((size_t)DP * DP);
+    if (am_sigma) {  // unfold [s][l] = Sigma[l][(l+s) mod DP]
+      const int NS = DP / 2 + 1;
+      std::vector<double> h((size_t)N * NS * DP);
+      HIP_TRY(hipMemcpy(h.data(), e->am_sigma.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
       for (int64_t c = 0; c < N; ++c) {
-        HIP_TRY(hipMemcpy(h.data(), e->am_sigma.p + (size_t)c * DP * DP, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+        const double* f = h.data() + (size_t)c * NS * DP;
         for (int i = 0; i < d; ++i)
-          for (int j = 0; j < d; ++j) am_sigma[((size_t)c * d + i) * d + j] = h[(size_t)i * DP + j];
+          for (int j = 0; j < d; ++j) {
+            const int sl = ((j - i) % DP + DP) % DP;
+            am_sigma[((size_t)c * d + i) * d + j] = sl <= DP / 2 ? f[(size_t)sl * DP + i] : f[(size_t)(DP - sl) * DP + j];
+          }
       }
     }
   }

@@ -11,8 +11,9 @@
 //                                the 4 waves, A fragments streamed from L2, residual + weighted SSE fused
 //                                in the MFMA epilogue, prior, log alpha, accept, coalesced record write
 //   k_adapt     wave per chain : RecursiveSampleMoments catch-up over the S recorded states in the
-//                                reference's exact elementwise arithmetic (utils.py:113-122), global
-//                                scaling adaptation, C <- Sigma swap + in-LDS Cholesky at period boundaries
+//                                reference's exact elementwise arithmetic (utils.py:113-122), symmetric half
+//                                only (circulant fold), global scaling adaptation at period boundaries
+//   k_chol      wave per chain : C <- Sigma swap, Cholesky in LDS (only at period boundaries with t >= t0)
 //
 // Chains never interact, so there is no inter-workgroup communication anywhere.
 #pragma once
@@ -104,8 +105,7 @@ struct AdaptArgs {
   double sd, eps;
   const double* rec_params;  // [S][N][d] states recorded by k_mh_steps
   double* am_mu;             // [NP][DPAD]
-  double* am_sigma;          // [NP][DPAD][DPAD]
-  double* Lk;                // [NP][DPAD][DPAD]
+  double* am_sigma;          // [NP][DPAD/2+1][DPAD] circulant fold: [s][l] = Sigma[l][(l+s) mod DPAD]
   double* scaling;           // [NP]
   int32_t* acc_count;        // [NP]
   int32_t* flags;            // [NP]
@@ -115,67 +115,80 @@ __device__ __forceinline__ double4_t mfma_f64(double a, double b, double4_t c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-// Sum over this wave's observation blocks of w_o (A theta' - ytil)_o^2 for the 16 chains of the tile.
-// Lane l holds chain (l & 15) and rows (l >> 4) + 4 r of every 16-row block (f64 MFMA C/D layout).
-// Two independent accumulators are interleaved and the next pair of fragments is prefetched from L2
-// while the current pair is in the matrix pipe.
+// MFMA A-operand fragments of one 16-row block: K2 16-byte loads per lane, unconditional (the block index is
+// clamped, out-of-range blocks are simply not accumulated) so that hipcc emits plain global_load_dwordx4
+// and counted vmcnt waits instead of one branch per load.
 template <int DPAD>
+__device__ __forceinline__ void frag_load(const double2* __restrict__ base, int cb, int ncb,
+                                          double2 (&f)[DPAD / 8]) {
+  const int cbc = cb < ncb ? cb : ncb - 1;
+  const double2* __restrict__ p = base + (size_t)cbc * (DPAD / 8) * 64;
+#pragma unroll
+  for (int k = 0; k < DPAD / 8; ++k) f[k] = p[k * 64];
+}
+
+// One pair of 16-row blocks: 2 x KS MFMAs on two accumulators, then the fused epilogue
+// sum_r w_o (F_o - ytil_o)^2 over the rows this lane holds ((l >> 4) + 4 r, C/D layout of the f64 MFMA).
+template <int DPAD, bool HAS_W>
+__device__ __forceinline__ double pair_sse(const double2 (&f0)[DPAD / 8], const double2 (&f1)[DPAD / 8],
+                                           const double (&th)[DPAD / 4], const double* __restrict__ s_y,
+                                           const double* __restrict__ s_w, int cb0, int cb1, bool v1, int hi) {
+  double4_t a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < DPAD / 8; ++k) {
+    a0 = mfma_f64(f0[k].x, th[2 * k], a0);
+    a1 = mfma_f64(f1[k].x, th[2 * k], a1);
+    a0 = mfma_f64(f0[k].y, th[2 * k + 1], a0);
+    a1 = mfma_f64(f1[k].y, th[2 * k + 1], a1);
+  }
+  double sse = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = cb0 * 16 + hi + 4 * r;
+    const double res = a0[r] - s_y[o];
+    double sq = res * res;
+    if (HAS_W) sq *= s_w[o];
+    sse += sq;
+  }
+  const int ob1 = v1 ? cb1 : cb0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = ob1 * 16 + hi + 4 * r;
+    const double res = a1[r] - s_y[o];
+    double sq = res * res;
+    if (HAS_W) sq *= s_w[o];
+    sse += v1 ? sq : 0.0;
+  }
+  return sse;
+}
+
+// Sum over this wave's observation blocks (wave, wave+4, wave+8, ...) of w_o (A theta' - ytil)_o^2 for the
+// 16 chains of the tile.  Software pipeline with two explicit register sets: while pair P is in the matrix
+// pipe (2 x KS x 64 cycles), the fragments of pair P+1 are in flight from L2.  The sched_barriers keep hipcc
+// from sinking the loads below the MFMAs that precede them in program order.
+// fa0 / fa1 must hold blocks `wave` and `wave + 4` on entry (issued by the caller ahead of its barrier).
+template <int DPAD, bool HAS_W>
 __device__ __forceinline__ double level_sse_partial(const double* __restrict__ Apk, int ncb,
                                                     const double* __restrict__ s_y,
                                                     const double* __restrict__ s_w,
-                                                    const double (&th)[DPAD / 4], int wave, int lane) {
-  constexpr int KS = DPAD / 4, K2 = KS / 2;
+                                                    const double (&th)[DPAD / 4], int wave, int lane,
+                                                    double2 (&fa0)[DPAD / 8], double2 (&fa1)[DPAD / 8]) {
+  constexpr int K2 = DPAD / 8;
   const int hi = lane >> 4;
   const double2* __restrict__ base = reinterpret_cast<const double2*>(Apk) + lane;
   double sse = 0.0;
-  double2 f0[K2], f1[K2], g0[K2], g1[K2];
-  int cb0 = wave, cb1 = wave + 4;
-  const double2 zero2 = make_double2(0.0, 0.0);
-#pragma unroll
-  for (int k = 0; k < K2; ++k) {
-    f0[k] = cb0 < ncb ? base[((size_t)cb0 * K2 + k) * 64] : zero2;
-    f1[k] = cb1 < ncb ? base[((size_t)cb1 * K2 + k) * 64] : zero2;
-  }
-  while (cb0 < ncb) {
-    const int nb0 = cb0 + 8, nb1 = cb1 + 8;
-#pragma unroll
-    for (int k = 0; k < K2; ++k) {
-      g0[k] = nb0 < ncb ? base[((size_t)nb0 * K2 + k) * 64] : zero2;
-      g1[k] = nb1 < ncb ? base[((size_t)nb1 * K2 + k) * 64] : zero2;
-    }
-    double4_t a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int k = 0; k < K2; ++k) {
-      a0 = mfma_f64(f0[k].x, th[2 * k], a0);
-      a1 = mfma_f64(f1[k].x, th[2 * k], a1);
-      a0 = mfma_f64(f0[k].y, th[2 * k + 1], a0);
-      a1 = mfma_f64(f1[k].y, th[2 * k + 1], a1);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int o = cb0 * 16 + hi + 4 * r;
-      const double res = a0[r] - s_y[o];
-      double sq = res * res;
-      if (s_w) sq *= s_w[o];
-      sse += sq;
-    }
-    if (cb1 < ncb) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int o = cb1 * 16 + hi + 4 * r;
-        const double res = a1[r] - s_y[o];
-        double sq = res * res;
-        if (s_w) sq *= s_w[o];
-        sse += sq;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < K2; ++k) {
-      f0[k] = g0[k];
-      f1[k] = g1[k];
-    }
-    cb0 = nb0;
-    cb1 = nb1;
+  double2 fb0[K2], fb1[K2];
+  for (int cb = wave; cb < ncb; cb += 16) {
+    frag_load<DPAD>(base, cb + 8, ncb, fb0);
+    frag_load<DPAD>(base, cb + 12, ncb, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    sse += pair_sse<DPAD, HAS_W>(fa0, fa1, th, s_y, s_w, cb, cb + 4, cb + 4 < ncb, hi);
+    __builtin_amdgcn_sched_barrier(0);
+    frag_load<DPAD>(base, cb + 16, ncb, fa0);
+    frag_load<DPAD>(base, cb + 20, ncb, fa1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (cb + 8 < ncb) sse += pair_sse<DPAD, HAS_W>(fb0, fb1, th, s_y, s_w, cb + 8, cb + 12, cb + 12 < ncb, hi);
+    __builtin_amdgcn_sched_barrier(0);
   }
   return sse;
 }
@@ -230,19 +243,35 @@ __global__ void __launch_bounds__(256, 1) k_mh_steps(const StepArgs a) {
     pinv[kk] = prior_dense ? 0.0 : a.pr.pinv[4 * kk + hi];
   }
 
-  double cur[EPT], prp[EPT];
+  double cur[EPT], prp[EPT], xin[EPT];
 #pragma unroll
-  for (int e = 0; e < EPT; ++e) cur[e] = active ? a.theta[gct * DPAD + q * EPT + e] : 0.0;
+  for (int e = 0; e < EPT; ++e) {
+    cur[e] = active ? a.theta[gct * DPAD + q * EPT + e] : 0.0;
+    xin[e] = 0.0;
+  }
   double lp = a.lp[gcl], ll = a.ll[gcl];
   const double scal_t = a.scaling[gct];
   const double keep_t = a.prop_kind == 1 ? sqrt(1.0 - scal_t * scal_t) : 1.0;  // proposal.py:351-352
   int nacc = 0;
   const bool is_eval = a.mode == MODE_EVAL;
   const bool is_pcn = a.prop_kind == 1;
-  const double* s_w_or_null = diag ? s_w : nullptr;
+  const double2* fbase = reinterpret_cast<const double2*>(a.lv.Apk) + lane;
+  const double2* pbase = reinterpret_cast<const double2*>(a.pr.Wpk) + lane;
+  double2 f0[KS / 2], f1[KS / 2];
+  double unext = 0.5;
+  if (!is_eval) {
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) xin[e] = a.inc[(size_t)gct * DPAD + q * EPT + e];
+    }
+    unext = a.u[gcl];
+  }
   __syncthreads();
 
   for (int s = 0; s < a.S; ++s) {
+    // first two fragment blocks of this step: independent of theta', issued ahead of the barrier
+    frag_load<DPAD>(fbase, wave, a.lv.ncb, f0);
+    frag_load<DPAD>(fbase, wave + 4, a.lv.ncb, f1);
     // ---- proposal: theta' (proposal.py:249-251 / :351-355) ----
     if (active) {
 #pragma unroll
@@ -250,12 +279,19 @@ __global__ void __launch_bounds__(256, 1) k_mh_steps(const StepArgs a) {
         if (is_eval) {
           prp[e] = cur[e];
         } else {
-          const double x = a.inc[((size_t)s * a.NP + gct) * DPAD + q * EPT + e];
-          const double sx = scal_t * x;
+          const double sx = scal_t * xin[e];
           prp[e] = is_pcn ? keep_t * cur[e] + sx : cur[e] + sx;
         }
         s_prop[c * LDP + q * EPT + e] = prp[e];
       }
+    }
+    const double u = unext;
+    if (!is_eval && s + 1 < a.S) {  // next step's increment and uniform fly during the MFMA phase
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) xin[e] = a.inc[((size_t)(s + 1) * a.NP + gct) * DPAD + q * EPT + e];
+      }
+      unext = a.u[(size_t)(s + 1) * a.NP + gcl];
     }
     __syncthreads();
 
@@ -277,14 +313,18 @@ __global__ void __launch_bounds__(256, 1) k_mh_steps(const StepArgs a) {
       p += __shfl_xor(p, 32);
       maha = p;
     } else {
-      double p = level_sse_partial<DPAD>(a.pr.Wpk, a.pr.ncb, s_py, nullptr, th, wave, lane);
+      double2 p0[KS / 2], p1[KS / 2];
+      frag_load<DPAD>(pbase, wave, a.pr.ncb, p0);
+      frag_load<DPAD>(pbase, wave + 4, a.pr.ncb, p1);
+      double p = level_sse_partial<DPAD, false>(a.pr.Wpk, a.pr.ncb, s_py, nullptr, th, wave, lane, p0, p1);
       p += __shfl_xor(p, 16);
       p += __shfl_xor(p, 32);
       if (lane < 16) s_redp[wave * 16 + lane] = p;
     }
 
     // ---- forward model + Gaussian log-likelihood (posterior.py:95-108, distributions.py:310-326) ----
-    double sse = level_sse_partial<DPAD>(a.lv.Apk, a.lv.ncb, s_y, s_w_or_null, th, wave, lane);
+    double sse = diag ? level_sse_partial<DPAD, true>(a.lv.Apk, a.lv.ncb, s_y, s_w, th, wave, lane, f0, f1)
+                      : level_sse_partial<DPAD, false>(a.lv.Apk, a.lv.ncb, s_y, nullptr, th, wave, lane, f0, f1);
     sse += __shfl_xor(sse, 16);
     sse += __shfl_xor(sse, 32);
     if (lane < 16) s_red[wave * 16 + lane] = sse;
@@ -303,7 +343,6 @@ __global__ void __launch_bounds__(256, 1) k_mh_steps(const StepArgs a) {
     } else {
       double alpha = is_pcn ? exp(ll_n - ll) : exp(post_n - (lp + ll));
       if (post_n != post_n) alpha = 0.0;
-      const double u = a.u[(size_t)s * a.NP + gcl];
       acc = u < alpha;
     }
     if (acc) {
@@ -417,97 +456,134 @@ __global__ void __launch_bounds__(64) k_propose(const ProposeArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Adaptation for a block: one wave per chain, lane j owns column j of Sigma in registers.
+// Adaptation for a block: one wave per chain.
 //   RecursiveSampleMoments.update (utils.py:113-124) for each recorded state, elementwise, unfused:
 //     mu' = (1/(t+1)) (t mu + x)
 //     Sigma' = (t-1)/t Sigma + sd/t ( t mu mu^T - (t+1) mu' mu'^T + x x^T + eps I )
-//   global scaling (proposal.py:234-243), C <- Sigma (proposal.py:509-510) + Cholesky in LDS.
+//   global scaling (proposal.py:234-243).
+// Sigma is symmetric and every product commutes bitwise, so only one of (i,j)/(j,i) is carried, in a
+// circulant fold: lane l, slot s holds Sigma[l][(l+s) mod D], s = 0..D/2.  The "row" operand is the lane's
+// own value and the "column" operand a rotation read from LDS with consecutive addresses (conflict free),
+// so a step costs (D/2+1) x (3 ds_read_b64 + 10 fp64 VALU ops) instead of D x (3 broadcasts + 10 ops).
 // This file is compiled with -ffp-contract=off so the products and sums round exactly like NumPy's.
 // ------------------------------------------------------------------------------------------------
 template <int DPAD>
 __global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
-  constexpr int LDM = DPAD + 1;
+  constexpr int NS = DPAD / 2 + 1;
   __shared__ double s_vec[3 * DPAD];
-  __shared__ double s_M[DPAD * LDM];
   const int lane = threadIdx.x;
   const int64_t c = blockIdx.x;
   if (c >= a.N) return;
   const bool lj = lane < a.d;
+  const bool lp = lane < DPAD;
 
-  double Sg[DPAD];
   if (a.do_am) {
-    double mu = lane < DPAD ? a.am_mu[c * DPAD + lane] : 0.0;
+    double Sg[NS];
+    double mu = lp ? a.am_mu[c * DPAD + lane] : 0.0;
 #pragma unroll
-    for (int i = 0; i < DPAD; ++i)
-      Sg[i] = lane < DPAD ? a.am_sigma[((size_t)c * DPAD + i) * DPAD + lane] : 0.0;
+    for (int sl = 0; sl < NS; ++sl) Sg[sl] = lp ? a.am_sigma[((size_t)c * NS + sl) * DPAD + lane] : 0.0;
+    double xn = lj ? a.rec_params[(size_t)c * a.d + lane] : 0.0;
     for (int s = 0; s < a.S; ++s) {
-      const double x = lj ? a.rec_params[((size_t)s * a.N + c) * a.d + lane] : 0.0;
+      const double x = xn;
+      if (s + 1 < a.S) xn = lj ? a.rec_params[((size_t)(s + 1) * a.N + c) * a.d + lane] : 0.0;
       const double t = (double)(a.t_base + s + 1);  // recursor.t before this update
       const double mup = (1.0 / (t + 1.0)) * (t * mu + x);
       const double ca = (t - 1.0) / t, cb = a.sd / t;
-      if (lane < DPAD) {
+      const double t1 = t + 1.0;
+      __syncthreads();  // previous step's rotation reads are done
+      if (lp) {
         s_vec[lane] = x;
         s_vec[DPAD + lane] = mu;
         s_vec[2 * DPAD + lane] = mup;
       }
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < DPAD; ++i) {
-        const double xi = s_vec[i], mi = s_vec[DPAD + i], mpi = s_vec[2 * DPAD + i];
-        double M = (t * (mi * mu) - (t + 1.0) * (mpi * mup)) + xi * x;
-        if (i == lane) M = M + a.eps;
-        Sg[i] = ca * Sg[i] + cb * M;
+      for (int sl = 0; sl < NS; ++sl) {
+        const int j = (lane + sl) & (DPAD - 1);
+        const double xj = s_vec[j], mj = s_vec[DPAD + j], mpj = s_vec[2 * DPAD + j];
+        double M = (t * (mu * mj) - t1 * (mup * mpj)) + x * xj;
+        if (sl == 0) M = lj ? M + a.eps : M;
+        Sg[sl] = ca * Sg[sl] + cb * M;
       }
       mu = mup;
-      __syncthreads();
     }
-    if (lane < DPAD) {
+    if (lp) {
       a.am_mu[c * DPAD + lane] = mu;
 #pragma unroll
-      for (int i = 0; i < DPAD; ++i) a.am_sigma[((size_t)c * DPAD + i) * DPAD + lane] = Sg[i];
+      for (int sl = 0; sl < NS; ++sl) a.am_sigma[((size_t)c * NS + sl) * DPAD + lane] = Sg[sl];
     }
   }
 
   if (!a.boundary) return;
-
   if (a.do_scale && lane == 0) {
     const double rate = (double)a.acc_count[c] / (double)a.period;  // np.mean(accepted[-period:])
     a.scaling[c] = exp(log(a.scaling[c]) + a.gamma_pow * (rate - 0.24));
   }
   if (lane == 0) a.acc_count[c] = 0;
+}
 
-  if (a.do_am && a.do_swap) {
-    // C <- Sigma; factor in LDS, left-looking, lane i = row i.
-#pragma unroll
-    for (int i = 0; i < DPAD; ++i)
-      if (lane < DPAD) s_M[i * LDM + lane] = Sg[i];
+// ------------------------------------------------------------------------------------------------
+// C <- Sigma (proposal.py:509-510) and its Cholesky factor, one wave per chain, matrix in LDS,
+// left-looking by columns with lane i = row i, sequential fma chain per element.
+// ------------------------------------------------------------------------------------------------
+struct CholArgs {
+  int64_t N;
+  int d;
+  const double* am_sigma;  // folded [NP][DPAD/2+1][DPAD]
+  double* Lk;              // [NP][DPAD][DPAD] k-major
+  int32_t* flags;
+};
+
+template <int DPAD>
+__global__ void __launch_bounds__(64) k_chol(const CholArgs a) {
+  constexpr int NS = DPAD / 2 + 1;
+  constexpr int LDM = DPAD + 1;
+  __shared__ double s_M[DPAD * LDM];
+  const int lane = threadIdx.x;
+  const int64_t c = blockIdx.x;
+  if (c >= a.N) return;
+  const bool lj = lane < a.d;
+  // unfold the lower triangle: row i = lane, columns j <= i
+  if (lj) {
+    for (int j = 0; j <= lane; ++j) {
+      const int sl = lane - j;  // (i - j)
+      double v;
+      if (sl <= DPAD / 2)
+        v = a.am_sigma[((size_t)c * NS + sl) * DPAD + j];  // lane j, slot sl -> Sigma[j][j+sl] = Sigma[j][i]
+      else
+        v = a.am_sigma[((size_t)c * NS + (DPAD - sl)) * DPAD + lane];  // lane i, slot D-sl -> Sigma[i][(i+D-sl)%D = j]
+      s_M[lane * LDM + j] = v;
+    }
+  }
+  __syncthreads();
+  bool ok = true;
+  for (int k = 0; k < a.d; ++k) {
+    double sacc = 0.0;
+    if (lane >= k && lj) {
+      sacc = s_M[lane * LDM + k];
+      // the LDS reads do not depend on the running sum: unrolling keeps 16 of them in flight
+#pragma unroll 8
+      for (int p = 0; p < k; ++p) sacc = fma(-s_M[lane * LDM + p], s_M[k * LDM + p], sacc);
+    }
+    const double dkk = __shfl(sacc, k);
+    if (!(dkk > 0.0)) {
+      ok = false;
+      break;
+    }
+    const double lkk = sqrt(dkk);
+    if (lane >= k && lj) s_M[lane * LDM + k] = (lane == k) ? lkk : sacc / lkk;
     __syncthreads();
-    bool ok = true;
-    for (int k = 0; k < a.d; ++k) {
-      double sacc = 0.0;
-      if (lane >= k && lj) {
-        sacc = s_M[lane * LDM + k];
-        for (int p = 0; p < k; ++p) sacc = fma(-s_M[lane * LDM + p], s_M[k * LDM + p], sacc);
+  }
+  if (ok) {
+    if (lane < DPAD) {
+#pragma unroll 8
+      for (int k = 0; k < DPAD; ++k) {
+        const double v = (lj && k < a.d && lane >= k) ? s_M[lane * LDM + k] : 0.0;
+        a.Lk[((size_t)c * DPAD + k) * DPAD + lane] = v;
       }
-      const double dkk = __shfl(sacc, k);
-      if (!(dkk > 0.0)) {
-        ok = false;
-        break;
-      }
-      const double lkk = sqrt(dkk);
-      if (lane >= k && lj) s_M[lane * LDM + k] = (lane == k) ? lkk : sacc / lkk;
-      __syncthreads();
     }
-    if (ok) {
-      if (lane < DPAD) {
-        for (int k = 0; k < DPAD; ++k) {
-          const double v = (lj && k < a.d && lane >= k) ? s_M[lane * LDM + k] : 0.0;
-          a.Lk[((size_t)c * DPAD + k) * DPAD + lane] = v;
-        }
-      }
-    } else if (lane == 0) {
-      atomicOr(&a.flags[c], 1);
-    }
+  } else if (lane == 0) {
+    atomicOr(&a.flags[c], 1);
   }
 }
 

@@ -1,7 +1,7 @@
 """Ad-hoc timing of BASELINE config 2a on one GPU with per-kernel HIP-event breakdown (not the bench contract)."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tinyda_amd.engine import Engine
 
