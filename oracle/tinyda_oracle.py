@@ -325,3 +325,161 @@ def run_mh(level, proposal, theta0, z, u):
     if kind == "am":
         res.update(am_mu=am_mu, am_sigma=am_sigma)
     return res
+
+
+# ----------------------------------------------------------------------------------------
+# Delayed Acceptance (chain.py:185-530) and MLDA (chain.py:534-769, proposal.py:1285-1624)
+# ----------------------------------------------------------------------------------------
+class _BaseProposalState:
+    """The coarsest-level proposal of a batch of chains: GRW / pCN / AM state + adapt(), with the
+    `accepted` list the reference hands to adapt() kept per chain (it contains the alignment entries that
+    DAChain / MLDA.align_chain append, chain.py:363,389,397 and proposal.py:1486, so the scaling window
+    of proposal.py:236 sees them)."""
+
+    def __init__(self, proposal, theta0, prior_cov):
+        N, d = theta0.shape
+        self.kind = proposal["kind"]
+        self.adaptive = bool(proposal.get("adaptive", False))
+        self.gamma = float(proposal.get("gamma", 1.01))
+        self.period = int(proposal.get("period", 100))
+        if self.kind == "grw":
+            C = np.asarray(proposal["C"], dtype=float)
+            self.scaling = np.full(N, float(proposal.get("scaling", 1.0)))
+        elif self.kind == "pcn":
+            C = np.asarray(prior_cov, dtype=float)
+            self.scaling = np.full(N, float(proposal.get("scaling", 0.1)))
+        else:
+            C = np.asarray(proposal["C0"], dtype=float)
+            self.scaling = np.ones(N)
+            sd = proposal.get("sd")
+            self.sd = min(1.0, 2.4 ** 2 / d) if sd is None else float(sd)
+            self.eps = float(proposal.get("epsilon", 1e-6))
+            self.t0 = int(proposal.get("t0", 0))
+            self.mu = theta0.copy()
+            self.sigma = np.zeros((N, d, d))
+        self.L = np.linalg.cholesky(np.broadcast_to(C, (N, d, d)).copy())
+        self.t = 0
+        self.k = 0
+        self.accepted = [np.ones(N, dtype=bool)]  # chain.py:256 / proposal.py:1380
+
+    def propose(self, theta, z):
+        inc = np.einsum("nij,nj->ni", self.L, z)
+        if self.kind == "pcn":
+            return np.sqrt(1 - self.scaling ** 2)[:, None] * theta + self.scaling[:, None] * inc
+        return theta + self.scaling[:, None] * inc
+
+    def adapt(self, theta):
+        self.t += 1
+        if self.adaptive and self.t % self.period == 0:
+            rate = np.mean(np.array(self.accepted[-self.period:]), axis=0)
+            self.scaling = np.exp(np.log(self.scaling) + self.gamma ** -self.k * (rate - 0.24))
+            self.k += 1
+        if self.kind == "am":
+            self.mu, self.sigma = moments_update(self.mu, self.sigma, self.t, theta, self.sd, self.eps)
+            if self.t >= self.t0 and self.t % self.period == 0:
+                self.L = np.linalg.cholesky(self.sigma)
+
+
+def run_multilevel(levels, proposal, subchain_lengths, theta0, z, u_levels, n_fine, ridx=None):
+    """DAChain.sample (2 levels) / MLDAChain.sample (>2) for N chains in lock-step on recorded variates.
+
+    levels: LinearGaussianLevel list, coarsest first.  subchain_lengths[k] = steps of level k per step of
+    level k+1 (sampler.py:260-264).  z [N, T0, d] base-level normals, u_levels[k] [N, n_k] uniforms of level
+    k (NaN where the reference drew none), ridx [N, n_fine] DA promoted index in [-L, -1] (chain.py:525-527)
+    or None for the fixed last state.
+    Invariant used: after a step of level q completes, every level j < q sits at theta_q
+    and S[j][q] holds level j's (log-prior, log-like) there; a rejection at level q restores those.
+    Returns per-level traces of *local* steps (what sampler.py:421-427 / :535-538 return), the finest level
+    with its initial link first.
+    """
+    theta0 = np.asarray(theta0, dtype=float)
+    N, d = theta0.shape
+    nl = len(levels)
+    sl = list(subchain_lengths)
+    prop = _BaseProposalState(proposal, theta0, levels[0].prior.cov)
+    th = [theta0.copy() for _ in range(nl)]
+    lp, ll = [None] * nl, [None] * nl
+    for k in range(nl):
+        lp[k], ll[k], _ = levels[k].evaluate(theta0)
+    S = {(j, q): (lp[j].copy(), ll[j].copy()) for q in range(nl) for j in range(q)}
+    rec = [dict(theta=[], logprior=[], loglike=[], accepted=[]) for _ in range(nl)]
+    rec[nl - 1]["theta"].append(th[nl - 1].copy())
+    rec[nl - 1]["logprior"].append(lp[nl - 1].copy())
+    rec[nl - 1]["loglike"].append(ll[nl - 1].copy())
+    rec[nl - 1]["accepted"].append(np.ones(N, dtype=bool))
+    cnt = [0] * nl  # local steps done per level
+    promoted = {}
+
+    def record(k, acc):
+        rec[k]["theta"].append(th[k].copy())
+        rec[k]["logprior"].append(lp[k].copy())
+        rec[k]["loglike"].append(ll[k].copy())
+        rec[k]["accepted"].append(acc.copy())
+
+    def step(k, snap_at=None):
+        """one local step of level k; returns its accept mask"""
+        if k == 0:
+            t = cnt[0]
+            cand = prop.propose(th[0], z[:, t])
+            lpn, lln, _ = levels[0].evaluate(cand)
+            alpha = _acceptance(prop.kind, lpn, lln, lp[0], ll[0])
+            acc = u_levels[0][:, t] < alpha
+            th[0] = np.where(acc[:, None], cand, th[0])
+            lp[0] = np.where(acc, lpn, lp[0])
+            ll[0] = np.where(acc, lln, ll[0])
+            prop.accepted.append(acc.copy())
+            prop.adapt(th[0])  # proposal.py:1607-1611 / chain.py:440-444
+            record(0, acc)
+            cnt[0] += 1
+            return acc
+        L = sl[k - 1]
+        it = cnt[k]
+        start_lp, start_ll = S[(k - 1, k)]  # level k-1 at the subchain start = at theta_k
+        any_acc = np.zeros(N, dtype=bool)
+        # DA only: which coarse state is promoted (chain.py:369-375); -1 = last
+        pick = None
+        if ridx is not None and nl == 2 and k == 1:
+            pick = ridx[:, it]
+            pick = np.where(np.isnan(pick), -1, pick).astype(int) + L  # 0-based step index whose result is promoted
+            y_th, y_lp, y_ll = th[0].copy(), lp[0].copy(), ll[0].copy()
+        for i in range(L):
+            a = step(k - 1)
+            any_acc |= a
+            if pick is not None:
+                sel = pick == i
+                y_th[sel], y_lp[sel], y_ll[sel] = th[0][sel], lp[0][sel], ll[0][sel]
+        if pick is None:
+            y_th, y_lp, y_ll = th[k - 1], lp[k - 1], ll[k - 1]
+        lpn, lln, _ = levels[k].evaluate(y_th)  # only meaningful where any_acc (skip-eval rule)
+        with np.errstate(over="ignore", invalid="ignore"):
+            alpha = np.exp((lpn + lln) - (lp[k] + ll[k]) + (start_lp + start_ll) - (y_lp + y_ll))  # chain.py:475-483
+        acc = any_acc & (u_levels[k][:, it] < alpha)
+        # accept: level k takes y; with a promoted intermediate state the coarse chain restarts from it
+        th[k] = np.where(acc[:, None], y_th, th[k])
+        lp[k] = np.where(acc, lpn, lp[k])
+        ll[k] = np.where(acc, lln, ll[k])
+        for j in range(k):
+            if j == k - 1:
+                tj, lj, ljl = y_th, y_lp, y_ll
+            else:
+                tj, lj, ljl = th[j], lp[j], ll[j]
+            th[j] = np.where(acc[:, None], tj, th[k])  # reject: everything below reverts to theta_k
+            lp[j] = np.where(acc, lj, S[(j, k)][0])
+            ll[j] = np.where(acc, ljl, S[(j, k)][1])
+        for j in range(k):
+            for q in range(j + 1, k + 1):
+                S[(j, q)] = (lp[j].copy(), ll[j].copy())
+        prop.accepted.append(acc.copy())  # alignment entry on the base list (chain.py:363,389,397; proposal.py:1486)
+        record(k, acc)
+        cnt[k] += 1
+        return acc
+
+    for _ in range(n_fine):
+        step(nl - 1)
+    out = []
+    for k in range(nl):
+        r = rec[k]
+        lpk, llk = np.array(r["logprior"]).T, np.array(r["loglike"]).T
+        out.append(dict(theta=np.swapaxes(np.array(r["theta"]), 0, 1), logprior=lpk, loglike=llk, logpost=lpk + llk,
+                        accepted=np.array(r["accepted"]).T.astype(np.uint8)))
+    return out, prop

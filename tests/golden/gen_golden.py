@@ -45,6 +45,7 @@ class Tap:
     def __init__(self, seed):
         self.rs = np.random.RandomState(seed)
         self.log = []  # list of (kind, value)
+        self.ulog = []  # (level, uniform) in consumption order
         self._saved = {}
 
     # -- the replacement functions -------------------------------------------------
@@ -60,6 +61,21 @@ class Tap:
         assert size is None
         u = self.rs.random_sample()
         self.log.append(("u", u))
+        # which sampler level asked?  (DAChain._sample_coarse -> 0, DAChain.sample -> 1,
+        # MLDA.make_base_proposal -> 0, MLDA.make_mlda_proposal -> its level, MLDAChain.sample -> finest)
+        fr = sys._getframe(1)
+        name, owner = fr.f_code.co_name, fr.f_locals.get("self")
+        if name in ("_sample_coarse", "make_base_proposal"):
+            lvl = 0
+        elif name == "make_mlda_proposal":
+            lvl = owner.level
+        elif name == "sample" and hasattr(owner, "chain_fine"):
+            lvl = 1
+        elif name == "sample" and hasattr(owner, "level"):
+            lvl = owner.level
+        else:
+            lvl = 0
+        self.ulog.append((lvl, u))
         return u
 
     def uniform(self, low=0.0, high=1.0, size=None):
@@ -326,6 +342,153 @@ def g9_mvn_logpdf():
          logpdf_identity=ident.logpdf(X))
 
 
+def _ml_problem(seed, d, ms, sigma, prior_kind="identity"):
+    """Levels share theta*, each has its own operator (fine operator + level-dependent perturbation) and data."""
+    rng = np.random.default_rng(seed)
+    theta_true = rng.standard_normal(d)
+    Afine = rng.standard_normal((max(ms), d)) / np.sqrt(d)
+    As, ys = [], []
+    for k, m in enumerate(ms):
+        pert = 0.05 * (len(ms) - 1 - k) * rng.standard_normal((m, d)) / np.sqrt(d)
+        A = Afine[:m] + pert
+        As.append(A)
+        ys.append(Afine[:m] @ theta_true + sigma * rng.standard_normal(m))
+    if prior_kind == "identity":
+        pm, pc = np.zeros(d), np.eye(d)
+    else:
+        B = rng.standard_normal((d, d)) / np.sqrt(d)
+        pm, pc = np.zeros(d), B @ B.T + 0.5 * np.eye(d)
+    return As, ys, theta_true, pm, pc
+
+
+def _split_uniforms(ulog, n_levels, counts):
+    """per-level arrays of the uniforms each level consumed, NaN where a step consumed none is handled by
+    the caller (which knows from the accept history which steps evaluated)."""
+    out = [[] for _ in range(n_levels)]
+    for lvl, u in ulog:
+        out[lvl].append(u)
+    return out
+
+
+def _place(consumed, evaluated):
+    """consumed: uniforms in order; evaluated: bool per step -> array with NaN at steps that drew nothing."""
+    arr = np.full(len(evaluated), np.nan)
+    it = iter(consumed)
+    for i, ev in enumerate(evaluated):
+        if ev:
+            arr[i] = next(it)
+    assert next(it, None) is None
+    return arr
+
+
+def g4_da(name, proposal_kind, d=6, ms=(10, 24), L=4, iters=60, n_chains=4, seed=401, randomize=False,
+          adaptive=False, period=7, prior_kind="identity"):
+    sigma = 0.2
+    As, ys, theta_true, pm, pc = _ml_problem(seed, d, ms, sigma, prior_kind)
+    prior = stats.multivariate_normal(pm, pc)
+    posts = [tda.Posterior(prior, tda.GaussianLogLike(y, sigma ** 2 * np.eye(len(y))), make_model(A)) for A, y in zip(As, ys)]
+    rng = np.random.default_rng(seed + 1)
+    theta0 = theta_true[None] + 0.2 * rng.standard_normal((n_chains, d))
+    if proposal_kind == "pcn":
+        prop = tda.CrankNicolson(scaling=0.25, adaptive=adaptive, gamma=1.02, period=period)
+        pcfg = dict(kind="pcn", scaling=0.25, adaptive=adaptive, gamma=1.02, period=period)
+    elif proposal_kind == "grw":
+        prop = tda.GaussianRandomWalk(0.02 * np.eye(d), scaling=1.0, adaptive=adaptive, gamma=1.02, period=period)
+        pcfg = dict(kind="grw", C=0.02 * np.eye(d), scaling=1.0, adaptive=adaptive, gamma=1.02, period=period)
+    else:
+        prop = tda.AdaptiveMetropolis(0.02 * np.eye(d), t0=10, period=period, adaptive=adaptive, gamma=1.02)
+        pcfg = dict(kind="am", C0=0.02 * np.eye(d), t0=10, period=period, adaptive=adaptive, gamma=1.02,
+                    sd=float(prop.sd), epsilon=1e-6)
+    out = {k: [] for k in ("z", "u0", "u1", "ridx", "th0", "lp0", "ll0", "acc0", "th1", "lp1", "ll1", "acc1", "scaling")}
+    for c in range(n_chains):
+        with Tap(seed + 50 * c) as tap:
+            ch = tda.DAChain(copy.deepcopy(posts[0]), copy.deepcopy(posts[1]), copy.deepcopy(prop), L,
+                             randomize_subchain_length=randomize, initial_parameters=theta0[c].copy())
+            ch.sample(iters, progressbar=False)
+        loc = np.array(ch.is_coarse, dtype=bool)
+        cth, clp, cll, _ = chain_trace(ch.chain_coarse)
+        fth, flp, fll, _ = chain_trace(ch.chain_fine)
+        acc_c = np.array(ch.accepted_coarse, dtype=np.uint8)
+        out["th0"].append(cth[loc]); out["lp0"].append(clp[loc]); out["ll0"].append(cll[loc]); out["acc0"].append(acc_c[loc])
+        out["th1"].append(fth); out["lp1"].append(flp); out["ll1"].append(fll)
+        out["acc1"].append(np.array(ch.accepted_fine, dtype=np.uint8))
+        us = _split_uniforms(tap.ulog, 2, None)
+        out["z"].append(np.array(tap.take("z")))
+        out["u0"].append(np.array(us[0]))
+        evaluated = acc_c[loc].reshape(iters, L).sum(axis=1) > 0  # fine level draws only after a coarse accept
+        out["u1"].append(_place(us[1], evaluated))
+        r = tap.take("randint")
+        out["ridx"].append(_place([int(x) for x in r], evaluated) if randomize else np.full(iters, -1.0))
+        out["scaling"].append(float(ch.proposal.scaling))
+    arrays = {k: np.array(v) for k, v in out.items()}
+    flat = {}
+    for k, v in pcfg.items():
+        flat["prop_" + k] = np.array(v)
+    save(name, A0=As[0], A1=As[1], y0=ys[0], y1=ys[1], noise_var=np.array(sigma ** 2), prior_mean=pm, prior_cov=pc,
+         theta0=theta0, subchain_length=np.array(L), randomize=np.array(randomize), **flat, **arrays)
+
+
+def g5_mlda(name, proposal_kind, d=6, ms=(8, 14, 24), sl=(3, 2), iters=40, n_chains=4, seed=501, adaptive=False,
+            period=7):
+    sigma = 0.2
+    As, ys, theta_true, pm, pc = _ml_problem(seed, d, ms, sigma)
+    prior = stats.multivariate_normal(pm, pc)
+    posts = [tda.Posterior(prior, tda.GaussianLogLike(y, sigma ** 2 * np.eye(len(y))), make_model(A)) for A, y in zip(As, ys)]
+    rng = np.random.default_rng(seed + 1)
+    theta0 = theta_true[None] + 0.2 * rng.standard_normal((n_chains, d))
+    if proposal_kind == "grw":
+        prop = tda.GaussianRandomWalk(0.02 * np.eye(d), scaling=1.0, adaptive=adaptive, gamma=1.02, period=period)
+        pcfg = dict(kind="grw", C=0.02 * np.eye(d), scaling=1.0, adaptive=adaptive, gamma=1.02, period=period)
+    else:
+        prop = tda.AdaptiveMetropolis(0.02 * np.eye(d), t0=10, period=period, adaptive=adaptive, gamma=1.02)
+        pcfg = dict(kind="am", C0=0.02 * np.eye(d), t0=10, period=period, adaptive=adaptive, gamma=1.02,
+                    sd=float(prop.sd), epsilon=1e-6)
+    nl = len(ms)
+    out = {"z": [], "scaling": []}
+    for k in range(nl):
+        for key in ("u", "th", "lp", "ll", "acc"):
+            out["%s%d" % (key, k)] = []
+    for c in range(n_chains):
+        with Tap(seed + 50 * c) as tap:
+            ch = tda.MLDAChain([copy.deepcopy(p) for p in posts], copy.deepcopy(prop), list(sl),
+                               initial_parameters=theta0[c].copy())
+            ch.sample(iters, progressbar=False)
+        us = _split_uniforms(tap.ulog, nl, None)
+        out["z"].append(np.array(tap.take("z")))
+        objs = [ch]
+        cur = ch.proposal
+        while True:
+            objs.append(cur)
+            if cur.level == 0:
+                break
+            cur = cur.proposal
+        objs = objs[::-1]  # level 0 first
+        local_acc = []
+        for k, ob in enumerate(objs):
+            th, lp, ll, _ = chain_trace(ob.chain)
+            acc = np.array(ob.accepted, dtype=np.uint8)
+            if k < nl - 1:
+                loc = np.array(ob.is_local, dtype=bool)
+                th, lp, ll, acc = th[loc], lp[loc], ll[loc], acc[loc]
+            out["th%d" % k].append(th); out["lp%d" % k].append(lp); out["ll%d" % k].append(ll); out["acc%d" % k].append(acc)
+            local_acc.append(acc)
+        out["u0"].append(np.array(us[0]))
+        for k in range(1, nl):
+            below = local_acc[k - 1]
+            nsteps = len(local_acc[k]) - (1 if k == nl - 1 else 0)
+            evaluated = below.reshape(nsteps, sl[k - 1]).sum(axis=1) > 0
+            out["u%d" % k].append(_place(us[k], evaluated))
+        out["scaling"].append(float(objs[0].proposal.scaling))
+    arrays = {k: np.array(v) for k, v in out.items()}
+    flat = {"prop_" + k: np.array(v) for k, v in pcfg.items()}
+    lv = {}
+    for k in range(nl):
+        lv["A%d" % k] = As[k]
+        lv["y%d" % k] = ys[k]
+    save(name, noise_var=np.array(sigma ** 2), prior_mean=pm, prior_cov=pc, theta0=theta0,
+         subchain_lengths=np.array(sl), n_levels=np.array(nl), **lv, **flat, **arrays)
+
+
 FIXTURES = {
     "g1_basic_sampler": g1_basic_sampler,
     "g2_am_small": lambda: g2_am("g2_am_small", d=8, m=16, n_chains=8, iters=128, t0=16, period=16, seed=201),
@@ -339,6 +502,14 @@ FIXTURES = {
                               seed=1, c0=1e-4),
     "g2b_pcn": g2b_pcn,
     "g3_loglike_kats": g3_loglike_kats,
+    "g4_da_pcn": lambda: g4_da("g4_da_pcn", "pcn"),
+    "g4_da_grw_adaptive": lambda: g4_da("g4_da_grw_adaptive", "grw", adaptive=True, period=7, seed=402),
+    "g4_da_am_random": lambda: g4_da("g4_da_am_random", "am", randomize=True, period=10, seed=403, prior_kind="general"),
+    "g4_da_pcn_adaptive_c3shape": lambda: g4_da("g4_da_pcn_adaptive_c3shape", "pcn", d=16, ms=(32, 96), L=10, iters=30,
+                                                adaptive=True, period=25, seed=404),
+    "g5_mlda_am": lambda: g5_mlda("g5_mlda_am", "am", period=10),
+    "g5_mlda_grw_adaptive": lambda: g5_mlda("g5_mlda_grw_adaptive", "grw", adaptive=True, period=7, seed=502),
+    "g5_mlda_4level": lambda: g5_mlda("g5_mlda_4level", "am", ms=(6, 10, 16, 24), sl=(3, 2, 2), iters=20, period=10, seed=503),
     "g7_moments": g7_moments,
     "g9_mvn_logpdf": g9_mvn_logpdf,
 }
