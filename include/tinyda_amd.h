@@ -30,6 +30,8 @@
  *        r = sqrt(-2 ln(1 - u1));  z[2b] = r cos(2 pi u2), z[2b+1] = r sin(2 pi u2)   (proposal normals)
  *   stream 1, block = level    : u = u53(x0,x1)                                       (accept uniform)
  *   stream 2, block b          : as stream 0, step = 0                                (theta0 ~ prior)
+ *   stream 3, block 0, step = fine iteration : promoted index = (x0 * L) >> 32        (DA randomize_subchain_length)
+ *   For levels >= 1 the accept uniform of that level's step n is stream 1, block = level, step = n.
  *   "step" is the count of base-level proposals made so far on the chain (proposal.t in
  *   tinyDA/proposal.py:223,229).
  */
@@ -65,7 +67,7 @@ typedef struct tda_config {
   int64_t n_chains;      /* chains held by this engine (rows of the state matrix) */
   int64_t chain_offset;  /* global id of local chain 0 */
   int32_t dim;           /* parameter dimension d (1..64) */
-  int32_t n_levels;      /* 1 = single-level MH (sampler.py:213); >1 reserved for DA / MLDA */
+  int32_t n_levels;      /* 1 = MH (sampler.py:213), 2 = Delayed Acceptance (:231), 3..4 = MLDA (:260) */
   uint64_t seed;
   void* stream;          /* hipStream_t to run on, or NULL for an engine-owned stream */
   int32_t block_steps;   /* max MH steps fused per launch group (0 = default 128) */
@@ -89,6 +91,9 @@ typedef struct tda_proposal_params {
 } tda_proposal_params;
 
 /* Per-step records of one run() call; any pointer may be NULL (that record is then not produced).
+ * tda_engine_run takes an ARRAY of n_levels of these, coarsest level first.  Level k < n_levels-1 gets one
+ * record per *local* step of that level (what sampler.py:421-427 / :535-538 return after compress(is_coarse /
+ * is_local)): n_iterations * prod(subchain_lengths[k:]) rows; the finest level gets n_iterations rows.
  * Record r (0-based within this call) of chain c:
  *   params  [(r * n_chains + c) * dim + j]       chain state after the accept/reject decision
  *   stats   [(r * n_chains + c) * 3 + {0,1,2}]   log-prior, log-likelihood, log-posterior (link.py:41-48)
@@ -126,24 +131,36 @@ int tda_engine_set_level(tda_engine* e, int level, int m, const double* A, const
 
 int tda_engine_set_proposal(tda_engine* e, const tda_proposal_params* p);
 
+/* Multi-level schedule (sampler.py:260-264; chain.py:231-232): lengths[k], k = 0..n_levels-2, is the number of
+ * level-k steps per step of level k+1.  randomize != 0 selects DAChain's randomize_subchain_length
+ * (chain.py:310-321, 525-527; two levels only, needs lengths[0] > 1).  HOST pointer. */
+int tda_engine_set_subchains(tda_engine* e, const int32_t* lengths, int randomize);
+
 /* Start the chains: theta0 is n_chains x dim, or NULL to draw theta0 ~ prior from RNG stream 2
  * (sampler.py:209).  Evaluates the initial links (chain.py:70) and sets up the proposal
  * (chain.py:74-76, proposal.py:492-500). */
 int tda_engine_init(tda_engine* e, const double* theta0);
 
-/* Current state of every chain: theta [n_chains*dim], stats [n_chains*3]; either may be NULL. */
+/* Current state of every chain on the finest level: theta [n_chains*dim], stats [n_chains*3]; either may be NULL. */
 int tda_engine_get_current(tda_engine* e, double* theta, double* stats);
+/* Same for an explicit level. */
+int tda_engine_get_level_state(tda_engine* e, int level, double* theta, double* stats);
 
 /* Parity mode: consume caller-supplied variates instead of Philox.  z is [n_steps][n_chains][dim]
  * standard normals (mapped through chol(C) like tests/golden/gen_golden.py), u is [n_steps][n_chains]
  * uniforms; step index counts from the engine's current step.  NULL/0 switches replay off. */
 int tda_engine_set_replay(tda_engine* e, const double* z, const double* u, int64_t n_steps);
 
+/* Parity mode for levels >= 1: u is [n_steps_of_that_level][n_chains] (NaN where the reference drew none).
+ * level == -1 sets the DA promoted index instead: values in [-L, -1] per fine iteration (chain.py:525-527). */
+int tda_engine_set_replay_level(tda_engine* e, int level, const double* u, int64_t n_steps);
+
 /* Export mode: the engine writes the variates it generated into z / u (same layout as replay),
  * so the CPU oracle can be driven with the identical stream.  NULL/0 switches export off. */
 int tda_engine_set_export(tda_engine* e, double* z, double* u, int64_t n_steps);
 
-/* Advance every chain by n_iterations MH steps (Chain.sample, chain.py:95-125).  Asynchronous on the
+/* Advance every chain by n_iterations steps of the FINEST level (Chain.sample chain.py:95-125, DAChain.sample
+ * :342-402, MLDAChain.sample :697-765); `out` points to n_levels tda_outputs (may be NULL).  Asynchronous on the
  * engine's stream when all outputs are device pointers; tda_engine_sync() waits. */
 int tda_engine_run(tda_engine* e, int64_t n_iterations, const tda_outputs* out);
 int tda_engine_sync(tda_engine* e);

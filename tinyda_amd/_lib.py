@@ -82,6 +82,9 @@ SYMBOLS = {
     "tda_engine_set_prior": (C.c_int, [_P, _P, _P]),
     "tda_engine_set_level": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P]),
     "tda_engine_set_proposal": (C.c_int, [_P, C.POINTER(tda_proposal_params)]),
+    "tda_engine_set_subchains": (C.c_int, [_P, _P, C.c_int]),
+    "tda_engine_set_replay_level": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
+    "tda_engine_get_level_state": (C.c_int, [_P, C.c_int, _P, _P]),
     "tda_engine_init": (C.c_int, [_P, _P]),
     "tda_engine_get_current": (C.c_int, [_P, _P, _P]),
     "tda_engine_set_replay": (C.c_int, [_P, _P, _P, C.c_int64]),

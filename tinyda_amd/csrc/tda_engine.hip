@@ -172,6 +172,24 @@ struct tda_engine {
   DevBuf<double> inc, ublk, rec_params, rec_stats;
   DevBuf<uint8_t> rec_acc;
 
+  // multi-level state (n_levels > 1)
+  int nlev = 1;
+  int sl[tda::MAXLEV] = {1, 1, 1, 1};
+  bool sub_set = false;
+  int randomize = 0;
+  int cnt[tda::MAXLEV] = {0, 0, 0, 0};
+  int64_t done[tda::MAXLEV] = {0, 0, 0, 0};
+  int64_t ring_pos = 0;
+  int ring_P = 1;
+  DevBuf<double> ml_theta, ml_lp, ml_ll, ml_S, ml_ysnap;
+  DevBuf<int32_t> ml_anyacc, ml_pick;
+  DevBuf<uint8_t> ml_ring;
+  DevBuf<double> ml_rec_params[tda::MAXLEV], ml_rec_stats[tda::MAXLEV];
+  DevBuf<uint8_t> ml_rec_acc[tda::MAXLEV];
+  DevBuf<double> u_rep_lv[tda::MAXLEV], ridx_rep;
+  int64_t u_rep_lv_n[tda::MAXLEV] = {0, 0, 0, 0}, ridx_rep_n = 0;
+  int64_t u_rep_lv_pos[tda::MAXLEV] = {0, 0, 0, 0}, ridx_rep_pos = 0;
+
   // replay / export
   DevBuf<double> z_rep, u_rep;
   int64_t rep_steps = 0, rep_pos = 0;
@@ -204,6 +222,15 @@ void launch_adapt(const AdaptArgs& a, hipStream_t st) {
 template <int DPAD>
 void launch_chol(const CholArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_chol<DPAD>, dim3((unsigned)a.N), dim3(64), 0, st, a);
+}
+
+template <int DPAD>
+void launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st) {
+  switch (a.nlev) {
+    case 2: hipLaunchKernelGGL((k_ml_steps<DPAD, 2>), dim3((unsigned)tiles), dim3(256), lds, st, a); break;
+    case 3: hipLaunchKernelGGL((k_ml_steps<DPAD, 3>), dim3((unsigned)tiles), dim3(256), lds, st, a); break;
+    default: hipLaunchKernelGGL((k_ml_steps<DPAD, 4>), dim3((unsigned)tiles), dim3(256), lds, st, a); break;
+  }
 }
 
 #define DISPATCH_DPAD(dp, CALL)                  \
@@ -314,7 +341,8 @@ int tda_engine_create(const tda_config* cfg, tda_engine** out) {
   if (cfg->dim < 1 || cfg->dim > 64)
     return fail(TDA_ERR_UNSUPPORTED, "dim=%d outside the device engine's range 1..64", cfg->dim);
   if (cfg->n_chains < 1) return fail(TDA_ERR_INVALID, "n_chains must be >= 1");
-  if (cfg->n_levels != 1) return fail(TDA_ERR_UNSUPPORTED, "n_levels=%d: only single-level MH is lowered so far", cfg->n_levels);
+  if (cfg->n_levels < 1 || cfg->n_levels > MAXLEV)
+    return fail(TDA_ERR_UNSUPPORTED, "n_levels=%d outside 1..%d", cfg->n_levels, (int)MAXLEV);
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (ndev < 1) return fail(TDA_ERR_HIP, "no HIP device visible: the MH engine has no CPU fallback");
@@ -328,6 +356,7 @@ int tda_engine_create(const tda_config* cfg, tda_engine** out) {
   e->NP = (cfg->n_chains + 15) / 16 * 16;
   e->SMAX = cfg->block_steps > 0 ? cfg->block_steps : 128;
   e->levels.resize(cfg->n_levels);
+  e->nlev = cfg->n_levels;
   if (cfg->stream) {
     e->stream = (hipStream_t)cfg->stream;
   } else {
@@ -456,6 +485,81 @@ int tda_engine_set_proposal(tda_engine* e, const tda_proposal_params* p) {
   return TDA_OK;
 }
 
+int tda_engine_set_subchains(tda_engine* e, const int32_t* lengths, int randomize) {
+  if (!e || !lengths) return fail(TDA_ERR_INVALID, "null argument");
+  if (e->nlev < 2) return fail(TDA_ERR_STATE, "subchain lengths only apply to n_levels >= 2");
+  for (int k = 0; k < e->nlev - 1; ++k) {
+    if (lengths[k] < 1) return fail(TDA_ERR_INVALID, "subchain length must be >= 1");
+    e->sl[k] = lengths[k];
+  }
+  if (randomize) {
+    if (e->nlev != 2) return fail(TDA_ERR_UNSUPPORTED, "randomize_subchain_length is a two-level (DA) option");
+    if (e->sl[0] == 1) return fail(TDA_ERR_INVALID, "Randomize subchain length requires a subchain_length > 1.");
+  }
+  e->randomize = randomize ? 1 : 0;
+  e->sub_set = true;
+  e->inited = false;
+  return TDA_OK;
+}
+
+int tda_engine_set_replay_level(tda_engine* e, int level, const double* u, int64_t n_steps) {
+  if (!e) return fail(TDA_ERR_INVALID, "null engine");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  if (level == -1) {
+    e->ridx_rep.release();
+    e->ridx_rep_n = e->ridx_rep_pos = 0;
+    if (!u || n_steps <= 0) return TDA_OK;
+    int rc = e->ridx_rep.alloc((size_t)n_steps * e->N);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(e->ridx_rep.p, u, (size_t)n_steps * e->N * sizeof(double), is_device_ptr(u) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    e->ridx_rep_n = n_steps;
+    return TDA_OK;
+  }
+  if (level < 1 || level >= e->nlev) return fail(TDA_ERR_INVALID, "level %d out of range for replay_level", level);
+  e->u_rep_lv[level].release();
+  e->u_rep_lv_n[level] = e->u_rep_lv_pos[level] = 0;
+  if (!u || n_steps <= 0) return TDA_OK;
+  int rc = e->u_rep_lv[level].alloc((size_t)n_steps * e->N);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(e->u_rep_lv[level].p, u, (size_t)n_steps * e->N * sizeof(double), is_device_ptr(u) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  e->u_rep_lv_n[level] = n_steps;
+  return TDA_OK;
+}
+
+static int read_level_state(tda_engine* e, const double* th_dev, const double* lp_dev, const double* ll_dev, double* theta,
+                            double* stats) {
+  const int64_t N = e->N, NP = e->NP;
+  if (theta) {
+    std::vector<double> hh((size_t)NP * e->DP), o((size_t)N * e->d);
+    HIP_TRY(hipMemcpy(hh.data(), th_dev, hh.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int64_t c = 0; c < N; ++c)
+      for (int j = 0; j < e->d; ++j) o[(size_t)c * e->d + j] = hh[(size_t)c * e->DP + j];
+    HIP_TRY(hipMemcpy(theta, o.data(), o.size() * sizeof(double), is_device_ptr(theta) ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
+  }
+  if (stats) {
+    std::vector<double> a(NP), b(NP), o((size_t)N * 3);
+    HIP_TRY(hipMemcpy(a.data(), lp_dev, NP * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(b.data(), ll_dev, NP * sizeof(double), hipMemcpyDeviceToHost));
+    for (int64_t c = 0; c < N; ++c) {
+      o[c * 3] = a[c];
+      o[c * 3 + 1] = b[c];
+      o[c * 3 + 2] = a[c] + b[c];
+    }
+    HIP_TRY(hipMemcpy(stats, o.data(), o.size() * sizeof(double), is_device_ptr(stats) ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
+  }
+  return TDA_OK;
+}
+
+int tda_engine_get_level_state(tda_engine* e, int level, double* theta, double* stats) {
+  if (!e || !e->inited) return fail(TDA_ERR_STATE, "engine not initialised");
+  if (level < 0 || level >= e->nlev) return fail(TDA_ERR_INVALID, "level %d out of range", level);
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (e->nlev == 1) return read_level_state(e, e->theta.p, e->lp.p, e->ll.p, theta, stats);
+  return read_level_state(e, e->ml_theta.p + (size_t)level * e->NP * e->DP, e->ml_lp.p + (size_t)level * e->NP,
+                          e->ml_ll.p + (size_t)level * e->NP, theta, stats);
+}
+
 int tda_engine_init(tda_engine* e, const double* theta0) {
   if (!e) return fail(TDA_ERR_INVALID, "null engine");
   if (!e->prior_set || !e->prop_set) return fail(TDA_ERR_STATE, "set_prior and set_proposal must precede init");
@@ -535,6 +639,47 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
   e->exp_pos = 0;
   // initial links (chain.py:70)
   if ((rc = launch_eval(e, 0, e->theta.p, e->lp.p, e->ll.p))) return rc;
+  if (e->nlev > 1) {
+    // every level starts from theta0 (chain.py:253-261; proposal.py:1379); S[j][q] = level j's densities there
+    if (!e->sub_set) return fail(TDA_ERR_STATE, "set_subchains must precede init for n_levels > 1");
+    const int nl = e->nlev, npair = nl * (nl - 1) / 2;
+    if ((rc = e->ml_theta.alloc((size_t)nl * NP * DP))) return rc;
+    if ((rc = e->ml_lp.alloc((size_t)nl * NP))) return rc;
+    if ((rc = e->ml_ll.alloc((size_t)nl * NP))) return rc;
+    if ((rc = e->ml_S.alloc((size_t)npair * 2 * NP))) return rc;
+    if ((rc = e->ml_anyacc.alloc((size_t)nl * NP))) return rc;
+    if ((rc = e->ml_ysnap.alloc((size_t)NP * (DP + 2)))) return rc;
+    if ((rc = e->ml_pick.alloc(NP))) return rc;
+    e->ring_P = e->pp.adaptive ? e->pp.period + MAXLEV : 1;
+    if ((rc = e->ml_ring.alloc((size_t)e->ring_P * NP))) return rc;
+    HIP_TRY(hipMemsetAsync(e->ml_anyacc.p, 0, (size_t)nl * NP * sizeof(int32_t), e->stream));
+    HIP_TRY(hipMemsetAsync(e->ml_ysnap.p, 0, (size_t)NP * (DP + 2) * sizeof(double), e->stream));
+    HIP_TRY(hipMemsetAsync(e->ml_pick.p, 0, NP * sizeof(int32_t), e->stream));
+    HIP_TRY(hipMemsetAsync(e->ml_ring.p, 0, (size_t)e->ring_P * NP, e->stream));
+    for (int k = 0; k < nl; ++k) {
+      double* thk = e->ml_theta.p + (size_t)k * NP * DP;
+      HIP_TRY(hipMemcpyAsync(thk, e->theta.p, (size_t)NP * DP * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+      if ((rc = launch_eval(e, k, thk, e->ml_lp.p + (size_t)k * NP, e->ml_ll.p + (size_t)k * NP))) return rc;
+    }
+    for (int q = 1; q < nl; ++q)
+      for (int j = 0; j < q; ++j) {
+        const int p = q * (q - 1) / 2 + j;
+        HIP_TRY(hipMemcpyAsync(e->ml_S.p + ((size_t)p * 2 + 0) * NP, e->ml_lp.p + (size_t)j * NP, NP * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->ml_S.p + ((size_t)p * 2 + 1) * NP, e->ml_ll.p + (size_t)j * NP, NP * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+      }
+    for (int k = 0; k < MAXLEV; ++k) {
+      e->cnt[k] = 0;
+      e->done[k] = 0;
+      e->u_rep_lv_pos[k] = 0;
+    }
+    e->ridx_rep_pos = 0;
+    e->ring_pos = 0;
+    for (int k = 0; k < nl; ++k) {
+      if ((rc = e->ml_rec_params[k].alloc((size_t)e->SMAX * N * d))) return rc;
+      if ((rc = e->ml_rec_stats[k].alloc((size_t)e->SMAX * N * 3))) return rc;
+      if ((rc = e->ml_rec_acc[k].alloc((size_t)e->SMAX * N))) return rc;
+    }
+  }
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->inited = true;
   return TDA_OK;
@@ -542,6 +687,7 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
 
 int tda_engine_get_current(tda_engine* e, double* theta, double* stats) {
   if (!e || !e->inited) return fail(TDA_ERR_STATE, "engine not initialised");
+  if (e->nlev > 1) return tda_engine_get_level_state(e, e->nlev - 1, theta, stats);
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipStreamSynchronize(e->stream));
   const int64_t N = e->N, NP = e->NP;
@@ -606,9 +752,12 @@ int tda_engine_set_export(tda_engine* e, double* z, double* u, int64_t n_steps) 
   return TDA_OK;
 }
 
+static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs);
+
 int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
   if (!e || !e->inited) return fail(TDA_ERR_STATE, "engine not initialised");
   if (n_iter < 0) return fail(TDA_ERR_INVALID, "n_iterations < 0");
+  if (e->nlev > 1) return run_multilevel(e, n_iter, out);
   if (out && out->struct_size != sizeof(tda_outputs)) return fail(TDA_ERR_INVALID, "tda_outputs.struct_size mismatch");
   HIP_TRY(hipSetDevice(e->cfg.device));
   if (e->rep_steps && e->rep_pos + n_iter > e->rep_steps)
@@ -754,6 +903,248 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     if (e->exp_steps) e->exp_pos += S;
   }
 
+  if (e->exp_steps && !e->exp_dev) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(e->z_exp, e->z_exp_d.p, (size_t)e->exp_pos * N * d * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(e->u_exp, e->u_exp_d.p, (size_t)e->exp_pos * N * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  return TDA_OK;
+}
+
+static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs) {
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const int nl = e->nlev, d = e->d, DP = e->DP;
+  const int64_t N = e->N, NP = e->NP;
+  if (outs)
+    for (int k = 0; k < nl; ++k)
+      if (outs[k].struct_size != sizeof(tda_outputs)) return fail(TDA_ERR_INVALID, "tda_outputs[%d].struct_size mismatch", k);
+  int64_t mult[MAXLEV];  // local steps of level k per finest step
+  mult[nl - 1] = 1;
+  for (int k = nl - 2; k >= 0; --k) mult[k] = mult[k + 1] * e->sl[k];
+  const int64_t total_base = n_fine * mult[0];
+  if (e->rep_steps && e->rep_pos + total_base > e->rep_steps) return fail(TDA_ERR_INVALID, "replay buffer too short");
+  if (e->exp_steps && e->exp_pos + total_base > e->exp_steps) return fail(TDA_ERR_INVALID, "export buffer too small");
+  for (int k = 1; k < nl; ++k)
+    if (e->u_rep_lv_n[k] && e->u_rep_lv_pos[k] + n_fine * mult[k] > e->u_rep_lv_n[k])
+      return fail(TDA_ERR_INVALID, "replay buffer of level %d too short", k);
+  if (e->rep_steps)
+    for (int k = 1; k < nl; ++k)
+      if (!e->u_rep_lv_n[k]) return fail(TDA_ERR_STATE, "replay mode needs uniforms for every level (set_replay_level)");
+
+  const bool is_am = e->pp.kind == TDA_PROP_AM, adaptive = e->pp.adaptive != 0, periodic = is_am || adaptive;
+  const int period = e->pp.period;
+  // LDS staging layout of the per-level data vectors
+  int lds_y[MAXLEV] = {0, 0, 0, 0}, lds_w[MAXLEV] = {0, 0, 0, 0}, off = 0;
+  for (int k = 0; k < nl; ++k) {
+    lds_y[k] = off;
+    off += e->levels[k].m_pad;
+    if (e->levels[k].noise_kind == TDA_NOISE_DIAG) {
+      lds_w[k] = off;
+      off += e->levels[k].m_pad;
+    }
+  }
+  const int prow = e->prior_kind == PRIOR_DENSE ? e->prior_ncb * 16 : 0;
+  const size_t lds = ((size_t)16 * (DP + 2) + 128 + off + prow) * sizeof(double);
+  if (lds > 160 * 1024) return fail(TDA_ERR_UNSUPPORTED, "levels need %zu bytes of LDS staging", lds);
+
+  if (e->profiling) {
+    for (auto& t : e->timed) {
+      (void)hipEventDestroy(t.a);
+      (void)hipEventDestroy(t.b);
+    }
+    e->timed.clear();
+  }
+  int64_t rows_out[MAXLEV] = {0, 0, 0, 0};  // rows already written to the caller's buffers, per level
+  int64_t done_base = 0;
+  while (done_base < total_base) {
+    int64_t S = std::min<int64_t>(total_base - done_base, e->SMAX);
+    if (periodic) S = std::min<int64_t>(S, period - (e->t % period));
+    // how many local steps each level completes inside this block (uniform schedule)
+    int c2[MAXLEV];
+    int64_t nblk[MAXLEV] = {S, 0, 0, 0};
+    for (int k = 0; k < MAXLEV; ++k) c2[k] = e->cnt[k];
+    int64_t tail_appends = 0;  // alignment entries appended by the block's last base step
+    for (int64_t s = 0; s < S; ++s) {
+      c2[0] += 1;
+      for (int k = 0; k < nl - 1 && c2[k] == e->sl[k]; ++k) {
+        c2[k] = 0;
+        nblk[k + 1] += 1;
+        c2[k + 1] += 1;
+        if (s == S - 1) tail_appends += 1;
+      }
+    }
+
+    ProposeArgs pa{};
+    pa.N = N;
+    pa.NP = NP;
+    pa.chain_offset = e->cfg.chain_offset;
+    pa.d = d;
+    pa.S = (int)S;
+    pa.step0 = e->t;
+    pa.seed = e->cfg.seed;
+    pa.Lk = e->Lk.p;
+    pa.L_stride = e->L_shared ? 0 : (int64_t)DP * DP;
+    pa.inc = e->inc.p;
+    pa.u = e->ublk.p;
+    if (e->rep_steps) {
+      pa.z_replay = e->z_rep.p + (size_t)e->rep_pos * N * d;
+      pa.u_replay = e->u_rep.p + (size_t)e->rep_pos * N;
+    }
+    if (e->exp_steps) {
+      pa.z_export = (e->exp_dev ? e->z_exp : e->z_exp_d.p) + (size_t)e->exp_pos * N * d;
+      pa.u_export = (e->exp_dev ? e->u_exp : e->u_exp_d.p) + (size_t)e->exp_pos * N;
+    }
+    {
+      ScopedTimer tm(e, 0);
+      DISPATCH_DPAD(DP, launch_propose<DPAD>(pa, e->stream));
+    }
+
+    MLArgs ma{};
+    for (int k = 0; k < nl; ++k) {
+      const Level& lv = e->levels[k];
+      ma.lv[k].Apk = lv.Apk.p;
+      ma.lv[k].ytil = lv.ytil.p;
+      ma.lv[k].w = lv.w.p;
+      ma.lv[k].ncb = lv.ncb;
+      ma.lv[k].m_pad = lv.m_pad;
+      ma.lv[k].noise_kind = lv.noise_kind;
+      ma.lv[k].var = lv.var;
+      ma.lds_y[k] = lds_y[k];
+      ma.lds_w[k] = lds_w[k];
+      ma.sl[k] = e->sl[k];
+      ma.cnt[k] = e->cnt[k];
+      ma.done[k] = e->done[k];
+    }
+    ma.lds_total = off;
+    ma.pr.mean = e->prior_mean.p;
+    ma.pr.pinv = e->prior_pinv.p;
+    ma.pr.Wpk = e->prior_Wpk.p;
+    ma.pr.wmu = e->prior_wmu.p;
+    ma.pr.ncb = e->prior_ncb;
+    ma.pr.kind = e->prior_kind;
+    ma.pr.logconst = e->prior_logconst;
+    ma.N = N;
+    ma.NP = NP;
+    ma.d = d;
+    ma.S = (int)S;
+    ma.prop_kind = e->pp.kind;
+    ma.nlev = nl;
+    ma.randomize = e->randomize;
+    ma.seed = e->cfg.seed;
+    ma.chain_offset = e->cfg.chain_offset;
+    ma.theta = e->ml_theta.p;
+    ma.lp = e->ml_lp.p;
+    ma.ll = e->ml_ll.p;
+    ma.Sst = e->ml_S.p;
+    ma.anyacc = e->ml_anyacc.p;
+    ma.ysnap = e->ml_ysnap.p;
+    ma.pick = e->ml_pick.p;
+    ma.scaling = e->scaling.p;
+    ma.ring = e->ml_ring.p;
+    ma.ring_P = e->ring_P;
+    ma.ring_pos = e->ring_pos;
+    ma.inc = e->inc.p;
+    ma.u0 = e->ublk.p;
+    for (int k = 1; k < nl; ++k)
+      ma.u_rep[k] = e->u_rep_lv_n[k] ? e->u_rep_lv[k].p + (size_t)e->u_rep_lv_pos[k] * N : nullptr;
+    ma.ridx_rep = e->ridx_rep_n ? e->ridx_rep.p + (size_t)e->ridx_rep_pos * N : nullptr;
+    bool dev_p[MAXLEV], dev_s[MAXLEV], dev_a[MAXLEV];
+    for (int k = 0; k < nl; ++k) {
+      double* op = outs ? outs[k].params : nullptr;
+      double* os = outs ? outs[k].stats : nullptr;
+      uint8_t* oa = outs ? outs[k].accepted : nullptr;
+      dev_p[k] = is_device_ptr(op);
+      dev_s[k] = is_device_ptr(os);
+      dev_a[k] = is_device_ptr(oa);
+      const bool need_p = op || (k == 0 && is_am);
+      ma.rec_params[k] = dev_p[k] ? op + (size_t)rows_out[k] * N * d : (need_p ? e->ml_rec_params[k].p : nullptr);
+      ma.rec_stats[k] = dev_s[k] ? os + (size_t)rows_out[k] * N * 3 : (os ? e->ml_rec_stats[k].p : nullptr);
+      ma.rec_acc[k] = dev_a[k] ? oa + (size_t)rows_out[k] * N : (oa ? e->ml_rec_acc[k].p : nullptr);
+    }
+    {
+      ScopedTimer tm(e, 1);
+      DISPATCH_DPAD(DP, launch_ml<DPAD>(ma, NP / 16, lds, e->stream));
+    }
+
+    const bool boundary = periodic && ((e->t + S) % period == 0);
+    if (is_am || (boundary && adaptive)) {
+      AdaptArgs aa{};
+      aa.N = N;
+      aa.NP = NP;
+      aa.d = d;
+      aa.S = (int)S;
+      aa.t_base = e->t;
+      aa.do_am = is_am;
+      aa.boundary = boundary;
+      aa.do_scale = adaptive;
+      const bool do_swap = is_am && boundary && (e->t + S >= e->pp.t0);
+      aa.do_swap = do_swap;
+      aa.period = period;
+      aa.gamma_pow = std::pow(e->pp.gamma, -(double)e->k_adapt);
+      aa.sd = e->am_sd;
+      aa.eps = e->pp.epsilon;
+      aa.rec_params = ma.rec_params[0];
+      aa.am_mu = e->am_mu.p;
+      aa.am_sigma = e->am_sigma.p;
+      aa.scaling = e->scaling.p;
+      aa.acc_count = e->acc_count.p;
+      aa.flags = e->flags.p;
+      aa.ring = adaptive ? e->ml_ring.p : nullptr;
+      aa.ring_P = e->ring_P;
+      {
+        int64_t app = 0;
+        for (int k = 0; k < nl; ++k) app += nblk[k];
+        aa.ring_hi = e->ring_pos + app - tail_appends;
+      }
+      ScopedTimer tm(e, 2);
+      DISPATCH_DPAD(DP, launch_adapt<DPAD>(aa, e->stream));
+      if (do_swap) {
+        CholArgs ca{};
+        ca.N = N;
+        ca.d = d;
+        ca.am_sigma = e->am_sigma.p;
+        ca.Lk = e->Lk.p;
+        ca.flags = e->flags.p;
+        DISPATCH_DPAD(DP, launch_chol<DPAD>(ca, e->stream));
+      }
+    }
+    HIP_TRY(hipGetLastError());
+    if (boundary && adaptive) e->k_adapt += 1;
+
+    bool host_copies = false;
+    int rc;
+    for (int k = 0; k < nl; ++k) {
+      if (!outs) break;
+      if (outs[k].params && !dev_p[k]) {
+        if ((rc = copy_out(e, outs[k].params + (size_t)rows_out[k] * N * d, e->ml_rec_params[k].p, (size_t)nblk[k] * N * d * sizeof(double)))) return rc;
+        host_copies = true;
+      }
+      if (outs[k].stats && !dev_s[k]) {
+        if ((rc = copy_out(e, outs[k].stats + (size_t)rows_out[k] * N * 3, e->ml_rec_stats[k].p, (size_t)nblk[k] * N * 3 * sizeof(double)))) return rc;
+        host_copies = true;
+      }
+      if (outs[k].accepted && !dev_a[k]) {
+        if ((rc = copy_out(e, outs[k].accepted + (size_t)rows_out[k] * N, e->ml_rec_acc[k].p, (size_t)nblk[k] * N))) return rc;
+        host_copies = true;
+      }
+    }
+    if (host_copies) HIP_TRY(hipStreamSynchronize(e->stream));
+
+    int64_t appended = 0;
+    for (int k = 0; k < nl; ++k) {
+      e->cnt[k] = c2[k];
+      e->done[k] += nblk[k];
+      rows_out[k] += nblk[k];
+      appended += nblk[k];
+      if (k >= 1 && e->u_rep_lv_n[k]) e->u_rep_lv_pos[k] += nblk[k];
+    }
+    if (e->ridx_rep_n) e->ridx_rep_pos += nblk[1];
+    e->ring_pos += appended;
+    e->t += S;
+    done_base += S;
+    if (e->rep_steps) e->rep_pos += S;
+    if (e->exp_steps) e->exp_pos += S;
+  }
   if (e->exp_steps && !e->exp_dev) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(e->z_exp, e->z_exp_d.p, (size_t)e->exp_pos * N * d * sizeof(double), hipMemcpyDeviceToHost));

@@ -109,6 +109,10 @@ struct AdaptArgs {
   double* scaling;           // [NP]
   int32_t* acc_count;        // [NP]
   int32_t* flags;            // [NP]
+  const uint8_t* ring;       // multi-level: recent entries of the base proposal's accepted list, [ring_P][NP]
+  int ring_P;                // ring capacity (>= period + levels)
+  int64_t ring_hi;           // absolute list position just after the boundary base step's own flag: adapt()
+                             // runs before the upper level of that step appends its alignment entry
 };
 
 __device__ __forceinline__ double4_t mfma_f64(double a, double b, double4_t c) {
@@ -516,7 +520,13 @@ __global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
 
   if (!a.boundary) return;
   if (a.do_scale && lane == 0) {
-    const double rate = (double)a.acc_count[c] / (double)a.period;  // np.mean(accepted[-period:])
+    int hits = 0;
+    if (a.ring) {
+      for (int i = 1; i <= a.period; ++i) hits += a.ring[(size_t)((a.ring_hi - i) % a.ring_P) * a.NP + c];
+    } else {
+      hits = a.acc_count[c];
+    }
+    const double rate = (double)hits / (double)a.period;  // np.mean(accepted[-period:])
     a.scaling[c] = exp(log(a.scaling[c]) + a.gamma_pow * (rate - 0.24));
   }
   if (lane == 0) a.acc_count[c] = 0;
@@ -584,6 +594,391 @@ __global__ void __launch_bounds__(64) k_chol(const CholArgs a) {
     }
   } else if (lane == 0) {
     atomicOr(&a.flags[c], 1);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Multi-level engine: Delayed Acceptance (tinyDA/chain.py:325-444, 475-483) and MLDA
+// (chain.py:680-737, proposal.py:1502-1624) as ONE iterative state machine over base-level steps.
+//
+// All chains run the same schedule (subchain lengths are fixed), so control flow is uniform:
+//   for each base step:   level-0 MH step (as k_mh_steps)
+//     while the subchain of level k just completed (cnt[k] == sl[k]):  level k+1 acts:
+//        y = state of level k (DA with randomize_subchain_length: the state after step `pick`)
+//        skip-eval rule: chains whose level-k subchain accepted nothing record a rejection (chain.py:357-364)
+//        alpha = exp(pi_{k+1}(y) - pi_{k+1}(x) + pi_k(x_start) - pi_k(y))
+//        accept: level k+1 takes y.   reject: every level below reverts to theta_{k+1} with the
+//        log-densities it had there.  (Invariant: after a step of level q, all levels j < q sit at theta_q;
+//        S[j][q] caches level j's log-prior / log-like at theta_q.  This is what align_chain's identity
+//        search (proposal.py:1469-1493) and the coarse re-append (chain.py:360-362, 394-396) amount to.)
+// The accept flag of every upper-level step is also appended to the base proposal's `accepted` window
+// (chain.py:363,389,397; proposal.py:1486), kept as a ring of the last `period` entries.
+// ------------------------------------------------------------------------------------------------
+constexpr int MAXLEV = 4;
+enum : uint32_t { STREAM_INDEX = 3 };
+
+struct MLArgs {
+  LevelDev lv[MAXLEV];
+  int lds_y[MAXLEV];  // offset (doubles) of ytil / w of level k inside the staging region
+  int lds_w[MAXLEV];
+  int lds_total;      // doubles in the staging region
+  PriorDev pr;
+  int64_t N, NP;
+  int d, S, prop_kind, nlev, randomize;
+  int sl[MAXLEV];        // sl[k]: steps of level k per step of level k+1
+  int cnt[MAXLEV];       // position inside the running subchain of level k at launch
+  int64_t done[MAXLEV];  // local steps of level k completed before this launch (RNG step of level k)
+  uint64_t seed;
+  int64_t chain_offset;
+  double* theta;    // [nlev][NP][DPAD]
+  double* lp;       // [nlev][NP]
+  double* ll;       // [nlev][NP]
+  double* Sst;      // [npairs][2][NP], pair (j,q) at q(q-1)/2 + j
+  int32_t* anyacc;  // [nlev][NP]
+  double* ysnap;    // [NP][DPAD + 2] promoted coarse state of the running DA subchain
+  int32_t* pick;    // [NP]
+  const double* scaling;
+  uint8_t* ring;    // [P][NP]
+  int ring_P;
+  int64_t ring_pos;
+  const double* inc;  // [S][NP][DPAD]
+  const double* u0;   // [S][NP]
+  const double* u_rep[MAXLEV];  // replay uniforms of level k >= 1, row 0 = step done[k]; null -> Philox
+  const double* ridx_rep;       // replay promoted index (DA), row 0 = fine iteration done[1]
+  double* rec_params[MAXLEV];   // row 0 = first local step of level k in this launch
+  double* rec_stats[MAXLEV];
+  uint8_t* rec_acc[MAXLEV];
+};
+
+__device__ __forceinline__ constexpr int pair_index(int j, int q) { return q * (q - 1) / 2 + j; }
+
+template <int DPAD, int NLEV>
+__global__ void __launch_bounds__(256, 1) k_ml_steps(const MLArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int KS = DPAD / 4;
+  constexpr int LDP = DPAD + 2;
+  constexpr int EPT = DPAD >= 16 ? DPAD / 16 : 1;
+  constexpr int QACT = DPAD / EPT;
+  constexpr int NPAIR = NLEV * (NLEV - 1) / 2;
+
+  const bool prior_dense = a.pr.kind == PRIOR_DENSE;
+  double* s_prop = smem;
+  double* s_red = s_prop + 16 * LDP;
+  double* s_redp = s_red + 64;
+  double* s_stage = s_redp + 64;           // ytil / w of every level
+  double* s_py = s_stage + a.lds_total;    // dense prior: W mu
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t tile = blockIdx.x;
+  const int c = tid >> 4, q_ = tid & 15;
+  const int lc = lane & 15, hi = lane >> 4;
+  const int64_t gct = tile * 16 + c;
+  const int64_t gcl = tile * 16 + lc;
+  const bool active = q_ < QACT;
+  const uint32_t gchain = (uint32_t)(a.chain_offset + gcl);
+
+#pragma unroll
+  for (int k = 0; k < NLEV; ++k) {
+    for (int i = tid; i < a.lv[k].m_pad; i += 256) {
+      s_stage[a.lds_y[k] + i] = a.lv[k].ytil[i];
+      if (a.lv[k].noise_kind == 1) s_stage[a.lds_w[k] + i] = a.lv[k].w[i];
+    }
+  }
+  if (prior_dense)
+    for (int i = tid; i < a.pr.ncb * 16; i += 256) s_py[i] = a.pr.wmu[i];
+
+  double pm[KS], pinv[KS];
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    pm[kk] = a.pr.mean[4 * kk + hi];
+    pinv[kk] = prior_dense ? 0.0 : a.pr.pinv[4 * kk + hi];
+  }
+
+  // ---- per-chain state: thread-mapped parameter slices, lane-mapped scalars ----
+  double cur[NLEV][EPT], snp[EPT], prp[EPT], xin[EPT];
+  double lp[NLEV], ll[NLEV], Slp[NPAIR > 0 ? NPAIR : 1], Sll[NPAIR > 0 ? NPAIR : 1];
+  int anyacc[NLEV];
+#pragma unroll
+  for (int k = 0; k < NLEV; ++k) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+      cur[k][e] = active ? a.theta[((size_t)k * a.NP + gct) * DPAD + q_ * EPT + e] : 0.0;
+    lp[k] = a.lp[(size_t)k * a.NP + gcl];
+    ll[k] = a.ll[(size_t)k * a.NP + gcl];
+    anyacc[k] = a.anyacc[(size_t)k * a.NP + gcl];
+  }
+#pragma unroll
+  for (int p = 0; p < NPAIR; ++p) {
+    Slp[p] = a.Sst[((size_t)p * 2 + 0) * a.NP + gcl];
+    Sll[p] = a.Sst[((size_t)p * 2 + 1) * a.NP + gcl];
+  }
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    snp[e] = active ? a.ysnap[gct * LDP + q_ * EPT + e] : 0.0;
+    xin[e] = active ? a.inc[(size_t)gct * DPAD + q_ * EPT + e] : 0.0;
+  }
+  double snap_lp = a.ysnap[gcl * LDP + DPAD], snap_ll = a.ysnap[gcl * LDP + DPAD + 1];
+  int pick = a.pick[gcl];
+  const double scal_t = a.scaling[gct];
+  const bool is_pcn = a.prop_kind == 1;
+  const double keep_t = is_pcn ? sqrt(1.0 - scal_t * scal_t) : 1.0;
+  double unext = a.u0[gcl];
+
+  int cnt[NLEV];
+  int64_t stepno[NLEV];  // local step index (global, for RNG) of the NEXT step of level k
+  int nrec[NLEV];        // records written by this launch per level
+#pragma unroll
+  for (int k = 0; k < NLEV; ++k) {
+    cnt[k] = a.cnt[k];
+    stepno[k] = a.done[k];
+    nrec[k] = 0;
+  }
+  int64_t ringpos = a.ring_pos;
+  const double2* fbase = reinterpret_cast<const double2*>(a.lv[0].Apk) + lane;
+  double2 f0[KS / 2], f1[KS / 2];
+  __syncthreads();
+
+  // evaluate level `k` at the state currently in s_prop (all 4 waves); returns (lp_n, ll_n) lane-mapped
+  auto evaluate = [&](int k, double2 (&g0)[KS / 2], double2 (&g1)[KS / 2], double& lp_n, double& ll_n) {
+    double th[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) th[kk] = s_prop[lc * LDP + 4 * kk + hi];
+    double maha = 0.0;
+    if (!prior_dense) {
+      double p = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        const double dv = th[kk] - pm[kk];
+        p += dv * dv * pinv[kk];
+      }
+      p += __shfl_xor(p, 16);
+      p += __shfl_xor(p, 32);
+      maha = p;
+    } else {
+      const double2* pbase = reinterpret_cast<const double2*>(a.pr.Wpk) + lane;
+      double2 p0[KS / 2], p1[KS / 2];
+      frag_load<DPAD>(pbase, wave, a.pr.ncb, p0);
+      frag_load<DPAD>(pbase, wave + 4, a.pr.ncb, p1);
+      double p = level_sse_partial<DPAD, false>(a.pr.Wpk, a.pr.ncb, s_py, nullptr, th, wave, lane, p0, p1);
+      p += __shfl_xor(p, 16);
+      p += __shfl_xor(p, 32);
+      if (lane < 16) s_redp[wave * 16 + lane] = p;
+    }
+    const LevelDev& L = a.lv[k];
+    const bool dg = L.noise_kind == 1;
+    double sse = dg ? level_sse_partial<DPAD, true>(L.Apk, L.ncb, s_stage + a.lds_y[k], s_stage + a.lds_w[k], th, wave, lane, g0, g1)
+                    : level_sse_partial<DPAD, false>(L.Apk, L.ncb, s_stage + a.lds_y[k], nullptr, th, wave, lane, g0, g1);
+    sse += __shfl_xor(sse, 16);
+    sse += __shfl_xor(sse, 32);
+    if (lane < 16) s_red[wave * 16 + lane] = sse;
+    __syncthreads();
+    const double tot = ((s_red[lc] + s_red[16 + lc]) + s_red[32 + lc]) + s_red[48 + lc];
+    if (prior_dense) maha = ((s_redp[lc] + s_redp[16 + lc]) + s_redp[32 + lc]) + s_redp[48 + lc];
+    ll_n = dg ? -0.5 * tot : -0.5 * tot / L.var;
+    lp_n = -0.5 * (a.pr.logconst + maha);
+  };
+
+  for (int s = 0; s < a.S; ++s) {
+    // ================= level 0: one Metropolis-Hastings step =================
+    frag_load<DPAD>(fbase, wave, a.lv[0].ncb, f0);
+    frag_load<DPAD>(fbase, wave + 4, a.lv[0].ncb, f1);
+    if (a.randomize && cnt[0] == 0) {  // DA: draw the promoted index of the subchain that starts now
+      const int L0 = a.sl[0];
+      if (a.ridx_rep) {
+        const double r = a.ridx_rep[(size_t)(stepno[1] - a.done[1]) * a.N + (gcl < a.N ? gcl : 0)];
+        pick = (r != r) ? L0 - 1 : (int)r + L0;  // reference index in [-L, -1] (chain.py:525-527)
+      } else {
+        const u32x4 r = philox4x32_10(u32x4{0u, (uint32_t)stepno[1], gchain, STREAM_INDEX}, (uint32_t)a.seed,
+                                      (uint32_t)(a.seed >> 32));
+        pick = (int)(((uint64_t)r.x * (uint64_t)L0) >> 32);
+      }
+    }
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const double sx = scal_t * xin[e];
+        prp[e] = is_pcn ? keep_t * cur[0][e] + sx : cur[0][e] + sx;
+        s_prop[c * LDP + q_ * EPT + e] = prp[e];
+      }
+    }
+    const double u = unext;
+    if (s + 1 < a.S) {
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) xin[e] = a.inc[((size_t)(s + 1) * a.NP + gct) * DPAD + q_ * EPT + e];
+      }
+      unext = a.u0[(size_t)(s + 1) * a.NP + gcl];
+    }
+    __syncthreads();
+    double lp_n, ll_n;
+    evaluate(0, f0, f1, lp_n, ll_n);
+    const double post_n = lp_n + ll_n;
+    double alpha = is_pcn ? exp(ll_n - ll[0]) : exp(post_n - (lp[0] + ll[0]));
+    if (post_n != post_n) alpha = 0.0;
+    const bool acc0 = u < alpha;
+    if (acc0) {
+      lp[0] = lp_n;
+      ll[0] = ll_n;
+    }
+    anyacc[0] |= acc0 ? 1 : 0;
+    {
+      const int accf = __shfl(acc0 ? 1 : 0, c);
+      const bool take = a.randomize && cnt[0] == pick;
+      const int takef = __shfl(take ? 1 : 0, c);
+      if (take) {
+        snap_lp = lp[0];
+        snap_ll = ll[0];
+      }
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          cur[0][e] = accf ? prp[e] : cur[0][e];
+          if (takef) snp[e] = cur[0][e];
+          const int j = q_ * EPT + e;
+          if (a.rec_params[0] && gct < a.N && j < a.d)
+            a.rec_params[0][((size_t)nrec[0] * a.N + gct) * a.d + j] = cur[0][e];
+        }
+      }
+    }
+    if (wave == 0 && lane < 16) {
+      if (gcl < a.N) {
+        const size_t r = (size_t)nrec[0] * a.N + gcl;
+        if (a.rec_stats[0]) {
+          a.rec_stats[0][r * 3 + 0] = lp[0];
+          a.rec_stats[0][r * 3 + 1] = ll[0];
+          a.rec_stats[0][r * 3 + 2] = lp[0] + ll[0];
+        }
+        if (a.rec_acc[0]) a.rec_acc[0][r] = acc0 ? 1 : 0;
+      }
+      a.ring[(size_t)(ringpos % a.ring_P) * a.NP + gcl] = acc0 ? 1 : 0;
+    }
+    ringpos += 1;
+    nrec[0] += 1;
+    stepno[0] += 1;
+    cnt[0] += 1;
+
+    // ================= upper levels whose subchain just completed =================
+#pragma unroll
+    for (int k = 0; k < NLEV - 1; ++k) {
+      if (cnt[k] != a.sl[k]) break;
+      const int q = k + 1;
+      const bool use_snap = (a.randomize != 0) && k == 0;
+      // y -> LDS for the fragment gather
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) s_prop[c * LDP + q_ * EPT + e] = use_snap ? snp[e] : cur[k][e];
+      }
+      const double2* gb = reinterpret_cast<const double2*>(a.lv[q].Apk) + lane;
+      double2 g0[KS / 2], g1[KS / 2];
+      frag_load<DPAD>(gb, wave, a.lv[q].ncb, g0);
+      frag_load<DPAD>(gb, wave + 4, a.lv[q].ncb, g1);
+      __syncthreads();
+      double lpq, llq;
+      evaluate(q, g0, g1, lpq, llq);
+      const double y_lp = use_snap ? snap_lp : lp[k], y_ll = use_snap ? snap_ll : ll[k];
+      const int pkq = pair_index(k, q);
+      double uq;
+      if (a.u_rep[q])
+        uq = a.u_rep[q][(size_t)(stepno[q] - a.done[q]) * a.N + (gcl < a.N ? gcl : 0)];
+      else
+        uq = accept_uniform(a.seed, gchain, (uint32_t)stepno[q], (uint32_t)q);
+      const double alq = exp(((lpq + llq) - (lp[q] + ll[q])) + (Slp[pkq] + Sll[pkq]) - (y_lp + y_ll));
+      const bool accq = (anyacc[k] != 0) && (uq < alq);
+      const int accf = __shfl(accq ? 1 : 0, c);
+      // parameters: accept -> level q (and level k, if a promoted intermediate state) take y;
+      //             reject -> all levels below q return to theta_q
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          const double yv = use_snap ? snp[e] : cur[k][e];
+          if (accf) {
+            cur[q][e] = yv;
+            cur[k][e] = yv;
+          } else {
+#pragma unroll
+            for (int j = 0; j < q; ++j) cur[j][e] = cur[q][e];
+          }
+        }
+      }
+      if (accq) {
+        lp[q] = lpq;
+        ll[q] = llq;
+        lp[k] = y_lp;
+        ll[k] = y_ll;
+      } else {
+#pragma unroll
+        for (int j = 0; j < q; ++j) {
+          lp[j] = Slp[pair_index(j, q)];
+          ll[j] = Sll[pair_index(j, q)];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < q; ++j) {
+#pragma unroll
+        for (int q2 = j + 1; q2 <= q; ++q2) {
+          Slp[pair_index(j, q2)] = lp[j];
+          Sll[pair_index(j, q2)] = ll[j];
+        }
+      }
+      anyacc[k] = 0;
+      if (q < NLEV - 1) anyacc[q] |= accq ? 1 : 0;
+      // records of level q and the alignment entry in the base proposal's accepted window
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          const int j = q_ * EPT + e;
+          if (a.rec_params[q] && gct < a.N && j < a.d)
+            a.rec_params[q][((size_t)nrec[q] * a.N + gct) * a.d + j] = cur[q][e];
+        }
+      }
+      if (wave == 0 && lane < 16) {
+        if (gcl < a.N) {
+          const size_t r = (size_t)nrec[q] * a.N + gcl;
+          if (a.rec_stats[q]) {
+            a.rec_stats[q][r * 3 + 0] = lp[q];
+            a.rec_stats[q][r * 3 + 1] = ll[q];
+            a.rec_stats[q][r * 3 + 2] = lp[q] + ll[q];
+          }
+          if (a.rec_acc[q]) a.rec_acc[q][r] = accq ? 1 : 0;
+        }
+        a.ring[(size_t)(ringpos % a.ring_P) * a.NP + gcl] = accq ? 1 : 0;
+      }
+      ringpos += 1;
+      nrec[q] += 1;
+      stepno[q] += 1;
+      cnt[k] = 0;
+      cnt[q] += 1;
+    }
+  }
+
+  // ---- write the state back ----
+#pragma unroll
+  for (int k = 0; k < NLEV; ++k) {
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) a.theta[((size_t)k * a.NP + gct) * DPAD + q_ * EPT + e] = cur[k][e];
+    }
+    if (wave == 0 && lane < 16) {
+      a.lp[(size_t)k * a.NP + gcl] = lp[k];
+      a.ll[(size_t)k * a.NP + gcl] = ll[k];
+      a.anyacc[(size_t)k * a.NP + gcl] = anyacc[k];
+    }
+  }
+  if (wave == 0 && lane < 16) {
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) {
+      a.Sst[((size_t)p * 2 + 0) * a.NP + gcl] = Slp[p];
+      a.Sst[((size_t)p * 2 + 1) * a.NP + gcl] = Sll[p];
+    }
+    a.ysnap[gcl * LDP + DPAD] = snap_lp;
+    a.ysnap[gcl * LDP + DPAD + 1] = snap_ll;
+    a.pick[gcl] = pick;
+  }
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) a.ysnap[gct * LDP + q_ * EPT + e] = snp[e];
   }
 }
 

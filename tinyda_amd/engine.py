@@ -29,7 +29,8 @@ class Engine:
 
     def __init__(self, n_chains, dim, seed=0, device=0, chain_offset=0, n_levels=1, block_steps=0, stream=None):
         self.lib = _lib.load()
-        self.n_chains, self.dim = int(n_chains), int(dim)
+        self.n_chains, self.dim, self.n_levels = int(n_chains), int(dim), int(n_levels)
+        self.subchain_lengths = []
         cfg = _lib.tda_config(C.sizeof(_lib.tda_config), device, n_chains, chain_offset, dim, n_levels, seed,
                               stream, block_steps, 0)
         h = C.c_void_p()
@@ -68,6 +69,12 @@ class Engine:
                                      _ptr(Cm), -1.0 if sd is None else sd, epsilon, t0, 0)
         check(self.lib.tda_engine_set_proposal(self.h, C.byref(p)))
 
+    def set_subchains(self, lengths, randomize=False):
+        arr = np.ascontiguousarray(np.asarray(lengths, dtype=np.int32))
+        assert arr.shape == (self.n_levels - 1,)
+        self.subchain_lengths = [int(x) for x in arr]
+        check(self.lib.tda_engine_set_subchains(self.h, _ptr(arr), int(randomize)))
+
     def init(self, theta0=None):
         if theta0 is not None and isinstance(theta0, np.ndarray):
             theta0 = _f64(theta0)
@@ -84,6 +91,15 @@ class Engine:
         assert z.shape[1:] == (self.n_chains, self.dim) and u.shape == z.shape[:2]
         check(self.lib.tda_engine_set_replay(self.h, _ptr(z), _ptr(u), z.shape[0]))
 
+    def set_replay_level(self, level, u):
+        """uniforms of level >= 1 as [steps of that level, chains]; level = -1: DA promoted index in [-L, -1]"""
+        if u is None:
+            check(self.lib.tda_engine_set_replay_level(self.h, level, None, 0))
+            return
+        u = _f64(u)
+        assert u.shape[1] == self.n_chains
+        check(self.lib.tda_engine_set_replay_level(self.h, level, _ptr(u), u.shape[0]))
+
     def set_export(self, n_steps):
         z = np.zeros((n_steps, self.n_chains, self.dim))
         u = np.zeros((n_steps, self.n_chains))
@@ -97,6 +113,35 @@ class Engine:
         check(self.lib.tda_engine_run(self.h, n_iterations, C.byref(out)))
         if sync:
             self.sync()
+
+    def rows_per_level(self, n_iterations):
+        """records each level produces for n_iterations finest-level steps (include/tinyda_amd.h, tda_outputs)"""
+        rows = [n_iterations]
+        for L in reversed(self.subchain_lengths):
+            rows.insert(0, rows[0] * L)
+        return rows
+
+    def run_levels(self, n_iterations, outputs=None, sync=True):
+        """Multi-level run.  outputs: list (coarsest first) of (params, stats, accepted) arrays / tensors or None."""
+        arr = (_lib.tda_outputs * self.n_levels)()
+        for k in range(self.n_levels):
+            p, s_, a = outputs[k] if outputs and outputs[k] is not None else (None, None, None)
+            arr[k] = _lib.tda_outputs(C.sizeof(_lib.tda_outputs), 0, _ptr(p), _ptr(s_), _ptr(a))
+        check(self.lib.tda_engine_run(self.h, n_iterations, arr))
+        if sync:
+            self.sync()
+
+    def run_levels_host(self, n_iterations):
+        N, d = self.n_chains, self.dim
+        outs = [(np.empty((r, N, d)), np.empty((r, N, 3)), np.empty((r, N), dtype=np.uint8))
+                for r in self.rows_per_level(n_iterations)]
+        self.run_levels(n_iterations, outs)
+        return outs
+
+    def level_state(self, level):
+        th, st = np.empty((self.n_chains, self.dim)), np.empty((self.n_chains, 3))
+        check(self.lib.tda_engine_get_level_state(self.h, level, _ptr(th), _ptr(st)))
+        return th, st
 
     def run_host(self, n_iterations):
         """Convenience: run and return numpy records (params [T,N,d], stats [T,N,3], accepted [T,N])."""
