@@ -24,7 +24,8 @@ x = torch.randn(10, 3, generator=g, dtype=torch.float64)[off:off + cnt]
 mean = x.mean(0)
 m2 = (x - mean).T @ (x - mean)
 n, mu, M2 = tdist.gather_moments(cnt, mean, m2)
-print("RESULT" + json.dumps(dict(rank=rank, off=off, cnt=cnt, mx=mx, sm=sm, n=n, mu=mu.tolist(), M2=M2.tolist())))
+with open(os.path.join(%(out)r, "rank%%d.json" %% rank), "w") as fh:
+    json.dump(dict(rank=rank, off=off, cnt=cnt, mx=mx, sm=sm, n=n, mu=mu.tolist(), M2=M2.tolist()), fh)
 """
 
 
@@ -38,7 +39,7 @@ def test_shard_chains_partition():
 
 def test_world_size_2_gloo(tmp_path):
     script = tmp_path / "w.py"
-    script.write_text(_WORKER % {"root": ROOT})
+    script.write_text(_WORKER % {"root": ROOT, "out": str(tmp_path)})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
                         "127.0.0.1", "--master-port", "29617", str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
@@ -46,7 +47,7 @@ def test_world_size_2_gloo(tmp_path):
     assert r.returncode == 0, r.stdout[-3000:]
     import json
 
-    res = sorted((json.loads(l.split("RESULT", 1)[1]) for l in r.stdout.splitlines() if "RESULT" in l), key=lambda d: d["rank"])
+    res = [json.load(open(tmp_path / ("rank%d.json" % k))) for k in range(2)]
     assert [d["off"] for d in res] == [0, 5] and [d["cnt"] for d in res] == [5, 5]
     assert all(d["mx"] == 2.0 and d["sm"] == 10.0 and d["n"] == 10.0 for d in res)
     import torch

@@ -245,3 +245,48 @@ def test_full_size_properties(eng_mod):
     rate = Acc.mean()
     assert 0.05 < rate < 0.9, rate
     e.close()
+
+
+def test_sample_api_on_device(eng_mod):
+    """tinyda_amd.sample end to end on the GPU: MH / DA / MLDA result dicts with the reference's keys and lengths."""
+    import scipy.stats as st
+
+    import tinyda_amd as tda
+
+    rng = np.random.default_rng(3)
+    d = 5
+    truth = rng.standard_normal(d)
+    prior = st.multivariate_normal(np.zeros(d), np.eye(d))
+    posts = []
+    for m in (8, 16, 30):
+        A = rng.standard_normal((m, d)) / np.sqrt(d)
+        posts.append(tda.Posterior(prior, tda.GaussianLogLike(A @ truth + 0.1 * rng.standard_normal(m), 0.01 * np.eye(m)),
+                                   tda.LinearModel(A)))
+    A2 = posts[2].model.A
+    cov2 = np.linalg.inv(A2.T @ A2 / 0.01 + np.eye(d))
+    mean2 = cov2 @ (A2.T @ posts[2].likelihood.data / 0.01)
+    start = [mean2 + 0.01 * rng.standard_normal(d) for _ in range(24)]
+    res = tda.sample(posts[2], tda.AdaptiveMetropolis(1e-3 * np.eye(d), t0=50, period=50), 400, n_chains=24, seed=5,
+                     initial_parameters=start)
+    assert res["sampler"] == "MH" and res["backend"] == "hip" and res["iterations"] == 401 and len(res["chain_23"]) == 401
+    link = res["chain_3"][400]
+    assert isinstance(link, tda.Link) and link.model_output.shape == (30,)
+    ref = posts[2].create_link(link.parameters)
+    np.testing.assert_allclose([link.prior, link.likelihood], [ref.prior, ref.likelihood], rtol=1e-10)
+    s = tda.get_samples(res, burnin=200)
+    assert s["chain_0"].shape == (201, d)
+    pooled = np.concatenate([s["chain_%d" % i] for i in range(24)])
+    # loose sanity check of the sampled posterior against the conjugate answer (parity is tested elsewhere)
+    assert np.all(np.abs(pooled.mean(0) - mean2) < 1.0 * np.sqrt(np.diag(cov2)))
+    assert np.all(np.abs(pooled.std(0) / np.sqrt(np.diag(cov2)) - 1) < 0.5)
+
+    da = tda.sample(posts[1:], tda.CrankNicolson(scaling=0.2), 50, n_chains=8, subsampling_rate=4, seed=6)
+    assert da["sampler"] == "DA" and da["iterations"] == 51 and da["subchain_length"] == 4
+    assert len(da["chain_fine_0"]) == 51 and len(da["chain_coarse_7"]) == 200
+    assert tda.get_samples(da, level="coarse")["chain_0"].shape == (200, d)
+    assert tda.sample(posts[1:], tda.CrankNicolson(), 5, n_chains=2, subchain_length=2, store_coarse_chain=False, seed=1)["chain_coarse_1"] is None
+
+    ml = tda.sample(posts, tda.AdaptiveMetropolis(1e-2 * np.eye(d), t0=20, period=20), 30, n_chains=8, subchain_length=[3, 2], seed=7)
+    assert ml["sampler"] == "MLDA" and ml["levels"] == 3 and ml["subchain_lengths"] == [3, 2]
+    assert len(ml["chain_l2_0"]) == 31 and len(ml["chain_l1_0"]) == 60 and len(ml["chain_l0_0"]) == 180
+    assert tda.get_samples(ml, level=1)["iterations"] == 60

@@ -161,3 +161,26 @@ def test_lowering_pass():
         pass
 
     assert _device_plan([tda.Posterior(prior, like, tda.LinearModel(A))], Custom(np.eye(4))) is None
+
+
+def test_multilevel_lowering_and_argument_checks():
+    from tinyda_amd.sampler import _device_plan
+
+    rng = np.random.default_rng(1)
+    prior = stats.multivariate_normal(np.zeros(4), np.eye(4))
+    posts = [tda.Posterior(prior, tda.GaussianLogLike(np.zeros(m), 0.1 * np.eye(m)), tda.LinearModel(rng.standard_normal((m, 4))))
+             for m in (6, 12, 20)]
+    assert _device_plan(posts, tda.CrankNicolson()) is not None
+    other = tda.Posterior(stats.multivariate_normal(np.ones(4), np.eye(4)), posts[1].likelihood, posts[1].model)
+    assert _device_plan([posts[0], other], tda.CrankNicolson()) is None  # priors must agree across levels
+    with pytest.raises(ValueError):
+        tda.sample(posts[:2], tda.CrankNicolson(), 5, subchain_length=1, randomize_subchain_length=True)
+    with pytest.raises(ValueError):
+        tda.sample(posts[:2], tda.CrankNicolson(), 5, subchain_length=3, randomize_subchain_length=True, store_coarse_chain=False)
+    with pytest.raises(ValueError):
+        tda.sample(posts, tda.CrankNicolson(), 5, subchain_length=[3])
+    with pytest.raises(NotImplementedError):
+        tda.sample(posts[:2], tda.CrankNicolson(), 5, adaptive_error_model="state-independent")
+    with pytest.warns(UserWarning):  # deprecated alias still accepted (sampler.py:113-115)
+        with pytest.raises(tda.EngineError):
+            tda.sample(posts[:2], tda.CrankNicolson(), 5, subsampling_rate=10)

@@ -17,16 +17,25 @@ from .results import DeviceChain
 _DEVICE_PROPOSALS = (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis)
 
 
+MAX_LEVELS = 4
+
+
 def _device_plan(posteriors, proposal):
-    """Lowering pass: returns (level description, proposal description) or None."""
-    if len(posteriors) != 1 or type(proposal) not in _DEVICE_PROPOSALS:
+    """Lowering pass: returns (list of level descriptions, proposal description) or None."""
+    if not 1 <= len(posteriors) <= MAX_LEVELS or type(proposal) not in _DEVICE_PROPOSALS:
         return None
-    low = getattr(posteriors[0], "_lowering", lambda: None)()
-    if low is None or low["prior_mean"].shape[0] > 64:
-        return None
-    if low["noise_kind"] == _lib.NOISE_DENSE:
-        return None  # dense data covariance is evaluated on the host protocol for now
-    return low, proposal._lowering()
+    lows = []
+    for post in posteriors:
+        low = getattr(post, "_lowering", lambda: None)()
+        if low is None or low["prior_mean"].shape[0] > 64:
+            return None
+        if low["noise_kind"] == _lib.NOISE_DENSE:
+            return None  # dense data covariance is evaluated on the host protocol for now
+        lows.append(low)
+    for low in lows[1:]:  # one prior for the hierarchy (every tinyDA example shares it across levels)
+        if not (np.array_equal(low["prior_mean"], lows[0]["prior_mean"]) and np.array_equal(low["prior_cov"], lows[0]["prior_cov"])):
+            return None
+    return lows, proposal._lowering()
 
 
 def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None, subchain_length=1,
@@ -47,10 +56,23 @@ def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None
     ):
         raise TypeError("Prior must be of type scipy.stats.multivariate_normal for pCN proposal")
 
-    if len(posteriors) > 1:
-        raise NotImplementedError(
-            "Delayed Acceptance / MLDA (len(posteriors) > 1) is not built yet in tinyda_amd; see DESIGN.md scope table"
-        )
+    n_levels = len(posteriors)
+    if n_levels > 1:
+        if adaptive_error_model is not None:
+            raise NotImplementedError("adaptive_error_model is not lowered to the device engine yet (DESIGN.md scope table)")
+        if randomize_subchain_length:  # chain.py:310-314
+            if n_levels != 2:
+                raise NotImplementedError("randomize_subchain_length is a Delayed Acceptance (two-level) option")
+            if subchain_length == 1:
+                raise ValueError("Randomize subchain length requires a subchain_length > 1.")
+            if not store_coarse_chain:
+                raise ValueError("Randomize subchain length requires storing the coarse chain.")
+        if isinstance(subchain_length, (list, tuple)):  # sampler.py:260-264
+            subchain_lengths = [int(x) for x in subchain_length]
+            if len(subchain_lengths) != n_levels - 1:
+                raise ValueError("subchain_length list must have length len(posteriors) - 1")
+        else:
+            subchain_lengths = [int(subchain_length)] * (n_levels - 1)
 
     # initial parameters (sampler.py:196-209)
     if initial_parameters is not None:
@@ -68,8 +90,15 @@ def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None
     if backend == "hip" and plan is None:
         raise _lib.EngineError("this posterior / proposal combination cannot be lowered to the HIP engine")
     if plan is not None:
-        return _sample_device(plan, posteriors[0], iterations, n_chains, initial_parameters, seed, device,
-                              chain_offset)
+        if n_levels == 1:
+            return _sample_device(plan, posteriors[0], iterations, n_chains, initial_parameters, seed, device,
+                                  chain_offset)
+        return _sample_device_multilevel(plan, posteriors, iterations, n_chains, initial_parameters, subchain_length,
+                                         subchain_lengths, randomize_subchain_length, store_coarse_chain, seed, device,
+                                         chain_offset)
+    if n_levels > 1:
+        raise NotImplementedError("Delayed Acceptance / MLDA with opaque Python forward models has no host driver in "
+                                  "tinyda_amd; declare the models as tinyda_amd.LinearModel")
     return _sample_host(posteriors[0], proposal, iterations, n_chains, initial_parameters)
 
 
@@ -90,7 +119,8 @@ def _sample_host(posterior, proposal, iterations, n_chains, initial_parameters):
 def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, seed, device, chain_offset):
     from .engine import Engine  # raises EngineError when libtinyda_hip.so is missing: no CPU fallback
 
-    low, prop = plan
+    lows, prop = plan
+    low = lows[0]
     d = low["prior_mean"].shape[0]
     if seed is None:
         seed = int(np.random.randint(0, 2 ** 31 - 1))
@@ -115,4 +145,63 @@ def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, se
               "seed": seed, "proposal_state": state}
     for i in range(n_chains):
         result["chain_{}".format(i)] = DeviceChain(params[:, i], stat[:, i], acc[:, i], posterior.model)
+    return result
+
+
+def _sample_device_multilevel(plan, posteriors, iterations, n_chains, initial_parameters, subchain_length,
+                              subchain_lengths, randomize, store_coarse_chain, seed, device, chain_offset):
+    """Delayed Acceptance (2 levels, result of sampler.py:406-439) and MLDA (>= 3 levels, :510-547) on the device."""
+    from .engine import Engine
+
+    lows, prop = plan
+    nl = len(lows)
+    d = lows[0]["prior_mean"].shape[0]
+    if seed is None:
+        seed = int(np.random.randint(0, 2 ** 31 - 1))
+    eng = Engine(n_chains, d, seed=seed, device=device, chain_offset=chain_offset, n_levels=nl)
+    try:
+        eng.set_prior(lows[0]["prior_mean"], lows[0]["prior_cov"])
+        for k, low in enumerate(lows):
+            eng.set_level(k, low["A"], low["data"], low["noise_kind"], low["noise"], b=low["b"])
+        eng.set_proposal(**prop)
+        eng.set_subchains(subchain_lengths, randomize)
+        theta0 = None if initial_parameters is None else np.stack([np.asarray(p, float) for p in initial_parameters])
+        eng.init(theta0)
+        T, N = iterations, n_chains
+        rows = eng.rows_per_level(T)
+        outs = []
+        for k in range(nl):
+            if k < nl - 1 and not store_coarse_chain:
+                outs.append(None)
+                continue
+            extra = 1 if k == nl - 1 else 0  # only the finest chain carries the initial link
+            outs.append((np.empty((rows[k] + extra, N, d)), np.empty((rows[k] + extra, N, 3)),
+                         np.ones((rows[k] + extra, N), dtype=np.uint8)))
+        pf, sf, af = outs[nl - 1]
+        pf[0], sf[0] = eng.level_state(nl - 1)
+        run_outs = [o if (o is None or k < nl - 1) else (o[0][1:], o[1][1:], o[2][1:]) for k, o in enumerate(outs)]
+        if T > 0:
+            eng.run_levels(T, run_outs)
+    finally:
+        eng.close()
+
+    def chain_of(k, i):
+        if outs[k] is None:
+            return None
+        p, s_, a = outs[k]
+        return DeviceChain(p[:, i], s_[:, i], a[:, i], posteriors[k].model)
+
+    if nl == 2:
+        result = {"sampler": "DA", "n_chains": n_chains, "iterations": iterations + 1, "subchain_length": subchain_length,
+                  "backend": "hip", "seed": seed}
+        for i in range(n_chains):
+            result["chain_coarse_{}".format(i)] = chain_of(0, i)
+        for i in range(n_chains):
+            result["chain_fine_{}".format(i)] = chain_of(1, i)
+        return result
+    result = {"sampler": "MLDA", "n_chains": n_chains, "iterations": iterations + 1, "levels": nl,
+              "subchain_lengths": subchain_lengths, "backend": "hip", "seed": seed}
+    for k in reversed(range(nl)):
+        for i in range(n_chains):
+            result["chain_l{}_{}".format(k, i)] = chain_of(k, i)
     return result

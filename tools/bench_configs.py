@@ -1,0 +1,44 @@
+"""Throughput of the other BASELINE configurations (parity-test cases, not the bench line): C3 (2-level DA, pCN,
+256/2048 obs, subsampling 10) and C5-literal (3-level MLDA 128/512/2048 obs, AM, no error model), 4096 chains."""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tinyda_amd.engine import Engine
+
+def levels(ms, d=64, seed=2, sigma=0.1):
+    rng = np.random.default_rng(seed)
+    truth = rng.standard_normal(d)
+    out = []
+    for m in ms:
+        A = rng.standard_normal((m, d)) / 8
+        out.append((A, A @ truth + sigma * rng.standard_normal(m)))
+    return out
+
+def run(name, ms, sl, prop, n_fine, N=4096, d=64):
+    lv = levels(ms)
+    e = Engine(N, d, seed=9, n_levels=len(ms))
+    e.set_prior(np.zeros(d), np.eye(d))
+    for k, (A, y) in enumerate(lv):
+        e.set_level(k, A, y, 0, 0.01)
+    e.set_proposal(**prop)
+    e.set_subchains(sl)
+    e.init(None)
+    rows = e.rows_per_level(n_fine)
+    outs = [(torch.empty((r, N, d), dtype=torch.float64, device="cuda"), torch.empty((r, N, 3), dtype=torch.float64, device="cuda"),
+             torch.empty((r, N), dtype=torch.uint8, device="cuda")) for r in rows]
+    e.run_levels(max(1, n_fine // 10), outs)  # warm-up
+    e.set_profiling(True)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    e.run_levels(n_fine, outs)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    p = e.profile()
+    res = dict(config=name, chains=N, fine_iterations=n_fine, seconds=dt, coarse_evals_per_s=N * rows[0] / dt,
+               finest_iterations_per_s=N * n_fine / dt, acceptance=[float(o[2].float().mean().item()) for o in outs], kernel_ms=p)
+    print(json.dumps(res))
+    e.close()
+
+if __name__ == "__main__":
+    run("C3: DA pCN(0.02) 256/2048 obs, subsampling_rate=10", (256, 2048), [10], dict(kind=1, scaling=0.02), 200)
+    run("C5-literal: MLDA AM 128/512/2048 obs, subchains [5,3], no AEM", (128, 512, 2048), [5, 3],
+        dict(kind=2, C_=1e-4 * np.eye(64), t0=100, period=100), 60)
