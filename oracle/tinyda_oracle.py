@@ -483,3 +483,100 @@ def run_multilevel(levels, proposal, subchain_lengths, theta0, z, u_levels, n_fi
         out.append(dict(theta=np.swapaxes(np.array(r["theta"]), 0, 1), logprior=lpk, loglike=llk, logpost=lpk + llk,
                         accepted=np.array(r["accepted"]).T.astype(np.uint8)))
     return out, prop
+
+
+# ----------------------------------------------------------------------------------------
+# DREAM(Z) (proposal.py:608-852) inside the single-level chain (chain.py:95-125)
+# ----------------------------------------------------------------------------------------
+def rosenbrock_forward(theta, a=1.0, b=10.0):
+    """d-dimensional chain of examples/MALA Rosenbrock.ipynb's scalar 'forward model'; returns [N, 1]."""
+    t = np.atleast_2d(theta)
+    return np.sum((a - t[:, :-1]) ** 2 + b * (t[:, 1:] - t[:, :-1] ** 2) ** 2, axis=1, keepdims=True)
+
+
+class RosenbrockLevel:
+    """Posterior with the Rosenbrock forward model, data [0], isotropic unit-variance likelihood."""
+
+    def __init__(self, prior, a=1.0, b=10.0, data=0.0, var=1.0):
+        self.prior, self.a, self.b, self.data, self.var = prior, a, b, data, var
+
+    def evaluate(self, theta):
+        F = rosenbrock_forward(theta, self.a, self.b)
+        return self.prior.logpdf(theta), loglike_isotropic(F, np.array([self.data]), self.var), F
+
+
+def dreamz_jump(theta, Zr1, Zr2, mcr, sub_u, forced, e_u, eps_n, scaling, nCR, delta, b, b_star):
+    """DREAMZ.make_proposal (proposal.py:811-852) for a batch, given the variates it would have drawn:
+    Zr1 / Zr2 [N, d] = sums of the selected archive rows, mcr [N] crossover index, sub_u [N, d] subspace
+    uniforms, forced [N] index used when the subspace came out empty, e_u [N, d] uniforms mapped to (-b, b),
+    eps_n [N, d] standard normals scaled by b_star."""
+    N, d = theta.shape
+    CR = (mcr + 1) / nCR
+    ind = (sub_u < CR[:, None]).astype(float)
+    empty = ind.sum(axis=1) == 0
+    rows = np.nonzero(empty)[0]
+    ind[rows, forced[rows].astype(int)] = 1.0
+    gamma = scaling * 2.38 / np.sqrt(2 * delta * ind.sum(axis=1))
+    e = -b + (b - (-b)) * e_u
+    eps = 0.0 + b_star * eps_n
+    return theta + ind * ((np.ones(d) + e) * gamma[:, None] * (Zr1 - Zr2) + eps)
+
+
+def run_dreamz(level, cfg, theta0, Z0, var):
+    """N chains x T steps of Chain.sample with a DREAMZ proposal on recorded variates.
+    cfg: M0, delta, nCR, adaptive, period, gamma, b, b_star.  Z0 [N, M0, d] initial archives.
+    var: r [N,T,delta,2], mcr [N,T], sub_u [N,T,d], forced [N,T], e_u [N,T,d], eps_n [N,T,d], u [N,T]."""
+    theta0 = np.asarray(theta0, dtype=float)
+    N, d = theta0.shape
+    T = var["u"].shape[1]
+    M0, delta, nCR = int(cfg["M0"]), int(cfg["delta"]), int(cfg["nCR"])
+    adaptive, period, gam = bool(cfg["adaptive"]), int(cfg["period"]), float(cfg["gamma"])
+    b, b_star = float(cfg["b"]), float(cfg["b_star"])
+    Z = np.empty((N, M0 + T, d))
+    Z[:, :M0] = Z0
+    M = M0
+    scaling = np.ones(N)  # proposal.py:715
+    pCR = np.full((N, nCR), 1.0 / nCR)
+    LCR = np.zeros((N, nCR))
+    DeltaCR = np.ones((N, nCR))
+    theta = theta0.copy()
+    lp, ll, _ = level.evaluate(theta)
+    out_theta = np.empty((N, T + 1, d))
+    out_lp, out_ll = np.empty((N, T + 1)), np.empty((N, T + 1))
+    out_acc = np.ones((N, T + 1), dtype=np.uint8)
+    out_theta[:, 0], out_lp[:, 0], out_ll[:, 0] = theta, lp, ll
+    t = k = 0
+    rows = np.arange(N)
+    for s in range(T):
+        r = var["r"][:, s].astype(int)  # [N, delta, 2]
+        Zr1 = sum(Z[rows, r[:, i, 0]] for i in range(delta))
+        Zr2 = sum(Z[rows, r[:, i, 1]] for i in range(delta))
+        mcr = var["mcr"][:, s].astype(int)
+        prop = dreamz_jump(theta, Zr1, Zr2, mcr, var["sub_u"][:, s], var["forced"][:, s], var["e_u"][:, s],
+                           var["eps_n"][:, s], scaling, nCR, delta, b, b_star)
+        lpn, lln, _ = level.evaluate(prop)
+        alpha = _acceptance("grw", lpn, lln, lp, ll)
+        acc = var["u"][:, s] < alpha
+        prev = theta
+        theta = np.where(acc[:, None], prop, theta)
+        lp, ll = np.where(acc, lpn, lp), np.where(acc, lln, ll)
+        out_theta[:, s + 1], out_lp[:, s + 1], out_ll[:, s + 1], out_acc[:, s + 1] = theta, lp, ll, acc
+        # ---- adapt (proposal.py:790-809 after :228-245) ----
+        t += 1
+        boundary = adaptive and t % period == 0
+        if boundary:
+            rate = out_acc[:, : s + 2][:, -period:].mean(axis=1)
+            scaling = np.exp(np.log(scaling) + gam ** -k * (rate - 0.24))
+            k += 1
+        Z[:, M] = theta
+        M += 1
+        if boundary:
+            jd = theta - prev
+            inc = (jd ** 2 / np.var(Z[:, :M], axis=1)).sum(axis=1)
+            DeltaCR[rows, mcr] += inc
+            LCR[rows, mcr] += 1
+            ok = np.all(LCR > 0, axis=1)
+            mean = DeltaCR / np.where(LCR > 0, LCR, 1.0)
+            pCR = np.where(ok[:, None], mean / mean.sum(axis=1, keepdims=True), pCR)
+    return dict(theta=out_theta, logprior=out_lp, loglike=out_ll, logpost=out_lp + out_ll, accepted=out_acc,
+                scaling=scaling, pCR=pCR, archive=Z)

@@ -489,6 +489,79 @@ def g5_mlda(name, proposal_kind, d=6, ms=(8, 14, 24), sl=(3, 2), iters=40, n_cha
          subchain_lengths=np.array(sl), n_levels=np.array(nl), **lv, **flat, **arrays)
 
 
+def rosenbrock_model(a=1.0, b=10.0):
+    """d-dimensional chain of the notebook's 2-D Rosenbrock 'forward model' (examples/MALA Rosenbrock.ipynb):
+    one scalar output, data [0], unit variance -> loglike = -f(theta)^2 / 2."""
+    return lambda th: np.array([np.sum((a - th[:-1]) ** 2 + b * (th[1:] - th[:-1] ** 2) ** 2)])
+
+
+def g6_dreamz(name, problem, d, M0, delta, nCR, adaptive, period, iters, n_chains, seed, b=5e-2, b_star=1e-6, m=12):
+    rng = np.random.default_rng(seed)
+    pm, pc = np.zeros(d), np.eye(d)
+    prior = stats.multivariate_normal(pm, pc)
+    extra = {}
+    if problem == "linear":
+        A, theta_true, y = linear_problem(seed, d, m, sigma=0.3)
+        like = tda.GaussianLogLike(y, 0.09 * np.eye(m))
+        post = tda.Posterior(prior, like, make_model(A))
+        extra = dict(A=A, data=y, noise_var=np.array(0.09))
+    else:
+        like = tda.GaussianLogLike(np.zeros(1), np.eye(1))
+        post = tda.Posterior(prior, like, rosenbrock_model(1.0, 10.0))
+        extra = dict(rosen_a=np.array(1.0), rosen_b=np.array(10.0), data=np.zeros(1), noise_var=np.array(1.0))
+    theta0 = 0.5 * rng.standard_normal((n_chains, d))
+    keys = ("Z0", "r", "mcr", "sub_u", "forced", "e_u", "eps_n", "u", "theta", "logprior", "loglike", "accepted", "pCR",
+            "scaling")
+    out = {k: [] for k in keys}
+    for c in range(n_chains):
+        np.random.seed(seed + 7 * c)  # scipy's prior.rvs inside setup_proposal draws from the global stream
+        prop = tda.DREAMZ(M0, delta=delta, b=b, b_star=b_star, Z_method="random", nCR=nCR, adaptive=adaptive,
+                          gamma=1.02, period=period)
+        with Tap(seed + 50 * c) as tap:
+            ch = tda.Chain(copy.deepcopy(post), prop, theta0[c].copy())
+            out["Z0"].append(np.array(ch.proposal.Z, copy=True))
+            ch.sample(iters, progressbar=False)
+        # parse the sequential log: per step  delta x choice(2) , choice() , uniform(d) , [choice()] , uniform(d) , normal(d) , u
+        it = iter(tap.log)
+        R, MC, SU, FO, EU, EN, U = [], [], [], [], [], [], []
+        for _ in range(iters):
+            rr = []
+            for _i in range(delta):
+                kind, v = next(it)
+                assert kind == "choice" and np.size(v) == 2
+                rr.append(np.array(v))
+            kind, v = next(it)
+            assert kind == "choice" and np.size(v) == 1
+            MC.append(int(v))
+            kind, v = next(it)
+            assert kind == "uniform01"
+            SU.append(v)
+            kind, v = next(it)
+            if kind == "choice":
+                FO.append(int(v))
+                kind, v = next(it)
+            else:
+                FO.append(-1)
+            assert kind == "uniform01"
+            EU.append(v)
+            kind, v = next(it)
+            assert kind == "normal01"
+            EN.append(v)
+            kind, v = next(it)
+            assert kind == "u"
+            U.append(v)
+            R.append(np.array(rr))
+        assert next(it, None) is None
+        th, lp, ll, _ = chain_trace(ch.chain)
+        for k, v in zip(("r", "mcr", "sub_u", "forced", "e_u", "eps_n", "u", "theta", "logprior", "loglike", "accepted", "pCR", "scaling"),
+                        (R, MC, SU, FO, EU, EN, U, th, lp, ll, np.array(ch.accepted, dtype=np.uint8), ch.proposal.pCR,
+                         float(ch.proposal.scaling))):
+            out[k].append(np.array(v))
+    save(name, problem=np.array(problem), prior_mean=pm, prior_cov=pc, theta0=theta0, M0=np.array(M0), delta=np.array(delta),
+         nCR=np.array(nCR), adaptive=np.array(adaptive), period=np.array(period), gamma=np.array(1.02), b=np.array(b),
+         b_star=np.array(b_star), **extra, **{k: np.array(v) for k, v in out.items()})
+
+
 FIXTURES = {
     "g1_basic_sampler": g1_basic_sampler,
     "g2_am_small": lambda: g2_am("g2_am_small", d=8, m=16, n_chains=8, iters=128, t0=16, period=16, seed=201),
@@ -507,6 +580,12 @@ FIXTURES = {
     "g4_da_am_random": lambda: g4_da("g4_da_am_random", "am", randomize=True, period=10, seed=403, prior_kind="general"),
     "g4_da_pcn_adaptive_c3shape": lambda: g4_da("g4_da_pcn_adaptive_c3shape", "pcn", d=16, ms=(32, 96), L=10, iters=30,
                                                 adaptive=True, period=25, seed=404),
+    "g6_dreamz_linear": lambda: g6_dreamz("g6_dreamz_linear", "linear", d=6, M0=20, delta=1, nCR=3, adaptive=False, period=25,
+                                          iters=150, n_chains=4, seed=601),
+    "g6_dreamz_rosen_adaptive": lambda: g6_dreamz("g6_dreamz_rosen_adaptive", "rosenbrock", d=4, M0=30, delta=2, nCR=3,
+                                                  adaptive=True, period=25, iters=200, n_chains=4, seed=602),
+    "g6_dreamz_empty_subspace": lambda: g6_dreamz("g6_dreamz_empty_subspace", "linear", d=3, M0=12, delta=1, nCR=3,
+                                                  adaptive=True, period=20, iters=120, n_chains=3, seed=603, m=7),
     "g5_mlda_am": lambda: g5_mlda("g5_mlda_am", "am", period=10),
     "g5_mlda_grw_adaptive": lambda: g5_mlda("g5_mlda_grw_adaptive", "grw", adaptive=True, period=7, seed=502),
     "g5_mlda_4level": lambda: g5_mlda("g5_mlda_4level", "am", ms=(6, 10, 16, 24), sl=(3, 2, 2), iters=20, period=10, seed=503),
