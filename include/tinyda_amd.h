@@ -58,8 +58,8 @@ typedef enum tda_status {
 /* GaussianLogLike factory outcome, tinyDA/distributions.py:237-243 */
 typedef enum tda_noise_kind { TDA_NOISE_ISO = 0, TDA_NOISE_DIAG = 1, TDA_NOISE_DENSE = 2 } tda_noise_kind;
 
-/* tinyDA/proposal.py: GaussianRandomWalk :132, CrankNicolson :261, AdaptiveMetropolis :372 */
-typedef enum tda_proposal_kind { TDA_PROP_GRW = 0, TDA_PROP_PCN = 1, TDA_PROP_AM = 2 } tda_proposal_kind;
+/* tinyDA/proposal.py: GaussianRandomWalk :132, CrankNicolson :261, AdaptiveMetropolis :372, DREAMZ :608 / DREAM :1627 */
+typedef enum tda_proposal_kind { TDA_PROP_GRW = 0, TDA_PROP_PCN = 1, TDA_PROP_AM = 2, TDA_PROP_DREAMZ = 3 } tda_proposal_kind;
 
 typedef struct tda_config {
   uint32_t struct_size;  /* sizeof(tda_config) */
@@ -89,6 +89,23 @@ typedef struct tda_proposal_params {
   int32_t t0;        /* AM: first adapt() count at which C may be swapped (default 0) */
   int32_t reserved;
 } tda_proposal_params;
+
+/* DREAMZ / DREAM constructor arguments (proposal.py:663-742, :1627-1641). */
+typedef struct tda_dreamz_params {
+  uint32_t struct_size;
+  int32_t M0;        /* rows of the initial archive */
+  int32_t delta;     /* archive pairs per jump (1..4) */
+  int32_t nCR;       /* crossover values (1..8) */
+  double b;          /* e ~ U(-b, b) */
+  double b_star;     /* eps ~ N(0, b_star) */
+  int32_t adaptive;  /* adapt global scaling and crossover probabilities every `period` */
+  int32_t period;
+  double gamma;
+  int32_t shared;    /* 0: DREAMZ, one archive per chain; 1: DREAM, one archive for all chains (ray.py:365-384),
+                        synchronised at block boundaries instead of racily on every proposal */
+  int32_t sync_every; /* shared: steps between archive synchronisations (<= block_steps; 0 = block_steps) */
+  int64_t capacity;  /* archive rows to reserve (M0 + steps [* chains when shared]) */
+} tda_dreamz_params;
 
 /* Per-step records of one run() call; any pointer may be NULL (that record is then not produced).
  * tda_engine_run takes an ARRAY of n_levels of these, coarsest level first.  Level k < n_levels-1 gets one
@@ -130,6 +147,16 @@ int tda_engine_set_level(tda_engine* e, int level, int m, const double* A, const
                          const double* data, int noise_kind, const double* noise);
 
 int tda_engine_set_proposal(tda_engine* e, const tda_proposal_params* p);
+int tda_engine_set_proposal_dreamz(tda_engine* e, const tda_dreamz_params* p);
+
+/* Initial archive Z (DREAMZ.setup_proposal, proposal.py:744-788): [n_chains][M0][dim] (per chain) or [M0][dim]
+ * (shared).  NULL = draw the rows from the prior with RNG stream 2. Call after set_proposal_dreamz, before init. */
+int tda_engine_set_archive(tda_engine* e, const double* Z0);
+
+/* Forward model of the reference's Rosenbrock example (examples/MALA Rosenbrock.ipynb) generalised to d
+ * parameters: F(theta) = [ sum_i (a - theta_i)^2 + b (theta_{i+1} - theta_i^2)^2 ], one observation `data`,
+ * isotropic variance `noise_var`. */
+int tda_engine_set_level_rosenbrock(tda_engine* e, int level, double a, double b, double data, double noise_var);
 
 /* Multi-level schedule (sampler.py:260-264; chain.py:231-232): lengths[k], k = 0..n_levels-2, is the number of
  * level-k steps per step of level k+1.  randomize != 0 selects DAChain's randomize_subchain_length
@@ -155,6 +182,14 @@ int tda_engine_set_replay(tda_engine* e, const double* z, const double* u, int64
  * level == -1 sets the DA promoted index instead: values in [-L, -1] per fine iteration (chain.py:525-527). */
 int tda_engine_set_replay_level(tda_engine* e, int level, const double* u, int64_t n_steps);
 
+/* Parity mode for DREAMZ: everything DREAMZ.make_proposal draws, per step and chain, as recorded from the
+ * reference (tests/golden/gen_golden.py g6_*): r [T][N][delta][2] archive rows, mcr [T][N] crossover index,
+ * sub_u [T][N][d] subspace uniforms, forced [T][N] index used when the subspace is empty, e_u [T][N][d] uniforms
+ * mapped to (-b, b), eps_n [T][N][d] standard normals, u [T][N] accept uniforms. */
+int tda_engine_set_replay_dreamz(tda_engine* e, const int32_t* r, const int32_t* mcr, const double* sub_u,
+                                 const int32_t* forced, const double* e_u, const double* eps_n, const double* u,
+                                 int64_t n_steps);
+
 /* Export mode: the engine writes the variates it generated into z / u (same layout as replay),
  * so the CPU oracle can be driven with the identical stream.  NULL/0 switches export off. */
 int tda_engine_set_export(tda_engine* e, double* z, double* u, int64_t n_steps);
@@ -169,6 +204,16 @@ int tda_engine_sync(tda_engine* e);
  * am_mu[n_chains*d], am_sigma[n_chains*d*d] (RecursiveSampleMoments), counters[2] = {t, k}. */
 int tda_engine_get_proposal_state(tda_engine* e, double* scaling, double* C, double* am_mu,
                                   double* am_sigma, int64_t* counters);
+
+/* DREAMZ state, HOST pointers, any may be NULL: pCR [n_chains][nCR], archive_rows[1]. */
+int tda_engine_get_dreamz_state(tda_engine* e, double* pCR, int64_t* archive_rows);
+
+/* Shared-archive exchange for one process per GPU (DREAM over RCCL): after run() with auto-append off, take the
+ * rows this engine produced since the last exchange ([steps][n_chains][dim], device or host pointer) ... */
+int tda_engine_archive_take(tda_engine* e, double* rows, int64_t* n_steps);
+/* ... and append rows (any number, [n_rows][dim], canonical order = step-major, global chain id minor). */
+int tda_engine_archive_append(tda_engine* e, const double* rows, int64_t n_rows);
+int tda_engine_set_archive_auto_append(tda_engine* e, int on);
 
 /* Per-chain error flags (bit 0: Cholesky of an adapted covariance failed, previous factor kept). HOST. */
 int tda_engine_get_flags(tda_engine* e, int32_t* flags);

@@ -1,0 +1,160 @@
+"""GPU parity of DREAM(Z): replay of tinyDA's DREAMZ traces, Philox forward mode vs the oracle, shared archive."""
+import numpy as np
+import pytest
+
+from oracle import tinyda_oracle as orc
+from tests.test_oracle_dreamz import dreamz_inputs
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def eng_mod():
+    from tinyda_amd import _lib, engine
+
+    _lib.load()
+    return engine
+
+
+def _setup(eng_mod, g, cfg, T, block=0, seed=3):
+    N, d = g["theta0"].shape
+    e = eng_mod.Engine(N, d, seed=seed, block_steps=block)
+    e.set_prior(g["prior_mean"], g["prior_cov"])
+    if str(g["problem"]) == "linear":
+        e.set_level(0, g["A"], g["data"], 0, float(g["noise_var"]))
+    else:
+        e.set_level_rosenbrock(0, float(g["rosen_a"]), float(g["rosen_b"]), 0.0, 1.0)
+    e.set_proposal_dreamz(cfg["M0"], delta=cfg["delta"], b=cfg["b"], b_star=cfg["b_star"], nCR=cfg["nCR"],
+                          adaptive=cfg["adaptive"], gamma=cfg["gamma"], period=cfg["period"], capacity=cfg["M0"] + T)
+    return e
+
+
+@pytest.mark.parametrize("name,block", [("g6_dreamz_linear", 0), ("g6_dreamz_linear", 7), ("g6_dreamz_rosen_adaptive", 0),
+                                        ("g6_dreamz_empty_subspace", 0)])
+def test_dreamz_replay(eng_mod, golden, name, block):
+    g = golden(name)
+    _, cfg, var = dreamz_inputs(g)
+    T = g["u"].shape[1]
+    e = _setup(eng_mod, g, cfg, T, block)
+    e.set_archive(g["Z0"])
+    e.init(g["theta0"])
+    sw = lambda a: np.swapaxes(a, 0, 1)
+    e.set_replay_dreamz(sw(var["r"]), sw(var["mcr"]), sw(var["sub_u"]), sw(var["forced"]), sw(var["e_u"]), sw(var["eps_n"]),
+                        sw(var["u"]))
+    _, st0 = e.current()
+    params, stats, acc = e.run_host(T)
+    assert np.array_equal(acc, g["accepted"][:, 1:].T), "%d accept flips" % int((acc != g["accepted"][:, 1:].T).sum())
+    ref_post = g["logprior"] + g["loglike"]
+    np.testing.assert_allclose(st0[:, 2], ref_post[:, 0], rtol=RTOL)
+    np.testing.assert_allclose(stats[:, :, 2], ref_post[:, 1:].T, rtol=RTOL)
+    np.testing.assert_allclose(params, sw(g["theta"][:, 1:]), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(e.proposal_state_scaling(), g["scaling"], rtol=1e-12)
+    st = e.dreamz_state()
+    np.testing.assert_allclose(st["pCR"], g["pCR"], rtol=1e-8)
+    assert st["archive_rows"] == cfg["M0"] + T
+    e.close()
+
+
+def _philox_dreamz_variates(seed, N, T, d, delta, nCR, M0, pCR_fn, grow=True, chain_offset=0):
+    """The oracle's restatement of RNG stream 4 (include/tinyda_amd.h / tda_kernels.h k_dreamz_draw)."""
+    ps = orc.PhiloxStream(seed)
+    chains = (np.arange(N) + chain_offset).astype(np.uint32)
+    r = np.empty((N, T, delta, 2))
+    u_mcr = np.empty((N, T))
+    forced = np.empty((N, T))
+    sub_u = np.empty((N, T, d))
+    e_u = np.empty((N, T, d))
+    u = np.empty((N, T))
+    for t in range(T):
+        M = np.uint64(M0 + (t if grow else 0))
+        for i in range(delta):
+            x0, x1, _, _ = ps.words(chains, np.uint32(t), np.uint32(4), np.uint32(i))
+            r1 = (x0.astype(np.uint64) * M) >> np.uint64(32)
+            r2 = (x1.astype(np.uint64) * (M - np.uint64(1))) >> np.uint64(32)
+            r2 = r2 + (r2 >= r1)
+            r[:, t, i, 0], r[:, t, i, 1] = r1, r2
+        x0, x1, x2, _ = ps.words(chains, np.uint32(t), np.uint32(4), np.uint32(delta))
+        u_mcr[:, t] = orc.u53(x0, x1)
+        forced[:, t] = (x2.astype(np.uint64) * np.uint64(d)) >> np.uint64(32)
+        for j in range(d):
+            x0, x1, x2, x3 = ps.words(chains, np.uint32(t), np.uint32(4), np.uint32(delta + 1 + j))
+            sub_u[:, t, j], e_u[:, t, j] = orc.u53(x0, x1), orc.u53(x2, x3)
+        u[:, t] = ps.uniform(chains, t)
+    return dict(r=r, u_mcr=u_mcr, forced=forced, sub_u=sub_u, e_u=e_u, u=u)
+
+
+def test_dreamz_philox_forward_rosenbrock32(eng_mod):
+    """BASELINE config-4 shape (d = 32 Rosenbrock chain, per-chain archive, non-adaptive so pCR stays uniform):
+    the engine's own stream; integers / uniforms regenerated bit-exactly by the oracle, normals exported."""
+    d, N, T, M0, delta, nCR, seed = 32, 40, 120, 64, 1, 3, 2468
+    prior_mean, prior_cov = np.zeros(d), np.eye(d)
+    e = eng_mod.Engine(N, d, seed=seed)
+    e.set_prior(prior_mean, prior_cov)
+    e.set_level_rosenbrock(0, 1.0, 10.0, 0.0, 1.0)
+    e.set_proposal_dreamz(M0, delta=delta, nCR=nCR, capacity=M0 + T)
+    rng = np.random.default_rng(1)
+    Z0 = rng.standard_normal((N, M0, d))
+    theta0 = 0.3 * rng.standard_normal((N, d))
+    e.set_archive(Z0)
+    e.init(theta0)
+    eps, _ = e.set_export(T)
+    params, stats, acc = e.run_host(T)
+    v = _philox_dreamz_variates(seed, N, T, d, delta, nCR, M0, None)
+    cdf = np.cumsum(np.full(nCR, 1.0 / nCR))
+    mcr = np.minimum((v["u_mcr"][..., None] >= cdf).sum(-1), nCR - 1)
+    var = dict(r=v["r"], mcr=mcr, sub_u=v["sub_u"], forced=v["forced"], e_u=v["e_u"], eps_n=np.swapaxes(eps, 0, 1), u=v["u"])
+    level = orc.RosenbrockLevel(orc.MVNPrior(prior_mean, prior_cov))
+    cfg = dict(M0=M0, delta=delta, nCR=nCR, adaptive=False, period=100, gamma=1.01, b=5e-2, b_star=1e-6)
+    res = orc.run_dreamz(level, cfg, theta0, Z0, var)
+    assert np.array_equal(acc, res["accepted"][:, 1:].T)
+    np.testing.assert_allclose(stats[:, :, 2], res["logpost"][:, 1:].T, rtol=RTOL)
+    assert 0.02 < acc.mean() < 0.9
+    e.close()
+
+
+def test_dream_shared_archive_sharding_invariance(eng_mod):
+    """DREAM (one archive for all chains, synchronised every K steps): two engines holding half of the chains each,
+    exchanging rows through archive_take / archive_append in canonical (step, global chain) order, reproduce the
+    single-engine run bit for bit.  This is the exchange the RCCL all-gather performs across GPUs."""
+    d, N, T, M0, K, seed = 8, 32, 60, 24, 5, 99
+    rng = np.random.default_rng(2)
+    A = rng.standard_normal((12, d)) / np.sqrt(d)
+    y = rng.standard_normal(12)
+    Z0 = rng.standard_normal((M0, d))
+    theta0 = 0.3 * rng.standard_normal((N, d))
+
+    def make(n, off, th):
+        e = eng_mod.Engine(n, d, seed=seed, chain_offset=off)
+        e.set_prior(np.zeros(d), np.eye(d))
+        e.set_level(0, A, y, 0, 0.25)
+        e.set_proposal_dreamz(M0, delta=2, nCR=3, adaptive=True, period=20, gamma=1.02, shared=True, sync_every=K,
+                              capacity=M0 + T * N)
+        e.set_archive(Z0)
+        e.init(th)
+        return e
+
+    one = make(N, 0, theta0)
+    full = one.run_host(T)
+    ref_state = one.dreamz_state()
+    one.close()
+    h = N // 2
+    e0, e1 = make(h, 0, theta0[:h]), make(h, h, theta0[h:])
+    for e in (e0, e1):
+        e.set_archive_auto_append(False)
+    outs0, outs1 = [], []
+    for _ in range(T // K):
+        outs0.append(e0.run_host(K))
+        outs1.append(e1.run_host(K))
+        r0, r1 = np.empty((K, h, d)), np.empty((K, h, d))
+        assert e0.archive_take(r0) == K and e1.archive_take(r1) == K
+        rows = np.concatenate([r0, r1], axis=1).reshape(K * N, d)  # all_gather along the chain axis
+        e0.archive_append(rows)
+        e1.archive_append(rows)
+    for k in range(3):
+        joined = np.concatenate([np.concatenate([a[k] for a in outs0]), np.concatenate([a[k] for a in outs1])], axis=1)
+        assert np.array_equal(joined, full[k]), "shared-archive run depends on the sharding (record %d)" % k
+    assert e0.dreamz_state()["archive_rows"] == ref_state["archive_rows"] == M0 + T * N
+    np.testing.assert_array_equal(np.concatenate([e0.dreamz_state()["pCR"], e1.dreamz_state()["pCR"]]), ref_state["pCR"])
+    e0.close()
+    e1.close()

@@ -17,9 +17,9 @@ from .distributions import (  # noqa: F401
 )
 from .engine import Engine  # noqa: F401
 from .link import Link  # noqa: F401
-from .models import LinearModel  # noqa: F401
+from .models import LinearModel, Rosenbrock  # noqa: F401
 from .posterior import Posterior  # noqa: F401
-from .proposal import AdaptiveMetropolis, CrankNicolson, GaussianRandomWalk, Proposal  # noqa: F401
+from .proposal import DREAM, DREAMZ, AdaptiveMetropolis, CrankNicolson, GaussianRandomWalk, Proposal  # noqa: F401
 from .results import DeviceChain  # noqa: F401
 from .sampler import sample  # noqa: F401
 from .utils import RecursiveSampleMoments, ZeroMeanRecursiveSampleMoments  # noqa: F401

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtinyda_hip.so")
 
 TDA_OK = 0
 NOISE_ISO, NOISE_DIAG, NOISE_DENSE = 0, 1, 2
-PROP_GRW, PROP_PCN, PROP_AM = 0, 1, 2
+PROP_GRW, PROP_PCN, PROP_AM, PROP_DREAMZ = 0, 1, 2, 3
 
 
 class EngineError(RuntimeError):
@@ -49,6 +49,23 @@ class tda_proposal_params(C.Structure):
     ]
 
 
+class tda_dreamz_params(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("M0", C.c_int32),
+        ("delta", C.c_int32),
+        ("nCR", C.c_int32),
+        ("b", C.c_double),
+        ("b_star", C.c_double),
+        ("adaptive", C.c_int32),
+        ("period", C.c_int32),
+        ("gamma", C.c_double),
+        ("shared", C.c_int32),
+        ("sync_every", C.c_int32),
+        ("capacity", C.c_int64),
+    ]
+
+
 class tda_outputs(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32),
@@ -82,6 +99,14 @@ SYMBOLS = {
     "tda_engine_set_prior": (C.c_int, [_P, _P, _P]),
     "tda_engine_set_level": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P]),
     "tda_engine_set_proposal": (C.c_int, [_P, C.POINTER(tda_proposal_params)]),
+    "tda_engine_set_proposal_dreamz": (C.c_int, [_P, C.POINTER(tda_dreamz_params)]),
+    "tda_engine_set_archive": (C.c_int, [_P, _P]),
+    "tda_engine_set_level_rosenbrock": (C.c_int, [_P, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "tda_engine_set_replay_dreamz": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int64]),
+    "tda_engine_get_dreamz_state": (C.c_int, [_P, _P, _P]),
+    "tda_engine_archive_take": (C.c_int, [_P, _P, _P]),
+    "tda_engine_archive_append": (C.c_int, [_P, _P, C.c_int64]),
+    "tda_engine_set_archive_auto_append": (C.c_int, [_P, C.c_int]),
     "tda_engine_set_subchains": (C.c_int, [_P, _P, C.c_int]),
     "tda_engine_set_replay_level": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
     "tda_engine_get_level_state": (C.c_int, [_P, C.c_int, _P, _P]),

@@ -124,6 +124,8 @@ struct Level {
   bool set = false;
   int m = 0, m_pad = 0, ncb = 0, noise_kind = 0;
   double var = 1.0;
+  int model = 0;  // tda::MODEL_LINEAR / MODEL_ROSENBROCK
+  double ros_a = 1.0, ros_b = 10.0, ros_data = 0.0;
   DevBuf<double> Apk, ytil, w;
 };
 
@@ -198,6 +200,20 @@ struct tda_engine {
   DevBuf<double> z_exp_d, u_exp_d;
   int64_t exp_steps = 0, exp_pos = 0;
 
+  // DREAM(Z)
+  bool is_dreamz = false;
+  tda_dreamz_params dz{};
+  bool arch_set = false, auto_append = true;
+  std::vector<double> Z0_h;
+  int64_t arch_rows = 0;    // rows currently in the archive(s)
+  int64_t arch_cap = 0;
+  int64_t pending_steps = 0;  // shared mode: steps whose states are in blk_hist but not yet appended
+  DevBuf<double> arch, zsum, zsq, dz_pCR, dz_LCR, dz_Delta, dz_coef, dz_epsm, theta_prev, blk_states, blk_hist;
+  DevBuf<int32_t> dz_ridx, dz_mcr_last;
+  DevBuf<int32_t> rp_r, rp_mcr, rp_forced;
+  DevBuf<double> rp_sub, rp_e, rp_eps, rp_u;
+  int64_t rp_steps = 0, rp_pos = 0;
+
   // profiling
   bool profiling = false;
   std::vector<TimedLaunch> timed;
@@ -231,6 +247,19 @@ void launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st) {
     case 3: hipLaunchKernelGGL((k_ml_steps<DPAD, 3>), dim3((unsigned)tiles), dim3(256), lds, st, a); break;
     default: hipLaunchKernelGGL((k_ml_steps<DPAD, 4>), dim3((unsigned)tiles), dim3(256), lds, st, a); break;
   }
+}
+
+template <int DPAD>
+void launch_dz_draw(const DreamDrawArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_dreamz_draw<DPAD>, dim3((unsigned)a.NP), dim3(64), 0, st, a);
+}
+template <int DPAD>
+void launch_dz_steps(const DreamStepArgs& a, size_t lds, hipStream_t st) {
+  hipLaunchKernelGGL(k_dreamz_steps<DPAD>, dim3((unsigned)(a.NP / 16)), dim3(256), lds, st, a);
+}
+template <int DPAD>
+void launch_dz_adapt(const DreamAdaptArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_dreamz_adapt<DPAD>, dim3((unsigned)a.N), dim3(64), 0, st, a);
 }
 
 #define DISPATCH_DPAD(dp, CALL)                  \
@@ -485,6 +514,161 @@ int tda_engine_set_proposal(tda_engine* e, const tda_proposal_params* p) {
   return TDA_OK;
 }
 
+int tda_engine_set_level_rosenbrock(tda_engine* e, int level, double a, double b, double data, double noise_var) {
+  if (!e) return fail(TDA_ERR_INVALID, "null engine");
+  if (level < 0 || level >= (int)e->levels.size()) return fail(TDA_ERR_INVALID, "level %d out of range", level);
+  if (e->d < 2) return fail(TDA_ERR_INVALID, "the Rosenbrock chain needs dim >= 2");
+  if (!(noise_var > 0.0)) return fail(TDA_ERR_NUMERIC, "noise variance must be positive");
+  Level& lv = e->levels[level];
+  lv.model = MODEL_ROSENBROCK;
+  lv.ros_a = a;
+  lv.ros_b = b;
+  lv.ros_data = data;
+  lv.m = 1;
+  lv.m_pad = 0;
+  lv.ncb = 0;
+  lv.noise_kind = TDA_NOISE_ISO;
+  lv.var = noise_var;
+  lv.set = true;
+  return TDA_OK;
+}
+
+int tda_engine_set_proposal_dreamz(tda_engine* e, const tda_dreamz_params* p) {
+  if (!e || !p) return fail(TDA_ERR_INVALID, "null argument");
+  if (p->struct_size != sizeof(tda_dreamz_params)) return fail(TDA_ERR_INVALID, "tda_dreamz_params.struct_size mismatch");
+  if (e->nlev != 1) return fail(TDA_ERR_UNSUPPORTED, "DREAMZ is lowered for single-level chains only");
+  if (p->M0 < 2 * 1 + 1) return fail(TDA_ERR_INVALID, "M0 too small");
+  if (p->delta < 1 || p->delta > MAX_DELTA) return fail(TDA_ERR_UNSUPPORTED, "delta=%d outside 1..%d", p->delta, (int)MAX_DELTA);
+  if (p->nCR < 1 || p->nCR > MAX_NCR) return fail(TDA_ERR_UNSUPPORTED, "nCR=%d outside 1..%d", p->nCR, (int)MAX_NCR);
+  if (p->period < 1) return fail(TDA_ERR_INVALID, "period must be >= 1");
+  if (p->capacity < p->M0) return fail(TDA_ERR_INVALID, "archive capacity smaller than M0");
+  e->dz = *p;
+  e->is_dreamz = true;
+  e->pp = tda_proposal_params{};
+  e->pp.struct_size = sizeof(tda_proposal_params);
+  e->pp.kind = TDA_PROP_DREAMZ;
+  e->pp.scaling = 1.0;  // proposal.py:715
+  e->pp.adaptive = p->adaptive;
+  e->pp.period = p->period;
+  e->pp.gamma = p->gamma;
+  e->prop_set = true;
+  e->arch_set = false;
+  e->inited = false;
+  return TDA_OK;
+}
+
+int tda_engine_set_archive(tda_engine* e, const double* Z0) {
+  if (!e || !e->is_dreamz) return fail(TDA_ERR_STATE, "set_proposal_dreamz first");
+  if (!e->prior_set) return fail(TDA_ERR_STATE, "set_prior first");
+  const int d = e->d;
+  const int64_t rows = (e->dz.shared ? 1 : e->N) * (int64_t)e->dz.M0;
+  e->Z0_h.resize((size_t)rows * d);
+  if (Z0) {
+    if (is_device_ptr(Z0))
+      HIP_TRY(hipMemcpy(e->Z0_h.data(), Z0, e->Z0_h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    else
+      std::copy(Z0, Z0 + e->Z0_h.size(), e->Z0_h.begin());
+  } else {  // prior.rvs(M0) (proposal.py:788) from RNG stream 2; per-chain archives keyed by the global chain id
+    std::vector<double> z(d + 1);
+    for (int64_t r = 0; r < rows; ++r) {
+      const uint32_t key_chain = e->dz.shared ? 0xFFFFFFFFu : (uint32_t)(e->cfg.chain_offset + r / e->dz.M0);
+      const uint32_t row = (uint32_t)(e->dz.shared ? r : r % e->dz.M0);
+      for (int b = 0; b < (d + 1) / 2; ++b) normal_pair(e->cfg.seed, key_chain, 1u + row, STREAM_INIT, (uint32_t)b, z[2 * b], z[2 * b + 1]);
+      for (int i = 0; i < d; ++i) {
+        double s = 0.0;
+        for (int k = 0; k <= i; ++k) s = std::fma(e->prior_L_h[(size_t)i * d + k], z[k], s);
+        e->Z0_h[(size_t)r * d + i] = e->prior_mean_h[i] + s;
+      }
+    }
+  }
+  e->arch_set = true;
+  e->inited = false;
+  return TDA_OK;
+}
+
+int tda_engine_set_replay_dreamz(tda_engine* e, const int32_t* r, const int32_t* mcr, const double* sub_u,
+                                 const int32_t* forced, const double* e_u, const double* eps_n, const double* u,
+                                 int64_t n_steps) {
+  if (!e || !e->is_dreamz) return fail(TDA_ERR_STATE, "set_proposal_dreamz first");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  e->rp_steps = e->rp_pos = 0;
+  if (!r || n_steps <= 0) return TDA_OK;
+  if (!mcr || !sub_u || !forced || !e_u || !eps_n || !u) return fail(TDA_ERR_INVALID, "all DREAMZ replay arrays are required");
+  const size_t N = e->N, d = e->d, T = n_steps;
+  int rc;
+  std::vector<int32_t> vi;
+  std::vector<double> vd;
+#define UP_I(buf, src, count)                     \
+  vi.assign(src, src + (count));                  \
+  if ((rc = e->buf.upload(vi))) return rc;
+#define UP_D(buf, src, count)                     \
+  vd.assign(src, src + (count));                  \
+  if ((rc = e->buf.upload(vd))) return rc;
+  UP_I(rp_r, r, T * N * e->dz.delta * 2)
+  UP_I(rp_mcr, mcr, T * N)
+  UP_I(rp_forced, forced, T * N)
+  UP_D(rp_sub, sub_u, T * N * d)
+  UP_D(rp_e, e_u, T * N * d)
+  UP_D(rp_eps, eps_n, T * N * d)
+  UP_D(rp_u, u, T * N)
+#undef UP_I
+#undef UP_D
+  e->rp_steps = n_steps;
+  return TDA_OK;
+}
+
+int tda_engine_get_dreamz_state(tda_engine* e, double* pCR, int64_t* archive_rows) {
+  if (!e || !e->inited || !e->is_dreamz) return fail(TDA_ERR_STATE, "no DREAMZ engine initialised");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (pCR) {
+    std::vector<double> hbuf((size_t)e->NP * MAX_NCR);
+    HIP_TRY(hipMemcpy(hbuf.data(), e->dz_pCR.p, hbuf.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int64_t c = 0; c < e->N; ++c)
+      for (int k = 0; k < e->dz.nCR; ++k) pCR[c * e->dz.nCR + k] = hbuf[(size_t)c * MAX_NCR + k];
+  }
+  if (archive_rows) *archive_rows = e->arch_rows;
+  return TDA_OK;
+}
+
+int tda_engine_set_archive_auto_append(tda_engine* e, int on) {
+  if (!e) return fail(TDA_ERR_INVALID, "null engine");
+  e->auto_append = on != 0;
+  return TDA_OK;
+}
+
+static int dreamz_sums_catchup(tda_engine* e, int64_t row0, int64_t nrows, bool boundary, bool scale, double gamma_pow);
+
+int tda_engine_archive_take(tda_engine* e, double* rows, int64_t* n_steps) {
+  if (!e || !e->inited || !e->is_dreamz || !e->dz.shared) return fail(TDA_ERR_STATE, "no shared-archive engine initialised");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  if (n_steps) *n_steps = e->pending_steps;
+  if (rows && e->pending_steps) {  // [steps][N][d] without padding
+    const hipMemcpyKind kind = is_device_ptr(rows) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    for (int64_t s = 0; s < e->pending_steps; ++s)
+      HIP_TRY(hipMemcpy2DAsync(rows + (size_t)s * e->N * e->d, e->d * sizeof(double), e->blk_hist.p + (size_t)s * e->NP * e->DP,
+                               e->DP * sizeof(double), e->d * sizeof(double), e->N, kind, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
+  e->pending_steps = 0;
+  return TDA_OK;
+}
+
+int tda_engine_archive_append(tda_engine* e, const double* rows, int64_t n_rows) {
+  if (!e || !e->inited || !e->is_dreamz || !e->dz.shared) return fail(TDA_ERR_STATE, "no shared-archive engine initialised");
+  if (n_rows <= 0) return TDA_OK;
+  if (e->arch_rows + n_rows > e->arch_cap) return fail(TDA_ERR_INVALID, "shared archive capacity (%lld rows) exceeded", (long long)e->arch_cap);
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const hipMemcpyKind kind = is_device_ptr(rows) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  HIP_TRY(hipMemcpy2DAsync(e->arch.p + (size_t)e->arch_rows * e->DP, e->DP * sizeof(double), rows, e->d * sizeof(double),
+                           e->d * sizeof(double), n_rows, kind, e->stream));
+  int rc = dreamz_sums_catchup(e, e->arch_rows, n_rows, false, false, 1.0);
+  if (rc) return rc;
+  e->arch_rows += n_rows;
+  if (kind == hipMemcpyHostToDevice) HIP_TRY(hipStreamSynchronize(e->stream));
+  return TDA_OK;
+}
+
 int tda_engine_set_subchains(tda_engine* e, const int32_t* lengths, int randomize) {
   if (!e || !lengths) return fail(TDA_ERR_INVALID, "null argument");
   if (e->nlev < 2) return fail(TDA_ERR_STATE, "subchain lengths only apply to n_levels >= 2");
@@ -600,6 +784,84 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
   // proposal state (chain.py:74-76)
   std::vector<double> sc(NP, e->pp.kind == TDA_PROP_AM ? 1.0 : e->pp.scaling);
   if ((rc = e->scaling.upload(sc))) return rc;
+  if (e->is_dreamz) {
+    if (!e->arch_set && (rc = tda_engine_set_archive(e, nullptr))) return rc;
+    const bool sh = e->dz.shared != 0;
+    const int64_t M0 = e->dz.M0;
+    e->arch_cap = e->dz.capacity;
+    const size_t narch = (size_t)(sh ? 1 : NP) * e->arch_cap * DP;
+    if ((rc = e->arch.alloc(narch))) return rc;
+    HIP_TRY(hipMemsetAsync(e->arch.p, 0, narch * sizeof(double), e->stream));
+    {  // Z0 -> padded device layout
+      const int64_t nA = sh ? 1 : N;
+      std::vector<double> pad((size_t)M0 * DP, 0.0);
+      for (int64_t c = 0; c < nA; ++c) {
+        for (int64_t r = 0; r < M0; ++r)
+          for (int j = 0; j < d; ++j) pad[(size_t)r * DP + j] = e->Z0_h[((size_t)c * M0 + r) * d + j];
+        HIP_TRY(hipMemcpy(e->arch.p + (size_t)c * e->arch_cap * DP, pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice));
+      }
+    }
+    e->arch_rows = M0;
+    const size_t nsum = (size_t)(sh ? 1 : NP) * DP;
+    std::vector<double> zero(nsum, 0.0), pcr((size_t)NP * MAX_NCR, 0.0), ones((size_t)NP * MAX_NCR, 1.0), zer2((size_t)NP * MAX_NCR, 0.0);
+    for (int64_t c = 0; c < NP; ++c)
+      for (int k = 0; k < e->dz.nCR; ++k) pcr[(size_t)c * MAX_NCR + k] = 1.0 / e->dz.nCR;  // proposal.py:731
+    if ((rc = e->zsum.upload(zero))) return rc;
+    if ((rc = e->zsq.upload(zero))) return rc;
+    if ((rc = e->dz_pCR.upload(pcr))) return rc;
+    if ((rc = e->dz_Delta.upload(ones))) return rc;  // proposal.py:755
+    if ((rc = e->dz_LCR.upload(zer2))) return rc;    // proposal.py:754
+    if ((rc = e->dz_mcr_last.alloc(NP))) return rc;
+    HIP_TRY(hipMemsetAsync(e->dz_mcr_last.p, 0, NP * sizeof(int32_t), e->stream));
+    if ((rc = e->dz_coef.alloc((size_t)e->SMAX * NP * DP))) return rc;
+    if ((rc = e->dz_epsm.alloc((size_t)e->SMAX * NP * DP))) return rc;
+    if ((rc = e->dz_ridx.alloc((size_t)e->SMAX * NP * 2 * MAX_DELTA))) return rc;
+    if ((rc = e->theta_prev.alloc((size_t)NP * DP))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->theta_prev.p, e->theta.p, (size_t)NP * DP * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    if (sh) {
+      if ((rc = e->blk_states.alloc((size_t)e->SMAX * NP * DP))) return rc;
+      if ((rc = e->blk_hist.alloc((size_t)e->SMAX * NP * DP))) return rc;
+    }
+    if ((rc = e->ublk.alloc((size_t)e->SMAX * NP))) return rc;
+    if ((rc = e->rec_params.alloc((size_t)e->SMAX * N * d))) return rc;
+    if ((rc = e->rec_stats.alloc((size_t)e->SMAX * N * 3))) return rc;
+    if ((rc = e->rec_acc.alloc((size_t)e->SMAX * N))) return rc;
+    e->t = 0;
+    e->k_adapt = 0;
+    e->rp_pos = 0;
+    e->exp_pos = 0;
+    e->pending_steps = 0;
+    e->inited = true;  // dreamz_sums_catchup checks nothing else
+    if ((rc = dreamz_sums_catchup(e, 0, M0, false, false, 1.0))) return rc;
+    // initial link (chain.py:70)
+    if (e->levels[0].model == MODEL_LINEAR) {
+      if ((rc = launch_eval(e, 0, e->theta.p, e->lp.p, e->ll.p))) return rc;
+    } else {
+      // Rosenbrock level: evaluate theta0 with a zero-jump DREAMZ step (coef = eps = 0, u = 0 -> accepted)
+      HIP_TRY(hipMemsetAsync(e->dz_coef.p, 0, (size_t)NP * DP * sizeof(double), e->stream));
+      HIP_TRY(hipMemsetAsync(e->dz_epsm.p, 0, (size_t)NP * DP * sizeof(double), e->stream));
+      HIP_TRY(hipMemsetAsync(e->dz_ridx.p, 0, (size_t)NP * 2 * MAX_DELTA * sizeof(int32_t), e->stream));
+      std::vector<double> uz(NP, -1.0), big(NP, -1e300);
+      HIP_TRY(hipMemcpy(e->ublk.p, uz.data(), NP * sizeof(double), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(e->lp.p, big.data(), NP * sizeof(double), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemsetAsync(e->ll.p, 0, NP * sizeof(double), e->stream));
+      DreamStepArgs sa{};
+      extern void fill_dreamz_step_args(tda_engine*, DreamStepArgs&);
+      fill_dreamz_step_args(e, sa);
+      sa.S = 1;
+      sa.shared = 1;  // no archive append for this evaluation
+      sa.blk_states = nullptr;
+      sa.rec_params = nullptr;
+      sa.rec_stats = nullptr;
+      sa.rec_acc = nullptr;
+      const size_t lds = ((size_t)16 * (DP + 2) + 128 + 64) * sizeof(double);
+      DISPATCH_DPAD(DP, launch_dz_steps<DPAD>(sa, lds, e->stream));
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemsetAsync(e->acc_count.p, 0, NP * sizeof(int32_t), e->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return TDA_OK;
+  }
   std::vector<double> L;
   const double* Cuse = e->pp.kind == TDA_PROP_PCN ? e->prior_cov_h.data() : e->prop_C_h.data();  // proposal.py:336-341
   if (!cholesky_host(Cuse, d, L)) return fail(TDA_ERR_NUMERIC, "proposal covariance is not positive definite");
@@ -753,11 +1015,13 @@ int tda_engine_set_export(tda_engine* e, double* z, double* u, int64_t n_steps) 
 }
 
 static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs);
+static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out);
 
 int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
   if (!e || !e->inited) return fail(TDA_ERR_STATE, "engine not initialised");
   if (n_iter < 0) return fail(TDA_ERR_INVALID, "n_iterations < 0");
   if (e->nlev > 1) return run_multilevel(e, n_iter, out);
+  if (e->is_dreamz) return run_dreamz(e, n_iter, out);
   if (out && out->struct_size != sizeof(tda_outputs)) return fail(TDA_ERR_INVALID, "tda_outputs.struct_size mismatch");
   HIP_TRY(hipSetDevice(e->cfg.device));
   if (e->rep_steps && e->rep_pos + n_iter > e->rep_steps)
@@ -1143,6 +1407,234 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
     e->t += S;
     done_base += S;
     if (e->rep_steps) e->rep_pos += S;
+    if (e->exp_steps) e->exp_pos += S;
+  }
+  if (e->exp_steps && !e->exp_dev) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(e->z_exp, e->z_exp_d.p, (size_t)e->exp_pos * N * d * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(e->u_exp, e->u_exp_d.p, (size_t)e->exp_pos * N * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  return TDA_OK;
+}
+
+void fill_dreamz_step_args(tda_engine* e, DreamStepArgs& sa) {
+  const Level& lv = e->levels[0];
+  sa.lv.Apk = lv.Apk.p;
+  sa.lv.ytil = lv.ytil.p;
+  sa.lv.w = lv.w.p;
+  sa.lv.ncb = lv.ncb;
+  sa.lv.m_pad = lv.m_pad;
+  sa.lv.noise_kind = lv.noise_kind;
+  sa.lv.var = lv.var;
+  sa.pr.mean = e->prior_mean.p;
+  sa.pr.pinv = e->prior_pinv.p;
+  sa.pr.Wpk = e->prior_Wpk.p;
+  sa.pr.wmu = e->prior_wmu.p;
+  sa.pr.ncb = e->prior_ncb;
+  sa.pr.kind = e->prior_kind;
+  sa.pr.logconst = e->prior_logconst;
+  sa.model = lv.model;
+  sa.ros_a = lv.ros_a;
+  sa.ros_b = lv.ros_b;
+  sa.ros_data = lv.ros_data;
+  sa.N = e->N;
+  sa.NP = e->NP;
+  sa.d = e->d;
+  sa.delta = e->dz.delta;
+  sa.M_base = e->arch_rows;
+  sa.shared = e->dz.shared;
+  sa.cap = e->arch_cap;
+  sa.arch = e->arch.p;
+  sa.theta = e->theta.p;
+  sa.theta_prev = e->theta_prev.p;
+  sa.lp = e->lp.p;
+  sa.ll = e->ll.p;
+  sa.acc_count = e->acc_count.p;
+  sa.coef = e->dz_coef.p;
+  sa.epsm = e->dz_epsm.p;
+  sa.ridx = e->dz_ridx.p;
+  sa.u = e->ublk.p;
+}
+
+static int dreamz_sums_catchup(tda_engine* e, int64_t row0, int64_t nrows, bool boundary, bool scale, double gamma_pow) {
+  DreamAdaptArgs aa{};
+  aa.N = e->N;
+  aa.NP = e->NP;
+  aa.d = e->d;
+  aa.nCR = e->dz.nCR;
+  aa.period = e->dz.period;
+  aa.gamma_pow = gamma_pow;
+  aa.shared = e->dz.shared;
+  aa.cap = e->arch_cap;
+  aa.arch = e->arch.p;
+  aa.zsum = e->zsum.p;
+  aa.zsq = e->zsq.p;
+  aa.theta = e->theta.p;
+  aa.theta_prev = e->theta_prev.p;
+  aa.mcr_last = e->dz_mcr_last.p;
+  aa.pCR = e->dz_pCR.p;
+  aa.LCR = e->dz_LCR.p;
+  aa.DeltaCR = e->dz_Delta.p;
+  aa.scaling = e->scaling.p;
+  aa.acc_count = e->acc_count.p;
+  aa.row0 = row0;
+  aa.nrows = nrows;
+  aa.M_total = row0 + nrows;
+  if (e->dz.shared) {
+    if (nrows > 0) {  // one wave advances the shared column sums ...
+      DreamAdaptArgs a1 = aa;
+      a1.N = 1;
+      a1.boundary = 0;
+      DISPATCH_DPAD(e->DP, launch_dz_adapt<DPAD>(a1, e->stream));
+    }
+    if (!boundary) return TDA_OK;
+    aa.nrows = 0;  // ... then every chain adapts against the finished sums
+    aa.M_total = row0 + nrows;
+  }
+  aa.boundary = boundary;
+  aa.do_scale = scale;
+  DISPATCH_DPAD(e->DP, launch_dz_adapt<DPAD>(aa, e->stream));
+  HIP_TRY(hipGetLastError());
+  return TDA_OK;
+}
+
+static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  if (out && out->struct_size != sizeof(tda_outputs)) return fail(TDA_ERR_INVALID, "tda_outputs.struct_size mismatch");
+  const int d = e->d, DP = e->DP;
+  const int64_t N = e->N, NP = e->NP;
+  const bool sh = e->dz.shared != 0, adaptive = e->dz.adaptive != 0;
+  const int period = e->dz.period;
+  if (e->rp_steps && e->rp_pos + n_iter > e->rp_steps) return fail(TDA_ERR_INVALID, "DREAMZ replay buffer too short");
+  if (e->exp_steps && e->exp_pos + n_iter > e->exp_steps) return fail(TDA_ERR_INVALID, "export buffer too small");
+  if (!sh && e->arch_rows + n_iter > e->arch_cap) return fail(TDA_ERR_INVALID, "archive capacity (%lld rows) exceeded", (long long)e->arch_cap);
+  if (sh && e->auto_append && e->arch_rows + n_iter * N > e->arch_cap)
+    return fail(TDA_ERR_INVALID, "shared archive capacity (%lld rows) exceeded", (long long)e->arch_cap);
+  double* o_params = out ? out->params : nullptr;
+  double* o_stats = out ? out->stats : nullptr;
+  uint8_t* o_acc = out ? out->accepted : nullptr;
+  const bool p_dev = is_device_ptr(o_params), s_dev = is_device_ptr(o_stats), a_dev = is_device_ptr(o_acc);
+  const Level& lv = e->levels[0];
+  const bool linear = lv.model == MODEL_LINEAR;
+  const bool diag = lv.noise_kind == TDA_NOISE_DIAG;
+  const int prow = e->prior_kind == PRIOR_DENSE ? e->prior_ncb * 16 : 0;
+  const size_t lds = ((size_t)16 * (DP + 2) + 128 + (linear ? lv.m_pad * (diag ? 2 : 1) : 0) + prow) * sizeof(double);
+  if (e->profiling) {
+    for (auto& t : e->timed) {
+      (void)hipEventDestroy(t.a);
+      (void)hipEventDestroy(t.b);
+    }
+    e->timed.clear();
+  }
+  int64_t done = 0;
+  while (done < n_iter) {
+    int64_t S = std::min<int64_t>(n_iter - done, e->SMAX);
+    if (adaptive) S = std::min<int64_t>(S, period - (e->t % period));
+    if (sh) {
+      const int64_t K = e->dz.sync_every > 0 ? e->dz.sync_every : e->SMAX;
+      S = std::min<int64_t>(S, K);
+      if (!e->auto_append) {
+        if (e->pending_steps + S > e->SMAX) S = e->SMAX - e->pending_steps;
+        if (S <= 0) return fail(TDA_ERR_STATE, "shared archive: call archive_take / archive_append before running further");
+      }
+    }
+    DreamDrawArgs da{};
+    da.N = N;
+    da.NP = NP;
+    da.chain_offset = e->cfg.chain_offset;
+    da.d = d;
+    da.S = (int)S;
+    da.delta = e->dz.delta;
+    da.nCR = e->dz.nCR;
+    da.step0 = e->t;
+    da.M_base = e->arch_rows;
+    da.grow = sh ? 0 : 1;
+    da.seed = e->cfg.seed;
+    da.b = e->dz.b;
+    da.b_star = e->dz.b_star;
+    da.scaling = e->scaling.p;
+    da.pCR = e->dz_pCR.p;
+    da.coef = e->dz_coef.p;
+    da.epsm = e->dz_epsm.p;
+    da.ridx = e->dz_ridx.p;
+    da.u = e->ublk.p;
+    da.mcr_last = e->dz_mcr_last.p;
+    if (e->rp_steps) {
+      const size_t o = (size_t)e->rp_pos * N;
+      da.r_rep = e->rp_r.p + o * e->dz.delta * 2;
+      da.mcr_rep = e->rp_mcr.p + o;
+      da.forced_rep = e->rp_forced.p + o;
+      da.sub_rep = e->rp_sub.p + o * d;
+      da.e_rep = e->rp_e.p + o * d;
+      da.eps_rep = e->rp_eps.p + o * d;
+      da.u_rep = e->rp_u.p + o;
+    }
+    if (e->exp_steps) {
+      da.eps_export = (e->exp_dev ? e->z_exp : e->z_exp_d.p) + (size_t)e->exp_pos * N * d;
+      da.u_export = (e->exp_dev ? e->u_exp : e->u_exp_d.p) + (size_t)e->exp_pos * N;
+    }
+    {
+      ScopedTimer tm(e, 0);
+      DISPATCH_DPAD(DP, launch_dz_draw<DPAD>(da, e->stream));
+    }
+    DreamStepArgs sa{};
+    fill_dreamz_step_args(e, sa);
+    sa.S = (int)S;
+    sa.rec_params = p_dev ? o_params + (size_t)done * N * d : (o_params ? e->rec_params.p : nullptr);
+    sa.rec_stats = s_dev ? o_stats + (size_t)done * N * 3 : (o_stats ? e->rec_stats.p : nullptr);
+    sa.rec_acc = a_dev ? o_acc + (size_t)done * N : (o_acc ? e->rec_acc.p : nullptr);
+    sa.blk_states = sh ? e->blk_states.p : nullptr;
+    {
+      ScopedTimer tm(e, 1);
+      DISPATCH_DPAD(DP, launch_dz_steps<DPAD>(sa, lds, e->stream));
+    }
+    HIP_TRY(hipGetLastError());
+    const bool boundary = adaptive && ((e->t + S) % period == 0);
+    int rc;
+    if (!sh) {  // per-chain archives grew inside the kernel
+      ScopedTimer tm(e, 2);
+      if ((rc = dreamz_sums_catchup(e, e->arch_rows, S, boundary, adaptive, std::pow(e->dz.gamma, -(double)e->k_adapt)))) return rc;
+      e->arch_rows += S;
+    } else {
+      // keep this block's states for the exchange, [pending + s][NP][DP]
+      HIP_TRY(hipMemcpyAsync(e->blk_hist.p + (size_t)e->pending_steps * NP * DP, e->blk_states.p, (size_t)S * NP * DP * sizeof(double),
+                             hipMemcpyDeviceToDevice, e->stream));
+      e->pending_steps += S;
+      // crossover / scaling adaptation sees the archive the finished block proposed from (rows of this block are
+      // appended afterwards), so the result does not depend on who appends when
+      {
+        ScopedTimer tm(e, 2);
+        if (boundary && (rc = dreamz_sums_catchup(e, e->arch_rows, 0, true, adaptive, std::pow(e->dz.gamma, -(double)e->k_adapt)))) return rc;
+      }
+      if (e->auto_append) {  // single process: the local rows are all rows; canonical order = step-major, chain minor
+        for (int64_t s = 0; s < e->pending_steps; ++s)
+          HIP_TRY(hipMemcpy2DAsync(e->arch.p + (size_t)(e->arch_rows + s * N) * DP, DP * sizeof(double),
+                                   e->blk_hist.p + (size_t)s * NP * DP, DP * sizeof(double), DP * sizeof(double), N,
+                                   hipMemcpyDeviceToDevice, e->stream));
+        const int64_t new_rows = e->pending_steps * N;
+        e->pending_steps = 0;
+        if ((rc = dreamz_sums_catchup(e, e->arch_rows, new_rows, false, false, 1.0))) return rc;
+        e->arch_rows += new_rows;
+      }
+    }
+    if (boundary) e->k_adapt += 1;
+    bool host_copies = false;
+    if (o_params && !p_dev) {
+      if ((rc = copy_out(e, o_params + (size_t)done * N * d, e->rec_params.p, (size_t)S * N * d * sizeof(double)))) return rc;
+      host_copies = true;
+    }
+    if (o_stats && !s_dev) {
+      if ((rc = copy_out(e, o_stats + (size_t)done * N * 3, e->rec_stats.p, (size_t)S * N * 3 * sizeof(double)))) return rc;
+      host_copies = true;
+    }
+    if (o_acc && !a_dev) {
+      if ((rc = copy_out(e, o_acc + (size_t)done * N, e->rec_acc.p, (size_t)S * N))) return rc;
+      host_copies = true;
+    }
+    if (host_copies) HIP_TRY(hipStreamSynchronize(e->stream));
+    e->t += S;
+    done += S;
+    if (e->rp_steps) e->rp_pos += S;
     if (e->exp_steps) e->exp_pos += S;
   }
   if (e->exp_steps && !e->exp_dev) {

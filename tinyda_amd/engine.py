@@ -69,6 +69,54 @@ class Engine:
                                      _ptr(Cm), -1.0 if sd is None else sd, epsilon, t0, 0)
         check(self.lib.tda_engine_set_proposal(self.h, C.byref(p)))
 
+    def set_level_rosenbrock(self, level, a=1.0, b=10.0, data=0.0, noise_var=1.0):
+        check(self.lib.tda_engine_set_level_rosenbrock(self.h, level, a, b, data, noise_var))
+
+    def set_proposal_dreamz(self, M0, delta=1, b=5e-2, b_star=1e-6, nCR=3, adaptive=False, gamma=1.01, period=100,
+                            shared=False, sync_every=0, capacity=None):
+        cap = int(capacity if capacity is not None else M0)
+        p = _lib.tda_dreamz_params(C.sizeof(_lib.tda_dreamz_params), M0, delta, nCR, b, b_star, int(adaptive), period, gamma,
+                                   int(shared), sync_every, cap)
+        self._dz = dict(M0=M0, delta=delta, nCR=nCR, shared=bool(shared))
+        check(self.lib.tda_engine_set_proposal_dreamz(self.h, C.byref(p)))
+
+    def set_archive(self, Z0=None):
+        if Z0 is not None:
+            Z0 = _f64(Z0)
+            want = (self._dz["M0"], self.dim) if self._dz["shared"] else (self.n_chains, self._dz["M0"], self.dim)
+            assert Z0.shape == want, (Z0.shape, want)
+        check(self.lib.tda_engine_set_archive(self.h, _ptr(Z0)))
+
+    def set_replay_dreamz(self, r, mcr, sub_u, forced, e_u, eps_n, u):
+        """all arrays step-major: r [T,N,delta,2], mcr/forced/u [T,N], sub_u/e_u/eps_n [T,N,d]"""
+        i32 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+        r, mcr, forced = i32(r), i32(mcr), i32(forced)
+        sub_u, e_u, eps_n, u = _f64(sub_u), _f64(e_u), _f64(eps_n), _f64(u)
+        T = u.shape[0]
+        assert r.shape == (T, self.n_chains, self._dz["delta"], 2) and sub_u.shape == (T, self.n_chains, self.dim)
+        check(self.lib.tda_engine_set_replay_dreamz(self.h, _ptr(r), _ptr(mcr), _ptr(sub_u), _ptr(forced), _ptr(e_u),
+                                                    _ptr(eps_n), _ptr(u), T))
+
+    def dreamz_state(self):
+        pcr = np.empty((self.n_chains, self._dz["nCR"]))
+        rows = np.zeros(1, dtype=np.int64)
+        check(self.lib.tda_engine_get_dreamz_state(self.h, _ptr(pcr), _ptr(rows)))
+        return dict(pCR=pcr, archive_rows=int(rows[0]))
+
+    def set_archive_auto_append(self, on):
+        check(self.lib.tda_engine_set_archive_auto_append(self.h, int(on)))
+
+    def archive_take(self, rows=None):
+        """shared archive: number of pending steps; if `rows` ([steps, chains, dim] array / tensor) is given it is filled"""
+        n = np.zeros(1, dtype=np.int64)
+        check(self.lib.tda_engine_archive_take(self.h, _ptr(rows), _ptr(n)))
+        return int(n[0])
+
+    def archive_append(self, rows):
+        """rows: [n_rows, dim] numpy array or torch tensor (device ok)"""
+        n = rows.shape[0]
+        check(self.lib.tda_engine_archive_append(self.h, _ptr(rows), n))
+
     def set_subchains(self, lengths, randomize=False):
         arr = np.ascontiguousarray(np.asarray(lengths, dtype=np.int32))
         assert arr.shape == (self.n_levels - 1,)
@@ -166,6 +214,11 @@ class Engine:
         sg = np.empty((N, d, d)) if want_am else None
         check(self.lib.tda_engine_get_proposal_state(self.h, _ptr(sc), _ptr(Cm), _ptr(mu), _ptr(sg), _ptr(cnt)))
         return dict(scaling=sc, C=Cm, am_mu=mu, am_sigma=sg, t=int(cnt[0]), k=int(cnt[1]))
+
+    def proposal_state_scaling(self):
+        sc = np.empty(self.n_chains)
+        check(self.lib.tda_engine_get_proposal_state(self.h, _ptr(sc), None, None, None, None))
+        return sc
 
     def flags(self):
         f = np.zeros(self.n_chains, dtype=np.int32)

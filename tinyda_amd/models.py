@@ -20,3 +20,16 @@ class LinearModel:
     def __call__(self, parameters):
         out = self.A @ np.asarray(parameters, dtype=np.float64)
         return out if self.b is None else out + self.b
+
+
+class Rosenbrock:
+    """The reference's Rosenbrock example (examples/MALA Rosenbrock.ipynb) as a d-parameter chain with one
+    scalar output: F(theta) = [ sum_i (a - theta_i)^2 + b (theta_{i+1} - theta_i^2)^2 ].  With data [0] and unit
+    variance the log-likelihood is -F^2/2 (BASELINE config 4 uses d = 32, a = 1, b = 10)."""
+
+    def __init__(self, a=1.0, b=10.0):
+        self.a, self.b = float(a), float(b)
+
+    def __call__(self, parameters):
+        t = np.asarray(parameters, dtype=np.float64)
+        return np.array([np.sum((self.a - t[:-1]) ** 2 + self.b * (t[1:] - t[:-1] ** 2) ** 2)])

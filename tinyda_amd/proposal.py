@@ -151,3 +151,84 @@ class AdaptiveMetropolis(GaussianRandomWalk):
     def _lowering(self):
         return dict(kind=_lib.PROP_AM, C_=np.atleast_2d(self.C), adaptive=bool(self.adaptive), gamma=float(self.gamma),
                     period=int(self.period), sd=float(self.sd), epsilon=float(self.epsilon), t0=int(self.t0))
+
+
+class DREAMZ(GaussianRandomWalk):
+    """DREAM(Z): differential-evolution jumps from an archive of past states (proposal.py:608-852).
+    Host protocol = reference semantics (per-chain archive, np.random global stream); on the device path the
+    constructor arguments are lowered and the archive lives in HBM."""
+
+    def __init__(self, M0, delta=1, b=5e-2, b_star=1e-6, Z_method="random", nCR=3, adaptive=False, gamma=1.01, period=100):
+        self.M = M0
+        self.M0 = M0
+        self._init_scaling(1, adaptive, gamma, period)
+        self.delta, self.b, self.b_star = delta, b, b_star
+        self.Z_method = Z_method
+        self.nCR = nCR
+        self.mCR = None
+        self.pCR = np.array(nCR * [1 / nCR])
+
+    def setup_proposal(self, **kwargs):
+        prior = kwargs["posterior"].prior
+        self.d = prior.rvs().size
+        if self.adaptive:
+            self.LCR = np.zeros(self.nCR)
+            self.DeltaCR = np.ones(self.nCR)
+        if self.Z_method == "lhs":
+            import scipy.stats as st
+
+            u = st.qmc.LatinHypercube(d=self.d).random(n=self.M)
+            if hasattr(prior, "ppf"):
+                self.Z = prior.ppf(u)
+                return
+            if hasattr(prior, "mean") and (hasattr(prior, "cov") or hasattr(prior, "cov_object")):
+                cov = prior.cov if hasattr(prior, "cov") else prior.cov_object.covariance
+                self.Z = st.norm(loc=np.asarray(prior.mean), scale=np.sqrt(np.diag(cov))).ppf(u)
+                return
+        self.Z = prior.rvs(self.M)
+
+    def adapt(self, **kwargs):
+        GaussianRandomWalk.adapt(self, **kwargs)
+        self.Z = np.vstack((self.Z, kwargs["parameters"]))
+        self.M = self.Z.shape[0]
+        if self.adaptive and self.t % self.period == 0:
+            jump = kwargs["parameters"] - kwargs["parameters_previous"]
+            self.DeltaCR[self.mCR] += (jump ** 2 / np.var(self.Z, axis=0)).sum()
+            self.LCR[self.mCR] += 1
+            if np.all(self.LCR > 0):
+                mean = self.DeltaCR / self.LCR
+                self.pCR = mean / mean.sum()
+
+    def make_proposal(self, link, Z=None):
+        Z = self.Z if Z is None else Z
+        M = Z.shape[0]
+        up, down = np.zeros(self.d), np.zeros(self.d)
+        for _ in range(self.delta):
+            r1, r2 = np.random.choice(M, 2, replace=False)
+            up += Z[r1]
+            down += Z[r2]
+        self.mCR = np.random.choice(self.nCR, p=self.pCR)
+        mask = (np.random.uniform(size=self.d) < (self.mCR + 1) / self.nCR).astype(float)
+        if mask.sum() == 0:
+            mask[np.random.choice(self.d)] = 1
+        gamma = self.scaling * 2.38 / np.sqrt(2 * self.delta * mask.sum())
+        e = np.random.uniform(-self.b, self.b, size=self.d)
+        eps = np.random.normal(0, self.b_star, size=self.d)
+        return link.parameters + mask * ((1 + e) * gamma * (up - down) + eps)
+
+    _shared = False
+
+    def _lowering(self):
+        if self.Z_method != "random":
+            raise _lib.EngineError("only Z_method='random' is lowered to the device engine")
+        return dict(kind=_lib.PROP_DREAMZ, M0=int(self.M0), delta=int(self.delta), b=float(self.b), b_star=float(self.b_star),
+                    nCR=int(self.nCR), adaptive=bool(self.adaptive), gamma=float(self.gamma), period=int(self.period),
+                    shared=self._shared)
+
+
+class DREAM(DREAMZ):
+    """DREAM with one archive shared by all chains (proposal.py:1627-1656; ray.py:365-384 ArchiveManager).
+    The reference pushes rows to a Ray actor fire-and-forget, so what a proposal sees is timing dependent; the
+    device engine synchronises the archive at block boundaries (RCCL all-gather across GPUs)."""
+
+    _shared = True

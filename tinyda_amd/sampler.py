@@ -11,10 +11,10 @@ import scipy.stats as stats
 
 from . import _lib
 from .chain import Chain
-from .proposal import AdaptiveMetropolis, CrankNicolson, GaussianRandomWalk
+from .proposal import DREAM, DREAMZ, AdaptiveMetropolis, CrankNicolson, GaussianRandomWalk
 from .results import DeviceChain
 
-_DEVICE_PROPOSALS = (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis)
+_DEVICE_PROPOSALS = (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis, DREAMZ, DREAM)
 
 
 MAX_LEVELS = 4
@@ -32,6 +32,10 @@ def _device_plan(posteriors, proposal):
         if low["noise_kind"] == _lib.NOISE_DENSE:
             return None  # dense data covariance is evaluated on the host protocol for now
         lows.append(low)
+    if isinstance(proposal, DREAMZ) and len(posteriors) != 1:
+        return None  # DREAMZ below an MLDA hierarchy is not lowered yet
+    if any("rosenbrock" in low for low in lows) and not isinstance(proposal, DREAMZ):
+        return None  # the Rosenbrock model is fused into the DREAMZ kernel only
     for low in lows[1:]:  # one prior for the hierarchy (every tinyDA example shares it across levels)
         if not (np.array_equal(low["prior_mean"], lows[0]["prior_mean"]) and np.array_equal(low["prior_cov"], lows[0]["prior_cov"])):
             return None
@@ -127,8 +131,17 @@ def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, se
     eng = Engine(n_chains, d, seed=seed, device=device, chain_offset=chain_offset)
     try:
         eng.set_prior(low["prior_mean"], low["prior_cov"])
-        eng.set_level(0, low["A"], low["data"], low["noise_kind"], low["noise"], b=low["b"])
-        eng.set_proposal(**prop)
+        if "rosenbrock" in low:
+            eng.set_level_rosenbrock(0, low["rosenbrock"][0], low["rosenbrock"][1], float(low["data"][0]), float(low["noise"][0]))
+        else:
+            eng.set_level(0, low["A"], low["data"], low["noise_kind"], low["noise"], b=low["b"])
+        if prop["kind"] == _lib.PROP_DREAMZ:
+            dz = {k: v for k, v in prop.items() if k != "kind"}
+            rows = dz["M0"] + iterations * (n_chains if dz["shared"] else 1)
+            eng.set_proposal_dreamz(capacity=rows, **dz)
+            eng.set_archive(None)
+        else:
+            eng.set_proposal(**prop)
         theta0 = None if initial_parameters is None else np.stack([np.asarray(p, float) for p in initial_parameters])
         eng.init(theta0)
         T, N = iterations, n_chains
@@ -138,7 +151,10 @@ def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, se
         params[0], stat[0] = eng.current()
         if T > 0:
             eng.run(T, params[1:], stat[1:], acc[1:])
-        state = eng.proposal_state(want_am=prop["kind"] == _lib.PROP_AM)
+        if prop["kind"] == _lib.PROP_DREAMZ:
+            state = dict(eng.dreamz_state(), scaling=eng.proposal_state_scaling())
+        else:
+            state = eng.proposal_state(want_am=prop["kind"] == _lib.PROP_AM)
     finally:
         eng.close()
     result = {"sampler": "MH", "n_chains": n_chains, "iterations": iterations + 1, "backend": "hip",
