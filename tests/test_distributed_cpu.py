@@ -24,8 +24,11 @@ x = torch.randn(10, 3, generator=g, dtype=torch.float64)[off:off + cnt]
 mean = x.mean(0)
 m2 = (x - mean).T @ (x - mean)
 n, mu, M2 = tdist.gather_moments(cnt, mean, m2)
+# DREAM archive exchange: rank r holds chains [5r, 5r+5) of 3 steps; value encodes (step, global chain)
+loc = torch.tensor([[[100.0 * s + off + c, -1.0] for c in range(cnt)] for s in range(3)], dtype=torch.float64)
+rows = tdist.gather_archive_rows(loc)
 with open(os.path.join(%(out)r, "rank%%d.json" %% rank), "w") as fh:
-    json.dump(dict(rank=rank, off=off, cnt=cnt, mx=mx, sm=sm, n=n, mu=mu.tolist(), M2=M2.tolist()), fh)
+    json.dump(dict(rank=rank, off=off, cnt=cnt, mx=mx, sm=sm, n=n, mu=mu.tolist(), M2=M2.tolist(), rows=rows[:, 0].tolist()), fh)
 """
 
 
@@ -50,6 +53,8 @@ def test_world_size_2_gloo(tmp_path):
     res = [json.load(open(tmp_path / ("rank%d.json" % k))) for k in range(2)]
     assert [d["off"] for d in res] == [0, 5] and [d["cnt"] for d in res] == [5, 5]
     assert all(d["mx"] == 2.0 and d["sm"] == 10.0 and d["n"] == 10.0 for d in res)
+    expect = [100.0 * s_ + c for s_ in range(3) for c in range(10)]  # step-major, global chain minor, on every rank
+    assert res[0]["rows"] == expect and res[1]["rows"] == expect
     import torch
 
     x = torch.randn(10, 3, generator=torch.Generator().manual_seed(5), dtype=torch.float64).numpy()

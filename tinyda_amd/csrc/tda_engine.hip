@@ -210,6 +210,7 @@ struct tda_engine {
   int64_t pending_steps = 0;  // shared mode: steps whose states are in blk_hist but not yet appended
   DevBuf<double> arch, zsum, zsq, dz_pCR, dz_LCR, dz_Delta, dz_coef, dz_epsm, theta_prev, blk_states, blk_hist;
   DevBuf<int32_t> dz_ridx, dz_mcr_last;
+  DevBuf<double> dz_partial;
   DevBuf<int32_t> rp_r, rp_mcr, rp_forced;
   DevBuf<double> rp_sub, rp_e, rp_eps, rp_u;
   int64_t rp_steps = 0, rp_pos = 0;
@@ -256,6 +257,10 @@ void launch_dz_draw(const DreamDrawArgs& a, hipStream_t st) {
 template <int DPAD>
 void launch_dz_steps(const DreamStepArgs& a, size_t lds, hipStream_t st) {
   hipLaunchKernelGGL(k_dreamz_steps<DPAD>, dim3((unsigned)(a.NP / 16)), dim3(256), lds, st, a);
+}
+template <int DPAD>
+void launch_colsum(const double* m, int64_t row0, int64_t nrows, double* partial, int64_t nb, hipStream_t st) {
+  hipLaunchKernelGGL(k_colsum_partial<DPAD>, dim3((unsigned)nb), dim3(64), 0, st, m, row0, nrows, partial);
 }
 template <int DPAD>
 void launch_dz_adapt(const DreamAdaptArgs& a, hipStream_t st) {
@@ -650,7 +655,7 @@ int tda_engine_archive_take(tda_engine* e, double* rows, int64_t* n_steps) {
                                e->DP * sizeof(double), e->d * sizeof(double), e->N, kind, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
   }
-  e->pending_steps = 0;
+  if (rows) e->pending_steps = 0;  // a NULL buffer only asks how many steps are pending
   return TDA_OK;
 }
 
@@ -1481,10 +1486,19 @@ static int dreamz_sums_catchup(tda_engine* e, int64_t row0, int64_t nrows, bool 
   aa.nrows = nrows;
   aa.M_total = row0 + nrows;
   if (e->dz.shared) {
-    if (nrows > 0) {  // one wave advances the shared column sums ...
+    if (nrows > 0) {  // chunked column sums in parallel, then one wave accumulates the chunks in order
+      const int64_t nb = (nrows + COLSUM_CHUNK - 1) / COLSUM_CHUNK;
+      if (e->dz_partial.n < (size_t)nb * 2 * e->DP) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        int rc = e->dz_partial.alloc((size_t)nb * 2 * e->DP);
+        if (rc) return rc;
+      }
+      DISPATCH_DPAD(e->DP, launch_colsum<DPAD>(e->arch.p, row0, nrows, e->dz_partial.p, nb, e->stream));
       DreamAdaptArgs a1 = aa;
       a1.N = 1;
       a1.boundary = 0;
+      a1.partial = e->dz_partial.p;
+      a1.npart = nb;
       DISPATCH_DPAD(e->DP, launch_dz_adapt<DPAD>(a1, e->stream));
     }
     if (!boundary) return TDA_OK;

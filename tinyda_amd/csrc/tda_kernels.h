@@ -1340,6 +1340,8 @@ struct DreamAdaptArgs {
   const double* arch;      // per chain [NP][cap][DPAD] / shared [cap][DPAD]
   double* zsum;            // [NP or 1][DPAD] column sums of the archive
   double* zsq;             // [NP or 1][DPAD] column sums of squares
+  const double* partial;   // shared archive: per-chunk column sums [npart][2][DPAD] from k_colsum_partial (or null)
+  int64_t npart;
   const double* theta;
   const double* theta_prev;
   const int32_t* mcr_last;
@@ -1349,6 +1351,26 @@ struct DreamAdaptArgs {
   double* scaling;
   int32_t* acc_count;
 };
+
+// column sums / sums of squares of rows [row0 + 256 b, row0 + 256 (b+1)) of a row-major [.][DPAD] matrix
+constexpr int COLSUM_CHUNK = 256;
+template <int DPAD>
+__global__ void __launch_bounds__(64) k_colsum_partial(const double* __restrict__ m, int64_t row0, int64_t nrows,
+                                                       double* __restrict__ partial) {
+  const int lane = threadIdx.x;
+  if (lane >= DPAD) return;
+  const int64_t b = blockIdx.x;
+  const int64_t lo = b * COLSUM_CHUNK, hi = lo + COLSUM_CHUNK < nrows ? lo + COLSUM_CHUNK : nrows;
+  double zs = 0.0, zq = 0.0;
+#pragma unroll 8
+  for (int64_t r = lo; r < hi; ++r) {
+    const double z = m[(size_t)(row0 + r) * DPAD + lane];
+    zs += z;
+    zq += z * z;
+  }
+  partial[((size_t)b * 2 + 0) * DPAD + lane] = zs;
+  partial[((size_t)b * 2 + 1) * DPAD + lane] = zq;
+}
 
 template <int DPAD>
 __global__ void __launch_bounds__(64) k_dreamz_adapt(const DreamAdaptArgs a) {
@@ -1364,10 +1386,17 @@ __global__ void __launch_bounds__(64) k_dreamz_adapt(const DreamAdaptArgs a) {
   if (lane < DPAD) {
     zs = a.zsum[so + lane];
     zq = a.zsq[so + lane];
-    for (int64_t r = 0; r < a.nrows; ++r) {
-      const double z = arch_c[(size_t)(a.row0 + r) * DPAD + lane];
-      zs += z;
-      zq += z * z;
+    if (a.partial) {  // ordered accumulation of the chunk sums: deterministic for a given append
+      for (int64_t b = 0; b < a.npart; ++b) {
+        zs += a.partial[((size_t)b * 2 + 0) * DPAD + lane];
+        zq += a.partial[((size_t)b * 2 + 1) * DPAD + lane];
+      }
+    } else {
+      for (int64_t r = 0; r < a.nrows; ++r) {
+        const double z = arch_c[(size_t)(a.row0 + r) * DPAD + lane];
+        zs += z;
+        zq += z * z;
+      }
     }
     if (a.nrows > 0) {
       a.zsum[so + lane] = zs;

@@ -71,3 +71,35 @@ def gather_moments(count, mean, m2):
     tot = float(n.item())
     mu = s1 / tot
     return tot, mu, s2 - tot * torch.outer(mu, mu)
+
+
+def gather_archive_rows(local_rows):
+    """DREAM shared archive: local_rows [steps, n_local, d] (same n_local on every rank) -> all ranks' rows in the
+    canonical order the engine appends them, [steps * n_total, d] = step-major, global chain id minor.  One
+    all_gather per synchronisation (RCCL over xGMI on GPUs, gloo on CPU); identity when not distributed."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local_rows.reshape(-1, local_rows.shape[-1]).contiguous()
+    parts = [torch.empty_like(local_rows) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, local_rows.contiguous())
+    return torch.cat(parts, dim=1).reshape(-1, local_rows.shape[-1]).contiguous()
+
+
+def run_shared_dream(engine, n_iterations, sync_every, params=None, stats=None, accepted=None):
+    """Drive a shared-archive DREAM engine under a process group: `sync_every` steps, then one all_gather of the new
+    rows, appended identically on every rank (tests/test_gpu_dreamz.py checks the result is independent of sharding)."""
+    import torch
+
+    engine.set_archive_auto_append(False)
+    done = 0
+    while done < n_iterations:
+        k = min(sync_every, n_iterations - done)
+        sl = slice(done, done + k)
+        engine.run(k, None if params is None else params[sl], None if stats is None else stats[sl],
+                   None if accepted is None else accepted[sl])
+        buf = torch.empty((k, engine.n_chains, engine.dim), dtype=torch.float64, device="cuda")
+        engine.archive_take(buf)
+        engine.archive_append(gather_archive_rows(buf))
+        done += k

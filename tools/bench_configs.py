@@ -38,7 +38,32 @@ def run(name, ms, sl, prop, n_fine, N=4096, d=64):
     print(json.dumps(res))
     e.close()
 
+def run_c4(N=8192, d=32, T=400, M0=320, K=16):
+    """C4 on one GPU: d=32 Rosenbrock chain, DREAM (shared archive of M0 prior rows + every chain's states, synchronised
+    every K steps), 8192 chains/GPU."""
+    from tinyda_amd import distributed as tdist
+    e = Engine(N, d, seed=4)
+    e.set_prior(np.zeros(d), np.eye(d))
+    e.set_level_rosenbrock(0, 1.0, 10.0, 0.0, 1.0)
+    e.set_proposal_dreamz(M0, delta=1, nCR=3, adaptive=True, period=100, shared=True, sync_every=K, capacity=M0 + (T + 50) * N)
+    e.set_archive(None)
+    e.init(None)
+    params = torch.empty((T, N, d), dtype=torch.float64, device="cuda")
+    stats = torch.empty((T, N, 3), dtype=torch.float64, device="cuda")
+    acc = torch.empty((T, N), dtype=torch.uint8, device="cuda")
+    tdist.run_shared_dream(e, 48, K, params, stats, acc)  # warm-up
+    e.set_profiling(True)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    tdist.run_shared_dream(e, T, K, params, stats, acc)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(json.dumps(dict(config="C4: DREAM (shared archive, sync every %d) on 32-dim Rosenbrock" % K, chains=N, steps=T, seconds=dt,
+                          evals_per_s=N * T / dt, acceptance=float(acc.float().mean().item()), archive_rows=e.dreamz_state()["archive_rows"],
+                          alg_bytes_per_eval=1500, hbm_equiv_GBps=N * T / dt * 1500 / 1e9)))
+    e.close()
+
+
 if __name__ == "__main__":
+    run_c4()
     run("C3: DA pCN(0.02) 256/2048 obs, subsampling_rate=10", (256, 2048), [10], dict(kind=1, scaling=0.02), 200)
     run("C5-literal: MLDA AM 128/512/2048 obs, subchains [5,3], no AEM", (128, 512, 2048), [5, 3],
         dict(kind=2, C_=1e-4 * np.eye(64), t0=100, period=100), 60)
