@@ -33,7 +33,7 @@ def _mk_engine(eng_mod, g, n_chains, d, kind, **kw):
         elif nk == "diag":
             e.set_level(0, g["A"], g["data"], 1, g["noise_cov"])
         else:
-            raise AssertionError(nk)
+            e.set_level(0, g["A"], g["data"], 2, g["noise_cov"])
     return e
 
 
@@ -95,6 +95,27 @@ def test_evaluate_matches_oracle(eng_mod, d, m, noise, prior):
     e.close()
 
 
+@pytest.mark.parametrize("d,m", [(6, 20), (8, 16), (17, 33), (32, 100), (64, 300), (64, 1024)])
+def test_evaluate_dense_noise_matches_oracle(eng_mod, d, m):
+    """DefaultGaussianLogLike (dense data covariance, distributions.py:246-301): r^T Sigma^-1 r on the MFMA path."""
+    rng = np.random.default_rng(d * 7 + m)
+    A = rng.standard_normal((m, d)) / np.sqrt(d)
+    y = rng.standard_normal(m)
+    Lc = 0.3 * np.eye(m) + 0.02 * np.tril(rng.standard_normal((m, m)))
+    cov = Lc @ Lc.T
+    N = 29
+    e = eng_mod.Engine(N, d)
+    e.set_prior(np.zeros(d), np.eye(d))
+    e.set_level(0, A, y, 2, cov)
+    theta = rng.standard_normal((N, d))
+    st = e.evaluate(theta)
+    lvl = orc.LinearGaussianLevel(A, y, "dense", cov, orc.MVNPrior(np.zeros(d), np.eye(d)))
+    lp, ll, _ = lvl.evaluate(theta)
+    np.testing.assert_allclose(st[:, 1], ll, rtol=1e-11)
+    np.testing.assert_allclose(st[:, 2], lp + ll, rtol=1e-11)
+    e.close()
+
+
 def test_golden_g1_grw_adaptive_replay(eng_mod, golden):
     g = golden("g1_basic_sampler")
     N, T1, d = g["theta"].shape
@@ -111,7 +132,7 @@ def test_golden_g1_grw_adaptive_replay(eng_mod, golden):
 
 
 @pytest.mark.parametrize("name,block", [("g2_am_small", 0), ("g2_am_small", 5), ("g2_am_small_adaptive", 0),
-                                        ("g2_am_diag_genprior", 0), ("g2_am_c2", 0)])
+                                        ("g2_am_diag_genprior", 0), ("g2_am_dense", 0), ("g2_am_c2", 0)])
 def test_golden_g2_am_replay(eng_mod, golden, name, block):
     g = golden(name)
     N, T1, d = g["theta"].shape

@@ -79,7 +79,7 @@ void tri_inverse_host(const std::vector<double>& L, int d, std::vector<double>& 
   }
 }
 
-// pack an (rows x cols) row-major matrix into MFMA A-operand fragments, see LevelDev::Apk
+// pack an (rows x cols) row-major matrix into MFMA A-operand fragments, see LevelDev::Apk; kpad = padded K
 void pack_fragments(const double* A, int rows, int cols, int dpad, std::vector<double>& out, int& ncb) {
   ncb = (rows + 15) / 16;
   const int K2 = dpad / 8;
@@ -126,7 +126,7 @@ struct Level {
   double var = 1.0;
   int model = 0;  // tda::MODEL_LINEAR / MODEL_ROSENBROCK
   double ros_a = 1.0, ros_b = 10.0, ros_data = 0.0;
-  DevBuf<double> Apk, ytil, w;
+  DevBuf<double> Apk, ytil, w, Ppk;
 };
 
 struct TimedLaunch {
@@ -226,6 +226,8 @@ using namespace tda;
 
 template <int DPAD>
 void launch_steps(const StepArgs& a, int64_t tiles, size_t lds, hipStream_t st) {
+  if (lds > 64 * 1024)  // beyond the default dynamic-LDS window (gfx950 has 160 KiB per CU)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mh_steps<DPAD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_mh_steps<DPAD>, dim3((unsigned)tiles), dim3(256), lds, st, a);
 }
 template <int DPAD>
@@ -299,6 +301,7 @@ size_t steps_lds_bytes(const tda_engine* e, const Level& lv) {
   const bool diag = lv.noise_kind == TDA_NOISE_DIAG;
   const int prow = e->prior_kind == PRIOR_DENSE ? e->prior_ncb * 16 : 0;
   size_t nd = (size_t)16 * (e->DP + 2) + 128 + lv.m_pad + (diag ? lv.m_pad : 0) + prow;
+  if (lv.noise_kind == TDA_NOISE_DENSE) nd += (size_t)16 * (lv.m_pad + 2);
   return nd * sizeof(double);
 }
 
@@ -306,6 +309,7 @@ void fill_level(const tda_engine* e, const Level& lv, StepArgs& a) {
   a.lv.Apk = lv.Apk.p;
   a.lv.ytil = lv.ytil.p;
   a.lv.w = lv.w.p;
+  a.lv.Ppk = lv.Ppk.p;
   a.lv.ncb = lv.ncb;
   a.lv.m_pad = lv.m_pad;
   a.lv.noise_kind = lv.noise_kind;
@@ -473,9 +477,9 @@ int tda_engine_set_level(tda_engine* e, int level, int m, const double* A, const
   if (m < 1) return fail(TDA_ERR_INVALID, "m must be >= 1");
   HIP_TRY(hipSetDevice(e->cfg.device));
   Level& lv = e->levels[level];
-  if (noise_kind == TDA_NOISE_DENSE)
-    return fail(TDA_ERR_UNSUPPORTED, "dense noise covariance (DefaultGaussianLogLike) is not lowered to the device yet");
-  if (noise_kind != TDA_NOISE_ISO && noise_kind != TDA_NOISE_DIAG) return fail(TDA_ERR_INVALID, "noise_kind %d", noise_kind);
+  if (noise_kind < TDA_NOISE_ISO || noise_kind > TDA_NOISE_DENSE) return fail(TDA_ERR_INVALID, "noise_kind %d", noise_kind);
+  if (noise_kind == TDA_NOISE_DENSE && (e->nlev != 1))
+    return fail(TDA_ERR_UNSUPPORTED, "dense noise covariance is lowered for single-level chains only so far");
   std::vector<double> Apk;
   pack_fragments(A, m, e->d, e->DP, Apk, lv.ncb);
   lv.m = m;
@@ -483,7 +487,23 @@ int tda_engine_set_level(tda_engine* e, int level, int m, const double* A, const
   lv.noise_kind = noise_kind;
   std::vector<double> yt(lv.m_pad, 0.0), w;
   for (int i = 0; i < m; ++i) yt[i] = data[i] - (b ? b[i] : 0.0);
-  if (noise_kind == TDA_NOISE_ISO) {
+  std::vector<double> Ppk;
+  if (noise_kind == TDA_NOISE_DENSE) {
+    // Sigma^-1 (distributions.py:280) through the Cholesky factor: P = L^-T L^-1, symmetric by construction
+    std::vector<double> Lc, W;
+    if (!cholesky_host(noise, m, Lc)) return fail(TDA_ERR_NUMERIC, "noise covariance is not positive definite");
+    tri_inverse_host(Lc, m, W);
+    std::vector<double> P((size_t)m * m, 0.0);
+    for (int i = 0; i < m; ++i)
+      for (int j = 0; j <= i; ++j) {
+        double s = 0.0;
+        for (int k = i; k < m; ++k) s += W[(size_t)k * m + i] * W[(size_t)k * m + j];
+        P[(size_t)i * m + j] = P[(size_t)j * m + i] = s;
+      }
+    int ncb2 = 0;
+    pack_fragments(P.data(), m, m, lv.m_pad, Ppk, ncb2);
+    lv.var = 1.0;
+  } else if (noise_kind == TDA_NOISE_ISO) {
     if (!(noise[0] > 0.0)) return fail(TDA_ERR_NUMERIC, "noise variance must be positive");
     lv.var = noise[0];
   } else {
@@ -494,9 +514,11 @@ int tda_engine_set_level(tda_engine* e, int level, int m, const double* A, const
     }
     lv.var = 1.0;
   }
-  const size_t lds = ((size_t)16 * (e->DP + 2) + 128 + (size_t)lv.m_pad * 2 + 64) * sizeof(double);
-  if (lds > 150 * 1024) return fail(TDA_ERR_UNSUPPORTED, "m=%d observations exceed the LDS staging budget", m);
+  const size_t lds = ((size_t)16 * (e->DP + 2) + 128 + (size_t)lv.m_pad * 2 + 64 +
+                      (noise_kind == TDA_NOISE_DENSE ? (size_t)16 * (lv.m_pad + 2) : 0)) * sizeof(double);
+  if (lds > 158 * 1024) return fail(TDA_ERR_UNSUPPORTED, "m=%d observations exceed the LDS staging budget", m);
   int rc;
+  if ((rc = lv.Ppk.upload(Ppk))) return rc;
   if ((rc = lv.Apk.upload(Apk))) return rc;
   if ((rc = lv.ytil.upload(yt))) return rc;
   if ((rc = lv.w.upload(w))) return rc;

@@ -34,6 +34,7 @@ struct LevelDev {
   const double* Apk;   // packed MFMA fragments [ncb][KS/2][64 lanes][2]: A[cb*16+(l&15)][4*(2*k2+e)+(l>>4)]
   const double* ytil;  // [m_pad] data - b   (zero padded)
   const double* w;     // [m_pad] 1/diag(noise) for TDA_NOISE_DIAG, else nullptr
+  const double* Ppk;   // TDA_NOISE_DENSE: Sigma^-1 as MFMA fragments [ncb][m_pad/8][64 lanes][2] (rows = o', k = o)
   int ncb;             // m_pad / 16
   int m_pad;
   int noise_kind;
@@ -133,10 +134,11 @@ __device__ __forceinline__ void frag_load(const double2* __restrict__ base, int 
 
 // One pair of 16-row blocks: 2 x KS MFMAs on two accumulators, then the fused epilogue
 // sum_r w_o (F_o - ytil_o)^2 over the rows this lane holds ((l >> 4) + 4 r, C/D layout of the f64 MFMA).
-template <int DPAD, bool HAS_W>
+template <int DPAD, int MODE>
 __device__ __forceinline__ double pair_sse(const double2 (&f0)[DPAD / 8], const double2 (&f1)[DPAD / 8],
                                            const double (&th)[DPAD / 4], const double* __restrict__ s_y,
-                                           const double* __restrict__ s_w, int cb0, int cb1, bool v1, int hi) {
+                                           double* __restrict__ s_w, int cb0, int cb1, bool v1, int hi) {
+  constexpr bool HAS_W = MODE == 1;
   double4_t a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int k = 0; k < DPAD / 8; ++k) {
@@ -150,18 +152,26 @@ __device__ __forceinline__ double pair_sse(const double2 (&f0)[DPAD / 8], const 
   for (int r = 0; r < 4; ++r) {
     const int o = cb0 * 16 + hi + 4 * r;
     const double res = a0[r] - s_y[o];
-    double sq = res * res;
-    if (HAS_W) sq *= s_w[o];
-    sse += sq;
+    if (MODE == 2) {
+      s_w[o] = res;  // s_w = this lane's residual row (chain l & 15) of the LDS tile
+    } else {
+      double sq = res * res;
+      if (HAS_W) sq *= s_w[o];
+      sse += sq;
+    }
   }
   const int ob1 = v1 ? cb1 : cb0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int o = ob1 * 16 + hi + 4 * r;
     const double res = a1[r] - s_y[o];
-    double sq = res * res;
-    if (HAS_W) sq *= s_w[o];
-    sse += v1 ? sq : 0.0;
+    if (MODE == 2) {
+      if (v1) s_w[o] = res;
+    } else {
+      double sq = res * res;
+      if (HAS_W) sq *= s_w[o];
+      sse += v1 ? sq : 0.0;
+    }
   }
   return sse;
 }
@@ -171,10 +181,10 @@ __device__ __forceinline__ double pair_sse(const double2 (&f0)[DPAD / 8], const 
 // pipe (2 x KS x 64 cycles), the fragments of pair P+1 are in flight from L2.  The sched_barriers keep hipcc
 // from sinking the loads below the MFMAs that precede them in program order.
 // fa0 / fa1 must hold blocks `wave` and `wave + 4` on entry (issued by the caller ahead of its barrier).
-template <int DPAD, bool HAS_W>
+template <int DPAD, int MODE>
 __device__ __forceinline__ double level_sse_partial(const double* __restrict__ Apk, int ncb,
                                                     const double* __restrict__ s_y,
-                                                    const double* __restrict__ s_w,
+                                                    double* __restrict__ s_w,
                                                     const double (&th)[DPAD / 4], int wave, int lane,
                                                     double2 (&fa0)[DPAD / 8], double2 (&fa1)[DPAD / 8]) {
   constexpr int K2 = DPAD / 8;
@@ -186,15 +196,106 @@ __device__ __forceinline__ double level_sse_partial(const double* __restrict__ A
     frag_load<DPAD>(base, cb + 8, ncb, fb0);
     frag_load<DPAD>(base, cb + 12, ncb, fb1);
     __builtin_amdgcn_sched_barrier(0);
-    sse += pair_sse<DPAD, HAS_W>(fa0, fa1, th, s_y, s_w, cb, cb + 4, cb + 4 < ncb, hi);
+    sse += pair_sse<DPAD, MODE>(fa0, fa1, th, s_y, s_w, cb, cb + 4, cb + 4 < ncb, hi);
     __builtin_amdgcn_sched_barrier(0);
     frag_load<DPAD>(base, cb + 16, ncb, fa0);
     frag_load<DPAD>(base, cb + 20, ncb, fa1);
     __builtin_amdgcn_sched_barrier(0);
-    if (cb + 8 < ncb) sse += pair_sse<DPAD, HAS_W>(fb0, fb1, th, s_y, s_w, cb + 8, cb + 12, cb + 12 < ncb, hi);
+    if (cb + 8 < ncb) sse += pair_sse<DPAD, MODE>(fb0, fb1, th, s_y, s_w, cb + 8, cb + 12, cb + 12 < ncb, hi);
     __builtin_amdgcn_sched_barrier(0);
   }
   return sse;
+}
+
+// r^T Sigma^-1 r for the 16 chains of a tile, residual tile s_R[chain][o] (row stride RS doubles) in LDS,
+// DefaultGaussianLogLike.loglike (tinyDA/distributions.py:295-298).  The D layout of the f64 MFMA (row = (l>>4)+4r)
+// is also its B-operand layout, so the residuals feed the second GEMM straight from LDS with ds_read_b64.
+// Sigma^-1 is symmetric: only 16x16 blocks on or below the diagonal are multiplied, off-diagonal blocks count twice.
+// The (block row, k-group) work list of a wave is flattened so that the 8 fragment loads of the next item are in
+// flight from L2 / Infinity Cache while the current item's up to 16 MFMAs execute.
+__device__ __forceinline__ void dq_load(const double2* __restrict__ base, int K2tot, int cbp, int g0, int ncb,
+                                        double2 (&f)[8]) {
+  const int cb = cbp < ncb ? cbp : ncb - 1;
+  const int kend = 2 * (cb + 1);
+  const double2* __restrict__ row = base + (size_t)cb * K2tot * 64;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k2 = g0 + j < kend ? g0 + j : kend - 1;
+    f[j] = row[(size_t)k2 * 64];
+  }
+}
+
+__device__ __forceinline__ void dq_compute(const double2 (&f)[8], int cbp, int g0, const double* __restrict__ rrow,
+                                           int hi, double4_t& aoff, double4_t& adiag) {
+  const int kend = 2 * (cbp + 1), kdiag = 2 * cbp;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k2 = g0 + j;
+    if (k2 < kend) {
+      const double b0 = rrow[8 * k2 + hi], b1 = rrow[8 * k2 + 4 + hi];
+      if (k2 < kdiag) {
+        aoff = mfma_f64(f[j].x, b0, aoff);
+        aoff = mfma_f64(f[j].y, b1, aoff);
+      } else {
+        adiag = mfma_f64(f[j].x, b0, adiag);
+        adiag = mfma_f64(f[j].y, b1, adiag);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ double dense_quadform(const double* __restrict__ Ppk, int ncb, int m_pad,
+                                                 const double* __restrict__ s_R, int RS, int wave, int lane) {
+  const int lc = lane & 15, hi = lane >> 4;
+  const int K2tot = m_pad / 8;
+  const double2* __restrict__ base = reinterpret_cast<const double2*>(Ppk) + lane;
+  const double* __restrict__ rrow = s_R + lc * RS;
+  double s = 0.0;
+  double2 fa[8], fb[8];
+  int cbp = wave, g0 = 0;
+  double4_t aoff = {0.0, 0.0, 0.0, 0.0}, adiag = {0.0, 0.0, 0.0, 0.0};
+  dq_load(base, K2tot, cbp, g0, ncb, fa);
+  while (cbp < ncb) {
+    // ---- phase A: compute from fa while fb loads ----
+    int ncbp = cbp, ng0 = g0 + 8;
+    if (ng0 >= 2 * (cbp + 1)) {
+      ncbp = cbp + 4;
+      ng0 = 0;
+    }
+    dq_load(base, K2tot, ncbp, ng0, ncb, fb);
+    __builtin_amdgcn_sched_barrier(0);
+    dq_compute(fa, cbp, g0, rrow, hi, aoff, adiag);
+    if (ncbp != cbp) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s += rrow[cbp * 16 + hi + 4 * r] * (2.0 * aoff[r] + adiag[r]);
+      aoff = double4_t{0.0, 0.0, 0.0, 0.0};
+      adiag = double4_t{0.0, 0.0, 0.0, 0.0};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    cbp = ncbp;
+    g0 = ng0;
+    if (cbp >= ncb) break;
+    // ---- phase B: compute from fb while fa loads ----
+    ncbp = cbp;
+    ng0 = g0 + 8;
+    if (ng0 >= 2 * (cbp + 1)) {
+      ncbp = cbp + 4;
+      ng0 = 0;
+    }
+    dq_load(base, K2tot, ncbp, ng0, ncb, fa);
+    __builtin_amdgcn_sched_barrier(0);
+    dq_compute(fb, cbp, g0, rrow, hi, aoff, adiag);
+    if (ncbp != cbp) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s += rrow[cbp * 16 + hi + 4 * r] * (2.0 * aoff[r] + adiag[r]);
+      aoff = double4_t{0.0, 0.0, 0.0, 0.0};
+      adiag = double4_t{0.0, 0.0, 0.0, 0.0};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    cbp = ncbp;
+    g0 = ng0;
+  }
+  return s;
 }
 
 template <int DPAD>
@@ -214,13 +315,16 @@ __global__ void __launch_bounds__(256, 1) k_mh_steps(const StepArgs a) {
   constexpr int QACT = DPAD / EPT;
 
   const bool diag = a.lv.noise_kind == 1;
+  const bool dense = a.lv.noise_kind == 2;
   const bool prior_dense = a.pr.kind == PRIOR_DENSE;
+  const int RS = a.lv.m_pad + 2;  // residual tile row stride (dense noise)
   double* s_prop = smem;
   double* s_red = s_prop + 16 * LDP;
   double* s_redp = s_red + 64;
   double* s_y = s_redp + 64;
   double* s_w = s_y + a.lv.m_pad;
   double* s_py = s_w + (diag ? a.lv.m_pad : 0);
+  double* s_R = s_py + (prior_dense ? a.pr.ncb * 16 : 0);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -320,15 +424,23 @@ __global__ void __launch_bounds__(256, 1) k_mh_steps(const StepArgs a) {
       double2 p0[KS / 2], p1[KS / 2];
       frag_load<DPAD>(pbase, wave, a.pr.ncb, p0);
       frag_load<DPAD>(pbase, wave + 4, a.pr.ncb, p1);
-      double p = level_sse_partial<DPAD, false>(a.pr.Wpk, a.pr.ncb, s_py, nullptr, th, wave, lane, p0, p1);
+      double p = level_sse_partial<DPAD, 0>(a.pr.Wpk, a.pr.ncb, s_py, nullptr, th, wave, lane, p0, p1);
       p += __shfl_xor(p, 16);
       p += __shfl_xor(p, 32);
       if (lane < 16) s_redp[wave * 16 + lane] = p;
     }
 
     // ---- forward model + Gaussian log-likelihood (posterior.py:95-108, distributions.py:310-326) ----
-    double sse = diag ? level_sse_partial<DPAD, true>(a.lv.Apk, a.lv.ncb, s_y, s_w, th, wave, lane, f0, f1)
-                      : level_sse_partial<DPAD, false>(a.lv.Apk, a.lv.ncb, s_y, nullptr, th, wave, lane, f0, f1);
+    double sse;
+    if (dense) {
+      // residuals -> LDS tile, then r^T Sigma^-1 r on the matrix cores (distributions.py:295-298)
+      (void)level_sse_partial<DPAD, 2>(a.lv.Apk, a.lv.ncb, s_y, s_R + (lane & 15) * RS, th, wave, lane, f0, f1);
+      __syncthreads();
+      sse = dense_quadform(a.lv.Ppk, a.lv.ncb, a.lv.m_pad, s_R, RS, wave, lane);
+    } else {
+      sse = diag ? level_sse_partial<DPAD, 1>(a.lv.Apk, a.lv.ncb, s_y, s_w, th, wave, lane, f0, f1)
+                 : level_sse_partial<DPAD, 0>(a.lv.Apk, a.lv.ncb, s_y, nullptr, th, wave, lane, f0, f1);
+    }
     sse += __shfl_xor(sse, 16);
     sse += __shfl_xor(sse, 32);
     if (lane < 16) s_red[wave * 16 + lane] = sse;
@@ -336,7 +448,7 @@ __global__ void __launch_bounds__(256, 1) k_mh_steps(const StepArgs a) {
 
     const double tot = ((s_red[lc] + s_red[16 + lc]) + s_red[32 + lc]) + s_red[48 + lc];
     if (prior_dense) maha = ((s_redp[lc] + s_redp[16 + lc]) + s_redp[32 + lc]) + s_redp[48 + lc];
-    const double ll_n = diag ? -0.5 * tot : -0.5 * tot / a.lv.var;
+    const double ll_n = (diag || dense) ? -0.5 * tot : -0.5 * tot / a.lv.var;
     const double lp_n = -0.5 * (a.pr.logconst + maha);
     const double post_n = lp_n + ll_n;  // link.py:48
 
@@ -761,15 +873,15 @@ __global__ void __launch_bounds__(256, 1) k_ml_steps(const MLArgs a) {
       double2 p0[KS / 2], p1[KS / 2];
       frag_load<DPAD>(pbase, wave, a.pr.ncb, p0);
       frag_load<DPAD>(pbase, wave + 4, a.pr.ncb, p1);
-      double p = level_sse_partial<DPAD, false>(a.pr.Wpk, a.pr.ncb, s_py, nullptr, th, wave, lane, p0, p1);
+      double p = level_sse_partial<DPAD, 0>(a.pr.Wpk, a.pr.ncb, s_py, nullptr, th, wave, lane, p0, p1);
       p += __shfl_xor(p, 16);
       p += __shfl_xor(p, 32);
       if (lane < 16) s_redp[wave * 16 + lane] = p;
     }
     const LevelDev& L = a.lv[k];
     const bool dg = L.noise_kind == 1;
-    double sse = dg ? level_sse_partial<DPAD, true>(L.Apk, L.ncb, s_stage + a.lds_y[k], s_stage + a.lds_w[k], th, wave, lane, g0, g1)
-                    : level_sse_partial<DPAD, false>(L.Apk, L.ncb, s_stage + a.lds_y[k], nullptr, th, wave, lane, g0, g1);
+    double sse = dg ? level_sse_partial<DPAD, 1>(L.Apk, L.ncb, s_stage + a.lds_y[k], s_stage + a.lds_w[k], th, wave, lane, g0, g1)
+                    : level_sse_partial<DPAD, 0>(L.Apk, L.ncb, s_stage + a.lds_y[k], nullptr, th, wave, lane, g0, g1);
     sse += __shfl_xor(sse, 16);
     sse += __shfl_xor(sse, 32);
     if (lane < 16) s_red[wave * 16 + lane] = sse;
@@ -1252,7 +1364,7 @@ __global__ void __launch_bounds__(256, 1) k_dreamz_steps(const DreamStepArgs a) 
       double2 p0[KS / 2], p1[KS / 2];
       frag_load<DPAD>(pbase, wave, a.pr.ncb, p0);
       frag_load<DPAD>(pbase, wave + 4, a.pr.ncb, p1);
-      double p = level_sse_partial<DPAD, false>(a.pr.Wpk, a.pr.ncb, s_py, nullptr, th, wave, lane, p0, p1);
+      double p = level_sse_partial<DPAD, 0>(a.pr.Wpk, a.pr.ncb, s_py, nullptr, th, wave, lane, p0, p1);
       p += __shfl_xor(p, 16);
       p += __shfl_xor(p, 32);
       if (lane < 16) s_redp[wave * 16 + lane] = p;
@@ -1260,8 +1372,8 @@ __global__ void __launch_bounds__(256, 1) k_dreamz_steps(const DreamStepArgs a) 
     // ---- likelihood ----
     double ll_n;
     if (linear) {
-      double sse = diag ? level_sse_partial<DPAD, true>(a.lv.Apk, a.lv.ncb, s_y, s_w, th, wave, lane, f0, f1)
-                        : level_sse_partial<DPAD, false>(a.lv.Apk, a.lv.ncb, s_y, nullptr, th, wave, lane, f0, f1);
+      double sse = diag ? level_sse_partial<DPAD, 1>(a.lv.Apk, a.lv.ncb, s_y, s_w, th, wave, lane, f0, f1)
+                        : level_sse_partial<DPAD, 0>(a.lv.Apk, a.lv.ncb, s_y, nullptr, th, wave, lane, f0, f1);
       sse += __shfl_xor(sse, 16);
       sse += __shfl_xor(sse, 32);
       if (lane < 16) s_red[wave * 16 + lane] = sse;

@@ -29,8 +29,9 @@ def _device_plan(posteriors, proposal):
         low = getattr(post, "_lowering", lambda: None)()
         if low is None or low["prior_mean"].shape[0] > 64:
             return None
-        if low["noise_kind"] == _lib.NOISE_DENSE:
-            return None  # dense data covariance is evaluated on the host protocol for now
+        if low["noise_kind"] == _lib.NOISE_DENSE and (len(posteriors) != 1 or isinstance(proposal, DREAMZ)
+                                                      or low["A"] is None or low["A"].shape[0] > 1024):
+            return None  # dense data covariance: single-level GRW / pCN / AM with m <= 1024 on the device so far
         lows.append(low)
     if isinstance(proposal, DREAMZ) and len(posteriors) != 1:
         return None  # DREAMZ below an MLDA hierarchy is not lowered yet

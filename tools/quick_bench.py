@@ -17,7 +17,12 @@ T = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 A, th, y = problem(d, m)
 e = Engine(N, d, seed=1)
 e.set_prior(np.zeros(d), np.eye(d))
-e.set_level(0, A, y, 0, 0.01)
+if len(sys.argv) > 2 and sys.argv[2] == "dense":  # C2b: dense noise covariance (SURVEY 8d variant 2b)
+    rng = np.random.default_rng(1)
+    Lc = 0.1 * np.eye(m) + 0.01 * np.tril(rng.standard_normal((m, m)))
+    e.set_level(0, A, y, 2, Lc @ Lc.T)
+else:
+    e.set_level(0, A, y, 0, 0.01)
 e.set_proposal(2, 1e-4 * np.eye(d), t0=100, period=100)
 e.init(None)
 params = torch.empty((T, N, d), dtype=torch.float64, device="cuda")
