@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -224,11 +225,26 @@ namespace {
 
 using namespace tda;
 
+int g_steps_waves = 0;  // 0 = decide per launch; TINYDA_STEPS_WAVES=4|8 pins it (A/B measurements)
+
 template <int DPAD>
 void launch_steps(const StepArgs& a, int64_t tiles, size_t lds, hipStream_t st) {
-  if (lds > 64 * 1024)  // beyond the default dynamic-LDS window (gfx950 has 160 KiB per CU)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mh_steps<DPAD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_mh_steps<DPAD>, dim3((unsigned)tiles), dim3(256), lds, st, a);
+  if (g_steps_waves == 0) {
+    const char* ev = getenv("TINYDA_STEPS_WAVES");
+    g_steps_waves = (ev && atoi(ev) == 4) ? 4 : 8;
+  }
+  // dense noise keeps a 128 KiB residual tile and long MFMA chains per wave: 4 waves (512 registers) there
+  const bool eight = g_steps_waves == 8 && a.lv.noise_kind != TDA_NOISE_DENSE;
+  if (eight) {
+    const size_t l8 = lds + 2 * 64 * sizeof(double);  // two more [4][16] reduction slabs
+    if (l8 > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mh_steps<DPAD, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l8);
+    hipLaunchKernelGGL((k_mh_steps<DPAD, 8>), dim3((unsigned)tiles), dim3(512), l8, st, a);
+  } else {
+    if (lds > 64 * 1024)  // beyond the default dynamic-LDS window (gfx950 has 160 KiB per CU)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mh_steps<DPAD, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_mh_steps<DPAD, 4>), dim3((unsigned)tiles), dim3(256), lds, st, a);
+  }
 }
 template <int DPAD>
 void launch_propose(const ProposeArgs& a, hipStream_t st) {
@@ -300,7 +316,7 @@ struct ScopedTimer {
 size_t steps_lds_bytes(const tda_engine* e, const Level& lv) {
   const bool diag = lv.noise_kind == TDA_NOISE_DIAG;
   const int prow = e->prior_kind == PRIOR_DENSE ? e->prior_ncb * 16 : 0;
-  size_t nd = (size_t)16 * (e->DP + 2) + 128 + lv.m_pad + (diag ? lv.m_pad : 0) + prow;
+  size_t nd = (size_t)16 * (e->DP + 2) + 128 + 2 * e->DP + lv.m_pad + (diag ? lv.m_pad : 0) + prow;
   if (lv.noise_kind == TDA_NOISE_DENSE) nd += (size_t)16 * (lv.m_pad + 2);
   return nd * sizeof(double);
 }
@@ -514,7 +530,7 @@ int tda_engine_set_level(tda_engine* e, int level, int m, const double* A, const
     }
     lv.var = 1.0;
   }
-  const size_t lds = ((size_t)16 * (e->DP + 2) + 128 + (size_t)lv.m_pad * 2 + 64 +
+  const size_t lds = ((size_t)16 * (e->DP + 2) + 256 + 2 * e->DP + (size_t)lv.m_pad * 2 + 64 +
                       (noise_kind == TDA_NOISE_DENSE ? (size_t)16 * (lv.m_pad + 2) : 0)) * sizeof(double);
   if (lds > 158 * 1024) return fail(TDA_ERR_UNSUPPORTED, "m=%d observations exceed the LDS staging budget", m);
   int rc;

@@ -180,8 +180,9 @@ __device__ __forceinline__ double pair_sse(const double2 (&f0)[DPAD / 8], const 
 // 16 chains of the tile.  Software pipeline with two explicit register sets: while pair P is in the matrix
 // pipe (2 x KS x 64 cycles), the fragments of pair P+1 are in flight from L2.  The sched_barriers keep hipcc
 // from sinking the loads below the MFMAs that precede them in program order.
-// fa0 / fa1 must hold blocks `wave` and `wave + 4` on entry (issued by the caller ahead of its barrier).
-template <int DPAD, int MODE>
+// fa0 / fa1 must hold blocks `wave` and `wave + NW` on entry (issued by the caller ahead of its barrier);
+// NW = waves sharing the tile (observation blocks are dealt round-robin over them).
+template <int DPAD, int MODE, int NW = 4>
 __device__ __forceinline__ double level_sse_partial(const double* __restrict__ Apk, int ncb,
                                                     const double* __restrict__ s_y,
                                                     double* __restrict__ s_w,
@@ -192,16 +193,67 @@ __device__ __forceinline__ double level_sse_partial(const double* __restrict__ A
   const double2* __restrict__ base = reinterpret_cast<const double2*>(Apk) + lane;
   double sse = 0.0;
   double2 fb0[K2], fb1[K2];
-  for (int cb = wave; cb < ncb; cb += 16) {
-    frag_load<DPAD>(base, cb + 8, ncb, fb0);
-    frag_load<DPAD>(base, cb + 12, ncb, fb1);
+  for (int cb = wave; cb < ncb; cb += 4 * NW) {
+    frag_load<DPAD>(base, cb + 2 * NW, ncb, fb0);
+    frag_load<DPAD>(base, cb + 3 * NW, ncb, fb1);
     __builtin_amdgcn_sched_barrier(0);
-    sse += pair_sse<DPAD, MODE>(fa0, fa1, th, s_y, s_w, cb, cb + 4, cb + 4 < ncb, hi);
+    sse += pair_sse<DPAD, MODE>(fa0, fa1, th, s_y, s_w, cb, cb + NW, cb + NW < ncb, hi);
     __builtin_amdgcn_sched_barrier(0);
-    frag_load<DPAD>(base, cb + 16, ncb, fa0);
-    frag_load<DPAD>(base, cb + 20, ncb, fa1);
+    frag_load<DPAD>(base, cb + 4 * NW, ncb, fa0);
+    frag_load<DPAD>(base, cb + 5 * NW, ncb, fa1);
     __builtin_amdgcn_sched_barrier(0);
-    if (cb + 8 < ncb) sse += pair_sse<DPAD, MODE>(fb0, fb1, th, s_y, s_w, cb + 8, cb + 12, cb + 12 < ncb, hi);
+    if (cb + 2 * NW < ncb)
+      sse += pair_sse<DPAD, MODE>(fb0, fb1, th, s_y, s_w, cb + 2 * NW, cb + 3 * NW, cb + 3 * NW < ncb, hi);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return sse;
+}
+
+// Single-block variant of the pipeline for the 8-wave tile (two waves per SIMD, 256 registers each): one
+// accumulator chain per block (a dependent f64 MFMA chain issues at full rate), two fragment sets of 32 VGPRs.
+// The second wave of the SIMD covers this wave's epilogue and waits.  fa holds block `wave` on entry.
+template <int DPAD, int MODE>
+__device__ __forceinline__ double block_sse(const double2 (&f)[DPAD / 8], const double (&th)[DPAD / 4],
+                                            const double* __restrict__ s_y, double* __restrict__ s_w, int cb, int hi) {
+  double4_t a0 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < DPAD / 8; ++k) {
+    a0 = mfma_f64(f[k].x, th[2 * k], a0);
+    a0 = mfma_f64(f[k].y, th[2 * k + 1], a0);
+  }
+  double sse = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = cb * 16 + hi + 4 * r;
+    const double res = a0[r] - s_y[o];
+    if (MODE == 2) {
+      s_w[o] = res;
+    } else {
+      double sq = res * res;
+      if (MODE == 1) sq *= s_w[o];
+      sse += sq;
+    }
+  }
+  return sse;
+}
+
+template <int DPAD, int MODE, int NW>
+__device__ __forceinline__ double level_sse_single(const double* __restrict__ Apk, int ncb,
+                                                   const double* __restrict__ s_y, double* __restrict__ s_w,
+                                                   const double (&th)[DPAD / 4], int wave, int lane,
+                                                   double2 (&fa)[DPAD / 8]) {
+  const int hi = lane >> 4;
+  const double2* __restrict__ base = reinterpret_cast<const double2*>(Apk) + lane;
+  double sse = 0.0;
+  double2 fb[DPAD / 8];
+  for (int cb = wave; cb < ncb; cb += 2 * NW) {
+    frag_load<DPAD>(base, cb + NW, ncb, fb);
+    __builtin_amdgcn_sched_barrier(0);
+    sse += block_sse<DPAD, MODE>(fa, th, s_y, s_w, cb, hi);
+    __builtin_amdgcn_sched_barrier(0);
+    frag_load<DPAD>(base, cb + 2 * NW, ncb, fa);
+    __builtin_amdgcn_sched_barrier(0);
+    if (cb + NW < ncb) sse += block_sse<DPAD, MODE>(fb, th, s_y, s_w, cb + NW, hi);
     __builtin_amdgcn_sched_barrier(0);
   }
   return sse;
@@ -244,6 +296,7 @@ __device__ __forceinline__ void dq_compute(const double2 (&f)[8], int cbp, int g
   }
 }
 
+template <int NW = 4>
 __device__ __forceinline__ double dense_quadform(const double* __restrict__ Ppk, int ncb, int m_pad,
                                                  const double* __restrict__ s_R, int RS, int wave, int lane) {
   const int lc = lane & 15, hi = lane >> 4;
@@ -259,7 +312,7 @@ __device__ __forceinline__ double dense_quadform(const double* __restrict__ Ppk,
     // ---- phase A: compute from fa while fb loads ----
     int ncbp = cbp, ng0 = g0 + 8;
     if (ng0 >= 2 * (cbp + 1)) {
-      ncbp = cbp + 4;
+      ncbp = cbp + NW;
       ng0 = 0;
     }
     dq_load(base, K2tot, ncbp, ng0, ncb, fb);
@@ -279,7 +332,7 @@ __device__ __forceinline__ double dense_quadform(const double* __restrict__ Ppk,
     ncbp = cbp;
     ng0 = g0 + 8;
     if (ng0 >= 2 * (cbp + 1)) {
-      ncbp = cbp + 4;
+      ncbp = cbp + NW;
       ng0 = 0;
     }
     dq_load(base, K2tot, ncbp, ng0, ncb, fa);
@@ -305,13 +358,16 @@ __host__ __device__ constexpr int steps_lds_doubles(int m_pad, bool diag, int pr
 
 // ------------------------------------------------------------------------------------------------
 // S fused Metropolis-Hastings steps for one tile of 16 chains  (Chain.sample, tinyDA/chain.py:95-125)
+// NW waves share the tile (4 = one wave per SIMD with up to 512 registers, 8 = two per SIMD with 256):
+// the observation blocks of the forward model are dealt round-robin over the waves.
 // ------------------------------------------------------------------------------------------------
-template <int DPAD>
-__global__ void __launch_bounds__(256, 1) k_mh_steps(const StepArgs a) {
+template <int DPAD, int NW>
+__global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int KS = DPAD / 4;
   constexpr int LDP = DPAD + 2;  // row stride: conflict-free ds_read_b64 fragment gather
-  constexpr int EPT = DPAD >= 16 ? DPAD / 16 : 1;
+  constexpr int TPC = 4 * NW;    // threads per chain in the thread-mapped phases
+  constexpr int EPT = DPAD >= TPC ? DPAD / TPC : 1;
   constexpr int QACT = DPAD / EPT;
 
   const bool diag = a.lv.noise_kind == 1;
@@ -319,9 +375,11 @@ __global__ void __launch_bounds__(256, 1) k_mh_steps(const StepArgs a) {
   const bool prior_dense = a.pr.kind == PRIOR_DENSE;
   const int RS = a.lv.m_pad + 2;  // residual tile row stride (dense noise)
   double* s_prop = smem;
-  double* s_red = s_prop + 16 * LDP;
-  double* s_redp = s_red + 64;
-  double* s_y = s_redp + 64;
+  double* s_red = s_prop + 16 * LDP;   // [NW][16]
+  double* s_redp = s_red + 16 * NW;    // [NW][16]
+  double* s_pm = s_redp + 16 * NW;     // prior mean  [DPAD]
+  double* s_pinv = s_pm + DPAD;        // prior 1/var [DPAD]
+  double* s_y = s_pinv + DPAD;
   double* s_w = s_y + a.lv.m_pad;
   double* s_py = s_w + (diag ? a.lv.m_pad : 0);
   double* s_R = s_py + (prior_dense ? a.pr.ncb * 16 : 0);
@@ -330,25 +388,22 @@ __global__ void __launch_bounds__(256, 1) k_mh_steps(const StepArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t tile = blockIdx.x;
-  const int c = tid >> 4, q = tid & 15;  // thread-mapped (chain, element group)
+  const int c = tid / TPC, q = tid % TPC;    // thread-mapped (chain, element group)
   const int lc = lane & 15, hi = lane >> 4;  // lane-mapped chain / k sub-index
   const int64_t gct = tile * 16 + c;
   const int64_t gcl = tile * 16 + lc;
   const bool active = q < QACT;
+  constexpr int NT = 64 * NW;
 
-  for (int i = tid; i < a.lv.m_pad; i += 256) {
+  for (int i = tid; i < a.lv.m_pad; i += NT) {
     s_y[i] = a.lv.ytil[i];
     if (diag) s_w[i] = a.lv.w[i];
   }
   if (prior_dense)
-    for (int i = tid; i < a.pr.ncb * 16; i += 256) s_py[i] = a.pr.wmu[i];
-
-  // per-lane prior constants for parameters j = 4 kk + hi
-  double pm[KS], pinv[KS];
-#pragma unroll
-  for (int kk = 0; kk < KS; ++kk) {
-    pm[kk] = a.pr.mean[4 * kk + hi];
-    pinv[kk] = prior_dense ? 0.0 : a.pr.pinv[4 * kk + hi];
+    for (int i = tid; i < a.pr.ncb * 16; i += NT) s_py[i] = a.pr.wmu[i];
+  for (int i = tid; i < DPAD; i += NT) {
+    s_pm[i] = a.pr.mean[i];
+    s_pinv[i] = prior_dense ? 0.0 : a.pr.pinv[i];
   }
 
   double cur[EPT], prp[EPT], xin[EPT];
@@ -365,7 +420,8 @@ __global__ void __launch_bounds__(256, 1) k_mh_steps(const StepArgs a) {
   const bool is_pcn = a.prop_kind == 1;
   const double2* fbase = reinterpret_cast<const double2*>(a.lv.Apk) + lane;
   const double2* pbase = reinterpret_cast<const double2*>(a.pr.Wpk) + lane;
-  double2 f0[KS / 2], f1[KS / 2];
+  constexpr bool PAIRS = NW == 4;  // 4 waves: pairs of blocks, 4 fragment sets; 8 waves: single blocks, 2 sets
+  double2 f0[KS / 2], f1[PAIRS ? KS / 2 : 1];
   double unext = 0.5;
   if (!is_eval) {
     if (active) {
@@ -377,9 +433,9 @@ __global__ void __launch_bounds__(256, 1) k_mh_steps(const StepArgs a) {
   __syncthreads();
 
   for (int s = 0; s < a.S; ++s) {
-    // first two fragment blocks of this step: independent of theta', issued ahead of the barrier
+    // first fragment block(s) of this step: independent of theta', issued ahead of the barrier
     frag_load<DPAD>(fbase, wave, a.lv.ncb, f0);
-    frag_load<DPAD>(fbase, wave + 4, a.lv.ncb, f1);
+    if constexpr (PAIRS) frag_load<DPAD>(fbase, wave + NW, a.lv.ncb, f1);
     // ---- proposal: theta' (proposal.py:249-251 / :351-355) ----
     if (active) {
 #pragma unroll
@@ -414,40 +470,58 @@ __global__ void __launch_bounds__(256, 1) k_mh_steps(const StepArgs a) {
       double p = 0.0;
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) {
-        const double dv = th[kk] - pm[kk];
-        p += dv * dv * pinv[kk];
+        const double dv = th[kk] - s_pm[4 * kk + hi];
+        p += dv * dv * s_pinv[4 * kk + hi];
       }
       p += __shfl_xor(p, 16);
       p += __shfl_xor(p, 32);
       maha = p;
     } else {
-      double2 p0[KS / 2], p1[KS / 2];
-      frag_load<DPAD>(pbase, wave, a.pr.ncb, p0);
-      frag_load<DPAD>(pbase, wave + 4, a.pr.ncb, p1);
-      double p = level_sse_partial<DPAD, 0>(a.pr.Wpk, a.pr.ncb, s_py, nullptr, th, wave, lane, p0, p1);
+      double p;
+      if constexpr (PAIRS) {
+        double2 p0[KS / 2], p1[KS / 2];
+        frag_load<DPAD>(pbase, wave, a.pr.ncb, p0);
+        frag_load<DPAD>(pbase, wave + NW, a.pr.ncb, p1);
+        p = level_sse_partial<DPAD, 0, NW>(a.pr.Wpk, a.pr.ncb, s_py, nullptr, th, wave, lane, p0, p1);
+      } else {
+        double2 p0[KS / 2];
+        frag_load<DPAD>(pbase, wave, a.pr.ncb, p0);
+        p = level_sse_single<DPAD, 0, NW>(a.pr.Wpk, a.pr.ncb, s_py, nullptr, th, wave, lane, p0);
+      }
       p += __shfl_xor(p, 16);
       p += __shfl_xor(p, 32);
       if (lane < 16) s_redp[wave * 16 + lane] = p;
     }
 
-    // ---- forward model + Gaussian log-likelihood (posterior.py:95-108, distributions.py:310-326) ----
+    // ---- forward model + Gaussian log-likelihood (posterior.py:95-108, distributions.py:295-326) ----
     double sse;
-    if (dense) {
-      // residuals -> LDS tile, then r^T Sigma^-1 r on the matrix cores (distributions.py:295-298)
-      (void)level_sse_partial<DPAD, 2>(a.lv.Apk, a.lv.ncb, s_y, s_R + (lane & 15) * RS, th, wave, lane, f0, f1);
-      __syncthreads();
-      sse = dense_quadform(a.lv.Ppk, a.lv.ncb, a.lv.m_pad, s_R, RS, wave, lane);
-    } else {
-      sse = diag ? level_sse_partial<DPAD, 1>(a.lv.Apk, a.lv.ncb, s_y, s_w, th, wave, lane, f0, f1)
-                 : level_sse_partial<DPAD, 0>(a.lv.Apk, a.lv.ncb, s_y, nullptr, th, wave, lane, f0, f1);
+    if constexpr (PAIRS) {
+      if (dense) {
+        // residuals -> LDS tile, then r^T Sigma^-1 r on the matrix cores (distributions.py:295-298)
+        (void)level_sse_partial<DPAD, 2, NW>(a.lv.Apk, a.lv.ncb, s_y, s_R + (lane & 15) * RS, th, wave, lane, f0, f1);
+        __syncthreads();
+        sse = dense_quadform<NW>(a.lv.Ppk, a.lv.ncb, a.lv.m_pad, s_R, RS, wave, lane);
+      } else {
+        sse = diag ? level_sse_partial<DPAD, 1, NW>(a.lv.Apk, a.lv.ncb, s_y, s_w, th, wave, lane, f0, f1)
+                   : level_sse_partial<DPAD, 0, NW>(a.lv.Apk, a.lv.ncb, s_y, nullptr, th, wave, lane, f0, f1);
+      }
+    } else {  // the host launches the 8-wave tile for isotropic / diagonal noise only
+      sse = diag ? level_sse_single<DPAD, 1, NW>(a.lv.Apk, a.lv.ncb, s_y, s_w, th, wave, lane, f0)
+                 : level_sse_single<DPAD, 0, NW>(a.lv.Apk, a.lv.ncb, s_y, nullptr, th, wave, lane, f0);
     }
     sse += __shfl_xor(sse, 16);
     sse += __shfl_xor(sse, 32);
     if (lane < 16) s_red[wave * 16 + lane] = sse;
     __syncthreads();
 
-    const double tot = ((s_red[lc] + s_red[16 + lc]) + s_red[32 + lc]) + s_red[48 + lc];
-    if (prior_dense) maha = ((s_redp[lc] + s_redp[16 + lc]) + s_redp[32 + lc]) + s_redp[48 + lc];
+    double tot = s_red[lc];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) tot += s_red[w * 16 + lc];
+    if (prior_dense) {
+      maha = s_redp[lc];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) maha += s_redp[w * 16 + lc];
+    }
     const double ll_n = (diag || dense) ? -0.5 * tot : -0.5 * tot / a.lv.var;
     const double lp_n = -0.5 * (a.pr.logconst + maha);
     const double post_n = lp_n + ll_n;  // link.py:48
@@ -586,7 +660,10 @@ __global__ void __launch_bounds__(64) k_propose(const ProposeArgs a) {
 template <int DPAD>
 __global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
   constexpr int NS = DPAD / 2 + 1;
-  __shared__ double s_vec[3 * DPAD];
+  // x, mu, mu' each stored twice ([j] and [j + DPAD]) so that the rotated operand of slot s is a plain ds_read_b64
+  // at immediate offset s from the lane's own base: consecutive lanes hit consecutive banks (conflict free) and no
+  // per-slot address arithmetic is needed
+  __shared__ __attribute__((aligned(16))) double s_vec[3 * 2 * DPAD];
   const int lane = threadIdx.x;
   const int64_t c = blockIdx.x;
   if (c >= a.N) return;
@@ -609,14 +686,17 @@ __global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
       __syncthreads();  // previous step's rotation reads are done
       if (lp) {
         s_vec[lane] = x;
-        s_vec[DPAD + lane] = mu;
-        s_vec[2 * DPAD + lane] = mup;
+        s_vec[lane + DPAD] = x;
+        s_vec[2 * DPAD + lane] = mu;
+        s_vec[2 * DPAD + lane + DPAD] = mu;
+        s_vec[4 * DPAD + lane] = mup;
+        s_vec[4 * DPAD + lane + DPAD] = mup;
       }
       __syncthreads();
+      const double* __restrict__ rot = s_vec + (lane < DPAD ? lane : 0);
 #pragma unroll
       for (int sl = 0; sl < NS; ++sl) {
-        const int j = (lane + sl) & (DPAD - 1);
-        const double xj = s_vec[j], mj = s_vec[DPAD + j], mpj = s_vec[2 * DPAD + j];
+        const double xj = rot[sl], mj = rot[2 * DPAD + sl], mpj = rot[4 * DPAD + sl];
         double M = (t * (mu * mj) - t1 * (mup * mpj)) + x * xj;
         if (sl == 0) M = lj ? M + a.eps : M;
         Sg[sl] = ca * Sg[sl] + cb * M;
@@ -657,50 +737,55 @@ struct CholArgs {
 };
 
 template <int DPAD>
+__device__ __forceinline__ double bcast_lane(double v, int src) {  // wave-uniform broadcast of lane `src`'s value
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// Right-looking Cholesky with lane i holding row i of the (padded) matrix in registers; the k / j loops are fully
+// unrolled so every register index is static and L[j][k] reaches the other lanes through v_readlane: no LDS, no
+// barriers.  Element (i, j) receives the subtractions fma(-L[i][k], L[j][k], .) for k = 0..j-1 in ascending order,
+// the same sequence as a left-looking dot product.
+template <int DPAD>
 __global__ void __launch_bounds__(64) k_chol(const CholArgs a) {
   constexpr int NS = DPAD / 2 + 1;
-  constexpr int LDM = DPAD + 1;
-  __shared__ double s_M[DPAD * LDM];
   const int lane = threadIdx.x;
   const int64_t c = blockIdx.x;
   if (c >= a.N) return;
   const bool lj = lane < a.d;
-  // unfold the lower triangle: row i = lane, columns j <= i
-  if (lj) {
-    for (int j = 0; j <= lane; ++j) {
-      const int sl = lane - j;  // (i - j)
-      double v;
-      if (sl <= DPAD / 2)
-        v = a.am_sigma[((size_t)c * NS + sl) * DPAD + j];  // lane j, slot sl -> Sigma[j][j+sl] = Sigma[j][i]
-      else
-        v = a.am_sigma[((size_t)c * NS + (DPAD - sl)) * DPAD + lane];  // lane i, slot D-sl -> Sigma[i][(i+D-sl)%D = j]
-      s_M[lane * LDM + j] = v;
+  const int li = lane < DPAD ? lane : DPAD - 1;
+  double A[DPAD];
+  // row `lane` of Sigma (columns j <= lane) from the circulant fold; padded rows / columns = identity
+#pragma unroll
+  for (int j = 0; j < DPAD; ++j) {
+    double v = (j == li) ? 1.0 : 0.0;
+    if (lj && j < a.d && j <= li) {
+      const int sl = li - j;
+      v = sl <= DPAD / 2 ? a.am_sigma[((size_t)c * NS + sl) * DPAD + j]
+                         : a.am_sigma[((size_t)c * NS + (DPAD - sl)) * DPAD + li];
     }
+    A[j] = v;
   }
-  __syncthreads();
   bool ok = true;
-  for (int k = 0; k < a.d; ++k) {
-    double sacc = 0.0;
-    if (lane >= k && lj) {
-      sacc = s_M[lane * LDM + k];
-      // the LDS reads do not depend on the running sum: unrolling keeps 16 of them in flight
-#pragma unroll 8
-      for (int p = 0; p < k; ++p) sacc = fma(-s_M[lane * LDM + p], s_M[k * LDM + p], sacc);
-    }
-    const double dkk = __shfl(sacc, k);
-    if (!(dkk > 0.0)) {
-      ok = false;
-      break;
-    }
+#pragma unroll
+  for (int k = 0; k < DPAD; ++k) {
+    const double dkk = bcast_lane<DPAD>(A[k], k);
+    ok = ok && (dkk > 0.0);
     const double lkk = sqrt(dkk);
-    if (lane >= k && lj) s_M[lane * LDM + k] = (lane == k) ? lkk : sacc / lkk;
-    __syncthreads();
+    const double lik = (li == k) ? lkk : A[k] / lkk;  // L[i][k] for i >= k (garbage above the diagonal, never read)
+    A[k] = lik;
+#pragma unroll
+    for (int j = k + 1; j < DPAD; ++j) {
+      const double ljk = bcast_lane<DPAD>(lik, j);
+      A[j] = fma(-lik, ljk, A[j]);
+    }
   }
   if (ok) {
     if (lane < DPAD) {
-#pragma unroll 8
+#pragma unroll
       for (int k = 0; k < DPAD; ++k) {
-        const double v = (lj && k < a.d && lane >= k) ? s_M[lane * LDM + k] : 0.0;
+        const double v = (lj && k < a.d && li >= k) ? A[k] : 0.0;
         a.Lk[((size_t)c * DPAD + k) * DPAD + lane] = v;
       }
     }
