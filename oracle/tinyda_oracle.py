@@ -580,3 +580,174 @@ def run_dreamz(level, cfg, theta0, Z0, var):
             pCR = np.where(ok[:, None], mean / mean.sum(axis=1, keepdims=True), pCR)
     return dict(theta=out_theta, logprior=out_lp, loglike=out_ll, logpost=out_lp + out_ll, accepted=out_acc,
                 scaling=scaling, pCR=pCR, archive=Z)
+
+
+# ----------------------------------------------------------------------------------------
+# Adaptive error model (Cui et al. 2019) on top of DA / MLDA
+#   DAChain: chain.py:268-305 (set-up), :446-473 (state-dependent acceptance), :485-523 (update)
+#   MLDAChain / MLDA: chain.py:643-678, :739-765; proposal.py:1407-1467, :1547-1578
+# ----------------------------------------------------------------------------------------
+def run_multilevel_aem(levels, proposal, subchain_lengths, theta0, z, u_levels, n_fine, aem):
+    """Like run_multilevel, with tinyDA's adaptive error model.
+
+    levels[k] = dict(A, b, y, cov | var): every level but the finest has an AdaptiveGaussianLogLike (dense `cov`,
+    distributions.py:332-449), the finest an isotropic one (`var`).  All levels share the output dimension.
+    aem = 'state-independent' (DA and MLDA) or 'state-dependent' (DA only).
+    Book-keeping that differs from run_multilevel: a Link's likelihood can be refreshed later (update_link), and
+    align_chain looks links up by *identity* of their parameter array (proposal.py:1481-1483), so every state
+    carries an id and S[j][q] means "the latest level-j link whose parameters are theta_q".
+    """
+    theta0 = np.asarray(theta0, dtype=float)
+    N, d = theta0.shape
+    nl = len(levels)
+    sl = list(subchain_lengths)
+    m = levels[0]["A"].shape[0]
+    prior = levels[0]["prior"]
+    prop = _BaseProposalState(proposal, theta0, prior.cov)
+    dependent = aem == "state-dependent"
+    assert not dependent or nl == 2
+    is_da = nl == 2
+
+    def forward(k, theta):
+        F = theta @ levels[k]["A"].T
+        return F if levels[k].get("b") is None else F + levels[k]["b"]
+
+    cov_inv = [np.broadcast_to(np.linalg.inv(levels[k]["cov"]), (N, m, m)).copy() for k in range(nl - 1)]
+    bias_tot = [np.zeros((N, m)) for _ in range(nl - 1)]
+
+    def loglike(k, F, bias=None):
+        if k == nl - 1:
+            return loglike_isotropic(F, levels[k]["y"], levels[k]["var"])
+        r = F + (bias_tot[k] if bias is None else bias) - levels[k]["y"]
+        return -0.5 * np.einsum("ni,nij,nj->n", r, cov_inv[k], r)
+
+    def set_bias(k, mu, sigma):  # distributions.py:385-402, per chain
+        bias_tot[k] = mu.copy()
+        refresh = ~np.all(sigma < 1e-9, axis=(1, 2))
+        if refresh.any():
+            cov_inv[k][refresh] = np.linalg.inv(levels[k]["cov"] + sigma[refresh])
+
+    th = [theta0.copy() for _ in range(nl)]
+    F = [forward(k, theta0) for k in range(nl)]
+    lp = [prior.logpdf(theta0) for _ in range(nl)]
+    ll = [loglike(k, F[k]) for k in range(nl)]
+    sid = [np.zeros(N, dtype=np.int64) for _ in range(nl)]
+    # error-model trackers of levels q >= 1
+    mdiff = {q: F[q] - F[q - 1] for q in range(1, nl)}
+    b_mu = {q: mdiff[q].copy() for q in range(1, nl)}
+    b_sig = {q: np.zeros((N, m, m)) for q in range(1, nl)}
+    b_t = {q: 1 for q in range(1, nl)}
+    for q in range(nl - 1, 0, -1):  # chain.py:286-305, :659-678; proposal.py:1442-1467
+        if dependent:
+            set_bias(q - 1, mdiff[q], b_sig[q])
+        else:
+            set_bias(q - 1, sum(b_mu[p] for p in range(q, nl)), sum(b_sig[p] for p in range(q, nl)))
+        ll[q - 1] = loglike(q - 1, F[q - 1])
+    S = {(j, q): (lp[j].copy(), ll[j].copy(), F[j].copy()) for q in range(nl) for j in range(q)}
+    rec = [dict(theta=[], logprior=[], loglike=[], accepted=[]) for _ in range(nl)]
+    rec[nl - 1]["theta"].append(th[nl - 1].copy())
+    rec[nl - 1]["logprior"].append(lp[nl - 1].copy())
+    rec[nl - 1]["loglike"].append(ll[nl - 1].copy())
+    rec[nl - 1]["accepted"].append(np.ones(N, dtype=bool))
+    rec_slot = [[] for _ in range(nl)]  # per record: the state id, to apply later likelihood refreshes of stored links
+    cnt = [0] * nl
+    next_id = [1]
+
+    def record(k, acc):
+        rec[k]["theta"].append(th[k].copy())
+        rec[k]["logprior"].append(lp[k].copy())
+        rec[k]["loglike"].append(ll[k].copy())
+        rec[k]["accepted"].append(acc.copy())
+
+    def pcn_q(x, y):  # proposal.py:364-369
+        beta = prop.scaling
+        dev = y - np.sqrt(1 - beta ** 2)[:, None] * x
+        U = prior.U
+        maha = np.sum(np.square(dev @ U), axis=1) / beta ** 2
+        return -0.5 * (d * LOG_2PI + prior.log_pdet + d * np.log(beta ** 2) + maha)
+
+    def step(k):
+        if k == 0:
+            t = cnt[0]
+            cand = prop.propose(th[0], z[:, t])
+            Fn = forward(0, cand)
+            lpn, lln = prior.logpdf(cand), loglike(0, Fn)
+            alpha = _acceptance(prop.kind, lpn, lln, lp[0], ll[0])
+            acc = u_levels[0][:, t] < alpha
+            th[0] = np.where(acc[:, None], cand, th[0])
+            F[0] = np.where(acc[:, None], Fn, F[0])
+            lp[0], ll[0] = np.where(acc, lpn, lp[0]), np.where(acc, lln, ll[0])
+            sid[0] = np.where(acc, next_id[0], sid[0])
+            next_id[0] += 1
+            prop.accepted.append(acc.copy())
+            prop.adapt(th[0])
+            record(0, acc)
+            cnt[0] += 1
+            return acc
+        L = sl[k - 1]
+        it = cnt[k]
+        start_lp, start_ll, start_F = S[(k - 1, k)]
+        any_acc = np.zeros(N, dtype=bool)
+        for _ in range(L):
+            any_acc |= step(k - 1)
+        y_th, y_lp, y_ll, y_F, y_id = th[k - 1], lp[k - 1], ll[k - 1], F[k - 1], sid[k - 1]
+        Fq = forward(k, y_th)
+        lpn, lln = prior.logpdf(y_th), loglike(k, Fq)
+        with np.errstate(over="ignore", invalid="ignore"):
+            if dependent:  # chain.py:446-473
+                bias_next = Fq - y_F
+                ll_biased = loglike(k - 1, start_F, bias_next)
+                if prop.kind == "pcn":
+                    q_xy, q_yx = pcn_q(th[k], y_th), pcn_q(y_th, th[k])
+                else:
+                    q_xy = q_yx = 0.0
+                alpha = np.exp(np.minimum(lpn + lln + q_yx, start_lp + ll_biased + q_xy)
+                               - np.minimum(lp[k] + ll[k] + q_xy, y_lp + y_ll + q_yx))
+            else:
+                alpha = np.exp((lpn + lln) - (lp[k] + ll[k]) + (start_lp + start_ll) - (y_lp + y_ll))
+        acc = any_acc & (u_levels[k][:, it] < alpha)
+        th[k] = np.where(acc[:, None], y_th, th[k])
+        F[k] = np.where(acc[:, None], Fq, F[k])
+        lp[k], ll[k] = np.where(acc, lpn, lp[k]), np.where(acc, lln, ll[k])
+        sid[k] = np.where(acc, y_id, sid[k])
+        for j in range(k):  # reject: everything below returns to the latest link holding theta_k
+            th[j] = np.where(acc[:, None], th[j], th[k])
+            F[j] = np.where(acc[:, None], F[j], S[(j, k)][2])
+            lp[j] = np.where(acc, lp[j], S[(j, k)][0])
+            ll[j] = np.where(acc, ll[j], S[(j, k)][1])
+            sid[j] = np.where(acc, sid[j], sid[k])
+        for j in range(k):
+            for q in range(j + 1, k + 1):
+                S[(j, q)] = (lp[j].copy(), ll[j].copy(), F[j].copy())
+        prop.accepted.append(acc.copy())
+        # ---- error model update (chain.py:485-523 for DA; :739-765 and proposal.py:1547-1578 for MLDA) ----
+        new_diff = F[k] - F[k - 1]
+        if dependent:
+            corrected = F[k] - (F[k - 1] + mdiff[k])  # chain.py:505-507
+            mdiff[k] = new_diff
+            b_sig[k] = zero_mean_moments_update(b_sig[k], b_t[k], corrected)
+            b_t[k] += 1
+            set_bias(k - 1, mdiff[k], b_sig[k])
+        else:
+            mdiff[k] = new_diff if is_da else np.where(acc[:, None], new_diff, mdiff[k])  # MLDA refreshes on accept only
+            b_mu[k], b_sig[k] = moments_update(b_mu[k], b_sig[k], b_t[k], mdiff[k])
+            b_t[k] += 1
+            set_bias(k - 1, sum(b_mu[p] for p in range(k, nl)), sum(b_sig[p] for p in range(k, nl)))
+        ll[k - 1] = loglike(k - 1, F[k - 1])  # update_link of the latest link one level down
+        for q in range(k, nl):  # every "latest link with parameters theta_q" that is this very link
+            same = sid[q] == sid[k - 1]
+            o = S[(k - 1, q)]
+            S[(k - 1, q)] = (o[0], np.where(same, ll[k - 1], o[1]), o[2])
+        record(k, acc)
+        cnt[k] += 1
+        return acc
+
+    for _ in range(n_fine):
+        step(nl - 1)
+    out = []
+    for k in range(nl):
+        r = rec[k]
+        lpk, llk = np.array(r["logprior"]).T, np.array(r["loglike"]).T
+        out.append(dict(theta=np.swapaxes(np.array(r["theta"]), 0, 1), logprior=lpk, loglike=llk, logpost=lpk + llk,
+                        accepted=np.array(r["accepted"]).T.astype(np.uint8)))
+    return out, dict(bias=bias_tot, b_mu=b_mu, b_sigma=b_sig)

@@ -562,6 +562,112 @@ def g6_dreamz(name, problem, d, M0, delta, nCR, adaptive, period, iters, n_chain
          b_star=np.array(b_star), **extra, **{k: np.array(v) for k, v in out.items()})
 
 
+def _aem_problem(seed, d, m, n_levels, sigma):
+    """Levels share the observation vector (AEM subtracts model outputs of adjacent levels, chain.py:274-276)."""
+    rng = np.random.default_rng(seed)
+    theta_true = rng.standard_normal(d)
+    Afine = rng.standard_normal((m, d)) / np.sqrt(d)
+    y = Afine @ theta_true + sigma * rng.standard_normal(m)
+    As = [Afine + 0.15 * (n_levels - 1 - k) * rng.standard_normal((m, d)) / np.sqrt(d) for k in range(n_levels)]
+    bs = [0.1 * (n_levels - 1 - k) * rng.standard_normal(m) for k in range(n_levels)]
+    return As, bs, y, theta_true
+
+
+def g8_da_aem(name, aem, proposal_kind="grw", d=4, m=8, L=3, iters=50, n_chains=4, seed=801):
+    sigma = 0.3
+    As, bs, y, theta_true = _aem_problem(seed, d, m, 2, sigma)
+    pm, pc = np.zeros(d), np.eye(d)
+    prior = stats.multivariate_normal(pm, pc)
+    cov = sigma ** 2 * np.eye(m)
+    post_c = tda.Posterior(prior, tda.AdaptiveGaussianLogLike(y, cov), make_model(As[0], bs[0]))
+    post_f = tda.Posterior(prior, tda.GaussianLogLike(y, cov), make_model(As[1], bs[1]))
+    rng = np.random.default_rng(seed + 1)
+    theta0 = theta_true[None] + 0.2 * rng.standard_normal((n_chains, d))
+    if proposal_kind == "grw":
+        prop = tda.GaussianRandomWalk(0.05 * np.eye(d), scaling=1.0)
+        pcfg = dict(kind="grw", C=0.05 * np.eye(d), scaling=1.0, adaptive=False, gamma=1.01, period=100)
+    else:
+        prop = tda.CrankNicolson(scaling=0.3)
+        pcfg = dict(kind="pcn", scaling=0.3, adaptive=False, gamma=1.01, period=100)
+    out = {k: [] for k in ("z", "u0", "u1", "th0", "lp0", "ll0", "acc0", "th1", "lp1", "ll1", "acc1", "bias_mu", "bias_sigma")}
+    for c in range(n_chains):
+        with Tap(seed + 50 * c) as tap:
+            ch = tda.DAChain(copy.deepcopy(post_c), copy.deepcopy(post_f), copy.deepcopy(prop), L,
+                             initial_parameters=theta0[c].copy(), adaptive_error_model=aem)
+            ch.sample(iters, progressbar=False)
+        loc = np.array(ch.is_coarse, dtype=bool)
+        cth, clp, cll, _ = chain_trace(ch.chain_coarse)
+        fth, flp, fll, _ = chain_trace(ch.chain_fine)
+        acc_c = np.array(ch.accepted_coarse, dtype=np.uint8)
+        out["th0"].append(cth[loc]); out["lp0"].append(clp[loc]); out["ll0"].append(cll[loc]); out["acc0"].append(acc_c[loc])
+        out["th1"].append(fth); out["lp1"].append(flp); out["ll1"].append(fll)
+        out["acc1"].append(np.array(ch.accepted_fine, dtype=np.uint8))
+        us = _split_uniforms(tap.ulog, 2, None)
+        out["z"].append(np.array(tap.take("z")))
+        out["u0"].append(np.array(us[0]))
+        evaluated = acc_c[loc].reshape(iters, L).sum(axis=1) > 0
+        out["u1"].append(_place(us[1], evaluated))
+        out["bias_mu"].append(np.array(ch.posterior_coarse.likelihood.bias, copy=True))
+        out["bias_sigma"].append(np.array(ch.bias.get_sigma(), copy=True))
+    flat = {"prop_" + k: np.array(v) for k, v in pcfg.items()}
+    save(name, A0=As[0], A1=As[1], b0=bs[0], b1=bs[1], y0=y, y1=y, noise_var=np.array(sigma ** 2), prior_mean=pm, prior_cov=pc,
+         theta0=theta0, subchain_length=np.array(L), aem=np.array(aem), **flat, **{k: np.array(v) for k, v in out.items()})
+
+
+def g8_mlda_aem(name, d=4, m=8, sl=(3, 2), iters=30, n_chains=4, seed=811):
+    sigma = 0.3
+    nl = len(sl) + 1
+    As, bs, y, theta_true = _aem_problem(seed, d, m, nl, sigma)
+    pm, pc = np.zeros(d), np.eye(d)
+    prior = stats.multivariate_normal(pm, pc)
+    cov = sigma ** 2 * np.eye(m)
+    posts = [tda.Posterior(prior, tda.AdaptiveGaussianLogLike(y, cov) if k < nl - 1 else tda.GaussianLogLike(y, cov),
+                           make_model(As[k], bs[k])) for k in range(nl)]
+    rng = np.random.default_rng(seed + 1)
+    theta0 = theta_true[None] + 0.2 * rng.standard_normal((n_chains, d))
+    prop = tda.GaussianRandomWalk(0.05 * np.eye(d), scaling=1.0)
+    pcfg = dict(kind="grw", C=0.05 * np.eye(d), scaling=1.0, adaptive=False, gamma=1.01, period=100)
+    out = {"z": []}
+    for k in range(nl):
+        for key in ("u", "th", "lp", "ll", "acc"):
+            out["%s%d" % (key, k)] = []
+    for c in range(n_chains):
+        with Tap(seed + 50 * c) as tap:
+            ch = tda.MLDAChain([copy.deepcopy(p) for p in posts], copy.deepcopy(prop), list(sl), initial_parameters=theta0[c].copy(),
+                               adaptive_error_model="state-independent")
+            ch.sample(iters, progressbar=False)
+        us = _split_uniforms(tap.ulog, nl, None)
+        out["z"].append(np.array(tap.take("z")))
+        objs = [ch]
+        cur = ch.proposal
+        while True:
+            objs.append(cur)
+            if cur.level == 0:
+                break
+            cur = cur.proposal
+        objs = objs[::-1]
+        local_acc = []
+        for k, ob in enumerate(objs):
+            th, lp, ll, _ = chain_trace(ob.chain)
+            acc = np.array(ob.accepted, dtype=np.uint8)
+            if k < nl - 1:
+                loc = np.array(ob.is_local, dtype=bool)
+                th, lp, ll, acc = th[loc], lp[loc], ll[loc], acc[loc]
+            out["th%d" % k].append(th); out["lp%d" % k].append(lp); out["ll%d" % k].append(ll); out["acc%d" % k].append(acc)
+            local_acc.append(acc)
+        out["u0"].append(np.array(us[0]))
+        for k in range(1, nl):
+            nsteps = len(local_acc[k]) - (1 if k == nl - 1 else 0)
+            evaluated = local_acc[k - 1].reshape(nsteps, sl[k - 1]).sum(axis=1) > 0
+            out["u%d" % k].append(_place(us[k], evaluated))
+    flat = {"prop_" + k: np.array(v) for k, v in pcfg.items()}
+    lv = {}
+    for k in range(nl):
+        lv["A%d" % k], lv["b%d" % k], lv["y%d" % k] = As[k], bs[k], y
+    save(name, noise_var=np.array(sigma ** 2), prior_mean=pm, prior_cov=pc, theta0=theta0, subchain_lengths=np.array(sl),
+         n_levels=np.array(nl), aem=np.array("state-independent"), **lv, **flat, **{k: np.array(v) for k, v in out.items()})
+
+
 FIXTURES = {
     "g1_basic_sampler": g1_basic_sampler,
     "g2_am_small": lambda: g2_am("g2_am_small", d=8, m=16, n_chains=8, iters=128, t0=16, period=16, seed=201),
@@ -586,6 +692,10 @@ FIXTURES = {
                                                   adaptive=True, period=25, iters=200, n_chains=4, seed=602),
     "g6_dreamz_empty_subspace": lambda: g6_dreamz("g6_dreamz_empty_subspace", "linear", d=3, M0=12, delta=1, nCR=3,
                                                   adaptive=True, period=20, iters=120, n_chains=3, seed=603, m=7),
+    "g8_da_aem_indep": lambda: g8_da_aem("g8_da_aem_indep", "state-independent"),
+    "g8_da_aem_dep": lambda: g8_da_aem("g8_da_aem_dep", "state-dependent", seed=802),
+    "g8_da_aem_dep_pcn": lambda: g8_da_aem("g8_da_aem_dep_pcn", "state-dependent", proposal_kind="pcn", L=1, seed=803),
+    "g8_mlda_aem": lambda: g8_mlda_aem("g8_mlda_aem"),
     "g5_mlda_am": lambda: g5_mlda("g5_mlda_am", "am", period=10),
     "g5_mlda_grw_adaptive": lambda: g5_mlda("g5_mlda_grw_adaptive", "grw", adaptive=True, period=7, seed=502),
     "g5_mlda_4level": lambda: g5_mlda("g5_mlda_4level", "am", ms=(6, 10, 16, 24), sl=(3, 2, 2), iters=20, period=10, seed=503),
