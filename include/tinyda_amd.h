@@ -56,7 +56,15 @@ typedef enum tda_status {
 } tda_status;
 
 /* GaussianLogLike factory outcome, tinyDA/distributions.py:237-243 */
-typedef enum tda_noise_kind { TDA_NOISE_ISO = 0, TDA_NOISE_DIAG = 1, TDA_NOISE_DENSE = 2 } tda_noise_kind;
+typedef enum tda_noise_kind {
+  TDA_NOISE_ISO = 0,
+  TDA_NOISE_DIAG = 1,
+  TDA_NOISE_DENSE = 2,
+  TDA_NOISE_ADAPTIVE = 3 /* AdaptiveGaussianLogLike (distributions.py:332-449): dense covariance + per-chain bias */
+} tda_noise_kind;
+
+/* adaptive_error_model of sample() (sampler.py:82-87) */
+typedef enum tda_error_model { TDA_AEM_NONE = 0, TDA_AEM_STATE_INDEPENDENT = 1, TDA_AEM_STATE_DEPENDENT = 2 } tda_error_model;
 
 /* tinyDA/proposal.py: GaussianRandomWalk :132, CrankNicolson :261, AdaptiveMetropolis :372, DREAMZ :608 / DREAM :1627 */
 typedef enum tda_proposal_kind { TDA_PROP_GRW = 0, TDA_PROP_PCN = 1, TDA_PROP_AM = 2, TDA_PROP_DREAMZ = 3 } tda_proposal_kind;
@@ -162,6 +170,12 @@ int tda_engine_set_level_rosenbrock(tda_engine* e, int level, double a, double b
  * level-k steps per step of level k+1.  randomize != 0 selects DAChain's randomize_subchain_length
  * (chain.py:310-321, 525-527; two levels only, needs lengths[0] > 1).  HOST pointer. */
 int tda_engine_set_subchains(tda_engine* e, const int32_t* lengths, int randomize);
+
+/* Adaptive error model (chain.py:268-305, 485-523; :643-678, 739-765): every level below the finest must have been set
+ * with TDA_NOISE_ADAPTIVE (noise = m x m covariance), all levels share m <= 64.  State-dependent is two-level only. */
+int tda_engine_set_error_model(tda_engine* e, int kind);
+/* Error-model state of adaptive level `level` (HOST, any may be NULL): bias [n_chains][m], cov_inverse [n_chains][m][m]. */
+int tda_engine_get_error_model(tda_engine* e, int level, double* bias, double* cov_inverse);
 
 /* Start the chains: theta0 is n_chains x dim, or NULL to draw theta0 ~ prior from RNG stream 2
  * (sampler.py:209).  Evaluates the initial links (chain.py:70) and sets up the proposal

@@ -1,0 +1,86 @@
+"""GPU parity of the adaptive error model: replay of tinyDA's DAChain / MLDAChain traces with adaptive_error_model on."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+KIND = {"grw": 0, "pcn": 1, "am": 2}
+
+
+@pytest.fixture(scope="module")
+def eng_mod():
+    from tinyda_amd import _lib, engine
+
+    _lib.load()
+    return engine
+
+
+def _engine(eng_mod, g, nl, sl, aem):
+    from tests.test_oracle_multilevel import _prop
+
+    th0 = g["theta0"]
+    N, d = th0.shape
+    m = g["A0"].shape[0]
+    e = eng_mod.Engine(N, d, seed=5, n_levels=nl)
+    e.set_prior(g["prior_mean"], g["prior_cov"])
+    for k in range(nl):
+        if k < nl - 1:
+            e.set_level(k, g["A%d" % k], g["y%d" % k], 3, float(g["noise_var"]) * np.eye(m), b=g["b%d" % k])
+        else:
+            e.set_level(k, g["A%d" % k], g["y%d" % k], 0, float(g["noise_var"]), b=g["b%d" % k])
+    pr = _prop(g)
+    if pr["kind"] == "grw":
+        e.set_proposal(0, pr["C"], scaling=pr["scaling"])
+    else:
+        e.set_proposal(1, None, scaling=pr["scaling"])
+    e.set_subchains(sl)
+    e.set_error_model(aem)
+    e.init(th0)
+    return e
+
+
+def _check(outs, g, nl, st_init):
+    for k in range(nl):
+        params, stats, acc = outs[k]
+        ref_acc, ref_lp, ref_ll, ref_th = g["acc%d" % k], g["lp%d" % k], g["ll%d" % k], g["th%d" % k]
+        if k == nl - 1:
+            np.testing.assert_allclose(st_init[:, 2], ref_lp[:, 0] + ref_ll[:, 0], rtol=RTOL)
+            ref_acc, ref_lp, ref_ll, ref_th = ref_acc[:, 1:], ref_lp[:, 1:], ref_ll[:, 1:], ref_th[:, 1:]
+        assert np.array_equal(acc, ref_acc.T), "level %d: %d accept flips" % (k, int((acc != ref_acc.T).sum()))
+        np.testing.assert_allclose(params, np.swapaxes(ref_th, 0, 1), rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(stats[:, :, 0], ref_lp.T, rtol=RTOL)
+        if k == nl - 1:  # coarse links are refreshed after they were recorded (update_link), the finest never is
+            np.testing.assert_allclose(stats[:, :, 2], (ref_lp + ref_ll).T, rtol=RTOL)
+
+
+@pytest.mark.parametrize("name", ["g8_da_aem_indep", "g8_da_aem_dep", "g8_da_aem_dep_pcn"])
+def test_da_error_model_replay(eng_mod, golden, name):
+    g = golden(name)
+    L = int(g["subchain_length"])
+    n_fine = g["th1"].shape[1] - 1
+    e = _engine(eng_mod, g, 2, [L], str(g["aem"]))
+    e.set_replay(np.swapaxes(g["z"], 0, 1), g["u0"].T)
+    e.set_replay_level(1, g["u1"].T)
+    _, st1 = e.level_state(1)
+    outs = e.run_levels_host(n_fine)
+    _check(outs, g, 2, st1)
+    bias, P = e.error_model_state(0, g["A0"].shape[0])
+    np.testing.assert_allclose(bias, g["bias_mu"], rtol=1e-9, atol=1e-12)
+    cov = float(g["noise_var"]) * np.eye(g["A0"].shape[0]) + g["bias_sigma"]
+    np.testing.assert_allclose(P, np.linalg.inv(cov), rtol=1e-7, atol=1e-9)
+    e.close()
+
+
+def test_mlda_error_model_replay(eng_mod, golden):
+    g = golden("g8_mlda_aem")
+    nl = int(g["n_levels"])
+    sl = [int(x) for x in g["subchain_lengths"]]
+    n_fine = g["th%d" % (nl - 1)].shape[1] - 1
+    e = _engine(eng_mod, g, nl, sl, "state-independent")
+    e.set_replay(np.swapaxes(g["z"], 0, 1), g["u0"].T)
+    for k in range(1, nl):
+        e.set_replay_level(k, g["u%d" % k].T)
+    _, stf = e.level_state(nl - 1)
+    outs = e.run_levels_host(n_fine)
+    _check(outs, g, nl, stf)
+    e.close()

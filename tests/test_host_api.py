@@ -179,8 +179,8 @@ def test_multilevel_lowering_and_argument_checks():
         tda.sample(posts[:2], tda.CrankNicolson(), 5, subchain_length=3, randomize_subchain_length=True, store_coarse_chain=False)
     with pytest.raises(ValueError):
         tda.sample(posts, tda.CrankNicolson(), 5, subchain_length=[3])
-    with pytest.raises(NotImplementedError):
-        tda.sample(posts[:2], tda.CrankNicolson(), 5, adaptive_error_model="state-independent")
+    with pytest.raises(ValueError):
+        tda.sample(posts[:2], tda.CrankNicolson(), 5, adaptive_error_model="sometimes")
     with pytest.warns(UserWarning):  # deprecated alias still accepted (sampler.py:113-115)
         with pytest.raises(tda.EngineError):
             tda.sample(posts[:2], tda.CrankNicolson(), 5, subsampling_rate=10)

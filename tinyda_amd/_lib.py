@@ -10,7 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtinyda_hip.so")
 
 TDA_OK = 0
-NOISE_ISO, NOISE_DIAG, NOISE_DENSE = 0, 1, 2
+NOISE_ISO, NOISE_DIAG, NOISE_DENSE, NOISE_ADAPTIVE = 0, 1, 2, 3
+AEM_NONE, AEM_STATE_INDEPENDENT, AEM_STATE_DEPENDENT = 0, 1, 2
 PROP_GRW, PROP_PCN, PROP_AM, PROP_DREAMZ = 0, 1, 2, 3
 
 
@@ -108,6 +109,8 @@ SYMBOLS = {
     "tda_engine_archive_append": (C.c_int, [_P, _P, C.c_int64]),
     "tda_engine_set_archive_auto_append": (C.c_int, [_P, C.c_int]),
     "tda_engine_set_subchains": (C.c_int, [_P, _P, C.c_int]),
+    "tda_engine_set_error_model": (C.c_int, [_P, C.c_int]),
+    "tda_engine_get_error_model": (C.c_int, [_P, C.c_int, _P, _P]),
     "tda_engine_set_replay_level": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
     "tda_engine_get_level_state": (C.c_int, [_P, C.c_int, _P, _P]),
     "tda_engine_init": (C.c_int, [_P, _P]),

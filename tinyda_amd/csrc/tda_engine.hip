@@ -128,6 +128,9 @@ struct Level {
   int model = 0;  // tda::MODEL_LINEAR / MODEL_ROSENBROCK
   double ros_a = 1.0, ros_b = 10.0, ros_data = 0.0;
   DevBuf<double> Apk, ytil, w, Ppk;
+  // adaptive error model: plain row-major copies for the wave-per-chain kernel
+  std::vector<double> A_h, ytil_h, data_h, cov_h;
+  DevBuf<double> A_rm, ytil64, data64, cov64;
 };
 
 struct TimedLaunch {
@@ -189,6 +192,13 @@ struct tda_engine {
   DevBuf<uint8_t> ml_ring;
   DevBuf<double> ml_rec_params[tda::MAXLEV], ml_rec_stats[tda::MAXLEV];
   DevBuf<uint8_t> ml_rec_acc[tda::MAXLEV];
+  // adaptive error model
+  int aem = 0;
+  int aem_m = 0;
+  DevBuf<double> aem_bias[tda::MAXLEV], aem_covinv[tda::MAXLEV], aem_bmu[tda::MAXLEV], aem_bsig[tda::MAXLEV], aem_mdiff[tda::MAXLEV];
+  int64_t aem_bt[tda::MAXLEV] = {1, 1, 1, 1};
+  DevBuf<int64_t> ml_sid;
+  DevBuf<double> prior_W_rm;
   DevBuf<double> u_rep_lv[tda::MAXLEV], ridx_rep;
   int64_t u_rep_lv_n[tda::MAXLEV] = {0, 0, 0, 0}, ridx_rep_n = 0;
   int64_t u_rep_lv_pos[tda::MAXLEV] = {0, 0, 0, 0}, ridx_rep_pos = 0;
@@ -493,7 +503,9 @@ int tda_engine_set_level(tda_engine* e, int level, int m, const double* A, const
   if (m < 1) return fail(TDA_ERR_INVALID, "m must be >= 1");
   HIP_TRY(hipSetDevice(e->cfg.device));
   Level& lv = e->levels[level];
-  if (noise_kind < TDA_NOISE_ISO || noise_kind > TDA_NOISE_DENSE) return fail(TDA_ERR_INVALID, "noise_kind %d", noise_kind);
+  if (noise_kind < TDA_NOISE_ISO || noise_kind > TDA_NOISE_ADAPTIVE) return fail(TDA_ERR_INVALID, "noise_kind %d", noise_kind);
+  if (noise_kind == TDA_NOISE_ADAPTIVE && m > AEM_MP)
+    return fail(TDA_ERR_UNSUPPORTED, "AdaptiveGaussianLogLike on the device is limited to m <= %d observations (per-chain m x m state)", (int)AEM_MP);
   if (noise_kind == TDA_NOISE_DENSE && (e->nlev != 1))
     return fail(TDA_ERR_UNSUPPORTED, "dense noise covariance is lowered for single-level chains only so far");
   std::vector<double> Apk;
@@ -503,8 +515,22 @@ int tda_engine_set_level(tda_engine* e, int level, int m, const double* A, const
   lv.noise_kind = noise_kind;
   std::vector<double> yt(lv.m_pad, 0.0), w;
   for (int i = 0; i < m; ++i) yt[i] = data[i] - (b ? b[i] : 0.0);
+  // row-major copies (error-model kernel)
+  lv.A_h.assign(A, A + (size_t)m * e->d);
+  lv.ytil_h.assign(AEM_MP > m ? AEM_MP : m, 0.0);
+  lv.data_h.assign(AEM_MP > m ? AEM_MP : m, 0.0);
+  for (int i = 0; i < m; ++i) {
+    lv.ytil_h[i] = data[i] - (b ? b[i] : 0.0);
+    lv.data_h[i] = data[i];
+  }
+  lv.cov_h.clear();
   std::vector<double> Ppk;
-  if (noise_kind == TDA_NOISE_DENSE) {
+  if (noise_kind == TDA_NOISE_ADAPTIVE) {
+    std::vector<double> Lc;
+    if (!cholesky_host(noise, m, Lc)) return fail(TDA_ERR_NUMERIC, "noise covariance is not positive definite");
+    lv.cov_h.assign(noise, noise + (size_t)m * m);
+    lv.var = 1.0;
+  } else if (noise_kind == TDA_NOISE_DENSE) {
     // Sigma^-1 (distributions.py:280) through the Cholesky factor: P = L^-T L^-1, symmetric by construction
     std::vector<double> Lc, W;
     if (!cholesky_host(noise, m, Lc)) return fail(TDA_ERR_NUMERIC, "noise covariance is not positive definite");
@@ -534,6 +560,19 @@ int tda_engine_set_level(tda_engine* e, int level, int m, const double* A, const
                       (noise_kind == TDA_NOISE_DENSE ? (size_t)16 * (lv.m_pad + 2) : 0)) * sizeof(double);
   if (lds > 158 * 1024) return fail(TDA_ERR_UNSUPPORTED, "m=%d observations exceed the LDS staging budget", m);
   int rc;
+  if (m <= AEM_MP) {
+    std::vector<double> y64(lv.ytil_h.begin(), lv.ytil_h.begin() + AEM_MP), c64;
+    if ((rc = lv.A_rm.upload(lv.A_h))) return rc;
+    if ((rc = lv.ytil64.upload(y64))) return rc;
+    std::vector<double> d64(lv.data_h.begin(), lv.data_h.begin() + AEM_MP);
+    if ((rc = lv.data64.upload(d64))) return rc;
+    if (!lv.cov_h.empty()) {
+      c64.assign((size_t)AEM_MP * AEM_MP, 0.0);
+      for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m; ++j) c64[(size_t)i * AEM_MP + j] = lv.cov_h[(size_t)i * m + j];
+      if ((rc = lv.cov64.upload(c64))) return rc;
+    }
+  }
   if ((rc = lv.Ppk.upload(Ppk))) return rc;
   if ((rc = lv.Apk.upload(Apk))) return rc;
   if ((rc = lv.ytil.upload(yt))) return rc;
@@ -709,6 +748,39 @@ int tda_engine_archive_append(tda_engine* e, const double* rows, int64_t n_rows)
   if (rc) return rc;
   e->arch_rows += n_rows;
   if (kind == hipMemcpyHostToDevice) HIP_TRY(hipStreamSynchronize(e->stream));
+  return TDA_OK;
+}
+
+int tda_engine_set_error_model(tda_engine* e, int kind) {
+  if (!e) return fail(TDA_ERR_INVALID, "null engine");
+  if (kind < TDA_AEM_NONE || kind > TDA_AEM_STATE_DEPENDENT) return fail(TDA_ERR_INVALID, "Adaptive error model can only be state-dependent, state-independent or None.");
+  if (kind != TDA_AEM_NONE && e->nlev < 2) return fail(TDA_ERR_STATE, "the error model needs at least two levels");
+  if (kind == TDA_AEM_STATE_DEPENDENT && e->nlev != 2) return fail(TDA_ERR_UNSUPPORTED, "state-dependent error model is two-level (DA) only");
+  e->aem = kind;
+  e->inited = false;
+  return TDA_OK;
+}
+
+int tda_engine_get_error_model(tda_engine* e, int level, double* bias, double* cov_inverse) {
+  if (!e || !e->inited || !e->aem) return fail(TDA_ERR_STATE, "no error model active");
+  if (level < 0 || level >= e->nlev - 1) return fail(TDA_ERR_INVALID, "level %d has no adaptive likelihood", level);
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  const int m = e->aem_m;
+  if (bias) {
+    std::vector<double> hb((size_t)e->NP * AEM_MP);
+    HIP_TRY(hipMemcpy(hb.data(), e->aem_bias[level].p, hb.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int64_t c = 0; c < e->N; ++c)
+      for (int i = 0; i < m; ++i) bias[c * m + i] = hb[(size_t)c * AEM_MP + i];
+  }
+  if (cov_inverse) {
+    std::vector<double> hp((size_t)AEM_MP * AEM_MP);
+    for (int64_t c = 0; c < e->N; ++c) {
+      HIP_TRY(hipMemcpy(hp.data(), e->aem_covinv[level].p + (size_t)c * AEM_MP * AEM_MP, hp.size() * sizeof(double), hipMemcpyDeviceToHost));
+      for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m; ++j) cov_inverse[((size_t)c * m + i) * m + j] = hp[(size_t)i * AEM_MP + j];
+    }
+  }
   return TDA_OK;
 }
 
@@ -984,6 +1056,99 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
       if ((rc = e->ml_rec_stats[k].alloc((size_t)e->SMAX * N * 3))) return rc;
       if ((rc = e->ml_rec_acc[k].alloc((size_t)e->SMAX * N))) return rc;
     }
+    if ((rc = e->ml_sid.alloc((size_t)nl * NP))) return rc;
+    HIP_TRY(hipMemsetAsync(e->ml_sid.p, 0, (size_t)nl * NP * sizeof(int64_t), e->stream));
+    if (e->aem) {
+      // ---- adaptive error model set-up (chain.py:268-305; :643-678; proposal.py:1407-1467) ----
+      if (e->randomize) return fail(TDA_ERR_UNSUPPORTED, "randomize_subchain_length together with an error model is not lowered");
+      if (e->prior_kind == PRIOR_DENSE && e->aem == TDA_AEM_STATE_DEPENDENT && e->pp.kind != TDA_PROP_PCN) {}
+      const int m = e->levels[0].m;
+      for (int k = 0; k < nl; ++k) {
+        if (e->levels[k].m != m) return fail(TDA_ERR_INVALID, "error model: all levels must share the output dimension");
+        const bool want_adaptive = k < nl - 1;
+        if (want_adaptive && e->levels[k].noise_kind != TDA_NOISE_ADAPTIVE)
+          return fail(TDA_ERR_INVALID, "error model: level %d needs an AdaptiveGaussianLogLike (TDA_NOISE_ADAPTIVE)", k);
+        if (!want_adaptive && e->levels[k].noise_kind != TDA_NOISE_ISO)
+          return fail(TDA_ERR_UNSUPPORTED, "error model: the finest level must have an isotropic likelihood on the device");
+      }
+      e->aem_m = m;
+      HIP_TRY(hipStreamSynchronize(e->stream));
+      // host copies of theta0 / log-priors, model outputs of every level
+      std::vector<double> th((size_t)NP * DP), lph(NP);
+      HIP_TRY(hipMemcpy(th.data(), e->theta.p, th.size() * sizeof(double), hipMemcpyDeviceToHost));
+      std::vector<std::vector<double>> F(nl, std::vector<double>((size_t)N * m));
+      for (int k = 0; k < nl; ++k)
+        for (int64_t c = 0; c < N; ++c)
+          for (int o = 0; o < m; ++o) {
+            double f = 0.0;
+            for (int j = 0; j < d; ++j) f = std::fma(e->levels[k].A_h[(size_t)o * d + j], th[(size_t)c * DP + j], f);
+            F[k][(size_t)c * m + o] = f - e->levels[k].ytil_h[o];  // F - y + (y - ytil) handled below: residual form
+          }
+      // residual r_k = F_k - ytil_k ; model output F_k = r_k + ytil_k + b_k - b_k ... differences of outputs:
+      // F_q - F_{q-1} = (r_q + y_q) - (r_{q-1} + y_{q-1}) with y = data (ytil = data - b, F = A theta + b)
+      auto Fout = [&](int k, int64_t c, int o) { return F[k][(size_t)c * m + o] + e->levels[k].data_h[o]; };
+      const size_t MM = (size_t)AEM_MP * AEM_MP;
+      std::vector<std::vector<double>> mdiff(nl, std::vector<double>((size_t)NP * AEM_MP, 0.0));
+      for (int q = 1; q < nl; ++q)
+        for (int64_t c = 0; c < N; ++c)
+          for (int o = 0; o < m; ++o) mdiff[q][(size_t)c * AEM_MP + o] = Fout(q, c, o) - Fout(q - 1, c, o);
+      for (int q = 1; q < nl; ++q) {
+        if ((rc = e->aem_mdiff[q].upload(mdiff[q]))) return rc;
+        if ((rc = e->aem_bmu[q].upload(mdiff[q]))) return rc;  // RecursiveSampleMoments(mu0 = model_diff, sigma0 = 0)
+        if ((rc = e->aem_bsig[q].alloc((size_t)NP * MM))) return rc;
+        HIP_TRY(hipMemset(e->aem_bsig[q].p, 0, (size_t)NP * MM * sizeof(double)));
+        e->aem_bt[q] = 1;
+      }
+      std::vector<double> llh(NP, 0.0);
+      for (int k = 0; k < nl - 1; ++k) {
+        // Sigma_e^-1 (distributions.py:280), identical for all chains until a bias covariance exceeds 1e-9
+        std::vector<double> Lc, W, P(MM, 0.0);
+        cholesky_host(e->levels[k].cov_h.data(), m, Lc);
+        tri_inverse_host(Lc, m, W);
+        for (int i = 0; i < m; ++i)
+          for (int j = 0; j <= i; ++j) {
+            double s = 0.0;
+            for (int r = i; r < m; ++r) s += W[(size_t)r * m + i] * W[(size_t)r * m + j];
+            P[(size_t)i * AEM_MP + j] = P[(size_t)j * AEM_MP + i] = s;
+          }
+        if ((rc = e->aem_covinv[k].alloc((size_t)NP * MM))) return rc;
+        for (int64_t c = 0; c < NP; ++c)
+          HIP_TRY(hipMemcpy(e->aem_covinv[k].p + (size_t)c * MM, P.data(), MM * sizeof(double), hipMemcpyHostToDevice));
+        // total bias: state-dependent = the difference itself, otherwise the sum of the means of all trackers above
+        std::vector<double> bt((size_t)NP * AEM_MP, 0.0);
+        for (int64_t c = 0; c < N; ++c)
+          for (int o = 0; o < m; ++o) {
+            double s = 0.0;
+            if (e->aem == TDA_AEM_STATE_DEPENDENT) s = mdiff[k + 1][(size_t)c * AEM_MP + o];
+            else
+              for (int p = k + 1; p < nl; ++p) s += mdiff[p][(size_t)c * AEM_MP + o];
+            bt[(size_t)c * AEM_MP + o] = s;
+          }
+        if ((rc = e->aem_bias[k].upload(bt))) return rc;
+        // update_link of the initial link of level k
+        for (int64_t c = 0; c < N; ++c) {
+          double acc = 0.0;
+          for (int i = 0; i < m; ++i) {
+            double s = 0.0;
+            for (int j = 0; j < m; ++j) s += P[(size_t)i * AEM_MP + j] * (F[k][(size_t)c * m + j] + bt[(size_t)c * AEM_MP + j]);
+            acc += (F[k][(size_t)c * m + i] + bt[(size_t)c * AEM_MP + i]) * s;
+          }
+          llh[c] = -0.5 * acc;
+        }
+        HIP_TRY(hipMemcpy(e->ml_ll.p + (size_t)k * NP, llh.data(), NP * sizeof(double), hipMemcpyHostToDevice));
+      }
+      // S[j][q] = densities of level j at theta0 under the initial error model
+      for (int qq = 1; qq < nl; ++qq)
+        for (int j = 0; j < qq; ++j) {
+          const int p = qq * (qq - 1) / 2 + j;
+          HIP_TRY(hipMemcpy(e->ml_S.p + ((size_t)p * 2 + 0) * NP, e->ml_lp.p + (size_t)j * NP, NP * sizeof(double), hipMemcpyDeviceToDevice));
+          HIP_TRY(hipMemcpy(e->ml_S.p + ((size_t)p * 2 + 1) * NP, e->ml_ll.p + (size_t)j * NP, NP * sizeof(double), hipMemcpyDeviceToDevice));
+        }
+      // whitening matrix of the prior, row-major (pCN transition densities of the state-dependent acceptance)
+      std::vector<double> Wp;
+      tri_inverse_host(e->prior_L_h, d, Wp);
+      if ((rc = e->prior_W_rm.upload(Wp))) return rc;
+    }
   }
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->inited = true;
@@ -1251,7 +1416,7 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
     }
   }
   const int prow = e->prior_kind == PRIOR_DENSE ? e->prior_ncb * 16 : 0;
-  const size_t lds = ((size_t)16 * (DP + 2) + 128 + off + prow) * sizeof(double);
+  const size_t lds = ((size_t)16 * (DP + 2) + 128 + off + prow + (e->aem ? 16 * (e->levels[0].m_pad + 2) + 16 : 0)) * sizeof(double);
   if (lds > 160 * 1024) return fail(TDA_ERR_UNSUPPORTED, "levels need %zu bytes of LDS staging", lds);
 
   if (e->profiling) {
@@ -1266,6 +1431,7 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
   while (done_base < total_base) {
     int64_t S = std::min<int64_t>(total_base - done_base, e->SMAX);
     if (periodic) S = std::min<int64_t>(S, period - (e->t % period));
+    if (e->aem) S = std::min<int64_t>(S, e->sl[0] - e->cnt[0]);  // host-sequenced: stop when the base subchain completes
     // how many local steps each level completes inside this block (uniform schedule)
     int c2[MAXLEV];
     int64_t nblk[MAXLEV] = {S, 0, 0, 0};
@@ -1355,6 +1521,12 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
     for (int k = 1; k < nl; ++k)
       ma.u_rep[k] = e->u_rep_lv_n[k] ? e->u_rep_lv[k].p + (size_t)e->u_rep_lv_pos[k] * N : nullptr;
     ma.ridx_rep = e->ridx_rep_n ? e->ridx_rep.p + (size_t)e->ridx_rep_pos * N : nullptr;
+    ma.cascade = e->aem ? 0 : 1;
+    ma.aem_on = e->aem ? 1 : 0;
+    ma.aem_mp = e->aem ? e->levels[0].m_pad : 0;
+    ma.aem_bias = e->aem ? e->aem_bias[0].p : nullptr;
+    ma.aem_P = e->aem ? e->aem_covinv[0].p : nullptr;
+    ma.sid = e->ml_sid.p;
     bool dev_p[MAXLEV], dev_s[MAXLEV], dev_a[MAXLEV];
     for (int k = 0; k < nl; ++k) {
       double* op = outs ? outs[k].params : nullptr;
@@ -1417,6 +1589,64 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
     }
     HIP_TRY(hipGetLastError());
     if (boundary && adaptive) e->k_adapt += 1;
+
+    if (e->aem) {
+      // host-sequenced upper levels: decision of level q, then the error-model update of level q-1, in ascending q
+      int64_t extra = 0;
+      for (int qq = 1; qq < nl; ++qq) {
+        if (nblk[qq] == 0) continue;
+        AemArgs ag{};
+        ag.N = N;
+        ag.NP = NP;
+        ag.chain_offset = e->cfg.chain_offset;
+        ag.d = d;
+        ag.DP = DP;
+        ag.m = e->aem_m;
+        ag.MP = AEM_MP;
+        ag.nlev = nl;
+        ag.q = qq;
+        ag.is_da = nl == 2;
+        ag.dependent = e->aem == TDA_AEM_STATE_DEPENDENT;
+        ag.prop_kind = e->pp.kind;
+        ag.seed = e->cfg.seed;
+        ag.step = e->done[qq];
+        for (int k = 0; k < nl; ++k) {
+          ag.A[k] = e->levels[k].A_rm.p;
+          ag.ytil[k] = e->levels[k].ytil64.p;
+          ag.data[k] = e->levels[k].data64.p;
+          ag.cov[k] = e->levels[k].cov64.p;
+          ag.bias_tot[k] = e->aem_bias[k].p;
+          ag.cov_inv[k] = e->aem_covinv[k].p;
+          ag.b_mu[k] = e->aem_bmu[k].p;
+          ag.b_sig[k] = e->aem_bsig[k].p;
+          ag.mdiff[k] = e->aem_mdiff[k].p;
+        }
+        ag.var_finest = e->levels[nl - 1].var;
+        ag.pr_mean = e->prior_mean.p;
+        ag.pr_W = e->prior_W_rm.p;
+        ag.pr_logdet = e->prior_logconst - d * std::log(2.0 * M_PI);
+        ag.theta = e->ml_theta.p;
+        ag.lp = e->ml_lp.p;
+        ag.ll = e->ml_ll.p;
+        ag.Sst = e->ml_S.p;
+        ag.anyacc = e->ml_anyacc.p;
+        ag.sid = e->ml_sid.p;
+        ag.b_t = e->aem_bt[qq];
+        ag.scaling = e->scaling.p;
+        ag.u_rep = e->u_rep_lv_n[qq] ? e->u_rep_lv[qq].p + (size_t)e->u_rep_lv_pos[qq] * N : nullptr;
+        ag.ring = e->ml_ring.p;
+        ag.ring_P = e->ring_P;
+        ag.ring_pos = e->ring_pos + S + extra;
+        ag.rec_params = ma.rec_params[qq];
+        ag.rec_stats = ma.rec_stats[qq];
+        ag.rec_acc = ma.rec_acc[qq];
+        ScopedTimer tm(e, 2);
+        hipLaunchKernelGGL(k_aem_action, dim3((unsigned)N), dim3(64), 0, e->stream, ag);
+        e->aem_bt[qq] += 1;
+        extra += 1;
+      }
+      HIP_TRY(hipGetLastError());
+    }
 
     bool host_copies = false;
     int rc;

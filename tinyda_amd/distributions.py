@@ -94,7 +94,7 @@ class AdaptiveGaussianLogLike(DefaultGaussianLogLike):
         return -0.5 * np.linalg.multi_dot((r.T, self.cov_inverse, r))
 
     def _lowering(self):
-        raise _lib.EngineError("AdaptiveGaussianLogLike is not lowered to the device engine yet")
+        return _lib.NOISE_ADAPTIVE, np.asarray(self.cov, dtype=np.float64)
 
 
 def GaussianLogLike(data, covariance):

@@ -123,6 +123,15 @@ class Engine:
         self.subchain_lengths = [int(x) for x in arr]
         check(self.lib.tda_engine_set_subchains(self.h, _ptr(arr), int(randomize)))
 
+    def set_error_model(self, kind):
+        code = {None: 0, "state-independent": 1, "state-dependent": 2}[kind]
+        check(self.lib.tda_engine_set_error_model(self.h, code))
+
+    def error_model_state(self, level, m):
+        bias, P = np.empty((self.n_chains, m)), np.empty((self.n_chains, m, m))
+        check(self.lib.tda_engine_get_error_model(self.h, level, _ptr(bias), _ptr(P)))
+        return bias, P
+
     def init(self, theta0=None):
         if theta0 is not None and isinstance(theta0, np.ndarray):
             theta0 = _f64(theta0)

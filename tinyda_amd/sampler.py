@@ -29,6 +29,8 @@ def _device_plan(posteriors, proposal):
         low = getattr(post, "_lowering", lambda: None)()
         if low is None or low["prior_mean"].shape[0] > 64:
             return None
+        if low["noise_kind"] == _lib.NOISE_ADAPTIVE and (len(posteriors) < 2 or low["A"] is None or low["A"].shape[0] > 64):
+            return None  # AdaptiveGaussianLogLike: coarse levels of a hierarchy, m <= 64 on the device
         if low["noise_kind"] == _lib.NOISE_DENSE and (len(posteriors) != 1 or isinstance(proposal, DREAMZ)
                                                       or low["A"] is None or low["A"].shape[0] > 1024):
             return None  # dense data covariance: single-level GRW / pCN / AM with m <= 1024 on the device so far
@@ -63,8 +65,13 @@ def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None
 
     n_levels = len(posteriors)
     if n_levels > 1:
-        if adaptive_error_model is not None:
-            raise NotImplementedError("adaptive_error_model is not lowered to the device engine yet (DESIGN.md scope table)")
+        if adaptive_error_model not in (None, "state-independent", "state-dependent"):
+            raise ValueError("Adaptive error model can only be state-dependent, state-independent or None.")
+        if n_levels > 2 and adaptive_error_model == "state-dependent":  # sampler.py:184-188
+            warnings.warn(" A state-dedependent adaptive error model for MLDA has not been implemented yet, defaulting to state-independent AEM...")
+            adaptive_error_model = "state-independent"
+        if adaptive_error_model == "state-dependent" and not isinstance(subchain_length, (list, tuple)) and subchain_length > 1:
+            warnings.warn(" Using a state-dependent error model for subchain lengths larger than 1 is not guaranteed to be ergodic. \n")
         if randomize_subchain_length:  # chain.py:310-314
             if n_levels != 2:
                 raise NotImplementedError("randomize_subchain_length is a Delayed Acceptance (two-level) option")
@@ -100,7 +107,7 @@ def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None
                                   chain_offset)
         return _sample_device_multilevel(plan, posteriors, iterations, n_chains, initial_parameters, subchain_length,
                                          subchain_lengths, randomize_subchain_length, store_coarse_chain, seed, device,
-                                         chain_offset)
+                                         chain_offset, adaptive_error_model)
     if n_levels > 1:
         raise NotImplementedError("Delayed Acceptance / MLDA with opaque Python forward models has no host driver in "
                                   "tinyda_amd; declare the models as tinyda_amd.LinearModel")
@@ -166,7 +173,7 @@ def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, se
 
 
 def _sample_device_multilevel(plan, posteriors, iterations, n_chains, initial_parameters, subchain_length,
-                              subchain_lengths, randomize, store_coarse_chain, seed, device, chain_offset):
+                              subchain_lengths, randomize, store_coarse_chain, seed, device, chain_offset, aem=None):
     """Delayed Acceptance (2 levels, result of sampler.py:406-439) and MLDA (>= 3 levels, :510-547) on the device."""
     from .engine import Engine
 
@@ -182,6 +189,8 @@ def _sample_device_multilevel(plan, posteriors, iterations, n_chains, initial_pa
             eng.set_level(k, low["A"], low["data"], low["noise_kind"], low["noise"], b=low["b"])
         eng.set_proposal(**prop)
         eng.set_subchains(subchain_lengths, randomize)
+        if aem is not None:
+            eng.set_error_model(aem)
         theta0 = None if initial_parameters is None else np.stack([np.asarray(p, float) for p in initial_parameters])
         eng.init(theta0)
         T, N = iterations, n_chains
