@@ -1,0 +1,140 @@
+"""Edge cases of the device engine: degenerate sizes, ragged tiles, split runs, loud failures."""
+import numpy as np
+import pytest
+
+from oracle import tinyda_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng_mod():
+    from tinyda_amd import _lib, engine
+
+    _lib.load()
+    return engine
+
+
+def _problem(d, m, seed=0):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((m, d)) / np.sqrt(d)
+    return A, rng.standard_normal(m), rng
+
+
+@pytest.mark.parametrize("d,m,N", [(1, 1, 1), (1, 5, 3), (2, 1, 17), (5, 17, 33), (64, 16, 15), (63, 31, 16), (33, 2, 31)])
+def test_degenerate_and_ragged_shapes(eng_mod, d, m, N):
+    """one parameter, one observation, one chain, chain counts that are not a multiple of the 16-chain tile"""
+    A, y, rng = _problem(d, m, d * 100 + m)
+    T = 40
+    theta0 = 0.3 * rng.standard_normal((N, d))
+    z = rng.standard_normal((T, N, d))
+    u = rng.random((T, N))
+    e = eng_mod.Engine(N, d, seed=1)
+    e.set_prior(np.zeros(d), np.eye(d))
+    e.set_level(0, A, y, 0, 0.5)
+    e.set_proposal(2, 0.05 * np.eye(d), t0=10, period=10, adaptive=True)
+    e.init(theta0)
+    e.set_replay(z, u)
+    params, stats, acc = e.run_host(T)
+    lvl = orc.LinearGaussianLevel(A, y, "iso", 0.5, orc.MVNPrior(np.zeros(d), np.eye(d)))
+    ref = orc.run_mh(lvl, dict(kind="am", C0=0.05 * np.eye(d), t0=10, period=10, adaptive=True), theta0,
+                     np.swapaxes(z, 0, 1), u.T)
+    assert np.array_equal(acc, ref["accepted"][:, 1:].T)
+    np.testing.assert_allclose(stats[:, :, 2], ref["logpost"][:, 1:].T, rtol=1e-10)
+    e.close()
+
+
+def test_zero_and_single_iterations_and_split_runs(eng_mod):
+    d, m, N = 7, 11, 20
+    A, y, rng = _problem(d, m, 5)
+
+    def make():
+        e = eng_mod.Engine(N, d, seed=77, block_steps=13)
+        e.set_prior(np.zeros(d), np.eye(d))
+        e.set_level(0, A, y, 1, 0.2 + rng.random(m) * 0 + 0.3)
+        e.set_proposal(2, 0.02 * np.eye(d), t0=20, period=20, adaptive=True)
+        e.init(np.zeros((N, d)) + 0.1)
+        return e
+
+    e = make()
+    th_a, st_a = e.current()
+    e.run(0)  # no-op
+    th_b, st_b = e.current()
+    assert np.array_equal(th_a, th_b) and np.array_equal(st_a, st_b)
+    whole = e.run_host(200)
+    e.close()
+    e = make()
+    parts = [e.run_host(n) for n in (1, 129, 70)]  # splits that do not line up with blocks or adaptation periods
+    for k in range(3):
+        assert np.array_equal(np.concatenate([p[k] for p in parts]), whole[k]), "state is not carried across run() calls"
+    assert e.proposal_state()["t"] == 200
+    e.close()
+
+
+def test_records_are_optional(eng_mod):
+    d, m, N = 4, 6, 16
+    A, y, _ = _problem(d, m, 6)
+    outs = []
+    for want in ((True, True, True), (False, True, False), (False, False, False)):
+        e = eng_mod.Engine(N, d, seed=3)
+        e.set_prior(np.zeros(d), np.eye(d))
+        e.set_level(0, A, y, 0, 1.0)
+        e.set_proposal(2, 0.1 * np.eye(d), t0=5, period=5)  # AM needs the states even when the caller does not
+        e.init(np.zeros((N, d)))
+        p = np.empty((30, N, d)) if want[0] else None
+        s = np.empty((30, N, 3)) if want[1] else None
+        a = np.empty((30, N), dtype=np.uint8) if want[2] else None
+        e.run(30, p, s, a)
+        outs.append((e.current(), s))
+        e.close()
+    assert np.array_equal(outs[0][0][0], outs[1][0][0]) and np.array_equal(outs[0][0][0], outs[2][0][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_loud_failures(eng_mod):
+    from tinyda_amd import EngineError
+
+    with pytest.raises(EngineError, match="dim=65"):
+        eng_mod.Engine(4, 65)
+    with pytest.raises(EngineError, match="n_levels"):
+        eng_mod.Engine(4, 3, n_levels=5)
+    e = eng_mod.Engine(4, 3)
+    with pytest.raises(EngineError, match="not initialised"):
+        e.run(1)
+    with pytest.raises(EngineError, match="positive definite"):
+        e.set_prior(np.zeros(3), -np.eye(3))
+    e.set_prior(np.zeros(3), np.eye(3))
+    with pytest.raises(EngineError, match="positive"):
+        e.set_level(0, np.eye(3), np.zeros(3), 0, -1.0)
+    e.set_level(0, np.eye(3), np.zeros(3), 0, 1.0)
+    with pytest.raises(EngineError, match="set_prior and set_proposal"):
+        e.init(np.zeros((4, 3)))
+    e.set_proposal(0, np.array([[1.0, 2.0, 0], [2.0, 1.0, 0], [0, 0, 1.0]]))  # indefinite proposal covariance
+    with pytest.raises(EngineError, match="positive definite"):
+        e.init(np.zeros((4, 3)))
+    e.set_proposal(0, np.eye(3))
+    e.init(np.zeros((4, 3)))
+    e.set_replay(np.zeros((2, 4, 3)), np.zeros((2, 4)))
+    with pytest.raises(EngineError, match="replay buffer"):
+        e.run(3)
+    e.close()
+
+
+def test_nan_posterior_is_rejected_and_overflow_accepts(eng_mod):
+    """proposal.py:254-258: NaN proposal posterior -> alpha = 0; exp overflow -> inf -> accept."""
+    d, m, N = 2, 2, 16
+    e = eng_mod.Engine(N, d, seed=1)
+    e.set_prior(np.zeros(d), np.eye(d))
+    e.set_level(0, np.eye(2), np.zeros(2), 0, 1e-300)  # huge likelihood scale: exp overflows towards the mode
+    e.set_proposal(0, np.eye(d))
+    theta0 = np.full((N, d), 3.0)
+    e.init(theta0)
+    z = np.zeros((2, N, d))
+    z[0] = -1.0  # towards the mode: log-ratio ~ +1e300 -> exp = inf -> accept whatever u is
+    z[1, :, 0] = np.nan  # NaN proposal -> rejected
+    u = np.full((2, N), 0.999999)
+    e.set_replay(z, u)
+    params, stats, acc = e.run_host(2)
+    assert acc[0].all() and not acc[1].any()
+    assert np.array_equal(params[1], params[0])
+    e.close()
