@@ -1,0 +1,128 @@
+"""BASELINE configurations 3-5 at full chain counts: size-independent invariants of the device records, plus
+spot re-evaluation of recorded states with the oracle."""
+import numpy as np
+import pytest
+
+from oracle import tinyda_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng_mod():
+    from tinyda_amd import _lib, engine
+
+    _lib.load()
+    return engine
+
+
+def _levels(ms, d=64, seed=2, sigma=0.1):
+    rng = np.random.default_rng(seed)
+    truth = rng.standard_normal(d)
+    return [(A, A @ truth + sigma * rng.standard_normal(m)) for m in ms for A in [rng.standard_normal((m, d)) / 8]]
+
+
+def _check_level_records(P, S, Acc, th_init, level, n_check, seed):
+    assert np.isfinite(P).all() and np.isfinite(S).all()
+    assert np.array_equal(S[:, :, 2], S[:, :, 0] + S[:, :, 1])
+    rng = np.random.default_rng(seed)
+    for t in rng.choice(P.shape[0], 3, replace=False):
+        idx = rng.choice(P.shape[1], n_check, replace=False)
+        lp, ll, _ = level.evaluate(P[t, idx])
+        np.testing.assert_allclose(S[t, idx, 2], lp + ll, rtol=1e-10)
+
+
+def test_c3_delayed_acceptance_full_size(eng_mod):
+    """config 3: 2-level DA, coarse/fine 256/2048 obs, pCN, subsampling 10, 4096 chains."""
+    d, N, L, n_fine = 64, 4096, 10, 20
+    lv = _levels((256, 2048))
+    e = eng_mod.Engine(N, d, seed=3, n_levels=2)
+    e.set_prior(np.zeros(d), np.eye(d))
+    for k, (A, y) in enumerate(lv):
+        e.set_level(k, A, y, 0, 0.01)
+    e.set_proposal(1, None, scaling=0.02)
+    e.set_subchains([L])
+    e.init(None)
+    th0, _ = e.level_state(1)
+    outs = e.run_levels_host(n_fine)
+    prior = orc.MVNPrior(np.zeros(d), np.eye(d))
+    levels = [orc.LinearGaussianLevel(A, y, "iso", 0.01, prior) for A, y in lv]
+    (Pc, Sc, Ac), (Pf, Sf, Af) = outs
+    assert Pc.shape == (n_fine * L, N, d) and Pf.shape == (n_fine, N, d)
+    _check_level_records(Pc, Sc, Ac, th0, levels[0], 128, 1)
+    _check_level_records(Pf, Sf, Af, th0, levels[1], 128, 2)
+    prev_f = np.concatenate([th0[None], Pf[:-1]])
+    assert np.array_equal(Pf[Af == 0], prev_f[Af == 0]), "a rejected fine step changed the fine state"
+    # skip-eval rule: a fine step can only accept if its coarse subchain accepted something (chain.py:357-364)
+    any_coarse = Ac.reshape(n_fine, L, N).any(axis=1)
+    assert not (Af.astype(bool) & ~any_coarse).any()
+    # an accepted fine state is the last coarse state of its subchain
+    last_coarse = Pc.reshape(n_fine, L, N, d)[:, -1]
+    acc = Af.astype(bool)
+    assert np.array_equal(Pf[acc], last_coarse[acc])
+    # after a fine rejection the coarse chain restarts from the fine state (chain.py:394-396)
+    first_coarse_next = Pc.reshape(n_fine, L, N, d)[1:, 0]
+    first_acc_next = Ac.reshape(n_fine, L, N)[1:, 0].astype(bool)
+    same = ~first_acc_next  # coarse step rejected -> state = restart point = current fine state
+    assert np.array_equal(first_coarse_next[same], Pf[:-1][same])
+    assert 0.05 < Ac.mean() < 0.95
+    e.close()
+
+
+def test_c5_mlda_full_size(eng_mod):
+    """config 5 (literal variant): 3-level MLDA 128/512/2048 obs, AdaptiveMetropolis, subchains [5, 3], 4096 chains."""
+    d, N, sl, n_fine = 64, 4096, [5, 3], 8
+    lv = _levels((128, 512, 2048), seed=5)
+    e = eng_mod.Engine(N, d, seed=4, n_levels=3)
+    e.set_prior(np.zeros(d), np.eye(d))
+    for k, (A, y) in enumerate(lv):
+        e.set_level(k, A, y, 0, 0.01)
+    e.set_proposal(2, 1e-4 * np.eye(d), t0=30, period=30)
+    e.set_subchains(sl)
+    e.init(None)
+    th0, _ = e.level_state(2)
+    outs = e.run_levels_host(n_fine)
+    prior = orc.MVNPrior(np.zeros(d), np.eye(d))
+    levels = [orc.LinearGaussianLevel(A, y, "iso", 0.01, prior) for A, y in lv]
+    rows = e.rows_per_level(n_fine)
+    assert rows == [120, 24, 8]
+    for k in range(3):
+        assert outs[k][0].shape[0] == rows[k]
+        _check_level_records(outs[k][0], outs[k][1], outs[k][2], th0, levels[k], 96, 10 + k)
+    A1 = outs[1][2].reshape(n_fine, 3, N).astype(bool)
+    A0 = outs[0][2].reshape(n_fine, 3, 5, N).astype(bool)
+    assert not (A1 & ~A0.any(axis=2)).any(), "level 1 accepted although its level-0 subchain accepted nothing"
+    assert not (outs[2][2].astype(bool) & ~A1.any(axis=1)).any()
+    acc2 = outs[2][2].astype(bool)
+    last1 = outs[1][0].reshape(n_fine, 3, N, d)[:, -1]
+    assert np.array_equal(outs[2][0][acc2], last1[acc2])
+    assert not e.flags().any()
+    e.close()
+
+
+def test_c4_dream_full_size(eng_mod):
+    """config 4 (one GPU's share): DREAM with a shared archive on the 32-dim Rosenbrock chain, 8192 chains."""
+    d, N, T, M0, K = 32, 8192, 64, 320, 16
+    e = eng_mod.Engine(N, d, seed=8)
+    e.set_prior(np.zeros(d), np.eye(d))
+    e.set_level_rosenbrock(0, 1.0, 10.0, 0.0, 1.0)
+    e.set_proposal_dreamz(M0, delta=1, nCR=3, adaptive=True, period=32, shared=True, sync_every=K, capacity=M0 + T * N)
+    e.set_archive(None)
+    e.init(None)
+    th0, _ = e.current()
+    P, S, Acc = e.run_host(T)
+    assert np.isfinite(P).all() and np.isfinite(S).all()
+    level = orc.RosenbrockLevel(orc.MVNPrior(np.zeros(d), np.eye(d)))
+    for t in (0, 31, T - 1):
+        idx = np.random.default_rng(t).choice(N, 256, replace=False)
+        lp, ll, _ = level.evaluate(P[t, idx])
+        np.testing.assert_allclose(S[t, idx, 2], lp + ll, rtol=1e-10)
+    prev = np.concatenate([th0[None], P[:-1]])
+    assert np.array_equal(P[Acc == 0], prev[Acc == 0])
+    # DREAM jumps only move the crossover subspace: accepted moves differ from the previous state in >= 1 coordinate
+    moved = (P != prev).any(axis=-1)
+    assert np.array_equal(moved, Acc.astype(bool))
+    st = e.dreamz_state()
+    assert st["archive_rows"] == M0 + T * N
+    np.testing.assert_allclose(st["pCR"].sum(axis=1), 1.0, rtol=1e-12)
+    e.close()
