@@ -229,6 +229,13 @@ int tda_engine_archive_take(tda_engine* e, double* rows, int64_t* n_steps);
 int tda_engine_archive_append(tda_engine* e, const double* rows, int64_t n_rows);
 int tda_engine_set_archive_auto_append(tda_engine* e, int on);
 
+/* Pooled AdaptiveMetropolis (extension; tinyDA's AM is strictly per chain, proposal.py:492-500): sums over the rows
+ * of a record buffer, out = [n_rows, sum x (dim), sum x x^T (dim*dim)], `rows` a DEVICE pointer to [n_rows][dim],
+ * `out` device or host.  One process per GPU all-reduces `out` over RCCL and hands the pooled covariance back with
+ * tda_engine_set_proposal_covariance (GaussianRandomWalk engines; takes effect at the next run()). */
+int tda_engine_reduce_moments(tda_engine* e, const double* rows, int64_t n_rows, double* out);
+int tda_engine_set_proposal_covariance(tda_engine* e, const double* C);
+
 /* Per-chain error flags (bit 0: Cholesky of an adapted covariance failed, previous factor kept). HOST. */
 int tda_engine_get_flags(tda_engine* e, int32_t* flags);
 

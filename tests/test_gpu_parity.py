@@ -311,3 +311,41 @@ def test_sample_api_on_device(eng_mod):
     assert ml["sampler"] == "MLDA" and ml["levels"] == 3 and ml["subchain_lengths"] == [3, 2]
     assert len(ml["chain_l2_0"]) == 31 and len(ml["chain_l1_0"]) == 60 and len(ml["chain_l0_0"]) == 180
     assert tda.get_samples(ml, level=1)["iterations"] == 60
+
+
+def test_pooled_adaptive_metropolis_extension(eng_mod):
+    """Extension: one AM covariance pooled over all chains (and, under a process group, all GPUs): the device moment
+    reduction equals NumPy's, and the sampler recovers the conjugate posterior covariance."""
+    import torch
+
+    from tinyda_amd.distributed import PooledAdaptiveMetropolis
+
+    d, m, N, T = 16, 64, 512, 600
+    rng = np.random.default_rng(8)
+    A = rng.standard_normal((m, d)) / 4
+    truth = rng.standard_normal(d)
+    y = A @ truth + 0.2 * rng.standard_normal(m)
+    cov_post = np.linalg.inv(A.T @ A / 0.04 + np.eye(d))
+    mean_post = cov_post @ (A.T @ y / 0.04)
+    e = eng_mod.Engine(N, d, seed=21)
+    e.set_prior(np.zeros(d), np.eye(d))
+    e.set_level(0, A, y, 0, 0.04)
+    e.set_proposal(0, 1e-3 * np.eye(d))
+    e.init(mean_post + 0.05 * rng.standard_normal((N, d)))
+    params = torch.empty((T, N, d), dtype=torch.float64, device="cuda")
+    acc = torch.empty((T, N), dtype=torch.uint8, device="cuda")
+    pam = PooledAdaptiveMetropolis(e, 1e-3 * np.eye(d), t0=100, period=100)
+    pam.run(T, params, None, acc)
+    P = params.cpu().numpy()
+    s = pam.sums.cpu().numpy()
+    flat = P.reshape(-1, d)
+    np.testing.assert_allclose(s[0], flat.shape[0])
+    np.testing.assert_allclose(s[1:1 + d], flat.sum(0), rtol=1e-11)
+    np.testing.assert_allclose(s[1 + d:].reshape(d, d), flat.T @ flat, rtol=1e-11)
+    tail = P[300:].reshape(-1, d)
+    np.testing.assert_allclose(tail.mean(0), mean_post, atol=4 * np.sqrt(np.diag(cov_post)).max() / np.sqrt(200))
+    ratio = np.diag(np.cov(tail.T)) / np.diag(cov_post)
+    assert np.all((ratio > 0.7) & (ratio < 1.4)), ratio
+    np.testing.assert_allclose(e.proposal_state()["C"][0], pam.C, rtol=1e-10)
+    assert 0.1 < acc[300:].float().mean().item() < 0.6
+    e.close()

@@ -751,6 +751,45 @@ int tda_engine_archive_append(tda_engine* e, const double* rows, int64_t n_rows)
   return TDA_OK;
 }
 
+int tda_engine_reduce_moments(tda_engine* e, const double* rows, int64_t n_rows, double* out) {
+  if (!e || !rows || !out) return fail(TDA_ERR_INVALID, "null argument");
+  if (!is_device_ptr(rows)) return fail(TDA_ERR_INVALID, "reduce_moments needs a device record buffer");
+  if (n_rows < 1) return fail(TDA_ERR_INVALID, "n_rows must be >= 1");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const int d = e->d, DP = e->DP;
+  const int64_t nb = (n_rows + MOM_CHUNK - 1) / MOM_CHUNK;
+  DevBuf<double> partial, outd;
+  int rc;
+  if ((rc = partial.alloc((size_t)nb * (DP + (size_t)DP * DP)))) return rc;
+  const bool odev = is_device_ptr(out);
+  const size_t nout = 1 + d + (size_t)d * d;
+  if (!odev && (rc = outd.alloc(nout))) return rc;
+  double* o = odev ? out : outd.p;
+  DISPATCH_DPAD(DP, hipLaunchKernelGGL(k_moments_partial<DPAD>, dim3((unsigned)nb), dim3(64), 0, e->stream, rows, n_rows, d, partial.p));
+  DISPATCH_DPAD(DP, hipLaunchKernelGGL(k_moments_final<DPAD>, dim3((unsigned)(d + 1)), dim3(64), 0, e->stream, partial.p, nb, n_rows, d, o));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (!odev) HIP_TRY(hipMemcpy(out, outd.p, nout * sizeof(double), hipMemcpyDeviceToHost));
+  return TDA_OK;
+}
+
+int tda_engine_set_proposal_covariance(tda_engine* e, const double* C) {
+  if (!e || !C) return fail(TDA_ERR_INVALID, "null argument");
+  if (!e->inited || e->pp.kind != TDA_PROP_GRW || !e->L_shared)
+    return fail(TDA_ERR_STATE, "set_proposal_covariance applies to an initialised GaussianRandomWalk engine");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const int d = e->d, DP = e->DP;
+  std::vector<double> Ch(C, C + (size_t)d * d), L;
+  if (!cholesky_host(Ch.data(), d, L)) return fail(TDA_ERR_NUMERIC, "proposal covariance is not positive definite");
+  std::vector<double> Lk((size_t)DP * DP, 0.0);
+  for (int j = 0; j < d; ++j)
+    for (int k = 0; k <= j; ++k) Lk[(size_t)k * DP + j] = L[(size_t)j * d + k];
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipMemcpy(e->Lk.p, Lk.data(), Lk.size() * sizeof(double), hipMemcpyHostToDevice));
+  e->prop_C_h = Ch;
+  return TDA_OK;
+}
+
 int tda_engine_set_error_model(tda_engine* e, int kind) {
   if (!e) return fail(TDA_ERR_INVALID, "null engine");
   if (kind < TDA_AEM_NONE || kind > TDA_AEM_STATE_DEPENDENT) return fail(TDA_ERR_INVALID, "Adaptive error model can only be state-dependent, state-independent or None.");

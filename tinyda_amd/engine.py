@@ -123,6 +123,21 @@ class Engine:
         self.subchain_lengths = [int(x) for x in arr]
         check(self.lib.tda_engine_set_subchains(self.h, _ptr(arr), int(randomize)))
 
+    def reduce_moments(self, rows, out=None):
+        """[count, sum x, sum x x^T] over a device record buffer [..., dim]; `out` torch tensor (device) or None -> numpy"""
+        n = 1
+        for sdim in rows.shape[:-1]:
+            n *= int(sdim)
+        if out is None:
+            out = np.empty(1 + self.dim + self.dim * self.dim)
+        check(self.lib.tda_engine_reduce_moments(self.h, _ptr(rows), n, _ptr(out)))
+        return out
+
+    def set_proposal_covariance(self, Cm):
+        Cm = _f64(Cm)
+        assert Cm.shape == (self.dim, self.dim)
+        check(self.lib.tda_engine_set_proposal_covariance(self.h, _ptr(Cm)))
+
     def set_error_model(self, kind):
         code = {None: 0, "state-independent": 1, "state-dependent": 2}[kind]
         check(self.lib.tda_engine_set_error_model(self.h, code))
