@@ -48,7 +48,22 @@ def _device_plan(posteriors, proposal):
 def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None, subchain_length=1,
            randomize_subchain_length=False, adaptive_error_model=None, store_coarse_chain=True,
            force_sequential=False, force_progress_bar=False, subsampling_rate=None, *, seed=None,
-           backend="auto", device=0, chain_offset=0):
+           backend="auto", device=0, chain_offset=0, distributed=False):
+    """Extra keyword-only arguments (not in tinyDA): seed, backend ('auto' | 'hip' | 'host'), device, chain_offset, and
+    distributed=True: under torch.distributed (one process per GPU) `n_chains` is the GLOBAL chain count, this rank
+    samples its contiguous shard (tinyda_amd.distributed.shard_chains) on GPU LOCAL_RANK and returns it with
+    'chain_offset' set; chains are keyed by global id, so the union over ranks equals a single-process run."""
+    if distributed:
+        from . import distributed as tdist
+
+        rank, local_rank, world = tdist.init_process_group()
+        total = n_chains
+        chain_offset, n_chains = tdist.shard_chains(total, rank, world)
+        device = local_rank
+        if isinstance(initial_parameters, list):
+            initial_parameters = initial_parameters[chain_offset:chain_offset + n_chains]
+        if seed is None:
+            raise ValueError("distributed sampling needs an explicit seed shared by all ranks")
     if subsampling_rate is not None:  # deprecated alias, sampler.py:113-115
         warnings.warn(" subsampling_rate has been deprecated in favour of subchain_length.")
         subchain_length = subsampling_rate
@@ -104,7 +119,7 @@ def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None
     if plan is not None:
         if n_levels == 1:
             return _sample_device(plan, posteriors[0], iterations, n_chains, initial_parameters, seed, device,
-                                  chain_offset)
+                                  chain_offset, distributed, total if distributed else None)
         return _sample_device_multilevel(plan, posteriors, iterations, n_chains, initial_parameters, subchain_length,
                                          subchain_lengths, randomize_subchain_length, store_coarse_chain, seed, device,
                                          chain_offset, adaptive_error_model)
@@ -128,7 +143,8 @@ def _sample_host(posterior, proposal, iterations, n_chains, initial_parameters):
     return result
 
 
-def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, seed, device, chain_offset):
+def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, seed, device, chain_offset,
+                   distributed=False, total_chains=None):
     from .engine import Engine  # raises EngineError when libtinyda_hip.so is missing: no CPU fallback
 
     lows, prop = plan
@@ -145,7 +161,7 @@ def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, se
             eng.set_level(0, low["A"], low["data"], low["noise_kind"], low["noise"], b=low["b"])
         if prop["kind"] == _lib.PROP_DREAMZ:
             dz = {k: v for k, v in prop.items() if k != "kind"}
-            rows = dz["M0"] + iterations * (n_chains if dz["shared"] else 1)
+            rows = dz["M0"] + iterations * ((total_chains or n_chains) if dz["shared"] else 1)
             eng.set_proposal_dreamz(capacity=rows, **dz)
             eng.set_archive(None)
         else:
@@ -157,7 +173,17 @@ def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, se
         stat = np.empty((T + 1, N, 3))
         acc = np.ones((T + 1, N), dtype=np.uint8)
         params[0], stat[0] = eng.current()
-        if T > 0:
+        if T > 0 and prop["kind"] == _lib.PROP_DREAMZ and prop.get("shared") and distributed:
+            import torch
+
+            from . import distributed as tdist
+
+            dp = torch.empty((T, N, d), dtype=torch.float64, device="cuda")
+            ds = torch.empty((T, N, 3), dtype=torch.float64, device="cuda")
+            da = torch.empty((T, N), dtype=torch.uint8, device="cuda")
+            tdist.run_shared_dream(eng, T, 16, dp, ds, da)  # one all_gather of the new archive rows per 16 steps
+            params[1:], stat[1:], acc[1:] = dp.cpu().numpy(), ds.cpu().numpy(), da.cpu().numpy()
+        elif T > 0:
             eng.run(T, params[1:], stat[1:], acc[1:])
         if prop["kind"] == _lib.PROP_DREAMZ:
             state = dict(eng.dreamz_state(), scaling=eng.proposal_state_scaling())
@@ -166,7 +192,7 @@ def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, se
     finally:
         eng.close()
     result = {"sampler": "MH", "n_chains": n_chains, "iterations": iterations + 1, "backend": "hip",
-              "seed": seed, "proposal_state": state}
+              "seed": seed, "proposal_state": state, "chain_offset": chain_offset}
     for i in range(n_chains):
         result["chain_{}".format(i)] = DeviceChain(params[:, i], stat[:, i], acc[:, i], posterior.model)
     return result

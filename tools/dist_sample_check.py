@@ -1,0 +1,10 @@
+import sys, numpy as np, scipy.stats as st
+sys.path.insert(0, "/root/repo")
+import tinyda_amd as tda
+rng = np.random.default_rng(0)
+A = rng.standard_normal((12, 6)) / 2; y = rng.standard_normal(12)
+post = tda.Posterior(st.multivariate_normal(np.zeros(6), np.eye(6)), tda.GaussianLogLike(y, 0.25 * np.eye(12)), tda.LinearModel(A))
+res = tda.sample(post, tda.DREAM(24, adaptive=True, period=20), 40, n_chains=32, seed=5, distributed=True)
+print("DIST_OK", res["n_chains"], res["chain_offset"], len(res["chain_0"]), res["proposal_state"]["archive_rows"])
+res = tda.sample(post, tda.AdaptiveMetropolis(0.05 * np.eye(6), t0=10, period=10), 40, n_chains=32, seed=5, distributed=True)
+print("DIST_OK", res["n_chains"], res["chain_offset"], len(res["chain_31"]))
