@@ -75,7 +75,7 @@ def main():
 
     import torch
 
-    from tinyda_amd import diagnostics
+    from tinyda_amd import summaries as diagnostics
     from tinyda_amd import distributed as tdist
     from tinyda_amd.engine import Engine
 

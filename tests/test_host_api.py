@@ -148,7 +148,7 @@ def test_config1_basic_sampler_host_path():
 
 
 def test_lowering_pass():
-    from tinyda_amd.sampler import _device_plan
+    from tinyda_amd.api import _device_plan
 
     A = np.random.default_rng(0).standard_normal((10, 4))
     prior = stats.multivariate_normal(np.zeros(4), np.eye(4))
@@ -164,7 +164,7 @@ def test_lowering_pass():
 
 
 def test_multilevel_lowering_and_argument_checks():
-    from tinyda_amd.sampler import _device_plan
+    from tinyda_amd.api import _device_plan
 
     rng = np.random.default_rng(1)
     prior = stats.multivariate_normal(np.zeros(4), np.eye(4))

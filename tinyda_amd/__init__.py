@@ -6,9 +6,9 @@ Drop-in for the hot path tda.sample() -> Chain.sample -> Proposal / Posterior / 
 __version__ = "0.1.0"
 
 from ._lib import EngineError  # noqa: F401
-from .chain import Chain  # noqa: F401
-from .diagnostics import ess_bulk, ess_summary, get_samples, rhat, to_inference_data  # noqa: F401
-from .distributions import (  # noqa: F401
+from .hostloop import Chain  # noqa: F401
+from .summaries import ess_bulk, ess_summary, get_samples, rhat, to_inference_data  # noqa: F401
+from .likelihoods import (  # noqa: F401
     AdaptiveGaussianLogLike,
     DefaultGaussianLogLike,
     DiagonalGaussianLogLike,
@@ -16,10 +16,10 @@ from .distributions import (  # noqa: F401
     IsotropicGaussianLogLike,
 )
 from .engine import Engine  # noqa: F401
-from .link import Link  # noqa: F401
+from .records import Link  # noqa: F401
 from .models import LinearModel, Rosenbrock  # noqa: F401
-from .posterior import Posterior  # noqa: F401
-from .proposal import DREAM, DREAMZ, AdaptiveMetropolis, CrankNicolson, GaussianRandomWalk, Proposal  # noqa: F401
-from .results import DeviceChain  # noqa: F401
-from .sampler import sample  # noqa: F401
-from .utils import RecursiveSampleMoments, ZeroMeanRecursiveSampleMoments  # noqa: F401
+from .target import Posterior  # noqa: F401
+from .proposals import DREAM, DREAMZ, AdaptiveMetropolis, CrankNicolson, GaussianRandomWalk, Proposal  # noqa: F401
+from .records import DeviceChain  # noqa: F401
+from .api import sample  # noqa: F401
+from .moments import RecursiveSampleMoments, ZeroMeanRecursiveSampleMoments  # noqa: F401

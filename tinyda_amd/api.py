@@ -10,9 +10,9 @@ import numpy as np
 import scipy.stats as stats
 
 from . import _lib
-from .chain import Chain
-from .proposal import DREAM, DREAMZ, AdaptiveMetropolis, CrankNicolson, GaussianRandomWalk
-from .results import DeviceChain
+from .hostloop import Chain
+from .proposals import DREAM, DREAMZ, AdaptiveMetropolis, CrankNicolson, GaussianRandomWalk
+from .records import DeviceChain
 
 _DEVICE_PROPOSALS = (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis, DREAMZ, DREAM)
 

@@ -237,6 +237,17 @@ __device__ __forceinline__ double block_sse(const double2 (&f)[DPAD / 8], const 
   return sse;
 }
 
+// frag_load with wrap-around: past the wave's last block it fetches the wave's FIRST block again, i.e. the fragments
+// the next MH step starts with, so their L2 latency hides behind the serial end-of-step phase.
+template <int DPAD>
+__device__ __forceinline__ void frag_load_wrap(const double2* __restrict__ base, int cb, int ncb, int first,
+                                               double2 (&f)[DPAD / 8]) {
+  const int cbc = cb < ncb ? cb : first;
+  const double2* __restrict__ p = base + (size_t)cbc * (DPAD / 8) * 64;
+#pragma unroll
+  for (int k = 0; k < DPAD / 8; ++k) f[k] = p[k * 64];
+}
+
 template <int DPAD, int MODE, int NW>
 __device__ __forceinline__ double level_sse_single(const double* __restrict__ Apk, int ncb,
                                                    const double* __restrict__ s_y, double* __restrict__ s_w,
@@ -244,19 +255,29 @@ __device__ __forceinline__ double level_sse_single(const double* __restrict__ Ap
                                                    double2 (&fa)[DPAD / 8]) {
   const int hi = lane >> 4;
   const double2* __restrict__ base = reinterpret_cast<const double2*>(Apk) + lane;
+  const int first = wave < ncb ? wave : ncb - 1;
   double sse = 0.0;
   double2 fb[DPAD / 8];
+  bool next_in_fb = false;  // where the next step's first block ended up
   for (int cb = wave; cb < ncb; cb += 2 * NW) {
-    frag_load<DPAD>(base, cb + NW, ncb, fb);
+    frag_load_wrap<DPAD>(base, cb + NW, ncb, first, fb);
     __builtin_amdgcn_sched_barrier(0);
     sse += block_sse<DPAD, MODE>(fa, th, s_y, s_w, cb, hi);
     __builtin_amdgcn_sched_barrier(0);
-    frag_load<DPAD>(base, cb + 2 * NW, ncb, fa);
-    __builtin_amdgcn_sched_barrier(0);
-    if (cb + NW < ncb) sse += block_sse<DPAD, MODE>(fb, th, s_y, s_w, cb + NW, hi);
-    __builtin_amdgcn_sched_barrier(0);
+    if (cb + NW < ncb) {
+      frag_load_wrap<DPAD>(base, cb + 2 * NW, ncb, first, fa);
+      __builtin_amdgcn_sched_barrier(0);
+      sse += block_sse<DPAD, MODE>(fb, th, s_y, s_w, cb + NW, hi);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      next_in_fb = true;  // odd number of blocks: fb already holds the wrapped-around first block
+    }
   }
-  return sse;
+  if (next_in_fb) {
+#pragma unroll
+    for (int k = 0; k < DPAD / 8; ++k) fa[k] = fb[k];
+  }
+  return sse;  // fa now holds block `first` again, ready for the next step
 }
 
 // r^T Sigma^-1 r for the 16 chains of a tile, residual tile s_R[chain][o] (row stride RS doubles) in LDS,
@@ -432,10 +453,13 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
   }
   __syncthreads();
 
+  if constexpr (!PAIRS) frag_load<DPAD>(fbase, wave, a.lv.ncb, f0);  // later steps: prefetched by the previous step
   for (int s = 0; s < a.S; ++s) {
     // first fragment block(s) of this step: independent of theta', issued ahead of the barrier
-    frag_load<DPAD>(fbase, wave, a.lv.ncb, f0);
-    if constexpr (PAIRS) frag_load<DPAD>(fbase, wave + NW, a.lv.ncb, f1);
+    if constexpr (PAIRS) {
+      frag_load<DPAD>(fbase, wave, a.lv.ncb, f0);
+      frag_load<DPAD>(fbase, wave + NW, a.lv.ncb, f1);
+    }
     // ---- proposal: theta' (proposal.py:249-251 / :351-355) ----
     if (active) {
 #pragma unroll

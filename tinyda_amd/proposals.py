@@ -10,7 +10,7 @@ import numpy as np
 import scipy.stats as stats
 
 from . import _lib
-from .utils import RecursiveSampleMoments
+from .moments import RecursiveSampleMoments
 
 
 class Proposal:

@@ -7,7 +7,7 @@ definition ArviZ's `summary` (called in the reference's notebooks) uses.
 import numpy as np
 import scipy.stats as stats
 
-from .results import DeviceChain
+from .records import DeviceChain
 
 
 def _attribute_rows(chain, attribute, burnin):

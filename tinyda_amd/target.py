@@ -1,7 +1,7 @@
 """Posterior = prior x likelihood x forward model (tinyDA/posterior.py:41-151)."""
 import numpy as np
 
-from .link import Link
+from .records import Link
 from .models import LinearModel, Rosenbrock
 
 
