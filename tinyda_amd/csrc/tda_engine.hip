@@ -151,6 +151,7 @@ struct tda_engine {
   // prior
   bool prior_set = false;
   int prior_kind = tda::PRIOR_DIAG;
+  bool prior_is_standard = false;  // N(0, I): the single-level tile kernel skips the constant loads
   double prior_logconst = 0.0;
   std::vector<double> prior_mean_h, prior_cov_h, prior_L_h;
   DevBuf<double> prior_mean, prior_pinv, prior_Wpk, prior_wmu;
@@ -175,7 +176,7 @@ struct tda_engine {
   int64_t k_adapt = 0;                  // diminishing-adaptation counter
 
   // block buffers
-  DevBuf<double> inc, ublk, rec_params, rec_stats;
+  DevBuf<double> inc, ublk, lublk, rec_params, rec_stats;
   DevBuf<uint8_t> rec_acc;
 
   // multi-level state (n_levels > 1)
@@ -345,7 +346,7 @@ void fill_level(const tda_engine* e, const Level& lv, StepArgs& a) {
   a.pr.Wpk = e->prior_Wpk.p;
   a.pr.wmu = e->prior_wmu.p;
   a.pr.ncb = e->prior_ncb;
-  a.pr.kind = e->prior_kind;
+  a.pr.kind = (e->prior_kind == PRIOR_DIAG && e->prior_is_standard) ? PRIOR_STANDARD : e->prior_kind;
   a.pr.logconst = e->prior_logconst;
   a.N = e->N;
   a.NP = e->NP;
@@ -471,10 +472,13 @@ int tda_engine_set_prior(tda_engine* e, const double* mean, const double* cov) {
   if (diag) {
     e->prior_kind = PRIOR_DIAG;
     logdet = 0.0;
+    bool standard = true;
     for (int j = 0; j < d; ++j) {
       ph[j] = 1.0 / cov[(size_t)j * d + j];
       logdet += std::log(cov[(size_t)j * d + j]);
+      standard = standard && cov[(size_t)j * d + j] == 1.0 && mean[j] == 0.0;
     }
+    e->prior_is_standard = standard;
     e->prior_ncb = 0;
   } else {
     e->prior_kind = PRIOR_DENSE;
@@ -1045,6 +1049,7 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
   // block buffers
   if ((rc = e->inc.alloc((size_t)e->SMAX * NP * DP))) return rc;
   if ((rc = e->ublk.alloc((size_t)e->SMAX * NP))) return rc;
+  if ((rc = e->lublk.alloc((size_t)e->SMAX * NP))) return rc;
   if ((rc = e->rec_params.alloc((size_t)e->SMAX * N * d))) return rc;
   if ((rc = e->rec_stats.alloc((size_t)e->SMAX * N * 3))) return rc;
   if ((rc = e->rec_acc.alloc((size_t)e->SMAX * N))) return rc;
@@ -1316,6 +1321,7 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     pa.L_stride = e->L_shared ? 0 : (int64_t)e->DP * e->DP;
     pa.inc = e->inc.p;
     pa.u = e->ublk.p;
+    pa.logu = e->lublk.p;
     if (e->rep_steps) {
       pa.z_replay = e->z_rep.p + (size_t)e->rep_pos * N * d;
       pa.u_replay = e->u_rep.p + (size_t)e->rep_pos * N;
@@ -1342,6 +1348,7 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     sa.acc_count = e->acc_count.p;
     sa.inc = e->inc.p;
     sa.u = e->ublk.p;
+    sa.logu = e->lublk.p;
     // records go straight into caller memory when it is device memory; AM needs the states either way
     sa.rec_params = p_dev ? o_params + (size_t)done * N * d : ((o_params || is_am) ? e->rec_params.p : nullptr);
     sa.rec_stats = s_dev ? o_stats + (size_t)done * N * 3 : (o_stats ? e->rec_stats.p : nullptr);

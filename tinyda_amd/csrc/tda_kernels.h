@@ -27,7 +27,7 @@ namespace tda {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 enum : int { MODE_STEP = 0, MODE_EVAL = 1 };
-enum : int { PRIOR_DIAG = 0, PRIOR_DENSE = 1 };
+enum : int { PRIOR_DIAG = 0, PRIOR_DENSE = 1, PRIOR_STANDARD = 2 };  // STANDARD = N(0, I): no constants to load
 
 // One level's linear-Gaussian posterior pieces, device pointers.
 struct LevelDev {
@@ -69,6 +69,7 @@ struct StepArgs {
   // block inputs
   const double* inc;  // [S][NP][DPAD]
   const double* u;    // [S][NP]
+  const double* logu; // [S][NP] log(u), produced by k_propose off the critical path (may be null)
   // records, layout of tda_outputs (may be null)
   double* rec_params;
   double* rec_stats;
@@ -86,6 +87,7 @@ struct ProposeArgs {
   int64_t L_stride;       // DPAD*DPAD or 0 when shared
   double* inc;            // [S][NP][DPAD]
   double* u;              // [S][NP]
+  double* logu;           // [S][NP] (may be null)
   const double* z_replay; // [.][N][d] at step0 (may be null)
   const double* u_replay; // [.][N]
   double* z_export;       // same layout (may be null)
@@ -115,6 +117,23 @@ struct AdaptArgs {
   int64_t ring_hi;           // absolute list position just after the boundary base step's own flag: adapt()
                              // runs before the upper level of that step appends its alignment entry
 };
+
+typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
+
+// v + (lane ^ 16) + (lane ^ 32) + (lane ^ 48): the reduction over the four 16-lane rows that hold one chain's partial
+// sums in the MFMA C/D layout.  v_permlane16_swap / v_permlane32_swap (gfx950) instead of two dependent ds_bpermute
+// round trips; same grouping ((r0 + r1) + (r2 + r3)) as the shuffle form, so results are bit-identical.
+__device__ __forceinline__ double sum_rows(double v) {
+  unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  uint2_t a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  uint2_t b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double s = __hiloint2double(b.x, a.x) + __hiloint2double(b.y, a.y);
+  lo = __double2loint(s);
+  hi = __double2hiint(s);
+  a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(b.x, a.x) + __hiloint2double(b.y, a.y);
+}
 
 __device__ __forceinline__ double4_t mfma_f64(double a, double b, double4_t c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
@@ -443,13 +462,16 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
   const double2* pbase = reinterpret_cast<const double2*>(a.pr.Wpk) + lane;
   constexpr bool PAIRS = NW == 4;  // 4 waves: pairs of blocks, 4 fragment sets; 8 waves: single blocks, 2 sets
   double2 f0[KS / 2], f1[PAIRS ? KS / 2 : 1];
-  double unext = 0.5;
+  double unext = 0.5, lunext = 0.0;
+  const bool has_logu = a.logu != nullptr;
+  const bool prior_std = a.pr.kind == PRIOR_STANDARD;
   if (!is_eval) {
     if (active) {
 #pragma unroll
       for (int e = 0; e < EPT; ++e) xin[e] = a.inc[(size_t)gct * DPAD + q * EPT + e];
     }
     unext = a.u[gcl];
+    if (has_logu) lunext = a.logu[gcl];
   }
   __syncthreads();
 
@@ -473,13 +495,14 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
         s_prop[c * LDP + q * EPT + e] = prp[e];
       }
     }
-    const double u = unext;
+    const double u = unext, lu = lunext;
     if (!is_eval && s + 1 < a.S) {  // next step's increment and uniform fly during the MFMA phase
       if (active) {
 #pragma unroll
         for (int e = 0; e < EPT; ++e) xin[e] = a.inc[((size_t)(s + 1) * a.NP + gct) * DPAD + q * EPT + e];
       }
       unext = a.u[(size_t)(s + 1) * a.NP + gcl];
+      if (has_logu) lunext = a.logu[(size_t)(s + 1) * a.NP + gcl];
     }
     __syncthreads();
 
@@ -490,15 +513,20 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
 
     // ---- prior: scipy MVN logpdf (posterior.py:92) ----
     double maha = 0.0;
-    if (!prior_dense) {
+    if (prior_std) {
+      double p = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) p += th[kk] * th[kk];
+      p = sum_rows(p);
+      maha = p;
+    } else if (!prior_dense) {
       double p = 0.0;
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) {
         const double dv = th[kk] - s_pm[4 * kk + hi];
         p += dv * dv * s_pinv[4 * kk + hi];
       }
-      p += __shfl_xor(p, 16);
-      p += __shfl_xor(p, 32);
+      p = sum_rows(p);
       maha = p;
     } else {
       double p;
@@ -512,8 +540,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
         frag_load<DPAD>(pbase, wave, a.pr.ncb, p0);
         p = level_sse_single<DPAD, 0, NW>(a.pr.Wpk, a.pr.ncb, s_py, nullptr, th, wave, lane, p0);
       }
-      p += __shfl_xor(p, 16);
-      p += __shfl_xor(p, 32);
+      p = sum_rows(p);
       if (lane < 16) s_redp[wave * 16 + lane] = p;
     }
 
@@ -533,8 +560,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
       sse = diag ? level_sse_single<DPAD, 1, NW>(a.lv.Apk, a.lv.ncb, s_y, s_w, th, wave, lane, f0)
                  : level_sse_single<DPAD, 0, NW>(a.lv.Apk, a.lv.ncb, s_y, nullptr, th, wave, lane, f0);
     }
-    sse += __shfl_xor(sse, 16);
-    sse += __shfl_xor(sse, 32);
+    sse = sum_rows(sse);
     if (lane < 16) s_red[wave * 16 + lane] = sse;
     __syncthreads();
 
@@ -551,13 +577,21 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
     const double post_n = lp_n + ll_n;  // link.py:48
 
     // ---- Metropolis test (proposal.py:253-258, :357-362; chain.py:112) ----
+    // The reference tests u < exp(delta).  exp is monotone, so away from the knife edge log(u) < delta decides the
+    // same way without a transcendental on the critical path; within 1e-9 of the edge (probability ~1e-9 per step)
+    // the reference form itself is evaluated.
     bool acc;
     if (is_eval) {
       acc = true;
     } else {
-      double alpha = is_pcn ? exp(ll_n - ll) : exp(post_n - (lp + ll));
-      if (post_n != post_n) alpha = 0.0;
-      acc = u < alpha;
+      const double delta = is_pcn ? ll_n - ll : post_n - (lp + ll);
+      if (has_logu && (fabs(lu - delta) > 1e-9 || delta != delta)) {
+        acc = (post_n == post_n) && (lu < delta);
+      } else {
+        double alpha = exp(delta);
+        if (post_n != post_n) alpha = 0.0;
+        acc = u < alpha;
+      }
     }
     if (acc) {
       lp = lp_n;
@@ -666,6 +700,7 @@ __global__ void __launch_bounds__(64) k_propose(const ProposeArgs a) {
       if (a.u_export) a.u_export[(size_t)s * a.N + c] = u;
     }
     a.u[(size_t)s * a.NP + c] = u;
+    if (a.logu) a.logu[(size_t)s * a.NP + c] = log(u);
   }
 }
 
@@ -985,8 +1020,7 @@ __global__ void __launch_bounds__(256, 1) k_ml_steps(const MLArgs a) {
         const double dv = th[kk] - pm[kk];
         p += dv * dv * pinv[kk];
       }
-      p += __shfl_xor(p, 16);
-      p += __shfl_xor(p, 32);
+      p = sum_rows(p);
       maha = p;
     } else {
       const double2* pbase = reinterpret_cast<const double2*>(a.pr.Wpk) + lane;
@@ -994,8 +1028,7 @@ __global__ void __launch_bounds__(256, 1) k_ml_steps(const MLArgs a) {
       frag_load<DPAD>(pbase, wave, a.pr.ncb, p0);
       frag_load<DPAD>(pbase, wave + 4, a.pr.ncb, p1);
       double p = level_sse_partial<DPAD, 0>(a.pr.Wpk, a.pr.ncb, s_py, nullptr, th, wave, lane, p0, p1);
-      p += __shfl_xor(p, 16);
-      p += __shfl_xor(p, 32);
+      p = sum_rows(p);
       if (lane < 16) s_redp[wave * 16 + lane] = p;
     }
     const LevelDev& L = a.lv[k];
@@ -1031,8 +1064,7 @@ __global__ void __launch_bounds__(256, 1) k_ml_steps(const MLArgs a) {
     }
     double sse = dg ? level_sse_partial<DPAD, 1>(L.Apk, L.ncb, s_stage + a.lds_y[k], s_stage + a.lds_w[k], th, wave, lane, g0, g1)
                     : level_sse_partial<DPAD, 0>(L.Apk, L.ncb, s_stage + a.lds_y[k], nullptr, th, wave, lane, g0, g1);
-    sse += __shfl_xor(sse, 16);
-    sse += __shfl_xor(sse, 32);
+    sse = sum_rows(sse);
     if (lane < 16) s_red[wave * 16 + lane] = sse;
     __syncthreads();
     const double tot = ((s_red[lc] + s_red[16 + lc]) + s_red[32 + lc]) + s_red[48 + lc];
@@ -1807,8 +1839,7 @@ __global__ void __launch_bounds__(256, 1) k_dreamz_steps(const DreamStepArgs a) 
         const double dv = th[kk] - pm[kk];
         p += dv * dv * pinv[kk];
       }
-      p += __shfl_xor(p, 16);
-      p += __shfl_xor(p, 32);
+      p = sum_rows(p);
       maha = p;
     } else {
       const double2* pbase = reinterpret_cast<const double2*>(a.pr.Wpk) + lane;
@@ -1816,8 +1847,7 @@ __global__ void __launch_bounds__(256, 1) k_dreamz_steps(const DreamStepArgs a) 
       frag_load<DPAD>(pbase, wave, a.pr.ncb, p0);
       frag_load<DPAD>(pbase, wave + 4, a.pr.ncb, p1);
       double p = level_sse_partial<DPAD, 0>(a.pr.Wpk, a.pr.ncb, s_py, nullptr, th, wave, lane, p0, p1);
-      p += __shfl_xor(p, 16);
-      p += __shfl_xor(p, 32);
+      p = sum_rows(p);
       if (lane < 16) s_redp[wave * 16 + lane] = p;
     }
     // ---- likelihood ----
@@ -1825,8 +1855,7 @@ __global__ void __launch_bounds__(256, 1) k_dreamz_steps(const DreamStepArgs a) 
     if (linear) {
       double sse = diag ? level_sse_partial<DPAD, 1>(a.lv.Apk, a.lv.ncb, s_y, s_w, th, wave, lane, f0, f1)
                         : level_sse_partial<DPAD, 0>(a.lv.Apk, a.lv.ncb, s_y, nullptr, th, wave, lane, f0, f1);
-      sse += __shfl_xor(sse, 16);
-      sse += __shfl_xor(sse, 32);
+      sse = sum_rows(sse);
       if (lane < 16) s_red[wave * 16 + lane] = sse;
       __syncthreads();
       const double tot = ((s_red[lc] + s_red[16 + lc]) + s_red[32 + lc]) + s_red[48 + lc];
