@@ -1,0 +1,459 @@
+// DREAM(Z): draw / step / adapt kernels and the archive column-sum reduction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tda_kernels_mh.h"
+
+namespace tda {
+
+// ------------------------------------------------------------------------------------------------
+// DREAM(Z)  (tinyDA/proposal.py:608-852) for single-level chains.
+//   k_dreamz_draw   wave per chain: everything make_proposal draws that does not depend on the chain state
+//                   (archive row indices, crossover index, subspace mask, (1+e) gamma, eps) for a block of steps
+//   k_dreamz_steps  16-chain tile: theta' = theta + mask ((1+e) gamma (sum Z_r1 - sum Z_r2) + eps) with the rows
+//                   gathered from the chain's archive in HBM, evaluation (linear model on MFMA, or the
+//                   Rosenbrock chain on VALU), accept, record, archive append (proposal.py:794)
+//   k_dreamz_adapt  wave per chain: archive column sums catch-up, global scaling, pCR update (proposal.py:797-809)
+// RNG stream 4 (block = what, step, chain):  block i < delta : r1 = (x0*M)>>32, r2 = (x1*(M-1))>>32, r2 += r2>=r1
+//   block delta : mCR by inverse cdf of u53(x0,x1) over pCR, forced index = (x2*d)>>32
+//   block delta+1+j : subspace uniform u53(x0,x1) and e-uniform u53(x2,x3) of parameter j;  eps_j from stream 0.
+// ------------------------------------------------------------------------------------------------
+enum : uint32_t { STREAM_DREAM = 4 };
+constexpr int MAX_NCR = 8;
+constexpr int MAX_DELTA = 4;
+
+struct DreamDrawArgs {
+  int64_t N, NP, chain_offset;
+  int d, S, delta, nCR;
+  int64_t step0;   // proposal.t at s = 0
+  int64_t M_base;  // archive rows visible at s = 0
+  int grow;        // 1: archive grows by one row per step inside the block (per-chain DREAMZ); 0: frozen (shared DREAM)
+  uint64_t seed;
+  double b, b_star;
+  const double* scaling;  // [NP]
+  const double* pCR;      // [NP][MAX_NCR]
+  double* coef;           // [S][NP][DPAD]  mask * (1+e) * gamma
+  double* epsm;           // [S][NP][DPAD]  mask * eps
+  int32_t* ridx;          // [S][NP][2*MAX_DELTA]
+  double* u;              // [S][NP]
+  int32_t* mcr_last;      // [NP] crossover index of the block's last step (proposal.py:801)
+  // replay (all may be null) at step0: r [.][N][delta][2] int32, mcr [.][N] int32, sub_u/e_u/eps_n [.][N][d], forced [.][N] int32, u [.][N]
+  const int32_t* r_rep;
+  const int32_t* mcr_rep;
+  const double* sub_rep;
+  const int32_t* forced_rep;
+  const double* e_rep;
+  const double* eps_rep;
+  const double* u_rep;
+  double* eps_export;  // [.][N][d] standard normals actually used (null = off)
+  double* u_export;
+};
+
+template <int DPAD>
+__global__ void __launch_bounds__(64) k_dreamz_draw(const DreamDrawArgs a) {
+  const int lane = threadIdx.x;
+  const int64_t c = blockIdx.x;
+  const bool real_chain = c < a.N;
+  const uint32_t gc = (uint32_t)(a.chain_offset + c);
+  const bool lj = lane < a.d;
+  const double scaling = a.scaling[c];
+  double cdf[MAX_NCR];
+  {
+    double run = 0.0;
+#pragma unroll
+    for (int k = 0; k < MAX_NCR; ++k) {
+      run += k < a.nCR ? a.pCR[c * MAX_NCR + k] : 0.0;
+      cdf[k] = run;
+    }
+  }
+  const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
+  int mcr = 0;
+  for (int s = 0; s < a.S; ++s) {
+    const uint32_t step = (uint32_t)(a.step0 + s);
+    const int64_t M = a.M_base + (a.grow ? s : 0);
+    const size_t row = (size_t)s * a.N + c;  // replay / export row (real chains only)
+    // ---- archive row pairs (proposal.py:823-826) ----
+    if (lane < a.delta) {
+      int r1, r2;
+      if (a.r_rep && real_chain) {
+        r1 = a.r_rep[(row * a.delta + lane) * 2 + 0];
+        r2 = a.r_rep[(row * a.delta + lane) * 2 + 1];
+      } else {
+        const u32x4 x = philox4x32_10(u32x4{(uint32_t)lane, step, gc, STREAM_DREAM}, k0, k1);
+        r1 = (int)(((uint64_t)x.x * (uint64_t)M) >> 32);
+        r2 = (int)(((uint64_t)x.y * (uint64_t)(M - 1)) >> 32);
+        r2 += r2 >= r1 ? 1 : 0;
+      }
+      a.ridx[((size_t)s * a.NP + c) * (2 * MAX_DELTA) + 2 * lane + 0] = r1;
+      a.ridx[((size_t)s * a.NP + c) * (2 * MAX_DELTA) + 2 * lane + 1] = r2;
+    }
+    // ---- crossover index and the index forced when the subspace is empty (proposal.py:829-839) ----
+    int forced;
+    {
+      const u32x4 x = philox4x32_10(u32x4{(uint32_t)a.delta, step, gc, STREAM_DREAM}, k0, k1);
+      if (a.mcr_rep && real_chain) {
+        mcr = a.mcr_rep[row];
+        forced = a.forced_rep[row];
+      } else {
+        const double uu = u53(x.x, x.y);
+        mcr = a.nCR - 1;
+        for (int k = a.nCR - 1; k >= 0; --k)
+          if (cdf[k] > uu) mcr = k;
+        forced = (int)(((uint64_t)x.z * (uint64_t)a.d) >> 32);
+      }
+    }
+    const double CR = (double)(mcr + 1) / (double)a.nCR;
+    // ---- per-parameter draws ----
+    double su = 2.0, eu = 0.5, en = 0.0;
+    if (lj) {
+      if (a.sub_rep && real_chain) {
+        su = a.sub_rep[row * a.d + lane];
+        eu = a.e_rep[row * a.d + lane];
+        en = a.eps_rep[row * a.d + lane];
+      } else {
+        const u32x4 x = philox4x32_10(u32x4{(uint32_t)(a.delta + 1 + lane), step, gc, STREAM_DREAM}, k0, k1);
+        su = u53(x.x, x.y);
+        eu = u53(x.z, x.w);
+        double z0, z1;
+        normal_pair(a.seed, gc, step, STREAM_PROPOSAL, (uint32_t)(lane >> 1), z0, z1);
+        en = (lane & 1) ? z1 : z0;
+      }
+      if (a.eps_export && real_chain) a.eps_export[row * a.d + lane] = en;
+    }
+    bool ind = lj && (su < CR);
+    const unsigned long long bal = __ballot(ind);
+    int dsub = __popcll(bal);
+    if (dsub == 0) {  // proposal.py:838-839
+      ind = lane == forced;
+      dsub = 1;
+    }
+    const double gam = scaling * 2.38 / sqrt((double)(2 * a.delta * dsub));  // proposal.py:842-844
+    const double e = -a.b + (a.b - (-a.b)) * eu;
+    const double eps = 0.0 + a.b_star * en;
+    if (lane < DPAD) {
+      a.coef[((size_t)s * a.NP + c) * DPAD + lane] = ind ? (1.0 + e) * gam : 0.0;
+      a.epsm[((size_t)s * a.NP + c) * DPAD + lane] = ind ? eps : 0.0;
+    }
+    if (lane == 0) {
+      double u = 0.5;
+      if (real_chain) {
+        u = a.u_rep ? a.u_rep[row] : accept_uniform(a.seed, gc, step, 0u);
+        if (a.u_export) a.u_export[row] = u;
+      }
+      a.u[(size_t)s * a.NP + c] = u;
+    }
+  }
+  if (lane == 0) a.mcr_last[c] = mcr;
+}
+
+enum : int { MODEL_LINEAR = 0, MODEL_ROSENBROCK = 1 };
+
+struct DreamStepArgs {
+  LevelDev lv;
+  PriorDev pr;
+  int model;        // MODEL_*
+  double ros_a, ros_b, ros_data;
+  int64_t N, NP;
+  int d, S, delta;
+  int64_t M_base;      // archive rows at s = 0
+  int shared;          // 1: one archive for all chains (frozen inside the block), 0: per chain (grows every step)
+  int64_t cap;         // rows per archive
+  double* arch;        // per chain [NP][cap][DPAD] / shared [cap][DPAD]
+  double* theta;       // [NP][DPAD]
+  double* theta_prev;  // [NP][DPAD] state before the block's last step (jumping distance, proposal.py:800)
+  double* lp;
+  double* ll;
+  int32_t* acc_count;
+  const double* coef;
+  const double* epsm;
+  const int32_t* ridx;
+  const double* u;
+  double* rec_params;
+  double* rec_stats;
+  uint8_t* rec_acc;
+  double* blk_states;  // [S][NP][DPAD] states of this block (shared mode: appended to the archive afterwards)
+};
+
+template <int DPAD>
+__global__ void __launch_bounds__(256, 1) k_dreamz_steps(const DreamStepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int KS = DPAD / 4;
+  constexpr int LDP = DPAD + 2;
+  constexpr int EPT = DPAD >= 16 ? DPAD / 16 : 1;
+  constexpr int QACT = DPAD / EPT;
+  const bool diag = a.lv.noise_kind == 1;
+  const bool prior_dense = a.pr.kind == PRIOR_DENSE;
+  const bool linear = a.model == MODEL_LINEAR;
+  double* s_prop = smem;
+  double* s_red = s_prop + 16 * LDP;
+  double* s_redp = s_red + 64;
+  double* s_y = s_redp + 64;
+  double* s_w = s_y + (linear ? a.lv.m_pad : 0);
+  double* s_py = s_w + ((linear && diag) ? a.lv.m_pad : 0);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t tile = blockIdx.x;
+  const int c = tid >> 4, q_ = tid & 15;
+  const int lc = lane & 15, hi = lane >> 4;
+  const int64_t gct = tile * 16 + c;
+  const int64_t gcl = tile * 16 + lc;
+  const bool active = q_ < QACT;
+  if (linear) {
+    for (int i = tid; i < a.lv.m_pad; i += 256) {
+      s_y[i] = a.lv.ytil[i];
+      if (diag) s_w[i] = a.lv.w[i];
+    }
+  }
+  if (prior_dense)
+    for (int i = tid; i < a.pr.ncb * 16; i += 256) s_py[i] = a.pr.wmu[i];
+  double pm[KS], pinv[KS];
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    pm[kk] = a.pr.mean[4 * kk + hi];
+    pinv[kk] = prior_dense ? 0.0 : a.pr.pinv[4 * kk + hi];
+  }
+  double cur[EPT], prp[EPT], prev[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    cur[e] = active ? a.theta[gct * DPAD + q_ * EPT + e] : 0.0;
+    prev[e] = cur[e];
+  }
+  double lp = a.lp[gcl], ll = a.ll[gcl];
+  int nacc = 0;
+  double* arch_c = a.shared ? a.arch : a.arch + (size_t)gct * a.cap * DPAD;
+  const double2* fbase = reinterpret_cast<const double2*>(a.lv.Apk) + lane;
+  __syncthreads();
+
+  for (int s = 0; s < a.S; ++s) {
+    double2 f0[KS / 2], f1[KS / 2];
+    if (linear) {
+      frag_load<DPAD>(fbase, wave, a.lv.ncb, f0);
+      frag_load<DPAD>(fbase, wave + 4, a.lv.ncb, f1);
+    }
+    // ---- proposal (proposal.py:850-852) ----
+    if (active) {
+      double z1[EPT], z2[EPT];
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) z1[e] = z2[e] = 0.0;
+      for (int i = 0; i < a.delta; ++i) {
+        const int r1 = a.ridx[((size_t)s * a.NP + gct) * (2 * MAX_DELTA) + 2 * i + 0];
+        const int r2 = a.ridx[((size_t)s * a.NP + gct) * (2 * MAX_DELTA) + 2 * i + 1];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          z1[e] += arch_c[(size_t)r1 * DPAD + q_ * EPT + e];
+          z2[e] += arch_c[(size_t)r2 * DPAD + q_ * EPT + e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const size_t o = ((size_t)s * a.NP + gct) * DPAD + q_ * EPT + e;
+        const double jump = a.coef[o] * (z1[e] - z2[e]) + a.epsm[o];
+        prp[e] = cur[e] + jump;
+        s_prop[c * LDP + q_ * EPT + e] = prp[e];
+      }
+    }
+    const double u = a.u[(size_t)s * a.NP + gcl];
+    __syncthreads();
+    // ---- prior ----
+    double th[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) th[kk] = s_prop[lc * LDP + 4 * kk + hi];
+    double maha = 0.0;
+    if (!prior_dense) {
+      double p = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        const double dv = th[kk] - pm[kk];
+        p += dv * dv * pinv[kk];
+      }
+      p = sum_rows(p);
+      maha = p;
+    } else {
+      const double2* pbase = reinterpret_cast<const double2*>(a.pr.Wpk) + lane;
+      double2 p0[KS / 2], p1[KS / 2];
+      frag_load<DPAD>(pbase, wave, a.pr.ncb, p0);
+      frag_load<DPAD>(pbase, wave + 4, a.pr.ncb, p1);
+      double p = level_sse_partial<DPAD, 0>(a.pr.Wpk, a.pr.ncb, s_py, nullptr, th, wave, lane, p0, p1);
+      p = sum_rows(p);
+      if (lane < 16) s_redp[wave * 16 + lane] = p;
+    }
+    // ---- likelihood ----
+    double ll_n;
+    if (linear) {
+      double sse = diag ? level_sse_partial<DPAD, 1>(a.lv.Apk, a.lv.ncb, s_y, s_w, th, wave, lane, f0, f1)
+                        : level_sse_partial<DPAD, 0>(a.lv.Apk, a.lv.ncb, s_y, nullptr, th, wave, lane, f0, f1);
+      sse = sum_rows(sse);
+      if (lane < 16) s_red[wave * 16 + lane] = sse;
+      __syncthreads();
+      const double tot = ((s_red[lc] + s_red[16 + lc]) + s_red[32 + lc]) + s_red[48 + lc];
+      ll_n = diag ? -0.5 * tot : -0.5 * tot / a.lv.var;
+    } else {
+      // Rosenbrock chain: f = sum_i (a - x_i)^2 + b (x_{i+1} - x_i^2)^2 ; loglike = -0.5 (f - data)^2 / var
+      double f = 0.0;
+      for (int i = 0; i + 1 < a.d; ++i) {
+        const double x0 = s_prop[lc * LDP + i], x1 = s_prop[lc * LDP + i + 1];
+        const double t0 = a.ros_a - x0, t1 = x1 - x0 * x0;
+        f += t0 * t0 + a.ros_b * (t1 * t1);
+      }
+      const double r = f - a.ros_data;
+      ll_n = -0.5 * (r * r) / a.lv.var;
+      __syncthreads();
+    }
+    if (prior_dense) maha = ((s_redp[lc] + s_redp[16 + lc]) + s_redp[32 + lc]) + s_redp[48 + lc];
+    const double lp_n = -0.5 * (a.pr.logconst + maha);
+    const double post_n = lp_n + ll_n;
+    double alpha = exp(post_n - (lp + ll));
+    if (post_n != post_n) alpha = 0.0;
+    const bool acc = u < alpha;
+    if (acc) {
+      lp = lp_n;
+      ll = ll_n;
+    }
+    nacc += acc ? 1 : 0;
+    if (wave == 0 && lane < 16 && gcl < a.N) {
+      const size_t r = (size_t)s * a.N + gcl;
+      if (a.rec_stats) {
+        a.rec_stats[r * 3 + 0] = lp;
+        a.rec_stats[r * 3 + 1] = ll;
+        a.rec_stats[r * 3 + 2] = lp + ll;
+      }
+      if (a.rec_acc) a.rec_acc[r] = acc ? 1 : 0;
+    }
+    const int accf = __shfl(acc ? 1 : 0, c);
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        if (s == a.S - 1) prev[e] = cur[e];
+        cur[e] = accf ? prp[e] : cur[e];
+        const int j = q_ * EPT + e;
+        if (a.rec_params && gct < a.N && j < a.d) a.rec_params[((size_t)s * a.N + gct) * a.d + j] = cur[e];
+        // archive append (proposal.py:794): per-chain archives see it at once, the shared one after the block
+        if (!a.shared) arch_c[(size_t)(a.M_base + s) * DPAD + j] = cur[e];
+        if (a.blk_states) a.blk_states[((size_t)s * a.NP + gct) * DPAD + j] = cur[e];
+      }
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      a.theta[gct * DPAD + q_ * EPT + e] = cur[e];
+      a.theta_prev[gct * DPAD + q_ * EPT + e] = prev[e];
+    }
+  }
+  if (wave == 0 && lane < 16) {
+    a.lp[gcl] = lp;
+    a.ll[gcl] = ll;
+    a.acc_count[gcl] += nacc;
+  }
+}
+
+struct DreamAdaptArgs {
+  int64_t N, NP;
+  int d, nCR, period;
+  int boundary, do_scale;
+  double gamma_pow;
+  int shared;
+  int64_t cap;
+  int64_t row0, nrows;     // archive rows appended since the last catch-up
+  int64_t M_total;         // archive size after them
+  const double* arch;      // per chain [NP][cap][DPAD] / shared [cap][DPAD]
+  double* zsum;            // [NP or 1][DPAD] column sums of the archive
+  double* zsq;             // [NP or 1][DPAD] column sums of squares
+  const double* partial;   // shared archive: per-chunk column sums [npart][2][DPAD] from k_colsum_partial (or null)
+  int64_t npart;
+  const double* theta;
+  const double* theta_prev;
+  const int32_t* mcr_last;
+  double* pCR;             // [NP][MAX_NCR]
+  double* LCR;             // [NP][MAX_NCR]
+  double* DeltaCR;         // [NP][MAX_NCR]
+  double* scaling;
+  int32_t* acc_count;
+};
+
+// column sums / sums of squares of rows [row0 + 256 b, row0 + 256 (b+1)) of a row-major [.][DPAD] matrix
+constexpr int COLSUM_CHUNK = 256;
+template <int DPAD>
+__global__ void __launch_bounds__(64) k_colsum_partial(const double* __restrict__ m, int64_t row0, int64_t nrows,
+                                                       double* __restrict__ partial) {
+  const int lane = threadIdx.x;
+  if (lane >= DPAD) return;
+  const int64_t b = blockIdx.x;
+  const int64_t lo = b * COLSUM_CHUNK, hi = lo + COLSUM_CHUNK < nrows ? lo + COLSUM_CHUNK : nrows;
+  double zs = 0.0, zq = 0.0;
+#pragma unroll 8
+  for (int64_t r = lo; r < hi; ++r) {
+    const double z = m[(size_t)(row0 + r) * DPAD + lane];
+    zs += z;
+    zq += z * z;
+  }
+  partial[((size_t)b * 2 + 0) * DPAD + lane] = zs;
+  partial[((size_t)b * 2 + 1) * DPAD + lane] = zq;
+}
+
+template <int DPAD>
+__global__ void __launch_bounds__(64) k_dreamz_adapt(const DreamAdaptArgs a) {
+  const int lane = threadIdx.x;
+  const int64_t c = blockIdx.x;
+  if (c >= a.N) return;
+  const bool lj = lane < a.d;
+  const double* arch_c = a.shared ? a.arch : a.arch + (size_t)c * a.cap * DPAD;
+  const size_t so = a.shared ? 0 : (size_t)c * DPAD;
+  // archive column sums: per-chain archives are caught up by their own wave; for the shared archive the host
+  // first runs a one-wave launch (N = 1, nrows > 0) and then the per-chain launch with nrows = 0.
+  double zs = 0.0, zq = 0.0;
+  if (lane < DPAD) {
+    zs = a.zsum[so + lane];
+    zq = a.zsq[so + lane];
+    if (a.partial) {  // ordered accumulation of the chunk sums: deterministic for a given append
+      for (int64_t b = 0; b < a.npart; ++b) {
+        zs += a.partial[((size_t)b * 2 + 0) * DPAD + lane];
+        zq += a.partial[((size_t)b * 2 + 1) * DPAD + lane];
+      }
+    } else {
+      for (int64_t r = 0; r < a.nrows; ++r) {
+        const double z = arch_c[(size_t)(a.row0 + r) * DPAD + lane];
+        zs += z;
+        zq += z * z;
+      }
+    }
+    if (a.nrows > 0) {
+      a.zsum[so + lane] = zs;
+      a.zsq[so + lane] = zq;
+    }
+  }
+  if (!a.boundary) return;
+  if (a.do_scale) {
+    if (lane == 0) {
+      const double rate = (double)a.acc_count[c] / (double)a.period;
+      a.scaling[c] = exp(log(a.scaling[c]) + a.gamma_pow * (rate - 0.24));
+    }
+    // crossover probabilities (proposal.py:797-809)
+    const double Mt = (double)a.M_total;
+    const double mean = zs / Mt;
+    const double var = zq / Mt - mean * mean;  // np.var(Z, axis=0)
+    const double jd = lj ? a.theta[c * DPAD + lane] - a.theta_prev[c * DPAD + lane] : 0.0;
+    double term = lj ? jd * jd / var : 0.0;
+    for (int off = 32; off >= 1; off >>= 1) term += __shfl_xor(term, off);
+    if (lane == 0) {
+      const int m = a.mcr_last[c];
+      a.DeltaCR[c * MAX_NCR + m] += term;
+      a.LCR[c * MAX_NCR + m] += 1.0;
+      bool all = true;
+      double tot = 0.0, mn[MAX_NCR];
+      for (int k = 0; k < a.nCR; ++k) {
+        all = all && a.LCR[c * MAX_NCR + k] > 0.0;
+        mn[k] = a.DeltaCR[c * MAX_NCR + k] / (a.LCR[c * MAX_NCR + k] > 0.0 ? a.LCR[c * MAX_NCR + k] : 1.0);
+        tot += mn[k];
+      }
+      if (all)
+        for (int k = 0; k < a.nCR; ++k) a.pCR[c * MAX_NCR + k] = mn[k] / tot;
+    }
+  }
+  if (lane == 0) a.acc_count[c] = 0;
+}
+
+}  // namespace tda

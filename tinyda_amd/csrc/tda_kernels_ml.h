@@ -1,0 +1,734 @@
+// Multi-level tile kernel (Delayed Acceptance, MLDA) and the adaptive-error-model action kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tda_kernels_mh.h"
+
+namespace tda {
+
+// ------------------------------------------------------------------------------------------------
+// Multi-level engine: Delayed Acceptance (tinyDA/chain.py:325-444, 475-483) and MLDA
+// (chain.py:680-737, proposal.py:1502-1624) as ONE iterative state machine over base-level steps.
+//
+// All chains run the same schedule (subchain lengths are fixed), so control flow is uniform:
+//   for each base step:   level-0 MH step (as k_mh_steps)
+//     while the subchain of level k just completed (cnt[k] == sl[k]):  level k+1 acts:
+//        y = state of level k (DA with randomize_subchain_length: the state after step `pick`)
+//        skip-eval rule: chains whose level-k subchain accepted nothing record a rejection (chain.py:357-364)
+//        alpha = exp(pi_{k+1}(y) - pi_{k+1}(x) + pi_k(x_start) - pi_k(y))
+//        accept: level k+1 takes y.   reject: every level below reverts to theta_{k+1} with the
+//        log-densities it had there.  (Invariant: after a step of level q, all levels j < q sit at theta_q;
+//        S[j][q] caches level j's log-prior / log-like at theta_q.  This is what align_chain's identity
+//        search (proposal.py:1469-1493) and the coarse re-append (chain.py:360-362, 394-396) amount to.)
+// The accept flag of every upper-level step is also appended to the base proposal's `accepted` window
+// (chain.py:363,389,397; proposal.py:1486), kept as a ring of the last `period` entries.
+// ------------------------------------------------------------------------------------------------
+constexpr int MAXLEV = 4;
+constexpr int AEM_MP = 64;  // row stride of the per-chain error-model vectors / matrices in HBM
+enum : uint32_t { STREAM_INDEX = 3 };
+
+struct MLArgs {
+  LevelDev lv[MAXLEV];
+  int lds_y[MAXLEV];  // offset (doubles) of ytil / w of level k inside the staging region
+  int lds_w[MAXLEV];
+  int lds_total;      // doubles in the staging region
+  PriorDev pr;
+  int64_t N, NP;
+  int d, S, prop_kind, nlev, randomize;
+  int sl[MAXLEV];        // sl[k]: steps of level k per step of level k+1
+  int cnt[MAXLEV];       // position inside the running subchain of level k at launch
+  int64_t done[MAXLEV];  // local steps of level k completed before this launch (RNG step of level k)
+  uint64_t seed;
+  int64_t chain_offset;
+  double* theta;    // [nlev][NP][DPAD]
+  double* lp;       // [nlev][NP]
+  double* ll;       // [nlev][NP]
+  double* Sst;      // [npairs][2][NP], pair (j,q) at q(q-1)/2 + j
+  int32_t* anyacc;  // [nlev][NP]
+  double* ysnap;    // [NP][DPAD + 2] promoted coarse state of the running DA subchain
+  int32_t* pick;    // [NP]
+  const double* scaling;
+  uint8_t* ring;    // [P][NP]
+  int ring_P;
+  int64_t ring_pos;
+  const double* inc;  // [S][NP][DPAD]
+  const double* u0;   // [S][NP]
+  const double* u_rep[MAXLEV];  // replay uniforms of level k >= 1, row 0 = step done[k]; null -> Philox
+  const double* ridx_rep;       // replay promoted index (DA), row 0 = fine iteration done[1]
+  double* rec_params[MAXLEV];   // row 0 = first local step of level k in this launch
+  double* rec_stats[MAXLEV];
+  uint8_t* rec_acc[MAXLEV];
+  // adaptive error model (host-sequenced mode): the kernel only advances level 0, whose likelihood is the
+  // bias-corrected dense Gaussian of AdaptiveGaussianLogLike (distributions.py:404-425) with per-chain state
+  int cascade;             // 1: upper levels act inside the kernel; 0: the host launches k_aem_action between blocks
+  int aem_on;
+  int aem_mp;              // padded output dimension (<= 64)
+  const double* aem_bias;  // [NP][AEM_MP]          total bias of level 0
+  const double* aem_P;     // [NP][AEM_MP][AEM_MP]  (Sigma_e + Sigma_bias)^-1 of level 0
+  int64_t* sid;            // [nlev][NP] identity of the parameter vector each level currently holds
+};
+
+__device__ __forceinline__ constexpr int pair_index(int j, int q) { return q * (q - 1) / 2 + j; }
+
+template <int DPAD, int NLEV>
+__global__ void __launch_bounds__(256, 1) k_ml_steps(const MLArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int KS = DPAD / 4;
+  constexpr int LDP = DPAD + 2;
+  constexpr int EPT = DPAD >= 16 ? DPAD / 16 : 1;
+  constexpr int QACT = DPAD / EPT;
+  constexpr int NPAIR = NLEV * (NLEV - 1) / 2;
+
+  const bool prior_dense = a.pr.kind == PRIOR_DENSE;
+  double* s_prop = smem;
+  double* s_red = s_prop + 16 * LDP;
+  double* s_redp = s_red + 64;
+  double* s_stage = s_redp + 64;           // ytil / w of every level
+  double* s_py = s_stage + a.lds_total;    // dense prior: W mu
+  double* s_R = s_py + (prior_dense ? a.pr.ncb * 16 : 0);  // AEM: residual tile [16][aem_mp + 2], then [16] ll slots
+  const int RSa = a.aem_mp + 2;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t tile = blockIdx.x;
+  const int c = tid >> 4, q_ = tid & 15;
+  const int lc = lane & 15, hi = lane >> 4;
+  const int64_t gct = tile * 16 + c;
+  const int64_t gcl = tile * 16 + lc;
+  const bool active = q_ < QACT;
+  const uint32_t gchain = (uint32_t)(a.chain_offset + gcl);
+
+#pragma unroll
+  for (int k = 0; k < NLEV; ++k) {
+    for (int i = tid; i < a.lv[k].m_pad; i += 256) {
+      s_stage[a.lds_y[k] + i] = a.lv[k].ytil[i];
+      if (a.lv[k].noise_kind == 1) s_stage[a.lds_w[k] + i] = a.lv[k].w[i];
+    }
+  }
+  if (prior_dense)
+    for (int i = tid; i < a.pr.ncb * 16; i += 256) s_py[i] = a.pr.wmu[i];
+
+  double pm[KS], pinv[KS];
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    pm[kk] = a.pr.mean[4 * kk + hi];
+    pinv[kk] = prior_dense ? 0.0 : a.pr.pinv[4 * kk + hi];
+  }
+
+  // ---- per-chain state: thread-mapped parameter slices, lane-mapped scalars ----
+  double cur[NLEV][EPT], snp[EPT], prp[EPT], xin[EPT];
+  double lp[NLEV], ll[NLEV], Slp[NPAIR > 0 ? NPAIR : 1], Sll[NPAIR > 0 ? NPAIR : 1];
+  int anyacc[NLEV];
+#pragma unroll
+  for (int k = 0; k < NLEV; ++k) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+      cur[k][e] = active ? a.theta[((size_t)k * a.NP + gct) * DPAD + q_ * EPT + e] : 0.0;
+    lp[k] = a.lp[(size_t)k * a.NP + gcl];
+    ll[k] = a.ll[(size_t)k * a.NP + gcl];
+    anyacc[k] = a.anyacc[(size_t)k * a.NP + gcl];
+  }
+#pragma unroll
+  for (int p = 0; p < NPAIR; ++p) {
+    Slp[p] = a.Sst[((size_t)p * 2 + 0) * a.NP + gcl];
+    Sll[p] = a.Sst[((size_t)p * 2 + 1) * a.NP + gcl];
+  }
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    snp[e] = active ? a.ysnap[gct * LDP + q_ * EPT + e] : 0.0;
+    xin[e] = active ? a.inc[(size_t)gct * DPAD + q_ * EPT + e] : 0.0;
+  }
+  double snap_lp = a.ysnap[gcl * LDP + DPAD], snap_ll = a.ysnap[gcl * LDP + DPAD + 1];
+  int pick = a.pick[gcl];
+  const double scal_t = a.scaling[gct];
+  const bool is_pcn = a.prop_kind == 1;
+  const double keep_t = is_pcn ? sqrt(1.0 - scal_t * scal_t) : 1.0;
+  double unext = a.u0[gcl];
+
+  int cnt[NLEV];
+  int64_t stepno[NLEV];  // local step index (global, for RNG) of the NEXT step of level k
+  int nrec[NLEV];        // records written by this launch per level
+#pragma unroll
+  for (int k = 0; k < NLEV; ++k) {
+    cnt[k] = a.cnt[k];
+    stepno[k] = a.done[k];
+    nrec[k] = 0;
+  }
+  int64_t ringpos = a.ring_pos;
+  const double2* fbase = reinterpret_cast<const double2*>(a.lv[0].Apk) + lane;
+  double2 f0[KS / 2], f1[KS / 2];
+  __syncthreads();
+
+  // evaluate level `k` at the state currently in s_prop (all 4 waves); returns (lp_n, ll_n) lane-mapped
+  auto evaluate = [&](int k, double2 (&g0)[KS / 2], double2 (&g1)[KS / 2], double& lp_n, double& ll_n) {
+    double th[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) th[kk] = s_prop[lc * LDP + 4 * kk + hi];
+    double maha = 0.0;
+    if (!prior_dense) {
+      double p = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        const double dv = th[kk] - pm[kk];
+        p += dv * dv * pinv[kk];
+      }
+      p = sum_rows(p);
+      maha = p;
+    } else {
+      const double2* pbase = reinterpret_cast<const double2*>(a.pr.Wpk) + lane;
+      double2 p0[KS / 2], p1[KS / 2];
+      frag_load<DPAD>(pbase, wave, a.pr.ncb, p0);
+      frag_load<DPAD>(pbase, wave + 4, a.pr.ncb, p1);
+      double p = level_sse_partial<DPAD, 0>(a.pr.Wpk, a.pr.ncb, s_py, nullptr, th, wave, lane, p0, p1);
+      p = sum_rows(p);
+      if (lane < 16) s_redp[wave * 16 + lane] = p;
+    }
+    const LevelDev& L = a.lv[k];
+    const bool dg = L.noise_kind == 1;
+    if (a.aem_on && k == 0) {
+      // residual tile, then per chain  -1/2 (F + bias - y)^T P (F + bias - y)  with that chain's bias and P
+      (void)level_sse_partial<DPAD, 2>(L.Apk, L.ncb, s_stage + a.lds_y[k], s_R + lc * RSa, th, wave, lane, g0, g1);
+      __syncthreads();
+      const int MP = a.aem_mp;
+      for (int cc = wave; cc < 16; cc += 4) {
+        const int64_t gc = tile * 16 + cc;
+        double* rrow = s_R + cc * RSa;
+        double rb = 0.0;
+        if (lane < MP) rb = rrow[lane] + a.aem_bias[gc * AEM_MP + lane];
+        __builtin_amdgcn_wave_barrier();
+        if (lane < MP) rrow[lane] = rb;
+        __builtin_amdgcn_wave_barrier();
+        double sacc = 0.0;
+        if (lane < MP) {
+          const double* Pc = a.aem_P + (size_t)gc * AEM_MP * AEM_MP + lane;
+          for (int o = 0; o < MP; ++o) sacc = fma(Pc[(size_t)o * AEM_MP], rrow[o], sacc);
+          sacc *= rb;
+        }
+        for (int off = 32; off >= 1; off >>= 1) sacc += __shfl_xor(sacc, off);
+        if (lane == 0) s_R[16 * RSa + cc] = -0.5 * sacc;
+      }
+      if (prior_dense && lane < 16) {}  // (s_redp already written above)
+      __syncthreads();
+      ll_n = s_R[16 * RSa + lc];
+      if (prior_dense) maha = ((s_redp[lc] + s_redp[16 + lc]) + s_redp[32 + lc]) + s_redp[48 + lc];
+      lp_n = -0.5 * (a.pr.logconst + maha);
+      return;
+    }
+    double sse = dg ? level_sse_partial<DPAD, 1>(L.Apk, L.ncb, s_stage + a.lds_y[k], s_stage + a.lds_w[k], th, wave, lane, g0, g1)
+                    : level_sse_partial<DPAD, 0>(L.Apk, L.ncb, s_stage + a.lds_y[k], nullptr, th, wave, lane, g0, g1);
+    sse = sum_rows(sse);
+    if (lane < 16) s_red[wave * 16 + lane] = sse;
+    __syncthreads();
+    const double tot = ((s_red[lc] + s_red[16 + lc]) + s_red[32 + lc]) + s_red[48 + lc];
+    if (prior_dense) maha = ((s_redp[lc] + s_redp[16 + lc]) + s_redp[32 + lc]) + s_redp[48 + lc];
+    ll_n = dg ? -0.5 * tot : -0.5 * tot / L.var;
+    lp_n = -0.5 * (a.pr.logconst + maha);
+  };
+
+  for (int s = 0; s < a.S; ++s) {
+    // ================= level 0: one Metropolis-Hastings step =================
+    frag_load<DPAD>(fbase, wave, a.lv[0].ncb, f0);
+    frag_load<DPAD>(fbase, wave + 4, a.lv[0].ncb, f1);
+    if (a.randomize && cnt[0] == 0) {  // DA: draw the promoted index of the subchain that starts now
+      const int L0 = a.sl[0];
+      if (a.ridx_rep) {
+        const double r = a.ridx_rep[(size_t)(stepno[1] - a.done[1]) * a.N + (gcl < a.N ? gcl : 0)];
+        pick = (r != r) ? L0 - 1 : (int)r + L0;  // reference index in [-L, -1] (chain.py:525-527)
+      } else {
+        const u32x4 r = philox4x32_10(u32x4{0u, (uint32_t)stepno[1], gchain, STREAM_INDEX}, (uint32_t)a.seed,
+                                      (uint32_t)(a.seed >> 32));
+        pick = (int)(((uint64_t)r.x * (uint64_t)L0) >> 32);
+      }
+    }
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const double sx = scal_t * xin[e];
+        prp[e] = is_pcn ? keep_t * cur[0][e] + sx : cur[0][e] + sx;
+        s_prop[c * LDP + q_ * EPT + e] = prp[e];
+      }
+    }
+    const double u = unext;
+    if (s + 1 < a.S) {
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) xin[e] = a.inc[((size_t)(s + 1) * a.NP + gct) * DPAD + q_ * EPT + e];
+      }
+      unext = a.u0[(size_t)(s + 1) * a.NP + gcl];
+    }
+    __syncthreads();
+    double lp_n, ll_n;
+    evaluate(0, f0, f1, lp_n, ll_n);
+    const double post_n = lp_n + ll_n;
+    double alpha = is_pcn ? exp(ll_n - ll[0]) : exp(post_n - (lp[0] + ll[0]));
+    if (post_n != post_n) alpha = 0.0;
+    const bool acc0 = u < alpha;
+    if (acc0) {
+      lp[0] = lp_n;
+      ll[0] = ll_n;
+    }
+    anyacc[0] |= acc0 ? 1 : 0;
+    if (a.sid && acc0 && wave == 0 && lane < 16) a.sid[gcl] = stepno[0] + 1;  // a new parameter vector was created
+    {
+      const int accf = __shfl(acc0 ? 1 : 0, c);
+      const bool take = a.randomize && cnt[0] == pick;
+      const int takef = __shfl(take ? 1 : 0, c);
+      if (take) {
+        snap_lp = lp[0];
+        snap_ll = ll[0];
+      }
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          cur[0][e] = accf ? prp[e] : cur[0][e];
+          if (takef) snp[e] = cur[0][e];
+          const int j = q_ * EPT + e;
+          if (a.rec_params[0] && gct < a.N && j < a.d)
+            a.rec_params[0][((size_t)nrec[0] * a.N + gct) * a.d + j] = cur[0][e];
+        }
+      }
+    }
+    if (wave == 0 && lane < 16) {
+      if (gcl < a.N) {
+        const size_t r = (size_t)nrec[0] * a.N + gcl;
+        if (a.rec_stats[0]) {
+          a.rec_stats[0][r * 3 + 0] = lp[0];
+          a.rec_stats[0][r * 3 + 1] = ll[0];
+          a.rec_stats[0][r * 3 + 2] = lp[0] + ll[0];
+        }
+        if (a.rec_acc[0]) a.rec_acc[0][r] = acc0 ? 1 : 0;
+      }
+      a.ring[(size_t)(ringpos % a.ring_P) * a.NP + gcl] = acc0 ? 1 : 0;
+    }
+    ringpos += 1;
+    nrec[0] += 1;
+    stepno[0] += 1;
+    cnt[0] += 1;
+
+    // ================= upper levels whose subchain just completed =================
+#pragma unroll
+    for (int k = 0; k < NLEV - 1; ++k) {
+      if (!a.cascade || cnt[k] != a.sl[k]) break;
+      const int q = k + 1;
+      const bool use_snap = (a.randomize != 0) && k == 0;
+      // y -> LDS for the fragment gather
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) s_prop[c * LDP + q_ * EPT + e] = use_snap ? snp[e] : cur[k][e];
+      }
+      const double2* gb = reinterpret_cast<const double2*>(a.lv[q].Apk) + lane;
+      double2 g0[KS / 2], g1[KS / 2];
+      frag_load<DPAD>(gb, wave, a.lv[q].ncb, g0);
+      frag_load<DPAD>(gb, wave + 4, a.lv[q].ncb, g1);
+      __syncthreads();
+      double lpq, llq;
+      evaluate(q, g0, g1, lpq, llq);
+      const double y_lp = use_snap ? snap_lp : lp[k], y_ll = use_snap ? snap_ll : ll[k];
+      const int pkq = pair_index(k, q);
+      double uq;
+      if (a.u_rep[q])
+        uq = a.u_rep[q][(size_t)(stepno[q] - a.done[q]) * a.N + (gcl < a.N ? gcl : 0)];
+      else
+        uq = accept_uniform(a.seed, gchain, (uint32_t)stepno[q], (uint32_t)q);
+      const double alq = exp(((lpq + llq) - (lp[q] + ll[q])) + (Slp[pkq] + Sll[pkq]) - (y_lp + y_ll));
+      const bool accq = (anyacc[k] != 0) && (uq < alq);
+      const int accf = __shfl(accq ? 1 : 0, c);
+      // parameters: accept -> level q (and level k, if a promoted intermediate state) take y;
+      //             reject -> all levels below q return to theta_q
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          const double yv = use_snap ? snp[e] : cur[k][e];
+          if (accf) {
+            cur[q][e] = yv;
+            cur[k][e] = yv;
+          } else {
+#pragma unroll
+            for (int j = 0; j < q; ++j) cur[j][e] = cur[q][e];
+          }
+        }
+      }
+      if (accq) {
+        lp[q] = lpq;
+        ll[q] = llq;
+        lp[k] = y_lp;
+        ll[k] = y_ll;
+      } else {
+#pragma unroll
+        for (int j = 0; j < q; ++j) {
+          lp[j] = Slp[pair_index(j, q)];
+          ll[j] = Sll[pair_index(j, q)];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < q; ++j) {
+#pragma unroll
+        for (int q2 = j + 1; q2 <= q; ++q2) {
+          Slp[pair_index(j, q2)] = lp[j];
+          Sll[pair_index(j, q2)] = ll[j];
+        }
+      }
+      anyacc[k] = 0;
+      if (q < NLEV - 1) anyacc[q] |= accq ? 1 : 0;
+      // records of level q and the alignment entry in the base proposal's accepted window
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          const int j = q_ * EPT + e;
+          if (a.rec_params[q] && gct < a.N && j < a.d)
+            a.rec_params[q][((size_t)nrec[q] * a.N + gct) * a.d + j] = cur[q][e];
+        }
+      }
+      if (wave == 0 && lane < 16) {
+        if (gcl < a.N) {
+          const size_t r = (size_t)nrec[q] * a.N + gcl;
+          if (a.rec_stats[q]) {
+            a.rec_stats[q][r * 3 + 0] = lp[q];
+            a.rec_stats[q][r * 3 + 1] = ll[q];
+            a.rec_stats[q][r * 3 + 2] = lp[q] + ll[q];
+          }
+          if (a.rec_acc[q]) a.rec_acc[q][r] = accq ? 1 : 0;
+        }
+        a.ring[(size_t)(ringpos % a.ring_P) * a.NP + gcl] = accq ? 1 : 0;
+      }
+      ringpos += 1;
+      nrec[q] += 1;
+      stepno[q] += 1;
+      cnt[k] = 0;
+      cnt[q] += 1;
+    }
+  }
+
+  // ---- write the state back ----
+#pragma unroll
+  for (int k = 0; k < NLEV; ++k) {
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) a.theta[((size_t)k * a.NP + gct) * DPAD + q_ * EPT + e] = cur[k][e];
+    }
+    if (wave == 0 && lane < 16) {
+      a.lp[(size_t)k * a.NP + gcl] = lp[k];
+      a.ll[(size_t)k * a.NP + gcl] = ll[k];
+      a.anyacc[(size_t)k * a.NP + gcl] = anyacc[k];
+    }
+  }
+  if (wave == 0 && lane < 16) {
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) {
+      a.Sst[((size_t)p * 2 + 0) * a.NP + gcl] = Slp[p];
+      a.Sst[((size_t)p * 2 + 1) * a.NP + gcl] = Sll[p];
+    }
+    a.ysnap[gcl * LDP + DPAD] = snap_lp;
+    a.ysnap[gcl * LDP + DPAD + 1] = snap_ll;
+    a.pick[gcl] = pick;
+  }
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) a.ysnap[gct * LDP + q_ * EPT + e] = snp[e];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adaptive error model (Cui et al. 2019): one step of level q >= 1 for every chain, one wave per chain, followed by
+// the error-model update of level q-1.  Used in the host-sequenced mode (MLArgs::cascade = 0): the tile kernel
+// advances the base level, this kernel performs what DAChain.sample (chain.py:353-402, 446-523) / MLDA.make_mlda_proposal
+// (proposal.py:1515-1578) / MLDAChain.sample (chain.py:711-765) do once the subchain below has finished.
+// Sizes are "parity sizes": output dimension m <= 64 (lane = observation), per-chain m x m matrices in HBM; the
+// reference itself re-inverts an m x m matrix per chain per step (distributions.py:402).
+// ------------------------------------------------------------------------------------------------
+struct AemArgs {
+  int64_t N, NP, chain_offset;
+  int d, DP, m, MP, nlev, q;
+  int is_da, dependent, prop_kind;
+  uint64_t seed;
+  int64_t step;            // index of this level-q step (RNG / replay row)
+  const double* A[MAXLEV];     // row-major [m][d]
+  const double* ytil[MAXLEV];  // y - b, [MP]   (residual r = A theta - ytil = F - y)
+  const double* data[MAXLEV];  // y, [MP]       (model output F = r + y)
+  const double* cov[MAXLEV];   // adaptive levels: Sigma_e [MP][MP]
+  double var_finest;
+  const double* pr_mean;   // [DP]
+  const double* pr_W;      // [d][d] whitening (L^-1 of the prior covariance), row-major
+  double pr_logdet;
+  double* theta;   // [nlev][NP][DP]
+  double* lp;      // [nlev][NP]
+  double* ll;
+  double* Sst;     // [npairs][2][NP]
+  int32_t* anyacc; // [nlev][NP]
+  int64_t* sid;    // [nlev][NP]
+  double* bias_tot[MAXLEV];  // [NP][MP]     adaptive levels
+  double* cov_inv[MAXLEV];   // [NP][MP][MP]
+  double* b_mu[MAXLEV];      // trackers of levels >= 1: [NP][MP]
+  double* b_sig[MAXLEV];     // [NP][MP][MP]
+  double* mdiff[MAXLEV];     // [NP][MP]
+  int64_t b_t;               // recursion counter of level q's tracker before this update
+  const double* scaling;     // [NP] (pCN beta for the state-dependent q terms)
+  const double* u_rep;       // [N] replay uniform of this step (NaN = none drawn) or null
+  uint8_t* ring;
+  int ring_P;
+  int64_t ring_pos;
+  double* rec_params;  // row of this step, [N][d] (may be null)
+  double* rec_stats;
+  uint8_t* rec_acc;
+};
+
+__global__ void __launch_bounds__(64) k_aem_action(const AemArgs a) {
+  constexpr int LDM = AEM_MP + 1;
+  __shared__ double s_M[AEM_MP * LDM];
+  __shared__ double s_v[4 * AEM_MP];
+  const int lane = threadIdx.x;
+  const int64_t c = blockIdx.x;
+  if (c >= a.N) return;
+  const int q = a.q, k = a.q - 1, nl = a.nlev, MP = a.MP, d = a.d;
+  const bool lo = lane < a.m, lj = lane < d;
+  auto TH = [&](int lev) { return a.theta + ((size_t)lev * a.NP + c) * a.DP; };
+  auto bsum = [&](double v) {
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+  };
+  // F_lev(theta)[lane] - ytil_lev[lane]  (theta given through LDS vector s_v[0..d))
+  auto resid = [&](int lev) {
+    double f = 0.0;
+    if (lo) {
+      const double* Ar = a.A[lev] + (size_t)lane * d;
+      for (int j = 0; j < d; ++j) f = fma(Ar[j], s_v[j], f);
+      f -= a.ytil[lev][lane];
+    }
+    return f;
+  };
+  // -1/2 r^T P r with chain c's inverse of adaptive level lev; r given per lane (already bias corrected)
+  auto quad = [&](int lev, double r) {
+    __syncthreads();
+    s_v[AEM_MP + lane] = lo ? r : 0.0;
+    __syncthreads();
+    double s = 0.0;
+    if (lo) {
+      const double* Pc = a.cov_inv[lev] + (size_t)c * MP * MP + lane;
+      for (int o = 0; o < a.m; ++o) s = fma(Pc[(size_t)o * MP], s_v[AEM_MP + o], s);
+      s *= r;
+    }
+    return -0.5 * bsum(s);
+  };
+  auto loglike_of = [&](int lev, double r0) {  // r0 = F - ytil without bias
+    if (lev == nl - 1) return -0.5 * bsum(lo ? r0 * r0 : 0.0) / a.var_finest;
+    return quad(lev, lo ? r0 + a.bias_tot[lev][c * MP + lane] : 0.0);
+  };
+
+  // ---------------- the level-q decision ----------------
+  const double yj = lj ? TH(k)[lane] : 0.0, xj = lj ? TH(q)[lane] : 0.0;
+  const double y_lp = a.lp[(size_t)k * a.NP + c], y_ll = a.ll[(size_t)k * a.NP + c];
+  const double x_lp = a.lp[(size_t)q * a.NP + c], x_ll = a.ll[(size_t)q * a.NP + c];
+  const int pkq = pair_index(k, q);
+  const double st_lp = a.Sst[((size_t)pkq * 2 + 0) * a.NP + c], st_ll = a.Sst[((size_t)pkq * 2 + 1) * a.NP + c];
+  const bool any = a.anyacc[(size_t)k * a.NP + c] != 0;
+  __syncthreads();
+  if (lane < AEM_MP) s_v[lane] = yj;
+  __syncthreads();
+  const double rq_y = resid(q);                   // F_q(y) - ytil_q
+  const double rk_y = a.dependent ? resid(k) : 0.0;  // F_k(y) - ytil_k
+  const double lpn = y_lp;  // same prior, same parameters (posterior.py:92)
+  const double lln = loglike_of(q, rq_y);
+  double alpha;
+  if (a.dependent) {  // chain.py:446-473
+    // bias at the proposal and the coarse density of the subchain start under it
+    const double bias_next = (rq_y + a.data[q][lane < MP ? lane : 0]) - (rk_y + a.data[k][lane < MP ? lane : 0]);
+    __syncthreads();
+    if (lane < AEM_MP) s_v[lane] = xj;  // subchain start = the fine state
+    __syncthreads();
+    const double rk_x = resid(k);
+    const double ll_b = quad(k, lo ? rk_x + bias_next : 0.0);
+    double q_xy = 0.0, q_yx = 0.0;
+    if (a.prop_kind == 1) {  // pCN transition densities (proposal.py:364-369) between the fine links
+      const double beta = a.scaling[c], kp = sqrt(1.0 - beta * beta);
+      for (int dir = 0; dir < 2; ++dir) {
+        __syncthreads();
+        if (lane < AEM_MP) s_v[2 * AEM_MP + lane] = dir == 0 ? yj - kp * xj : xj - kp * yj;
+        __syncthreads();
+        double w = 0.0;
+        if (lj) {
+          const double* Wr = a.pr_W + (size_t)lane * d;
+          for (int j = 0; j <= lane; ++j) w = fma(Wr[j], s_v[2 * AEM_MP + j], w);
+        }
+        const double maha = bsum(lj ? w * w : 0.0) / (beta * beta);
+        const double v = -0.5 * (d * 1.8378770664093453 + a.pr_logdet + d * log(beta * beta) + maha);
+        if (dir == 0) q_xy = v; else q_yx = v;
+      }
+    }
+    const double n1 = (lpn + lln) + q_yx, n2 = (st_lp + ll_b) + q_xy;
+    const double d1 = (x_lp + x_ll) + q_xy, d2 = (y_lp + y_ll) + q_yx;
+    alpha = exp((n1 < n2 ? n1 : n2) - (d1 < d2 ? d1 : d2));
+  } else {
+    alpha = exp(((lpn + lln) - (x_lp + x_ll)) + (st_lp + st_ll) - (y_lp + y_ll));  // chain.py:475-483, proposal.py:1615-1624
+  }
+  double u;
+  if (a.u_rep) u = a.u_rep[c];
+  else u = accept_uniform(a.seed, (uint32_t)(a.chain_offset + c), (uint32_t)a.step, (uint32_t)q);
+  const bool acc = any && (u < alpha);
+
+  // ---------------- alignment (chain.py:357-398; proposal.py:1469-1493) ----------------
+  if (acc) {
+    if (lane < a.DP) TH(q)[lane] = lj ? yj : 0.0;
+  } else {
+    for (int j = 0; j < q; ++j)
+      if (lane < a.DP) TH(j)[lane] = lj ? xj : 0.0;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    if (acc) {
+      a.lp[(size_t)q * a.NP + c] = lpn;
+      a.ll[(size_t)q * a.NP + c] = lln;
+      a.sid[(size_t)q * a.NP + c] = a.sid[(size_t)k * a.NP + c];
+    } else {
+      for (int j = 0; j < q; ++j) {
+        const int p = pair_index(j, q);
+        a.lp[(size_t)j * a.NP + c] = a.Sst[((size_t)p * 2 + 0) * a.NP + c];
+        a.ll[(size_t)j * a.NP + c] = a.Sst[((size_t)p * 2 + 1) * a.NP + c];
+        a.sid[(size_t)j * a.NP + c] = a.sid[(size_t)q * a.NP + c];
+      }
+    }
+    for (int j = 0; j < q; ++j)
+      for (int q2 = j + 1; q2 <= q; ++q2) {
+        const int p = pair_index(j, q2);
+        a.Sst[((size_t)p * 2 + 0) * a.NP + c] = a.lp[(size_t)j * a.NP + c];
+        a.Sst[((size_t)p * 2 + 1) * a.NP + c] = a.ll[(size_t)j * a.NP + c];
+      }
+    a.anyacc[(size_t)k * a.NP + c] = 0;
+    if (q < nl - 1) a.anyacc[(size_t)q * a.NP + c] |= acc ? 1 : 0;
+    a.ring[(size_t)(a.ring_pos % a.ring_P) * a.NP + c] = acc ? 1 : 0;
+    if (a.rec_stats) {
+      const double l1 = a.lp[(size_t)q * a.NP + c], l2 = a.ll[(size_t)q * a.NP + c];
+      a.rec_stats[c * 3 + 0] = l1;
+      a.rec_stats[c * 3 + 1] = l2;
+      a.rec_stats[c * 3 + 2] = l1 + l2;
+    }
+    if (a.rec_acc) a.rec_acc[c] = acc ? 1 : 0;
+  }
+  if (a.rec_params && lj) a.rec_params[c * d + lane] = acc ? yj : xj;
+  __syncthreads();
+
+  // ---------------- error model update (chain.py:485-523, :739-765; proposal.py:1547-1578) ----------------
+  const double cj = acc ? yj : xj;  // theta_q = theta_k now
+  __syncthreads();
+  if (lane < AEM_MP) s_v[lane] = cj;
+  __syncthreads();
+  const double rq = resid(q), rk = resid(k);
+  const double diff_new = lo ? (rq + a.data[q][lane]) - (rk + a.data[k][lane]) : 0.0;
+  double* md = a.mdiff[q] + c * MP;
+  double* Sg = a.b_sig[q] + (size_t)c * MP * MP;
+  const double t = (double)a.b_t;
+  double xupd;  // the sample fed to the running moments
+  if (a.dependent) {
+    xupd = lo ? (rq + a.data[q][lane]) - ((rk + a.data[k][lane]) + md[lane]) : 0.0;  // chain.py:505-507
+    if (lo) md[lane] = diff_new;
+    __syncthreads();
+    if (lane < AEM_MP) s_v[AEM_MP + lane] = xupd;
+    __syncthreads();
+    if (lo)
+      for (int i = 0; i < a.m; ++i) {  // utils.py:199  Sigma <- (t-1)/t Sigma + 1/t x x^T
+        const double xi = s_v[AEM_MP + i];
+        Sg[(size_t)i * MP + lane] = (t - 1.0) / t * Sg[(size_t)i * MP + lane] + 1.0 / t * (xi * xupd);
+      }
+  } else {
+    const double dm = (a.is_da || acc) ? diff_new : (lo ? md[lane] : 0.0);  // MLDA refreshes the difference on accept only
+    if (lo) md[lane] = dm;
+    double* mu = a.b_mu[q] + c * MP;
+    const double mu_o = lo ? mu[lane] : 0.0;
+    const double mu_n = (1.0 / (t + 1.0)) * (t * mu_o + dm);  // utils.py:113-122 with sd = 1, eps = 0
+    __syncthreads();
+    if (lane < AEM_MP) {
+      s_v[AEM_MP + lane] = dm;
+      s_v[2 * AEM_MP + lane] = mu_o;
+      s_v[3 * AEM_MP + lane] = mu_n;
+    }
+    __syncthreads();
+    if (lo) {
+      const double ca = (t - 1.0) / t, cb = 1.0 / t;
+      for (int i = 0; i < a.m; ++i) {
+        const double M = (t * (s_v[2 * AEM_MP + i] * mu_o) - (t + 1.0) * (s_v[3 * AEM_MP + i] * mu_n)) + s_v[AEM_MP + i] * dm;
+        Sg[(size_t)i * MP + lane] = ca * Sg[(size_t)i * MP + lane] + cb * M;
+      }
+      mu[lane] = mu_n;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  // total bias of level k: state-dependent = the last difference; otherwise sums over the trackers of levels >= q
+  double bt = 0.0;
+  if (lo) {
+    if (a.dependent) bt = md[lane];
+    else
+      for (int p = q; p < nl; ++p) bt += a.b_mu[p][c * MP + lane];
+    a.bias_tot[k][c * MP + lane] = bt;
+  }
+  // Sigma_e + Sigma_bias into LDS (row i = lane), and the 1e-9 rule of distributions.py:399-402
+  bool big = false;
+  if (lo) {
+    for (int j = 0; j < a.m; ++j) {
+      // symmetric matrices: element (lane, j) is read as (j, lane), the entry this very lane wrote above
+      double sb = 0.0;
+      if (a.dependent) sb = Sg[(size_t)j * MP + lane];
+      else
+        for (int p = q; p < nl; ++p) sb += a.b_sig[p][(size_t)c * MP * MP + (size_t)j * MP + lane];
+      big = big || !(sb < 1e-9);
+      s_M[lane * LDM + j] = a.cov[k][(size_t)j * MP + lane] + sb;
+    }
+  }
+  const bool refresh = __ballot(big) != 0ull;
+  __syncthreads();
+  if (refresh) {
+    // inverse through the Cholesky factor: M = L L^T, W = L^-1, P = W^T W
+    for (int kk = 0; kk < a.m; ++kk) {
+      double sacc = 0.0;
+      if (lane >= kk && lo) {
+        sacc = s_M[lane * LDM + kk];
+        for (int p = 0; p < kk; ++p) sacc = fma(-s_M[lane * LDM + p], s_M[kk * LDM + p], sacc);
+      }
+      const double lkk = sqrt(__shfl(sacc, kk));
+      if (lane >= kk && lo) s_M[lane * LDM + kk] = lane == kk ? lkk : sacc / lkk;
+      __syncthreads();
+    }
+    // W = L^-1 : lane = column j, forward substitution down the rows; stored in the upper triangle region via a second pass
+    double Wc[AEM_MP];
+#pragma unroll 1
+    for (int i = 0; i < a.m; ++i) {
+      double v = 0.0;
+      if (lo && i >= lane) {
+        if (i == lane) v = 1.0 / s_M[i * LDM + i];
+        else {
+          double sacc = 0.0;
+          for (int p = lane; p < i; ++p) sacc = fma(s_M[i * LDM + p], Wc[p], sacc);
+          v = -sacc / s_M[i * LDM + i];
+        }
+      }
+      Wc[i] = v;
+    }
+    __syncthreads();
+    // s_M <- W (row i, column j = lane)
+    for (int i = 0; i < a.m; ++i)
+      if (lo) s_M[i * LDM + lane] = Wc[i];
+    __syncthreads();
+    if (lo) {
+      double* Pc = a.cov_inv[k] + (size_t)c * MP * MP;
+      for (int i = 0; i < a.m; ++i) {  // P[i][lane] = sum_r W[r][i] W[r][lane]
+        double sacc = 0.0;
+        const int r0 = i > lane ? i : lane;
+        for (int r = r0; r < a.m; ++r) sacc = fma(s_M[r * LDM + i], s_M[r * LDM + lane], sacc);
+        Pc[(size_t)i * MP + lane] = sacc;
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  // update_link of level k's latest link (posterior.py:112-134)
+  const double llk = quad(k, lo ? rk + bt : 0.0);
+  if (lane == 0) {
+    a.ll[(size_t)k * a.NP + c] = llk;
+    const int64_t idk = a.sid[(size_t)k * a.NP + c];
+    for (int q2 = q; q2 < nl; ++q2)
+      if (a.sid[(size_t)q2 * a.NP + c] == idk) a.Sst[((size_t)pair_index(k, q2) * 2 + 1) * a.NP + c] = llk;
+  }
+}
+
+}  // namespace tda
