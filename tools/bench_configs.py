@@ -38,6 +38,63 @@ def run(name, ms, sl, prop, n_fine, N=4096, d=64):
     print(json.dumps(res))
     e.close()
 
+def run_c5_aem(N=4096, d=64, m=64, n_fine=20):
+    """C5 with the state-independent adaptive error model: levels share the output dimension, here m = 64
+    (the device error-model limit); levels 0/1 AdaptiveGaussianLogLike, level 2 isotropic; AM; subchains [5, 3]."""
+    rng = np.random.default_rng(6)
+    truth = rng.standard_normal(d)
+    Af = rng.standard_normal((m, d)) / 8
+    y = Af @ truth + 0.1 * rng.standard_normal(m)
+    e = Engine(N, d, seed=10, n_levels=3)
+    e.set_prior(np.zeros(d), np.eye(d))
+    for k in range(3):
+        A = Af + 0.02 * (2 - k) * rng.standard_normal((m, d)) / 8
+        if k < 2:
+            e.set_level(k, A, y, 3, 0.01 * np.eye(m))
+        else:
+            e.set_level(k, A, y, 0, 0.01)
+    e.set_proposal(2, 1e-4 * np.eye(d), t0=100, period=100)
+    e.set_subchains([5, 3])
+    e.set_error_model("state-independent")
+    e.init(None)
+    rows = e.rows_per_level(n_fine)
+    outs = [(torch.empty((r, N, d), dtype=torch.float64, device="cuda"), torch.empty((r, N, 3), dtype=torch.float64, device="cuda"),
+             torch.empty((r, N), dtype=torch.uint8, device="cuda")) for r in rows]
+    e.run_levels(2, outs)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    e.run_levels(n_fine, outs)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(json.dumps(dict(config="C5 + state-independent AEM, common m=64, AM, subchains [5,3]", chains=N, fine_iterations=n_fine, seconds=dt,
+                          coarse_evals_per_s=N * rows[0] / dt, finest_iterations_per_s=N * n_fine / dt,
+                          acceptance=[float(o[2].float().mean().item()) for o in outs])))
+    e.close()
+
+
+def run_c2b(N=4096, d=64, m=1024, T=300):
+    """C2b: dense data covariance (DefaultGaussianLogLike), AM, 4096 chains."""
+    rng = np.random.default_rng(1)
+    A = rng.standard_normal((m, d)) / 8
+    y = A @ rng.standard_normal(d) + 0.1 * rng.standard_normal(m)
+    Lc = 0.1 * np.eye(m) + 0.01 * np.tril(rng.standard_normal((m, m)))
+    e = Engine(N, d, seed=1)
+    e.set_prior(np.zeros(d), np.eye(d)); e.set_level(0, A, y, 2, Lc @ Lc.T)
+    e.set_proposal(2, 1e-4 * np.eye(d), t0=100, period=100)
+    e.init(None)
+    p = torch.empty((T, N, d), dtype=torch.float64, device="cuda"); s = torch.empty((T, N, 3), dtype=torch.float64, device="cuda")
+    a = torch.empty((T, N), dtype=torch.uint8, device="cuda")
+    e.run(100, p[:100], s[:100], a[:100])
+    e.set_profiling(True)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    e.run(T, p, s, a)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    pr = e.profile()
+    flops = 2 * m * d + 2 * m * m + 3 * m
+    print(json.dumps(dict(config="C2b: dense Sigma (m=1024), AM", chains=N, steps=T, evals_per_s=N * T / dt,
+                          steps_kernel_ns_per_eval=pr["ms_steps"] * 1e6 / (N * T),
+                          mfma_tflops_survey_accounting=flops * N * T / (pr["ms_steps"] * 1e-3) / 1e12, mfma_peak_tflops=78.6)))
+    e.close()
+
+
 def run_c4(N=8192, d=32, T=400, M0=320, K=16):
     """C4 on one GPU: d=32 Rosenbrock chain, DREAM (shared archive of M0 prior rows + every chain's states, synchronised
     every K steps), 8192 chains/GPU."""
@@ -63,6 +120,8 @@ def run_c4(N=8192, d=32, T=400, M0=320, K=16):
 
 
 if __name__ == "__main__":
+    run_c2b()
+    run_c5_aem()
     run_c4()
     run("C3: DA pCN(0.02) 256/2048 obs, subsampling_rate=10", (256, 2048), [10], dict(kind=1, scaling=0.02), 200)
     run("C5-literal: MLDA AM 128/512/2048 obs, subchains [5,3], no AEM", (128, 512, 2048), [5, 3],
