@@ -236,6 +236,14 @@ int tda_engine_set_archive_auto_append(tda_engine* e, int on);
 int tda_engine_reduce_moments(tda_engine* e, const double* rows, int64_t n_rows, double* out);
 int tda_engine_set_proposal_covariance(tda_engine* e, const double* C);
 
+/* Checkpoint / resume (the reference has none: sample() cannot continue a previous run).  The blob holds every chain's
+ * state at every level, the proposal state (scaling, factors, running moments, archives, error-model trackers) and the
+ * step / RNG counters; restoring it into an engine that was configured and init()-ed identically continues the run
+ * bit for bit.  HOST pointers. */
+int64_t tda_engine_state_size(tda_engine* e);
+int tda_engine_get_state(tda_engine* e, void* blob, int64_t bytes);
+int tda_engine_set_state(tda_engine* e, const void* blob, int64_t bytes);
+
 /* Per-chain error flags (bit 0: Cholesky of an adapted covariance failed, previous factor kept). HOST. */
 int tda_engine_get_flags(tda_engine* e, int32_t* flags);
 

@@ -110,6 +110,9 @@ SYMBOLS = {
     "tda_engine_set_archive_auto_append": (C.c_int, [_P, C.c_int]),
     "tda_engine_reduce_moments": (C.c_int, [_P, _P, C.c_int64, _P]),
     "tda_engine_set_proposal_covariance": (C.c_int, [_P, _P]),
+    "tda_engine_state_size": (C.c_int64, [_P]),
+    "tda_engine_get_state": (C.c_int, [_P, _P, C.c_int64]),
+    "tda_engine_set_state": (C.c_int, [_P, _P, C.c_int64]),
     "tda_engine_set_subchains": (C.c_int, [_P, _P, C.c_int]),
     "tda_engine_set_error_model": (C.c_int, [_P, C.c_int]),
     "tda_engine_get_error_model": (C.c_int, [_P, C.c_int, _P, _P]),

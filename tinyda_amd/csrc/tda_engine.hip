@@ -794,6 +794,125 @@ int tda_engine_set_proposal_covariance(tda_engine* e, const double* C) {
   return TDA_OK;
 }
 
+namespace {
+struct StateItem {
+  void* p;
+  size_t bytes;
+  bool device;
+};
+
+// every piece of mutable state of an initialised engine, in a fixed order for its configuration
+void enumerate_state(tda_engine* e, std::vector<StateItem>& v) {
+  auto dev = [&](auto& buf) {
+    if (buf.p && buf.n) v.push_back({(void*)buf.p, buf.n * sizeof(*buf.p), true});
+  };
+  auto host = [&](void* p, size_t b) { v.push_back({p, b, false}); };
+  host(&e->t, sizeof e->t);
+  host(&e->k_adapt, sizeof e->k_adapt);
+  dev(e->theta);
+  dev(e->lp);
+  dev(e->ll);
+  dev(e->scaling);
+  dev(e->acc_count);
+  dev(e->flags);
+  dev(e->Lk);
+  dev(e->am_mu);
+  dev(e->am_sigma);
+  if (e->nlev > 1) {
+    host(e->cnt, sizeof e->cnt);
+    host(e->done, sizeof e->done);
+    host(&e->ring_pos, sizeof e->ring_pos);
+    host(e->aem_bt, sizeof e->aem_bt);
+    dev(e->ml_theta);
+    dev(e->ml_lp);
+    dev(e->ml_ll);
+    dev(e->ml_S);
+    dev(e->ml_anyacc);
+    dev(e->ml_ysnap);
+    dev(e->ml_pick);
+    dev(e->ml_ring);
+    dev(e->ml_sid);
+    for (int k = 0; k < MAXLEV; ++k) {
+      dev(e->aem_bias[k]);
+      dev(e->aem_covinv[k]);
+      dev(e->aem_bmu[k]);
+      dev(e->aem_bsig[k]);
+      dev(e->aem_mdiff[k]);
+    }
+  }
+  if (e->is_dreamz) {
+    host(&e->arch_rows, sizeof e->arch_rows);
+    host(&e->pending_steps, sizeof e->pending_steps);
+    dev(e->arch);
+    dev(e->zsum);
+    dev(e->zsq);
+    dev(e->dz_pCR);
+    dev(e->dz_LCR);
+    dev(e->dz_Delta);
+    dev(e->dz_mcr_last);
+    dev(e->theta_prev);
+    dev(e->blk_hist);
+  }
+}
+}  // namespace
+
+int64_t tda_engine_state_size(tda_engine* e) {
+  if (!e || !e->inited) return fail(TDA_ERR_STATE, "engine not initialised");
+  std::vector<StateItem> v;
+  enumerate_state(e, v);
+  int64_t n = 16;  // header: magic + item count
+  for (auto& it : v) n += 8 + (int64_t)it.bytes;
+  return n;
+}
+
+int tda_engine_get_state(tda_engine* e, void* blob, int64_t bytes) {
+  if (!e || !e->inited || !blob) return fail(TDA_ERR_STATE, "engine not initialised");
+  if (bytes != tda_engine_state_size(e)) return fail(TDA_ERR_INVALID, "state blob must be exactly tda_engine_state_size() bytes");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  std::vector<StateItem> v;
+  enumerate_state(e, v);
+  char* o = (char*)blob;
+  const uint64_t magic = 0x3141445454414453ull, cnt = v.size();
+  memcpy(o, &magic, 8);
+  memcpy(o + 8, &cnt, 8);
+  o += 16;
+  for (auto& it : v) {
+    const uint64_t b = it.bytes;
+    memcpy(o, &b, 8);
+    o += 8;
+    if (it.device) HIP_TRY(hipMemcpy(o, it.p, it.bytes, hipMemcpyDeviceToHost));
+    else memcpy(o, it.p, it.bytes);
+    o += it.bytes;
+  }
+  return TDA_OK;
+}
+
+int tda_engine_set_state(tda_engine* e, const void* blob, int64_t bytes) {
+  if (!e || !e->inited || !blob) return fail(TDA_ERR_STATE, "engine not initialised (configure and init() it like the saved one first)");
+  if (bytes != tda_engine_state_size(e)) return fail(TDA_ERR_INVALID, "state blob does not match this engine's configuration");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  std::vector<StateItem> v;
+  enumerate_state(e, v);
+  const char* o = (const char*)blob;
+  uint64_t magic, cnt;
+  memcpy(&magic, o, 8);
+  memcpy(&cnt, o + 8, 8);
+  if (magic != 0x3141445454414453ull || cnt != v.size()) return fail(TDA_ERR_INVALID, "not a state blob of this engine configuration");
+  o += 16;
+  for (auto& it : v) {
+    uint64_t b;
+    memcpy(&b, o, 8);
+    if (b != it.bytes) return fail(TDA_ERR_INVALID, "state blob layout mismatch");
+    o += 8;
+    if (it.device) HIP_TRY(hipMemcpy(it.p, o, it.bytes, hipMemcpyHostToDevice));
+    else memcpy(it.p, o, it.bytes);
+    o += it.bytes;
+  }
+  return TDA_OK;
+}
+
 int tda_engine_set_error_model(tda_engine* e, int kind) {
   if (!e) return fail(TDA_ERR_INVALID, "null engine");
   if (kind < TDA_AEM_NONE || kind > TDA_AEM_STATE_DEPENDENT) return fail(TDA_ERR_INVALID, "Adaptive error model can only be state-dependent, state-independent or None.");

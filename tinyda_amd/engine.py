@@ -138,6 +138,19 @@ class Engine:
         assert Cm.shape == (self.dim, self.dim)
         check(self.lib.tda_engine_set_proposal_covariance(self.h, _ptr(Cm)))
 
+    def get_state(self):
+        """checkpoint: opaque bytes (numpy uint8) holding chain, proposal and counter state"""
+        n = int(self.lib.tda_engine_state_size(self.h))
+        if n < 0:
+            check(n)
+        blob = np.empty(n, dtype=np.uint8)
+        check(self.lib.tda_engine_get_state(self.h, _ptr(blob), n))
+        return blob
+
+    def set_state(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        check(self.lib.tda_engine_set_state(self.h, _ptr(blob), blob.size))
+
     def set_error_model(self, kind):
         code = {None: 0, "state-independent": 1, "state-dependent": 2}[kind]
         check(self.lib.tda_engine_set_error_model(self.h, code))
