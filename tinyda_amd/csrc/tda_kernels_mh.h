@@ -74,6 +74,7 @@ struct StepArgs {
   double* rec_params;
   double* rec_stats;
   uint8_t* rec_acc;
+  long long* trace;  // debug builds (-DTDA_STEP_TRACE, tools/steps_microbench.hip): [S][waves][8] cycle stamps of tile 0
 };
 
 struct ProposeArgs {
@@ -476,7 +477,17 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
   __syncthreads();
 
   if constexpr (!PAIRS) frag_load<DPAD>(fbase, wave, a.lv.ncb, f0);  // later steps: prefetched by the previous step
+  // cycle stamps for tools/steps_microbench.hip: compiled in only on request, because even a never-taken s_memtime
+  // makes hipcc fall back to lgkmcnt(0) waits in the hot loop
+#ifdef TDA_STEP_TRACE
+  const bool tracing = a.trace != nullptr && blockIdx.x == 0 && lane == 0;
+#define TDA_STAMP(i) \
+  if (tracing) a.trace[((size_t)s * NW + wave) * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime()
+#else
+#define TDA_STAMP(i)
+#endif
   for (int s = 0; s < a.S; ++s) {
+    TDA_STAMP(0);
     // first fragment block(s) of this step: independent of theta', issued ahead of the barrier
     if constexpr (PAIRS) {
       frag_load<DPAD>(fbase, wave, a.lv.ncb, f0);
@@ -504,7 +515,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
       unext = a.u[(size_t)(s + 1) * a.NP + gcl];
       if (has_logu) lunext = a.logu[(size_t)(s + 1) * a.NP + gcl];
     }
+    TDA_STAMP(1);
     __syncthreads();
+    TDA_STAMP(2);
 
     // ---- gather theta' into MFMA B-operand fragments ----
     double th[KS];
@@ -545,6 +558,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
     }
 
     // ---- forward model + Gaussian log-likelihood (posterior.py:95-108, distributions.py:295-326) ----
+    TDA_STAMP(3);
     double sse;
     if constexpr (PAIRS) {
       if (dense) {
@@ -560,9 +574,12 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
       sse = diag ? level_sse_single<DPAD, 1, NW>(a.lv.Apk, a.lv.ncb, s_y, s_w, th, wave, lane, f0)
                  : level_sse_single<DPAD, 0, NW>(a.lv.Apk, a.lv.ncb, s_y, nullptr, th, wave, lane, f0);
     }
+    TDA_STAMP(4);
     sse = sum_rows(sse);
     if (lane < 16) s_red[wave * 16 + lane] = sse;
+    TDA_STAMP(5);
     __syncthreads();
+    TDA_STAMP(6);
 
     double tot = s_red[lc];
 #pragma unroll
@@ -620,7 +637,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
           a.rec_params[((size_t)s * a.N + gct) * a.d + j] = cur[e];
       }
     }
+    TDA_STAMP(7);
   }
+#undef TDA_STAMP
 
   if (active) {
 #pragma unroll
