@@ -95,7 +95,12 @@ typedef struct tda_proposal_params {
   double sd;         /* AM scaling; <= 0 means min(1, 2.4^2/d) (proposal.py:465-468) */
   double epsilon;    /* AM regulariser (default 1e-6) */
   int32_t t0;        /* AM: first adapt() count at which C may be swapped (default 0) */
-  int32_t reserved;
+  int32_t block_moments; /* AM, extension (default 0).  0: the running covariance follows RecursiveSampleMoments.update
+                          * (utils.py:113-124) operation for operation, so results do not depend on how a run is cut
+                          * into run() calls and match the reference's traces to its own rounding.  1: one rank-S
+                          * update per block of steps on the matrix cores -- algebraically identical, free of the
+                          * reference form's cancellation, ~8x cheaper; deviates from the reference recursion by that
+                          * recursion's rounding error (1e-11 .. 1e-8 relative in Sigma on ill-conditioned chains). */
 } tda_proposal_params;
 
 /* DREAMZ / DREAM constructor arguments (proposal.py:663-742, :1627-1641). */

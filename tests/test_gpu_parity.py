@@ -153,6 +153,52 @@ def test_golden_g2_am_replay(eng_mod, golden, name, block):
     e.close()
 
 
+@pytest.mark.parametrize("name", ["g2_am_small", "g2_am_small_adaptive", "g2_am_diag_genprior", "g2_am_c2"])
+def test_golden_g2_am_replay_block_moments(eng_mod, golden, name):
+    """AdaptiveMetropolis(block_moments=True): the covariance is updated once per block in closed form on the matrix
+    cores.  Same accept masks as the reference's traces; the log-posterior agrees to 1e-8 instead of 1e-10, because
+    the closed form does not reproduce the rounding error of the reference recursion (which cancels t mu mu^T against
+    (t+1) mu' mu'^T); the mean is still bit-comparable."""
+    g = golden(name)
+    N, T1, d = g["theta"].shape
+    e = _mk_engine(eng_mod, g, N, d, "am")
+    e.set_proposal(2, g["C0"], adaptive=bool(g["adaptive"]), gamma=float(g["gamma"]), period=int(g["period"]),
+                   sd=float(g["sd"]), epsilon=float(g["epsilon"]), t0=int(g["t0"]), block_moments=True)
+    e.init(g["theta0"])
+    e.set_replay(np.swapaxes(g["z"], 0, 1), np.swapaxes(g["u"], 0, 1))
+    params, stats, acc = e.run_host(T1 - 1)
+    assert np.array_equal(acc, np.swapaxes(g["accepted"][:, 1:], 0, 1))
+    np.testing.assert_allclose(stats[:, :, 2], np.swapaxes(g["logpost"][:, 1:], 0, 1), rtol=1e-8)
+    ps = e.proposal_state(want_am=True)
+    assert not e.flags().any()
+    np.testing.assert_allclose(ps["am_mu"], g["mu_hist"][:, -1], rtol=1e-9, atol=1e-11)
+    sig_ref = g["sigma_hist"][:, -1]
+    np.testing.assert_allclose(ps["am_sigma"], sig_ref, rtol=1e-6, atol=1e-7 * np.abs(sig_ref).max())
+    e.close()
+
+
+def test_block_moments_forward_mode_vs_oracle(eng_mod):
+    """block_moments at the C2a shape in Philox mode, ragged blocks (block_steps = 37 against period 50)."""
+    d, m, N, T = 64, 256, 40, 230
+    A, th, y = _c2_problem(d, m)
+    theta0 = th + 0.02 * np.random.default_rng(3).standard_normal((N, d))
+    e = eng_mod.Engine(N, d, seed=99, block_steps=37)
+    e.set_prior(np.zeros(d), np.eye(d))
+    e.set_level(0, A, y, 0, 0.01)
+    e.set_proposal(2, 1e-4 * np.eye(d), t0=50, period=50, block_moments=True)
+    e.init(theta0)
+    z, u = e.set_export(T)
+    params, stats, acc = e.run_host(T)
+    ps = e.proposal_state(want_am=True)
+    e.close()
+    lvl = orc.LinearGaussianLevel(A, y, "iso", 0.01, orc.MVNPrior(np.zeros(d), np.eye(d)))
+    ref = orc.run_mh(lvl, dict(kind="am", C0=1e-4 * np.eye(d), t0=50, period=50), theta0,
+                     np.swapaxes(z, 0, 1), np.swapaxes(u, 0, 1))
+    assert np.array_equal(acc, np.swapaxes(ref["accepted"][:, 1:], 0, 1))
+    np.testing.assert_allclose(stats[:, :, 2], np.swapaxes(ref["logpost"][:, 1:], 0, 1), rtol=1e-9)
+    np.testing.assert_allclose(ps["am_sigma"], ref["am_sigma"], rtol=1e-8, atol=1e-8 * np.abs(ref["am_sigma"]).max())
+
+
 def test_golden_g2b_pcn_replay(eng_mod, golden):
     g = golden("g2b_pcn")
     N, T1, d = g["theta"].shape

@@ -46,7 +46,7 @@ class tda_proposal_params(C.Structure):
         ("sd", C.c_double),
         ("epsilon", C.c_double),
         ("t0", C.c_int32),
-        ("reserved", C.c_int32),
+        ("block_moments", C.c_int32),
     ]
 
 

@@ -236,6 +236,11 @@ namespace {
 
 using namespace tda;
 
+inline int am_tiles_rt(int dp) {
+  const int t = dp >= 16 ? dp / 16 : 1;
+  return t * (t + 1) / 2;
+}
+
 int g_steps_waves = 0;  // 0 = decide per launch; TINYDA_STEPS_WAVES=4|8 pins it (A/B measurements)
 
 template <int DPAD>
@@ -263,7 +268,8 @@ void launch_propose(const ProposeArgs& a, hipStream_t st) {
 }
 template <int DPAD>
 void launch_adapt(const AdaptArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_adapt<DPAD>, dim3((unsigned)a.N), dim3(64), 0, st, a);
+  if (a.do_am && a.block_moments) hipLaunchKernelGGL(k_adapt_block<DPAD>, dim3((unsigned)a.N), dim3(64), 0, st, a);
+  else hipLaunchKernelGGL(k_adapt<DPAD>, dim3((unsigned)a.N), dim3(64), 0, st, a);
 }
 template <int DPAD>
 void launch_chol(const CholArgs& a, hipStream_t st) {
@@ -1156,7 +1162,8 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
     }
     // RecursiveSampleMoments(mu0 = theta0, sigma0 = 0) (proposal.py:495-500)
     if ((rc = e->am_mu.alloc((size_t)NP * DP))) return rc;
-    const size_t nsig = (size_t)NP * (DP / 2 + 1) * DP;  // circulant-folded symmetric storage
+    // circulant fold (reference-form recursion) or lower 16x16 tiles in MFMA C/D layout (block form), see AdaptArgs
+    const size_t nsig = e->pp.block_moments ? (size_t)NP * am_tiles_rt(DP) * 256 : (size_t)NP * (DP / 2 + 1) * DP;
     if ((rc = e->am_sigma.alloc(nsig))) return rc;
     HIP_TRY(hipMemcpyAsync(e->am_mu.p, e->theta.p, (size_t)NP * DP * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
     HIP_TRY(hipMemsetAsync(e->am_sigma.p, 0, nsig * sizeof(double), e->stream));
@@ -1491,6 +1498,7 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
       aa.do_scale = adaptive;
       const bool do_swap = is_am && boundary && (e->t + S >= e->pp.t0);
       aa.do_swap = do_swap;
+      aa.block_moments = e->pp.block_moments != 0;
       aa.period = period;
       aa.gamma_pow = std::pow(e->pp.gamma, -(double)e->k_adapt);
       aa.sd = e->am_sd;
@@ -1508,6 +1516,7 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
         ca.N = N;
         ca.d = d;
         ca.am_sigma = e->am_sigma.p;
+        ca.tiled = e->pp.block_moments != 0;
         ca.Lk = e->Lk.p;
         ca.flags = e->flags.p;
         DISPATCH_DPAD(e->DP, launch_chol<DPAD>(ca, e->stream));
@@ -1723,6 +1732,7 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
       aa.do_scale = adaptive;
       const bool do_swap = is_am && boundary && (e->t + S >= e->pp.t0);
       aa.do_swap = do_swap;
+      aa.block_moments = e->pp.block_moments != 0;
       aa.period = period;
       aa.gamma_pow = std::pow(e->pp.gamma, -(double)e->k_adapt);
       aa.sd = e->am_sd;
@@ -1747,6 +1757,7 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
         ca.N = N;
         ca.d = d;
         ca.am_sigma = e->am_sigma.p;
+        ca.tiled = e->pp.block_moments != 0;
         ca.Lk = e->Lk.p;
         ca.flags = e->flags.p;
         DISPATCH_DPAD(DP, launch_chol<DPAD>(ca, e->stream));
@@ -2133,16 +2144,24 @@ int tda_engine_get_proposal_state(tda_engine* e, double* scaling, double* C, dou
       for (int64_t c = 0; c < N; ++c)
         for (int j = 0; j < d; ++j) am_mu[(size_t)c * d + j] = h[(size_t)c * DP + j];
     }
-    if (am_sigma) {  // unfold [s][l] = Sigma[l][(l+s) mod DP]
+    if (am_sigma) {  // dense symmetric matrices from the device storage (two layouts, see AdaptArgs)
+      const bool tiled = e->pp.block_moments != 0;
       const int NS = DP / 2 + 1;
-      std::vector<double> h((size_t)N * NS * DP);
+      const size_t per = tiled ? (size_t)am_tiles_rt(DP) * 256 : (size_t)NS * DP;
+      std::vector<double> h((size_t)N * per);
       HIP_TRY(hipMemcpy(h.data(), e->am_sigma.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
       for (int64_t c = 0; c < N; ++c) {
-        const double* f = h.data() + (size_t)c * NS * DP;
+        const double* f = h.data() + (size_t)c * per;
         for (int i = 0; i < d; ++i)
           for (int j = 0; j < d; ++j) {
-            const int sl = ((j - i) % DP + DP) % DP;
-            am_sigma[((size_t)c * d + i) * d + j] = sl <= DP / 2 ? f[(size_t)sl * DP + i] : f[(size_t)(DP - sl) * DP + j];
+            double v;
+            if (tiled) {
+              v = f[am_sigma_offset(std::max(i, j), std::min(i, j))];
+            } else {  // [s][l] = Sigma[l][(l+s) mod DP]
+              const int sl = ((j - i) % DP + DP) % DP;
+              v = sl <= DP / 2 ? f[(size_t)sl * DP + i] : f[(size_t)(DP - sl) * DP + j];
+            }
+            am_sigma[((size_t)c * d + i) * d + j] = v;
           }
       }
     }

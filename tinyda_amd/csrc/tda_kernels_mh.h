@@ -10,9 +10,9 @@
 //                                F = A theta' on fp64 MFMA (v_mfma_f64_16x16x4), observations split over
 //                                the 4 waves, A fragments streamed from L2, residual + weighted SSE fused
 //                                in the MFMA epilogue, prior, log alpha, accept, coalesced record write
-//   k_adapt     wave per chain : RecursiveSampleMoments catch-up over the S recorded states in the
-//                                reference's exact elementwise arithmetic (utils.py:113-122), symmetric half
-//                                only (circulant fold), global scaling adaptation at period boundaries
+//   k_adapt     wave per chain : RecursiveSampleMoments catch-up over the S recorded states (utils.py:113-122): the
+//                                mean recursion literally, the covariance as one rank-S update on the matrix
+//                                cores; global scaling adaptation at period boundaries
 //   k_chol      wave per chain : C <- Sigma swap, Cholesky in LDS (only at period boundaries with t >= t0)
 //
 // Chains never interact, so there is no inter-workgroup communication anywhere.
@@ -104,12 +104,14 @@ struct AdaptArgs {
   int boundary;    // (t_base + S) % period == 0
   int do_scale;    // adaptive scaling at boundary
   int do_swap;     // AM: t >= t0 at boundary -> C <- Sigma
+  int block_moments;  // AM: 0 = the reference's elementwise covariance recursion, 1 = one rank-S update per block
   int period;
   double gamma_pow;  // gamma ** -k  (proposal.py:240)
   double sd, eps;
   const double* rec_params;  // [S][N][d] states recorded by k_mh_steps
   double* am_mu;             // [NP][DPAD]
-  double* am_sigma;          // [NP][DPAD/2+1][DPAD] circulant fold: [s][l] = Sigma[l][(l+s) mod DPAD]
+  double* am_sigma;          // reference form: [NP][DPAD/2+1][DPAD] circulant fold, [s][l] = Sigma[l][(l+s) mod DPAD];
+                             // block form: [NP][am_tiles][4][64], lower 16x16 tiles in MFMA C/D layout (k_adapt_block)
   double* scaling;           // [NP]
   int32_t* acc_count;        // [NP]
   int32_t* flags;            // [NP]
@@ -725,23 +727,61 @@ __global__ void __launch_bounds__(64) k_propose(const ProposeArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // Adaptation for a block: one wave per chain.
-//   RecursiveSampleMoments.update (utils.py:113-124) for each recorded state, elementwise, unfused:
-//     mu' = (1/(t+1)) (t mu + x)
+//   RecursiveSampleMoments.update (utils.py:113-124) for each recorded state x (t = recursor.t before the update):
+//     mu'    = (1/(t+1)) (t mu + x)
 //     Sigma' = (t-1)/t Sigma + sd/t ( t mu mu^T - (t+1) mu' mu'^T + x x^T + eps I )
 //   global scaling (proposal.py:234-243).
-// Sigma is symmetric and every product commutes bitwise, so only one of (i,j)/(j,i) is carried, in a
-// circulant fold: lane l, slot s holds Sigma[l][(l+s) mod D], s = 0..D/2.  The "row" operand is the lane's
-// own value and the "column" operand a rotation read from LDS with consecutive addresses (conflict free),
-// so a step costs (D/2+1) x (3 ds_read_b64 + 10 fp64 VALU ops) instead of D x (3 broadcasts + 10 ops).
-// This file is compiled with -ffp-contract=off so the products and sums round exactly like NumPy's.
+// The bracket equals t/(t+1) (x - mu)(x - mu)^T identically, so over a block of S updates (t_1 .. t_S)
+//     Sigma_S = (t_1 - 1)/t_S Sigma_0 + sum_s w_s delta_s delta_s^T + (S sd eps / t_S) I,
+//     delta_s = x_s - mu_{s-1},   w_s = sd t_s / ((t_s + 1) t_S)
+// (the factors (t-1)/t telescope).  mu follows the reference recursion literally (bit-identical); the rank-S update
+// is a 64 x S x 64 SYRK per chain and runs on the matrix cores: rows sqrt(w_s) delta_s are staged in LDS in chunks of
+// AM_CH steps and every 16 x 16 tile on or below the diagonal accumulates 4 steps per v_mfma_f64_16x16x4_f64.
+// Against the reference's elementwise recursion this differs by rounding only -- and by less than the reference's own
+// error, whose form cancels t mu mu^T against (t+1) mu' mu'^T (1e-11 .. 1e-8 relative when |mu| >> spread).  The
+// elementwise form costs 330 non-fusable fp64 VALU operations per state and was 23 % of the pipeline (1.07 ns/eval).
+// Sigma is stored per chain as the 16 x 16 tiles on or below the diagonal in the MFMA C/D register layout
+// ([tile][r][lane] <-> row 16 ti + (lane >> 4) + 4 r, column 16 tj + (lane & 15); tile = ti (ti + 1) / 2 + tj), so its
+// read-modify-write is four coalesced 512-byte accesses per tile.
 // ------------------------------------------------------------------------------------------------
+constexpr int AM_CH = 20;  // steps per LDS chunk (multiple of 4)
+
+template <int DPAD>
+__host__ __device__ constexpr int am_tile_rows() {
+  return DPAD >= 16 ? DPAD / 16 : 1;
+}
+template <int DPAD>
+__host__ __device__ constexpr int am_tiles() {
+  return am_tile_rows<DPAD>() * (am_tile_rows<DPAD>() + 1) / 2;
+}
+// offset (in doubles, within one chain's block of am_tiles * 256) of Sigma[i][j], i >= j
+__host__ __device__ inline int am_sigma_offset(int i, int j) {
+  const int ti = i >> 4, tj = j >> 4, ri = i & 15, cj = j & 15;
+  return (((ti * (ti + 1) / 2 + tj) * 4 + (ri >> 2)) * 64) + (ri & 3) * 16 + cj;
+}
+
+// global scaling adaptation at a period boundary (proposal.py:234-243) and the reset of the acceptance counter
+__device__ __forceinline__ void adapt_scaling(const AdaptArgs& a, int64_t c, int lane) {
+  if (!a.boundary) return;
+  if (a.do_scale && lane == 0) {
+    int hits = 0;
+    if (a.ring) {
+      for (int i = 1; i <= a.period; ++i) hits += a.ring[(size_t)((a.ring_hi - i) % a.ring_P) * a.NP + c];
+    } else {
+      hits = a.acc_count[c];
+    }
+    const double rate = (double)hits / (double)a.period;  // np.mean(accepted[-period:])
+    a.scaling[c] = exp(log(a.scaling[c]) + a.gamma_pow * (rate - 0.24));
+  }
+  if (lane == 0) a.acc_count[c] = 0;
+}
+
 template <int DPAD>
 __global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
   constexpr int NS = DPAD / 2 + 1;
   // x, mu, mu' each stored twice ([j] and [j + DPAD]) so that the rotated operand of slot s is a plain ds_read_b64
-  // at immediate offset s from the lane's own base: consecutive lanes hit consecutive banks (conflict free) and no
-  // per-slot address arithmetic is needed
-  __shared__ __attribute__((aligned(16))) double s_vec[3 * 2 * DPAD];
+  // at immediate offset s from the lane's own base: consecutive lanes hit consecutive banks (conflict free)
+  __shared__ __attribute__((aligned(16))) double s_vec[6 * DPAD];
   const int lane = threadIdx.x;
   const int64_t c = blockIdx.x;
   if (c >= a.N) return;
@@ -788,18 +828,79 @@ __global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
     }
   }
 
-  if (!a.boundary) return;
-  if (a.do_scale && lane == 0) {
-    int hits = 0;
-    if (a.ring) {
-      for (int i = 1; i <= a.period; ++i) hits += a.ring[(size_t)((a.ring_hi - i) % a.ring_P) * a.NP + c];
-    } else {
-      hits = a.acc_count[c];
+  adapt_scaling(a, c, lane);
+}
+
+// AdaptiveMetropolis(block_moments=True): the covariance as one rank-S update per block (see above)
+template <int DPAD>
+__global__ void __launch_bounds__(64) k_adapt_block(const AdaptArgs a) {
+  constexpr int T = am_tile_rows<DPAD>();
+  constexpr int NTL = am_tiles<DPAD>();
+  constexpr int W = 16 * T;   // staged row width (>= DPAD)
+  constexpr int RS = W + 2;   // row stride in LDS
+  __shared__ __attribute__((aligned(16))) double s_d[AM_CH * RS];
+  const int lane = threadIdx.x;
+  const int64_t c = blockIdx.x;
+  if (c >= a.N) return;
+  const bool lj = lane < a.d;
+  const int lc = lane & 15, hi = lane >> 4;
+
+  if (a.do_am) {
+    double4_t acc[NTL];
+#pragma unroll
+    for (int i = 0; i < NTL; ++i) acc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
+    double mu = lane < DPAD ? a.am_mu[c * DPAD + lane] : 0.0;
+    const double tS = (double)(a.t_base + a.S);
+    for (int s0 = 0; s0 < a.S; s0 += AM_CH) {
+      const int ns = a.S - s0 < AM_CH ? a.S - s0 : AM_CH;
+      double xs[AM_CH];  // the chunk's states, all requested before the sequential recursion consumes them
+#pragma unroll
+      for (int i = 0; i < AM_CH; ++i)
+        xs[i] = (lj && i < ns) ? a.rec_params[((size_t)(s0 + i) * a.N + c) * a.d + lane] : 0.0;
+#pragma unroll
+      for (int i = 0; i < AM_CH; ++i) {
+        double dv = 0.0;
+        if (i < ns) {
+          const double t = (double)(a.t_base + s0 + i + 1);  // recursor.t before this update
+          const double w = a.sd * t / ((t + 1.0) * tS);
+          dv = sqrt(w) * (xs[i] - mu);
+          mu = (1.0 / (t + 1.0)) * (t * mu + xs[i]);
+        }
+        if (lane < W) s_d[i * RS + lane] = dv;
+      }
+      __syncthreads();
+      const int nq = (ns + 3) >> 2;
+      for (int kq = 0; kq < nq; ++kq) {
+        double v[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) v[t] = s_d[(4 * kq + hi) * RS + 16 * t + lc];
+#pragma unroll
+        for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+          for (int tj = 0; tj <= ti; ++tj) acc[ti * (ti + 1) / 2 + tj] = mfma_f64(v[ti], v[tj], acc[ti * (ti + 1) / 2 + tj]);
+      }
+      __syncthreads();
     }
-    const double rate = (double)hits / (double)a.period;  // np.mean(accepted[-period:])
-    a.scaling[c] = exp(log(a.scaling[c]) + a.gamma_pow * (rate - 0.24));
+    const double P = (double)a.t_base / tS;
+    const double e = (double)a.S * a.sd * a.eps / tS;
+    double* __restrict__ sig = a.am_sigma + (size_t)c * NTL * 256;
+#pragma unroll
+    for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+      for (int tj = 0; tj <= ti; ++tj) {
+        const int idx = ti * (ti + 1) / 2 + tj;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int off = (idx * 4 + r) * 64 + lane;
+          double v = P * sig[off] + acc[idx][r];
+          if (ti == tj && hi + 4 * r == lc && 16 * ti + lc < a.d) v += e;
+          sig[off] = v;
+        }
+      }
+    if (lane < DPAD) a.am_mu[c * DPAD + lane] = mu;
   }
-  if (lane == 0) a.acc_count[c] = 0;
+
+  adapt_scaling(a, c, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -809,7 +910,8 @@ __global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
 struct CholArgs {
   int64_t N;
   int d;
-  const double* am_sigma;  // folded [NP][DPAD/2+1][DPAD]
+  const double* am_sigma;  // layout of the adapt kernel in use (see AdaptArgs)
+  int tiled;               // 1: tile storage of k_adapt_block, 0: circulant fold of k_adapt
   double* Lk;              // [NP][DPAD][DPAD] k-major
   int32_t* flags;
 };
@@ -827,6 +929,7 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {  // wave-unifo
 // the same sequence as a left-looking dot product.
 template <int DPAD>
 __global__ void __launch_bounds__(64) k_chol(const CholArgs a) {
+  constexpr int NTL = am_tiles<DPAD>();
   constexpr int NS = DPAD / 2 + 1;
   const int lane = threadIdx.x;
   const int64_t c = blockIdx.x;
@@ -834,14 +937,18 @@ __global__ void __launch_bounds__(64) k_chol(const CholArgs a) {
   const bool lj = lane < a.d;
   const int li = lane < DPAD ? lane : DPAD - 1;
   double A[DPAD];
-  // row `lane` of Sigma (columns j <= lane) from the circulant fold; padded rows / columns = identity
+  // row `lane` of Sigma (columns j <= lane); padded rows / columns = identity
 #pragma unroll
   for (int j = 0; j < DPAD; ++j) {
     double v = (j == li) ? 1.0 : 0.0;
     if (lj && j < a.d && j <= li) {
-      const int sl = li - j;
-      v = sl <= DPAD / 2 ? a.am_sigma[((size_t)c * NS + sl) * DPAD + j]
-                         : a.am_sigma[((size_t)c * NS + (DPAD - sl)) * DPAD + li];
+      if (a.tiled) {
+        v = a.am_sigma[(size_t)c * NTL * 256 + am_sigma_offset(li, j)];
+      } else {
+        const int sl = li - j;
+        v = sl <= DPAD / 2 ? a.am_sigma[((size_t)c * NS + sl) * DPAD + j]
+                           : a.am_sigma[((size_t)c * NS + (DPAD - sl)) * DPAD + li];
+      }
     }
     A[j] = v;
   }

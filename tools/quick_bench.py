@@ -23,7 +23,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "dense":  # C2b: dense noise covariance 
     e.set_level(0, A, y, 2, Lc @ Lc.T)
 else:
     e.set_level(0, A, y, 0, 0.01)
-e.set_proposal(2, 1e-4 * np.eye(d), t0=100, period=100)
+e.set_proposal(2, 1e-4 * np.eye(d), t0=100, period=100, block_moments="block" in sys.argv)
 e.init(None)
 params = torch.empty((T, N, d), dtype=torch.float64, device="cuda")
 stats = torch.empty((T, N, 3), dtype=torch.float64, device="cuda")
