@@ -657,59 +657,84 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
 // ------------------------------------------------------------------------------------------------
 // Proposal increments for a block of steps: one wave per chain.
 //   np.random.multivariate_normal(0, C) (proposal.py:249-251) as L z with L = chol(C), z from Philox.
-// Lane j owns row j of L in registers; Box-Muller pairs of 64/(DPAD/2) steps are generated per pass.
-// inc_j = sum_k fma(L[j][k], z[k]) in ascending k.
+// INC[S][d] = Z[S][d] L^T is a per-chain GEMM and runs on the matrix cores, 16 steps at a time: lane (lc, hi) owns
+// step lc of the group and draws the Box-Muller pair p = 4 q + hi (dims 2p, 2p + 1, the RNG contract) for
+// q = 0 .. d/8 - 1; a 16 x d tile in LDS turns pairs into MFMA A fragments (z[step lc][4 kk + hi]); L sits in
+// registers as B fragments (L[16 tj + lc][4 kk + hi]) for the whole block.  The normals are the bound (~240 VALU
+// instructions per pair); the products ride on the otherwise idle matrix pipe, and two waves per SIMD overlap one
+// wave's MFMAs with the other's RNG.  The earlier form (lane j = row j of L, 64 broadcast FMAs per step from LDS,
+// one wave per SIMD) spent 0.73 ns/eval.
 // ------------------------------------------------------------------------------------------------
+// out of line: inlined eight times into the unrolled pair loop, the polynomial constants of log / sincospi push the
+// kernel past the 256 registers that two waves per SIMD allow
+__device__ __attribute__((noinline)) double2 normal_pair_call(uint64_t seed, uint32_t chain, uint32_t step, uint32_t p) {
+  double z0, z1;
+  normal_pair(seed, chain, step, STREAM_PROPOSAL, p, z0, z1);
+  return double2{z0, z1};
+}
+
 template <int DPAD>
-__global__ void __launch_bounds__(64) k_propose(const ProposeArgs a) {
-  constexpr int HP = DPAD / 2;     // Box-Muller pairs per step
-  constexpr int SPP = 64 / HP;     // steps per pass
-  __shared__ double s_z[SPP * DPAD];
+__global__ void __launch_bounds__(64, 2) k_propose(const ProposeArgs a) {
+  constexpr int KK = DPAD / 4;                  // k-steps of the 16x16x4 MFMA
+  constexpr int QN = DPAD / 8;                  // Box-Muller pairs per lane and 16-step group
+  constexpr int TJ = DPAD >= 16 ? DPAD / 16 : 1;  // 16-column output tiles
+  constexpr int RS = DPAD + 2;
+  __shared__ __attribute__((aligned(16))) double s_z[16 * RS];
   const int lane = threadIdx.x;
+  const int lc = lane & 15, hi = lane >> 4;
   const int64_t c = blockIdx.x;
   const bool real_chain = c < a.N;
   const uint32_t gc = (uint32_t)(a.chain_offset + c);
 
-  double Lrow[DPAD];
+  double Lf[TJ][KK];  // B fragments: B[k = hi][j = lc] of tile tj, k-step kk  <->  L[16 tj + lc][4 kk + hi]
 #pragma unroll
-  for (int k = 0; k < DPAD; ++k)
-    Lrow[k] = lane < DPAD ? a.Lk[(size_t)c * a.L_stride + (size_t)k * DPAD + lane] : 0.0;
+  for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+      Lf[tj][kk] = 16 * tj + lc < DPAD ? a.Lk[(size_t)c * a.L_stride + (size_t)(4 * kk + hi) * DPAD + 16 * tj + lc] : 0.0;
 
-  const int sp = lane / HP, p = lane % HP;
-  for (int s0 = 0; s0 < a.S; s0 += SPP) {
-    const int s = s0 + sp;
-    double z0 = 0.0, z1 = 0.0;
-    if (s < a.S && real_chain && 2 * p < a.d) {
-      if (a.z_replay) {
-        const size_t o = ((size_t)s * a.N + c) * a.d + 2 * p;
-        z0 = a.z_replay[o];
-        z1 = (2 * p + 1 < a.d) ? a.z_replay[o + 1] : 0.0;
-      } else {
-        normal_pair(a.seed, gc, (uint32_t)(a.step0 + s), STREAM_PROPOSAL, (uint32_t)p, z0, z1);
-        if (2 * p + 1 >= a.d) z1 = 0.0;
+  for (int s0 = 0; s0 < a.S; s0 += 16) {
+    const int s = s0 + lc;  // this lane's step
+    double4_t acc[TJ];
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) acc[tj] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+      const int p = 4 * q + hi;  // pair index: dims 2p, 2p + 1
+      double z0 = 0.0, z1 = 0.0;
+      if (s < a.S && real_chain && 2 * p < a.d) {
+        if (a.z_replay) {
+          const size_t o = ((size_t)s * a.N + c) * a.d + 2 * p;
+          z0 = a.z_replay[o];
+          z1 = (2 * p + 1 < a.d) ? a.z_replay[o + 1] : 0.0;
+        } else {
+          const double2 zz = normal_pair_call(a.seed, gc, (uint32_t)(a.step0 + s), (uint32_t)p);
+          z0 = zz.x;
+          z1 = (2 * p + 1 >= a.d) ? 0.0 : zz.y;
+        }
+        if (a.z_export) {
+          const size_t o = ((size_t)s * a.N + c) * a.d + 2 * p;
+          a.z_export[o] = z0;
+          if (2 * p + 1 < a.d) a.z_export[o + 1] = z1;
+        }
       }
-      if (a.z_export) {
-        const size_t o = ((size_t)s * a.N + c) * a.d + 2 * p;
-        a.z_export[o] = z0;
-        if (2 * p + 1 < a.d) a.z_export[o + 1] = z1;
+      *reinterpret_cast<double2*>(&s_z[lc * RS + 2 * p]) = double2{z0, z1};
+      __syncthreads();
+      const double za = s_z[lc * RS + 8 * q + hi], zb = s_z[lc * RS + 8 * q + 4 + hi];  // k-steps 2q, 2q + 1
+      // all tiles with za, then all with zb: back-to-back MFMAs never wait on their own accumulator
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) acc[tj] = mfma_f64(za, Lf[tj][2 * q], acc[tj]);
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) acc[tj] = mfma_f64(zb, Lf[tj][2 * q + 1], acc[tj]);
+    }
+    // D layout: step hi + 4 r of the group, column 16 tj + lc
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int so = s0 + hi + 4 * r;
+        if (so < a.S && 16 * tj + lc < DPAD) a.inc[((size_t)so * a.NP + c) * DPAD + 16 * tj + lc] = acc[tj][r];
       }
-    }
-    s_z[sp * DPAD + 2 * p] = z0;
-    s_z[sp * DPAD + 2 * p + 1] = z1;
-    __syncthreads();
-    double accv[SPP];
-#pragma unroll
-    for (int i = 0; i < SPP; ++i) accv[i] = 0.0;
-#pragma unroll
-    for (int k = 0; k < DPAD; ++k) {
-#pragma unroll
-      for (int i = 0; i < SPP; ++i) accv[i] = fma(Lrow[k], s_z[i * DPAD + k], accv[i]);
-    }
-    if (lane < DPAD) {
-#pragma unroll
-      for (int i = 0; i < SPP; ++i)
-        if (s0 + i < a.S) a.inc[((size_t)(s0 + i) * a.NP + c) * DPAD + lane] = accv[i];
-    }
     __syncthreads();
   }
   // accept uniforms (chain.py:112)
@@ -839,6 +864,7 @@ __global__ void __launch_bounds__(64) k_adapt_block(const AdaptArgs a) {
   constexpr int W = 16 * T;   // staged row width (>= DPAD)
   constexpr int RS = W + 2;   // row stride in LDS
   __shared__ __attribute__((aligned(16))) double s_d[AM_CH * RS];
+  __shared__ double s_coef[3 * AM_CH];
   const int lane = threadIdx.x;
   const int64_t c = blockIdx.x;
   if (c >= a.N) return;
@@ -857,14 +883,23 @@ __global__ void __launch_bounds__(64) k_adapt_block(const AdaptArgs a) {
 #pragma unroll
       for (int i = 0; i < AM_CH; ++i)
         xs[i] = (lj && i < ns) ? a.rec_params[((size_t)(s0 + i) * a.N + c) * a.d + lane] : 0.0;
+      // the step coefficients depend on t only: lane i works out those of step s0 + i (two divisions and a square
+      // root) while the loads fly, so that the sequential recursion below is five VALU operations per state
+      {
+        const double t = (double)(a.t_base + s0 + lane + 1);  // recursor.t before the update of step s0 + lane
+        if (lane < AM_CH) {
+          s_coef[3 * lane + 0] = sqrt(a.sd * t / ((t + 1.0) * tS));
+          s_coef[3 * lane + 1] = 1.0 / (t + 1.0);
+          s_coef[3 * lane + 2] = t;
+        }
+      }
+      __syncthreads();
 #pragma unroll
       for (int i = 0; i < AM_CH; ++i) {
         double dv = 0.0;
         if (i < ns) {
-          const double t = (double)(a.t_base + s0 + i + 1);  // recursor.t before this update
-          const double w = a.sd * t / ((t + 1.0) * tS);
-          dv = sqrt(w) * (xs[i] - mu);
-          mu = (1.0 / (t + 1.0)) * (t * mu + xs[i]);
+          dv = s_coef[3 * i + 0] * (xs[i] - mu);
+          mu = s_coef[3 * i + 1] * (s_coef[3 * i + 2] * mu + xs[i]);
         }
         if (lane < W) s_d[i * RS + lane] = dv;
       }

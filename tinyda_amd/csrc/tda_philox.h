@@ -25,8 +25,11 @@ __host__ __device__ inline u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = mulhi32(M0, c.x), lo0 = M0 * c.x;
-    const uint32_t hi1 = mulhi32(M1, c.z), lo1 = M1 * c.z;
+    // one 32 x 32 -> 64 product per lane (v_mad_u64_u32 on the device) instead of a mul_hi / mul_lo pair: the integer
+    // multiplies run at quarter rate and are half of the generator's cost
+    const uint64_t p0 = (uint64_t)M0 * (uint64_t)c.x, p1 = (uint64_t)M1 * (uint64_t)c.z;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     u32x4 n;
     n.x = hi1 ^ c.y ^ k0;
     n.y = lo1;
