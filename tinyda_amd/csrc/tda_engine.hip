@@ -177,6 +177,10 @@ struct tda_engine {
 
   // block buffers
   DevBuf<double> inc, ublk, lublk, rec_params, rec_stats;
+  // split proposal path (Philox mode): normals of block b+1 are drawn on a second stream under block b's steps
+  hipStream_t rng_stream = nullptr;
+  hipEvent_t ev_rng[2] = {nullptr, nullptr}, ev_apply[2] = {nullptr, nullptr}, ev_steps[2] = {nullptr, nullptr};
+  DevBuf<double> zfrag[2], ublk2[2], lublk2[2];
   DevBuf<uint8_t> rec_acc;
 
   // multi-level state (n_levels > 1)
@@ -265,6 +269,15 @@ void launch_steps(const StepArgs& a, int64_t tiles, size_t lds, hipStream_t st) 
 template <int DPAD>
 void launch_propose(const ProposeArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_propose<DPAD>, dim3((unsigned)a.NP), dim3(64), 0, st, a);
+}
+template <int DPAD>
+void launch_rng(const RngArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_rng<DPAD>, dim3((unsigned)a.NP, (unsigned)((a.S + 15) / 16)), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(k_rng_uniforms, dim3((unsigned)(((int64_t)a.S * a.NP + 255) / 256)), dim3(256), 0, st, a);
+}
+template <int DPAD>
+void launch_apply(const ApplyArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_apply<DPAD>, dim3((unsigned)a.NP), dim3(64), 0, st, a);
 }
 template <int DPAD>
 void launch_adapt(const AdaptArgs& a, hipStream_t st) {
@@ -449,6 +462,15 @@ void tda_engine_destroy(tda_engine* e) {
   for (auto& t : e->timed) {
     (void)hipEventDestroy(t.a);
     (void)hipEventDestroy(t.b);
+  }
+  if (e->rng_stream) {
+    (void)hipStreamSynchronize(e->rng_stream);
+    (void)hipStreamDestroy(e->rng_stream);
+    for (int i = 0; i < 2; ++i) {
+      (void)hipEventDestroy(e->ev_rng[i]);
+      (void)hipEventDestroy(e->ev_apply[i]);
+      (void)hipEventDestroy(e->ev_steps[i]);
+    }
   }
   if (e->own_stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -1429,12 +1451,95 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     e->timed.clear();
   }
 
-  int64_t done = 0;
+  // Philox mode: the normals and uniforms of a block do not depend on the chains, so block b+1's are drawn on a second
+  // stream while block b's k_mh_steps runs (k_rng fits into the registers the step kernel leaves free); only
+  // INC = Z L^T (k_apply) stays on the critical path behind the Cholesky swap.  Replay mode keeps the fused k_propose.
+  static const bool split_ok = !(getenv("TINYDA_SPLIT_PROPOSE") && atoi(getenv("TINYDA_SPLIT_PROPOSE")) == 0);
+  const bool split = split_ok && !e->rep_steps;
+  if (split && !e->rng_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&e->rng_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      HIP_TRY(hipEventCreateWithFlags(&e->ev_rng[i], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&e->ev_apply[i], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&e->ev_steps[i], hipEventDisableTiming));
+      int rc;
+      if ((rc = e->zfrag[i].alloc((size_t)((e->SMAX + 15) / 16 * 16) * NP * e->DP))) return rc;
+      if ((rc = e->ublk2[i].alloc((size_t)e->SMAX * NP))) return rc;
+      if ((rc = e->lublk2[i].alloc((size_t)e->SMAX * NP))) return rc;
+    }
+  }
+  auto block_len = [&](int64_t t_now, int64_t left) {
+    int64_t S = std::min<int64_t>(left, e->SMAX);
+    if (periodic) S = std::min<int64_t>(S, period - (t_now % period));
+    return S;
+  };
+  // draw block `blk` (steps t0 .. t0 + S - 1, the exp_off-th exported step) into buffer blk & 1 on the rng stream
+  auto enqueue_rng = [&](int64_t blk, int64_t t0, int64_t S, int64_t exp_off) -> int {
+    const int b = (int)(blk & 1);
+    RngArgs ra{};
+    ra.N = N;
+    ra.NP = NP;
+    ra.chain_offset = e->cfg.chain_offset;
+    ra.d = d;
+    ra.S = (int)S;
+    ra.step0 = t0;
+    ra.seed = e->cfg.seed;
+    ra.zf = e->zfrag[b].p;
+    ra.u = e->ublk2[b].p;
+    ra.logu = e->lublk2[b].p;
+    if (e->exp_steps) {
+      ra.z_export = (e->exp_dev ? e->z_exp : e->z_exp_d.p) + (size_t)exp_off * N * d;
+      ra.u_export = (e->exp_dev ? e->u_exp : e->u_exp_d.p) + (size_t)exp_off * N;
+    }
+    if (blk >= 2) {  // the buffers were last read by block blk - 2: its k_apply (fragments) and k_mh_steps (uniforms)
+      HIP_TRY(hipStreamWaitEvent(e->rng_stream, e->ev_apply[b], 0));
+      HIP_TRY(hipStreamWaitEvent(e->rng_stream, e->ev_steps[b], 0));
+    }
+    DISPATCH_DPAD(e->DP, launch_rng<DPAD>(ra, e->rng_stream));
+    HIP_TRY(hipEventRecord(e->ev_rng[b], e->rng_stream));
+    return TDA_OK;
+  };
+
+  int64_t done = 0, blk = 0;
+  if (split && n_iter > 0) {
+    // everything queued on the main stream so far (init, earlier run() calls) precedes the first draw
+    HIP_TRY(hipEventRecord(e->ev_steps[0], e->stream));
+    HIP_TRY(hipStreamWaitEvent(e->rng_stream, e->ev_steps[0], 0));
+    int rc = enqueue_rng(0, e->t, block_len(e->t, n_iter), e->exp_pos);
+    if (rc) return rc;
+  }
   while (done < n_iter) {
-    int64_t S = std::min<int64_t>(n_iter - done, e->SMAX);
-    if (periodic) S = std::min<int64_t>(S, period - (e->t % period));
+    const int64_t S = block_len(e->t, n_iter - done);
+    const double* u_blk = e->ublk.p;
+    const double* lu_blk = e->lublk.p;
 
     // ---- proposal increments + uniforms ----
+    if (split) {
+      const int b = (int)(blk & 1);
+      HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_rng[b], 0));
+      ApplyArgs ap{};
+      ap.NP = NP;
+      ap.S = (int)S;
+      ap.Lk = e->Lk.p;
+      ap.L_stride = e->L_shared ? 0 : (int64_t)e->DP * e->DP;
+      ap.zf = e->zfrag[b].p;
+      ap.inc = e->inc.p;
+      {
+        ScopedTimer tm(e, 0);
+        DISPATCH_DPAD(e->DP, launch_apply<DPAD>(ap, e->stream));
+      }
+      HIP_TRY(hipEventRecord(e->ev_apply[b], e->stream));
+      u_blk = e->ublk2[b].p;
+      lu_blk = e->lublk2[b].p;
+      if (done + S < n_iter) {
+        // next block's draws go under THIS block's steps: released by this block's k_apply (the host runs ahead of the
+        // GPU; without the wait the draws would start as soon as block blk - 1's steps end, i.e. next to its k_adapt,
+        // which is itself bound by the VALU)
+        HIP_TRY(hipStreamWaitEvent(e->rng_stream, e->ev_apply[b], 0));
+        int rc = enqueue_rng(blk + 1, e->t + S, block_len(e->t + S, n_iter - done - S), e->exp_pos + S);
+        if (rc) return rc;
+      }
+    } else {
     ProposeArgs pa{};
     pa.N = N;
     pa.NP = NP;
@@ -1460,6 +1565,7 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
       ScopedTimer tm(e, 0);
       DISPATCH_DPAD(e->DP, launch_propose<DPAD>(pa, e->stream));
     }
+    }
 
     // ---- fused MH steps ----
     StepArgs sa{};
@@ -1473,8 +1579,8 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     sa.scaling = e->scaling.p;
     sa.acc_count = e->acc_count.p;
     sa.inc = e->inc.p;
-    sa.u = e->ublk.p;
-    sa.logu = e->lublk.p;
+    sa.u = u_blk;
+    sa.logu = lu_blk;
     // records go straight into caller memory when it is device memory; AM needs the states either way
     sa.rec_params = p_dev ? o_params + (size_t)done * N * d : ((o_params || is_am) ? e->rec_params.p : nullptr);
     sa.rec_stats = s_dev ? o_stats + (size_t)done * N * 3 : (o_stats ? e->rec_stats.p : nullptr);
@@ -1483,6 +1589,7 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
       ScopedTimer tm(e, 1);
       DISPATCH_DPAD(e->DP, launch_steps<DPAD>(sa, NP / 16, lds, e->stream));
     }
+    if (split) HIP_TRY(hipEventRecord(e->ev_steps[blk & 1], e->stream));
 
     // ---- adaptation (proposal.py:228-245, :502-512) ----
     const bool boundary = periodic && ((e->t + S) % period == 0);
@@ -1545,6 +1652,7 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
 
     e->t += S;
     done += S;
+    blk += 1;
     if (e->rep_steps) e->rep_pos += S;
     if (e->exp_steps) e->exp_pos += S;
   }

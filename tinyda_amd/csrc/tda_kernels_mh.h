@@ -394,6 +394,15 @@ __device__ __forceinline__ double dense_quadform(const double* __restrict__ Ppk,
   return s;
 }
 
+// u < exp(delta) (chain.py:112), out of line: it is only needed within 1e-9 of the knife edge, and inlining exp's
+// polynomial costs the hot loop 16 registers -- with it the 8-wave tile allocates 2 x 240 of a SIMD's 512 registers,
+// without it 2 x 224, which leaves room for a 64-register kernel (k_rng) to share the SIMD
+__device__ __attribute__((noinline)) bool accept_exact(double u, double delta, double post_n) {
+  double alpha = exp(delta);
+  if (post_n != post_n) alpha = 0.0;
+  return u < alpha;
+}
+
 template <int DPAD>
 __host__ __device__ constexpr int steps_lds_doubles(int m_pad, bool diag, int prior_rows) {
   return 16 * (DPAD + 2) + 64 + 64 + m_pad + (diag ? m_pad : 0) + prior_rows;
@@ -427,6 +436,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
   double* s_py = s_w + (diag ? a.lv.m_pad : 0);
   double* s_R = s_py + (prior_dense ? a.pr.ncb * 16 : 0);
 
+  // the step kernel is the critical path: kernels that share its SIMDs (k_rng on the second stream) only get the
+  // issue slots it leaves empty
+  __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -607,9 +619,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
       if (has_logu && (fabs(lu - delta) > 1e-9 || delta != delta)) {
         acc = (post_n == post_n) && (lu < delta);
       } else {
-        double alpha = exp(delta);
-        if (post_n != post_n) alpha = 0.0;
-        acc = u < alpha;
+        acc = accept_exact(u, delta, post_n);
       }
     }
     if (acc) {
@@ -747,6 +757,127 @@ __global__ void __launch_bounds__(64, 2) k_propose(const ProposeArgs a) {
     }
     a.u[(size_t)s * a.NP + c] = u;
     if (a.logu) a.logu[(size_t)s * a.NP + c] = log(u);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same work split in two, for runs on the engine's own Philox stream:
+//   k_rng    the normals of a block (state independent, so they can be drawn while the PREVIOUS block's k_mh_steps
+//            runs: at 62 registers this kernel shares the SIMDs with the step kernel's 2 x 224 and uses the VALU slots
+//            the matrix phase leaves idle -- tools/overlap_probe.hip: 0.10 ms alone, 0 ms extra next to the steps),
+//            stored as the MFMA A fragments k_apply consumes: Zf[group][chain][kk][lane], 512-byte rows;
+//            also the accept uniforms and their logs
+//   k_apply  INC = Z L^T for one chain per wave (after the Cholesky swap of the block boundary)
+// ------------------------------------------------------------------------------------------------
+struct RngArgs {
+  int64_t N, NP;
+  int64_t chain_offset;
+  int d;
+  int S;
+  int64_t step0;
+  uint64_t seed;
+  double* zf;        // [groups][NP][DPAD/4][64]
+  double* u;         // [S][NP]
+  double* logu;      // [S][NP]
+  double* z_export;  // [S][N][d] (may be null)
+  double* u_export;
+};
+
+template <int DPAD>
+__global__ void __launch_bounds__(64, 8) k_rng(const RngArgs a) {
+  constexpr int KK = DPAD / 4, QN = DPAD / 8;
+  const int lane = threadIdx.x, lc = lane & 15, hi = lane >> 4;
+  const int64_t c = blockIdx.x;
+  const int g = blockIdx.y;
+  const int s = g * 16 + lc;
+  const bool real_chain = c < a.N;
+  const uint32_t gc = (uint32_t)(a.chain_offset + c);
+  double* __restrict__ dst = a.zf + ((size_t)g * a.NP + c) * KK * 64;
+#pragma unroll 1
+  for (int q = 0; q < QN; ++q) {
+    const int p = 4 * q + hi;  // pair index: dims 2p, 2p + 1
+    double z0 = 0.0, z1 = 0.0;
+    if (s < a.S && real_chain && 2 * p < a.d) {
+      normal_pair(a.seed, gc, (uint32_t)(a.step0 + s), STREAM_PROPOSAL, (uint32_t)p, z0, z1);
+      if (2 * p + 1 >= a.d) z1 = 0.0;
+      if (a.z_export) {
+        const size_t o = ((size_t)s * a.N + c) * a.d + 2 * p;
+        a.z_export[o] = z0;
+        if (2 * p + 1 < a.d) a.z_export[o + 1] = z1;
+      }
+    }
+    // dim 2p = 4 kk + h with kk = 2q + (hi >> 1), h = 2 (hi & 1): fragment lane lc + 16 h (and + 16 for dim 2p + 1)
+    const int kk = 2 * q + (hi >> 1), h = 2 * (hi & 1);
+    dst[kk * 64 + lc + 16 * h] = z0;
+    dst[kk * 64 + lc + 16 * h + 16] = z1;
+  }
+}
+
+// accept uniforms of a block (chain.py:112) and their logs: one thread per (step, chain)
+__global__ void __launch_bounds__(256, 2) k_rng_uniforms(const RngArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)a.S * a.NP) return;
+  const int64_t s = i / a.NP, c = i % a.NP;
+  double u = 0.5;
+  if (c < a.N) {
+    u = accept_uniform(a.seed, (uint32_t)(a.chain_offset + c), (uint32_t)(a.step0 + s), 0u);
+    if (a.u_export) a.u_export[(size_t)s * a.N + c] = u;
+  }
+  a.u[i] = u;
+  a.logu[i] = log(u);
+}
+
+struct ApplyArgs {
+  int64_t NP;
+  int S;
+  const double* Lk;   // [NP or 1][DPAD][DPAD] k-major
+  int64_t L_stride;
+  const double* zf;   // [groups][NP][DPAD/4][64]
+  double* inc;        // [S][NP][DPAD]
+};
+
+template <int DPAD>
+__global__ void __launch_bounds__(64, 2) k_apply(const ApplyArgs a) {
+  constexpr int KK = DPAD / 4;
+  constexpr int TJ = DPAD >= 16 ? DPAD / 16 : 1;
+  const int lane = threadIdx.x, lc = lane & 15, hi = lane >> 4;
+  const int64_t c = blockIdx.x;
+  double Lf[TJ][KK];  // B fragments, see k_propose
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+      Lf[tj][kk] = 16 * tj + lc < DPAD ? a.Lk[(size_t)c * a.L_stride + (size_t)(4 * kk + hi) * DPAD + 16 * tj + lc] : 0.0;
+  const int ng = (a.S + 15) / 16;
+  double zf[KK], zn[KK];
+  {
+    const double* __restrict__ src = a.zf + (size_t)c * KK * 64 + lane;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) zf[kk] = src[kk * 64];
+  }
+  for (int g = 0; g < ng; ++g) {
+    {  // next group's fragments fly during this group's MFMAs (clamped: the last group re-reads itself)
+      const int gn = g + 1 < ng ? g + 1 : g;
+      const double* __restrict__ src = a.zf + ((size_t)gn * a.NP + c) * KK * 64 + lane;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) zn[kk] = src[kk * 64];
+    }
+    double4_t acc[TJ];
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) acc[tj] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) acc[tj] = mfma_f64(zf[kk], Lf[tj][kk], acc[tj]);
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int so = g * 16 + hi + 4 * r;
+        if (so < a.S && 16 * tj + lc < DPAD) a.inc[((size_t)so * a.NP + c) * DPAD + 16 * tj + lc] = acc[tj][r];
+      }
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) zf[kk] = zn[kk];
   }
 }
 

@@ -283,14 +283,6 @@ __device__ __forceinline__ double pick_frag(const double (&v)[KS], int w) {
   }
 }
 
-// u < exp(delta) (chain.py:112), out of line: it is only needed within 1e-9 of the knife edge and inlining exp's
-// polynomial costs the hot loop 16 registers
-__device__ __attribute__((noinline)) bool accept_exact(double u, double delta, double post_n) {
-  double alpha = exp(delta);
-  if (post_n != post_n) alpha = 0.0;
-  return u < alpha;
-}
-
 template <int DPAD>
 __host__ __device__ constexpr int steps_frag_lds_doubles(int m_pad, bool diag) {
   return 2 * 16 * 8 + 2 * 2 * 16 + 2 * DPAD + 2 * 64 * (DPAD / 4 + 2) + m_pad + (diag ? m_pad : 0);
