@@ -1184,8 +1184,7 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
     }
     // RecursiveSampleMoments(mu0 = theta0, sigma0 = 0) (proposal.py:495-500)
     if ((rc = e->am_mu.alloc((size_t)NP * DP))) return rc;
-    // circulant fold (reference-form recursion) or lower 16x16 tiles in MFMA C/D layout (block form), see AdaptArgs
-    const size_t nsig = e->pp.block_moments ? (size_t)NP * am_tiles_rt(DP) * 256 : (size_t)NP * (DP / 2 + 1) * DP;
+    const size_t nsig = (size_t)NP * am_tiles_rt(DP) * 256;  // lower 16x16 tiles in MFMA C/D layout (k_adapt)
     if ((rc = e->am_sigma.alloc(nsig))) return rc;
     HIP_TRY(hipMemcpyAsync(e->am_mu.p, e->theta.p, (size_t)NP * DP * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
     HIP_TRY(hipMemsetAsync(e->am_sigma.p, 0, nsig * sizeof(double), e->stream));
@@ -1623,7 +1622,6 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
         ca.N = N;
         ca.d = d;
         ca.am_sigma = e->am_sigma.p;
-        ca.tiled = e->pp.block_moments != 0;
         ca.Lk = e->Lk.p;
         ca.flags = e->flags.p;
         DISPATCH_DPAD(e->DP, launch_chol<DPAD>(ca, e->stream));
@@ -1865,7 +1863,6 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
         ca.N = N;
         ca.d = d;
         ca.am_sigma = e->am_sigma.p;
-        ca.tiled = e->pp.block_moments != 0;
         ca.Lk = e->Lk.p;
         ca.flags = e->flags.p;
         DISPATCH_DPAD(DP, launch_chol<DPAD>(ca, e->stream));
@@ -2252,25 +2249,15 @@ int tda_engine_get_proposal_state(tda_engine* e, double* scaling, double* C, dou
       for (int64_t c = 0; c < N; ++c)
         for (int j = 0; j < d; ++j) am_mu[(size_t)c * d + j] = h[(size_t)c * DP + j];
     }
-    if (am_sigma) {  // dense symmetric matrices from the device storage (two layouts, see AdaptArgs)
-      const bool tiled = e->pp.block_moments != 0;
-      const int NS = DP / 2 + 1;
-      const size_t per = tiled ? (size_t)am_tiles_rt(DP) * 256 : (size_t)NS * DP;
+    if (am_sigma) {  // dense symmetric matrices from the lower-tile storage
+      const size_t per = (size_t)am_tiles_rt(DP) * 256;
       std::vector<double> h((size_t)N * per);
       HIP_TRY(hipMemcpy(h.data(), e->am_sigma.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
       for (int64_t c = 0; c < N; ++c) {
         const double* f = h.data() + (size_t)c * per;
         for (int i = 0; i < d; ++i)
-          for (int j = 0; j < d; ++j) {
-            double v;
-            if (tiled) {
-              v = f[am_sigma_offset(std::max(i, j), std::min(i, j))];
-            } else {  // [s][l] = Sigma[l][(l+s) mod DP]
-              const int sl = ((j - i) % DP + DP) % DP;
-              v = sl <= DP / 2 ? f[(size_t)sl * DP + i] : f[(size_t)(DP - sl) * DP + j];
-            }
-            am_sigma[((size_t)c * d + i) * d + j] = v;
-          }
+          for (int j = 0; j < d; ++j)
+            am_sigma[((size_t)c * d + i) * d + j] = f[am_sigma_offset(std::max(i, j), std::min(i, j))];
       }
     }
   }

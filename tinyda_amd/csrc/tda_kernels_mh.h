@@ -110,8 +110,7 @@ struct AdaptArgs {
   double sd, eps;
   const double* rec_params;  // [S][N][d] states recorded by k_mh_steps
   double* am_mu;             // [NP][DPAD]
-  double* am_sigma;          // reference form: [NP][DPAD/2+1][DPAD] circulant fold, [s][l] = Sigma[l][(l+s) mod DPAD];
-                             // block form: [NP][am_tiles][4][64], lower 16x16 tiles in MFMA C/D layout (k_adapt_block)
+  double* am_sigma;          // [NP][am_tiles][4][64]: lower 16x16 tiles in MFMA C/D layout (see k_adapt)
   double* scaling;           // [NP]
   int32_t* acc_count;        // [NP]
   int32_t* flags;            // [NP]
@@ -932,23 +931,36 @@ __device__ __forceinline__ void adapt_scaling(const AdaptArgs& a, int64_t c, int
   if (lane == 0) a.acc_count[c] = 0;
 }
 
+// Reference-form recursion (the default).  Every element follows RecursiveSampleMoments.update operation for operation
+// (this file is compiled with -ffp-contract=off, so products and sums round exactly like NumPy's).  Sigma lives in
+// registers in the tile layout described above: lane (lc, hi) holds, for each tile (ti, tj) on or below the diagonal,
+// the 4 elements (16 ti + hi + 4 r, 16 tj + lc).  Per state the three vectors x, mu, mu' go to LDS twice: in natural
+// order (column operands: one ds_read_b64 per tile column) and permuted so that a lane's four row indices are
+// contiguous (row operands: two ds_read_b128 per tile row).  36 LDS reads + 400 fp64 operations per state, where the
+// circulant fold used earlier needed 99 + 330 and was bound by the LDS.
 template <int DPAD>
 __global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
-  constexpr int NS = DPAD / 2 + 1;
-  // x, mu, mu' each stored twice ([j] and [j + DPAD]) so that the rotated operand of slot s is a plain ds_read_b64
-  // at immediate offset s from the lane's own base: consecutive lanes hit consecutive banks (conflict free)
-  __shared__ __attribute__((aligned(16))) double s_vec[6 * DPAD];
+  constexpr int T = am_tile_rows<DPAD>();
+  constexpr int NTL = am_tiles<DPAD>();
+  constexpr int W = 16 * T;
+  __shared__ __attribute__((aligned(16))) double s_nat[3 * W];  // x, mu, mu' by dimension
+  __shared__ __attribute__((aligned(16))) double s_prm[3 * W];  // the same, dimension 16 ti + h + 4 r at 16 ti + 4 h + r
   const int lane = threadIdx.x;
   const int64_t c = blockIdx.x;
   if (c >= a.N) return;
   const bool lj = lane < a.d;
   const bool lp = lane < DPAD;
+  const int lc = lane & 15, hi = lane >> 4;
 
   if (a.do_am) {
-    double Sg[NS];
-    double mu = lp ? a.am_mu[c * DPAD + lane] : 0.0;
+    double* __restrict__ sig = a.am_sigma + (size_t)c * NTL * 256;
+    double Sg[NTL][4];
 #pragma unroll
-    for (int sl = 0; sl < NS; ++sl) Sg[sl] = lp ? a.am_sigma[((size_t)c * NS + sl) * DPAD + lane] : 0.0;
+    for (int idx = 0; idx < NTL; ++idx)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Sg[idx][r] = sig[(idx * 4 + r) * 64 + lane];
+    double mu = lp ? a.am_mu[c * DPAD + lane] : 0.0;
+    const int ppos = (lane & ~15) | ((lane & 3) << 2) | ((lane >> 2) & 3);
     double xn = lj ? a.rec_params[(size_t)c * a.d + lane] : 0.0;
     for (int s = 0; s < a.S; ++s) {
       const double x = xn;
@@ -957,33 +969,52 @@ __global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
       const double mup = (1.0 / (t + 1.0)) * (t * mu + x);
       const double ca = (t - 1.0) / t, cb = a.sd / t;
       const double t1 = t + 1.0;
-      __syncthreads();  // previous step's rotation reads are done
-      if (lp) {
-        s_vec[lane] = x;
-        s_vec[lane + DPAD] = x;
-        s_vec[2 * DPAD + lane] = mu;
-        s_vec[2 * DPAD + lane + DPAD] = mu;
-        s_vec[4 * DPAD + lane] = mup;
-        s_vec[4 * DPAD + lane + DPAD] = mup;
+      __syncthreads();  // previous step's operand reads are done
+      if (lane < W) {
+        s_nat[lane] = x;
+        s_nat[W + lane] = mu;
+        s_nat[2 * W + lane] = mup;
+        s_prm[ppos] = x;
+        s_prm[W + ppos] = mu;
+        s_prm[2 * W + ppos] = mup;
       }
       __syncthreads();
-      const double* __restrict__ rot = s_vec + (lane < DPAD ? lane : 0);
+      double xc[T], mc[T], pc[T];
 #pragma unroll
-      for (int sl = 0; sl < NS; ++sl) {
-        const double xj = rot[sl], mj = rot[2 * DPAD + sl], mpj = rot[4 * DPAD + sl];
-        double M = (t * (mu * mj) - t1 * (mup * mpj)) + x * xj;
-        if (sl == 0) M = lj ? M + a.eps : M;
-        Sg[sl] = ca * Sg[sl] + cb * M;
+      for (int tj = 0; tj < T; ++tj) {
+        xc[tj] = s_nat[16 * tj + lc];
+        mc[tj] = s_nat[W + 16 * tj + lc];
+        pc[tj] = s_nat[2 * W + 16 * tj + lc];
+      }
+#pragma unroll
+      for (int ti = 0; ti < T; ++ti) {
+        double xr[4], mr[4], pr[4];
+        {
+          const double2* __restrict__ q = reinterpret_cast<const double2*>(s_prm + 16 * ti + 4 * hi);
+          const double2 x01 = q[0], x23 = q[1], m01 = q[W / 2], m23 = q[W / 2 + 1], p01 = q[W], p23 = q[W + 1];
+          xr[0] = x01.x; xr[1] = x01.y; xr[2] = x23.x; xr[3] = x23.y;
+          mr[0] = m01.x; mr[1] = m01.y; mr[2] = m23.x; mr[3] = m23.y;
+          pr[0] = p01.x; pr[1] = p01.y; pr[2] = p23.x; pr[3] = p23.y;
+        }
+#pragma unroll
+        for (int tj = 0; tj <= ti; ++tj) {
+          const int idx = ti * (ti + 1) / 2 + tj;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            double M = (t * (mr[r] * mc[tj]) - t1 * (pr[r] * pc[tj])) + xr[r] * xc[tj];
+            if (ti == tj && hi + 4 * r == lc) M = (16 * ti + lc < a.d) ? M + a.eps : M;
+            Sg[idx][r] = ca * Sg[idx][r] + cb * M;
+          }
+        }
       }
       mu = mup;
     }
-    if (lp) {
-      a.am_mu[c * DPAD + lane] = mu;
+    if (lp) a.am_mu[c * DPAD + lane] = mu;
 #pragma unroll
-      for (int sl = 0; sl < NS; ++sl) a.am_sigma[((size_t)c * NS + sl) * DPAD + lane] = Sg[sl];
-    }
+    for (int idx = 0; idx < NTL; ++idx)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sig[(idx * 4 + r) * 64 + lane] = Sg[idx][r];
   }
-
   adapt_scaling(a, c, lane);
 }
 
@@ -1076,8 +1107,7 @@ __global__ void __launch_bounds__(64) k_adapt_block(const AdaptArgs a) {
 struct CholArgs {
   int64_t N;
   int d;
-  const double* am_sigma;  // layout of the adapt kernel in use (see AdaptArgs)
-  int tiled;               // 1: tile storage of k_adapt_block, 0: circulant fold of k_adapt
+  const double* am_sigma;  // [NP][am_tiles][4][64] (see k_adapt)
   double* Lk;              // [NP][DPAD][DPAD] k-major
   int32_t* flags;
 };
@@ -1096,7 +1126,6 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {  // wave-unifo
 template <int DPAD>
 __global__ void __launch_bounds__(64) k_chol(const CholArgs a) {
   constexpr int NTL = am_tiles<DPAD>();
-  constexpr int NS = DPAD / 2 + 1;
   const int lane = threadIdx.x;
   const int64_t c = blockIdx.x;
   if (c >= a.N) return;
@@ -1107,15 +1136,7 @@ __global__ void __launch_bounds__(64) k_chol(const CholArgs a) {
 #pragma unroll
   for (int j = 0; j < DPAD; ++j) {
     double v = (j == li) ? 1.0 : 0.0;
-    if (lj && j < a.d && j <= li) {
-      if (a.tiled) {
-        v = a.am_sigma[(size_t)c * NTL * 256 + am_sigma_offset(li, j)];
-      } else {
-        const int sl = li - j;
-        v = sl <= DPAD / 2 ? a.am_sigma[((size_t)c * NS + sl) * DPAD + j]
-                           : a.am_sigma[((size_t)c * NS + (DPAD - sl)) * DPAD + li];
-      }
-    }
+    if (lj && j < a.d && j <= li) v = a.am_sigma[(size_t)c * NTL * 256 + am_sigma_offset(li, j)];
     A[j] = v;
   }
   bool ok = true;
