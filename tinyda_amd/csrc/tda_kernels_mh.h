@@ -937,7 +937,7 @@ __device__ __forceinline__ void adapt_scaling(const AdaptArgs& a, int64_t c, int
 // the 4 elements (16 ti + hi + 4 r, 16 tj + lc).  Per state the three vectors x, mu, mu' go to LDS twice: in natural
 // order (column operands: one ds_read_b64 per tile column) and permuted so that a lane's four row indices are
 // contiguous (row operands: two ds_read_b128 per tile row).  36 LDS reads + 400 fp64 operations per state, where the
-// circulant fold used earlier needed 99 + 330 and was bound by the LDS.
+// circulant fold used earlier needed 99 + 330 and ran at the same speed: the bound is the VALU.
 template <int DPAD>
 __global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
   constexpr int T = am_tile_rows<DPAD>();
