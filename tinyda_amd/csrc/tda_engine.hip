@@ -594,7 +594,12 @@ int tda_engine_set_level(tda_engine* e, int level, int m, const double* A, const
   int rc;
   if (m <= AEM_MP) {
     std::vector<double> y64(lv.ytil_h.begin(), lv.ytil_h.begin() + AEM_MP), c64;
-    if ((rc = lv.A_rm.upload(lv.A_h))) return rc;
+    {  // column-major [d][AEM_MP] for k_aem_action: lane = observation reads consecutive addresses
+      std::vector<double> acm((size_t)e->d * AEM_MP, 0.0);
+      for (int i = 0; i < m; ++i)
+        for (int j = 0; j < e->d; ++j) acm[(size_t)j * AEM_MP + i] = lv.A_h[(size_t)i * e->d + j];
+      if ((rc = lv.A_rm.upload(acm))) return rc;
+    }
     if ((rc = lv.ytil64.upload(y64))) return rc;
     std::vector<double> d64(lv.data_h.begin(), lv.data_h.begin() + AEM_MP);
     if ((rc = lv.data64.upload(d64))) return rc;

@@ -492,8 +492,9 @@ __global__ void __launch_bounds__(64) k_aem_action(const AemArgs a) {
   auto resid = [&](int lev) {
     double f = 0.0;
     if (lo) {
-      const double* Ar = a.A[lev] + (size_t)lane * d;
-      for (int j = 0; j < d; ++j) f = fma(Ar[j], s_v[j], f);
+      const double* __restrict__ Ac = a.A[lev] + lane;  // column-major [d][AEM_MP]
+#pragma unroll 8
+      for (int j = 0; j < d; ++j) f = fma(Ac[(size_t)j * AEM_MP], s_v[j], f);
       f -= a.ytil[lev][lane];
     }
     return f;
@@ -505,7 +506,8 @@ __global__ void __launch_bounds__(64) k_aem_action(const AemArgs a) {
     __syncthreads();
     double s = 0.0;
     if (lo) {
-      const double* Pc = a.cov_inv[lev] + (size_t)c * MP * MP + lane;
+      const double* __restrict__ Pc = a.cov_inv[lev] + (size_t)c * MP * MP + lane;
+#pragma unroll 8
       for (int o = 0; o < a.m; ++o) s = fma(Pc[(size_t)o * MP], s_v[AEM_MP + o], s);
       s *= r;
     }
@@ -626,9 +628,16 @@ __global__ void __launch_bounds__(64) k_aem_action(const AemArgs a) {
     if (lane < AEM_MP) s_v[AEM_MP + lane] = xupd;
     __syncthreads();
     if (lo)
-      for (int i = 0; i < a.m; ++i) {  // utils.py:199  Sigma <- (t-1)/t Sigma + 1/t x x^T
-        const double xi = s_v[AEM_MP + i];
-        Sg[(size_t)i * MP + lane] = (t - 1.0) / t * Sg[(size_t)i * MP + lane] + 1.0 / t * (xi * xupd);
+      for (int i0 = 0; i0 < a.m; i0 += 8) {  // utils.py:199  Sigma <- (t-1)/t Sigma + 1/t x x^T; 8 rows in flight
+        double old[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) old[u] = i0 + u < a.m ? Sg[(size_t)(i0 + u) * MP + lane] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (i0 + u < a.m) {
+            const double xi = s_v[AEM_MP + i0 + u];
+            Sg[(size_t)(i0 + u) * MP + lane] = (t - 1.0) / t * old[u] + 1.0 / t * (xi * xupd);
+          }
       }
   } else {
     const double dm = (a.is_da || acc) ? diff_new : (lo ? md[lane] : 0.0);  // MLDA refreshes the difference on accept only
@@ -645,9 +654,17 @@ __global__ void __launch_bounds__(64) k_aem_action(const AemArgs a) {
     __syncthreads();
     if (lo) {
       const double ca = (t - 1.0) / t, cb = 1.0 / t;
-      for (int i = 0; i < a.m; ++i) {
-        const double M = (t * (s_v[2 * AEM_MP + i] * mu_o) - (t + 1.0) * (s_v[3 * AEM_MP + i] * mu_n)) + s_v[AEM_MP + i] * dm;
-        Sg[(size_t)i * MP + lane] = ca * Sg[(size_t)i * MP + lane] + cb * M;
+      for (int i0 = 0; i0 < a.m; i0 += 8) {  // 8 rows in flight
+        double old[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) old[u] = i0 + u < a.m ? Sg[(size_t)(i0 + u) * MP + lane] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (i0 + u < a.m) {
+            const int i = i0 + u;
+            const double M = (t * (s_v[2 * AEM_MP + i] * mu_o) - (t + 1.0) * (s_v[3 * AEM_MP + i] * mu_n)) + s_v[AEM_MP + i] * dm;
+            Sg[(size_t)i * MP + lane] = ca * old[u] + cb * M;
+          }
       }
       mu[lane] = mu_n;
     }
@@ -665,6 +682,7 @@ __global__ void __launch_bounds__(64) k_aem_action(const AemArgs a) {
   // Sigma_e + Sigma_bias into LDS (row i = lane), and the 1e-9 rule of distributions.py:399-402
   bool big = false;
   if (lo) {
+#pragma unroll 4
     for (int j = 0; j < a.m; ++j) {
       // symmetric matrices: element (lane, j) is read as (j, lane), the entry this very lane wrote above
       double sb = 0.0;
@@ -683,38 +701,40 @@ __global__ void __launch_bounds__(64) k_aem_action(const AemArgs a) {
       double sacc = 0.0;
       if (lane >= kk && lo) {
         sacc = s_M[lane * LDM + kk];
-        for (int p = 0; p < kk; ++p) sacc = fma(-s_M[lane * LDM + p], s_M[kk * LDM + p], sacc);
+#pragma unroll 8
+        for (int p = 0; p < kk; ++p) sacc = fma(-s_M[lane * LDM + p], s_M[kk * LDM + p], sacc);  // unrolled: LDS reads in flight
       }
       const double lkk = sqrt(__shfl(sacc, kk));
       if (lane >= kk && lo) s_M[lane * LDM + kk] = lane == kk ? lkk : sacc / lkk;
       __syncthreads();
     }
-    // W = L^-1 : lane = column j, forward substitution down the rows; stored in the upper triangle region via a second pass
-    double Wc[AEM_MP];
-#pragma unroll 1
+    // W = L^-1, lane = column j: W[i][j] for i >= j by forward substitution down the rows.  W^T goes into the strict
+    // upper triangle of s_M (W[i][j] at s_M[j][i]; L stays below), its diagonal into s_v[2 AEM_MP ..): a per-lane array
+    // indexed by the loop variable would live in scratch memory and made this kernel 85 % of an error-model run.
+    double* const s_wd = s_v + 2 * AEM_MP;
     for (int i = 0; i < a.m; ++i) {
-      double v = 0.0;
       if (lo && i >= lane) {
-        if (i == lane) v = 1.0 / s_M[i * LDM + i];
-        else {
-          double sacc = 0.0;
-          for (int p = lane; p < i; ++p) sacc = fma(s_M[i * LDM + p], Wc[p], sacc);
-          v = -sacc / s_M[i * LDM + i];
+        const double lii = s_M[i * LDM + i];
+        if (i == lane) {
+          s_wd[lane] = 1.0 / lii;
+        } else {
+          double sacc = fma(s_M[i * LDM + lane], s_wd[lane], 0.0);
+#pragma unroll 8
+          for (int p = lane + 1; p < i; ++p) sacc = fma(s_M[i * LDM + p], s_M[lane * LDM + p], sacc);
+          s_M[lane * LDM + i] = -sacc / lii;
         }
       }
-      Wc[i] = v;
     }
-    __syncthreads();
-    // s_M <- W (row i, column j = lane)
-    for (int i = 0; i < a.m; ++i)
-      if (lo) s_M[i * LDM + lane] = Wc[i];
     __syncthreads();
     if (lo) {
       double* Pc = a.cov_inv[k] + (size_t)c * MP * MP;
-      for (int i = 0; i < a.m; ++i) {  // P[i][lane] = sum_r W[r][i] W[r][lane]
-        double sacc = 0.0;
+      for (int i = 0; i < a.m; ++i) {  // P[i][lane] = sum_{r >= max(i, lane)} W[r][i] W[r][lane]
         const int r0 = i > lane ? i : lane;
-        for (int r = r0; r < a.m; ++r) sacc = fma(s_M[r * LDM + i], s_M[r * LDM + lane], sacc);
+        const double wi = i == r0 ? s_wd[i] : s_M[i * LDM + r0];           // W[r0][i]
+        const double wl = lane == r0 ? s_wd[lane] : s_M[lane * LDM + r0];  // W[r0][lane]
+        double sacc = fma(wi, wl, 0.0);
+#pragma unroll 8
+        for (int r = r0 + 1; r < a.m; ++r) sacc = fma(s_M[i * LDM + r], s_M[lane * LDM + r], sacc);
         Pc[(size_t)i * MP + lane] = sacc;
       }
     }

@@ -1,0 +1,4 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tools.bench_configs as bc
+bc.run_c5_aem()
