@@ -247,6 +247,40 @@ def test_philox_forward_mode_vs_oracle(eng_mod):
     e.close()
 
 
+@pytest.mark.parametrize("d,m,kind,block", [(2, 20, "grw", 0), (7, 33, "am", 0), (17, 40, "am", 23), (32, 64, "pcn", 0),
+                                             (33, 70, "am", 16)])
+def test_philox_forward_mode_small_dims(eng_mod, d, m, kind, block):
+    """The split proposal path (k_rng on the second stream, k_apply) at every padded dimension (8, 16, 32, 64) and with
+    ragged blocks, against the oracle on the exported stream."""
+    N, T = 21, 130
+    A, theta_true, y = _c2_problem(d, m, seed=d)
+    theta0 = theta_true + 0.05 * np.random.default_rng(d).standard_normal((N, d))
+    e = eng_mod.Engine(N, d, seed=5 + d, chain_offset=3, block_steps=block)
+    e.set_prior(np.zeros(d), np.eye(d))
+    e.set_level(0, A, y, 0, 0.01)
+    C0 = 1e-3 * (np.eye(d) + 0.3 * np.ones((d, d)) / d)
+    if kind == "grw":
+        e.set_proposal(0, C0, scaling=0.7, adaptive=True, period=20)
+        prop = dict(kind="grw", C=C0, scaling=0.7, adaptive=True, period=20)
+    elif kind == "pcn":
+        e.set_proposal(1, None, scaling=0.05, adaptive=True, period=25)
+        prop = dict(kind="pcn", scaling=0.05, adaptive=True, period=25)
+    else:
+        e.set_proposal(2, C0, t0=40, period=20)
+        prop = dict(kind="am", C0=C0, t0=40, period=20)
+    e.init(theta0)
+    z, u = e.set_export(T)
+    params, stats, acc = e.run_host(T)
+    e.close()
+    lvl = orc.LinearGaussianLevel(A, y, "iso", 0.01, orc.MVNPrior(np.zeros(d), np.eye(d)))
+    res = orc.run_mh(lvl, prop, theta0, np.swapaxes(z, 0, 1), np.swapaxes(u, 0, 1))
+    assert np.array_equal(acc, np.swapaxes(res["accepted"][:, 1:], 0, 1))
+    np.testing.assert_allclose(stats[:, :, 2], np.swapaxes(res["logpost"][:, 1:], 0, 1), rtol=RTOL)
+    ps = orc.PhiloxStream(5 + d)
+    np.testing.assert_allclose(z[T - 1], ps.normals(np.arange(3, 3 + N), T - 1, d), rtol=1e-13, atol=1e-14)
+    assert np.array_equal(u[T - 1], ps.uniform(np.arange(3, 3 + N), T - 1))
+
+
 def test_results_do_not_depend_on_sharding(eng_mod):
     """Chains keyed by global id: one engine with 32 chains == two engines with 16 (offsets 0 and 16)."""
     d, m, T = 8, 16, 120
