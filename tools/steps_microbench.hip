@@ -2,7 +2,7 @@
 // Build on the GPU box:  hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -w -Itinyda_amd/csrc -Itools \
 //                              [-DTDA_EXP_...] -o /tmp/smb tools/steps_microbench.hip
 //        (-DTDA_STEP_TRACE additionally prints where the cycles of a step go; the stamps themselves cost a few percent)
-// Run:  /tmp/smb [kernel: 0 = k_mh_steps<64,8>, 1 = k_mh_steps_frag<64,false,1>, 2 = the 4-wave gapless k_mh_steps_frag<64,false,1,4>] [records: 0 none, 1 stats only, 2 all] [m]
+// Run:  /tmp/smb [kernel: 0 = k_mh_steps<64,8>, 1 = k_mh_steps_frag<64,false,1>, 2 = the 4-wave gapless k_mh_steps_frag<64,false,1,4>, 3 = k_mh_steps_lin<64,false,1>] [records: 0 none, 1 stats only, 2 all] [m]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -10,7 +10,7 @@
 #include <vector>
 #include <random>
 #include <algorithm>
-#include "experimental/tda_kernels_mh_frag.h"
+#include "experimental/tda_kernels_mh_lin.h"
 using namespace tda;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
@@ -56,13 +56,15 @@ int main(int argc, char** argv) {
   size_t lds; const void* fn;
   if (which == 0) { lds = (16 * (D + 2) + 256 + 2 * D + m) * 8; fn = (const void*)&k_mh_steps<D, 8>; }
   else if (which == 1) { lds = steps_frag_lds_doubles<D>(m, false) * 8; fn = (const void*)&k_mh_steps_frag<D, false, 1>; }
-  else { lds = steps_frag_lds_doubles<D>(m, false) * 8; fn = (const void*)&k_mh_steps_frag<D, false, 1, 4>; }
+  else if (which == 2) { lds = steps_frag_lds_doubles<D>(m, false) * 8; fn = (const void*)&k_mh_steps_frag<D, false, 1, 4>; }
+  else { lds = steps_lin_lds_doubles<D>(m, false) * 8; fn = (const void*)&k_mh_steps_lin<D, false, 1>; }
   if (lds > 64 * 1024) CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto launch = [&]() {
     if (which == 0) hipLaunchKernelGGL((k_mh_steps<D, 8>), dim3(NP / 16), dim3(512), lds, 0, a);
     else if (which == 1) hipLaunchKernelGGL((k_mh_steps_frag<D, false, 1>), dim3(NP / 16), dim3(512), lds, 0, a);
-    else hipLaunchKernelGGL((k_mh_steps_frag<D, false, 1, 4>), dim3(NP / 16), dim3(256), lds, 0, a);
+    else if (which == 2) hipLaunchKernelGGL((k_mh_steps_frag<D, false, 1, 4>), dim3(NP / 16), dim3(256), lds, 0, a);
+    else hipLaunchKernelGGL((k_mh_steps_lin<D, false, 1>), dim3(NP / 16), dim3(512), lds, 0, a);
   };
   for (int i = 0; i < 3; ++i) launch();
   CK(hipDeviceSynchronize());
@@ -85,8 +87,8 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     std::vector<long long> h((size_t)S * 64);
     CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
-    const int ord_frag[8] = {0, 2, 3, 1, 4, 5, 6, 7}, ord_tm[8] = {0, 1, 2, 3, 4, 5, 6, 7};
-    const int* ord = which >= 1 ? ord_frag : ord_tm;
+    const int ord_frag[8] = {0, 2, 3, 1, 4, 5, 6, 7}, ord_tm[8] = {0, 1, 2, 3, 4, 5, 6, 7}, ord_lin[8] = {0, 2, 3, 1, 4, 5, 6, 7};
+    const int* ord = which == 3 ? ord_lin : (which >= 1 ? ord_frag : ord_tm);
     const int nwk = which == 2 ? 4 : 8;
     auto med = [&](int w, int ia, int ib, int shift) {
       std::vector<long long> v;
