@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(256, 1) k_dreamz_steps(const DreamStepArgs a) 
   double lp = a.lp[gcl], ll = a.ll[gcl];
   int nacc = 0;
   double* arch_c = a.shared ? a.arch : a.arch + (size_t)gct * a.cap * DPAD;
-  const double2* fbase = reinterpret_cast<const double2*>(a.lv.Apk) + lane;
+  const FragSrc fbase = frag_src(a.lv.Apk, lane);
   __syncthreads();
 
   for (int s = 0; s < a.S; ++s) {
@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(256, 1) k_dreamz_steps(const DreamStepArgs a) 
       p = sum_rows(p);
       maha = p;
     } else {
-      const double2* pbase = reinterpret_cast<const double2*>(a.pr.Wpk) + lane;
+      const FragSrc pbase = frag_src(a.pr.Wpk, lane);
       double2 p0[KS / 2], p1[KS / 2];
       frag_load<DPAD>(pbase, wave, a.pr.ncb, p0);
       frag_load<DPAD>(pbase, wave + 4, a.pr.ncb, p1);

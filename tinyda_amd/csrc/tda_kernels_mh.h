@@ -141,16 +141,33 @@ __device__ __forceinline__ double4_t mfma_f64(double a, double b, double4_t c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-// MFMA A-operand fragments of one 16-row block: K2 16-byte loads per lane, unconditional (the block index is
-// clamped, out-of-range blocks are simply not accumulated) so that hipcc emits plain global_load_dwordx4
-// and counted vmcnt waits instead of one branch per load.
+// Fragment source for buffer loads: resource descriptor (4 SGPRs) + scalar block offset + one 32-bit lane offset.
+// With per-lane 64-bit pointers hipcc keeps an address pair per block half alive across the step loop (tens of
+// registers); the descriptor form needs one VGPR.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+struct FragSrc {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int lane_off;
+};
+__device__ __forceinline__ FragSrc frag_src(const double* packed, int lane) {
+  return FragSrc{__builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(packed), 0, 0x7fffffff, 0x00020000), lane * 16};
+}
 template <int DPAD>
-__device__ __forceinline__ void frag_load(const double2* __restrict__ base, int cb, int ncb,
-                                          double2 (&f)[DPAD / 8]) {
-  const int cbc = cb < ncb ? cb : ncb - 1;
-  const double2* __restrict__ p = base + (size_t)cbc * (DPAD / 8) * 64;
+__device__ __forceinline__ void frag_load_buf(const FragSrc& src, int cb, double2 (&f)[DPAD / 8]) {
+  const int soff = cb * (DPAD / 8) * 1024;
 #pragma unroll
-  for (int k = 0; k < DPAD / 8; ++k) f[k] = p[k * 64];
+  for (int k = 0; k < DPAD / 8; ++k) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(src.rsrc, src.lane_off + (k & 3) * 1024, soff + (k >> 2) * 4096, 0);
+    f[k] = *reinterpret_cast<const double2*>(&v);
+  }
+}
+
+// MFMA A-operand fragments of one 16-row block: K2 16-byte buffer loads per lane, unconditional (the block index is
+// clamped, out-of-range blocks are simply not accumulated) so that hipcc emits counted vmcnt waits instead of one
+// branch per load.
+template <int DPAD>
+__device__ __forceinline__ void frag_load(const FragSrc& src, int cb, int ncb, double2 (&f)[DPAD / 8]) {
+  frag_load_buf<DPAD>(src, cb < ncb ? cb : ncb - 1, f);
 }
 
 // One pair of 16-row blocks: 2 x KS MFMAs on two accumulators, then the fused epilogue
@@ -211,7 +228,7 @@ __device__ __forceinline__ double level_sse_partial(const double* __restrict__ A
                                                     double2 (&fa0)[DPAD / 8], double2 (&fa1)[DPAD / 8]) {
   constexpr int K2 = DPAD / 8;
   const int hi = lane >> 4;
-  const double2* __restrict__ base = reinterpret_cast<const double2*>(Apk) + lane;
+  const FragSrc base = frag_src(Apk, lane);
   double sse = 0.0;
   double2 fb0[K2], fb1[K2];
   for (int cb = wave; cb < ncb; cb += 4 * NW) {
@@ -258,35 +275,24 @@ __device__ __forceinline__ double block_sse(const double2 (&f)[DPAD / 8], const 
   return sse;
 }
 
-// frag_load with wrap-around: past the wave's last block it fetches the wave's FIRST block again, i.e. the fragments
-// the next MH step starts with, so their L2 latency hides behind the serial end-of-step phase.
-template <int DPAD>
-__device__ __forceinline__ void frag_load_wrap(const double2* __restrict__ base, int cb, int ncb, int first,
-                                               double2 (&f)[DPAD / 8]) {
-  const int cbc = cb < ncb ? cb : first;
-  const double2* __restrict__ p = base + (size_t)cbc * (DPAD / 8) * 64;
-#pragma unroll
-  for (int k = 0; k < DPAD / 8; ++k) f[k] = p[k * 64];
-}
-
 template <int DPAD, int MODE, int NW>
 __device__ __forceinline__ double level_sse_single(const double* __restrict__ Apk, int ncb,
                                                    const double* __restrict__ s_y, double* __restrict__ s_w,
                                                    const double (&th)[DPAD / 4], int wave, int lane,
                                                    double2 (&fa)[DPAD / 8]) {
   const int hi = lane >> 4;
-  const double2* __restrict__ base = reinterpret_cast<const double2*>(Apk) + lane;
+  const FragSrc src = frag_src(Apk, lane);
   const int first = wave < ncb ? wave : ncb - 1;
   double sse = 0.0;
   double2 fb[DPAD / 8];
   bool next_in_fb = false;  // where the next step's first block ended up
   for (int cb = wave; cb < ncb; cb += 2 * NW) {
-    frag_load_wrap<DPAD>(base, cb + NW, ncb, first, fb);
+    frag_load_buf<DPAD>(src, cb + NW < ncb ? cb + NW : first, fb);
     __builtin_amdgcn_sched_barrier(0);
     sse += block_sse<DPAD, MODE>(fa, th, s_y, s_w, cb, hi);
     __builtin_amdgcn_sched_barrier(0);
     if (cb + NW < ncb) {
-      frag_load_wrap<DPAD>(base, cb + 2 * NW, ncb, first, fa);
+      frag_load_buf<DPAD>(src, cb + 2 * NW < ncb ? cb + 2 * NW : first, fa);
       __builtin_amdgcn_sched_barrier(0);
       sse += block_sse<DPAD, MODE>(fb, th, s_y, s_w, cb + NW, hi);
       __builtin_amdgcn_sched_barrier(0);
@@ -472,8 +478,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
   int nacc = 0;
   const bool is_eval = a.mode == MODE_EVAL;
   const bool is_pcn = a.prop_kind == 1;
-  const double2* fbase = reinterpret_cast<const double2*>(a.lv.Apk) + lane;
-  const double2* pbase = reinterpret_cast<const double2*>(a.pr.Wpk) + lane;
+  const FragSrc fbase = frag_src(a.lv.Apk, lane);
+  const FragSrc pbase = frag_src(a.pr.Wpk, lane);
   constexpr bool PAIRS = NW == 4;  // 4 waves: pairs of blocks, 4 fragment sets; 8 waves: single blocks, 2 sets
   double2 f0[KS / 2], f1[PAIRS ? KS / 2 : 1];
   double unext = 0.5, lunext = 0.0;
@@ -489,7 +495,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
   }
   __syncthreads();
 
-  if constexpr (!PAIRS) frag_load<DPAD>(fbase, wave, a.lv.ncb, f0);  // later steps: prefetched by the previous step
+  if constexpr (!PAIRS) frag_load_buf<DPAD>(frag_src(a.lv.Apk, lane), wave < a.lv.ncb ? wave : a.lv.ncb - 1, f0);  // later steps: prefetched by the previous step
   // cycle stamps for tools/steps_microbench.hip: compiled in only on request, because even a never-taken s_memtime
   // makes hipcc fall back to lgkmcnt(0) waits in the hot loop
 #ifdef TDA_STEP_TRACE
@@ -563,7 +569,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
         p = level_sse_partial<DPAD, 0, NW>(a.pr.Wpk, a.pr.ncb, s_py, nullptr, th, wave, lane, p0, p1);
       } else {
         double2 p0[KS / 2];
-        frag_load<DPAD>(pbase, wave, a.pr.ncb, p0);
+        frag_load_buf<DPAD>(frag_src(a.pr.Wpk, lane), wave < a.pr.ncb ? wave : a.pr.ncb - 1, p0);
         p = level_sse_single<DPAD, 0, NW>(a.pr.Wpk, a.pr.ncb, s_py, nullptr, th, wave, lane, p0);
       }
       p = sum_rows(p);

@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256, 1) k_ml_steps(const MLArgs a) {
     nrec[k] = 0;
   }
   int64_t ringpos = a.ring_pos;
-  const double2* fbase = reinterpret_cast<const double2*>(a.lv[0].Apk) + lane;
+  const FragSrc fbase = frag_src(a.lv[0].Apk, lane);
   double2 f0[KS / 2], f1[KS / 2];
   __syncthreads();
 
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(256, 1) k_ml_steps(const MLArgs a) {
       p = sum_rows(p);
       maha = p;
     } else {
-      const double2* pbase = reinterpret_cast<const double2*>(a.pr.Wpk) + lane;
+      const FragSrc pbase = frag_src(a.pr.Wpk, lane);
       double2 p0[KS / 2], p1[KS / 2];
       frag_load<DPAD>(pbase, wave, a.pr.ncb, p0);
       frag_load<DPAD>(pbase, wave + 4, a.pr.ncb, p1);
@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(256, 1) k_ml_steps(const MLArgs a) {
 #pragma unroll
         for (int e = 0; e < EPT; ++e) s_prop[c * LDP + q_ * EPT + e] = use_snap ? snp[e] : cur[k][e];
       }
-      const double2* gb = reinterpret_cast<const double2*>(a.lv[q].Apk) + lane;
+      const FragSrc gb = frag_src(a.lv[q].Apk, lane);
       double2 g0[KS / 2], g1[KS / 2];
       frag_load<DPAD>(gb, wave, a.lv[q].ncb, g0);
       frag_load<DPAD>(gb, wave + 4, a.lv[q].ncb, g1);

@@ -103,12 +103,12 @@ __device__ __forceinline__ double level_sse_frag(const double* __restrict__ Apk,
                                                  const double* __restrict__ s_pinv, double& prior_partial, Mid&& mid,
                                                  long long* stamp = nullptr) {
   const int hi = lane >> 4;
-  const double2* __restrict__ base = reinterpret_cast<const double2*>(Apk) + lane;
+  const FragSrc base = frag_src(Apk, lane);
   const int first = wave < ncb ? wave : ncb - 1;
   double sse = 0.0;
   double2 fb[DPAD / 8];
   bool next_in_fb = false;
-  frag_load_wrap<DPAD>(base, wave + NW, ncb, first, fb);
+  frag_load_buf<DPAD>(base, (wave + NW) < ncb ? (wave + NW) : first, fb);
   __builtin_amdgcn_sched_barrier(0);
 #ifdef TDA_STEP_TRACE
   if (stamp) stamp[2] = (long long)__builtin_amdgcn_s_memtime();
@@ -124,7 +124,7 @@ __device__ __forceinline__ double level_sse_frag(const double* __restrict__ Apk,
   }
   __builtin_amdgcn_sched_barrier(0);
   if (wave + NW < ncb) {
-    frag_load_wrap<DPAD>(base, wave + 2 * NW, ncb, first, fa);
+    frag_load_buf<DPAD>(base, (wave + 2 * NW) < ncb ? (wave + 2 * NW) : first, fa);
     __builtin_amdgcn_sched_barrier(0);
     const double4_t acc = block_mfma<DPAD, MODE>(fb, th);
     sse += block_epilogue<MODE>(acc, s_y, s_w, wave + NW, hi);
@@ -139,7 +139,7 @@ __device__ __forceinline__ double level_sse_frag(const double* __restrict__ Apk,
     if (wave >= NW / 2 && cb >= wave + (TDA_PRIO_SWITCH) * 2 * NW && cb < wave + (TDA_PRIO_SWITCH + 1) * 2 * NW)
       __builtin_amdgcn_s_setprio(3);
 #endif
-    frag_load_wrap<DPAD>(base, cb + NW, ncb, first, fb);
+    frag_load_buf<DPAD>(base, (cb + NW) < ncb ? (cb + NW) : first, fb);
     __builtin_amdgcn_sched_barrier(0);
     {
       const double4_t acc = block_mfma<DPAD, MODE>(fa, th);
@@ -147,7 +147,7 @@ __device__ __forceinline__ double level_sse_frag(const double* __restrict__ Apk,
     }
     __builtin_amdgcn_sched_barrier(0);
     if (cb + NW < ncb) {
-      frag_load_wrap<DPAD>(base, cb + 2 * NW, ncb, first, fa);
+      frag_load_buf<DPAD>(base, (cb + 2 * NW) < ncb ? (cb + 2 * NW) : first, fa);
       __builtin_amdgcn_sched_barrier(0);
       const double4_t acc = block_mfma<DPAD, MODE>(fb, th);
       sse += block_epilogue<MODE>(acc, s_y, s_w, cb + NW, hi);
@@ -183,8 +183,8 @@ template <int DPAD, int MODE, bool REFILL>
 __device__ __forceinline__ double chain_with_epilogue(const double2 (&f)[DPAD / 8], const double (&th)[DPAD / 4],
                                                       acc2_t& acc, const acc2_t prev, int cb_prev,
                                                       const double* __restrict__ s_y, const double* __restrict__ s_w,
-                                                      int hi, double2 (&refill)[DPAD / 8],
-                                                      const double2* __restrict__ src) {
+                                                      int hi, double2 (&refill)[DPAD / 8], const FragSrc& fsrc,
+                                                      int src_cb) {
   constexpr int K2 = DPAD / 8;
   double y[4], w[4];
 #pragma unroll
@@ -204,7 +204,10 @@ __device__ __forceinline__ double chain_with_epilogue(const double2 (&f)[DPAD / 
 #pragma unroll
   for (int k = 0; k < K2; ++k) {
     acc.a = mfma_f64(f[k].x, th[2 * k], acc.a);
-    if (REFILL) refill[k] = src[k * 64];  // one 16-byte load per MFMA pair: the wave never sits in a burst of issues
+    if (REFILL) {  // one 16-byte load per MFMA pair: the wave never sits in a burst of issues
+      const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(fsrc.rsrc, fsrc.lane_off + (k & 3) * 1024, src_cb * (DPAD / 8) * 1024 + (k >> 2) * 4096, 0);
+      refill[k] = *reinterpret_cast<const double2*>(&v);
+    }
     if (k >= 1 && k - 1 < 4) piece(k - 1);
     acc.b = mfma_f64(f[k].y, th[2 * k + 1], acc.b);
     __builtin_amdgcn_sched_barrier(0);
@@ -223,7 +226,7 @@ __device__ __forceinline__ double level_sse_pipe(const double* __restrict__ Apk,
                                                  const double* __restrict__ s_pm, const double* __restrict__ s_pinv,
                                                  double& prior_partial, Mid&& mid, long long* stamp = nullptr) {
   const int hi = lane >> 4;
-  const double2* __restrict__ base = reinterpret_cast<const double2*>(Apk) + lane;
+  const FragSrc base = frag_src(Apk, lane);
   const int nb = wave < ncb ? (ncb - wave + NW - 1) / NW : 0;  // blocks wave, wave + NW, ... of this wave
   double sse = 0.0;
   acc2_t a0, a1, a2;
@@ -240,22 +243,22 @@ __device__ __forceinline__ double level_sse_pipe(const double* __restrict__ Apk,
   // chain j runs on set j % 3 and accumulates into a{j % 3}; the epilogue of chain j - 1 rides along.  Full triples in
   // a plain counted loop (a loop with exits in the middle makes hipcc fall back to near-zero vmcnt waits at its
   // header, i.e. no prefetch), then up to two leftover chains and the last epilogue.
-  auto src_of = [&](int c) {  // fragments of this wave's c-th block, clamped into the matrix
+  auto src_of = [&](int c) {  // this wave's c-th block, clamped into the matrix
     const int cb = wave + c * NW;
-    return base + (size_t)(cb < ncb ? cb : ncb - 1) * (DPAD / 8) * 64;
+    return cb < ncb ? cb : ncb - 1;
   };
   int j = 1;
   for (; j + 2 < nb; j += 3) {
     // chain j also refills the set chain j - 1 has just released with block j + 2
-    sse += chain_with_epilogue<DPAD, MODE, true>(f1, th, a1, a0, wave + (j - 1) * NW, s_y, s_w, hi, f0, src_of(j + 2));
-    sse += chain_with_epilogue<DPAD, MODE, true>(f2, th, a2, a1, wave + j * NW, s_y, s_w, hi, f1, src_of(j + 3));
-    sse += chain_with_epilogue<DPAD, MODE, true>(f0, th, a0, a2, wave + (j + 1) * NW, s_y, s_w, hi, f2, src_of(j + 4));
+    sse += chain_with_epilogue<DPAD, MODE, true>(f1, th, a1, a0, wave + (j - 1) * NW, s_y, s_w, hi, f0, base, src_of(j + 2));
+    sse += chain_with_epilogue<DPAD, MODE, true>(f2, th, a2, a1, wave + j * NW, s_y, s_w, hi, f1, base, src_of(j + 3));
+    sse += chain_with_epilogue<DPAD, MODE, true>(f0, th, a0, a2, wave + (j + 1) * NW, s_y, s_w, hi, f2, base, src_of(j + 4));
   }
   const int rem = nb - j;  // chains left: 0, 1 or 2 (negative: this wave has no block at all)
   if (rem >= 1) {
-    sse += chain_with_epilogue<DPAD, MODE, false>(f1, th, a1, a0, wave + (j - 1) * NW, s_y, s_w, hi, f0, base);
+    sse += chain_with_epilogue<DPAD, MODE, false>(f1, th, a1, a0, wave + (j - 1) * NW, s_y, s_w, hi, f0, base, 0);
     if (rem >= 2) {
-      sse += chain_with_epilogue<DPAD, MODE, false>(f2, th, a2, a1, wave + j * NW, s_y, s_w, hi, f0, base);
+      sse += chain_with_epilogue<DPAD, MODE, false>(f2, th, a2, a1, wave + j * NW, s_y, s_w, hi, f0, base, 0);
       sse += block_epilogue<MODE>(a2.a + a2.b, s_y, s_w, wave + (j + 1) * NW, hi);
     } else {
       sse += block_epilogue<MODE>(a1.a + a1.b, s_y, s_w, wave + j * NW, hi);
@@ -417,7 +420,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps_frag(const StepArg
   };
   stage_load(0);
   stage_store(0);
-  const double2* fbase = reinterpret_cast<const double2*>(a.lv.Apk) + lane;
+  const FragSrc fbase = frag_src(a.lv.Apk, lane);
   double2 f0[KS / 2], f1[NW == 4 ? KS / 2 : 1], f2[NW == 4 ? KS / 2 : 1];
   frag_load<DPAD>(fbase, wave, a.lv.ncb, f0);  // later steps: prefetched by the previous step
   if constexpr (NW == 4) {
