@@ -249,6 +249,13 @@ int64_t tda_engine_state_size(tda_engine* e);
 int tda_engine_get_state(tda_engine* e, void* blob, int64_t bytes);
 int tda_engine_set_state(tda_engine* e, const void* blob, int64_t bytes);
 
+/* Convergence diagnostics of a device-resident history (the reference hands its chains to ArviZ, diagnostics.py:6-111):
+ * rank-normalised split bulk ESS and R-hat (Vehtari et al. 2021) of every parameter.  params: DEVICE
+ * [n_steps][n_chains][dim] (layout of tda_outputs.params), the first `burnin` steps are dropped; ess, rhat: HOST [dim].
+ * `stream` may be NULL. */
+int tda_diag_ess_rhat(int device, void* stream, const double* params, int64_t n_steps, int64_t n_chains, int32_t dim,
+                      int64_t burnin, double* ess, double* rhat);
+
 /* Per-chain error flags (bit 0: Cholesky of an adapted covariance failed, previous factor kept). HOST. */
 int tda_engine_get_flags(tda_engine* e, int32_t* flags);
 

@@ -121,6 +121,10 @@ struct DevBuf {
   ~DevBuf() { release(); }
 };
 
+}  // namespace
+#include "tda_diag.inc"
+namespace {
+
 struct Level {
   bool set = false;
   int m = 0, m_pad = 0, ncb = 0, noise_kind = 0;

@@ -136,6 +136,25 @@ def rhat(x):
     return max(_r(_rank_normalise(s)), _r(_rank_normalise(np.abs(s - np.median(s)))))
 
 
+def ess_rhat_device(params, burnin=0, device=0, stream=None):
+    """Bulk ESS and R-hat of every parameter of a DEVICE history [draws, chains, dim] (a torch tensor or anything with
+    data_ptr()/shape), computed on the GPU (tda_diag_ess_rhat: hipCUB radix sort + hipFFT).  Same estimators as
+    ess_bulk / rhat above, which are the checker.  Returns dict(ess=[dim], rhat=[dim])."""
+    import ctypes as C
+
+    from . import _lib
+
+    lib = _lib.load()
+    T, N, d = (int(v) for v in params.shape)
+    if hasattr(params, "is_contiguous") and not params.is_contiguous():
+        raise ValueError("params must be contiguous [draws, chains, dim]")
+    ess = np.empty(d)
+    rh = np.empty(d)
+    _lib.check(lib.tda_diag_ess_rhat(int(device), C.c_void_p(stream), C.c_void_p(params.data_ptr()), T, N, d, int(burnin),
+                                     ess.ctypes.data_as(C.c_void_p), rh.ctypes.data_as(C.c_void_p)))
+    return dict(ess=ess, rhat=rh)
+
+
 def ess_summary(samples, burnin=0):
     """min / median bulk ESS over parameters for a parameters array [draws, chains, dim] (engine layout)."""
     arr = np.asarray(samples)[burnin:]
