@@ -249,6 +249,15 @@ int64_t tda_engine_state_size(tda_engine* e);
 int tda_engine_get_state(tda_engine* e, void* blob, int64_t bytes);
 int tda_engine_set_state(tda_engine* e, const void* blob, int64_t bytes);
 
+/* Forward model given as HIP source (extension; the reference calls a Python callable per chain and step,
+ * posterior.py:95-96).  The source must define
+ *     __device__ double tda_forward(const double* theta, int dim, int o);     // output o of F(theta), o in [0, m)
+ * and is compiled at run time (hiprtc, gfx950) into a fused step kernel: one wave per chain, the lanes stride over the
+ * outputs.  data: HOST [m]; noise: ISO (noise[0] = variance) or DIAG (HOST [m]).  Single-level chains, GRW / pCN / AM,
+ * diagonal prior.  A source that does not compile returns TDA_ERR_INVALID with the compiler log in tda_last_error(). */
+int tda_engine_set_level_source(tda_engine* e, int level, const char* source, int32_t m, const double* data,
+                                int32_t noise_kind, const double* noise);
+
 /* Convergence diagnostics of a device-resident history (the reference hands its chains to ArviZ, diagnostics.py:6-111):
  * rank-normalised split bulk ESS and R-hat (Vehtari et al. 2021) of every parameter.  params: DEVICE
  * [n_steps][n_chains][dim] (layout of tda_outputs.params), the first `burnin` steps are dropped; ess, rhat: HOST [dim].

@@ -228,6 +228,23 @@ class LinearGaussianLevel:
         return lp, ll, F
 
 
+class CallableGaussianLevel:
+    """Posterior.create_link (posterior.py:78-110) for an arbitrary forward model given as a batched Python callable
+    theta[N, d] -> F[N, m] (checker for the engine's source-defined models)."""
+
+    def __init__(self, fn, data, noise_kind, noise, prior):
+        self.fn = fn
+        self.prior = prior
+        self.loglike = make_loglike(noise_kind, data, noise)
+
+    def forward(self, theta):
+        return np.asarray(self.fn(theta), dtype=float)
+
+    def evaluate(self, theta):
+        F = self.forward(theta)
+        return self.prior.logpdf(theta), self.loglike(F), F
+
+
 def _acceptance(kind, lp_new, ll_new, lp_old, ll_old):
     """proposal.py:253-258 (GRW/AM/DREAMZ: posterior ratio) and :357-362 (pCN: likelihood ratio).
     posterior = prior + likelihood as in link.py:48; NaN posterior -> 0."""

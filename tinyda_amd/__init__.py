@@ -17,7 +17,7 @@ from .likelihoods import (  # noqa: F401
 )
 from .engine import Engine  # noqa: F401
 from .records import Link  # noqa: F401
-from .models import LinearModel, Rosenbrock  # noqa: F401
+from .models import DeviceModel, LinearModel, Rosenbrock  # noqa: F401
 from .target import Posterior  # noqa: F401
 from .proposals import DREAM, DREAMZ, AdaptiveMetropolis, CrankNicolson, GaussianRandomWalk, Proposal  # noqa: F401
 from .records import DeviceChain  # noqa: F401

@@ -123,13 +123,17 @@ struct DevBuf {
 
 }  // namespace
 #include "tda_diag.inc"
+#include "tda_usermodel.inc"
 namespace {
 
 struct Level {
   bool set = false;
   int m = 0, m_pad = 0, ncb = 0, noise_kind = 0;
   double var = 1.0;
-  int model = 0;  // tda::MODEL_LINEAR / MODEL_ROSENBROCK
+  int model = 0;  // tda::MODEL_LINEAR / MODEL_ROSENBROCK / MODEL_USER (hiprtc-compiled source, tda_usermodel.inc)
+  hipModule_t umod = nullptr;
+  hipFunction_t ufn = nullptr;
+  DevBuf<double> udata, uw;
   double ros_a = 1.0, ros_b = 10.0, ros_data = 0.0;
   DevBuf<double> Apk, ytil, w, Ppk;
   // adaptive error model: plain row-major copies for the wave-per-chain kernel
@@ -376,7 +380,37 @@ void fill_level(const tda_engine* e, const Level& lv, StepArgs& a) {
   a.d = e->d;
 }
 
+constexpr int MODEL_USER = 2;
+
+int fill_user_args(tda_engine* e, const Level& lv, UserStepArgs& ua) {
+  if (e->prior_kind == PRIOR_DENSE) return fail(TDA_ERR_UNSUPPORTED, "source-defined forward models need a diagonal prior covariance");
+  ua.N = e->N;
+  ua.NP = e->NP;
+  ua.d = e->d;
+  ua.DP = e->DP;
+  ua.m = lv.m;
+  ua.data = lv.udata.p;
+  ua.w = lv.noise_kind == TDA_NOISE_DIAG ? lv.uw.p : nullptr;
+  ua.var = lv.var;
+  ua.pr_mean = e->prior_mean.p;
+  ua.pr_pinv = e->prior_pinv.p;
+  ua.logconst = e->prior_logconst;
+  return TDA_OK;
+}
+
 int launch_eval(tda_engine* e, int level, double* theta, double* lp, double* ll) {
+  if (e->levels[level].model == MODEL_USER) {
+    UserStepArgs ua{};
+    int rc = fill_user_args(e, e->levels[level], ua);
+    if (rc) return rc;
+    ua.S = 1;
+    ua.mode = 1;
+    ua.theta = theta;
+    ua.lp = lp;
+    ua.ll = ll;
+    ua.scaling = e->scaling.p;
+    return launch_user_steps(e->levels[level].ufn, ua, e->stream);
+  }
   StepArgs a{};
   fill_level(e, e->levels[level], a);
   a.S = 1;
@@ -467,6 +501,8 @@ void tda_engine_destroy(tda_engine* e) {
     (void)hipEventDestroy(t.a);
     (void)hipEventDestroy(t.b);
   }
+  for (auto& lv : e->levels)
+    if (lv.umod) (void)hipModuleUnload(lv.umod);
   if (e->rng_stream) {
     (void)hipStreamSynchronize(e->rng_stream);
     (void)hipStreamDestroy(e->rng_stream);
@@ -653,6 +689,46 @@ int tda_engine_set_level_rosenbrock(tda_engine* e, int level, double a, double b
   lv.noise_kind = TDA_NOISE_ISO;
   lv.var = noise_var;
   lv.set = true;
+  return TDA_OK;
+}
+
+int tda_engine_set_level_source(tda_engine* e, int level, const char* source, int32_t m, const double* data, int32_t noise_kind,
+                                const double* noise) {
+  if (!e || !source || !data || !noise) return fail(TDA_ERR_INVALID, "null argument");
+  if (level != 0 || e->nlev != 1) return fail(TDA_ERR_UNSUPPORTED, "source-defined forward models are lowered for single-level chains only");
+  if (m < 1) return fail(TDA_ERR_INVALID, "m must be >= 1");
+  if (noise_kind != TDA_NOISE_ISO && noise_kind != TDA_NOISE_DIAG)
+    return fail(TDA_ERR_UNSUPPORTED, "source-defined forward models take isotropic or diagonal noise");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  Level& lv = e->levels[level];
+  if (lv.umod) {
+    (void)hipModuleUnload(lv.umod);
+    lv.umod = nullptr;
+    lv.ufn = nullptr;
+  }
+  int rc = compile_user_model(source, &lv.umod, &lv.ufn);
+  if (rc) return rc;
+  std::vector<double> y(data, data + m), w;
+  if (noise_kind == TDA_NOISE_ISO) {
+    if (!(noise[0] > 0.0)) return fail(TDA_ERR_NUMERIC, "noise variance must be positive");
+    lv.var = noise[0];
+  } else {
+    w.resize(m);
+    for (int i = 0; i < m; ++i) {
+      if (!(noise[i] > 0.0)) return fail(TDA_ERR_NUMERIC, "noise variance must be positive");
+      w[i] = 1.0 / noise[i];
+    }
+    lv.var = 1.0;
+    if ((rc = lv.uw.upload(w))) return rc;
+  }
+  if ((rc = lv.udata.upload(y))) return rc;
+  lv.model = MODEL_USER;
+  lv.m = m;
+  lv.m_pad = 16;  // (no MFMA staging; keeps the shared LDS-size arithmetic of the run loop valid)
+  lv.ncb = 1;
+  lv.noise_kind = noise_kind;
+  lv.set = true;
+  e->inited = false;
   return TDA_OK;
 }
 
@@ -1593,7 +1669,26 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     sa.rec_params = p_dev ? o_params + (size_t)done * N * d : ((o_params || is_am) ? e->rec_params.p : nullptr);
     sa.rec_stats = s_dev ? o_stats + (size_t)done * N * 3 : (o_stats ? e->rec_stats.p : nullptr);
     sa.rec_acc = a_dev ? o_acc + (size_t)done * N : (o_acc ? e->rec_acc.p : nullptr);
-    {
+    if (lv.model == MODEL_USER) {
+      UserStepArgs ua{};
+      int urc = fill_user_args(e, lv, ua);
+      if (urc) return urc;
+      ua.S = (int)S;
+      ua.mode = 0;
+      ua.prop_kind = e->pp.kind;
+      ua.theta = sa.theta;
+      ua.lp = sa.lp;
+      ua.ll = sa.ll;
+      ua.scaling = sa.scaling;
+      ua.acc_count = sa.acc_count;
+      ua.inc = sa.inc;
+      ua.u = sa.u;
+      ua.rec_params = sa.rec_params;
+      ua.rec_stats = sa.rec_stats;
+      ua.rec_acc = sa.rec_acc;
+      ScopedTimer tm(e, 1);
+      if ((urc = launch_user_steps(lv.ufn, ua, e->stream))) return urc;
+    } else {
       ScopedTimer tm(e, 1);
       DISPATCH_DPAD(e->DP, launch_steps<DPAD>(sa, NP / 16, lds, e->stream));
     }

@@ -69,6 +69,12 @@ class Engine:
                                      _ptr(Cm), -1.0 if sd is None else sd, epsilon, t0, int(block_moments))
         check(self.lib.tda_engine_set_proposal(self.h, C.byref(p)))
 
+    def set_level_source(self, level, source, data, noise_kind, noise):
+        """forward model as HIP source defining `__device__ double tda_forward(const double* theta, int dim, int o)`"""
+        data = _f64(np.atleast_1d(data))
+        noise = _f64(np.atleast_1d(noise))
+        check(self.lib.tda_engine_set_level_source(self.h, level, source.encode(), data.size, _ptr(data), noise_kind, _ptr(noise)))
+
     def set_level_rosenbrock(self, level, a=1.0, b=10.0, data=0.0, noise_var=1.0):
         check(self.lib.tda_engine_set_level_rosenbrock(self.h, level, a, b, data, noise_var))
 

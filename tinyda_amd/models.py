@@ -33,3 +33,25 @@ class Rosenbrock:
     def __call__(self, parameters):
         t = np.asarray(parameters, dtype=np.float64)
         return np.array([np.sum((self.a - t[:-1]) ** 2 + self.b * (t[1:] - t[:-1] ** 2) ** 2)])
+
+
+class DeviceModel:
+    """A (possibly non-linear) forward model given as HIP source, compiled at run time into the fused step kernel
+    (extension; tinyDA only knows Python callables).  The source must define
+
+        __device__ double tda_forward(const double* theta, int dim, int o);   // output o of F(theta), 0 <= o < n_outputs
+
+    `reference`, if given, is a Python callable theta -> outputs used when the model is called on the host (host
+    protocol, tests); without it the model only runs on the device."""
+
+    def __init__(self, source, n_outputs, reference=None):
+        self.source = str(source)
+        self.n_outputs = int(n_outputs)
+        self.reference = reference
+        if "tda_forward" not in self.source:
+            raise ValueError("the source must define __device__ double tda_forward(const double* theta, int dim, int o)")
+
+    def __call__(self, parameters):
+        if self.reference is None:
+            raise TypeError("this DeviceModel has no host reference implementation; run it with backend='hip'")
+        return np.atleast_1d(np.asarray(self.reference(np.asarray(parameters, dtype=np.float64)), dtype=np.float64))

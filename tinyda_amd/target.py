@@ -2,7 +2,7 @@
 import numpy as np
 
 from .records import Link
-from .models import LinearModel, Rosenbrock
+from .models import DeviceModel, LinearModel, Rosenbrock
 
 
 class Posterior:
@@ -48,7 +48,7 @@ class Posterior:
             cov = prior.cov_object.covariance
         if mean is None or cov is None or not hasattr(prior, "logpdf"):
             return None
-        if not isinstance(self.model, (LinearModel, Rosenbrock)) or not hasattr(self.likelihood, "_lowering"):
+        if not isinstance(self.model, (LinearModel, Rosenbrock, DeviceModel)) or not hasattr(self.likelihood, "_lowering"):
             return None
         mean = np.atleast_1d(np.asarray(mean, dtype=np.float64))
         cov = np.atleast_2d(np.asarray(cov, dtype=np.float64))
@@ -59,6 +59,13 @@ class Posterior:
                 return None
             return dict(prior_mean=mean, prior_cov=cov, rosenbrock=(self.model.a, self.model.b), A=None, b=None, data=data,
                         noise_kind=kind, noise=np.asarray(noise, dtype=np.float64).reshape(1))
+        if isinstance(self.model, DeviceModel):
+            kind, noise = self.likelihood._lowering()
+            data = np.atleast_1d(np.asarray(self.likelihood.data, dtype=np.float64))
+            if data.shape != (self.model.n_outputs,):
+                return None
+            return dict(prior_mean=mean, prior_cov=cov, source=self.model.source, A=None, b=None, data=data,
+                        noise_kind=kind, noise=np.asarray(noise, dtype=np.float64))
         if self.model.A.shape[1] != mean.shape[0]:
             return None
         kind, noise = self.likelihood._lowering()
