@@ -249,6 +249,12 @@ int64_t tda_engine_state_size(tda_engine* e);
 int tda_engine_get_state(tda_engine* e, void* blob, int64_t bytes);
 int tda_engine_set_state(tda_engine* e, const void* blob, int64_t bytes);
 
+/* JointPrior of independent scalar components (distributions.py:8-100) instead of a multivariate normal: kind[j] = 0 is
+ * scipy.stats.norm(loc[j], scale[j]), kind[j] = 1 scipy.stats.uniform(loc[j], scale[j]) (density 1/scale on
+ * [loc, loc + scale], log-density -inf outside: such proposals are rejected).  HOST arrays [dim].  Single-level chains,
+ * GRW / AM, iso / diag noise (also with tda_engine_set_level_source); explicit initial parameters. */
+int tda_engine_set_prior_joint(tda_engine* e, const int32_t* kind, const double* loc, const double* scale);
+
 /* Forward model given as HIP source (extension; the reference calls a Python callable per chain and step,
  * posterior.py:95-96).  The source must define
  *     __device__ double tda_forward(const double* theta, int dim, int o);     // output o of F(theta), o in [0, m)

@@ -208,6 +208,27 @@ def zero_mean_moments_update(sigma, t, x):
 # ----------------------------------------------------------------------------------------
 # single-level Metropolis-Hastings (chain.py:37-129) with GRW / pCN / AM proposals
 # ----------------------------------------------------------------------------------------
+class JointPriorOracle:
+    """JointPrior.logpdf (distributions.py:45-58): the sum over components, in parameter order, of scipy's scalar
+    log-densities; kinds[j] 0 = norm(loc, scale), 1 = uniform(loc, scale)."""
+
+    def __init__(self, kinds, loc, scale):
+        import scipy.stats as stats
+
+        self.kinds, self.loc, self.scale = np.asarray(kinds), np.asarray(loc, dtype=float), np.asarray(scale, dtype=float)
+        self.comps = [stats.norm(l, s) if k == 0 else stats.uniform(l, s) for k, l, s in zip(self.kinds, self.loc, self.scale)]
+        self.mean = np.where(self.kinds == 0, self.loc, self.loc + 0.5 * self.scale)
+        self.cov = np.diag(np.where(self.kinds == 0, self.scale ** 2, self.scale ** 2 / 12.0))
+
+    def logpdf(self, theta):
+        theta = np.atleast_2d(theta)
+        out = np.zeros(theta.shape[0])
+        with np.errstate(divide="ignore"):
+            for j, c in enumerate(self.comps):  # sum([...]) in the reference: left to right from 0
+                out = out + c.logpdf(theta[:, j])
+        return out
+
+
 class LinearGaussianLevel:
     """Posterior.create_link (posterior.py:78-110) for model F = A theta (+ b)."""
 

@@ -668,6 +668,32 @@ def g8_mlda_aem(name, d=4, m=8, sl=(3, 2), iters=30, n_chains=4, seed=811):
          n_levels=np.array(nl), aem=np.array("state-independent"), **lv, **flat, **{k: np.array(v) for k, v in out.items()})
 
 
+def g10_jointprior():
+    """JointPrior (distributions.py:8-100) of scalar normal and uniform components under a random-walk chain whose
+    proposals leave the uniform supports now and then (log-prior -inf -> rejected), plus log-density known answers."""
+    d, m = 5, 12
+    A, theta_true, y = linear_problem(1001, d, m, sigma=0.2)
+    kinds = np.array([0, 1, 0, 1, 1])                      # 0 = norm(loc, scale), 1 = uniform(loc, scale)
+    loc = np.array([0.3, -1.0, -0.5, -2.0, 0.0])
+    scale = np.array([1.5, 2.0, 0.7, 4.0, 1.0])
+    comps = [stats.norm(loc[j], scale[j]) if kinds[j] == 0 else stats.uniform(loc[j], scale[j]) for j in range(d)]
+    prior = tda.JointPrior(comps)
+    like = tda.GaussianLogLike(y, 0.04 * np.eye(m))
+    post = tda.Posterior(prior, like, make_model(A))
+    prop = tda.GaussianRandomWalk(C=0.3 * np.eye(d), scaling=1.0, adaptive=True, gamma=1.01, period=25)
+    rs = np.random.RandomState(5)
+    n_chains = 4
+    theta0 = np.array([[loc[j] + (0.2 + 0.6 * rs.rand()) * scale[j] if kinds[j] else loc[j] + 0.3 * rs.randn() for j in range(d)]
+                       for _ in range(n_chains)])
+    res, snaps = run_mh(post, prop, theta0, 150, n_chains, seed=1011, snapshot={"period": 25, "fn": lambda p: (p.scaling, p.k, p.t)})
+    pts = np.concatenate([theta0, theta0 + rs.randn(n_chains, d) * 1.5, loc[None, :] + scale[None, :] * np.array([[0.0, 0.0, 1.0, 1.0, 0.5]])])
+    kat = np.array([prior.logpdf(x) for x in pts])
+    assert np.isinf(res["logprior"]).sum() == 0 and (res["accepted"] == 0).sum() > 0
+    save("g10_jointprior", A=A, data=y, noise_var=np.array(0.04), kinds=kinds, loc=loc, scale=scale, C=0.3 * np.eye(d),
+         scaling0=np.array(1.0), gamma=np.array(1.01), period=np.array(25), theta0=theta0,
+         scaling_hist=np.array(snaps)[:, :, 0], kat_points=pts, kat_logpdf=kat, **res)
+
+
 FIXTURES = {
     "g1_basic_sampler": g1_basic_sampler,
     "g2_am_small": lambda: g2_am("g2_am_small", d=8, m=16, n_chains=8, iters=128, t0=16, period=16, seed=201),
@@ -701,6 +727,7 @@ FIXTURES = {
     "g5_mlda_4level": lambda: g5_mlda("g5_mlda_4level", "am", ms=(6, 10, 16, 24), sl=(3, 2, 2), iters=20, period=10, seed=503),
     "g7_moments": g7_moments,
     "g9_mvn_logpdf": g9_mvn_logpdf,
+    "g10_jointprior": g10_jointprior,
 }
 
 if __name__ == "__main__":

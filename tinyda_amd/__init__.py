@@ -9,6 +9,7 @@ from ._lib import EngineError  # noqa: F401
 from .hostloop import Chain  # noqa: F401
 from .summaries import ess_bulk, ess_summary, get_samples, rhat, to_inference_data  # noqa: F401
 from .likelihoods import (  # noqa: F401
+    JointPrior,
     AdaptiveGaussianLogLike,
     DefaultGaussianLogLike,
     DiagonalGaussianLogLike,

@@ -110,6 +110,7 @@ SYMBOLS = {
     "tda_engine_set_archive_auto_append": (C.c_int, [_P, C.c_int]),
     "tda_engine_reduce_moments": (C.c_int, [_P, _P, C.c_int64, _P]),
     "tda_engine_set_proposal_covariance": (C.c_int, [_P, _P]),
+    "tda_engine_set_prior_joint": (C.c_int, [_P, _P, _P, _P]),
     "tda_engine_set_level_source": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_int32, _P, C.c_int32, _P]),
     "tda_diag_ess_rhat": (C.c_int, [C.c_int, _P, _P, C.c_int64, C.c_int64, C.c_int32, C.c_int64, _P, _P]),
     "tda_engine_state_size": (C.c_int64, [_P]),

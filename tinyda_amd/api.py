@@ -39,6 +39,11 @@ def _device_plan(posteriors, proposal):
         return None  # DREAMZ below an MLDA hierarchy is not lowered yet
     if any("rosenbrock" in low for low in lows) and not isinstance(proposal, DREAMZ):
         return None  # the Rosenbrock model is fused into the DREAMZ kernel only
+    if any("prior_joint" in low for low in lows):  # JointPrior: single level, GRW / AM, iso / diag noise, linear or source model
+        low = lows[0]
+        if (len(posteriors) != 1 or isinstance(proposal, (DREAMZ, CrankNicolson)) or "rosenbrock" in low
+                or low["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG)):
+            return None
     if any("source" in low for low in lows):  # source-defined models: single level, GRW / pCN / AM, iso / diag noise, diagonal prior
         low = lows[0]
         if len(posteriors) != 1 or isinstance(proposal, DREAMZ) or low["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG):
@@ -160,7 +165,12 @@ def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, se
         seed = int(np.random.randint(0, 2 ** 31 - 1))
     eng = Engine(n_chains, d, seed=seed, device=device, chain_offset=chain_offset)
     try:
-        eng.set_prior(low["prior_mean"], low["prior_cov"])
+        if "prior_joint" in low:
+            eng.set_prior_joint(*low["prior_joint"])
+            if initial_parameters is None:  # sampler.py:209: theta0 ~ prior; uniform components are drawn on the host
+                initial_parameters = [posterior.prior.rvs() for _ in range(n_chains)]
+        else:
+            eng.set_prior(low["prior_mean"], low["prior_cov"])
         if "rosenbrock" in low:
             eng.set_level_rosenbrock(0, low["rosenbrock"][0], low["rosenbrock"][1], float(low["data"][0]), float(low["noise"][0]))
         elif "source" in low:

@@ -160,8 +160,10 @@ struct tda_engine {
   bool prior_set = false;
   int prior_kind = tda::PRIOR_DIAG;
   bool prior_is_standard = false;  // N(0, I): the single-level tile kernel skips the constant loads
+  bool prior_bounded = false;      // JointPrior with uniform components: support bounds in prior_lo / prior_hi
   double prior_logconst = 0.0;
   std::vector<double> prior_mean_h, prior_cov_h, prior_L_h;
+  DevBuf<double> prior_lo, prior_hi;
   DevBuf<double> prior_mean, prior_pinv, prior_Wpk, prior_wmu;
   int prior_ncb = 0;
 
@@ -375,6 +377,8 @@ void fill_level(const tda_engine* e, const Level& lv, StepArgs& a) {
   a.pr.ncb = e->prior_ncb;
   a.pr.kind = (e->prior_kind == PRIOR_DIAG && e->prior_is_standard) ? PRIOR_STANDARD : e->prior_kind;
   a.pr.logconst = e->prior_logconst;
+  a.pr.lo = e->prior_bounded ? e->prior_lo.p : nullptr;
+  a.pr.hi = e->prior_bounded ? e->prior_hi.p : nullptr;
   a.N = e->N;
   a.NP = e->NP;
   a.d = e->d;
@@ -394,6 +398,8 @@ int fill_user_args(tda_engine* e, const Level& lv, UserStepArgs& ua) {
   ua.var = lv.var;
   ua.pr_mean = e->prior_mean.p;
   ua.pr_pinv = e->prior_pinv.p;
+  ua.pr_lo = e->prior_bounded ? e->prior_lo.p : nullptr;
+  ua.pr_hi = e->prior_bounded ? e->prior_hi.p : nullptr;
   ua.logconst = e->prior_logconst;
   return TDA_OK;
 }
@@ -564,6 +570,51 @@ int tda_engine_set_prior(tda_engine* e, const double* mean, const double* cov) {
   }
   if ((rc = e->prior_pinv.upload(ph))) return rc;
   e->prior_logconst = d * std::log(2.0 * M_PI) + logdet;
+  e->prior_bounded = false;
+  e->prior_set = true;
+  return TDA_OK;
+}
+
+int tda_engine_set_prior_joint(tda_engine* e, const int32_t* kind, const double* loc, const double* scale) {
+  if (!e || !kind || !loc || !scale) return fail(TDA_ERR_INVALID, "null argument");
+  if (e->nlev != 1) return fail(TDA_ERR_UNSUPPORTED, "joint priors are lowered for single-level chains only");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const int d = e->d, DP = e->DP;
+  std::vector<double> mh(DP, 0.0), ph(DP, 0.0), lo(DP, -INFINITY), hi(DP, INFINITY);
+  e->prior_mean_h.assign(d, 0.0);
+  e->prior_cov_h.assign((size_t)d * d, 0.0);
+  e->prior_L_h.assign((size_t)d * d, 0.0);
+  double logconst = 0.0;
+  bool bounded = false;
+  for (int j = 0; j < d; ++j) {
+    if (!(scale[j] > 0.0)) return fail(TDA_ERR_NUMERIC, "prior component %d: scale must be positive", j);
+    if (kind[j] == 0) {  // scipy.stats.norm(loc, scale)
+      mh[j] = loc[j];
+      ph[j] = 1.0 / (scale[j] * scale[j]);
+      logconst += std::log(2.0 * M_PI) + 2.0 * std::log(scale[j]);
+      e->prior_mean_h[j] = loc[j];
+      e->prior_cov_h[(size_t)j * d + j] = scale[j] * scale[j];
+      e->prior_L_h[(size_t)j * d + j] = scale[j];
+    } else if (kind[j] == 1) {  // scipy.stats.uniform(loc, scale): density 1/scale on [loc, loc + scale]
+      lo[j] = loc[j];
+      hi[j] = loc[j] + scale[j];
+      logconst += 2.0 * std::log(scale[j]);
+      bounded = true;
+      e->prior_mean_h[j] = loc[j] + 0.5 * scale[j];
+      e->prior_cov_h[(size_t)j * d + j] = scale[j] * scale[j] / 12.0;
+      e->prior_L_h[(size_t)j * d + j] = scale[j] / std::sqrt(12.0);
+    } else {
+      return fail(TDA_ERR_UNSUPPORTED, "prior component %d: kind %d (0 = normal, 1 = uniform)", j, (int)kind[j]);
+    }
+  }
+  int rc;
+  if ((rc = e->prior_mean.upload(mh)) || (rc = e->prior_pinv.upload(ph)) || (rc = e->prior_lo.upload(lo)) || (rc = e->prior_hi.upload(hi)))
+    return rc;
+  e->prior_kind = PRIOR_DIAG;
+  e->prior_is_standard = false;
+  e->prior_ncb = 0;
+  e->prior_logconst = logconst;
+  e->prior_bounded = bounded;
   e->prior_set = true;
   return TDA_OK;
 }
@@ -1139,6 +1190,12 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
   if (!e->prior_set || !e->prop_set) return fail(TDA_ERR_STATE, "set_prior and set_proposal must precede init");
   for (auto& lv : e->levels)
     if (!lv.set) return fail(TDA_ERR_STATE, "set_level missing");
+  if (e->prior_bounded) {  // JointPrior with uniform components
+    if (e->nlev != 1 || e->is_dreamz) return fail(TDA_ERR_UNSUPPORTED, "priors with uniform components: single-level GRW / AM only");
+    if (e->pp.kind == TDA_PROP_PCN) return fail(TDA_ERR_UNSUPPORTED, "pCN needs a Gaussian prior");
+    if (e->levels[0].noise_kind == TDA_NOISE_DENSE) return fail(TDA_ERR_UNSUPPORTED, "priors with uniform components: iso / diag noise only");
+    if (!theta0) return fail(TDA_ERR_INVALID, "priors with uniform components need explicit initial parameters");
+  }
   HIP_TRY(hipSetDevice(e->cfg.device));
   const int d = e->d, DP = e->DP;
   const int64_t N = e->N, NP = e->NP;

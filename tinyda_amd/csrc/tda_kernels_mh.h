@@ -48,7 +48,9 @@ struct PriorDev {
   const double* wmu;   // PRIOR_DENSE: W mean, [ncb*16]
   int ncb;
   int kind;
-  double logconst;  // d*log(2 pi) + log det cov
+  double logconst;  // d*log(2 pi) + log det cov  (JointPrior: + 2 log(width) per uniform component)
+  const double* lo;  // JointPrior with uniform components (distributions.py:8-100): support [lo_j, hi_j] per parameter
+  const double* hi;  // (+-inf for normal components), null when unbounded; outside the support log-prior = -inf
 };
 
 struct StepArgs {
@@ -557,6 +559,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
       for (int kk = 0; kk < KS; ++kk) {
         const double dv = th[kk] - s_pm[4 * kk + hi];
         p += dv * dv * s_pinv[4 * kk + hi];
+      }
+      if (a.pr.lo) {  // uniform components: zero density outside their support (rare path, bounds read through L1)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+          if (th[kk] < a.pr.lo[4 * kk + hi] || th[kk] > a.pr.hi[4 * kk + hi]) p = INFINITY;
       }
       p = sum_rows(p);
       maha = p;

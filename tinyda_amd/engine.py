@@ -69,6 +69,13 @@ class Engine:
                                      _ptr(Cm), -1.0 if sd is None else sd, epsilon, t0, int(block_moments))
         check(self.lib.tda_engine_set_proposal(self.h, C.byref(p)))
 
+    def set_prior_joint(self, kinds, loc, scale):
+        """JointPrior of scalar components: kinds[j] 0 = norm(loc, scale), 1 = uniform(loc, scale)"""
+        kinds = np.ascontiguousarray(np.asarray(kinds, dtype=np.int32))
+        loc, scale = _f64(loc), _f64(scale)
+        assert kinds.shape == loc.shape == scale.shape == (self.dim,)
+        check(self.lib.tda_engine_set_prior_joint(self.h, _ptr(kinds), _ptr(loc), _ptr(scale)))
+
     def set_level_source(self, level, source, data, noise_kind, noise):
         """forward model as HIP source defining `__device__ double tda_forward(const double* theta, int dim, int o)`"""
         data = _f64(np.atleast_1d(data))

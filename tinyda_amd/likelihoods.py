@@ -106,3 +106,39 @@ def GaussianLogLike(data, covariance):
             return IsotropicGaussianLogLike(data, covariance[0, 0])
         return DiagonalGaussianLogLike(data, covariance)
     return DefaultGaussianLogLike(data, covariance)
+
+
+class JointPrior:
+    """A list of independent scalar priors, one per parameter, in parameter order (tinyDA/distributions.py:8-100)."""
+
+    def __init__(self, distributions):
+        self.distributions = distributions
+        self.dim = len(distributions)
+
+    def logpdf(self, x):
+        return sum([self.distributions[i].logpdf(x[i]) for i in range(self.dim)])
+
+    def rvs(self, n_samples=1):
+        x = np.zeros((n_samples, self.dim))
+        for i in range(self.dim):
+            x[:, i] = self.distributions[i].rvs(size=n_samples)
+        return x.flatten() if n_samples == 1 else x
+
+    def ppf(self, x):
+        y = np.zeros(x.shape)
+        for i in range(self.dim):
+            y[:, i] = self.distributions[i].ppf(x[:, i])
+        return y
+
+    def _lowering(self):
+        """(kinds, loc, scale) when every component is a frozen scipy norm or uniform, else None."""
+        kinds, loc, scale = [], [], []
+        for dist in self.distributions:
+            name = getattr(getattr(dist, "dist", None), "name", None)
+            if name not in ("norm", "uniform"):
+                return None
+            _, l, s = dist.dist._parse_args(*dist.args, **dist.kwds)
+            kinds.append(0 if name == "norm" else 1)
+            loc.append(float(l))
+            scale.append(float(s))
+        return np.array(kinds, dtype=np.int32), np.array(loc), np.array(scale)

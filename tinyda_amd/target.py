@@ -42,12 +42,26 @@ class Posterior:
         """What the HIP engine needs, or None when this posterior only runs through the host protocol
         (opaque Python model, non-Gaussian prior, ...)."""
         prior = self.prior
+        joint = None
+        if hasattr(prior, "distributions") and hasattr(prior, "_lowering"):  # JointPrior of scalar norm / uniform components
+            joint = prior._lowering()
+            if joint is None:
+                return None
+            kinds, loc, scale = joint
+            low = self._lowering_with(np.where(kinds == 0, loc, loc + 0.5 * scale),
+                                      np.diag(np.where(kinds == 0, scale ** 2, scale ** 2 / 12.0)))
+            if low is not None:
+                low["prior_joint"] = joint
+            return low
         mean = getattr(prior, "mean", None)
         cov = getattr(prior, "cov", None)
         if cov is None and hasattr(prior, "cov_object"):
             cov = prior.cov_object.covariance
         if mean is None or cov is None or not hasattr(prior, "logpdf"):
             return None
+        return self._lowering_with(mean, cov)
+
+    def _lowering_with(self, mean, cov):
         if not isinstance(self.model, (LinearModel, Rosenbrock, DeviceModel)) or not hasattr(self.likelihood, "_lowering"):
             return None
         mean = np.atleast_1d(np.asarray(mean, dtype=np.float64))
