@@ -67,7 +67,10 @@ typedef enum tda_noise_kind {
 typedef enum tda_error_model { TDA_AEM_NONE = 0, TDA_AEM_STATE_INDEPENDENT = 1, TDA_AEM_STATE_DEPENDENT = 2 } tda_error_model;
 
 /* tinyDA/proposal.py: GaussianRandomWalk :132, CrankNicolson :261, AdaptiveMetropolis :372, DREAMZ :608 / DREAM :1627 */
-typedef enum tda_proposal_kind { TDA_PROP_GRW = 0, TDA_PROP_PCN = 1, TDA_PROP_AM = 2, TDA_PROP_DREAMZ = 3 } tda_proposal_kind;
+typedef enum tda_proposal_kind {
+  TDA_PROP_GRW = 0, TDA_PROP_PCN = 1, TDA_PROP_AM = 2, TDA_PROP_DREAMZ = 3,
+  TDA_PROP_INDEPENDENCE = 4 /* IndependenceSampler with a Gaussian q (proposal.py:65-129) */
+} tda_proposal_kind;
 
 typedef struct tda_config {
   uint32_t struct_size;  /* sizeof(tda_config) */
@@ -101,6 +104,8 @@ typedef struct tda_proposal_params {
                           * update per block of steps on the matrix cores -- algebraically identical, free of the
                           * reference form's cancellation, ~8x cheaper; deviates from the reference recursion by that
                           * recursion's rounding error (1e-11 .. 1e-8 relative in Sigma on ill-conditioned chains). */
+  const double* q_mean; /* INDEPENDENCE: HOST [d] mean of q = N(q_mean, C); proposals are q_mean + chol(C) z, accepted with
+                         * exp(post' - post + log q(theta) - log q(theta')); no adaptation.  NULL otherwise. */
 } tda_proposal_params;
 
 /* DREAMZ / DREAM constructor arguments (proposal.py:663-742, :1627-1641). */

@@ -313,12 +313,18 @@ def run_mh(level, proposal, theta0, z, u):
         t0 = int(proposal.get("t0", 0))
         am_mu = theta0.copy()  # proposal.py:495-500
         am_sigma = np.zeros((N, d, d))
+    elif kind == "indep":  # IndependenceSampler with q = N(q_mean, q_cov)  (proposal.py:65-129); never adapts
+        q = MVNPrior(proposal["q_mean"], proposal["q_cov"])
+        C = np.broadcast_to(q.cov, (N, d, d)).copy()
+        scaling = np.ones(N)
+        adaptive = False
     else:
         raise ValueError(kind)
     L = np.linalg.cholesky(C)
 
     theta = theta0.copy()
     lp, ll, _ = level.evaluate(theta)
+    lq = q.logpdf(theta) if kind == "indep" else None
     out_theta = np.empty((N, T + 1, d))
     out_lp = np.empty((N, T + 1))
     out_ll = np.empty((N, T + 1))
@@ -332,11 +338,20 @@ def run_mh(level, proposal, theta0, z, u):
         inc = np.einsum("nij,nj->ni", L, z[:, s])
         if kind == "pcn":
             prop = np.sqrt(1 - scaling ** 2)[:, None] * theta + scaling[:, None] * inc  # proposal.py:351-355
+        elif kind == "indep":
+            prop = q.mean[None, :] + inc  # q.rvs (proposal.py:113-115) through the Cholesky map of the variate tap
         else:
             prop = theta + scaling[:, None] * inc  # proposal.py:249-251
         lp_n, ll_n, _ = level.evaluate(prop)
-        alpha = _acceptance(kind, lp_n, ll_n, lp, ll)
+        if kind == "indep":  # proposal.py:117-123: exp(post' - post + q(prev) - q(prop))
+            lq_n = q.logpdf(prop)
+            with np.errstate(over="ignore", invalid="ignore"):
+                alpha = np.exp((lp_n + ll_n) - (lp + ll) + lq - lq_n)
+        else:
+            alpha = _acceptance(kind, lp_n, ll_n, lp, ll)
         acc = u[:, s] < alpha  # chain.py:112
+        if kind == "indep":
+            lq = np.where(acc, lq_n, lq)
         theta = np.where(acc[:, None], prop, theta)
         lp = np.where(acc, lp_n, lp)
         ll = np.where(acc, ll_n, ll)

@@ -694,6 +694,43 @@ def g10_jointprior():
          scaling_hist=np.array(snaps)[:, :, 0], kat_points=pts, kat_logpdf=kat, **res)
 
 
+class _MVNq:
+    """q for IndependenceSampler: draws through np.random.multivariate_normal (so the tap records the normals and maps
+    them through chol(cov)), log-density from scipy."""
+
+    def __init__(self, mean, cov):
+        self.mean, self.cov = np.asarray(mean, dtype=float), np.asarray(cov, dtype=float)
+        self._dist = stats.multivariate_normal(self.mean, self.cov)
+
+    def rvs(self, n):
+        return np.random.multivariate_normal(self.mean, self.cov)[None, :]
+
+    def logpdf(self, x):
+        return self._dist.logpdf(x)
+
+
+def g12_independence():
+    """IndependenceSampler (proposal.py:65-129) with a Gaussian q centred near the posterior."""
+    d, m = 4, 10
+    A, theta_true, y = linear_problem(1201, d, m, sigma=0.3)
+    prior = stats.multivariate_normal(np.zeros(d), np.eye(d))
+    like = tda.GaussianLogLike(y, 0.09 * np.eye(m))
+    post = tda.Posterior(prior, like, make_model(A))
+    cov_post = np.linalg.inv(A.T @ A / 0.09 + np.eye(d))
+    mean_post = cov_post @ (A.T @ y / 0.09)
+    rs = np.random.RandomState(12)
+    B = rs.randn(d, d) * 0.15
+    q_mean = mean_post + 0.1 * rs.randn(d)
+    q_cov = 2.0 * cov_post + B @ B.T
+    prop = tda.IndependenceSampler(_MVNq(q_mean, q_cov))
+    n_chains = 4
+    theta0 = mean_post[None, :] + 0.3 * rs.randn(n_chains, d)
+    res, _ = run_mh(post, prop, theta0, 120, n_chains, seed=1211)
+    assert 0.1 < res["accepted"][:, 1:].mean() < 0.9
+    save("g12_independence", A=A, data=y, noise_var=np.array(0.09), prior_mean=np.zeros(d), prior_cov=np.eye(d),
+         q_mean=q_mean, q_cov=q_cov, theta0=theta0, **res)
+
+
 FIXTURES = {
     "g1_basic_sampler": g1_basic_sampler,
     "g2_am_small": lambda: g2_am("g2_am_small", d=8, m=16, n_chains=8, iters=128, t0=16, period=16, seed=201),
@@ -728,6 +765,7 @@ FIXTURES = {
     "g7_moments": g7_moments,
     "g9_mvn_logpdf": g9_mvn_logpdf,
     "g10_jointprior": g10_jointprior,
+    "g12_independence": g12_independence,
 }
 
 if __name__ == "__main__":

@@ -41,7 +41,7 @@ def test_struct_sizes_match_header(lib):
     import ctypes as C
 
     assert C.sizeof(lib.tda_config) == 56
-    assert C.sizeof(lib.tda_proposal_params) == 64
+    assert C.sizeof(lib.tda_proposal_params) == 72  # + q_mean (independence sampler)
     assert C.sizeof(lib.tda_outputs) == 32
     assert C.sizeof(lib.tda_profile) == 48
 

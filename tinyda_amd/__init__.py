@@ -20,7 +20,8 @@ from .engine import Engine  # noqa: F401
 from .records import Link  # noqa: F401
 from .models import DeviceModel, LinearModel, Rosenbrock  # noqa: F401
 from .target import Posterior  # noqa: F401
-from .proposals import DREAM, DREAMZ, AdaptiveMetropolis, CrankNicolson, GaussianRandomWalk, Proposal  # noqa: F401
+from .proposals import (  # noqa: F401
+    DREAM, DREAMZ, AdaptiveMetropolis, CrankNicolson, GaussianRandomWalk, IndependenceSampler, Proposal)
 from .records import DeviceChain  # noqa: F401
 from .api import sample  # noqa: F401
 from .moments import RecursiveSampleMoments, ZeroMeanRecursiveSampleMoments  # noqa: F401

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtinyda_hip.so")
 TDA_OK = 0
 NOISE_ISO, NOISE_DIAG, NOISE_DENSE, NOISE_ADAPTIVE = 0, 1, 2, 3
 AEM_NONE, AEM_STATE_INDEPENDENT, AEM_STATE_DEPENDENT = 0, 1, 2
-PROP_GRW, PROP_PCN, PROP_AM, PROP_DREAMZ = 0, 1, 2, 3
+PROP_GRW, PROP_PCN, PROP_AM, PROP_DREAMZ, PROP_INDEPENDENCE = 0, 1, 2, 3, 4
 
 
 class EngineError(RuntimeError):
@@ -47,6 +47,7 @@ class tda_proposal_params(C.Structure):
         ("epsilon", C.c_double),
         ("t0", C.c_int32),
         ("block_moments", C.c_int32),
+        ("q_mean", C.c_void_p),
     ]
 
 

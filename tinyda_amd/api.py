@@ -11,10 +11,10 @@ import scipy.stats as stats
 
 from . import _lib
 from .hostloop import Chain
-from .proposals import DREAM, DREAMZ, AdaptiveMetropolis, CrankNicolson, GaussianRandomWalk
+from .proposals import DREAM, DREAMZ, AdaptiveMetropolis, CrankNicolson, GaussianRandomWalk, IndependenceSampler
 from .records import DeviceChain
 
-_DEVICE_PROPOSALS = (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis, DREAMZ, DREAM)
+_DEVICE_PROPOSALS = (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis, DREAMZ, DREAM, IndependenceSampler)
 
 
 MAX_LEVELS = 4
@@ -49,6 +49,9 @@ def _device_plan(posteriors, proposal):
         if len(posteriors) != 1 or isinstance(proposal, DREAMZ) or low["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG):
             return None
         if np.count_nonzero(low["prior_cov"] - np.diag(np.diag(low["prior_cov"]))):
+            return None
+    if isinstance(proposal, IndependenceSampler):  # Gaussian q, single level, linear model
+        if len(posteriors) != 1 or proposal._lowering() is None or "source" in lows[0] or "rosenbrock" in lows[0]:
             return None
     for low in lows[1:]:  # one prior for the hierarchy (every tinyDA example shares it across levels)
         if not (np.array_equal(low["prior_mean"], lows[0]["prior_mean"]) and np.array_equal(low["prior_cov"], lows[0]["prior_cov"])):

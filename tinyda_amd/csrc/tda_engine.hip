@@ -172,7 +172,8 @@ struct tda_engine {
   // proposal
   bool prop_set = false;
   tda_proposal_params pp{};
-  std::vector<double> prop_C_h;
+  std::vector<double> prop_C_h, q_mean_h;  // q_mean_h: independence sampler
+  DevBuf<double> q_mean_d, lq, qzblk, qzblk2[2];
   double am_sd = 1.0;
   bool L_shared = true;
   DevBuf<double> Lk, am_mu, am_sigma, scaling;
@@ -265,15 +266,19 @@ void launch_steps(const StepArgs& a, int64_t tiles, size_t lds, hipStream_t st) 
   }
   // dense noise keeps a 128 KiB residual tile and long MFMA chains per wave: 4 waves (512 registers) there
   const bool eight = g_steps_waves == 8 && a.lv.noise_kind != TDA_NOISE_DENSE;
+  const bool ind = a.prop_kind == TDA_PROP_INDEPENDENCE;
+  auto go = [&](auto kern, unsigned threads, size_t bytes) {
+    if (bytes > 64 * 1024)  // beyond the default dynamic-LDS window (gfx950 has 160 KiB per CU)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(threads), bytes, st, a);
+  };
   if (eight) {
     const size_t l8 = lds + 2 * 64 * sizeof(double);  // two more [4][16] reduction slabs
-    if (l8 > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mh_steps<DPAD, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l8);
-    hipLaunchKernelGGL((k_mh_steps<DPAD, 8>), dim3((unsigned)tiles), dim3(512), l8, st, a);
+    if (ind) go(&k_mh_steps<DPAD, 8, true>, 512, l8);
+    else go(&k_mh_steps<DPAD, 8, false>, 512, l8);
   } else {
-    if (lds > 64 * 1024)  // beyond the default dynamic-LDS window (gfx950 has 160 KiB per CU)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mh_steps<DPAD, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_mh_steps<DPAD, 4>), dim3((unsigned)tiles), dim3(256), lds, st, a);
+    if (ind) go(&k_mh_steps<DPAD, 4, true>, 256, lds);
+    else go(&k_mh_steps<DPAD, 4, false>, 256, lds);
   }
 }
 template <int DPAD>
@@ -712,10 +717,19 @@ int tda_engine_set_level(tda_engine* e, int level, int m, const double* A, const
 int tda_engine_set_proposal(tda_engine* e, const tda_proposal_params* p) {
   if (!e || !p) return fail(TDA_ERR_INVALID, "null argument");
   if (p->struct_size != sizeof(tda_proposal_params)) return fail(TDA_ERR_INVALID, "tda_proposal_params.struct_size mismatch");
-  if (p->kind < TDA_PROP_GRW || p->kind > TDA_PROP_AM) return fail(TDA_ERR_UNSUPPORTED, "proposal kind %d", p->kind);
-  if ((p->kind == TDA_PROP_GRW || p->kind == TDA_PROP_AM) && !p->C) return fail(TDA_ERR_INVALID, "proposal covariance missing");
+  const bool indep = p->kind == TDA_PROP_INDEPENDENCE;
+  if ((p->kind < TDA_PROP_GRW || p->kind > TDA_PROP_AM) && !indep) return fail(TDA_ERR_UNSUPPORTED, "proposal kind %d", p->kind);
+  if ((p->kind == TDA_PROP_GRW || p->kind == TDA_PROP_AM || indep) && !p->C) return fail(TDA_ERR_INVALID, "proposal covariance missing");
+  if (indep && !p->q_mean) return fail(TDA_ERR_INVALID, "independence sampler: q_mean missing");
+  if (indep && e->nlev != 1) return fail(TDA_ERR_UNSUPPORTED, "the independence sampler is lowered for single-level chains only");
   if (p->period < 1) return fail(TDA_ERR_INVALID, "period must be >= 1");
   e->pp = *p;
+  e->pp.q_mean = nullptr;
+  if (indep) {  // never adapts (proposal.py:107-111); scaling plays no role
+    e->pp.adaptive = 0;
+    e->pp.scaling = 1.0;
+    e->q_mean_h.assign(p->q_mean, p->q_mean + e->d);
+  }
   if (p->C) e->prop_C_h.assign(p->C, p->C + (size_t)e->d * e->d);
   e->pp.C = nullptr;
   e->am_sd = p->sd > 0.0 ? p->sd : std::min(1.0, 2.4 * 2.4 / e->d);
@@ -982,6 +996,7 @@ void enumerate_state(tda_engine* e, std::vector<StateItem>& v) {
   dev(e->Lk);
   dev(e->am_mu);
   dev(e->am_sigma);
+  dev(e->lq);
   if (e->nlev > 1) {
     host(e->cnt, sizeof e->cnt);
     host(e->done, sizeof e->done);
@@ -1227,9 +1242,36 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
     theta0 = th0.data();
   }
   if ((rc = upload_states(e, theta0, N, e->theta.p))) return rc;
+  if (e->pp.kind == TDA_PROP_INDEPENDENCE) {
+    // log q(theta0) up to q's constant: -|L^-1 (theta0 - q_mean)|^2 / 2 (the kernels carry -|z|^2 / 2 for proposals)
+    std::vector<double> Lq, th_h;
+    if (!cholesky_host(e->prop_C_h.data(), d, Lq)) return fail(TDA_ERR_NUMERIC, "proposal covariance is not positive definite");
+    const double* hs = theta0;
+    if (is_device_ptr(theta0)) {
+      th_h.resize((size_t)N * d);
+      HIP_TRY(hipMemcpy(th_h.data(), theta0, th_h.size() * sizeof(double), hipMemcpyDeviceToHost));
+      hs = th_h.data();
+    }
+    std::vector<double> lq0(NP, 0.0), w(d), qm(DP, 0.0);
+    for (int64_t c = 0; c < N; ++c) {
+      double s2 = 0.0;
+      for (int i = 0; i < d; ++i) {
+        double s = hs[(size_t)c * d + i] - e->q_mean_h[i];
+        for (int k = 0; k < i; ++k) s -= Lq[(size_t)i * d + k] * w[k];
+        w[i] = s / Lq[(size_t)i * d + i];
+        s2 += w[i] * w[i];
+      }
+      lq0[c] = -0.5 * s2;
+    }
+    for (int j = 0; j < d; ++j) qm[j] = e->q_mean_h[j];
+    if ((rc = e->lq.upload(lq0)) || (rc = e->q_mean_d.upload(qm))) return rc;
+    if ((rc = e->qzblk.alloc((size_t)e->SMAX * NP)) || (rc = e->qzblk2[0].alloc((size_t)e->SMAX * NP)) ||
+        (rc = e->qzblk2[1].alloc((size_t)e->SMAX * NP)))
+      return rc;
+  }
 
   // proposal state (chain.py:74-76)
-  std::vector<double> sc(NP, e->pp.kind == TDA_PROP_AM ? 1.0 : e->pp.scaling);
+  std::vector<double> sc(NP, (e->pp.kind == TDA_PROP_AM || e->pp.kind == TDA_PROP_INDEPENDENCE) ? 1.0 : e->pp.scaling);
   if ((rc = e->scaling.upload(sc))) return rc;
   if (e->is_dreamz) {
     if (!e->arch_set && (rc = tda_engine_set_archive(e, nullptr))) return rc;
@@ -1628,6 +1670,7 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     ra.zf = e->zfrag[b].p;
     ra.u = e->ublk2[b].p;
     ra.logu = e->lublk2[b].p;
+    ra.qz = e->pp.kind == TDA_PROP_INDEPENDENCE ? e->qzblk2[b].p : nullptr;
     if (e->exp_steps) {
       ra.z_export = (e->exp_dev ? e->z_exp : e->z_exp_d.p) + (size_t)exp_off * N * d;
       ra.u_export = (e->exp_dev ? e->u_exp : e->u_exp_d.p) + (size_t)exp_off * N;
@@ -1653,6 +1696,7 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     const int64_t S = block_len(e->t, n_iter - done);
     const double* u_blk = e->ublk.p;
     const double* lu_blk = e->lublk.p;
+    const double* qz_blk = e->qzblk.p;
 
     // ---- proposal increments + uniforms ----
     if (split) {
@@ -1672,6 +1716,7 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
       HIP_TRY(hipEventRecord(e->ev_apply[b], e->stream));
       u_blk = e->ublk2[b].p;
       lu_blk = e->lublk2[b].p;
+      qz_blk = e->qzblk2[b].p;
       if (done + S < n_iter) {
         // next block's draws go under THIS block's steps: released by this block's k_apply (the host runs ahead of the
         // GPU; without the wait the draws would start as soon as block blk - 1's steps end, i.e. next to its k_adapt,
@@ -1694,6 +1739,7 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     pa.inc = e->inc.p;
     pa.u = e->ublk.p;
     pa.logu = e->lublk.p;
+    pa.qz = e->pp.kind == TDA_PROP_INDEPENDENCE ? e->qzblk.p : nullptr;
     if (e->rep_steps) {
       pa.z_replay = e->z_rep.p + (size_t)e->rep_pos * N * d;
       pa.u_replay = e->u_rep.p + (size_t)e->rep_pos * N;
@@ -1722,6 +1768,12 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     sa.inc = e->inc.p;
     sa.u = u_blk;
     sa.logu = lu_blk;
+    if (e->pp.kind == TDA_PROP_INDEPENDENCE) {
+      if (lv.model == MODEL_USER) return fail(TDA_ERR_UNSUPPORTED, "the independence sampler is not lowered for source-defined models");
+      sa.q_mean = e->q_mean_d.p;
+      sa.qz = qz_blk;
+      sa.lq = e->lq.p;
+    }
     // records go straight into caller memory when it is device memory; AM needs the states either way
     sa.rec_params = p_dev ? o_params + (size_t)done * N * d : ((o_params || is_am) ? e->rec_params.p : nullptr);
     sa.rec_stats = s_dev ? o_stats + (size_t)done * N * 3 : (o_stats ? e->rec_stats.p : nullptr);

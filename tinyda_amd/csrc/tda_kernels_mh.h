@@ -72,6 +72,10 @@ struct StepArgs {
   const double* inc;  // [S][NP][DPAD]
   const double* u;    // [S][NP]
   const double* logu; // [S][NP] log(u), produced by k_propose off the critical path (may be null)
+  // independence sampler (prop_kind 4): theta' = q_mean + inc, alpha = exp(post' - post + lq - qz)
+  const double* q_mean;  // [DPAD]
+  const double* qz;      // [S][NP] log q(theta') up to q's constant: -|z|^2 / 2
+  double* lq;            // [NP]    the same for the current state
   // records, layout of tda_outputs (may be null)
   double* rec_params;
   double* rec_stats;
@@ -91,6 +95,7 @@ struct ProposeArgs {
   double* inc;            // [S][NP][DPAD]
   double* u;              // [S][NP]
   double* logu;           // [S][NP] (may be null)
+  double* qz;             // [S][NP] -|z_s|^2 / 2 for the independence sampler (may be null)
   const double* z_replay; // [.][N][d] at step0 (may be null)
   const double* u_replay; // [.][N]
   double* z_export;       // same layout (may be null)
@@ -420,7 +425,9 @@ __host__ __device__ constexpr int steps_lds_doubles(int m_pad, bool diag, int pr
 // NW waves share the tile (4 = one wave per SIMD with up to 512 registers, 8 = two per SIMD with 256):
 // the observation blocks of the forward model are dealt round-robin over the waves.
 // ------------------------------------------------------------------------------------------------
-template <int DPAD, int NW>
+// IND = IndependenceSampler proposals (a template parameter: as a run-time flag it costs the random-walk path 16 registers
+// and 3 %)
+template <int DPAD, int NW, bool IND = false>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int KS = DPAD / 4;
@@ -480,6 +487,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
   int nacc = 0;
   const bool is_eval = a.mode == MODE_EVAL;
   const bool is_pcn = a.prop_kind == 1;
+  constexpr bool is_ind = IND;  // IndependenceSampler (proposal.py:65-129)
+  double qm[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) qm[e] = (is_ind && active) ? a.q_mean[q * EPT + e] : 0.0;
+  double lq = is_ind ? a.lq[gcl] : 0.0, qznext = 0.0;
   const FragSrc fbase = frag_src(a.lv.Apk, lane);
   const FragSrc pbase = frag_src(a.pr.Wpk, lane);
   constexpr bool PAIRS = NW == 4;  // 4 waves: pairs of blocks, 4 fragment sets; 8 waves: single blocks, 2 sets
@@ -494,6 +506,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
     }
     unext = a.u[gcl];
     if (has_logu) lunext = a.logu[gcl];
+    if (is_ind) qznext = a.qz[gcl];
   }
   __syncthreads();
 
@@ -522,13 +535,14 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
           prp[e] = cur[e];
         } else {
           const double sx = scal_t * xin[e];
-          prp[e] = is_pcn ? keep_t * cur[e] + sx : cur[e] + sx;
+          prp[e] = is_ind ? qm[e] + xin[e] : (is_pcn ? keep_t * cur[e] + sx : cur[e] + sx);
         }
         s_prop[c * LDP + q * EPT + e] = prp[e];
       }
     }
-    const double u = unext, lu = lunext;
+    const double u = unext, lu = lunext, qzs = qznext;
     if (!is_eval && s + 1 < a.S) {  // next step's increment and uniform fly during the MFMA phase
+      if (is_ind) qznext = a.qz[(size_t)(s + 1) * a.NP + gcl];
       if (active) {
 #pragma unroll
         for (int e = 0; e < EPT; ++e) xin[e] = a.inc[((size_t)(s + 1) * a.NP + gct) * DPAD + q * EPT + e];
@@ -627,7 +641,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
     if (is_eval) {
       acc = true;
     } else {
-      const double delta = is_pcn ? ll_n - ll : post_n - (lp + ll);
+      const double delta = is_pcn ? ll_n - ll : (is_ind ? ((post_n - (lp + ll)) + lq) - qzs : post_n - (lp + ll));
       if (has_logu && (fabs(lu - delta) > 1e-9 || delta != delta)) {
         acc = (post_n == post_n) && (lu < delta);
       } else {
@@ -637,6 +651,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
     if (acc) {
       lp = lp_n;
       ll = ll_n;
+      lq = qzs;
     }
     nacc += acc ? 1 : 0;
 
@@ -672,6 +687,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
   if (wave == 0 && lane < 16) {
     a.lp[gcl] = lp;
     a.ll[gcl] = ll;
+    if (is_ind && !is_eval) a.lq[gcl] = lq;
     if (!is_eval && a.acc_count) a.acc_count[gcl] += nacc;
   }
 }
@@ -720,6 +736,7 @@ __global__ void __launch_bounds__(64, 2) k_propose(const ProposeArgs a) {
     double4_t acc[TJ];
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) acc[tj] = double4_t{0.0, 0.0, 0.0, 0.0};
+    double zz = 0.0;
 #pragma unroll
     for (int q = 0; q < QN; ++q) {
       const int p = 4 * q + hi;  // pair index: dims 2p, 2p + 1
@@ -740,6 +757,8 @@ __global__ void __launch_bounds__(64, 2) k_propose(const ProposeArgs a) {
           if (2 * p + 1 < a.d) a.z_export[o + 1] = z1;
         }
       }
+      zz += z0 * z0;
+      zz += z1 * z1;
       *reinterpret_cast<double2*>(&s_z[lc * RS + 2 * p]) = double2{z0, z1};
       __syncthreads();
       const double za = s_z[lc * RS + 8 * q + hi], zb = s_z[lc * RS + 8 * q + 4 + hi];  // k-steps 2q, 2q + 1
@@ -748,6 +767,10 @@ __global__ void __launch_bounds__(64, 2) k_propose(const ProposeArgs a) {
       for (int tj = 0; tj < TJ; ++tj) acc[tj] = mfma_f64(za, Lf[tj][2 * q], acc[tj]);
 #pragma unroll
       for (int tj = 0; tj < TJ; ++tj) acc[tj] = mfma_f64(zb, Lf[tj][2 * q + 1], acc[tj]);
+    }
+    if (a.qz) {  // the four lanes of a step hold a quarter of its pairs each
+      zz = sum_rows(zz);
+      if (hi == 0 && s < a.S) a.qz[(size_t)s * a.NP + c] = -0.5 * zz;
     }
     // D layout: step hi + 4 r of the group, column 16 tj + lc
 #pragma unroll
@@ -791,6 +814,7 @@ struct RngArgs {
   double* zf;        // [groups][NP][DPAD/4][64]
   double* u;         // [S][NP]
   double* logu;      // [S][NP]
+  double* qz;        // [S][NP] -|z_s|^2 / 2 (may be null)
   double* z_export;  // [S][N][d] (may be null)
   double* u_export;
 };
@@ -805,6 +829,7 @@ __global__ void __launch_bounds__(64, 8) k_rng(const RngArgs a) {
   const bool real_chain = c < a.N;
   const uint32_t gc = (uint32_t)(a.chain_offset + c);
   double* __restrict__ dst = a.zf + ((size_t)g * a.NP + c) * KK * 64;
+  double zz = 0.0;
 #pragma unroll 1
   for (int q = 0; q < QN; ++q) {
     const int p = 4 * q + hi;  // pair index: dims 2p, 2p + 1
@@ -822,6 +847,12 @@ __global__ void __launch_bounds__(64, 8) k_rng(const RngArgs a) {
     const int kk = 2 * q + (hi >> 1), h = 2 * (hi & 1);
     dst[kk * 64 + lc + 16 * h] = z0;
     dst[kk * 64 + lc + 16 * h + 16] = z1;
+    zz += z0 * z0;
+    zz += z1 * z1;
+  }
+  if (a.qz) {
+    zz = sum_rows(zz);
+    if (hi == 0 && s < a.S) a.qz[(size_t)s * a.NP + c] = -0.5 * zz;
   }
 }
 

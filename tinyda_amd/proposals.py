@@ -32,6 +32,33 @@ class Proposal:
         pass
 
 
+class IndependenceSampler(Proposal):
+    """Independent proposals from a fixed distribution q with .rvs() and .logpdf() (proposal.py:65-129).  On the device
+    path q must be Gaussian (a frozen scipy.stats.multivariate_normal, or any object with `mean` and `cov`)."""
+
+    def __init__(self, q):
+        self.q = q
+        self.q.logpdf(self.q.rvs(1))  # the reference's interface check (proposal.py:101-105)
+
+    def make_proposal(self, link):
+        return self.q.rvs(1).flatten()
+
+    def get_acceptance(self, proposal_link, previous_link):
+        q_proposal = self.get_q(None, proposal_link)
+        q_previous = self.get_q(None, previous_link)
+        return np.exp(proposal_link.posterior - previous_link.posterior + q_previous - q_proposal)
+
+    def get_q(self, x_link, y_link):
+        return self.q.logpdf(y_link.parameters)
+
+    def _lowering(self):
+        mean, cov = getattr(self.q, "mean", None), getattr(self.q, "cov", None)
+        if mean is None or cov is None:
+            return None
+        return dict(kind=_lib.PROP_INDEPENDENCE, C_=np.atleast_2d(np.asarray(cov, dtype=np.float64)),
+                    q_mean=np.atleast_1d(np.asarray(mean, dtype=np.float64)))
+
+
 def _require_square(C, name):
     # same checks and messages as proposal.py:189-196 / :443-450
     if not isinstance(C, np.ndarray):
