@@ -975,6 +975,13 @@ __device__ __forceinline__ void adapt_scaling(const AdaptArgs& a, int64_t c, int
   if (lane == 0) a.acc_count[c] = 0;
 }
 
+// wave-uniform broadcast of lane `src`'s value (src uniform)
+__device__ __forceinline__ double bcast_lane64(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
 // Reference-form recursion (the default).  Every element follows RecursiveSampleMoments.update operation for operation
 // (this file is compiled with -ffp-contract=off, so products and sums round exactly like NumPy's).  Sigma lives in
 // registers in the tile layout described above: lane (lc, hi) holds, for each tile (ti, tj) on or below the diagonal,
@@ -1006,12 +1013,21 @@ __global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
     double mu = lp ? a.am_mu[c * DPAD + lane] : 0.0;
     const int ppos = (lane & ~15) | ((lane & 3) << 2) | ((lane >> 2) & 3);
     double xn = lj ? a.rec_params[(size_t)c * a.d + lane] : 0.0;
+    // the step coefficients depend on t only: lane l works out those of step 64 k + l (three fp64 divisions, ~45
+    // instructions that every lane would otherwise repeat in every step) and the loop reads them back with v_readlane
+    double c_inv = 0.0, c_a = 0.0, c_b = 0.0;
     for (int s = 0; s < a.S; ++s) {
+      if ((s & 63) == 0) {
+        const double tl = (double)(a.t_base + s + lane + 1);
+        c_inv = 1.0 / (tl + 1.0);
+        c_a = (tl - 1.0) / tl;
+        c_b = a.sd / tl;
+      }
       const double x = xn;
       if (s + 1 < a.S) xn = lj ? a.rec_params[((size_t)(s + 1) * a.N + c) * a.d + lane] : 0.0;
       const double t = (double)(a.t_base + s + 1);  // recursor.t before this update
-      const double mup = (1.0 / (t + 1.0)) * (t * mu + x);
-      const double ca = (t - 1.0) / t, cb = a.sd / t;
+      const double mup = bcast_lane64(c_inv, s & 63) * (t * mu + x);
+      const double ca = bcast_lane64(c_a, s & 63), cb = bcast_lane64(c_b, s & 63);
       const double t1 = t + 1.0;
       __syncthreads();  // previous step's operand reads are done
       if (lane < W) {
