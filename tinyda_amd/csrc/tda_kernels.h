@@ -1,5 +1,6 @@
 // All HIP kernels of the engine (gfx950 only), one header per family:
-//   tda_kernels_mh.h      MFMA fragment pipeline, k_mh_steps, k_propose, k_adapt, k_chol   (single-level MH, the hot path)
+//   tda_kernels_mh.h      MFMA fragment pipeline, k_mh_steps, k_rng / k_apply / k_propose, k_adapt / k_adapt_block, k_chol
+//                         (single-level MH, the hot path)
 //   tda_kernels_ml.h      k_ml_steps (DA / MLDA state machine), k_aem_action (adaptive error model)
 //   tda_kernels_dreamz.h  k_dreamz_draw / steps / adapt, k_colsum_partial
 //   tda_kernels_pooled.h  k_moments_partial / final

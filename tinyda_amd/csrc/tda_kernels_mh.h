@@ -1,19 +1,22 @@
 // HIP kernels of the many-chain MH engine for gfx950 (MI355X).  No CUDA / multi-backend paths.
 //
-// Pipeline per block of S <= period steps (proposal distribution is constant inside a block, because
-// tinyDA's proposals only change at adapt-count multiples of `period`, proposal.py:234,509):
+// Pipeline per block of S <= period steps (the proposal distribution is constant inside a block, because tinyDA's
+// proposals only change at adapt-count multiples of `period`, proposal.py:234,509):
 //
-//   k_propose   wave per chain : Philox normals z_s, increments inc_s = L z_s (L = chol C, per chain for
-//                                AdaptiveMetropolis), accept uniforms u_s            -> HBM [S][N][D]
-//   k_mh_steps  workgroup = 16 chains x 4 waves, S fused steps:
-//                                theta' = theta + scaling * inc_s  (pCN: sqrt(1-b^2) theta + b inc_s)
-//                                F = A theta' on fp64 MFMA (v_mfma_f64_16x16x4), observations split over
-//                                the 4 waves, A fragments streamed from L2, residual + weighted SSE fused
-//                                in the MFMA epilogue, prior, log alpha, accept, coalesced record write
-//   k_adapt     wave per chain : RecursiveSampleMoments catch-up over the S recorded states (utils.py:113-122): the
-//                                mean recursion literally, the covariance as one rank-S update on the matrix
-//                                cores; global scaling adaptation at period boundaries
-//   k_chol      wave per chain : C <- Sigma swap, Cholesky in LDS (only at period boundaries with t >= t0)
+//   k_rng        wave per (chain, 16 steps): Philox normals z_s as MFMA A fragments, accept uniforms u_s and log u_s.
+//                State independent, so block b+1's draws run on a second stream UNDER block b's k_mh_steps
+//                (64 registers: shares the SIMDs with the step kernel's 2 x 224)
+//   k_apply      wave per chain: INC = Z L^T on the matrix cores (L = chol C as B fragments in registers)  -> HBM [S][N][D]
+//                (k_propose fuses k_rng + k_apply for recorded variates and the multi-level / DREAM paths)
+//   k_mh_steps   workgroup = 16 chains x 8 waves (two per SIMD), S fused steps:
+//                theta' = theta + scaling * inc_s  (pCN: sqrt(1-b^2) theta + b inc_s; independence: mu_q + inc_s),
+//                F = A theta' on fp64 MFMA (v_mfma_f64_16x16x4), observation blocks dealt over the waves, A fragments
+//                streamed from L2 with buffer loads, residual + weighted SSE fused in the MFMA epilogue, prior,
+//                log alpha, accept, coalesced record write (4-wave variant: dense noise, residual tile in LDS)
+//   k_adapt      wave per chain: RecursiveSampleMoments catch-up over the S recorded states (utils.py:113-122) in the
+//                reference's exact arithmetic, Sigma as 16x16 tiles in registers; global scaling adaptation at period
+//                boundaries.  k_adapt_block: the same covariance as one rank-S SYRK on the matrix cores (opt-in)
+//   k_chol       wave per chain: C <- Sigma swap, register-resident Cholesky (only at period boundaries with t >= t0)
 //
 // Chains never interact, so there is no inter-workgroup communication anywhere.
 #pragma once
