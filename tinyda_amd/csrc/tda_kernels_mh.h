@@ -990,15 +990,16 @@ __device__ __forceinline__ double bcast_lane64(double v, int src) {
 // registers in the tile layout described above: lane (lc, hi) holds, for each tile (ti, tj) on or below the diagonal,
 // the 4 elements (16 ti + hi + 4 r, 16 tj + lc).  Per state the three vectors x, mu, mu' go to LDS twice: in natural
 // order (column operands: one ds_read_b64 per tile column) and permuted so that a lane's four row indices are
-// contiguous (row operands: two ds_read_b128 per tile row).  36 LDS reads + 400 fp64 operations per state, where the
-// circulant fold used earlier needed 99 + 330 and ran at the same speed: the bound is the VALU.
+// contiguous (row operands: two ds_read_b128 per tile row); mu mu^T is carried over from the previous step's
+// mu' mu'^T.  24 LDS reads + 360 fp64 operations per state; the circulant fold used earlier needed 99 + 330 and ran
+// at the speed of the 36 + 400 tile version: the bound is the VALU.
 template <int DPAD>
 __global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
   constexpr int T = am_tile_rows<DPAD>();
   constexpr int NTL = am_tiles<DPAD>();
   constexpr int W = 16 * T;
-  __shared__ __attribute__((aligned(16))) double s_nat[3 * W];  // x, mu, mu' by dimension
-  __shared__ __attribute__((aligned(16))) double s_prm[3 * W];  // the same, dimension 16 ti + h + 4 r at 16 ti + 4 h + r
+  __shared__ __attribute__((aligned(16))) double s_nat[2 * W];  // x, mu' by dimension
+  __shared__ __attribute__((aligned(16))) double s_prm[2 * W];  // the same, dimension 16 ti + h + 4 r at 16 ti + 4 h + r
   const int lane = threadIdx.x;
   const int64_t c = blockIdx.x;
   if (c >= a.N) return;
@@ -1008,17 +1009,39 @@ __global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
 
   if (a.do_am) {
     double* __restrict__ sig = a.am_sigma + (size_t)c * NTL * 256;
-    double Sg[NTL][4];
+    double Sg[NTL][4], MM[NTL][4];  // Sigma and mu mu^T of the current mean, element (16 ti + hi + 4 r, 16 tj + lc)
 #pragma unroll
     for (int idx = 0; idx < NTL; ++idx)
 #pragma unroll
       for (int r = 0; r < 4; ++r) Sg[idx][r] = sig[(idx * 4 + r) * 64 + lane];
     double mu = lp ? a.am_mu[c * DPAD + lane] : 0.0;
     const int ppos = (lane & ~15) | ((lane & 3) << 2) | ((lane >> 2) & 3);
-    double xn = lj ? a.rec_params[(size_t)c * a.d + lane] : 0.0;
+    // mu'_s mu'_s^T of step s IS mu_{s+1} mu_{s+1}^T of step s + 1 (same operands, same rounding): it is carried in
+    // registers instead of being multiplied out again, and mu itself never goes through LDS after this prologue
+    if (lane < W) {
+      s_nat[lane] = mu;
+      s_prm[ppos] = mu;
+    }
+    __syncthreads();
+    {
+      double mc[T];
+#pragma unroll
+      for (int tj = 0; tj < T; ++tj) mc[tj] = s_nat[16 * tj + lc];
+#pragma unroll
+      for (int ti = 0; ti < T; ++ti) {
+        const double2* __restrict__ q = reinterpret_cast<const double2*>(s_prm + 16 * ti + 4 * hi);
+        const double2 m01 = q[0], m23 = q[1];
+        const double mr[4] = {m01.x, m01.y, m23.x, m23.y};
+#pragma unroll
+        for (int tj = 0; tj <= ti; ++tj)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) MM[ti * (ti + 1) / 2 + tj][r] = mr[r] * mc[tj];
+      }
+    }
     // the step coefficients depend on t only: lane l works out those of step 64 k + l (three fp64 divisions, ~45
     // instructions that every lane would otherwise repeat in every step) and the loop reads them back with v_readlane
     double c_inv = 0.0, c_a = 0.0, c_b = 0.0;
+    double xn = lj ? a.rec_params[(size_t)c * a.d + lane] : 0.0;
     for (int s = 0; s < a.S; ++s) {
       if ((s & 63) == 0) {
         const double tl = (double)(a.t_base + s + lane + 1);
@@ -1035,28 +1058,24 @@ __global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
       __syncthreads();  // previous step's operand reads are done
       if (lane < W) {
         s_nat[lane] = x;
-        s_nat[W + lane] = mu;
-        s_nat[2 * W + lane] = mup;
+        s_nat[W + lane] = mup;
         s_prm[ppos] = x;
-        s_prm[W + ppos] = mu;
-        s_prm[2 * W + ppos] = mup;
+        s_prm[W + ppos] = mup;
       }
       __syncthreads();
-      double xc[T], mc[T], pc[T];
+      double xc[T], pc[T];
 #pragma unroll
       for (int tj = 0; tj < T; ++tj) {
         xc[tj] = s_nat[16 * tj + lc];
-        mc[tj] = s_nat[W + 16 * tj + lc];
-        pc[tj] = s_nat[2 * W + 16 * tj + lc];
+        pc[tj] = s_nat[W + 16 * tj + lc];
       }
 #pragma unroll
       for (int ti = 0; ti < T; ++ti) {
-        double xr[4], mr[4], pr[4];
+        double xr[4], pr[4];
         {
           const double2* __restrict__ q = reinterpret_cast<const double2*>(s_prm + 16 * ti + 4 * hi);
-          const double2 x01 = q[0], x23 = q[1], m01 = q[W / 2], m23 = q[W / 2 + 1], p01 = q[W], p23 = q[W + 1];
+          const double2 x01 = q[0], x23 = q[1], p01 = q[W / 2], p23 = q[W / 2 + 1];
           xr[0] = x01.x; xr[1] = x01.y; xr[2] = x23.x; xr[3] = x23.y;
-          mr[0] = m01.x; mr[1] = m01.y; mr[2] = m23.x; mr[3] = m23.y;
           pr[0] = p01.x; pr[1] = p01.y; pr[2] = p23.x; pr[3] = p23.y;
         }
 #pragma unroll
@@ -1064,9 +1083,11 @@ __global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
           const int idx = ti * (ti + 1) / 2 + tj;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            double M = (t * (mr[r] * mc[tj]) - t1 * (pr[r] * pc[tj])) + xr[r] * xc[tj];
+            const double pp = pr[r] * pc[tj];
+            double M = (t * MM[idx][r] - t1 * pp) + xr[r] * xc[tj];
             if (ti == tj && hi + 4 * r == lc) M = (16 * ti + lc < a.d) ? M + a.eps : M;
             Sg[idx][r] = ca * Sg[idx][r] + cb * M;
+            MM[idx][r] = pp;
           }
         }
       }
