@@ -991,7 +991,7 @@ __device__ __forceinline__ double bcast_lane64(double v, int src) {
 // the 4 elements (16 ti + hi + 4 r, 16 tj + lc).  Per state the three vectors x, mu, mu' go to LDS twice: in natural
 // order (column operands: one ds_read_b64 per tile column) and permuted so that a lane's four row indices are
 // contiguous (row operands: two ds_read_b128 per tile row); mu mu^T is carried over from the previous step's
-// mu' mu'^T.  24 LDS reads + 360 fp64 operations per state; the circulant fold used earlier needed 99 + 330 and ran
+// (t + 1) mu' mu'^T.  24 LDS reads + 320 fp64 operations per state; the circulant fold used earlier needed 99 + 330 and ran
 // at the speed of the 36 + 400 tile version: the bound is the VALU.
 template <int DPAD>
 __global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
@@ -1009,15 +1009,15 @@ __global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
 
   if (a.do_am) {
     double* __restrict__ sig = a.am_sigma + (size_t)c * NTL * 256;
-    double Sg[NTL][4], MM[NTL][4];  // Sigma and mu mu^T of the current mean, element (16 ti + hi + 4 r, 16 tj + lc)
+    double Sg[NTL][4], TM[NTL][4];  // Sigma and t mu mu^T of the current mean, element (16 ti + hi + 4 r, 16 tj + lc)
 #pragma unroll
     for (int idx = 0; idx < NTL; ++idx)
 #pragma unroll
       for (int r = 0; r < 4; ++r) Sg[idx][r] = sig[(idx * 4 + r) * 64 + lane];
     double mu = lp ? a.am_mu[c * DPAD + lane] : 0.0;
     const int ppos = (lane & ~15) | ((lane & 3) << 2) | ((lane >> 2) & 3);
-    // mu'_s mu'_s^T of step s IS mu_{s+1} mu_{s+1}^T of step s + 1 (same operands, same rounding): it is carried in
-    // registers instead of being multiplied out again, and mu itself never goes through LDS after this prologue
+    // (t + 1) (mu'_s mu'_s^T) of step s IS t (mu_{s+1} mu_{s+1}^T) of step s + 1 (same operands, same rounding): it is
+    // carried in registers instead of being multiplied out again, and mu itself never goes through LDS after this prologue
     if (lane < W) {
       s_nat[lane] = mu;
       s_prm[ppos] = mu;
@@ -1035,7 +1035,7 @@ __global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
 #pragma unroll
         for (int tj = 0; tj <= ti; ++tj)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) MM[ti * (ti + 1) / 2 + tj][r] = mr[r] * mc[tj];
+          for (int r = 0; r < 4; ++r) TM[ti * (ti + 1) / 2 + tj][r] = (double)(a.t_base + 1) * (mr[r] * mc[tj]);
       }
     }
     // the step coefficients depend on t only: lane l works out those of step 64 k + l (three fp64 divisions, ~45
@@ -1083,11 +1083,11 @@ __global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
           const int idx = ti * (ti + 1) / 2 + tj;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const double pp = pr[r] * pc[tj];
-            double M = (t * MM[idx][r] - t1 * pp) + xr[r] * xc[tj];
+            const double tp = t1 * (pr[r] * pc[tj]);
+            double M = (TM[idx][r] - tp) + xr[r] * xc[tj];
             if (ti == tj && hi + 4 * r == lc) M = (16 * ti + lc < a.d) ? M + a.eps : M;
             Sg[idx][r] = ca * Sg[idx][r] + cb * M;
-            MM[idx][r] = pp;
+            TM[idx][r] = tp;
           }
         }
       }
