@@ -188,3 +188,30 @@ def test_checkpoint_resume_is_bitwise(eng_mod, kind):
     with pytest.raises(Exception):
         b.set_state(blob[:-8])
     b.close()
+
+
+def test_pinned_host_records_equal_pageable(eng_mod):
+    """Records into page-locked host memory take the asynchronous path (second stream, two sets of block buffers); the
+    bytes are those of the synchronous pageable path."""
+    rng = np.random.default_rng(3)
+    d, N, T = 9, 37, 95
+
+    def make():
+        e = eng_mod.Engine(N, d, seed=21, block_steps=16)
+        e.set_prior(np.zeros(d), np.eye(d))
+        r2 = np.random.default_rng(1)
+        e.set_level(0, r2.standard_normal((14, d)) / 3, r2.standard_normal(14), 0, 0.3)
+        e.set_proposal(2, 0.05 * np.eye(d), t0=20, period=10, adaptive=True)
+        e.init(np.full((N, d), 0.1))
+        return e
+
+    a = make()
+    pa, sa, aa = np.empty((T, N, d)), np.empty((T, N, 3)), np.empty((T, N), dtype=np.uint8)
+    a.run(T, pa, sa, aa)
+    a.close()
+    b = make()
+    pb, sb, ab = (eng_mod.pinned_empty((T, N, d)), eng_mod.pinned_empty((T, N, 3)), eng_mod.pinned_empty((T, N), dtype=np.uint8))
+    b.run(40, pb[:40], sb[:40], ab[:40])
+    b.run(T - 40, pb[40:], sb[40:], ab[40:])
+    b.close()
+    assert np.array_equal(pa, pb) and np.array_equal(sa, sb) and np.array_equal(aa, ab)

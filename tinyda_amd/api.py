@@ -190,9 +190,12 @@ def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, se
         theta0 = None if initial_parameters is None else np.stack([np.asarray(p, float) for p in initial_parameters])
         eng.init(theta0)
         T, N = iterations, n_chains
-        params = np.empty((T + 1, N, d))
-        stat = np.empty((T + 1, N, 3))
-        acc = np.ones((T + 1, N), dtype=np.uint8)
+        from .engine import pinned_empty
+
+        params = pinned_empty((T + 1, N, d))
+        stat = pinned_empty((T + 1, N, 3))
+        acc = pinned_empty((T + 1, N), dtype=np.uint8)
+        acc[0] = 1
         params[0], stat[0] = eng.current()
         if T > 0 and prop["kind"] == _lib.PROP_DREAMZ and prop.get("shared") and distributed:
             import torch

@@ -47,6 +47,17 @@ bool is_device_ptr(const void* p) {
   return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
 }
 
+bool is_pinned_host_ptr(const void* p) {
+  if (!p) return false;
+  hipPointerAttribute_t at;
+  hipError_t er = hipPointerGetAttributes(&at, p);
+  if (er != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
+}
+
 int dpad_for(int d) { return d <= 8 ? 8 : d <= 16 ? 16 : d <= 32 ? 32 : 64; }
 
 // lower Cholesky of a d x d row-major SPD matrix; returns false if not positive definite
@@ -188,6 +199,11 @@ struct tda_engine {
 
   // block buffers
   DevBuf<double> inc, ublk, lublk, rec_params, rec_stats;
+  // records into PINNED host memory: device block buffers double-buffered, copies on their own stream under the next block
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_rec[2] = {nullptr, nullptr}, ev_cp[2] = {nullptr, nullptr};
+  DevBuf<double> rec_params2, rec_stats2;
+  DevBuf<uint8_t> rec_acc2;
   // split proposal path (Philox mode): normals of block b+1 are drawn on a second stream under block b's steps
   hipStream_t rng_stream = nullptr;
   hipEvent_t ev_rng[2] = {nullptr, nullptr}, ev_apply[2] = {nullptr, nullptr}, ev_steps[2] = {nullptr, nullptr};
@@ -514,6 +530,14 @@ void tda_engine_destroy(tda_engine* e) {
   }
   for (auto& lv : e->levels)
     if (lv.umod) (void)hipModuleUnload(lv.umod);
+  if (e->copy_stream) {
+    (void)hipStreamSynchronize(e->copy_stream);
+    (void)hipStreamDestroy(e->copy_stream);
+    for (int i = 0; i < 2; ++i) {
+      (void)hipEventDestroy(e->ev_rec[i]);
+      (void)hipEventDestroy(e->ev_cp[i]);
+    }
+  }
   if (e->rng_stream) {
     (void)hipStreamSynchronize(e->rng_stream);
     (void)hipStreamDestroy(e->rng_stream);
@@ -1625,6 +1649,23 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
   const Level& lv = e->levels[0];
   const size_t lds = steps_lds_bytes(e, lv);
   bool host_copies = false;
+  // Host outputs in pinned memory (hipHostMalloc / torch pin_memory): the block's records are copied by a second
+  // stream while the next block computes (two sets of device block buffers).  Pageable memory: one synchronous copy
+  // per block, as before.
+  const bool any_host = (o_params && !p_dev) || (o_stats && !s_dev) || (o_acc && !a_dev);
+  const bool async_host = any_host && (!o_params || p_dev || is_pinned_host_ptr(o_params)) &&
+                          (!o_stats || s_dev || is_pinned_host_ptr(o_stats)) && (!o_acc || a_dev || is_pinned_host_ptr(o_acc));
+  if (async_host && !e->copy_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      HIP_TRY(hipEventCreateWithFlags(&e->ev_rec[i], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&e->ev_cp[i], hipEventDisableTiming));
+    }
+    int rc;
+    if ((rc = e->rec_params2.alloc((size_t)e->SMAX * N * d)) || (rc = e->rec_stats2.alloc((size_t)e->SMAX * N * 3)) ||
+        (rc = e->rec_acc2.alloc((size_t)e->SMAX * N)))
+      return rc;
+  }
 
   if (e->profiling) {
     for (auto& t : e->timed) {
@@ -1775,9 +1816,13 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
       sa.lq = e->lq.p;
     }
     // records go straight into caller memory when it is device memory; AM needs the states either way
-    sa.rec_params = p_dev ? o_params + (size_t)done * N * d : ((o_params || is_am) ? e->rec_params.p : nullptr);
-    sa.rec_stats = s_dev ? o_stats + (size_t)done * N * 3 : (o_stats ? e->rec_stats.p : nullptr);
-    sa.rec_acc = a_dev ? o_acc + (size_t)done * N : (o_acc ? e->rec_acc.p : nullptr);
+    double* const blk_params = (async_host && (blk & 1)) ? e->rec_params2.p : e->rec_params.p;
+    double* const blk_stats = (async_host && (blk & 1)) ? e->rec_stats2.p : e->rec_stats.p;
+    uint8_t* const blk_acc = (async_host && (blk & 1)) ? e->rec_acc2.p : e->rec_acc.p;
+    if (async_host && blk >= 2) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_cp[blk & 1], 0));  // buffer set free again
+    sa.rec_params = p_dev ? o_params + (size_t)done * N * d : ((o_params || is_am) ? blk_params : nullptr);
+    sa.rec_stats = s_dev ? o_stats + (size_t)done * N * 3 : (o_stats ? blk_stats : nullptr);
+    sa.rec_acc = a_dev ? o_acc + (size_t)done * N : (o_acc ? blk_acc : nullptr);
     if (lv.model == MODEL_USER) {
       UserStepArgs ua{};
       int urc = fill_user_args(e, lv, ua);
@@ -1847,19 +1892,32 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
 
     // ---- host-side records ----
     int rc;
-    if (o_params && !p_dev) {
-      if ((rc = copy_out(e, o_params + (size_t)done * N * d, e->rec_params.p, (size_t)S * N * d * sizeof(double)))) return rc;
-      host_copies = true;
+    if (async_host) {
+      const int i = (int)(blk & 1);
+      HIP_TRY(hipEventRecord(e->ev_rec[i], e->stream));
+      HIP_TRY(hipStreamWaitEvent(e->copy_stream, e->ev_rec[i], 0));
+      if (o_params && !p_dev)
+        HIP_TRY(hipMemcpyAsync(o_params + (size_t)done * N * d, blk_params, (size_t)S * N * d * sizeof(double), hipMemcpyDeviceToHost, e->copy_stream));
+      if (o_stats && !s_dev)
+        HIP_TRY(hipMemcpyAsync(o_stats + (size_t)done * N * 3, blk_stats, (size_t)S * N * 3 * sizeof(double), hipMemcpyDeviceToHost, e->copy_stream));
+      if (o_acc && !a_dev)
+        HIP_TRY(hipMemcpyAsync(o_acc + (size_t)done * N, blk_acc, (size_t)S * N, hipMemcpyDeviceToHost, e->copy_stream));
+      HIP_TRY(hipEventRecord(e->ev_cp[i], e->copy_stream));
+    } else {
+      if (o_params && !p_dev) {
+        if ((rc = copy_out(e, o_params + (size_t)done * N * d, e->rec_params.p, (size_t)S * N * d * sizeof(double)))) return rc;
+        host_copies = true;
+      }
+      if (o_stats && !s_dev) {
+        if ((rc = copy_out(e, o_stats + (size_t)done * N * 3, e->rec_stats.p, (size_t)S * N * 3 * sizeof(double)))) return rc;
+        host_copies = true;
+      }
+      if (o_acc && !a_dev) {
+        if ((rc = copy_out(e, o_acc + (size_t)done * N, e->rec_acc.p, (size_t)S * N))) return rc;
+        host_copies = true;
+      }
+      if (host_copies) HIP_TRY(hipStreamSynchronize(e->stream));  // block buffers are reused next iteration
     }
-    if (o_stats && !s_dev) {
-      if ((rc = copy_out(e, o_stats + (size_t)done * N * 3, e->rec_stats.p, (size_t)S * N * 3 * sizeof(double)))) return rc;
-      host_copies = true;
-    }
-    if (o_acc && !a_dev) {
-      if ((rc = copy_out(e, o_acc + (size_t)done * N, e->rec_acc.p, (size_t)S * N))) return rc;
-      host_copies = true;
-    }
-    if (host_copies) HIP_TRY(hipStreamSynchronize(e->stream));  // block buffers are reused next iteration
 
     e->t += S;
     done += S;
@@ -1868,6 +1926,10 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     if (e->exp_steps) e->exp_pos += S;
   }
 
+  if (async_host) {  // host outputs: run() returns with the records in place
+    HIP_TRY(hipStreamSynchronize(e->copy_stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
   if (e->exp_steps && !e->exp_dev) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(e->z_exp, e->z_exp_d.p, (size_t)e->exp_pos * N * d * sizeof(double), hipMemcpyDeviceToHost));

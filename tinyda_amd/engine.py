@@ -24,6 +24,20 @@ def _f64(a):
     return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
 
 
+def pinned_empty(shape, dtype=np.float64):
+    """Host array in page-locked memory when a GPU is present (torch is the allocator): records written there are copied
+    by a second stream while the next block computes (tda_engine_run); plain np.empty otherwise."""
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            tdt = {np.dtype(np.float64): torch.float64, np.dtype(np.uint8): torch.uint8}[np.dtype(dtype)]
+            return torch.empty(tuple(int(v) for v in shape), dtype=tdt, pin_memory=True).numpy()
+    except Exception:  # no torch / no GPU / allocation refused: pageable memory works too, only slower
+        pass
+    return np.empty(shape, dtype=dtype)
+
+
 class Engine:
     """One many-chain MH engine on one GPU (one per process under torch.distributed)."""
 
@@ -245,8 +259,8 @@ class Engine:
     def run_host(self, n_iterations):
         """Convenience: run and return numpy records (params [T,N,d], stats [T,N,3], accepted [T,N])."""
         T, N, d = n_iterations, self.n_chains, self.dim
-        params, stats = np.empty((T, N, d)), np.empty((T, N, 3))
-        acc = np.empty((T, N), dtype=np.uint8)
+        params, stats = pinned_empty((T, N, d)), pinned_empty((T, N, 3))
+        acc = pinned_empty((T, N), dtype=np.uint8)
         self.run(T, params, stats, acc)
         return params, stats, acc
 

@@ -17,4 +17,9 @@ t0 = time.perf_counter(); e.run(T, P, S, Acc); dt = time.perf_counter() - t0
 print("host (pageable NumPy) record buffers: %.3e evals/s, %.2f GB/s of records over PCIe" % (N * T / dt, N * T * 537 / dt / 1e9))
 t0 = time.perf_counter(); e.run(T, None, S, None); dt = time.perf_counter() - t0
 print("host stats only (24 B/eval)          : %.3e evals/s" % (N * T / dt))
+from tinyda_amd.engine import pinned_empty
+P, S, Acc = pinned_empty((T, N, d)), pinned_empty((T, N, 3)), pinned_empty((T, N), dtype=np.uint8)
+e.run(100, P[:100], S[:100], Acc[:100])
+t0 = time.perf_counter(); e.run(T, P, S, Acc); dt = time.perf_counter() - t0
+print("host (pinned) record buffers, copies on a second stream: %.3e evals/s, %.2f GB/s of records over PCIe" % (N * T / dt, N * T * 537 / dt / 1e9))
 e.close()
