@@ -245,14 +245,17 @@ def _sample_device_multilevel(plan, posteriors, iterations, n_chains, initial_pa
         eng.init(theta0)
         T, N = iterations, n_chains
         rows = eng.rows_per_level(T)
+        from .engine import pinned_empty
+
         outs = []
         for k in range(nl):
             if k < nl - 1 and not store_coarse_chain:
                 outs.append(None)
                 continue
             extra = 1 if k == nl - 1 else 0  # only the finest chain carries the initial link
-            outs.append((np.empty((rows[k] + extra, N, d)), np.empty((rows[k] + extra, N, 3)),
-                         np.ones((rows[k] + extra, N), dtype=np.uint8)))
+            acc_k = pinned_empty((rows[k] + extra, N), dtype=np.uint8)
+            acc_k[:extra] = 1
+            outs.append((pinned_empty((rows[k] + extra, N, d)), pinned_empty((rows[k] + extra, N, 3)), acc_k))
         pf, sf, af = outs[nl - 1]
         pf[0], sf[0] = eng.level_state(nl - 1)
         run_outs = [o if (o is None or k < nl - 1) else (o[0][1:], o[1][1:], o[2][1:]) for k, o in enumerate(outs)]

@@ -224,6 +224,8 @@ struct tda_engine {
   DevBuf<uint8_t> ml_ring;
   DevBuf<double> ml_rec_params[tda::MAXLEV], ml_rec_stats[tda::MAXLEV];
   DevBuf<uint8_t> ml_rec_acc[tda::MAXLEV];
+  DevBuf<double> ml_rec_params2[tda::MAXLEV], ml_rec_stats2[tda::MAXLEV];  // second set: pinned-host async copies
+  DevBuf<uint8_t> ml_rec_acc2[tda::MAXLEV];
   // adaptive error model
   int aem = 0;
   int aem_m = 0;
@@ -1982,6 +1984,35 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
     e->timed.clear();
   }
   int64_t rows_out[MAXLEV] = {0, 0, 0, 0};  // rows already written to the caller's buffers, per level
+  // host outputs in pinned memory: copies on a second stream under the next block (see tda_engine_run)
+  bool any_host = false, all_pinned = true;
+  if (outs)
+    for (int k = 0; k < nl; ++k) {
+      const void* hp[3] = {outs[k].params, outs[k].stats, outs[k].accepted};
+      for (const void* q : hp)
+        if (q && !is_device_ptr(q)) {
+          any_host = true;
+          all_pinned = all_pinned && is_pinned_host_ptr(q);
+        }
+    }
+  const bool async_host = any_host && all_pinned;
+  if (async_host) {
+    if (!e->copy_stream) {
+      HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+      for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_rec[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_cp[i], hipEventDisableTiming));
+      }
+    }
+    for (int k = 0; k < nl; ++k)
+      if (!e->ml_rec_params2[k].p) {
+        int rc;
+        if ((rc = e->ml_rec_params2[k].alloc((size_t)e->SMAX * N * d)) || (rc = e->ml_rec_stats2[k].alloc((size_t)e->SMAX * N * 3)) ||
+            (rc = e->ml_rec_acc2[k].alloc((size_t)e->SMAX * N)))
+          return rc;
+      }
+  }
+  int64_t blk_ix = 0;
   int64_t done_base = 0;
   while (done_base < total_base) {
     int64_t S = std::min<int64_t>(total_base - done_base, e->SMAX);
@@ -2091,10 +2122,12 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
       dev_s[k] = is_device_ptr(os);
       dev_a[k] = is_device_ptr(oa);
       const bool need_p = op || (k == 0 && is_am);
-      ma.rec_params[k] = dev_p[k] ? op + (size_t)rows_out[k] * N * d : (need_p ? e->ml_rec_params[k].p : nullptr);
-      ma.rec_stats[k] = dev_s[k] ? os + (size_t)rows_out[k] * N * 3 : (os ? e->ml_rec_stats[k].p : nullptr);
-      ma.rec_acc[k] = dev_a[k] ? oa + (size_t)rows_out[k] * N : (oa ? e->ml_rec_acc[k].p : nullptr);
+      const bool second = async_host && (blk_ix & 1);
+      ma.rec_params[k] = dev_p[k] ? op + (size_t)rows_out[k] * N * d : (need_p ? (second ? e->ml_rec_params2[k].p : e->ml_rec_params[k].p) : nullptr);
+      ma.rec_stats[k] = dev_s[k] ? os + (size_t)rows_out[k] * N * 3 : (os ? (second ? e->ml_rec_stats2[k].p : e->ml_rec_stats[k].p) : nullptr);
+      ma.rec_acc[k] = dev_a[k] ? oa + (size_t)rows_out[k] * N : (oa ? (second ? e->ml_rec_acc2[k].p : e->ml_rec_acc[k].p) : nullptr);
     }
+    if (async_host && blk_ix >= 2) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_cp[blk_ix & 1], 0));  // buffer set free again
     {
       ScopedTimer tm(e, 1);
       DISPATCH_DPAD(DP, launch_ml<DPAD>(ma, NP / 16, lds, e->stream));
@@ -2206,22 +2239,38 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
 
     bool host_copies = false;
     int rc;
-    for (int k = 0; k < nl; ++k) {
-      if (!outs) break;
-      if (outs[k].params && !dev_p[k]) {
-        if ((rc = copy_out(e, outs[k].params + (size_t)rows_out[k] * N * d, e->ml_rec_params[k].p, (size_t)nblk[k] * N * d * sizeof(double)))) return rc;
-        host_copies = true;
+    if (async_host) {
+      const int i = (int)(blk_ix & 1);
+      HIP_TRY(hipEventRecord(e->ev_rec[i], e->stream));
+      HIP_TRY(hipStreamWaitEvent(e->copy_stream, e->ev_rec[i], 0));
+      for (int k = 0; k < nl; ++k) {
+        if (outs[k].params && !dev_p[k])
+          HIP_TRY(hipMemcpyAsync(outs[k].params + (size_t)rows_out[k] * N * d, ma.rec_params[k], (size_t)nblk[k] * N * d * sizeof(double), hipMemcpyDeviceToHost, e->copy_stream));
+        if (outs[k].stats && !dev_s[k])
+          HIP_TRY(hipMemcpyAsync(outs[k].stats + (size_t)rows_out[k] * N * 3, ma.rec_stats[k], (size_t)nblk[k] * N * 3 * sizeof(double), hipMemcpyDeviceToHost, e->copy_stream));
+        if (outs[k].accepted && !dev_a[k])
+          HIP_TRY(hipMemcpyAsync(outs[k].accepted + (size_t)rows_out[k] * N, ma.rec_acc[k], (size_t)nblk[k] * N, hipMemcpyDeviceToHost, e->copy_stream));
       }
-      if (outs[k].stats && !dev_s[k]) {
-        if ((rc = copy_out(e, outs[k].stats + (size_t)rows_out[k] * N * 3, e->ml_rec_stats[k].p, (size_t)nblk[k] * N * 3 * sizeof(double)))) return rc;
-        host_copies = true;
+      HIP_TRY(hipEventRecord(e->ev_cp[i], e->copy_stream));
+    } else {
+      for (int k = 0; k < nl; ++k) {
+        if (!outs) break;
+        if (outs[k].params && !dev_p[k]) {
+          if ((rc = copy_out(e, outs[k].params + (size_t)rows_out[k] * N * d, e->ml_rec_params[k].p, (size_t)nblk[k] * N * d * sizeof(double)))) return rc;
+          host_copies = true;
+        }
+        if (outs[k].stats && !dev_s[k]) {
+          if ((rc = copy_out(e, outs[k].stats + (size_t)rows_out[k] * N * 3, e->ml_rec_stats[k].p, (size_t)nblk[k] * N * 3 * sizeof(double)))) return rc;
+          host_copies = true;
+        }
+        if (outs[k].accepted && !dev_a[k]) {
+          if ((rc = copy_out(e, outs[k].accepted + (size_t)rows_out[k] * N, e->ml_rec_acc[k].p, (size_t)nblk[k] * N))) return rc;
+          host_copies = true;
+        }
       }
-      if (outs[k].accepted && !dev_a[k]) {
-        if ((rc = copy_out(e, outs[k].accepted + (size_t)rows_out[k] * N, e->ml_rec_acc[k].p, (size_t)nblk[k] * N))) return rc;
-        host_copies = true;
-      }
+      if (host_copies) HIP_TRY(hipStreamSynchronize(e->stream));
     }
-    if (host_copies) HIP_TRY(hipStreamSynchronize(e->stream));
+    blk_ix += 1;
 
     int64_t appended = 0;
     for (int k = 0; k < nl; ++k) {
@@ -2237,6 +2286,10 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
     done_base += S;
     if (e->rep_steps) e->rep_pos += S;
     if (e->exp_steps) e->exp_pos += S;
+  }
+  if (async_host) {  // host outputs: run() returns with the records in place
+    HIP_TRY(hipStreamSynchronize(e->copy_stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
   }
   if (e->exp_steps && !e->exp_dev) {
     HIP_TRY(hipStreamSynchronize(e->stream));

@@ -246,7 +246,7 @@ class Engine:
 
     def run_levels_host(self, n_iterations):
         N, d = self.n_chains, self.dim
-        outs = [(np.empty((r, N, d)), np.empty((r, N, 3)), np.empty((r, N), dtype=np.uint8))
+        outs = [(pinned_empty((r, N, d)), pinned_empty((r, N, 3)), pinned_empty((r, N), dtype=np.uint8))
                 for r in self.rows_per_level(n_iterations)]
         self.run_levels(n_iterations, outs)
         return outs
