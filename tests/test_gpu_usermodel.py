@@ -95,3 +95,34 @@ def test_source_that_does_not_compile_is_reported():
         e.set_level_source(0, "__device__ double tda_forward(const double* t, int d, int o) { return undefined_symbol; }",
                            np.zeros(2), 0, [1.0])
     e.close()
+
+
+def test_source_model_with_joint_prior_bounds():
+    """A source-defined model under a JointPrior with uniform components: proposals outside the support are rejected, the
+    trace equals the oracle's."""
+    from tinyda_amd.engine import Engine
+
+    d, m, N, T = 5, 23, 12, 120
+    rng = np.random.default_rng(8)
+    kinds = np.array([1, 0, 1, 0, 1])
+    loc = np.array([-0.4, 0.0, -0.3, 0.1, -0.5])
+    scale = np.array([0.8, 0.7, 0.6, 0.5, 1.0])
+    truth = np.array([0.0, 0.2, 0.0, -0.1, 0.1])
+    y = np_model(truth)[0] + 0.05 * rng.standard_normal(m)
+    theta0 = truth + 0.02 * rng.standard_normal((N, d))
+    e = Engine(N, d, seed=5)
+    e.set_prior_joint(kinds, loc, scale)
+    e.set_level_source(0, SRC, y, 0, [0.05 ** 2])
+    e.set_proposal(0, 0.02 * np.eye(d), scaling=1.0, adaptive=True, period=20)
+    e.init(theta0)
+    z, u = e.set_export(T)
+    params, stats, acc = e.run_host(T)
+    e.close()
+    lvl = orc.CallableGaussianLevel(np_model, y, "iso", 0.05 ** 2, orc.JointPriorOracle(kinds, loc, scale))
+    ref = orc.run_mh(lvl, dict(kind="grw", C=0.02 * np.eye(d), scaling=1.0, adaptive=True, period=20), theta0,
+                     np.swapaxes(z, 0, 1), np.swapaxes(u, 0, 1))
+    assert np.array_equal(acc, np.swapaxes(ref["accepted"][:, 1:], 0, 1))
+    np.testing.assert_allclose(stats[:, :, 2], np.swapaxes(ref["logpost"][:, 1:], 0, 1), rtol=1e-10)
+    lo, hi = np.where(kinds == 1, loc, -np.inf), np.where(kinds == 1, loc + scale, np.inf)
+    assert np.all(params >= lo) and np.all(params <= hi)
+    assert (acc == 0).sum() > 0
