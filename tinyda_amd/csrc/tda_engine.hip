@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "tda_kernels.h"
@@ -480,6 +481,16 @@ int copy_out(tda_engine* e, void* dst, const void* src_dev, size_t bytes) {
 }
 
 }  // namespace
+
+// Host-side unpacking of per-chain matrices is split over a few threads: f(c0, c1) handles chains [c0, c1).
+template <class F>
+static void host_chain_ranges(int64_t n, F f) {
+  const int64_t nt = std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 16, n / 64}));
+  if (nt == 1) return f(0, n);
+  std::vector<std::thread> pool;
+  for (int64_t t = 0; t < nt; ++t) pool.emplace_back(f, n * t / nt, n * (t + 1) / nt);
+  for (auto& th : pool) th.join();
+}
 
 extern "C" {
 
@@ -2559,14 +2570,31 @@ int tda_engine_get_proposal_state(tda_engine* e, double* scaling, double* C, dou
     const int64_t nL = e->L_shared ? 1 : NP;
     std::vector<double> h((size_t)nL * DP * DP);
     HIP_TRY(hipMemcpy(h.data(), e->Lk.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
-    for (int64_t c = 0; c < N; ++c) {
-      const double* Lc = h.data() + (e->L_shared ? 0 : (size_t)c * DP * DP);
-      for (int i = 0; i < d; ++i)
-        for (int j = 0; j < d; ++j) {
-          double s = 0.0;
-          for (int k = 0; k <= std::min(i, j); ++k) s += Lc[(size_t)k * DP + i] * Lc[(size_t)k * DP + j];
-          C[((size_t)c * d + i) * d + j] = s;
+    // C = L L^T as d rank-1 updates per chain (the innermost loop runs over contiguous memory and vectorises; every
+    // element still accumulates its products in ascending k); a factor shared by all chains is multiplied out once
+    auto unpack = [&](int64_t c0, int64_t c1) {
+      std::vector<double> acc((size_t)d * d);
+      for (int64_t c = c0; c < c1; ++c) {
+        const double* Lc = h.data() + (size_t)c * DP * DP;
+        std::fill(acc.begin(), acc.end(), 0.0);
+        for (int k = 0; k < d; ++k) {
+          const double* Lk = Lc + (size_t)k * DP;  // column k of L: Lk[i] = L[i][k], zero for i < k
+          for (int i = k; i < d; ++i) {
+            const double lik = Lk[i];
+            double* row = acc.data() + (size_t)i * d;
+            for (int j = k; j <= i; ++j) row[j] += lik * Lk[j];
+          }
         }
+        double* Cc = C + (size_t)c * d * d;
+        for (int i = 0; i < d; ++i)
+          for (int j = 0; j <= i; ++j) Cc[(size_t)i * d + j] = Cc[(size_t)j * d + i] = acc[(size_t)i * d + j];
+      }
+    };
+    if (e->L_shared) {
+      unpack(0, 1);
+      for (int64_t c = 1; c < N; ++c) std::copy(C, C + (size_t)d * d, C + (size_t)c * d * d);
+    } else {
+      host_chain_ranges(N, unpack);
     }
   }
   if (am_mu || am_sigma) {
@@ -2581,12 +2609,14 @@ int tda_engine_get_proposal_state(tda_engine* e, double* scaling, double* C, dou
       const size_t per = (size_t)am_tiles_rt(DP) * 256;
       std::vector<double> h((size_t)N * per);
       HIP_TRY(hipMemcpy(h.data(), e->am_sigma.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
-      for (int64_t c = 0; c < N; ++c) {
-        const double* f = h.data() + (size_t)c * per;
-        for (int i = 0; i < d; ++i)
-          for (int j = 0; j < d; ++j)
-            am_sigma[((size_t)c * d + i) * d + j] = f[am_sigma_offset(std::max(i, j), std::min(i, j))];
-      }
+      host_chain_ranges(N, [&](int64_t c0, int64_t c1) {
+        for (int64_t c = c0; c < c1; ++c) {
+          const double* f = h.data() + (size_t)c * per;
+          for (int i = 0; i < d; ++i)
+            for (int j = 0; j < d; ++j)
+              am_sigma[((size_t)c * d + i) * d + j] = f[am_sigma_offset(std::max(i, j), std::min(i, j))];
+        }
+      });
     }
   }
   if (counters) {
