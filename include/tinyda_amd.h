@@ -52,7 +52,8 @@ typedef enum tda_status {
   TDA_ERR_HIP = -2,         /* a HIP runtime call failed */
   TDA_ERR_STATE = -3,       /* call order (e.g. run before init) */
   TDA_ERR_UNSUPPORTED = -4, /* configuration outside what the device engine lowers */
-  TDA_ERR_NUMERIC = -5      /* e.g. covariance not positive definite */
+  TDA_ERR_NUMERIC = -5,     /* e.g. covariance not positive definite */
+  TDA_ERR_CALLBACK = -6     /* a host forward-model callback reported failure */
 } tda_status;
 
 /* GaussianLogLike factory outcome, tinyDA/distributions.py:237-243 */
@@ -268,6 +269,18 @@ int tda_engine_set_prior_joint(tda_engine* e, const int32_t* kind, const double*
  * diagonal prior.  A source that does not compile returns TDA_ERR_INVALID with the compiler log in tda_last_error(). */
 int tda_engine_set_level_source(tda_engine* e, int level, const char* source, int32_t m, const double* data,
                                 int32_t noise_kind, const double* noise);
+
+/* Forward model behind a batched host callback (extension; the reference calls a Python callable once per chain and step,
+ * posterior.py:95-96, and umbridge.py:56-80 does the same over HTTP).  Once per step the engine hands the callback ALL
+ * chains' proposals, theta: [n_chains][dim], and takes all model outputs back, F: [n_chains][m]; both are page-locked HOST
+ * buffers owned by the engine and valid during the call only.  Proposals, log-densities, the accept test, adaptation and the
+ * records stay on the device.  The callback returns 0, or non-zero to abort the run (tda_engine_init / tda_engine_run then
+ * return TDA_ERR_CALLBACK).  It is called on the thread that calls init / run; it must not call into the same engine.
+ * data: HOST [m]; noise: ISO (noise[0] = variance) or DIAG (HOST [m]).  Single-level chains, GRW / pCN / AM, diagonal
+ * prior (also tda_engine_set_prior_joint). */
+typedef int (*tda_forward_batch_fn)(void* user, const double* theta, double* F, int64_t n_chains, int32_t dim, int32_t m);
+int tda_engine_set_level_callback(tda_engine* e, int level, tda_forward_batch_fn fn, void* user, int32_t m,
+                                  const double* data, int32_t noise_kind, const double* noise);
 
 /* Convergence diagnostics of a device-resident history (the reference hands its chains to ArviZ, diagnostics.py:6-111):
  * rank-normalised split bulk ESS and R-hat (Vehtari et al. 2021) of every parameter.  params: DEVICE

@@ -18,7 +18,7 @@ from .likelihoods import (  # noqa: F401
 )
 from .engine import Engine  # noqa: F401
 from .records import Link  # noqa: F401
-from .models import DeviceModel, LinearModel, Rosenbrock  # noqa: F401
+from .models import BatchedModel, DeviceModel, LinearModel, Rosenbrock  # noqa: F401
 from .target import Posterior  # noqa: F401
 from .proposals import (  # noqa: F401
     DREAM, DREAMZ, AdaptiveMetropolis, CrankNicolson, GaussianRandomWalk, IndependenceSampler, Proposal)

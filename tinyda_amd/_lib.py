@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtinyda_hip.so")
 
 TDA_OK = 0
+TDA_ERR_CALLBACK = -6
 NOISE_ISO, NOISE_DIAG, NOISE_DENSE, NOISE_ADAPTIVE = 0, 1, 2, 3
 AEM_NONE, AEM_STATE_INDEPENDENT, AEM_STATE_DEPENDENT = 0, 1, 2
 PROP_GRW, PROP_PCN, PROP_AM, PROP_DREAMZ, PROP_INDEPENDENCE = 0, 1, 2, 3, 4
@@ -93,6 +94,8 @@ class tda_profile(C.Structure):
 
 # every symbol include/tinyda_amd.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
+# int (*tda_forward_batch_fn)(void* user, const double* theta, double* F, int64_t n_chains, int32_t dim, int32_t m)
+FORWARD_BATCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64, C.c_int32, C.c_int32)
 SYMBOLS = {
     "tda_last_error": (C.c_char_p, []),
     "tda_version": (C.c_char_p, []),
@@ -113,6 +116,7 @@ SYMBOLS = {
     "tda_engine_set_proposal_covariance": (C.c_int, [_P, _P]),
     "tda_engine_set_prior_joint": (C.c_int, [_P, _P, _P, _P]),
     "tda_engine_set_level_source": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_int32, _P, C.c_int32, _P]),
+    "tda_engine_set_level_callback": (C.c_int, [_P, C.c_int, _P, _P, C.c_int32, _P, C.c_int32, _P]),
     "tda_diag_ess_rhat": (C.c_int, [C.c_int, _P, _P, C.c_int64, C.c_int64, C.c_int32, C.c_int64, _P, _P]),
     "tda_engine_state_size": (C.c_int64, [_P]),
     "tda_engine_get_state": (C.c_int, [_P, _P, C.c_int64]),

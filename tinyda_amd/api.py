@@ -44,14 +44,14 @@ def _device_plan(posteriors, proposal):
         if (len(posteriors) != 1 or isinstance(proposal, (DREAMZ, CrankNicolson)) or "rosenbrock" in low
                 or low["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG)):
             return None
-    if any("source" in low for low in lows):  # source-defined models: single level, GRW / pCN / AM, iso / diag noise, diagonal prior
+    if any("source" in low or "batched" in low for low in lows):  # source-defined / batched host models: single level, GRW / pCN / AM, iso / diag noise, diagonal prior
         low = lows[0]
         if len(posteriors) != 1 or isinstance(proposal, DREAMZ) or low["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG):
             return None
         if np.count_nonzero(low["prior_cov"] - np.diag(np.diag(low["prior_cov"]))):
             return None
     if isinstance(proposal, IndependenceSampler):  # Gaussian q, single level, linear model
-        if len(posteriors) != 1 or proposal._lowering() is None or "source" in lows[0] or "rosenbrock" in lows[0]:
+        if len(posteriors) != 1 or proposal._lowering() is None or "source" in lows[0] or "batched" in lows[0] or "rosenbrock" in lows[0]:
             return None
     for low in lows[1:]:  # one prior for the hierarchy (every tinyDA example shares it across levels)
         if not (np.array_equal(low["prior_mean"], lows[0]["prior_mean"]) and np.array_equal(low["prior_cov"], lows[0]["prior_cov"])):
@@ -178,6 +178,8 @@ def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, se
             eng.set_level_rosenbrock(0, low["rosenbrock"][0], low["rosenbrock"][1], float(low["data"][0]), float(low["noise"][0]))
         elif "source" in low:
             eng.set_level_source(0, low["source"], low["data"], low["noise_kind"], low["noise"])
+        elif "batched" in low:
+            eng.set_level_callback(0, low["batched"], low["data"], low["noise_kind"], low["noise"], inplace=True)
         else:
             eng.set_level(0, low["A"], low["data"], low["noise_kind"], low["noise"], b=low["b"])
         if prop["kind"] == _lib.PROP_DREAMZ:

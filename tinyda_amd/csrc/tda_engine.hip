@@ -142,7 +142,18 @@ struct Level {
   bool set = false;
   int m = 0, m_pad = 0, ncb = 0, noise_kind = 0;
   double var = 1.0;
-  int model = 0;  // tda::MODEL_LINEAR / MODEL_ROSENBROCK / MODEL_USER (hiprtc-compiled source, tda_usermodel.inc)
+  int model = 0;  // tda::MODEL_LINEAR / MODEL_ROSENBROCK / MODEL_USER (hiprtc-compiled source, tda_usermodel.inc) /
+                  // MODEL_CALLBACK (batched host callback, tda_kernels_ext.h)
+  tda_forward_batch_fn cb_fn = nullptr;
+  void* cb_user = nullptr;
+  double* cb_theta_h = nullptr;  // page-locked [N][d] / [N][m]
+  double* cb_F_h = nullptr;
+  DevBuf<double> cb_prop, cb_F;
+  void release_callback_buffers() {
+    if (cb_theta_h) (void)hipHostFree(cb_theta_h);
+    if (cb_F_h) (void)hipHostFree(cb_F_h);
+    cb_theta_h = cb_F_h = nullptr;
+  }
   hipModule_t umod = nullptr;
   hipFunction_t ufn = nullptr;
   DevBuf<double> udata, uw;
@@ -428,7 +439,52 @@ int fill_user_args(tda_engine* e, const Level& lv, UserStepArgs& ua) {
   return TDA_OK;
 }
 
+constexpr int MODEL_CALLBACK = 3;
+
+void fill_ext_args(tda_engine* e, const Level& lv, ExtArgs& xa) {
+  xa.N = e->N;
+  xa.NP = e->NP;
+  xa.d = e->d;
+  xa.DP = e->DP;
+  xa.m = lv.m;
+  xa.prop = lv.cb_prop.p;
+  xa.F = lv.cb_F.p;
+  xa.data = lv.udata.p;
+  xa.w = lv.noise_kind == TDA_NOISE_DIAG ? lv.uw.p : nullptr;
+  xa.var = lv.var;
+  xa.pr_mean = e->prior_mean.p;
+  xa.pr_pinv = e->prior_pinv.p;
+  xa.pr_lo = e->prior_bounded ? e->prior_lo.p : nullptr;
+  xa.pr_hi = e->prior_bounded ? e->prior_hi.p : nullptr;
+  xa.logconst = e->prior_logconst;
+}
+
+// one step of a callback level: proposals -> host -> callback -> model outputs -> device -> accept (xa.s, xa.mode set)
+int ext_step(tda_engine* e, const Level& lv, const ExtArgs& xa) {
+  if (e->prior_kind == PRIOR_DENSE) return fail(TDA_ERR_UNSUPPORTED, "callback forward models need a diagonal prior covariance");
+  const unsigned grid = (unsigned)((e->N + EXT_WAVES - 1) / EXT_WAVES);
+  hipLaunchKernelGGL(k_ext_propose, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, xa);
+  HIP_TRY(hipMemcpyAsync(lv.cb_theta_h, lv.cb_prop.p, (size_t)e->N * e->d * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  const int crc = lv.cb_fn(lv.cb_user, lv.cb_theta_h, lv.cb_F_h, e->N, e->d, lv.m);
+  if (crc != 0) return fail(TDA_ERR_CALLBACK, "the forward-model callback returned %d", crc);
+  HIP_TRY(hipMemcpyAsync(lv.cb_F.p, lv.cb_F_h, (size_t)e->N * lv.m * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(k_ext_accept, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, xa);
+  HIP_TRY(hipGetLastError());
+  return TDA_OK;
+}
+
 int launch_eval(tda_engine* e, int level, double* theta, double* lp, double* ll) {
+  if (e->levels[level].model == MODEL_CALLBACK) {
+    ExtArgs xa{};
+    fill_ext_args(e, e->levels[level], xa);
+    xa.mode = 1;
+    xa.theta = theta;
+    xa.lp = lp;
+    xa.ll = ll;
+    xa.scaling = e->scaling.p;
+    return ext_step(e, e->levels[level], xa);
+  }
   if (e->levels[level].model == MODEL_USER) {
     UserStepArgs ua{};
     int rc = fill_user_args(e, e->levels[level], ua);
@@ -541,8 +597,10 @@ void tda_engine_destroy(tda_engine* e) {
     (void)hipEventDestroy(t.a);
     (void)hipEventDestroy(t.b);
   }
-  for (auto& lv : e->levels)
+  for (auto& lv : e->levels) {
     if (lv.umod) (void)hipModuleUnload(lv.umod);
+    lv.release_callback_buffers();
+  }
   if (e->copy_stream) {
     (void)hipStreamSynchronize(e->copy_stream);
     (void)hipStreamDestroy(e->copy_stream);
@@ -825,6 +883,47 @@ int tda_engine_set_level_source(tda_engine* e, int level, const char* source, in
   }
   if ((rc = lv.udata.upload(y))) return rc;
   lv.model = MODEL_USER;
+  lv.m = m;
+  lv.m_pad = 16;  // (no MFMA staging; keeps the shared LDS-size arithmetic of the run loop valid)
+  lv.ncb = 1;
+  lv.noise_kind = noise_kind;
+  lv.set = true;
+  e->inited = false;
+  return TDA_OK;
+}
+
+int tda_engine_set_level_callback(tda_engine* e, int level, tda_forward_batch_fn fn, void* user, int32_t m, const double* data,
+                                  int32_t noise_kind, const double* noise) {
+  if (!e || !fn || !data || !noise) return fail(TDA_ERR_INVALID, "null argument");
+  if (level != 0 || e->nlev != 1) return fail(TDA_ERR_UNSUPPORTED, "callback forward models are lowered for single-level chains only");
+  if (m < 1) return fail(TDA_ERR_INVALID, "m must be >= 1");
+  if (noise_kind != TDA_NOISE_ISO && noise_kind != TDA_NOISE_DIAG)
+    return fail(TDA_ERR_UNSUPPORTED, "callback forward models take isotropic or diagonal noise");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  Level& lv = e->levels[level];
+  std::vector<double> y(data, data + m), w;
+  int rc;
+  if (noise_kind == TDA_NOISE_ISO) {
+    if (!(noise[0] > 0.0)) return fail(TDA_ERR_NUMERIC, "noise variance must be positive");
+    lv.var = noise[0];
+  } else {
+    w.resize(m);
+    for (int i = 0; i < m; ++i) {
+      if (!(noise[i] > 0.0)) return fail(TDA_ERR_NUMERIC, "noise variance must be positive");
+      w[i] = 1.0 / noise[i];
+    }
+    lv.var = 1.0;
+    if ((rc = lv.uw.upload(w))) return rc;
+  }
+  if ((rc = lv.udata.upload(y))) return rc;
+  lv.release_callback_buffers();
+  HIP_TRY(hipHostMalloc((void**)&lv.cb_theta_h, (size_t)e->N * e->d * sizeof(double), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&lv.cb_F_h, (size_t)e->N * m * sizeof(double), hipHostMallocDefault));
+  if ((rc = lv.cb_prop.alloc((size_t)e->N * e->d))) return rc;
+  if ((rc = lv.cb_F.alloc((size_t)e->N * m))) return rc;
+  lv.cb_fn = fn;
+  lv.cb_user = user;
+  lv.model = MODEL_CALLBACK;
   lv.m = m;
   lv.m_pad = 16;  // (no MFMA staging; keeps the shared LDS-size arithmetic of the run loop valid)
   lv.ncb = 1;
@@ -1836,7 +1935,28 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     sa.rec_params = p_dev ? o_params + (size_t)done * N * d : ((o_params || is_am) ? blk_params : nullptr);
     sa.rec_stats = s_dev ? o_stats + (size_t)done * N * 3 : (o_stats ? blk_stats : nullptr);
     sa.rec_acc = a_dev ? o_acc + (size_t)done * N : (o_acc ? blk_acc : nullptr);
-    if (lv.model == MODEL_USER) {
+    if (lv.model == MODEL_CALLBACK) {
+      if (e->pp.kind == TDA_PROP_INDEPENDENCE) return fail(TDA_ERR_UNSUPPORTED, "the independence sampler is not lowered for callback models");
+      ExtArgs xa{};
+      fill_ext_args(e, lv, xa);
+      xa.mode = 0;
+      xa.prop_kind = e->pp.kind;
+      xa.theta = sa.theta;
+      xa.lp = sa.lp;
+      xa.ll = sa.ll;
+      xa.scaling = sa.scaling;
+      xa.acc_count = sa.acc_count;
+      xa.inc = sa.inc;
+      xa.u = sa.u;
+      xa.rec_params = sa.rec_params;
+      xa.rec_stats = sa.rec_stats;
+      xa.rec_acc = sa.rec_acc;
+      for (int s = 0; s < (int)S; ++s) {
+        xa.s = s;
+        int xrc = ext_step(e, lv, xa);
+        if (xrc) return xrc;
+      }
+    } else if (lv.model == MODEL_USER) {
       UserStepArgs ua{};
       int urc = fill_user_args(e, lv, ua);
       if (urc) return urc;

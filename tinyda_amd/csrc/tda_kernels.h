@@ -4,8 +4,10 @@
 //   tda_kernels_ml.h      k_ml_steps (DA / MLDA state machine), k_aem_action (adaptive error model)
 //   tda_kernels_dreamz.h  k_dreamz_draw / steps / adapt, k_colsum_partial
 //   tda_kernels_pooled.h  k_moments_partial / final
+//   tda_kernels_ext.h     k_ext_propose / k_ext_accept (batched host-callback forward models)
 #pragma once
 #include "tda_kernels_mh.h"
 #include "tda_kernels_ml.h"
 #include "tda_kernels_dreamz.h"
 #include "tda_kernels_pooled.h"
+#include "tda_kernels_ext.h"

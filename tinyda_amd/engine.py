@@ -97,6 +97,42 @@ class Engine:
         noise = _f64(np.atleast_1d(noise))
         check(self.lib.tda_engine_set_level_source(self.h, level, source.encode(), data.size, _ptr(data), noise_kind, _ptr(noise)))
 
+    def set_level_callback(self, level, fn, data, noise_kind, noise, inplace=False):
+        """forward model behind a batched host callback: fn maps the (n_chains, dim) proposals of a step to the
+        (n_chains, m) model outputs; everything else of the step stays on the device.  inplace: fn(thetas, out) writes
+        the outputs into the engine's page-locked buffer itself (saves an allocation and a copy per step)"""
+        data = _f64(np.atleast_1d(data))
+        noise = _f64(np.atleast_1d(noise))
+        m = data.size
+        self._cb_exc = None
+
+        def trampoline(_user, theta_p, F_p, n, dim, m_):
+            try:
+                theta = np.ctypeslib.as_array(theta_p, shape=(n, dim))
+                F = np.ctypeslib.as_array(F_p, shape=(n, m_))
+                if inplace:
+                    fn(theta, F)
+                    return 0
+                out = np.asarray(fn(theta), dtype=np.float64)
+                if out.shape != (n, m_):
+                    raise ValueError("the batched model returned shape %s, expected %s" % (out.shape, (n, m_)))
+                F[...] = out
+                return 0
+            except BaseException as exc:  # an exception must not unwind through the C frames
+                self._cb_exc = exc
+                return 1
+
+        self._cb = _lib.FORWARD_BATCH_FN(trampoline)  # keep the thunk alive as long as the engine
+        check(self.lib.tda_engine_set_level_callback(self.h, level, C.cast(self._cb, C.c_void_p), None, m, _ptr(data),
+                                                     noise_kind, _ptr(noise)))
+
+    def _check_run(self, rc):
+        exc = getattr(self, "_cb_exc", None)
+        if rc == _lib.TDA_ERR_CALLBACK and exc is not None:
+            self._cb_exc = None
+            raise exc
+        check(rc)
+
     def set_level_rosenbrock(self, level, a=1.0, b=10.0, data=0.0, noise_var=1.0):
         check(self.lib.tda_engine_set_level_rosenbrock(self.h, level, a, b, data, noise_var))
 
@@ -192,7 +228,7 @@ class Engine:
         if theta0 is not None and isinstance(theta0, np.ndarray):
             theta0 = _f64(theta0)
             assert theta0.shape == (self.n_chains, self.dim)
-        check(self.lib.tda_engine_init(self.h, _ptr(theta0)))
+        self._check_run(self.lib.tda_engine_init(self.h, _ptr(theta0)))
 
     # -- variates -----------------------------------------------------------------------
     def set_replay(self, z, u):
@@ -223,7 +259,7 @@ class Engine:
     # -- running ------------------------------------------------------------------------
     def run(self, n_iterations, params=None, stats=None, accepted=None, sync=True):
         out = _lib.tda_outputs(C.sizeof(_lib.tda_outputs), 0, _ptr(params), _ptr(stats), _ptr(accepted))
-        check(self.lib.tda_engine_run(self.h, n_iterations, C.byref(out)))
+        self._check_run(self.lib.tda_engine_run(self.h, n_iterations, C.byref(out)))
         if sync:
             self.sync()
 
@@ -240,7 +276,7 @@ class Engine:
         for k in range(self.n_levels):
             p, s_, a = outputs[k] if outputs and outputs[k] is not None else (None, None, None)
             arr[k] = _lib.tda_outputs(C.sizeof(_lib.tda_outputs), 0, _ptr(p), _ptr(s_), _ptr(a))
-        check(self.lib.tda_engine_run(self.h, n_iterations, arr))
+        self._check_run(self.lib.tda_engine_run(self.h, n_iterations, arr))
         if sync:
             self.sync()
 

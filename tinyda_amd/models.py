@@ -55,3 +55,37 @@ class DeviceModel:
         if self.reference is None:
             raise TypeError("this DeviceModel has no host reference implementation; run it with backend='hip'")
         return np.atleast_1d(np.asarray(self.reference(np.asarray(parameters, dtype=np.float64)), dtype=np.float64))
+
+
+class BatchedModel:
+    """An arbitrary host forward model evaluated for ALL chains at once (extension; tinyDA calls the model once per chain
+    and step, posterior.py:95-96).  `fn` maps an (n_chains, dim) array of parameters to an (n_chains, n_outputs) array of
+    model outputs -- a vectorised NumPy function, a batched solver, a remote service.  On the device path the engine hands
+    it each step's proposals in one call and keeps proposals, log-densities, accept test, adaptation and records on the
+    GPU; called with a single parameter vector it honours the reference's model protocol.
+
+    inplace=True: `fn(parameters, out)` writes the outputs into `out` (the engine's page-locked staging buffer) instead
+    of returning a new array."""
+
+    def __init__(self, fn, n_outputs, inplace=False):
+        self.fn = fn
+        self.n_outputs = int(n_outputs)
+        self.inplace = bool(inplace)
+
+    def batch(self, parameters, out=None):
+        parameters = np.asarray(parameters, dtype=np.float64)
+        if not self.inplace:
+            res = np.asarray(self.fn(parameters), dtype=np.float64)
+            if out is None:
+                return res
+            if res.shape != out.shape:
+                raise ValueError("the batched model returned shape %s, expected %s" % (res.shape, out.shape))
+            out[...] = res
+            return out
+        if out is None:
+            out = np.empty((parameters.shape[0], self.n_outputs))
+        self.fn(parameters, out)
+        return out
+
+    def __call__(self, parameters):
+        return self.batch(np.asarray(parameters, dtype=np.float64)[None, :])[0]

@@ -2,7 +2,7 @@
 import numpy as np
 
 from .records import Link
-from .models import DeviceModel, LinearModel, Rosenbrock
+from .models import BatchedModel, DeviceModel, LinearModel, Rosenbrock
 
 
 class Posterior:
@@ -62,7 +62,7 @@ class Posterior:
         return self._lowering_with(mean, cov)
 
     def _lowering_with(self, mean, cov):
-        if not isinstance(self.model, (LinearModel, Rosenbrock, DeviceModel)) or not hasattr(self.likelihood, "_lowering"):
+        if not isinstance(self.model, (LinearModel, Rosenbrock, DeviceModel, BatchedModel)) or not hasattr(self.likelihood, "_lowering"):
             return None
         mean = np.atleast_1d(np.asarray(mean, dtype=np.float64))
         cov = np.atleast_2d(np.asarray(cov, dtype=np.float64))
@@ -79,6 +79,13 @@ class Posterior:
             if data.shape != (self.model.n_outputs,):
                 return None
             return dict(prior_mean=mean, prior_cov=cov, source=self.model.source, A=None, b=None, data=data,
+                        noise_kind=kind, noise=np.asarray(noise, dtype=np.float64))
+        if isinstance(self.model, BatchedModel):
+            kind, noise = self.likelihood._lowering()
+            data = np.atleast_1d(np.asarray(self.likelihood.data, dtype=np.float64))
+            if data.shape != (self.model.n_outputs,):
+                return None
+            return dict(prior_mean=mean, prior_cov=cov, batched=self.model.batch, A=None, b=None, data=data,
                         noise_kind=kind, noise=np.asarray(noise, dtype=np.float64))
         if self.model.A.shape[1] != mean.shape[0]:
             return None
