@@ -79,9 +79,13 @@ def main():
     from tinyda_amd import distributed as tdist
     from tinyda_amd.engine import Engine
 
-    rank, local_rank, world = tdist.init_process_group()
+    # TINYDA_BENCH_ONE_GPU=1 (testing the N > 1 code path on a one-GPU box): every rank on cuda:0, gloo instead of RCCL
+    one_gpu = os.environ.get("TINYDA_BENCH_ONE_GPU") == "1"
+    rank, local_rank, world = tdist.init_process_group("gloo" if one_gpu else None)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     N, K, W = args.chains, args.steps, args.warmup
@@ -165,7 +169,8 @@ def main():
             out["ess"] = {"min_bulk_ess_node": ess_min * world, "median_bulk_ess_node": ess_med * world,
                           "max_rhat": float(np.nanmax(dd["rhat"])), "chains_used": N, "draws_per_chain": K - K // 2,
                           "computed": "on device, all chains"}
-        if not args.no_ess:
+        extras = world == 1  # the side measurements below are single-GPU figures (and the pooled one holds a collective)
+        if extras and not args.no_ess:
             # The C2 recipe starts every chain from a prior draw with C0 = 1e-4 I, so the timed window is still burn-in
             # and its ESS is dominated by between-chain variance.  For reference, the same kernel pipeline started in
             # stationarity (theta0 ~ exact conjugate posterior, C0 = sd * posterior covariance): ESS/s of the sampler
@@ -214,21 +219,22 @@ def main():
             e3.close()
         # extension, not the headline: AdaptiveMetropolis(block_moments=True) -- the running covariance as one rank-S update
         # per block on the matrix cores instead of the reference's elementwise recursion (parity 1e-8 instead of 1e-10)
-        e4 = Engine(N, D, seed=2026, device=local_rank, chain_offset=rank * N)
-        e4.set_prior(np.zeros(D), np.eye(D))
-        e4.set_level(0, A, y, 0, SIGMA ** 2)
-        e4.set_proposal(2, 1e-4 * np.eye(D), t0=100, period=100, block_moments=True)
-        e4.init(None)
-        if W > 0:
-            e4.run(W, params[:W], stats[:W], acc[:W])
-        torch.cuda.synchronize()
-        t3 = time.perf_counter()
-        e4.run(K, params[:K], stats[:K], acc[:K], sync=True)
-        torch.cuda.synchronize()
-        dtb = time.perf_counter() - t3
-        out["block_moments_extension"] = {"evals_per_sec_per_gpu": N * K / dtb, "seconds": dtb,
-                                          "acceptance_rate": float(acc[:K].float().mean().item())}
-        e4.close()
+        if extras:
+            e4 = Engine(N, D, seed=2026, device=local_rank, chain_offset=rank * N)
+            e4.set_prior(np.zeros(D), np.eye(D))
+            e4.set_level(0, A, y, 0, SIGMA ** 2)
+            e4.set_proposal(2, 1e-4 * np.eye(D), t0=100, period=100, block_moments=True)
+            e4.init(None)
+            if W > 0:
+                e4.run(W, params[:W], stats[:W], acc[:W])
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            e4.run(K, params[:K], stats[:K], acc[:K], sync=True)
+            torch.cuda.synchronize()
+            dtb = time.perf_counter() - t3
+            out["block_moments_extension"] = {"evals_per_sec_per_gpu": N * K / dtb, "seconds": dtb,
+                                              "acceptance_rate": float(acc[:K].float().mean().item())}
+            e4.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(A, y)
         print(json.dumps(out))
