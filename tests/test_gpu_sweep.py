@@ -1,0 +1,162 @@
+"""Seeded random sweep of single-level configurations (dimension, observations, chains, proposal, noise and prior kind,
+block length, split runs) against the oracle on the exported Philox stream.  Same bar as test_gpu_parity.py: accept masks
+bit-exact, log-posterior within 1e-10 relative."""
+import numpy as np
+import pytest
+
+from oracle import tinyda_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+
+
+def _spd(rng, n, scale):
+    B = rng.standard_normal((n, n))
+    return scale * (np.eye(n) + 0.3 * B @ B.T / n)
+
+
+def _case(i):
+    rng = np.random.default_rng(1000 + i)
+    d = int(rng.choice([1, 2, 3, 5, 8, 9, 15, 16, 17, 24, 31, 32, 33, 48, 63, 64]))
+    m = int(rng.choice([1, 2, 7, 16, 17, 40, 64, 65, 130, 257]))
+    N = int(rng.choice([1, 2, 15, 16, 17, 33, 50]))
+    T = int(rng.choice([1, 37, 90, 140]))
+    kind = str(rng.choice(["grw", "grw_adaptive", "pcn", "pcn_adaptive", "am", "am_adaptive"]))
+    noise = str(rng.choice(["iso", "diag", "dense"]))
+    prior = str(rng.choice(["identity", "diag", "dense"])) if "pcn" not in kind else str(rng.choice(["identity", "dense0"]))
+    block = int(rng.choice([0, 0, 7, 16, 33]))
+    split = bool(rng.integers(0, 2))
+    return dict(i=i, d=d, m=m, N=N, T=T, kind=kind, noise=noise, prior=prior, block=block, split=split)
+
+
+@pytest.mark.parametrize("i", range(40))
+def test_random_single_level_configuration(i):
+    from tinyda_amd.engine import Engine
+
+    c = _case(i)
+    d, m, N, T = c["d"], c["m"], c["N"], c["T"]
+    rng = np.random.default_rng(5000 + i)
+    A = rng.standard_normal((m, d)) / np.sqrt(max(d, 4))
+    b = rng.standard_normal(m) * 0.1 if i % 3 == 0 else None
+    truth = 0.7 * rng.standard_normal(d)
+    y = A @ truth + (0 if b is None else b) + 0.1 * rng.standard_normal(m)
+    if c["prior"] == "identity":
+        pm, pc = np.zeros(d), np.eye(d)
+    elif c["prior"] == "diag":
+        pm, pc = 0.1 * rng.standard_normal(d), np.diag(0.5 + rng.random(d))
+    elif c["prior"] == "dense0":  # pCN ignores the prior mean (proposal.py:349-355): zero-mean priors only
+        pm, pc = np.zeros(d), _spd(rng, d, 1.0)
+    else:
+        pm, pc = 0.1 * rng.standard_normal(d), _spd(rng, d, 1.0)
+    if c["noise"] == "iso":
+        nk, nz, onz = 0, 0.01, 0.01
+    elif c["noise"] == "diag":
+        nz = 0.01 * (0.5 + rng.random(m))
+        nk, onz = 1, nz
+    else:
+        nz = _spd(rng, m, 0.01)
+        nk, onz = 2, nz
+    theta0 = truth + 0.05 * rng.standard_normal((N, d))
+    period = int(rng.choice([10, 16, 25]))
+    C0 = _spd(rng, d, 2e-3 / max(d, 1) * 4)
+    e = Engine(N, d, seed=40 + i, chain_offset=int(rng.integers(0, 100)), block_steps=c["block"])
+    e.set_prior(pm, pc)
+    e.set_level(0, A, y, nk, nz, b=b)
+    adaptive = c["kind"].endswith("adaptive")
+    if c["kind"].startswith("grw"):
+        e.set_proposal(0, C0, scaling=0.8, adaptive=adaptive, period=period, gamma=1.05)
+        prop = dict(kind="grw", C=C0, scaling=0.8, adaptive=adaptive, period=period, gamma=1.05)
+    elif c["kind"].startswith("pcn"):
+        e.set_proposal(1, None, scaling=0.04, adaptive=adaptive, period=period)
+        prop = dict(kind="pcn", scaling=0.04, adaptive=adaptive, period=period)
+    else:
+        t0 = int(rng.choice([0, period, 3 * period]))
+        e.set_proposal(2, C0, t0=t0, period=period, adaptive=adaptive)
+        prop = dict(kind="am", C0=C0, t0=t0, period=period, adaptive=adaptive)
+    e.init(theta0)
+    z, u = e.set_export(T)
+    if c["split"] and T > 2:  # two run() calls continue the same chains
+        k = T // 3
+        p1, s1, a1 = e.run_host(k)
+        p2, s2, a2 = e.run_host(T - k)
+        params, stats, acc = np.concatenate([p1, p2]), np.concatenate([s1, s2]), np.concatenate([a1, a2])
+    else:
+        params, stats, acc = e.run_host(T)
+    e.close()
+    lvl = orc.LinearGaussianLevel(A, y, c["noise"], onz, orc.MVNPrior(pm, pc), b=b)
+    res = orc.run_mh(lvl, prop, theta0, np.swapaxes(z, 0, 1), np.swapaxes(u, 0, 1))
+    ref_acc = np.swapaxes(res["accepted"][:, 1:], 0, 1)
+    assert np.array_equal(acc, ref_acc), "%s: %d accept flips" % (c, int((acc != ref_acc).sum()))
+    np.testing.assert_allclose(stats[:, :, 2], np.swapaxes(res["logpost"][:, 1:], 0, 1), rtol=RTOL, err_msg=str(c))
+    np.testing.assert_allclose(params, np.swapaxes(res["theta"][:, 1:], 0, 1), rtol=1e-8, atol=1e-10, err_msg=str(c))
+
+
+def _ml_case(i):
+    rng = np.random.default_rng(3000 + i)
+    nl = int(rng.choice([2, 2, 3, 4]))
+    d = int(rng.choice([2, 5, 8, 16, 17, 33, 64]))
+    ms = tuple(int(x) for x in rng.choice([3, 16, 20, 65, 130], size=nl))
+    sl = [int(x) for x in rng.choice([1, 2, 3, 5], size=nl - 1)]
+    N = int(rng.choice([1, 16, 17, 35]))
+    n_fine = int(rng.choice([1, 6, 11]))
+    kind = str(rng.choice(["pcn", "grw_adaptive", "am", "am_adaptive"]))
+    noise = str(rng.choice(["iso", "diag"]))
+    randomize = bool(nl == 2 and sl[0] > 1 and rng.integers(0, 2))
+    return dict(i=i, nl=nl, d=d, ms=ms, sl=sl, N=N, n_fine=n_fine, kind=kind, noise=noise, randomize=randomize)
+
+
+@pytest.mark.parametrize("i", range(24))
+def test_random_multilevel_configuration(i):
+    """Delayed Acceptance / MLDA hierarchies of 2-4 levels on the engine's own Philox stream against the oracle."""
+    from tinyda_amd.engine import Engine
+    from tests.test_gpu_multilevel import _oracle_uniforms
+
+    c = _ml_case(i)
+    nl, d, ms, sl, N, n_fine = c["nl"], c["d"], c["ms"], c["sl"], c["N"], c["n_fine"]
+    rng = np.random.default_rng(7000 + i)
+    truth = 0.5 * rng.standard_normal(d)
+    As = [rng.standard_normal((m, d)) / np.sqrt(max(d, 4)) for m in ms]
+    ys = [A @ truth + 0.1 * rng.standard_normal(len(A)) for A in As]
+    theta0 = truth + 0.05 * rng.standard_normal((N, d))
+    period = int(rng.choice([8, 20]))
+    C0 = _spd(rng, d, 4e-3 / max(d, 1))
+    if c["kind"] == "pcn":
+        prop = dict(kind="pcn", scaling=0.05, adaptive=True, gamma=1.01, period=period)
+    elif c["kind"] == "grw_adaptive":
+        prop = dict(kind="grw", C=C0, scaling=0.9, adaptive=True, gamma=1.02, period=period)
+    else:
+        prop = dict(kind="am", C0=C0, t0=period, period=period, adaptive=c["kind"].endswith("adaptive"))
+    seed = 900 + i
+    e = Engine(N, d, seed=seed, n_levels=nl)
+    e.set_prior(np.zeros(d), np.eye(d))
+    noises = []
+    for k in range(nl):
+        if c["noise"] == "iso":
+            e.set_level(k, As[k], ys[k], 0, 0.01)
+            noises.append(0.01)
+        else:
+            nz = 0.01 * (0.5 + rng.random(ms[k]))
+            e.set_level(k, As[k], ys[k], 1, nz)
+            noises.append(nz)
+    if prop["kind"] == "pcn":
+        e.set_proposal(1, None, scaling=prop["scaling"], adaptive=True, gamma=prop["gamma"], period=period)
+    elif prop["kind"] == "grw":
+        e.set_proposal(0, C0, scaling=0.9, adaptive=True, gamma=1.02, period=period)
+    else:
+        e.set_proposal(2, C0, t0=period, period=period, adaptive=prop["adaptive"])
+    e.set_subchains(sl, c["randomize"])
+    e.init(theta0)
+    rows = e.rows_per_level(n_fine)
+    z, _ = e.set_export(rows[0])
+    outs = e.run_levels_host(n_fine)
+    e.close()
+    us, ridx = _oracle_uniforms(seed, N, rows, sl, sl[0] if c["randomize"] else None)
+    prior = orc.MVNPrior(np.zeros(d), np.eye(d))
+    levels = [orc.LinearGaussianLevel(As[k], ys[k], c["noise"], noises[k], prior) for k in range(nl)]
+    res, _ = orc.run_multilevel(levels, prop, sl, theta0, np.swapaxes(z, 0, 1), us, n_fine, ridx)
+    for k in range(nl):
+        ref = res[k]
+        sk = slice(1, None) if k == nl - 1 else slice(None)
+        assert np.array_equal(outs[k][2], ref["accepted"][:, sk].T), "%s: level %d accept masks differ" % (c, k)
+        np.testing.assert_allclose(outs[k][1][:, :, 2], ref["logpost"][:, sk].T, rtol=RTOL, err_msg=str(c))
