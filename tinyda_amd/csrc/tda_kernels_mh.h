@@ -1042,6 +1042,11 @@ __global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
     // instructions that every lane would otherwise repeat in every step) and the loop reads them back with v_readlane
     double c_inv = 0.0, c_a = 0.0, c_b = 0.0;
     double xn = lj ? a.rec_params[(size_t)c * a.d + lane] : 0.0;
+    // the eps I term as an operand instead of a select: element r of a diagonal tile is on the diagonal iff hi + 4 r == lc
+    // (padded dimensions collect eps too; nothing reads them)
+    double epsd[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) epsd[r] = (hi + 4 * r == lc) ? a.eps : 0.0;
     for (int s = 0; s < a.S; ++s) {
       if ((s & 63) == 0) {
         const double tl = (double)(a.t_base + s + lane + 1);
@@ -1085,7 +1090,7 @@ __global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
           for (int r = 0; r < 4; ++r) {
             const double tp = t1 * (pr[r] * pc[tj]);
             double M = (TM[idx][r] - tp) + xr[r] * xc[tj];
-            if (ti == tj && hi + 4 * r == lc) M = (16 * ti + lc < a.d) ? M + a.eps : M;
+            if (ti == tj) M += epsd[r];  // + eps on the diagonal, + 0 beside it
             Sg[idx][r] = ca * Sg[idx][r] + cb * M;
             TM[idx][r] = tp;
           }
