@@ -345,7 +345,7 @@ void launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st) {
 
 template <int DPAD>
 void launch_dz_draw(const DreamDrawArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_dreamz_draw<DPAD>, dim3((unsigned)a.NP), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(k_dreamz_draw<DPAD>, dim3((unsigned)(a.NP / dz_chains_per_wave<DPAD>())), dim3(64), 0, st, a);
 }
 template <int DPAD>
 void launch_dz_steps(const DreamStepArgs& a, size_t lds, hipStream_t st) {
@@ -354,6 +354,10 @@ void launch_dz_steps(const DreamStepArgs& a, size_t lds, hipStream_t st) {
 template <int DPAD>
 void launch_colsum(const double* m, int64_t row0, int64_t nrows, double* partial, int64_t nb, hipStream_t st) {
   hipLaunchKernelGGL(k_colsum_partial<DPAD>, dim3((unsigned)nb), dim3(64), 0, st, m, row0, nrows, partial);
+}
+template <int DPAD>
+void launch_colsum_final(const double* partial, int64_t nb, double* zsum, double* zsq, hipStream_t st) {
+  hipLaunchKernelGGL(k_colsum_final<DPAD>, dim3(1), dim3(64 * COLSUM_FINAL_WAVES), 0, st, partial, nb, zsum, zsq);
 }
 template <int DPAD>
 void launch_dz_adapt(const DreamAdaptArgs& a, hipStream_t st) {
@@ -1045,9 +1049,14 @@ int tda_engine_archive_take(tda_engine* e, double* rows, int64_t* n_steps) {
   if (n_steps) *n_steps = e->pending_steps;
   if (rows && e->pending_steps) {  // [steps][N][d] without padding
     const hipMemcpyKind kind = is_device_ptr(rows) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    for (int64_t s = 0; s < e->pending_steps; ++s)
-      HIP_TRY(hipMemcpy2DAsync(rows + (size_t)s * e->N * e->d, e->d * sizeof(double), e->blk_hist.p + (size_t)s * e->NP * e->DP,
-                               e->DP * sizeof(double), e->d * sizeof(double), e->N, kind, e->stream));
+    if (e->N == e->NP) {  // no padded chains: the pending rows are one [steps * N][DP] matrix
+      HIP_TRY(hipMemcpy2DAsync(rows, e->d * sizeof(double), e->blk_hist.p, e->DP * sizeof(double), e->d * sizeof(double),
+                               e->pending_steps * e->N, kind, e->stream));
+    } else {
+      for (int64_t s = 0; s < e->pending_steps; ++s)
+        HIP_TRY(hipMemcpy2DAsync(rows + (size_t)s * e->N * e->d, e->d * sizeof(double), e->blk_hist.p + (size_t)s * e->NP * e->DP,
+                                 e->DP * sizeof(double), e->d * sizeof(double), e->N, kind, e->stream));
+    }
     HIP_TRY(hipStreamSynchronize(e->stream));
   }
   if (rows) e->pending_steps = 0;  // a NULL buffer only asks how many steps are pending
@@ -2502,12 +2511,7 @@ static int dreamz_sums_catchup(tda_engine* e, int64_t row0, int64_t nrows, bool 
         if (rc) return rc;
       }
       DISPATCH_DPAD(e->DP, launch_colsum<DPAD>(e->arch.p, row0, nrows, e->dz_partial.p, nb, e->stream));
-      DreamAdaptArgs a1 = aa;
-      a1.N = 1;
-      a1.boundary = 0;
-      a1.partial = e->dz_partial.p;
-      a1.npart = nb;
-      DISPATCH_DPAD(e->DP, launch_dz_adapt<DPAD>(a1, e->stream));
+      DISPATCH_DPAD(e->DP, launch_colsum_final<DPAD>(e->dz_partial.p, nb, e->zsum.p, e->zsq.p, e->stream));
     }
     if (!boundary) return TDA_OK;
     aa.nrows = 0;  // ... then every chain adapts against the finished sums
@@ -2629,10 +2633,15 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
         if (boundary && (rc = dreamz_sums_catchup(e, e->arch_rows, 0, true, adaptive, std::pow(e->dz.gamma, -(double)e->k_adapt)))) return rc;
       }
       if (e->auto_append) {  // single process: the local rows are all rows; canonical order = step-major, chain minor
-        for (int64_t s = 0; s < e->pending_steps; ++s)
-          HIP_TRY(hipMemcpy2DAsync(e->arch.p + (size_t)(e->arch_rows + s * N) * DP, DP * sizeof(double),
-                                   e->blk_hist.p + (size_t)s * NP * DP, DP * sizeof(double), DP * sizeof(double), N,
-                                   hipMemcpyDeviceToDevice, e->stream));
+        if (N == NP) {
+          HIP_TRY(hipMemcpyAsync(e->arch.p + (size_t)e->arch_rows * DP, e->blk_hist.p, (size_t)e->pending_steps * N * DP * sizeof(double),
+                                 hipMemcpyDeviceToDevice, e->stream));
+        } else {
+          for (int64_t s = 0; s < e->pending_steps; ++s)
+            HIP_TRY(hipMemcpy2DAsync(e->arch.p + (size_t)(e->arch_rows + s * N) * DP, DP * sizeof(double),
+                                     e->blk_hist.p + (size_t)s * NP * DP, DP * sizeof(double), DP * sizeof(double), N,
+                                     hipMemcpyDeviceToDevice, e->stream));
+        }
         const int64_t new_rows = e->pending_steps * N;
         e->pending_steps = 0;
         if ((rc = dreamz_sums_catchup(e, e->arch_rows, new_rows, false, false, 1.0))) return rc;

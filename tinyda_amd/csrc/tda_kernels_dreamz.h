@@ -50,10 +50,18 @@ struct DreamDrawArgs {
   double* u_export;
 };
 
+// 64 / DPAD chains share a wave (lane = chain-in-wave * DPAD + parameter), so small dimensions do not idle lanes
+template <int DPAD>
+constexpr int dz_chains_per_wave() {
+  return 64 / DPAD;
+}
+
 template <int DPAD>
 __global__ void __launch_bounds__(64) k_dreamz_draw(const DreamDrawArgs a) {
-  const int lane = threadIdx.x;
-  const int64_t c = blockIdx.x;
+  constexpr int CPW = dz_chains_per_wave<DPAD>();
+  const int seg = threadIdx.x / DPAD;
+  const int lane = threadIdx.x % DPAD;  // parameter index within the chain
+  const int64_t c = (int64_t)blockIdx.x * CPW + seg;  // NP is a multiple of 16 >= CPW: every c < NP
   const bool real_chain = c < a.N;
   const uint32_t gc = (uint32_t)(a.chain_offset + c);
   const bool lj = lane < a.d;
@@ -122,7 +130,8 @@ __global__ void __launch_bounds__(64) k_dreamz_draw(const DreamDrawArgs a) {
       if (a.eps_export && real_chain) a.eps_export[row * a.d + lane] = en;
     }
     bool ind = lj && (su < CR);
-    const unsigned long long bal = __ballot(ind);
+    unsigned long long bal = __ballot(ind);
+    if (CPW > 1) bal = (bal >> (seg * DPAD)) & ((1ull << (DPAD & 63)) - 1ull);  // this chain's lanes
     int dsub = __popcll(bal);
     if (dsub == 0) {  // proposal.py:838-839
       ind = lane == forced;
@@ -392,6 +401,35 @@ __global__ void __launch_bounds__(64) k_colsum_partial(const double* __restrict_
   }
   partial[((size_t)b * 2 + 0) * DPAD + lane] = zs;
   partial[((size_t)b * 2 + 1) * DPAD + lane] = zq;
+}
+
+// zsum / zsq += the chunk sums, in an order that depends on the number of chunks only: wave w adds chunks w, w + W, ...
+// in ascending order, then the W wave totals are added in ascending order (deterministic for a given append)
+constexpr int COLSUM_FINAL_WAVES = 16;
+template <int DPAD>
+__global__ void __launch_bounds__(64 * COLSUM_FINAL_WAVES) k_colsum_final(const double* __restrict__ partial, int64_t npart,
+                                                                          double* __restrict__ zsum, double* __restrict__ zsq) {
+  __shared__ double s_part[COLSUM_FINAL_WAVES][2][DPAD];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane < DPAD) {
+    double zs = 0.0, zq = 0.0;
+    for (int64_t b = w; b < npart; b += COLSUM_FINAL_WAVES) {
+      zs += partial[((size_t)b * 2 + 0) * DPAD + lane];
+      zq += partial[((size_t)b * 2 + 1) * DPAD + lane];
+    }
+    s_part[w][0][lane] = zs;
+    s_part[w][1][lane] = zq;
+  }
+  __syncthreads();
+  if (w == 0 && lane < DPAD) {
+    double zs = zsum[lane], zq = zsq[lane];
+    for (int k = 0; k < COLSUM_FINAL_WAVES; ++k) {
+      zs += s_part[k][0][lane];
+      zq += s_part[k][1][lane];
+    }
+    zsum[lane] = zs;
+    zsq[lane] = zq;
+  }
 }
 
 template <int DPAD>
