@@ -573,7 +573,7 @@ def _aem_problem(seed, d, m, n_levels, sigma):
     return As, bs, y, theta_true
 
 
-def g8_da_aem(name, aem, proposal_kind="grw", d=4, m=8, L=3, iters=50, n_chains=4, seed=801):
+def g8_da_aem(name, aem, proposal_kind="grw", d=4, m=8, L=3, iters=50, n_chains=4, seed=801, prop_var=0.05, beta=0.3):
     sigma = 0.3
     As, bs, y, theta_true = _aem_problem(seed, d, m, 2, sigma)
     pm, pc = np.zeros(d), np.eye(d)
@@ -584,11 +584,11 @@ def g8_da_aem(name, aem, proposal_kind="grw", d=4, m=8, L=3, iters=50, n_chains=
     rng = np.random.default_rng(seed + 1)
     theta0 = theta_true[None] + 0.2 * rng.standard_normal((n_chains, d))
     if proposal_kind == "grw":
-        prop = tda.GaussianRandomWalk(0.05 * np.eye(d), scaling=1.0)
-        pcfg = dict(kind="grw", C=0.05 * np.eye(d), scaling=1.0, adaptive=False, gamma=1.01, period=100)
+        prop = tda.GaussianRandomWalk(prop_var * np.eye(d), scaling=1.0)
+        pcfg = dict(kind="grw", C=prop_var * np.eye(d), scaling=1.0, adaptive=False, gamma=1.01, period=100)
     else:
-        prop = tda.CrankNicolson(scaling=0.3)
-        pcfg = dict(kind="pcn", scaling=0.3, adaptive=False, gamma=1.01, period=100)
+        prop = tda.CrankNicolson(scaling=beta)
+        pcfg = dict(kind="pcn", scaling=beta, adaptive=False, gamma=1.01, period=100)
     out = {k: [] for k in ("z", "u0", "u1", "th0", "lp0", "ll0", "acc0", "th1", "lp1", "ll1", "acc1", "bias_mu", "bias_sigma")}
     for c in range(n_chains):
         with Tap(seed + 50 * c) as tap:
@@ -614,7 +614,7 @@ def g8_da_aem(name, aem, proposal_kind="grw", d=4, m=8, L=3, iters=50, n_chains=
          theta0=theta0, subchain_length=np.array(L), aem=np.array(aem), **flat, **{k: np.array(v) for k, v in out.items()})
 
 
-def g8_mlda_aem(name, d=4, m=8, sl=(3, 2), iters=30, n_chains=4, seed=811):
+def g8_mlda_aem(name, d=4, m=8, sl=(3, 2), iters=30, n_chains=4, seed=811, prop_var=0.05):
     sigma = 0.3
     nl = len(sl) + 1
     As, bs, y, theta_true = _aem_problem(seed, d, m, nl, sigma)
@@ -625,8 +625,8 @@ def g8_mlda_aem(name, d=4, m=8, sl=(3, 2), iters=30, n_chains=4, seed=811):
                            make_model(As[k], bs[k])) for k in range(nl)]
     rng = np.random.default_rng(seed + 1)
     theta0 = theta_true[None] + 0.2 * rng.standard_normal((n_chains, d))
-    prop = tda.GaussianRandomWalk(0.05 * np.eye(d), scaling=1.0)
-    pcfg = dict(kind="grw", C=0.05 * np.eye(d), scaling=1.0, adaptive=False, gamma=1.01, period=100)
+    prop = tda.GaussianRandomWalk(prop_var * np.eye(d), scaling=1.0)
+    pcfg = dict(kind="grw", C=prop_var * np.eye(d), scaling=1.0, adaptive=False, gamma=1.01, period=100)
     out = {"z": []}
     for k in range(nl):
         for key in ("u", "th", "lp", "ll", "acc"):
@@ -759,6 +759,13 @@ FIXTURES = {
     "g8_da_aem_dep": lambda: g8_da_aem("g8_da_aem_dep", "state-dependent", seed=802),
     "g8_da_aem_dep_pcn": lambda: g8_da_aem("g8_da_aem_dep_pcn", "state-dependent", proposal_kind="pcn", L=1, seed=803),
     "g8_mlda_aem": lambda: g8_mlda_aem("g8_mlda_aem"),
+    # error models beyond 64 outputs (two waves per chain in k_aem_action): ragged 72 / 100 and the full 128
+    "g8_da_aem_indep_m72": lambda: g8_da_aem("g8_da_aem_indep_m72", "state-independent", d=5, m=72, L=3, iters=16, n_chains=2,
+                                             seed=821, prop_var=0.004),
+    "g8_da_aem_dep_pcn_m128": lambda: g8_da_aem("g8_da_aem_dep_pcn_m128", "state-dependent", proposal_kind="pcn", d=6, m=128, L=1,
+                                                iters=24, n_chains=2, seed=822, beta=0.08),
+    "g8_mlda_aem_m100": lambda: g8_mlda_aem("g8_mlda_aem_m100", d=5, m=100, sl=(3, 2), iters=10, n_chains=2, seed=823,
+                                            prop_var=0.004),
     "g5_mlda_am": lambda: g5_mlda("g5_mlda_am", "am", period=10),
     "g5_mlda_grw_adaptive": lambda: g5_mlda("g5_mlda_grw_adaptive", "grw", adaptive=True, period=7, seed=502),
     "g5_mlda_4level": lambda: g5_mlda("g5_mlda_4level", "am", ms=(6, 10, 16, 24), sl=(3, 2, 2), iters=20, period=10, seed=503),

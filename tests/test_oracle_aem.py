@@ -31,7 +31,7 @@ def _compare(res, g, nl, accepted_only=False):
             np.testing.assert_allclose(res[k]["loglike"], g["ll%d" % k], rtol=1e-10)
 
 
-@pytest.mark.parametrize("name", ["g8_da_aem_indep", "g8_da_aem_dep", "g8_da_aem_dep_pcn"])
+@pytest.mark.parametrize("name", ["g8_da_aem_indep", "g8_da_aem_dep", "g8_da_aem_dep_pcn", "g8_da_aem_indep_m72", "g8_da_aem_dep_pcn_m128"])
 def test_da_with_error_model(golden, name):
     g = golden(name)
     L = int(g["subchain_length"])
@@ -43,8 +43,9 @@ def test_da_with_error_model(golden, name):
     np.testing.assert_allclose(st[key][1], g["bias_sigma"], rtol=1e-8, atol=1e-12)
 
 
-def test_mlda_with_error_model(golden):
-    g = golden("g8_mlda_aem")
+@pytest.mark.parametrize("name", ["g8_mlda_aem", "g8_mlda_aem_m100"])
+def test_mlda_with_error_model(golden, name):
+    g = golden(name)
     nl = int(g["n_levels"])
     n_fine = g["th%d" % (nl - 1)].shape[1] - 1
     res, _ = orc.run_multilevel_aem(aem_levels(g, nl), _prop(g), list(g["subchain_lengths"]), g["theta0"], g["z"],

@@ -29,8 +29,8 @@ def _device_plan(posteriors, proposal):
         low = getattr(post, "_lowering", lambda: None)()
         if low is None or low["prior_mean"].shape[0] > 64:
             return None
-        if low["noise_kind"] == _lib.NOISE_ADAPTIVE and (len(posteriors) < 2 or low["A"] is None or low["A"].shape[0] > 64):
-            return None  # AdaptiveGaussianLogLike: coarse levels of a hierarchy, m <= 64 on the device
+        if low["noise_kind"] == _lib.NOISE_ADAPTIVE and (len(posteriors) < 2 or low["A"] is None or low["A"].shape[0] > 128):
+            return None  # AdaptiveGaussianLogLike: coarse levels of a hierarchy, m <= 128 on the device
         if low["noise_kind"] == _lib.NOISE_DENSE and (len(posteriors) != 1 or isinstance(proposal, DREAMZ)
                                                       or low["A"] is None or low["A"].shape[0] > 1024):
             return None  # dense data covariance: single-level GRW / pCN / AM with m <= 1024 on the device so far

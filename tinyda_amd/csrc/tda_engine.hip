@@ -161,7 +161,8 @@ struct Level {
   DevBuf<double> Apk, ytil, w, Ppk;
   // adaptive error model: plain row-major copies for the wave-per-chain kernel
   std::vector<double> A_h, ytil_h, data_h, cov_h;
-  DevBuf<double> A_rm, ytil64, data64, cov64;
+  DevBuf<double> A_rm, ytil64, data64, cov64;  // error-model copies, row stride em_ld
+  int em_ld = 0;                               // 64 (m <= 64) or 128 (m <= 128); 0: level too large for an error model
 };
 
 struct TimedLaunch {
@@ -240,7 +241,7 @@ struct tda_engine {
   DevBuf<uint8_t> ml_rec_acc2[tda::MAXLEV];
   // adaptive error model
   int aem = 0;
-  int aem_m = 0;
+  int aem_m = 0, aem_ld = 64;
   DevBuf<double> aem_bias[tda::MAXLEV], aem_covinv[tda::MAXLEV], aem_bmu[tda::MAXLEV], aem_bsig[tda::MAXLEV], aem_mdiff[tda::MAXLEV];
   int64_t aem_bt[tda::MAXLEV] = {1, 1, 1, 1};
   DevBuf<int64_t> ml_sid;
@@ -333,6 +334,9 @@ template <int DPAD>
 void launch_chol(const CholArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_chol<DPAD>, dim3((unsigned)a.N), dim3(64), 0, st, a);
 }
+
+// dynamic LDS of k_aem_action<MPT>: the m x m work matrix (row stride MPT + 1), four vectors, exchange slots
+constexpr size_t aem_lds_bytes(int mpt) { return ((size_t)mpt * (mpt + 1) + 4 * (size_t)mpt + 8) * sizeof(double); }
 
 template <int DPAD>
 void launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st) {
@@ -731,8 +735,9 @@ int tda_engine_set_level(tda_engine* e, int level, int m, const double* A, const
   HIP_TRY(hipSetDevice(e->cfg.device));
   Level& lv = e->levels[level];
   if (noise_kind < TDA_NOISE_ISO || noise_kind > TDA_NOISE_ADAPTIVE) return fail(TDA_ERR_INVALID, "noise_kind %d", noise_kind);
-  if (noise_kind == TDA_NOISE_ADAPTIVE && m > AEM_MP)
-    return fail(TDA_ERR_UNSUPPORTED, "AdaptiveGaussianLogLike on the device is limited to m <= %d observations (per-chain m x m state)", (int)AEM_MP);
+  if (noise_kind == TDA_NOISE_ADAPTIVE && m > AEM_MP_MAX)
+    return fail(TDA_ERR_UNSUPPORTED, "AdaptiveGaussianLogLike on the device is limited to m <= %d observations (per-chain m x m state)", (int)AEM_MP_MAX);
+  const int AEM_MP = m <= 64 ? 64 : 128;  // row stride of this level's error-model copies
   if (noise_kind == TDA_NOISE_DENSE && (e->nlev != 1))
     return fail(TDA_ERR_UNSUPPORTED, "dense noise covariance is lowered for single-level chains only so far");
   std::vector<double> Apk;
@@ -787,7 +792,8 @@ int tda_engine_set_level(tda_engine* e, int level, int m, const double* A, const
                       (noise_kind == TDA_NOISE_DENSE ? (size_t)16 * (lv.m_pad + 2) : 0)) * sizeof(double);
   if (lds > 158 * 1024) return fail(TDA_ERR_UNSUPPORTED, "m=%d observations exceed the LDS staging budget", m);
   int rc;
-  if (m <= AEM_MP) {
+  lv.em_ld = m <= AEM_MP_MAX ? AEM_MP : 0;
+  if (m <= AEM_MP_MAX) {
     std::vector<double> y64(lv.ytil_h.begin(), lv.ytil_h.begin() + AEM_MP), c64;
     {  // column-major [d][AEM_MP] for k_aem_action: lane = observation reads consecutive addresses
       std::vector<double> acm((size_t)e->d * AEM_MP, 0.0);
@@ -1252,7 +1258,7 @@ int tda_engine_get_error_model(tda_engine* e, int level, double* bias, double* c
   if (level < 0 || level >= e->nlev - 1) return fail(TDA_ERR_INVALID, "level %d has no adaptive likelihood", level);
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipStreamSynchronize(e->stream));
-  const int m = e->aem_m;
+  const int m = e->aem_m, AEM_MP = e->aem_ld;
   if (bias) {
     std::vector<double> hb((size_t)e->NP * AEM_MP);
     HIP_TRY(hipMemcpy(hb.data(), e->aem_bias[level].p, hb.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -1592,6 +1598,7 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
           return fail(TDA_ERR_UNSUPPORTED, "error model: the finest level must have an isotropic likelihood on the device");
       }
       e->aem_m = m;
+      const int AEM_MP = e->aem_ld = e->levels[0].em_ld;
       HIP_TRY(hipStreamSynchronize(e->stream));
       // host copies of theta0 / log-priors, model outputs of every level
       std::vector<double> th((size_t)NP * DP), lph(NP);
@@ -1632,8 +1639,10 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
             P[(size_t)i * AEM_MP + j] = P[(size_t)j * AEM_MP + i] = s;
           }
         if ((rc = e->aem_covinv[k].alloc((size_t)NP * MM))) return rc;
-        for (int64_t c = 0; c < NP; ++c)
-          HIP_TRY(hipMemcpy(e->aem_covinv[k].p + (size_t)c * MM, P.data(), MM * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->aem_covinv[k].p, P.data(), MM * sizeof(double), hipMemcpyHostToDevice));
+        for (int64_t have = 1; have < NP; have *= 2)  // replicate to every chain by doubling device copies
+          HIP_TRY(hipMemcpy(e->aem_covinv[k].p + (size_t)have * MM, e->aem_covinv[k].p,
+                            (size_t)std::min<int64_t>(have, NP - have) * MM * sizeof(double), hipMemcpyDeviceToDevice));
         // total bias: state-dependent = the difference itself, otherwise the sum of the means of all trackers above
         std::vector<double> bt((size_t)NP * AEM_MP, 0.0);
         for (int64_t c = 0; c < N; ++c)
@@ -2250,6 +2259,7 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
     ma.cascade = e->aem ? 0 : 1;
     ma.aem_on = e->aem ? 1 : 0;
     ma.aem_mp = e->aem ? e->levels[0].m_pad : 0;
+    ma.aem_ld = e->aem_ld;
     ma.aem_bias = e->aem ? e->aem_bias[0].p : nullptr;
     ma.aem_P = e->aem ? e->aem_covinv[0].p : nullptr;
     ma.sid = e->ml_sid.p;
@@ -2331,7 +2341,7 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
         ag.d = d;
         ag.DP = DP;
         ag.m = e->aem_m;
-        ag.MP = AEM_MP;
+        ag.MP = e->aem_ld;
         ag.nlev = nl;
         ag.q = qq;
         ag.is_da = nl == 2;
@@ -2370,7 +2380,13 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
         ag.rec_stats = ma.rec_stats[qq];
         ag.rec_acc = ma.rec_acc[qq];
         ScopedTimer tm(e, 2);
-        hipLaunchKernelGGL(k_aem_action, dim3((unsigned)N), dim3(64), 0, e->stream, ag);
+        if (e->aem_ld == 64) {
+          hipLaunchKernelGGL(k_aem_action<64>, dim3((unsigned)N), dim3(64), aem_lds_bytes(64), e->stream, ag);
+        } else {  // 133 KiB work matrix: beyond the default dynamic-LDS window
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aem_action<128>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)aem_lds_bytes(128)));
+          hipLaunchKernelGGL(k_aem_action<128>, dim3((unsigned)N), dim3(128), aem_lds_bytes(128), e->stream, ag);
+        }
         e->aem_bt[qq] += 1;
         extra += 1;
       }

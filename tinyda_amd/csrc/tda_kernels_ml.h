@@ -25,7 +25,7 @@ namespace tda {
 // (chain.py:363,389,397; proposal.py:1486), kept as a ring of the last `period` entries.
 // ------------------------------------------------------------------------------------------------
 constexpr int MAXLEV = 4;
-constexpr int AEM_MP = 64;  // row stride of the per-chain error-model vectors / matrices in HBM
+constexpr int AEM_MP_MAX = 128;  // error-model output dimension limit; per-chain vectors / matrices in HBM have row stride 64 or 128
 enum : uint32_t { STREAM_INDEX = 3 };
 
 struct MLArgs {
@@ -63,9 +63,10 @@ struct MLArgs {
   // bias-corrected dense Gaussian of AdaptiveGaussianLogLike (distributions.py:404-425) with per-chain state
   int cascade;             // 1: upper levels act inside the kernel; 0: the host launches k_aem_action between blocks
   int aem_on;
-  int aem_mp;              // padded output dimension (<= 64)
-  const double* aem_bias;  // [NP][AEM_MP]          total bias of level 0
-  const double* aem_P;     // [NP][AEM_MP][AEM_MP]  (Sigma_e + Sigma_bias)^-1 of level 0
+  int aem_mp;              // output dimension padded to 16 (<= 128)
+  int aem_ld;              // row stride of the per-chain error-model state: 64 or 128
+  const double* aem_bias;  // [NP][aem_ld]          total bias of level 0
+  const double* aem_P;     // [NP][aem_ld][aem_ld]  (Sigma_e + Sigma_bias)^-1 of level 0
   int64_t* sid;            // [nlev][NP] identity of the parameter vector each level currently holds
 };
 
@@ -191,20 +192,33 @@ __global__ void __launch_bounds__(256, 1) k_ml_steps(const MLArgs a) {
       // residual tile, then per chain  -1/2 (F + bias - y)^T P (F + bias - y)  with that chain's bias and P
       (void)level_sse_partial<DPAD, 2>(L.Apk, L.ncb, s_stage + a.lds_y[k], s_R + lc * RSa, th, wave, lane, g0, g1);
       __syncthreads();
-      const int MP = a.aem_mp;
-      for (int cc = wave; cc < 16; cc += 4) {
+      const int MP = a.aem_mp, LD = a.aem_ld;
+      for (int cc = wave; cc < 16; cc += 4) {  // lane = observation (and observation + 64 beyond 64 outputs)
         const int64_t gc = tile * 16 + cc;
         double* rrow = s_R + cc * RSa;
-        double rb = 0.0;
-        if (lane < MP) rb = rrow[lane] + a.aem_bias[gc * AEM_MP + lane];
+        const bool l0 = lane < MP, l1 = lane + 64 < MP;
+        double rb0 = 0.0, rb1 = 0.0;
+        if (l0) rb0 = rrow[lane] + a.aem_bias[gc * LD + lane];
+        if (l1) rb1 = rrow[lane + 64] + a.aem_bias[gc * LD + lane + 64];
         __builtin_amdgcn_wave_barrier();
-        if (lane < MP) rrow[lane] = rb;
+        if (l0) rrow[lane] = rb0;
+        if (l1) rrow[lane + 64] = rb1;
         __builtin_amdgcn_wave_barrier();
         double sacc = 0.0;
-        if (lane < MP) {
-          const double* Pc = a.aem_P + (size_t)gc * AEM_MP * AEM_MP + lane;
-          for (int o = 0; o < MP; ++o) sacc = fma(Pc[(size_t)o * AEM_MP], rrow[o], sacc);
-          sacc *= rb;
+        const double* Pc = a.aem_P + (size_t)gc * LD * LD + lane;
+        if (MP <= 64) {
+          if (l0) {
+            for (int o = 0; o < MP; ++o) sacc = fma(Pc[(size_t)o * LD], rrow[o], sacc);
+            sacc *= rb0;
+          }
+        } else {
+          double s0 = 0.0, s1 = 0.0;
+          for (int o = 0; o < MP; ++o) {
+            const double ro = rrow[o];
+            s0 = fma(Pc[(size_t)o * LD], ro, s0);  // l0 holds for every lane here
+            if (l1) s1 = fma(Pc[(size_t)o * LD + 64], ro, s1);
+          }
+          sacc = s0 * rb0 + s1 * rb1;
         }
         for (int off = 32; off >= 1; off >>= 1) sacc += __shfl_xor(sacc, off);
         if (lane == 0) s_R[16 * RSa + cc] = -0.5 * sacc;
@@ -474,10 +488,14 @@ struct AemArgs {
   uint8_t* rec_acc;
 };
 
-__global__ void __launch_bounds__(64) k_aem_action(const AemArgs a) {
-  constexpr int LDM = AEM_MP + 1;
-  __shared__ double s_M[AEM_MP * LDM];
-  __shared__ double s_v[4 * AEM_MP];
+template <int MPT>
+__global__ void __launch_bounds__(MPT) k_aem_action(const AemArgs a) {
+  constexpr int LDM = MPT + 1;
+  constexpr int NW = MPT / 64;  // thread = observation: one wave up to 64 outputs, two up to 128
+  extern __shared__ __attribute__((aligned(16))) double aem_smem[];
+  double* const s_M = aem_smem;           // [MPT][LDM]
+  double* const s_v = s_M + MPT * LDM;    // [4][MPT]
+  double* const s_x = s_v + 4 * MPT;      // [8] exchange slots between the waves
   const int lane = threadIdx.x;
   const int64_t c = blockIdx.x;
   if (c >= a.N) return;
@@ -486,15 +504,21 @@ __global__ void __launch_bounds__(64) k_aem_action(const AemArgs a) {
   auto TH = [&](int lev) { return a.theta + ((size_t)lev * a.NP + c) * a.DP; };
   auto bsum = [&](double v) {
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    if constexpr (NW > 1) {
+      __syncthreads();
+      if ((lane & 63) == 0) s_x[lane >> 6] = v;
+      __syncthreads();
+      v = s_x[0] + s_x[1];
+    }
     return v;
   };
   // F_lev(theta)[lane] - ytil_lev[lane]  (theta given through LDS vector s_v[0..d))
   auto resid = [&](int lev) {
     double f = 0.0;
     if (lo) {
-      const double* __restrict__ Ac = a.A[lev] + lane;  // column-major [d][AEM_MP]
+      const double* __restrict__ Ac = a.A[lev] + lane;  // column-major [d][MPT]
 #pragma unroll 8
-      for (int j = 0; j < d; ++j) f = fma(Ac[(size_t)j * AEM_MP], s_v[j], f);
+      for (int j = 0; j < d; ++j) f = fma(Ac[(size_t)j * MPT], s_v[j], f);
       f -= a.ytil[lev][lane];
     }
     return f;
@@ -502,13 +526,13 @@ __global__ void __launch_bounds__(64) k_aem_action(const AemArgs a) {
   // -1/2 r^T P r with chain c's inverse of adaptive level lev; r given per lane (already bias corrected)
   auto quad = [&](int lev, double r) {
     __syncthreads();
-    s_v[AEM_MP + lane] = lo ? r : 0.0;
+    s_v[MPT + lane] = lo ? r : 0.0;
     __syncthreads();
     double s = 0.0;
     if (lo) {
       const double* __restrict__ Pc = a.cov_inv[lev] + (size_t)c * MP * MP + lane;
 #pragma unroll 8
-      for (int o = 0; o < a.m; ++o) s = fma(Pc[(size_t)o * MP], s_v[AEM_MP + o], s);
+      for (int o = 0; o < a.m; ++o) s = fma(Pc[(size_t)o * MP], s_v[MPT + o], s);
       s *= r;
     }
     return -0.5 * bsum(s);
@@ -526,7 +550,7 @@ __global__ void __launch_bounds__(64) k_aem_action(const AemArgs a) {
   const double st_lp = a.Sst[((size_t)pkq * 2 + 0) * a.NP + c], st_ll = a.Sst[((size_t)pkq * 2 + 1) * a.NP + c];
   const bool any = a.anyacc[(size_t)k * a.NP + c] != 0;
   __syncthreads();
-  if (lane < AEM_MP) s_v[lane] = yj;
+  s_v[lane] = yj;
   __syncthreads();
   const double rq_y = resid(q);                   // F_q(y) - ytil_q
   const double rk_y = a.dependent ? resid(k) : 0.0;  // F_k(y) - ytil_k
@@ -537,7 +561,7 @@ __global__ void __launch_bounds__(64) k_aem_action(const AemArgs a) {
     // bias at the proposal and the coarse density of the subchain start under it
     const double bias_next = (rq_y + a.data[q][lane < MP ? lane : 0]) - (rk_y + a.data[k][lane < MP ? lane : 0]);
     __syncthreads();
-    if (lane < AEM_MP) s_v[lane] = xj;  // subchain start = the fine state
+    s_v[lane] = xj;  // subchain start = the fine state
     __syncthreads();
     const double rk_x = resid(k);
     const double ll_b = quad(k, lo ? rk_x + bias_next : 0.0);
@@ -546,12 +570,12 @@ __global__ void __launch_bounds__(64) k_aem_action(const AemArgs a) {
       const double beta = a.scaling[c], kp = sqrt(1.0 - beta * beta);
       for (int dir = 0; dir < 2; ++dir) {
         __syncthreads();
-        if (lane < AEM_MP) s_v[2 * AEM_MP + lane] = dir == 0 ? yj - kp * xj : xj - kp * yj;
+        s_v[2 * MPT + lane] = dir == 0 ? yj - kp * xj : xj - kp * yj;
         __syncthreads();
         double w = 0.0;
         if (lj) {
           const double* Wr = a.pr_W + (size_t)lane * d;
-          for (int j = 0; j <= lane; ++j) w = fma(Wr[j], s_v[2 * AEM_MP + j], w);
+          for (int j = 0; j <= lane; ++j) w = fma(Wr[j], s_v[2 * MPT + j], w);
         }
         const double maha = bsum(lj ? w * w : 0.0) / (beta * beta);
         const double v = -0.5 * (d * 1.8378770664093453 + a.pr_logdet + d * log(beta * beta) + maha);
@@ -613,7 +637,7 @@ __global__ void __launch_bounds__(64) k_aem_action(const AemArgs a) {
   // ---------------- error model update (chain.py:485-523, :739-765; proposal.py:1547-1578) ----------------
   const double cj = acc ? yj : xj;  // theta_q = theta_k now
   __syncthreads();
-  if (lane < AEM_MP) s_v[lane] = cj;
+  s_v[lane] = cj;
   __syncthreads();
   const double rq = resid(q), rk = resid(k);
   const double diff_new = lo ? (rq + a.data[q][lane]) - (rk + a.data[k][lane]) : 0.0;
@@ -625,7 +649,7 @@ __global__ void __launch_bounds__(64) k_aem_action(const AemArgs a) {
     xupd = lo ? (rq + a.data[q][lane]) - ((rk + a.data[k][lane]) + md[lane]) : 0.0;  // chain.py:505-507
     if (lo) md[lane] = diff_new;
     __syncthreads();
-    if (lane < AEM_MP) s_v[AEM_MP + lane] = xupd;
+    s_v[MPT + lane] = xupd;
     __syncthreads();
     if (lo)
       for (int i0 = 0; i0 < a.m; i0 += 8) {  // utils.py:199  Sigma <- (t-1)/t Sigma + 1/t x x^T; 8 rows in flight
@@ -635,7 +659,7 @@ __global__ void __launch_bounds__(64) k_aem_action(const AemArgs a) {
 #pragma unroll
         for (int u = 0; u < 8; ++u)
           if (i0 + u < a.m) {
-            const double xi = s_v[AEM_MP + i0 + u];
+            const double xi = s_v[MPT + i0 + u];
             Sg[(size_t)(i0 + u) * MP + lane] = (t - 1.0) / t * old[u] + 1.0 / t * (xi * xupd);
           }
       }
@@ -646,11 +670,9 @@ __global__ void __launch_bounds__(64) k_aem_action(const AemArgs a) {
     const double mu_o = lo ? mu[lane] : 0.0;
     const double mu_n = (1.0 / (t + 1.0)) * (t * mu_o + dm);  // utils.py:113-122 with sd = 1, eps = 0
     __syncthreads();
-    if (lane < AEM_MP) {
-      s_v[AEM_MP + lane] = dm;
-      s_v[2 * AEM_MP + lane] = mu_o;
-      s_v[3 * AEM_MP + lane] = mu_n;
-    }
+    s_v[MPT + lane] = dm;
+    s_v[2 * MPT + lane] = mu_o;
+    s_v[3 * MPT + lane] = mu_n;
     __syncthreads();
     if (lo) {
       const double ca = (t - 1.0) / t, cb = 1.0 / t;
@@ -662,7 +684,7 @@ __global__ void __launch_bounds__(64) k_aem_action(const AemArgs a) {
         for (int u = 0; u < 8; ++u)
           if (i0 + u < a.m) {
             const int i = i0 + u;
-            const double M = (t * (s_v[2 * AEM_MP + i] * mu_o) - (t + 1.0) * (s_v[3 * AEM_MP + i] * mu_n)) + s_v[AEM_MP + i] * dm;
+            const double M = (t * (s_v[2 * MPT + i] * mu_o) - (t + 1.0) * (s_v[3 * MPT + i] * mu_n)) + s_v[MPT + i] * dm;
             Sg[(size_t)i * MP + lane] = ca * old[u] + cb * M;
           }
       }
@@ -693,8 +715,7 @@ __global__ void __launch_bounds__(64) k_aem_action(const AemArgs a) {
       s_M[lane * LDM + j] = a.cov[k][(size_t)j * MP + lane] + sb;
     }
   }
-  const bool refresh = __ballot(big) != 0ull;
-  __syncthreads();
+  const bool refresh = __syncthreads_or(big ? 1 : 0) != 0;
   if (refresh) {
     // inverse through the Cholesky factor: M = L L^T, W = L^-1, P = W^T W
     for (int kk = 0; kk < a.m; ++kk) {
@@ -704,14 +725,21 @@ __global__ void __launch_bounds__(64) k_aem_action(const AemArgs a) {
 #pragma unroll 8
         for (int p = 0; p < kk; ++p) sacc = fma(-s_M[lane * LDM + p], s_M[kk * LDM + p], sacc);  // unrolled: LDS reads in flight
       }
-      const double lkk = sqrt(__shfl(sacc, kk));
+      double lkk;
+      if constexpr (NW > 1) {
+        if (lane == kk) s_x[2] = sacc;
+        __syncthreads();
+        lkk = sqrt(s_x[2]);
+      } else {
+        lkk = sqrt(__shfl(sacc, kk));
+      }
       if (lane >= kk && lo) s_M[lane * LDM + kk] = lane == kk ? lkk : sacc / lkk;
       __syncthreads();
     }
     // W = L^-1, lane = column j: W[i][j] for i >= j by forward substitution down the rows.  W^T goes into the strict
-    // upper triangle of s_M (W[i][j] at s_M[j][i]; L stays below), its diagonal into s_v[2 AEM_MP ..): a per-lane array
+    // upper triangle of s_M (W[i][j] at s_M[j][i]; L stays below), its diagonal into s_v[2 MPT ..): a per-lane array
     // indexed by the loop variable would live in scratch memory and made this kernel 85 % of an error-model run.
-    double* const s_wd = s_v + 2 * AEM_MP;
+    double* const s_wd = s_v + 2 * MPT;
     for (int i = 0; i < a.m; ++i) {
       if (lo && i >= lane) {
         const double lii = s_M[i * LDM + i];

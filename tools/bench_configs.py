@@ -39,8 +39,8 @@ def run(name, ms, sl, prop, n_fine, N=4096, d=64):
     e.close()
 
 def run_c5_aem(N=4096, d=64, m=64, n_fine=20):
-    """C5 with the state-independent adaptive error model: levels share the output dimension, here m = 64
-    (the device error-model limit); levels 0/1 AdaptiveGaussianLogLike, level 2 isotropic; AM; subchains [5, 3]."""
+    """C5 with the state-independent adaptive error model: levels share the output dimension (m = 128 is SURVEY
+    §8(d)'s C5, the device error-model limit); levels 0/1 AdaptiveGaussianLogLike, level 2 isotropic; AM; subchains [5, 3]."""
     rng = np.random.default_rng(6)
     truth = rng.standard_normal(d)
     Af = rng.standard_normal((m, d)) / 8
@@ -61,10 +61,11 @@ def run_c5_aem(N=4096, d=64, m=64, n_fine=20):
     outs = [(torch.empty((r, N, d), dtype=torch.float64, device="cuda"), torch.empty((r, N, 3), dtype=torch.float64, device="cuda"),
              torch.empty((r, N), dtype=torch.uint8, device="cuda")) for r in rows]
     e.run_levels(2, outs)
+    e.set_profiling(True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     e.run_levels(n_fine, outs)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(json.dumps(dict(config="C5 + state-independent AEM, common m=64, AM, subchains [5,3]", chains=N, fine_iterations=n_fine, seconds=dt,
+    print(json.dumps(dict(config="C5 + state-independent AEM, common m=%d, AM, subchains [5,3]" % m, chains=N, kernel_ms=e.profile(), fine_iterations=n_fine, seconds=dt,
                           coarse_evals_per_s=N * rows[0] / dt, finest_iterations_per_s=N * n_fine / dt,
                           acceptance=[float(o[2].float().mean().item()) for o in outs])))
     e.close()
@@ -120,6 +121,9 @@ def run_c4(N=8192, d=32, T=400, M0=320, K=16):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "c5aem":  # python tools/bench_configs.py c5aem 128 [n_fine]
+        run_c5_aem(m=int(sys.argv[2]), n_fine=int(sys.argv[3]) if len(sys.argv) > 3 else 20)
+        sys.exit(0)
     run_c2b()
     run_c5_aem()
     run_c4()
