@@ -335,8 +335,8 @@ void launch_chol(const CholArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_chol<DPAD>, dim3((unsigned)a.N), dim3(64), 0, st, a);
 }
 
-// dynamic LDS of k_aem_action<MPT>: the m x m work matrix (row stride MPT + 1), four vectors, exchange slots
-constexpr size_t aem_lds_bytes(int mpt) { return ((size_t)mpt * (mpt + 1) + 4 * (size_t)mpt + 8) * sizeof(double); }
+// dynamic LDS of k_aem_inverse: the 16 x 16 blocks on or below the diagonal, row stride 17
+constexpr size_t aem_inverse_lds_bytes(int nb) { return (size_t)(nb * (nb + 1) / 2) * AEM_BS * sizeof(double); }
 
 template <int DPAD>
 void launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st) {
@@ -2380,12 +2380,28 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
         ag.rec_stats = ma.rec_stats[qq];
         ag.rec_acc = ma.rec_acc[qq];
         ScopedTimer tm(e, 2);
-        if (e->aem_ld == 64) {
-          hipLaunchKernelGGL(k_aem_action<64>, dim3((unsigned)N), dim3(64), aem_lds_bytes(64), e->stream, ag);
-        } else {  // 133 KiB work matrix: beyond the default dynamic-LDS window
-          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aem_action<128>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)aem_lds_bytes(128)));
-          hipLaunchKernelGGL(k_aem_action<128>, dim3((unsigned)N), dim3(128), aem_lds_bytes(128), e->stream, ag);
+        AemInvArgs iv{};
+        iv.N = N;
+        iv.m = e->aem_m;
+        iv.MP = e->aem_ld;
+        iv.nb = (e->aem_m + 15) / 16;
+        iv.cov = e->levels[qq - 1].cov64.p;
+        if (ag.dependent) {
+          iv.nsum = 1;
+          iv.sig[0] = e->aem_bsig[qq].p;
+        } else {
+          iv.nsum = nl - qq;
+          for (int p = qq; p < nl; ++p) iv.sig[p - qq] = e->aem_bsig[p].p;
+        }
+        iv.P = e->aem_covinv[qq - 1].p;
+        const size_t inv_lds = aem_inverse_lds_bytes(iv.nb);
+        if (inv_lds > 64 * 1024)  // beyond the default dynamic-LDS window
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aem_inverse<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)inv_lds));
+        for (int phase = 0; phase < 2; ++phase) {
+          ag.phase = phase;
+          if (e->aem_ld == 64) hipLaunchKernelGGL(k_aem_action<64>, dim3((unsigned)N), dim3(64), 0, e->stream, ag);
+          else hipLaunchKernelGGL(k_aem_action<128>, dim3((unsigned)N), dim3(128), 0, e->stream, ag);
+          if (phase == 0) hipLaunchKernelGGL(k_aem_inverse<0>, dim3((unsigned)N), dim3(256), inv_lds, e->stream, iv);
         }
         e->aem_bt[qq] += 1;
         extra += 1;

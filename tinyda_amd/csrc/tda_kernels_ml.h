@@ -206,17 +206,33 @@ __global__ void __launch_bounds__(256, 1) k_ml_steps(const MLArgs a) {
         __builtin_amdgcn_wave_barrier();
         double sacc = 0.0;
         const double* Pc = a.aem_P + (size_t)gc * LD * LD + lane;
+        // MP is a multiple of 16: eight rows of P in flight per lane (same summation order as a plain loop)
         if (MP <= 64) {
           if (l0) {
-            for (int o = 0; o < MP; ++o) sacc = fma(Pc[(size_t)o * LD], rrow[o], sacc);
+            for (int o = 0; o < MP; o += 8) {
+              double pv[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) pv[u] = Pc[(size_t)(o + u) * LD];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) sacc = fma(pv[u], rrow[o + u], sacc);
+            }
             sacc *= rb0;
           }
         } else {
           double s0 = 0.0, s1 = 0.0;
-          for (int o = 0; o < MP; ++o) {
-            const double ro = rrow[o];
-            s0 = fma(Pc[(size_t)o * LD], ro, s0);  // l0 holds for every lane here
-            if (l1) s1 = fma(Pc[(size_t)o * LD + 64], ro, s1);
+          for (int o = 0; o < MP; o += 8) {
+            double pv[8], pw[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              pv[u] = Pc[(size_t)(o + u) * LD];  // l0 holds for every lane here
+              pw[u] = l1 ? Pc[(size_t)(o + u) * LD + 64] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const double ro = rrow[o + u];
+              s0 = fma(pv[u], ro, s0);
+              s1 = fma(pw[u], ro, s1);
+            }
           }
           sacc = s0 * rb0 + s1 * rb1;
         }
@@ -478,6 +494,7 @@ struct AemArgs {
   double* b_sig[MAXLEV];     // [NP][MP][MP]
   double* mdiff[MAXLEV];     // [NP][MP]
   int64_t b_t;               // recursion counter of level q's tracker before this update
+  int phase;                 // 0: decision + error-model update (then k_aem_inverse); 1: update_link of level q-1
   const double* scaling;     // [NP] (pCN beta for the state-dependent q terms)
   const double* u_rep;       // [N] replay uniform of this step (NaN = none drawn) or null
   uint8_t* ring;
@@ -490,12 +507,9 @@ struct AemArgs {
 
 template <int MPT>
 __global__ void __launch_bounds__(MPT) k_aem_action(const AemArgs a) {
-  constexpr int LDM = MPT + 1;
   constexpr int NW = MPT / 64;  // thread = observation: one wave up to 64 outputs, two up to 128
-  extern __shared__ __attribute__((aligned(16))) double aem_smem[];
-  double* const s_M = aem_smem;           // [MPT][LDM]
-  double* const s_v = s_M + MPT * LDM;    // [4][MPT]
-  double* const s_x = s_v + 4 * MPT;      // [8] exchange slots between the waves
+  __shared__ double s_v[4 * MPT];
+  __shared__ double s_x[8];  // exchange slots between the waves
   const int lane = threadIdx.x;
   const int64_t c = blockIdx.x;
   if (c >= a.N) return;
@@ -541,6 +555,23 @@ __global__ void __launch_bounds__(MPT) k_aem_action(const AemArgs a) {
     if (lev == nl - 1) return -0.5 * bsum(lo ? r0 * r0 : 0.0) / a.var_finest;
     return quad(lev, lo ? r0 + a.bias_tot[lev][c * MP + lane] : 0.0);
   };
+
+  if (a.phase == 1) {
+    // update_link of level k's latest link (posterior.py:112-134) under the bias / inverse k_aem_inverse has refreshed
+    __syncthreads();
+    s_v[lane] = lj ? TH(k)[lane] : 0.0;
+    __syncthreads();
+    const double rk = resid(k);
+    const double bt = lo ? a.bias_tot[k][c * MP + lane] : 0.0;
+    const double llk = quad(k, lo ? rk + bt : 0.0);
+    if (lane == 0) {
+      a.ll[(size_t)k * a.NP + c] = llk;
+      const int64_t idk = a.sid[(size_t)k * a.NP + c];
+      for (int q2 = q; q2 < nl; ++q2)
+        if (a.sid[(size_t)q2 * a.NP + c] == idk) a.Sst[((size_t)pair_index(k, q2) * 2 + 1) * a.NP + c] = llk;
+    }
+    return;
+  }
 
   // ---------------- the level-q decision ----------------
   const double yj = lj ? TH(k)[lane] : 0.0, xj = lj ? TH(q)[lane] : 0.0;
@@ -701,82 +732,237 @@ __global__ void __launch_bounds__(MPT) k_aem_action(const AemArgs a) {
       for (int p = q; p < nl; ++p) bt += a.b_mu[p][c * MP + lane];
     a.bias_tot[k][c * MP + lane] = bt;
   }
-  // Sigma_e + Sigma_bias into LDS (row i = lane), and the 1e-9 rule of distributions.py:399-402
+}
+
+// ------------------------------------------------------------------------------------------------
+// (Sigma_e + Sigma_bias)^-1 for every chain (distributions.py:399-402: set_bias re-inverts unless every entry of
+// Sigma_bias is < 1e-9), one workgroup of four waves per chain, on the matrix cores.  The matrix lives in LDS as the
+// 16 x 16 blocks on or below the diagonal (row stride 17):
+//   1. blocked Cholesky, left-looking by block column: trailing products on v_mfma_f64_16x16x4_f64, the 16 x 16 diagonal
+//      block factored and inverted by one wave with its rows in registers (v_readlane broadcasts, fully unrolled),
+//      the panel below multiplied by that inverse;
+//   2. W = L^-1 in place, block column by block column from the right (W[i][j] = -(sum_k W[i][k] L[k][j]) W[j][j]);
+//   3. P = W^T W written straight to HBM from the accumulators (both triangles).
+// Padding rows / columns (m not a multiple of 16) are identity and never stored.
+// ------------------------------------------------------------------------------------------------
+struct AemInvArgs {
+  int64_t N;
+  int m, MP, nb;              // outputs, row stride of the per-chain matrices (64 / 128), block rows = ceil(m / 16)
+  int nsum;                   // tracker covariances summed into Sigma_bias
+  const double* cov;          // [MP][MP] Sigma_e
+  const double* sig[MAXLEV];  // [NP][MP][MP]
+  double* P;                  // [NP][MP][MP]
+};
+
+constexpr int AEM_BS = 16 * 17;  // doubles per LDS block
+
+__device__ __forceinline__ double aem_bcast(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// one wave: block <- inverse of the Cholesky factor of the symmetric positive definite 16 x 16 block (lower triangle read).
+// The pivots go through 1 / sqrt (one v_rsq_f64 + refinement per step, no division anywhere); the inverse is built
+// column by column with sixteen independent accumulators instead of one dot product per element.
+__device__ __forceinline__ void aem_diag_block(double* __restrict__ blkp, int lane) {
+  const int li = lane & 15;  // lanes 16.. replicate lanes 0..15
+  double A[16], w[16], rinv[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) A[j] = blkp[li * 17 + j];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const double dkk = aem_bcast(A[k], k);
+    const double r = rsqrt(dkk);
+    rinv[k] = r;
+    const double lik = (li == k) ? dkk * r : A[k] * r;
+    A[k] = lik;
+#pragma unroll
+    for (int j = k + 1; j < 16; ++j) A[j] = fma(-lik, aem_bcast(lik, j), A[j]);
+  }
+  // column li of W = L^-1:  w[i] = -(sum_{p < i} L[i][p] w[p]) / L[i][i]  for i > li, 1 / L[li][li] at i = li, 0 above;
+  // as soon as w[p] is final every later row receives its term (L[i][p] is lane i's A[p])
+#pragma unroll
+  for (int i = 0; i < 16; ++i) w[i] = 0.0;
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    w[p] = p < li ? 0.0 : (p == li ? rinv[p] : -w[p] * rinv[p]);
+#pragma unroll
+    for (int i = p + 1; i < 16; ++i) w[i] = fma(aem_bcast(A[p], i), w[p], w[i]);
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 16) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) blkp[i * 17 + li] = w[i];
+  }
+}
+
+// SKIP (tools/aem_inverse_probe.hip only; the library instantiates 0): 1 = no diagonal-block factorisation, 2 = return
+// after the matrix is staged, 4 = no P = W^T W, 8 = no triangular inverse, 16 = P computed but not stored -- wrong
+// results, stage timings.
+template <int SKIP = 0>
+__global__ void __launch_bounds__(256) k_aem_inverse(const AemInvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double aem_blocks[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lc = lane & 15, hi = lane >> 4;
+  const int64_t c = blockIdx.x;
+  if (c >= a.N) return;
+  const int nb = a.nb, m = a.m, MP = a.MP;
+  auto blk = [&](int bi, int bj) { return aem_blocks + (size_t)(bi * (bi + 1) / 2 + bj) * AEM_BS; };
+  const int rowp = lc * 17 + hi;  // + 4 kc: element [lc][4 kc + hi]   (A operand of X, B operand of X^T)
+  const int colp = hi * 17 + lc;  // + 68 kc: element [4 kc + hi][lc]  (B operand of X, A operand of X^T)
+  const int cdp = hi * 17 + lc;   // + 68 r: C/D element [hi + 4 r][lc]
+
+  // ---- Sigma_e + Sigma_bias into the blocks, and the 1e-9 rule ----
+  // thread (r, cc) = element [r][cc] of every block; twelve blocks in flight (the stage is bound by the latency of
+  // the global loads at two workgroups per CU, not by their volume)
   bool big = false;
-  if (lo) {
-#pragma unroll 4
-    for (int j = 0; j < a.m; ++j) {
-      // symmetric matrices: element (lane, j) is read as (j, lane), the entry this very lane wrote above
-      double sb = 0.0;
-      if (a.dependent) sb = Sg[(size_t)j * MP + lane];
-      else
-        for (int p = q; p < nl; ++p) sb += a.b_sig[p][(size_t)c * MP * MP + (size_t)j * MP + lane];
-      big = big || !(sb < 1e-9);
-      s_M[lane * LDM + j] = a.cov[k][(size_t)j * MP + lane] + sb;
+  const size_t cbase = (size_t)c * MP * MP;
+  const double* __restrict__ sg0 = a.sig[0] + cbase;
+  const double* __restrict__ sg1 = a.nsum > 1 ? a.sig[1] + cbase : sg0;
+  const double* __restrict__ sg2 = a.nsum > 2 ? a.sig[2] + cbase : sg0;
+  const int nblk = nb * (nb + 1) / 2;
+  const int er = tid >> 4, ec = tid & 15;
+  for (int b0 = 0; b0 < nblk; b0 += 12) {
+    double v0[12], v1[12], v2[12], ce[12];
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+      const int b = b0 + u < nblk ? b0 + u : nblk - 1;
+      int bi = 0;
+      while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
+      const int bj = b - bi * (bi + 1) / 2;
+      const int i = 16 * bi + er, j = 16 * bj + ec;
+      const bool in = i < m && j < m;
+      const size_t o = in ? (size_t)i * MP + j : 0;
+      v0[u] = sg0[o];
+      v1[u] = a.nsum > 1 ? sg1[o] : 0.0;
+      v2[u] = a.nsum > 2 ? sg2[o] : 0.0;
+      ce[u] = a.cov[o];
     }
-  }
-  const bool refresh = __syncthreads_or(big ? 1 : 0) != 0;
-  if (refresh) {
-    // inverse through the Cholesky factor: M = L L^T, W = L^-1, P = W^T W
-    for (int kk = 0; kk < a.m; ++kk) {
-      double sacc = 0.0;
-      if (lane >= kk && lo) {
-        sacc = s_M[lane * LDM + kk];
-#pragma unroll 8
-        for (int p = 0; p < kk; ++p) sacc = fma(-s_M[lane * LDM + p], s_M[kk * LDM + p], sacc);  // unrolled: LDS reads in flight
-      }
-      double lkk;
-      if constexpr (NW > 1) {
-        if (lane == kk) s_x[2] = sacc;
-        __syncthreads();
-        lkk = sqrt(s_x[2]);
-      } else {
-        lkk = sqrt(__shfl(sacc, kk));
-      }
-      if (lane >= kk && lo) s_M[lane * LDM + kk] = lane == kk ? lkk : sacc / lkk;
-      __syncthreads();
-    }
-    // W = L^-1, lane = column j: W[i][j] for i >= j by forward substitution down the rows.  W^T goes into the strict
-    // upper triangle of s_M (W[i][j] at s_M[j][i]; L stays below), its diagonal into s_v[2 MPT ..): a per-lane array
-    // indexed by the loop variable would live in scratch memory and made this kernel 85 % of an error-model run.
-    double* const s_wd = s_v + 2 * MPT;
-    for (int i = 0; i < a.m; ++i) {
-      if (lo && i >= lane) {
-        const double lii = s_M[i * LDM + i];
-        if (i == lane) {
-          s_wd[lane] = 1.0 / lii;
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+      if (b0 + u < nblk) {
+        const int b = b0 + u;
+        int bi = 0;
+        while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
+        const int bj = b - bi * (bi + 1) / 2;
+        const int i = 16 * bi + er, j = 16 * bj + ec;
+        double v;
+        if (i < m && j < m) {
+          double sb = 0.0 + v0[u];  // the reference's sum over the trackers starts from zero (proposal.py:1563-1569)
+          if (a.nsum > 1) sb += v1[u];
+          if (a.nsum > 2) sb += v2[u];
+          big = big || !(sb < 1e-9);
+          v = ce[u] + sb;
         } else {
-          double sacc = fma(s_M[i * LDM + lane], s_wd[lane], 0.0);
-#pragma unroll 8
-          for (int p = lane + 1; p < i; ++p) sacc = fma(s_M[i * LDM + p], s_M[lane * LDM + p], sacc);
-          s_M[lane * LDM + i] = -sacc / lii;
+          v = (i == j) ? 1.0 : 0.0;
         }
+        aem_blocks[(size_t)b * AEM_BS + er * 17 + ec] = v;
+      }
+    }
+  }
+  if (!__syncthreads_or(big ? 1 : 0)) return;
+  if constexpr ((SKIP & 2) != 0) return;
+
+  // ---- 1. blocked Cholesky; the diagonal blocks end up holding the inverses of their factors ----
+  for (int j = 0; j < nb; ++j) {
+    for (int i = j + wave; i < nb; i += 4) {
+      double* Cij = blk(i, j);
+      double4_t acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = Cij[cdp + 68 * r];
+      for (int k = 0; k < j; ++k) {
+        const double* Lik = blk(i, k);
+        const double* Ljk = blk(j, k);
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) acc = mfma_f64(-Lik[rowp + 4 * kc], Ljk[rowp + 4 * kc], acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cij[cdp + 68 * r] = acc[r];
+    }
+    __syncthreads();
+    if ((SKIP & 1) == 0 && wave == ((j + (int)c) & 3)) aem_diag_block(blk(j, j), lane);  // rotated over the SIMDs
+    __syncthreads();
+    const double* Wjj = blk(j, j);
+    for (int i = j + 1 + wave; i < nb; i += 4) {  // L[i][j] = A[i][j] W[j][j]^T
+      double* Cij = blk(i, j);
+      double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) acc = mfma_f64(Cij[rowp + 4 * kc], Wjj[rowp + 4 * kc], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cij[cdp + 68 * r] = acc[r];
+    }
+    __syncthreads();
+  }
+
+  // ---- 2. W = L^-1 in place ----
+  for (int j = (SKIP & 8) ? -1 : nb - 2; j >= 0; --j) {
+    double4_t t[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int i = j + 1 + wave + 4 * s;
+      t[s] = double4_t{0.0, 0.0, 0.0, 0.0};
+      if (i < nb)
+        for (int k = j + 1; k <= i; ++k) {
+          const double* Wik = blk(i, k);
+          const double* Lkj = blk(k, j);
+#pragma unroll
+          for (int kc = 0; kc < 4; ++kc) t[s] = mfma_f64(Wik[rowp + 4 * kc], Lkj[colp + 68 * kc], t[s]);
+        }
+    }
+    __syncthreads();  // every L[k][j] of this block column has been read
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int i = j + 1 + wave + 4 * s;
+      if (i < nb) {
+        double* Tij = blk(i, j);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tij[cdp + 68 * r] = t[s][r];
       }
     }
     __syncthreads();
-    if (lo) {
-      double* Pc = a.cov_inv[k] + (size_t)c * MP * MP;
-      for (int i = 0; i < a.m; ++i) {  // P[i][lane] = sum_{r >= max(i, lane)} W[r][i] W[r][lane]
-        const int r0 = i > lane ? i : lane;
-        const double wi = i == r0 ? s_wd[i] : s_M[i * LDM + r0];           // W[r0][i]
-        const double wl = lane == r0 ? s_wd[lane] : s_M[lane * LDM + r0];  // W[r0][lane]
-        double sacc = fma(wi, wl, 0.0);
-#pragma unroll 8
-        for (int r = r0 + 1; r < a.m; ++r) sacc = fma(s_M[i * LDM + r], s_M[lane * LDM + r], sacc);
-        Pc[(size_t)i * MP + lane] = sacc;
+    const double* Wjj = blk(j, j);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int i = j + 1 + wave + 4 * s;
+      if (i < nb) {
+        double* Tij = blk(i, j);
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) acc = mfma_f64(-Tij[rowp + 4 * kc], Wjj[colp + 68 * kc], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tij[cdp + 68 * r] = acc[r];
       }
     }
-    __threadfence_block();
     __syncthreads();
   }
-  // update_link of level k's latest link (posterior.py:112-134)
-  const double llk = quad(k, lo ? rk + bt : 0.0);
-  if (lane == 0) {
-    a.ll[(size_t)k * a.NP + c] = llk;
-    const int64_t idk = a.sid[(size_t)k * a.NP + c];
-    for (int q2 = q; q2 < nl; ++q2)
-      if (a.sid[(size_t)q2 * a.NP + c] == idk) a.Sst[((size_t)pair_index(k, q2) * 2 + 1) * a.NP + c] = llk;
-  }
+
+  // ---- 3. P = W^T W ----
+  if constexpr ((SKIP & 4) != 0) return;
+  double* Pc = a.P + cbase;
+  int idx = 0;
+  for (int i = 0; i < nb; ++i)
+    for (int jj = 0; jj <= i; ++jj, ++idx) {
+      if ((idx & 3) != wave) continue;
+      double4_t acc = {0.0, 0.0, 0.0, 0.0};
+      for (int k = i; k < nb; ++k) {
+        const double* Wki = blk(k, i);
+        const double* Wkj = blk(k, jj);
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) acc = mfma_f64(Wki[colp + 68 * kc], Wkj[colp + 68 * kc], acc);
+      }
+      // the block in 128-byte row segments, its mirror image element by element (the stores are asynchronous and the
+      // stage is bound by the matrix cores: a second product for the mirror block cost more than the scattered stores)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * i + hi + 4 * r, col = 16 * jj + lc;
+        const bool st = ((SKIP & 16) == 0 || acc[r] == 1.2345) && row < m && col < m;
+        if (st) Pc[(size_t)row * MP + col] = acc[r];
+        if (st && i != jj) Pc[(size_t)col * MP + row] = acc[r];
+      }
+    }
 }
 
 }  // namespace tda
