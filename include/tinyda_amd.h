@@ -70,7 +70,8 @@ typedef enum tda_error_model { TDA_AEM_NONE = 0, TDA_AEM_STATE_INDEPENDENT = 1, 
 /* tinyDA/proposal.py: GaussianRandomWalk :132, CrankNicolson :261, AdaptiveMetropolis :372, DREAMZ :608 / DREAM :1627 */
 typedef enum tda_proposal_kind {
   TDA_PROP_GRW = 0, TDA_PROP_PCN = 1, TDA_PROP_AM = 2, TDA_PROP_DREAMZ = 3,
-  TDA_PROP_INDEPENDENCE = 4 /* IndependenceSampler with a Gaussian q (proposal.py:65-129) */
+  TDA_PROP_INDEPENDENCE = 4, /* IndependenceSampler with a Gaussian q (proposal.py:65-129) */
+  TDA_PROP_OWCN = 5          /* OperatorWeightedCrankNicolson with fixed operators (proposal.py:515-605) */
 } tda_proposal_kind;
 
 typedef struct tda_config {
@@ -167,6 +168,11 @@ int tda_engine_set_level(tda_engine* e, int level, int m, const double* A, const
 
 int tda_engine_set_proposal(tda_engine* e, const tda_proposal_params* p);
 int tda_engine_set_proposal_dreamz(tda_engine* e, const tda_dreamz_params* p);
+/* OperatorWeightedCrankNicolson (proposal.py:515-605; kind TDA_PROP_OWCN set by tda_engine_set_proposal with C = NULL, adaptive = 0):
+ * theta' = state_operator theta + noise_operator N(0, C_prior), acceptance on the likelihood ratio like pCN.  Both operators
+ * [dim][dim] row-major, what the reference computes in setup_proposal (:576-580: real(sqrtm(I - scaling B)), real(sqrtm(scaling B))).
+ * Single-level chains with a linear forward model.  Call after set_proposal, before init. */
+int tda_engine_set_proposal_operators(tda_engine* e, const double* state_operator, const double* noise_operator);
 
 /* Initial archive Z (DREAMZ.setup_proposal, proposal.py:744-788): [n_chains][M0][dim] (per chain) or [M0][dim]
  * (shared).  NULL = draw the rows from the prior with RNG stream 2. Call after set_proposal_dreamz, before init. */

@@ -272,17 +272,27 @@ def _acceptance(kind, lp_new, ll_new, lp_old, ll_old):
     post_new = lp_new + ll_new
     post_old = lp_old + ll_old
     with np.errstate(over="ignore", invalid="ignore"):
-        if kind == "pcn":
+        if kind in ("pcn", "owcn"):  # OperatorWeightedCrankNicolson inherits CrankNicolson.get_acceptance
             alpha = np.exp(ll_new - ll_old)
         else:
             alpha = np.exp(post_new - post_old)
     return np.where(np.isnan(post_new), 0.0, alpha)
 
 
+def owcn_operators(B, scaling):
+    """state / noise operators of OperatorWeightedCrankNicolson (proposal.py:576-580): real parts of the principal
+    matrix square roots of I - scaling B and scaling B (scipy.linalg.sqrtm, as the reference calls it)."""
+    from scipy.linalg import sqrtm
+
+    d = B.shape[0]
+    return np.real(sqrtm(np.eye(d) - scaling * B)), np.real(sqrtm(scaling * B))
+
+
 def run_mh(level, proposal, theta0, z, u):
     """N chains x T steps of Chain.sample (chain.py:95-125) on recorded variates.
 
-    proposal: dict with 'kind' in {'grw','pcn','am'} and
+    proposal: dict with 'kind' in {'grw','pcn','am','owcn','indep'} and
+        owcn: B[d,d], scaling, adaptive, gamma, period; C = prior covariance (proposal.py:515-605)
         grw: C[d,d], scaling, adaptive, gamma, period            (proposal.py:171-258)
         pcn: scaling(beta), adaptive, gamma, period; C = prior covariance (proposal.py:302-362)
         am : C0[d,d], sd, epsilon, t0, period, adaptive, gamma   (proposal.py:416-512)
@@ -313,6 +323,12 @@ def run_mh(level, proposal, theta0, z, u):
         t0 = int(proposal.get("t0", 0))
         am_mu = theta0.copy()  # proposal.py:495-500
         am_sigma = np.zeros((N, d, d))
+    elif kind == "owcn":  # OperatorWeightedCrankNicolson (proposal.py:515-605): C = prior covariance, operators from B
+        C = np.broadcast_to(level.prior.cov, (N, d, d)).copy()
+        scaling = np.full(N, float(proposal.get("scaling", 1.0)))
+        B = np.asarray(proposal["B"], dtype=float)
+        state_op, noise_op = zip(*[owcn_operators(B, sc) for sc in scaling])  # proposal.py:576-580
+        state_op, noise_op = np.array(state_op), np.array(noise_op)
     elif kind == "indep":  # IndependenceSampler with q = N(q_mean, q_cov)  (proposal.py:65-129); never adapts
         q = MVNPrior(proposal["q_mean"], proposal["q_cov"])
         C = np.broadcast_to(q.cov, (N, d, d)).copy()
@@ -338,6 +354,8 @@ def run_mh(level, proposal, theta0, z, u):
         inc = np.einsum("nij,nj->ni", L, z[:, s])
         if kind == "pcn":
             prop = np.sqrt(1 - scaling ** 2)[:, None] * theta + scaling[:, None] * inc  # proposal.py:351-355
+        elif kind == "owcn":  # proposal.py:592-598
+            prop = np.einsum("nij,nj->ni", state_op, theta) + np.einsum("nij,nj->ni", noise_op, inc)
         elif kind == "indep":
             prop = q.mean[None, :] + inc  # q.rvs (proposal.py:113-115) through the Cholesky map of the variate tap
         else:
@@ -363,6 +381,9 @@ def run_mh(level, proposal, theta0, z, u):
             rate = out_acc[:, : s + 2][:, -period:].mean(axis=1)
             scaling = np.exp(np.log(scaling) + gamma ** -k * (rate - alpha_star))
             k += 1
+            if kind == "owcn":  # proposal.py:582-590
+                state_op, noise_op = zip(*[owcn_operators(B, sc) for sc in scaling])
+                state_op, noise_op = np.array(state_op), np.array(noise_op)
         if kind == "am":
             am_mu, am_sigma = moments_update(am_mu, am_sigma, t, theta, sd, eps)  # recursor.t == t here
             if t >= t0 and t % period == 0:

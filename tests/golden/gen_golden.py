@@ -262,6 +262,26 @@ def g2b_pcn():
          scaling_hist=np.array(snaps), **res)
 
 
+def g13_owcn(name, adaptive):
+    """OperatorWeightedCrankNicolson (proposal.py:515-605) on a linear-Gaussian posterior with a general prior covariance."""
+    d, m, n_chains, iters = 8, 16, 4, 150
+    A, theta_true, y = linear_problem(131, d, m, sigma=0.2)
+    rng = np.random.default_rng(132)
+    R = rng.standard_normal((d, d)) / np.sqrt(d)
+    pc = R @ R.T + 0.5 * np.eye(d)
+    pm = np.zeros(d)
+    Q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    Bop = Q @ np.diag(np.linspace(0.05, 0.6, d)) @ Q.T  # symmetric, spectrum inside (0, 1 / scaling)
+    prior = stats.multivariate_normal(pm, pc)
+    post = tda.Posterior(prior, tda.GaussianLogLike(y, 0.04 * np.eye(m)), make_model(A))
+    prop = tda.OperatorWeightedCrankNicolson(Bop, scaling=0.4, adaptive=adaptive, gamma=1.02, period=30)
+    theta0 = 0.3 * rng.standard_normal((n_chains, d))
+    res, snaps = run_mh(post, prop, theta0, iters, n_chains, seed=1330,
+                        snapshot={"period": 30, "fn": lambda p: float(p.scaling)})
+    save(name, A=A, data=y, noise_var=np.array(0.04), prior_mean=pm, prior_cov=pc, B=Bop, scaling0=np.array(0.4),
+         adaptive=np.array(adaptive), gamma=np.array(1.02), period=np.array(30), theta0=theta0, scaling_hist=np.array(snaps), **res)
+
+
 def g3_loglike_kats():
     rng = np.random.default_rng(31)
     m = 12
@@ -773,6 +793,8 @@ FIXTURES = {
     "g9_mvn_logpdf": g9_mvn_logpdf,
     "g10_jointprior": g10_jointprior,
     "g12_independence": g12_independence,
+    "g13_owcn": lambda: g13_owcn("g13_owcn", False),
+    "g13_owcn_adaptive": lambda: g13_owcn("g13_owcn_adaptive", True),
 }
 
 if __name__ == "__main__":

@@ -64,6 +64,16 @@ def test_g2b_pcn(golden):
     np.testing.assert_allclose(res["scaling_hist"], g["scaling_hist"], rtol=1e-13)
 
 
+@pytest.mark.parametrize("name", ["g13_owcn", "g13_owcn_adaptive"])
+def test_g13_operator_weighted_pcn(golden, name):
+    g = golden(name)
+    prop = dict(kind="owcn", B=g["B"], scaling=float(g["scaling0"]), adaptive=bool(g["adaptive"]), gamma=float(g["gamma"]),
+                period=int(g["period"]))
+    res = orc.run_mh(_level(g), prop, g["theta0"], g["z"], g["u"])
+    _check_traces(res, g)
+    np.testing.assert_allclose(res["scaling_hist"], g["scaling_hist"], rtol=1e-13)
+
+
 def test_g3_loglike_kats(golden):
     g = golden("g3_loglike_kats")
     data, X = g["data"], g["X"]

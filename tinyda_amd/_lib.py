@@ -13,7 +13,7 @@ TDA_OK = 0
 TDA_ERR_CALLBACK = -6
 NOISE_ISO, NOISE_DIAG, NOISE_DENSE, NOISE_ADAPTIVE = 0, 1, 2, 3
 AEM_NONE, AEM_STATE_INDEPENDENT, AEM_STATE_DEPENDENT = 0, 1, 2
-PROP_GRW, PROP_PCN, PROP_AM, PROP_DREAMZ, PROP_INDEPENDENCE = 0, 1, 2, 3, 4
+PROP_GRW, PROP_PCN, PROP_AM, PROP_DREAMZ, PROP_INDEPENDENCE, PROP_OWCN = 0, 1, 2, 3, 4, 5
 
 
 class EngineError(RuntimeError):
@@ -105,6 +105,7 @@ SYMBOLS = {
     "tda_engine_set_level": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P]),
     "tda_engine_set_proposal": (C.c_int, [_P, C.POINTER(tda_proposal_params)]),
     "tda_engine_set_proposal_dreamz": (C.c_int, [_P, C.POINTER(tda_dreamz_params)]),
+    "tda_engine_set_proposal_operators": (C.c_int, [_P, _P, _P]),
     "tda_engine_set_archive": (C.c_int, [_P, _P]),
     "tda_engine_set_level_rosenbrock": (C.c_int, [_P, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]),
     "tda_engine_set_replay_dreamz": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int64]),

@@ -197,6 +197,8 @@ struct tda_engine {
   bool prop_set = false;
   tda_proposal_params pp{};
   std::vector<double> prop_C_h, q_mean_h;  // q_mean_h: independence sampler
+  std::vector<double> ow_state_h, ow_noise_h;  // OperatorWeightedCrankNicolson operators [d][d]
+  DevBuf<double> ow_SopT;                      // state operator, transposed and padded: [DP][DP], SopT[j][i] = S[i][j]
   DevBuf<double> q_mean_d, lq, qzblk, qzblk2[2];
   double am_sd = 1.0;
   bool L_shared = true;
@@ -298,6 +300,8 @@ void launch_steps(const StepArgs& a, int64_t tiles, size_t lds, hipStream_t st) 
   // dense noise keeps a 128 KiB residual tile and long MFMA chains per wave: 4 waves (512 registers) there
   const bool eight = g_steps_waves == 8 && a.lv.noise_kind != TDA_NOISE_DENSE;
   const bool ind = a.prop_kind == TDA_PROP_INDEPENDENCE;
+  const bool ow = a.prop_kind == TDA_PROP_OWCN && a.mode == MODE_STEP;  // + current-state tile and the state operator in LDS
+  if (ow) lds += ((size_t)16 * (DPAD + 2) + (size_t)DPAD * DPAD) * sizeof(double);
   auto go = [&](auto kern, unsigned threads, size_t bytes) {
     if (bytes > 64 * 1024)  // beyond the default dynamic-LDS window (gfx950 has 160 KiB per CU)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -306,9 +310,11 @@ void launch_steps(const StepArgs& a, int64_t tiles, size_t lds, hipStream_t st) 
   if (eight) {
     const size_t l8 = lds + 2 * 64 * sizeof(double);  // two more [4][16] reduction slabs
     if (ind) go(&k_mh_steps<DPAD, 8, true>, 512, l8);
+    else if (ow) go(&k_mh_steps<DPAD, 8, false, true>, 512, l8);
     else go(&k_mh_steps<DPAD, 8, false>, 512, l8);
   } else {
     if (ind) go(&k_mh_steps<DPAD, 4, true>, 256, lds);
+    else if (ow) go(&k_mh_steps<DPAD, 4, false, true>, 256, lds);
     else go(&k_mh_steps<DPAD, 4, false>, 256, lds);
   }
 }
@@ -822,14 +828,21 @@ int tda_engine_set_level(tda_engine* e, int level, int m, const double* A, const
 int tda_engine_set_proposal(tda_engine* e, const tda_proposal_params* p) {
   if (!e || !p) return fail(TDA_ERR_INVALID, "null argument");
   if (p->struct_size != sizeof(tda_proposal_params)) return fail(TDA_ERR_INVALID, "tda_proposal_params.struct_size mismatch");
-  const bool indep = p->kind == TDA_PROP_INDEPENDENCE;
-  if ((p->kind < TDA_PROP_GRW || p->kind > TDA_PROP_AM) && !indep) return fail(TDA_ERR_UNSUPPORTED, "proposal kind %d", p->kind);
+  const bool indep = p->kind == TDA_PROP_INDEPENDENCE, owcn = p->kind == TDA_PROP_OWCN;
+  if ((p->kind < TDA_PROP_GRW || p->kind > TDA_PROP_AM) && !indep && !owcn) return fail(TDA_ERR_UNSUPPORTED, "proposal kind %d", p->kind);
+  if (owcn && e->nlev != 1) return fail(TDA_ERR_UNSUPPORTED, "the operator-weighted pCN proposal is lowered for single-level chains only");
+  if (owcn && p->adaptive) return fail(TDA_ERR_UNSUPPORTED, "operator-weighted pCN: adaptive scaling (per-chain operators) is not lowered");
   if ((p->kind == TDA_PROP_GRW || p->kind == TDA_PROP_AM || indep) && !p->C) return fail(TDA_ERR_INVALID, "proposal covariance missing");
   if (indep && !p->q_mean) return fail(TDA_ERR_INVALID, "independence sampler: q_mean missing");
   if (indep && e->nlev != 1) return fail(TDA_ERR_UNSUPPORTED, "the independence sampler is lowered for single-level chains only");
   if (p->period < 1) return fail(TDA_ERR_INVALID, "period must be >= 1");
   e->pp = *p;
   e->pp.q_mean = nullptr;
+  if (owcn) {  // the scaling is inside the operators (proposal.py:579-580)
+    e->pp.scaling = 1.0;
+    e->ow_state_h.clear();
+    e->ow_noise_h.clear();
+  }
   if (indep) {  // never adapts (proposal.py:107-111); scaling plays no role
     e->pp.adaptive = 0;
     e->pp.scaling = 1.0;
@@ -839,6 +852,18 @@ int tda_engine_set_proposal(tda_engine* e, const tda_proposal_params* p) {
   e->pp.C = nullptr;
   e->am_sd = p->sd > 0.0 ? p->sd : std::min(1.0, 2.4 * 2.4 / e->d);
   e->prop_set = true;
+  e->inited = false;
+  return TDA_OK;
+}
+
+int tda_engine_set_proposal_operators(tda_engine* e, const double* state_operator, const double* noise_operator) {
+  if (!e || !state_operator || !noise_operator) return fail(TDA_ERR_INVALID, "null argument");
+  if (!e->prop_set || e->pp.kind != TDA_PROP_OWCN) return fail(TDA_ERR_STATE, "set_proposal with kind TDA_PROP_OWCN must precede set_proposal_operators");
+  const size_t dd = (size_t)e->d * e->d;
+  for (size_t i = 0; i < dd; ++i)
+    if (!std::isfinite(state_operator[i]) || !std::isfinite(noise_operator[i])) return fail(TDA_ERR_NUMERIC, "proposal operators must be finite");
+  e->ow_state_h.assign(state_operator, state_operator + dd);
+  e->ow_noise_h.assign(noise_operator, noise_operator + dd);
   e->inited = false;
   return TDA_OK;
 }
@@ -1356,6 +1381,11 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
   if (!e->prior_set || !e->prop_set) return fail(TDA_ERR_STATE, "set_prior and set_proposal must precede init");
   for (auto& lv : e->levels)
     if (!lv.set) return fail(TDA_ERR_STATE, "set_level missing");
+  if (e->prop_set && !e->is_dreamz && e->pp.kind == TDA_PROP_OWCN) {
+    if (e->ow_state_h.empty()) return fail(TDA_ERR_STATE, "operator-weighted pCN: set_proposal_operators missing");
+    if (e->levels[0].model != MODEL_LINEAR) return fail(TDA_ERR_UNSUPPORTED, "operator-weighted pCN is lowered for linear forward models only");
+    if (e->prior_bounded) return fail(TDA_ERR_UNSUPPORTED, "operator-weighted pCN needs a Gaussian prior");
+  }
   if (e->prior_bounded) {  // JointPrior with uniform components
     if (e->nlev != 1 || e->is_dreamz) return fail(TDA_ERR_UNSUPPORTED, "priors with uniform components: single-level GRW / AM only");
     if (e->pp.kind == TDA_PROP_PCN) return fail(TDA_ERR_UNSUPPORTED, "pCN needs a Gaussian prior");
@@ -1503,11 +1533,26 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
     return TDA_OK;
   }
   std::vector<double> L;
-  const double* Cuse = e->pp.kind == TDA_PROP_PCN ? e->prior_cov_h.data() : e->prop_C_h.data();  // proposal.py:336-341
+  const bool owcn = e->pp.kind == TDA_PROP_OWCN;
+  const double* Cuse = (e->pp.kind == TDA_PROP_PCN || owcn) ? e->prior_cov_h.data() : e->prop_C_h.data();  // proposal.py:336-341
   if (!cholesky_host(Cuse, d, L)) return fail(TDA_ERR_NUMERIC, "proposal covariance is not positive definite");
   std::vector<double> Lk((size_t)DP * DP, 0.0);
-  for (int j = 0; j < d; ++j)
-    for (int k = 0; k <= j; ++k) Lk[(size_t)k * DP + j] = L[(size_t)j * d + k];
+  if (owcn) {
+    // increments = noise_operator N(0, C_prior) = (noise_operator chol(C_prior)) z (proposal.py:596-598): a full factor
+    for (int j = 0; j < d; ++j)
+      for (int k = 0; k < d; ++k) {
+        double g = 0.0;
+        for (int i = k; i < d; ++i) g = std::fma(e->ow_noise_h[(size_t)j * d + i], L[(size_t)i * d + k], g);
+        Lk[(size_t)k * DP + j] = g;
+      }
+    std::vector<double> St((size_t)DP * DP, 0.0);
+    for (int i = 0; i < d; ++i)
+      for (int j = 0; j < d; ++j) St[(size_t)j * DP + i] = e->ow_state_h[(size_t)i * d + j];
+    if ((rc = e->ow_SopT.upload(St))) return rc;
+  } else {
+    for (int j = 0; j < d; ++j)
+      for (int k = 0; k <= j; ++k) Lk[(size_t)k * DP + j] = L[(size_t)j * d + k];
+  }
   if (e->pp.kind == TDA_PROP_AM) {
     e->L_shared = false;
     if ((rc = e->Lk.alloc((size_t)NP * DP * DP))) return rc;
@@ -1939,6 +1984,7 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     sa.inc = e->inc.p;
     sa.u = u_blk;
     sa.logu = lu_blk;
+    sa.SopT = e->pp.kind == TDA_PROP_OWCN ? e->ow_SopT.p : nullptr;
     if (e->pp.kind == TDA_PROP_INDEPENDENCE) {
       if (lv.model == MODEL_USER) return fail(TDA_ERR_UNSUPPORTED, "the independence sampler is not lowered for source-defined models");
       sa.q_mean = e->q_mean_d.p;

@@ -79,6 +79,8 @@ struct StepArgs {
   const double* q_mean;  // [DPAD]
   const double* qz;      // [S][NP] log q(theta') up to q's constant: -|z|^2 / 2
   double* lq;            // [NP]    the same for the current state
+  // operator-weighted pCN (prop_kind 5): theta' = S theta + inc
+  const double* SopT;    // [DPAD][DPAD] transposed state operator: SopT[j][i] = S[i][j]
   // records, layout of tda_outputs (may be null)
   double* rec_params;
   double* rec_stats;
@@ -430,7 +432,10 @@ __host__ __device__ constexpr int steps_lds_doubles(int m_pad, bool diag, int pr
 // ------------------------------------------------------------------------------------------------
 // IND = IndependenceSampler proposals (a template parameter: as a run-time flag it costs the random-walk path 16 registers
 // and 3 %)
-template <int DPAD, int NW, bool IND = false>
+// OW = OperatorWeightedCrankNicolson proposals (proposal.py:592-598): theta' = S theta + inc needs the whole current
+// state of a chain in every thread of its group, so the variant keeps a current-state tile and S^T in LDS and pays one
+// more barrier per step; a template parameter for the same reason as IND.
+template <int DPAD, int NW, bool IND = false, bool OW = false>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int KS = DPAD / 4;
@@ -452,6 +457,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
   double* s_w = s_y + a.lv.m_pad;
   double* s_py = s_w + (diag ? a.lv.m_pad : 0);
   double* s_R = s_py + (prior_dense ? a.pr.ncb * 16 : 0);
+  double* s_cur = s_R + (dense ? 16 * RS : 0);  // OW: current states [16][LDP]
+  double* s_S = s_cur + 16 * LDP;               // OW: S^T [DPAD][DPAD]
 
   // the step kernel is the critical path: kernels that share its SIMDs (k_rng on the second stream) only get the
   // issue slots it leaves empty
@@ -489,7 +496,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
   const double keep_t = a.prop_kind == 1 ? sqrt(1.0 - scal_t * scal_t) : 1.0;  // proposal.py:351-352
   int nacc = 0;
   const bool is_eval = a.mode == MODE_EVAL;
-  const bool is_pcn = a.prop_kind == 1;
+  const bool is_pcn = a.prop_kind == 1 || OW;  // OperatorWeightedCrankNicolson inherits pCN's likelihood-ratio acceptance
   constexpr bool is_ind = IND;  // IndependenceSampler (proposal.py:65-129)
   double qm[EPT];
 #pragma unroll
@@ -511,6 +518,13 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
     if (has_logu) lunext = a.logu[gcl];
     if (is_ind) qznext = a.qz[gcl];
   }
+  if constexpr (OW) {
+    for (int i = tid; i < DPAD * DPAD; i += NT) s_S[i] = a.SopT[i];
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) s_cur[c * LDP + q * EPT + e] = cur[e];
+    }
+  }
   __syncthreads();
 
   if constexpr (!PAIRS) frag_load_buf<DPAD>(frag_src(a.lv.Apk, lane), wave < a.lv.ncb ? wave : a.lv.ncb - 1, f0);  // later steps: prefetched by the previous step
@@ -530,8 +544,25 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
       frag_load<DPAD>(fbase, wave, a.lv.ncb, f0);
       frag_load<DPAD>(fbase, wave + NW, a.lv.ncb, f1);
     }
-    // ---- proposal: theta' (proposal.py:249-251 / :351-355) ----
-    if (active) {
+    // ---- proposal: theta' (proposal.py:249-251 / :351-355 / :592-598) ----
+    if constexpr (OW) {
+      if (s > 0) __syncthreads();  // the accepted states of the previous step are in s_cur
+      if (active) {
+        double st[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) st[e] = 0.0;
+        for (int j = 0; j < DPAD; ++j) {  // (S theta)[i] = sum_j S^T[j][i] theta[j]: consecutive threads, consecutive i
+          const double tj = s_cur[c * LDP + j];
+#pragma unroll
+          for (int e = 0; e < EPT; ++e) st[e] = fma(s_S[j * DPAD + q * EPT + e], tj, st[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          prp[e] = st[e] + xin[e];
+          s_prop[c * LDP + q * EPT + e] = prp[e];
+        }
+      }
+    } else if (active) {
 #pragma unroll
       for (int e = 0; e < EPT; ++e) {
         if (is_eval) {
@@ -674,6 +705,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
 #pragma unroll
       for (int e = 0; e < EPT; ++e) {
         cur[e] = accf ? prp[e] : cur[e];
+        if constexpr (OW) s_cur[c * LDP + q * EPT + e] = cur[e];
         const int j = q * EPT + e;
         if (!is_eval && a.rec_params && gct < a.N && j < a.d)
           a.rec_params[((size_t)s * a.N + gct) * a.d + j] = cur[e];

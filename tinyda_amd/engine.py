@@ -77,12 +77,16 @@ class Engine:
         check(self.lib.tda_engine_set_level(self.h, level, m, _ptr(A), _ptr(b), _ptr(data), noise_kind, _ptr(noise)))
 
     def set_proposal(self, kind, C_=None, scaling=1.0, adaptive=False, gamma=1.01, period=100, sd=None,
-                     epsilon=1e-6, t0=0, block_moments=False, q_mean=None):
+                     epsilon=1e-6, t0=0, block_moments=False, q_mean=None, state_operator=None, noise_operator=None):
         Cm = None if C_ is None else _f64(C_)
         p = _lib.tda_proposal_params(C.sizeof(_lib.tda_proposal_params), kind, scaling, int(adaptive), period, gamma,
                                      _ptr(Cm), -1.0 if sd is None else sd, epsilon, t0, int(block_moments),
                                      _ptr(None if q_mean is None else _f64(q_mean)))
         check(self.lib.tda_engine_set_proposal(self.h, C.byref(p)))
+        if state_operator is not None:  # OperatorWeightedCrankNicolson (kind 5): theta' = S theta + N chol(C_prior) z
+            So, No = _f64(state_operator), _f64(noise_operator)
+            assert So.shape == (self.dim, self.dim) and No.shape == (self.dim, self.dim)
+            check(self.lib.tda_engine_set_proposal_operators(self.h, _ptr(So), _ptr(No)))
 
     def set_prior_joint(self, kinds, loc, scale):
         """JointPrior of scalar components: kinds[j] 0 = norm(loc, scale), 1 = uniform(loc, scale)"""

@@ -151,6 +151,48 @@ class CrankNicolson(GaussianRandomWalk):
                     gamma=float(self.gamma), period=int(self.period))
 
 
+class OperatorWeightedCrankNicolson(CrankNicolson):
+    """Operator-weighted pCN (Law 2014): theta' = sqrtm(I - scaling B) theta + sqrtm(scaling B) N(0, C_prior), acceptance on
+    the likelihood ratio (proposal.py:515-605).  The operators are recomputed when the adaptive scaling changes.  On the
+    device path the (non-adaptive) operators are handed to the engine: single-level chains, linear forward model."""
+
+    def __init__(self, B, scaling=1.0, adaptive=False, gamma=1.01, period=100):
+        self.B = B
+        super().__init__(scaling, adaptive, gamma, period)
+
+    def _operators(self):
+        from scipy.linalg import sqrtm
+
+        d = np.atleast_2d(self.B).shape[0]
+        self.state_operator = np.real(sqrtm(np.eye(d) - self.scaling * self.B))
+        self.noise_operator = np.real(sqrtm(self.scaling * self.B))
+
+    def setup_proposal(self, **kwargs):
+        super().setup_proposal(**kwargs)
+        self._operators()
+
+    def adapt(self, **kwargs):
+        super().adapt(**kwargs)
+        if self.adaptive and self.t % self.period == 0:
+            self._operators()
+
+    def make_proposal(self, link):
+        return np.dot(self.state_operator, link.parameters) + np.dot(self.noise_operator, self._draw())
+
+    def get_q(self, x_link, y_link):
+        return stats.multivariate_normal.logpdf(
+            y_link.parameters, mean=np.dot(self.state_operator, x_link.parameters), cov=np.dot(self.scaling * self.B, self.C)
+        )
+
+    def _lowering(self):
+        if self.adaptive:
+            return None  # per-chain operators would need a matrix square root per chain and period: host protocol
+        self._operators()
+        return dict(kind=_lib.PROP_OWCN, C_=None, scaling=1.0, adaptive=False, gamma=float(self.gamma), period=int(self.period),
+                    state_operator=np.ascontiguousarray(self.state_operator, dtype=np.float64),
+                    noise_operator=np.ascontiguousarray(self.noise_operator, dtype=np.float64))
+
+
 class AdaptiveMetropolis(GaussianRandomWalk):
     """Haario et al. (2001): proposal covariance <- running sample covariance every `period` adapt calls
     once t >= t0 (proposal.py:372-512).
