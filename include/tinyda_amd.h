@@ -71,7 +71,8 @@ typedef enum tda_error_model { TDA_AEM_NONE = 0, TDA_AEM_STATE_INDEPENDENT = 1, 
 typedef enum tda_proposal_kind {
   TDA_PROP_GRW = 0, TDA_PROP_PCN = 1, TDA_PROP_AM = 2, TDA_PROP_DREAMZ = 3,
   TDA_PROP_INDEPENDENCE = 4, /* IndependenceSampler with a Gaussian q (proposal.py:65-129) */
-  TDA_PROP_OWCN = 5          /* OperatorWeightedCrankNicolson with fixed operators (proposal.py:515-605) */
+  TDA_PROP_OWCN = 5,         /* OperatorWeightedCrankNicolson with fixed operators (proposal.py:515-605) */
+  TDA_PROP_MALA = 6          /* MALA with the exact gradient of a linear-Gaussian posterior (proposal.py:861-1005): scaling = sigma */
 } tda_proposal_kind;
 
 typedef struct tda_config {

@@ -141,15 +141,22 @@ def make_loglike(kind, data, noise):
     """GaussianLogLike factory outcome (distributions.py:203-243) as a closure over F[chain, m].
     kind: 'iso' (noise = variance), 'diag' (noise = diagonal), 'dense' (noise = covariance)."""
     data = np.asarray(data, dtype=float)
+    # .grad = grad_loglike with respect to the model output (distributions.py:300-301, :314-315, :328-329), used by MALA
     if kind == "iso":
         var = float(noise)
-        return lambda F: loglike_isotropic(F, data, var)
+        fn = lambda F: loglike_isotropic(F, data, var)
+        fn.grad = lambda F: 1 / var * (data - F)
+        return fn
     if kind == "diag":
         dg = np.asarray(noise, dtype=float)
-        return lambda F: loglike_diagonal(F, data, dg)
+        fn = lambda F: loglike_diagonal(F, data, dg)
+        fn.grad = lambda F: 1 / dg * (data - F)
+        return fn
     if kind == "dense":
         inv = np.linalg.inv(np.asarray(noise, dtype=float))  # distributions.py:280
-        return lambda F: loglike_dense(F, data, inv)
+        fn = lambda F: loglike_dense(F, data, inv)
+        fn.grad = lambda F: (data - F) @ inv.T
+        return fn
     raise ValueError(kind)
 
 
@@ -248,6 +255,12 @@ class LinearGaussianLevel:
         ll = self.loglike(F)
         return lp, ll, F
 
+    def grad_logpost(self, theta, F):
+        """MALA._compute_gradient (proposal.py:986-998) for a model whose `gradient(theta, s)` returns A^T s:
+        grad_log_p (utils.py:273-280) + A^T grad_log_l (utils.py:283-287)."""
+        g_prior = (self.prior.mean[None, :] - theta) @ np.linalg.inv(self.prior.cov).T
+        return g_prior + self.loglike.grad(F) @ self.A
+
 
 class CallableGaussianLevel:
     """Posterior.create_link (posterior.py:78-110) for an arbitrary forward model given as a batched Python callable
@@ -291,7 +304,8 @@ def owcn_operators(B, scaling):
 def run_mh(level, proposal, theta0, z, u):
     """N chains x T steps of Chain.sample (chain.py:95-125) on recorded variates.
 
-    proposal: dict with 'kind' in {'grw','pcn','am','owcn','indep'} and
+    proposal: dict with 'kind' in {'grw','pcn','am','owcn','mala','indep'} and
+        mala: scaling(sigma), adaptive, gamma, period           (proposal.py:861-1005)
         owcn: B[d,d], scaling, adaptive, gamma, period; C = prior covariance (proposal.py:515-605)
         grw: C[d,d], scaling, adaptive, gamma, period            (proposal.py:171-258)
         pcn: scaling(beta), adaptive, gamma, period; C = prior covariance (proposal.py:302-362)
@@ -329,6 +343,10 @@ def run_mh(level, proposal, theta0, z, u):
         B = np.asarray(proposal["B"], dtype=float)
         state_op, noise_op = zip(*[owcn_operators(B, sc) for sc in scaling])  # proposal.py:576-580
         state_op, noise_op = np.array(state_op), np.array(noise_op)
+    elif kind == "mala":  # MALA (proposal.py:861-1005): unit-covariance normals, drift along the posterior gradient
+        C = np.broadcast_to(np.eye(d), (N, d, d)).copy()
+        scaling = np.full(N, float(proposal.get("scaling", 0.1)))
+        alpha_star = 0.57  # proposal.py:899
     elif kind == "indep":  # IndependenceSampler with q = N(q_mean, q_cov)  (proposal.py:65-129); never adapts
         q = MVNPrior(proposal["q_mean"], proposal["q_cov"])
         C = np.broadcast_to(q.cov, (N, d, d)).copy()
@@ -339,8 +357,9 @@ def run_mh(level, proposal, theta0, z, u):
     L = np.linalg.cholesky(C)
 
     theta = theta0.copy()
-    lp, ll, _ = level.evaluate(theta)
+    lp, ll, F0 = level.evaluate(theta)
     lq = q.logpdf(theta) if kind == "indep" else None
+    grad = level.grad_logpost(theta, F0) if kind == "mala" else None
     out_theta = np.empty((N, T + 1, d))
     out_lp = np.empty((N, T + 1))
     out_ll = np.empty((N, T + 1))
@@ -354,14 +373,25 @@ def run_mh(level, proposal, theta0, z, u):
         inc = np.einsum("nij,nj->ni", L, z[:, s])
         if kind == "pcn":
             prop = np.sqrt(1 - scaling ** 2)[:, None] * theta + scaling[:, None] * inc  # proposal.py:351-355
+        elif kind == "mala":  # proposal.py:945-956
+            sg = scaling[:, None]
+            prop = theta + 0.5 * sg ** 2 * grad + sg * inc
         elif kind == "owcn":  # proposal.py:592-598
             prop = np.einsum("nij,nj->ni", state_op, theta) + np.einsum("nij,nj->ni", noise_op, inc)
         elif kind == "indep":
             prop = q.mean[None, :] + inc  # q.rvs (proposal.py:113-115) through the Cholesky map of the variate tap
         else:
             prop = theta + scaling[:, None] * inc  # proposal.py:249-251
-        lp_n, ll_n, _ = level.evaluate(prop)
-        if kind == "indep":  # proposal.py:117-123: exp(post' - post + q(prev) - q(prop))
+        lp_n, ll_n, F_n = level.evaluate(prop)
+        if kind == "mala":  # proposal.py:958-984
+            grad_n = level.grad_logpost(prop, F_n)
+            sg = scaling[:, None]
+            q_x_y = -0.5 / scaling ** 2 * np.linalg.norm(theta - prop - 0.5 * sg ** 2 * grad_n, axis=1) ** 2
+            q_y_x = -0.5 / scaling ** 2 * np.linalg.norm(prop - theta - 0.5 * sg ** 2 * grad, axis=1) ** 2
+            with np.errstate(over="ignore", invalid="ignore"):
+                alpha = np.exp((lp_n + ll_n) - (lp + ll) + q_x_y - q_y_x)
+            alpha = np.where(np.isnan(lp_n + ll_n), 0.0, alpha)
+        elif kind == "indep":  # proposal.py:117-123: exp(post' - post + q(prev) - q(prop))
             lq_n = q.logpdf(prop)
             with np.errstate(over="ignore", invalid="ignore"):
                 alpha = np.exp((lp_n + ll_n) - (lp + ll) + lq - lq_n)
@@ -370,6 +400,8 @@ def run_mh(level, proposal, theta0, z, u):
         acc = u[:, s] < alpha  # chain.py:112
         if kind == "indep":
             lq = np.where(acc, lq_n, lq)
+        if kind == "mala":
+            grad = np.where(acc[:, None], grad_n, grad)
         theta = np.where(acc[:, None], prop, theta)
         lp = np.where(acc, lp_n, lp)
         ll = np.where(acc, ll_n, ll)

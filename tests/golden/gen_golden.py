@@ -138,7 +138,7 @@ def chain_trace(chain_links):
     return th, pr, ll, po
 
 
-def run_mh(posterior, proposal, theta0, iterations, n_chains, seed, snapshot=None):
+def run_mh(posterior, proposal, theta0, iterations, n_chains, seed, snapshot=None, zkind="z"):
     """Run tinyDA.Chain for each chain; returns stacked traces [chain][step]."""
     out = {k: [] for k in ("theta", "logprior", "loglike", "logpost", "accepted", "z", "u")}
     snaps = []
@@ -165,7 +165,7 @@ def run_mh(posterior, proposal, theta0, iterations, n_chains, seed, snapshot=Non
         out["loglike"].append(ll)
         out["logpost"].append(po)
         out["accepted"].append(np.array(ch.accepted, dtype=np.uint8))
-        out["z"].append(np.array(tap.take("z")))
+        out["z"].append(np.array(tap.take(zkind)))
         out["u"].append(np.array(tap.take("u")))
     res = {k: np.array(v) for k, v in out.items()}
     return res, snaps
@@ -280,6 +280,42 @@ def g13_owcn(name, adaptive):
                         snapshot={"period": 30, "fn": lambda p: float(p.scaling)})
     save(name, A=A, data=y, noise_var=np.array(0.04), prior_mean=pm, prior_cov=pc, B=Bop, scaling0=np.array(0.4),
          adaptive=np.array(adaptive), gamma=np.array(1.02), period=np.array(30), theta0=theta0, scaling_hist=np.array(snaps), **res)
+
+
+class _LinearModelWithGradient:
+    """Forward model with the `gradient(parameters, sensitivity)` method MALA looks for (proposal.py:938-943, :996-998)."""
+
+    def __init__(self, A):
+        self.A = A
+
+    def __call__(self, th):
+        return self.A @ th
+
+    def gradient(self, th, sensitivity):
+        return self.A.T @ sensitivity
+
+
+def g14_mala(name, adaptive, cov_kind="iso"):
+    """MALA (proposal.py:861-1005) with the exact gradient of a linear-Gaussian posterior, general prior covariance."""
+    d, m, n_chains, iters = 8, 16, 4, 150
+    A, theta_true, y = linear_problem(141, d, m, sigma=0.2)
+    rng = np.random.default_rng(142)
+    R = rng.standard_normal((d, d)) / np.sqrt(d)
+    pc = R @ R.T + 0.5 * np.eye(d)
+    pm = 0.1 * rng.standard_normal(d)
+    if cov_kind == "iso":
+        cov = 0.04 * np.eye(m)
+    else:
+        Ln = 0.2 * np.eye(m) + 0.03 * np.tril(rng.standard_normal((m, m)))
+        cov = Ln @ Ln.T
+    prior = stats.multivariate_normal(pm, pc)
+    post = tda.Posterior(prior, tda.GaussianLogLike(y, cov), _LinearModelWithGradient(A))
+    prop = tda.MALA(scaling=0.12, adaptive=adaptive, gamma=1.02, period=30)
+    theta0 = theta_true[None] + 0.1 * rng.standard_normal((n_chains, d))
+    res, snaps = run_mh(post, prop, theta0, iters, n_chains, seed=1430, zkind="normal01",
+                        snapshot={"period": 30, "fn": lambda p: float(p.scaling)})
+    save(name, A=A, data=y, noise_cov=cov, prior_mean=pm, prior_cov=pc, scaling0=np.array(0.12), adaptive=np.array(adaptive),
+         gamma=np.array(1.02), period=np.array(30), theta0=theta0, scaling_hist=np.array(snaps), **res)
 
 
 def g3_loglike_kats():
@@ -795,6 +831,8 @@ FIXTURES = {
     "g12_independence": g12_independence,
     "g13_owcn": lambda: g13_owcn("g13_owcn", False),
     "g13_owcn_adaptive": lambda: g13_owcn("g13_owcn_adaptive", True),
+    "g14_mala": lambda: g14_mala("g14_mala", False),
+    "g14_mala_adaptive_dense": lambda: g14_mala("g14_mala_adaptive_dense", True, cov_kind="dense"),
 }
 
 if __name__ == "__main__":

@@ -74,6 +74,18 @@ def test_g13_operator_weighted_pcn(golden, name):
     np.testing.assert_allclose(res["scaling_hist"], g["scaling_hist"], rtol=1e-13)
 
 
+@pytest.mark.parametrize("name,noise", [("g14_mala", "iso"), ("g14_mala_adaptive_dense", "dense")])
+def test_g14_mala(golden, name, noise):
+    g = golden(name)
+    cov = g["noise_cov"]
+    lvl = orc.LinearGaussianLevel(g["A"], g["data"], noise, float(cov[0, 0]) if noise == "iso" else cov,
+                                  orc.MVNPrior(g["prior_mean"], g["prior_cov"]))
+    prop = dict(kind="mala", scaling=float(g["scaling0"]), adaptive=bool(g["adaptive"]), gamma=float(g["gamma"]), period=int(g["period"]))
+    res = orc.run_mh(lvl, prop, g["theta0"], g["z"], g["u"])
+    _check_traces(res, g)
+    np.testing.assert_allclose(res["scaling_hist"], g["scaling_hist"], rtol=1e-13)
+
+
 def test_g3_loglike_kats(golden):
     g = golden("g3_loglike_kats")
     data, X = g["data"], g["X"]

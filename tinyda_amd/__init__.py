@@ -21,8 +21,8 @@ from .records import Link  # noqa: F401
 from .models import BatchedModel, DeviceModel, LinearModel, Rosenbrock  # noqa: F401
 from .target import Posterior  # noqa: F401
 from .proposals import (  # noqa: F401
-    DREAM, DREAMZ, AdaptiveMetropolis, CrankNicolson, GaussianRandomWalk, IndependenceSampler, OperatorWeightedCrankNicolson,
-    Proposal)
+    DREAM, DREAMZ, MALA, AdaptiveMetropolis, CrankNicolson, GaussianRandomWalk, IndependenceSampler,
+    OperatorWeightedCrankNicolson, Proposal)
 from .records import DeviceChain  # noqa: F401
 from .api import sample  # noqa: F401
 from .moments import RecursiveSampleMoments, ZeroMeanRecursiveSampleMoments  # noqa: F401

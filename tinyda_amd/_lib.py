@@ -13,7 +13,7 @@ TDA_OK = 0
 TDA_ERR_CALLBACK = -6
 NOISE_ISO, NOISE_DIAG, NOISE_DENSE, NOISE_ADAPTIVE = 0, 1, 2, 3
 AEM_NONE, AEM_STATE_INDEPENDENT, AEM_STATE_DEPENDENT = 0, 1, 2
-PROP_GRW, PROP_PCN, PROP_AM, PROP_DREAMZ, PROP_INDEPENDENCE, PROP_OWCN = 0, 1, 2, 3, 4, 5
+PROP_GRW, PROP_PCN, PROP_AM, PROP_DREAMZ, PROP_INDEPENDENCE, PROP_OWCN, PROP_MALA = 0, 1, 2, 3, 4, 5, 6
 
 
 class EngineError(RuntimeError):

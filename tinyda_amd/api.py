@@ -11,12 +11,12 @@ import scipy.stats as stats
 
 from . import _lib
 from .hostloop import Chain
-from .proposals import (DREAM, DREAMZ, AdaptiveMetropolis, CrankNicolson, GaussianRandomWalk, IndependenceSampler,
+from .proposals import (DREAM, DREAMZ, MALA, AdaptiveMetropolis, CrankNicolson, GaussianRandomWalk, IndependenceSampler,
                         OperatorWeightedCrankNicolson)
 from .records import DeviceChain
 
 _DEVICE_PROPOSALS = (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis, DREAMZ, DREAM, IndependenceSampler,
-                     OperatorWeightedCrankNicolson)
+                     OperatorWeightedCrankNicolson, MALA)
 
 
 MAX_LEVELS = 4
@@ -51,6 +51,9 @@ def _device_plan(posteriors, proposal):
         if len(posteriors) != 1 or isinstance(proposal, DREAMZ) or low["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG):
             return None
         if np.count_nonzero(low["prior_cov"] - np.diag(np.diag(low["prior_cov"]))):
+            return None
+    if isinstance(proposal, MALA):  # exact gradient of a linear-Gaussian posterior: single level, linear model, Gaussian prior
+        if len(posteriors) != 1 or "source" in lows[0] or "batched" in lows[0] or "rosenbrock" in lows[0] or "prior_joint" in lows[0]:
             return None
     if isinstance(proposal, OperatorWeightedCrankNicolson):  # fixed operators, single level, linear model
         if (len(posteriors) != 1 or proposal._lowering() is None or "source" in lows[0] or "batched" in lows[0] or "rosenbrock" in lows[0]

@@ -161,6 +161,7 @@ struct Level {
   DevBuf<double> Apk, ytil, w, Ppk;
   // adaptive error model: plain row-major copies for the wave-per-chain kernel
   std::vector<double> A_h, ytil_h, data_h, cov_h;
+  std::vector<double> w_h, Pinv_h;  // diagonal weights 1 / sigma_i^2, dense Sigma_e^-1 [m][m] (MALA's gradient operator)
   DevBuf<double> A_rm, ytil64, data64, cov64;  // error-model copies, row stride em_ld
   int em_ld = 0;                               // 64 (m <= 64) or 128 (m <= 128); 0: level too large for an error model
 };
@@ -199,6 +200,7 @@ struct tda_engine {
   std::vector<double> prop_C_h, q_mean_h;  // q_mean_h: independence sampler
   std::vector<double> ow_state_h, ow_noise_h;  // OperatorWeightedCrankNicolson operators [d][d]
   DevBuf<double> ow_SopT;                      // state operator, transposed and padded: [DP][DP], SopT[j][i] = S[i][j]
+  DevBuf<double> mala_H, mala_c, mala_grad;    // MALA: H [DP][DP] (symmetric), c [DP], grad log post of the current states [NP][DP]
   DevBuf<double> q_mean_d, lq, qzblk, qzblk2[2];
   double am_sd = 1.0;
   bool L_shared = true;
@@ -301,7 +303,8 @@ void launch_steps(const StepArgs& a, int64_t tiles, size_t lds, hipStream_t st) 
   const bool eight = g_steps_waves == 8 && a.lv.noise_kind != TDA_NOISE_DENSE;
   const bool ind = a.prop_kind == TDA_PROP_INDEPENDENCE;
   const bool ow = a.prop_kind == TDA_PROP_OWCN && a.mode == MODE_STEP;  // + current-state tile and the state operator in LDS
-  if (ow) lds += ((size_t)16 * (DPAD + 2) + (size_t)DPAD * DPAD) * sizeof(double);
+  const bool ma = a.prop_kind == TDA_PROP_MALA && a.mode == MODE_STEP;  // + the gradient operator and 32 transition-density slots
+  if (ow || ma) lds += ((size_t)16 * (DPAD + 2) + (size_t)DPAD * DPAD) * sizeof(double);
   auto go = [&](auto kern, unsigned threads, size_t bytes) {
     if (bytes > 64 * 1024)  // beyond the default dynamic-LDS window (gfx950 has 160 KiB per CU)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -310,11 +313,13 @@ void launch_steps(const StepArgs& a, int64_t tiles, size_t lds, hipStream_t st) 
   if (eight) {
     const size_t l8 = lds + 2 * 64 * sizeof(double);  // two more [4][16] reduction slabs
     if (ind) go(&k_mh_steps<DPAD, 8, true>, 512, l8);
-    else if (ow) go(&k_mh_steps<DPAD, 8, false, true>, 512, l8);
+    else if (ow) go(&k_mh_steps<DPAD, 8, false, 1>, 512, l8);
+    else if (ma) go(&k_mh_steps<DPAD, 8, false, 2>, 512, l8);
     else go(&k_mh_steps<DPAD, 8, false>, 512, l8);
   } else {
     if (ind) go(&k_mh_steps<DPAD, 4, true>, 256, lds);
-    else if (ow) go(&k_mh_steps<DPAD, 4, false, true>, 256, lds);
+    else if (ow) go(&k_mh_steps<DPAD, 4, false, 1>, 256, lds);
+    else if (ma) go(&k_mh_steps<DPAD, 4, false, 2>, 256, lds);
     else go(&k_mh_steps<DPAD, 4, false>, 256, lds);
   }
 }
@@ -782,6 +787,7 @@ int tda_engine_set_level(tda_engine* e, int level, int m, const double* A, const
       }
     int ncb2 = 0;
     pack_fragments(P.data(), m, m, lv.m_pad, Ppk, ncb2);
+    lv.Pinv_h = P;
     lv.var = 1.0;
   } else if (noise_kind == TDA_NOISE_ISO) {
     if (!(noise[0] > 0.0)) return fail(TDA_ERR_NUMERIC, "noise variance must be positive");
@@ -792,6 +798,7 @@ int tda_engine_set_level(tda_engine* e, int level, int m, const double* A, const
       if (!(noise[i] > 0.0)) return fail(TDA_ERR_NUMERIC, "noise variance must be positive");
       w[i] = 1.0 / noise[i];
     }
+    lv.w_h.assign(w.begin(), w.begin() + m);
     lv.var = 1.0;
   }
   const size_t lds = ((size_t)16 * (e->DP + 2) + 256 + 2 * e->DP + (size_t)lv.m_pad * 2 + 64 +
@@ -828,8 +835,10 @@ int tda_engine_set_level(tda_engine* e, int level, int m, const double* A, const
 int tda_engine_set_proposal(tda_engine* e, const tda_proposal_params* p) {
   if (!e || !p) return fail(TDA_ERR_INVALID, "null argument");
   if (p->struct_size != sizeof(tda_proposal_params)) return fail(TDA_ERR_INVALID, "tda_proposal_params.struct_size mismatch");
-  const bool indep = p->kind == TDA_PROP_INDEPENDENCE, owcn = p->kind == TDA_PROP_OWCN;
-  if ((p->kind < TDA_PROP_GRW || p->kind > TDA_PROP_AM) && !indep && !owcn) return fail(TDA_ERR_UNSUPPORTED, "proposal kind %d", p->kind);
+  const bool indep = p->kind == TDA_PROP_INDEPENDENCE, owcn = p->kind == TDA_PROP_OWCN, mala = p->kind == TDA_PROP_MALA;
+  if ((p->kind < TDA_PROP_GRW || p->kind > TDA_PROP_AM) && !indep && !owcn && !mala) return fail(TDA_ERR_UNSUPPORTED, "proposal kind %d", p->kind);
+  if (mala && e->nlev != 1) return fail(TDA_ERR_UNSUPPORTED, "MALA is lowered for single-level chains only");
+  if (mala && !(p->scaling > 0.0)) return fail(TDA_ERR_INVALID, "MALA: scaling must be positive");
   if (owcn && e->nlev != 1) return fail(TDA_ERR_UNSUPPORTED, "the operator-weighted pCN proposal is lowered for single-level chains only");
   if (owcn && p->adaptive) return fail(TDA_ERR_UNSUPPORTED, "operator-weighted pCN: adaptive scaling (per-chain operators) is not lowered");
   if ((p->kind == TDA_PROP_GRW || p->kind == TDA_PROP_AM || indep) && !p->C) return fail(TDA_ERR_INVALID, "proposal covariance missing");
@@ -1173,6 +1182,7 @@ void enumerate_state(tda_engine* e, std::vector<StateItem>& v) {
   dev(e->am_mu);
   dev(e->am_sigma);
   dev(e->lq);
+  dev(e->mala_grad);
   if (e->nlev > 1) {
     host(e->cnt, sizeof e->cnt);
     host(e->done, sizeof e->done);
@@ -1386,6 +1396,11 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
     if (e->levels[0].model != MODEL_LINEAR) return fail(TDA_ERR_UNSUPPORTED, "operator-weighted pCN is lowered for linear forward models only");
     if (e->prior_bounded) return fail(TDA_ERR_UNSUPPORTED, "operator-weighted pCN needs a Gaussian prior");
   }
+  if (e->prop_set && !e->is_dreamz && e->pp.kind == TDA_PROP_MALA) {
+    if (e->levels[0].model != MODEL_LINEAR) return fail(TDA_ERR_UNSUPPORTED, "MALA is lowered for linear forward models only (exact gradient)");
+    if (e->prior_bounded) return fail(TDA_ERR_UNSUPPORTED, "MALA needs a Gaussian prior");
+    if (e->levels[0].noise_kind == TDA_NOISE_ADAPTIVE) return fail(TDA_ERR_UNSUPPORTED, "MALA: adaptive likelihoods are not lowered");
+  }
   if (e->prior_bounded) {  // JointPrior with uniform components
     if (e->nlev != 1 || e->is_dreamz) return fail(TDA_ERR_UNSUPPORTED, "priors with uniform components: single-level GRW / AM only");
     if (e->pp.kind == TDA_PROP_PCN) return fail(TDA_ERR_UNSUPPORTED, "pCN needs a Gaussian prior");
@@ -1533,11 +1548,55 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
     return TDA_OK;
   }
   std::vector<double> L;
-  const bool owcn = e->pp.kind == TDA_PROP_OWCN;
+  const bool owcn = e->pp.kind == TDA_PROP_OWCN, mala = e->pp.kind == TDA_PROP_MALA;
   const double* Cuse = (e->pp.kind == TDA_PROP_PCN || owcn) ? e->prior_cov_h.data() : e->prop_C_h.data();  // proposal.py:336-341
-  if (!cholesky_host(Cuse, d, L)) return fail(TDA_ERR_NUMERIC, "proposal covariance is not positive definite");
+  if (!mala && !cholesky_host(Cuse, d, L)) return fail(TDA_ERR_NUMERIC, "proposal covariance is not positive definite");
   std::vector<double> Lk((size_t)DP * DP, 0.0);
-  if (owcn) {
+  if (mala) {
+    // np.random.normal(size = d) (proposal.py:955): unit factor.  Gradient of the log-posterior of the linear-Gaussian
+    // target (proposal.py:986-998; utils.py:273-287) in closed form: grad = c - H theta with
+    //   H = Sigma_prior^-1 + A^T Sigma_e^-1 A,   c = Sigma_prior^-1 mu + A^T Sigma_e^-1 (data - b)
+    for (int j = 0; j < d; ++j) Lk[(size_t)j * DP + j] = 1.0;
+    const Level& lv0 = e->levels[0];
+    const int m = lv0.m;
+    std::vector<double> Wp, H((size_t)DP * DP, 0.0), cv(DP, 0.0);
+    tri_inverse_host(e->prior_L_h, d, Wp);
+    for (int i = 0; i < d; ++i)
+      for (int j = 0; j <= i; ++j) {
+        double sacc = 0.0;
+        for (int k = i; k < d; ++k) sacc += Wp[(size_t)k * d + i] * Wp[(size_t)k * d + j];
+        H[(size_t)i * DP + j] = H[(size_t)j * DP + i] = sacc;
+      }
+    for (int i = 0; i < d; ++i) {
+      double sacc = 0.0;
+      for (int j = 0; j < d; ++j) sacc += H[(size_t)i * DP + j] * e->prior_mean_h[j];
+      cv[i] = sacc;
+    }
+    // WA = Sigma_e^-1 A  [m][d]
+    std::vector<double> WA((size_t)m * d, 0.0);
+    if (lv0.noise_kind == TDA_NOISE_DENSE) {
+      for (int o = 0; o < m; ++o)
+        for (int q = 0; q < m; ++q) {
+          const double pv = lv0.Pinv_h[(size_t)o * m + q];
+          for (int j = 0; j < d; ++j) WA[(size_t)o * d + j] += pv * lv0.A_h[(size_t)q * d + j];
+        }
+    } else {
+      for (int o = 0; o < m; ++o) {
+        const double wv = lv0.noise_kind == TDA_NOISE_DIAG ? lv0.w_h[o] : 1.0 / lv0.var;
+        for (int j = 0; j < d; ++j) WA[(size_t)o * d + j] = wv * lv0.A_h[(size_t)o * d + j];
+      }
+    }
+    for (int o = 0; o < m; ++o)
+      for (int i = 0; i < d; ++i) {
+        const double ai = lv0.A_h[(size_t)o * d + i];
+        for (int j = 0; j < d; ++j) H[(size_t)i * DP + j] += ai * WA[(size_t)o * d + j];
+      }
+    for (int o = 0; o < m; ++o)
+      for (int j = 0; j < d; ++j) cv[j] += WA[(size_t)o * d + j] * lv0.ytil_h[o];
+    if ((rc = e->mala_H.upload(H))) return rc;
+    if ((rc = e->mala_c.upload(cv))) return rc;
+    if ((rc = e->mala_grad.alloc((size_t)NP * DP))) return rc;
+  } else if (owcn) {
     // increments = noise_operator N(0, C_prior) = (noise_operator chol(C_prior)) z (proposal.py:596-598): a full factor
     for (int j = 0; j < d; ++j)
       for (int k = 0; k < d; ++k) {
@@ -1587,6 +1646,12 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
   e->exp_pos = 0;
   // initial links (chain.py:70)
   if ((rc = launch_eval(e, 0, e->theta.p, e->lp.p, e->ll.p))) return rc;
+  if (mala) {
+    const int64_t nt = NP * DP;
+    hipLaunchKernelGGL(k_mala_grad0, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, e->stream, NP, DP, e->mala_H.p, e->mala_c.p,
+                       e->theta.p, e->mala_grad.p);
+    HIP_TRY(hipGetLastError());
+  }
   if (e->nlev > 1) {
     // every level starts from theta0 (chain.py:253-261; proposal.py:1379); S[j][q] = level j's densities there
     if (!e->sub_set) return fail(TDA_ERR_STATE, "set_subchains must precede init for n_levels > 1");
@@ -1984,7 +2049,9 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     sa.inc = e->inc.p;
     sa.u = u_blk;
     sa.logu = lu_blk;
-    sa.SopT = e->pp.kind == TDA_PROP_OWCN ? e->ow_SopT.p : nullptr;
+    sa.SopT = e->pp.kind == TDA_PROP_OWCN ? e->ow_SopT.p : (e->pp.kind == TDA_PROP_MALA ? e->mala_H.p : nullptr);
+    sa.cvec = e->pp.kind == TDA_PROP_MALA ? e->mala_c.p : nullptr;
+    sa.grad = e->pp.kind == TDA_PROP_MALA ? e->mala_grad.p : nullptr;
     if (e->pp.kind == TDA_PROP_INDEPENDENCE) {
       if (lv.model == MODEL_USER) return fail(TDA_ERR_UNSUPPORTED, "the independence sampler is not lowered for source-defined models");
       sa.q_mean = e->q_mean_d.p;
@@ -2063,6 +2130,7 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
       aa.period = period;
       aa.gamma_pow = std::pow(e->pp.gamma, -(double)e->k_adapt);
       aa.sd = e->am_sd;
+      aa.alpha_star = e->pp.kind == TDA_PROP_MALA ? 0.57 : 0.24;  // proposal.py:899 / :169
       aa.eps = e->pp.epsilon;
       aa.rec_params = sa.rec_params;
       aa.am_mu = e->am_mu.p;
@@ -2346,6 +2414,7 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
       aa.period = period;
       aa.gamma_pow = std::pow(e->pp.gamma, -(double)e->k_adapt);
       aa.sd = e->am_sd;
+      aa.alpha_star = e->pp.kind == TDA_PROP_MALA ? 0.57 : 0.24;  // proposal.py:899 / :169
       aa.eps = e->pp.epsilon;
       aa.rec_params = ma.rec_params[0];
       aa.am_mu = e->am_mu.p;

@@ -81,6 +81,9 @@ struct StepArgs {
   double* lq;            // [NP]    the same for the current state
   // operator-weighted pCN (prop_kind 5): theta' = S theta + inc
   const double* SopT;    // [DPAD][DPAD] transposed state operator: SopT[j][i] = S[i][j]
+  // MALA (prop_kind 6): grad log post = cvec - H theta with H (symmetric) in SopT; theta' = theta + s^2/2 grad + s inc
+  const double* cvec;    // [DPAD]
+  double* grad;          // [NP][DPAD] gradient at the current state (chain state, like theta)
   // records, layout of tda_outputs (may be null)
   double* rec_params;
   double* rec_stats;
@@ -120,6 +123,7 @@ struct AdaptArgs {
   int period;
   double gamma_pow;  // gamma ** -k  (proposal.py:240)
   double sd, eps;
+  double alpha_star;  // target acceptance of the scaling adaptation: 0.24 (proposal.py:169), MALA 0.57 (:899)
   const double* rec_params;  // [S][N][d] states recorded by k_mh_steps
   double* am_mu;             // [NP][DPAD]
   double* am_sigma;          // [NP][am_tiles][4][64]: lower 16x16 tiles in MFMA C/D layout (see k_adapt)
@@ -432,11 +436,17 @@ __host__ __device__ constexpr int steps_lds_doubles(int m_pad, bool diag, int pr
 // ------------------------------------------------------------------------------------------------
 // IND = IndependenceSampler proposals (a template parameter: as a run-time flag it costs the random-walk path 16 registers
 // and 3 %)
-// OW = OperatorWeightedCrankNicolson proposals (proposal.py:592-598): theta' = S theta + inc needs the whole current
+// PX = 1: OperatorWeightedCrankNicolson proposals (proposal.py:592-598): theta' = S theta + inc needs the whole current
 // state of a chain in every thread of its group, so the variant keeps a current-state tile and S^T in LDS and pays one
 // more barrier per step; a template parameter for the same reason as IND.
-template <int DPAD, int NW, bool IND = false, bool OW = false>
+// PX = 2: MALA (proposal.py:945-984).  The target is linear-Gaussian, so grad log post(theta) = c - H theta with the
+// d x d matrix H = Sigma_prior^-1 + A^T Sigma_e^-1 A built once by the host: the gradient at the proposal is one more
+// d x d product from LDS (the operator sits where S^T does) instead of a second pass over the observations; the
+// gradient at the current state is chain state.  The two transition densities reach the lane-mapped accept test
+// through 32 LDS slots.
+template <int DPAD, int NW, bool IND = false, int PX = 0>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) {
+  constexpr bool OW = PX == 1, MA = PX == 2;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int KS = DPAD / 4;
   constexpr int LDP = DPAD + 2;  // row stride: conflict-free ds_read_b64 fragment gather
@@ -457,8 +467,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
   double* s_w = s_y + a.lv.m_pad;
   double* s_py = s_w + (diag ? a.lv.m_pad : 0);
   double* s_R = s_py + (prior_dense ? a.pr.ncb * 16 : 0);
-  double* s_cur = s_R + (dense ? 16 * RS : 0);  // OW: current states [16][LDP]
-  double* s_S = s_cur + 16 * LDP;               // OW: S^T [DPAD][DPAD]
+  double* s_cur = s_R + (dense ? 16 * RS : 0);  // OW: current states [16][LDP]; MALA: [0..32) the transition densities
+  double* s_S = s_cur + 16 * LDP;               // OW: S^T [DPAD][DPAD]; MALA: H
 
   // the step kernel is the critical path: kernels that share its SIMDs (k_rng on the second stream) only get the
   // issue slots it leaves empty
@@ -518,9 +528,18 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
     if (has_logu) lunext = a.logu[gcl];
     if (is_ind) qznext = a.qz[gcl];
   }
-  if constexpr (OW) {
+  double gcur[EPT], gprp[EPT], cv[EPT];  // MALA: gradient at the current state / at the proposal, constant term
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    gcur[e] = (MA && active) ? a.grad[gct * DPAD + q * EPT + e] : 0.0;
+    cv[e] = (MA && active) ? a.cvec[q * EPT + e] : 0.0;
+    gprp[e] = 0.0;
+  }
+  const double sig_t = scal_t, half_s2 = 0.5 * sig_t * sig_t;  // thread-mapped chain: 0.5 * scaling**2 (proposal.py:953)
+  const double sig_l = MA ? a.scaling[gcl] : 1.0;              // lane-mapped chain
+  if constexpr (OW || MA) {
     for (int i = tid; i < DPAD * DPAD; i += NT) s_S[i] = a.SopT[i];
-    if (active) {
+    if (OW && active) {
 #pragma unroll
       for (int e = 0; e < EPT; ++e) s_cur[c * LDP + q * EPT + e] = cur[e];
     }
@@ -562,6 +581,14 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
           s_prop[c * LDP + q * EPT + e] = prp[e];
         }
       }
+    } else if constexpr (MA) {
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          prp[e] = (cur[e] + half_s2 * gcur[e]) + sig_t * xin[e];  // proposal.py:951-956
+          s_prop[c * LDP + q * EPT + e] = prp[e];
+        }
+      }
     } else if (active) {
 #pragma unroll
       for (int e = 0; e < EPT; ++e) {
@@ -587,6 +614,39 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
     TDA_STAMP(1);
     __syncthreads();
     TDA_STAMP(2);
+
+    if constexpr (MA) {
+      // gradient at the proposal and the two transition densities (proposal.py:958-984), thread-mapped:
+      //   q_x_y = -|theta - theta' - s^2/2 grad'|^2 / (2 s^2),  q_y_x = -|theta' - theta - s^2/2 grad|^2 / (2 s^2)
+      double qa = 0.0, qb = 0.0;
+      if (active) {
+        double hg[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) hg[e] = 0.0;
+        for (int j = 0; j < DPAD; ++j) {
+          const double tj = s_prop[c * LDP + j];
+#pragma unroll
+          for (int e = 0; e < EPT; ++e) hg[e] = fma(s_S[j * DPAD + q * EPT + e], tj, hg[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          gprp[e] = cv[e] - hg[e];
+          const double da = (cur[e] - prp[e]) - half_s2 * gprp[e];
+          const double db = (prp[e] - cur[e]) - half_s2 * gcur[e];
+          qa += da * da;
+          qb += db * db;
+        }
+      }
+#pragma unroll
+      for (int off = TPC / 2; off >= 1; off >>= 1) {  // the TPC threads of a chain are consecutive lanes of one wave
+        qa += __shfl_xor(qa, off);
+        qb += __shfl_xor(qb, off);
+      }
+      if (q == 0) {
+        s_cur[c] = qa;
+        s_cur[16 + c] = qb;
+      }
+    }
 
     // ---- gather theta' into MFMA B-operand fragments ----
     double th[KS];
@@ -675,7 +735,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
     if (is_eval) {
       acc = true;
     } else {
-      const double delta = is_pcn ? ll_n - ll : (is_ind ? ((post_n - (lp + ll)) + lq) - qzs : post_n - (lp + ll));
+      double delta = is_pcn ? ll_n - ll : (is_ind ? ((post_n - (lp + ll)) + lq) - qzs : post_n - (lp + ll));
+      if constexpr (MA) {
+        const double kq = -0.5 / (sig_l * sig_l);
+        delta = (delta + kq * s_cur[lc]) - kq * s_cur[16 + lc];  // exp(post' - post + q_x_y - q_y_x)
+      }
       if (has_logu && (fabs(lu - delta) > 1e-9 || delta != delta)) {
         acc = (post_n == post_n) && (lu < delta);
       } else {
@@ -706,6 +770,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
       for (int e = 0; e < EPT; ++e) {
         cur[e] = accf ? prp[e] : cur[e];
         if constexpr (OW) s_cur[c * LDP + q * EPT + e] = cur[e];
+        if constexpr (MA) gcur[e] = accf ? gprp[e] : gcur[e];
         const int j = q * EPT + e;
         if (!is_eval && a.rec_params && gct < a.N && j < a.d)
           a.rec_params[((size_t)s * a.N + gct) * a.d + j] = cur[e];
@@ -717,7 +782,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
 
   if (active) {
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) a.theta[gct * DPAD + q * EPT + e] = cur[e];
+    for (int e = 0; e < EPT; ++e) {
+      a.theta[gct * DPAD + q * EPT + e] = cur[e];
+      if constexpr (MA) a.grad[gct * DPAD + q * EPT + e] = gcur[e];
+    }
   }
   if (wave == 0 && lane < 16) {
     a.lp[gcl] = lp;
@@ -725,6 +793,18 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
     if (is_ind && !is_eval) a.lq[gcl] = lq;
     if (!is_eval && a.acc_count) a.acc_count[gcl] += nacc;
   }
+}
+
+// MALA: gradient of the log-posterior at the initial states, grad = c - H theta (thread = (chain, component))
+__global__ void k_mala_grad0(int64_t NP, int DP, const double* __restrict__ H, const double* __restrict__ cvec,
+                             const double* __restrict__ theta, double* __restrict__ grad) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= NP * DP) return;
+  const int64_t c = t / DP;
+  const int i = (int)(t % DP);
+  double hg = 0.0;
+  for (int j = 0; j < DP; ++j) hg = fma(H[(size_t)j * DP + i], theta[c * DP + j], hg);
+  grad[t] = cvec[i] - hg;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1005,7 +1085,7 @@ __device__ __forceinline__ void adapt_scaling(const AdaptArgs& a, int64_t c, int
       hits = a.acc_count[c];
     }
     const double rate = (double)hits / (double)a.period;  // np.mean(accepted[-period:])
-    a.scaling[c] = exp(log(a.scaling[c]) + a.gamma_pow * (rate - 0.24));
+    a.scaling[c] = exp(log(a.scaling[c]) + a.gamma_pow * (rate - a.alpha_star));
   }
   if (lane == 0) a.acc_count[c] = 0;
 }

@@ -21,6 +21,10 @@ class LinearModel:
         out = self.A @ np.asarray(parameters, dtype=np.float64)
         return out if self.b is None else out + self.b
 
+    def gradient(self, parameters, sensitivity):
+        """J^T s, the method MALA looks for on a model (proposal.py:938-943, :996-998)."""
+        return self.A.T @ np.asarray(sensitivity, dtype=np.float64)
+
 
 class Rosenbrock:
     """The reference's Rosenbrock example (examples/MALA Rosenbrock.ipynb) as a d-parameter chain with one

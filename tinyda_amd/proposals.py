@@ -193,6 +193,70 @@ class OperatorWeightedCrankNicolson(CrankNicolson):
                     noise_operator=np.ascontiguousarray(self.noise_operator, dtype=np.float64))
 
 
+def _grad_log_prior(x, prior):
+    """utils.py:273-280 for a frozen scipy multivariate normal (anything with mean / cov); finite differences otherwise."""
+    cov = getattr(prior, "cov", None)
+    if cov is None and hasattr(prior, "cov_object"):
+        cov = prior.cov_object.covariance
+    if cov is not None and hasattr(prior, "mean"):
+        return np.dot(np.linalg.inv(np.atleast_2d(cov)), (prior.mean - x))
+    from scipy.optimize import approx_fprime
+
+    return approx_fprime(x, prior.logpdf)
+
+
+class MALA(GaussianRandomWalk):
+    """Metropolis-adjusted Langevin: theta' = theta + scaling^2/2 grad log post(theta) + scaling N(0, I), acceptance with
+    the two transition densities (proposal.py:861-1005).  The gradient is exact when the model has a
+    `gradient(parameters, sensitivity)` method and the likelihood a `grad_loglike`, finite differences of
+    `posterior.logpdf` otherwise.  On the device path (linear model, Gaussian prior) the gradient is c - H theta with
+    H = Sigma_prior^-1 + A^T Sigma_e^-1 A precomputed once: a d x d product per step instead of a second pass over the
+    observations."""
+
+    is_symmetric = False
+    alpha_star = 0.57
+
+    def __init__(self, scaling=0.1, adaptive=False, gamma=1.01, period=100):
+        self._init_scaling(scaling, adaptive, gamma, period)
+
+    def setup_proposal(self, **kwargs):
+        self.posterior = kwargs["posterior"]
+        self.d = np.asarray(self.posterior.prior.rvs()).size
+        exact = callable(getattr(self.posterior.model, "gradient", None)) and hasattr(self.posterior.likelihood, "grad_loglike")
+        self.compute_gradient = self._compute_gradient if exact else self._compute_gradient_approx
+
+    def _compute_gradient(self, link):
+        sens = self.posterior.likelihood.grad_loglike(link.model_output)
+        return _grad_log_prior(link.parameters, self.posterior.prior) + self.posterior.model.gradient(link.parameters, sens)
+
+    def _compute_gradient_approx(self, link):
+        from scipy.optimize import approx_fprime
+
+        return approx_fprime(link.parameters, self.posterior.logpdf)
+
+    def make_proposal(self, link):
+        if not hasattr(link, "gradient"):
+            link.gradient = self.compute_gradient(link)
+        return link.parameters + 0.5 * self.scaling ** 2 * link.gradient + self.scaling * np.random.standard_normal(self.d)
+
+    def get_acceptance(self, proposal_link, previous_link):
+        if np.isnan(proposal_link.posterior):
+            return 0
+        if not hasattr(proposal_link, "gradient"):
+            proposal_link.gradient = self.compute_gradient(proposal_link)
+        q_x_y = self.get_q(previous_link, proposal_link)
+        q_y_x = self.get_q(proposal_link, previous_link)
+        return np.exp(proposal_link.posterior - previous_link.posterior + q_x_y - q_y_x)
+
+    def get_q(self, x_link, y_link):
+        return -0.5 / self.scaling ** 2 * np.linalg.norm(
+            x_link.parameters - y_link.parameters - 0.5 * self.scaling ** 2 * y_link.gradient) ** 2
+
+    def _lowering(self):
+        return dict(kind=_lib.PROP_MALA, C_=None, scaling=float(self.scaling), adaptive=bool(self.adaptive),
+                    gamma=float(self.gamma), period=int(self.period))
+
+
 class AdaptiveMetropolis(GaussianRandomWalk):
     """Haario et al. (2001): proposal covariance <- running sample covariance every `period` adapt calls
     once t >= t0 (proposal.py:372-512).

@@ -11,7 +11,7 @@ class Link:
     """parameters, log-prior, model output, log-likelihood, optional quantity of interest; `posterior` is the sum of a
     *normalised* log-prior and an *unnormalised* Gaussian log-likelihood, exactly as the reference combines them."""
 
-    __slots__ = _FIELDS + ("posterior",)
+    __slots__ = _FIELDS + ("posterior", "gradient")  # `gradient` is attached lazily by MALA (proposal.py:948-949)
 
     def __init__(self, parameters, prior, model_output, likelihood, qoi=None):
         for name, value in zip(_FIELDS, (parameters, prior, model_output, likelihood, qoi)):
