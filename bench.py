@@ -217,6 +217,27 @@ def main():
                                               "evals_per_sec_per_gpu": N * Ks / dtp, "steps": Ks, "seconds": dtp,
                                               "acceptance_rate_second_half": float(acc[Ks // 2:Ks].float().mean().item())}
             e3.close()
+        if extras and not args.no_ess:
+            # the same target and start (theta0 ~ prior, same seed) sampled with the reference's MALA proposal
+            # (proposal.py:861-1005), adaptive scaling: what the choice of proposal does to ESS/s on this engine.  Not the headline.
+            e5 = Engine(N, D, seed=2026, device=local_rank, chain_offset=rank * N)
+            e5.set_prior(np.zeros(D), np.eye(D))
+            e5.set_level(0, A, y, 0, SIGMA ** 2)
+            e5.set_proposal(6, None, scaling=0.02, adaptive=True, gamma=1.01, period=50)
+            e5.init(None)
+            if W > 0:
+                e5.run(W, params[:W], stats[:W], acc[:W])
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            e5.run(K, params[:K], stats[:K], acc[:K], sync=True)
+            torch.cuda.synchronize()
+            dtm = time.perf_counter() - t4
+            dm = diagnostics.ess_rhat_device(params[K // 2:K], device=local_rank)
+            out["mala_same_target"] = {"evals_per_sec_per_gpu": N * K / dtm, "ess_per_sec_per_gpu": float(np.nanmin(dm["ess"])) / dtm,
+                                       "min_bulk_ess": float(np.nanmin(dm["ess"])), "max_rhat": float(np.nanmax(dm["rhat"])),
+                                       "acceptance_rate_second_half": float(acc[K // 2:K].float().mean().item()), "seconds": dtm,
+                                       "proposal": "MALA(scaling=0.02, adaptive=True, period=50), exact gradient c - H theta on the device"}
+            e5.close()
         # extension, not the headline: AdaptiveMetropolis(block_moments=True) -- the running covariance as one rank-S update
         # per block on the matrix cores instead of the reference's elementwise recursion (parity 1e-8 instead of 1e-10)
         if extras:

@@ -71,6 +71,36 @@ def run_c5_aem(N=4096, d=64, m=64, n_fine=20):
     e.close()
 
 
+def run_mala(N=4096, d=64, m=1024, T=2000):
+    """C2a target (d = 64, m = 1024, iso noise, prior N(0, I), theta0 ~ prior) sampled with MALA, adaptive scaling: evals/s and
+    bulk ESS/s of the second half computed on the device, next to AdaptiveMetropolis on the same target."""
+    from tinyda_amd import summaries
+    rng = np.random.default_rng(1)
+    A = rng.standard_normal((m, d)) / 8
+    y = A @ rng.standard_normal(d) + 0.1 * rng.standard_normal(m)
+    for name, prop in (("MALA(scaling=0.02, adaptive, period=50)", dict(kind=6, scaling=0.02, adaptive=True, gamma=1.01, period=50)),
+                       ("AdaptiveMetropolis(C0=1e-4 I, t0=100, period=100)", dict(kind=2, C_=1e-4 * np.eye(d), t0=100, period=100))):
+        e = Engine(N, d, seed=1)
+        e.set_prior(np.zeros(d), np.eye(d)); e.set_level(0, A, y, 0, 0.01)
+        e.set_proposal(**prop)
+        e.init(None)
+        p = torch.empty((T, N, d), dtype=torch.float64, device="cuda"); s = torch.empty((T, N, 3), dtype=torch.float64, device="cuda")
+        a = torch.empty((T, N), dtype=torch.uint8, device="cuda")
+        e.run(200, p[:200], s[:200], a[:200])
+        e.set_profiling(True)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        e.run(T, p, s, a)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        pr = e.profile()
+        di = summaries.ess_rhat_device(p, burnin=T // 2)
+        ess, rhat = di["ess"], di["rhat"]
+        print(json.dumps(dict(config="C2a target, " + name, chains=N, steps=T, evals_per_s=N * T / dt,
+                              steps_kernel_ns_per_eval=pr["ms_steps"] * 1e6 / (N * T), acceptance_second_half=float(a[T // 2:].float().mean().item()),
+                              min_bulk_ess=float(np.min(ess)), ess_per_s=float(np.min(ess)) / dt, max_rhat=float(np.max(rhat)),
+                              scaling_mean=float(np.mean(e.proposal_state()["scaling"])))))
+        e.close()
+
+
 def run_c2b(N=4096, d=64, m=1024, T=300):
     """C2b: dense data covariance (DefaultGaussianLogLike), AM, 4096 chains."""
     rng = np.random.default_rng(1)
@@ -123,6 +153,9 @@ def run_c4(N=8192, d=32, T=400, M0=320, K=16):
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "c5aem":  # python tools/bench_configs.py c5aem 128 [n_fine]
         run_c5_aem(m=int(sys.argv[2]), n_fine=int(sys.argv[3]) if len(sys.argv) > 3 else 20)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "mala":
+        run_mala()
         sys.exit(0)
     run_c2b()
     run_c5_aem()
