@@ -2746,6 +2746,7 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
       da.eps_export = (e->exp_dev ? e->z_exp : e->z_exp_d.p) + (size_t)e->exp_pos * N * d;
       da.u_export = (e->exp_dev ? e->u_exp : e->u_exp_d.p) + (size_t)e->exp_pos * N;
     }
+    da.arch_shared = sh ? e->arch.p : nullptr;
     {
       ScopedTimer tm(e, 0);
       DISPATCH_DPAD(DP, launch_dz_draw<DPAD>(da, e->stream));
@@ -2753,10 +2754,14 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     DreamStepArgs sa{};
     fill_dreamz_step_args(e, sa);
     sa.S = (int)S;
+    sa.jump_ready = sh ? 1 : 0;
     sa.rec_params = p_dev ? o_params + (size_t)done * N * d : (o_params ? e->rec_params.p : nullptr);
     sa.rec_stats = s_dev ? o_stats + (size_t)done * N * 3 : (o_stats ? e->rec_stats.p : nullptr);
     sa.rec_acc = a_dev ? o_acc + (size_t)done * N : (o_acc ? e->rec_acc.p : nullptr);
-    sa.blk_states = sh ? e->blk_states.p : nullptr;
+    // single process, no padding chains: the block's states ARE the next archive rows in canonical order (step-major,
+    // chain minor), the kernel appends them in place (the jumps of this block were gathered before it started)
+    const bool direct = sh && e->auto_append && N == NP && e->pending_steps == 0;
+    sa.blk_states = sh ? (direct ? e->arch.p + (size_t)e->arch_rows * DP : e->blk_states.p) : nullptr;
     {
       ScopedTimer tm(e, 1);
       DISPATCH_DPAD(DP, launch_dz_steps<DPAD>(sa, lds, e->stream));
@@ -2770,8 +2775,9 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
       e->arch_rows += S;
     } else {
       // keep this block's states for the exchange, [pending + s][NP][DP]
-      HIP_TRY(hipMemcpyAsync(e->blk_hist.p + (size_t)e->pending_steps * NP * DP, e->blk_states.p, (size_t)S * NP * DP * sizeof(double),
-                             hipMemcpyDeviceToDevice, e->stream));
+      if (!direct)
+        HIP_TRY(hipMemcpyAsync(e->blk_hist.p + (size_t)e->pending_steps * NP * DP, e->blk_states.p, (size_t)S * NP * DP * sizeof(double),
+                               hipMemcpyDeviceToDevice, e->stream));
       e->pending_steps += S;
       // crossover / scaling adaptation sees the archive the finished block proposed from (rows of this block are
       // appended afterwards), so the result does not depend on who appends when
@@ -2780,7 +2786,9 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
         if (boundary && (rc = dreamz_sums_catchup(e, e->arch_rows, 0, true, adaptive, std::pow(e->dz.gamma, -(double)e->k_adapt)))) return rc;
       }
       if (e->auto_append) {  // single process: the local rows are all rows; canonical order = step-major, chain minor
-        if (N == NP) {
+        if (direct) {
+          // already in place
+        } else if (N == NP) {
           HIP_TRY(hipMemcpyAsync(e->arch.p + (size_t)e->arch_rows * DP, e->blk_hist.p, (size_t)e->pending_steps * N * DP * sizeof(double),
                                  hipMemcpyDeviceToDevice, e->stream));
         } else {

@@ -48,6 +48,10 @@ struct DreamDrawArgs {
   const double* u_rep;
   double* eps_export;  // [.][N][d] standard normals actually used (null = off)
   double* u_export;
+  // shared archive (frozen inside the block): the jumps do not depend on the chain states, so this kernel -- parallel over
+  // chains AND free of the step kernel's accept/reject chain -- gathers the archive rows and writes the finished jump
+  // mask * ((1 + e) * gamma * (sum Z[r1] - sum Z[r2]) + eps) into `coef`; k_dreamz_steps then only adds it (jump_ready)
+  const double* arch_shared;  // [cap][DPAD] or null
 };
 
 // 64 / DPAD chains share a wave (lane = chain-in-wave * DPAD + parameter), so small dimensions do not idle lanes
@@ -77,18 +81,34 @@ __global__ void __launch_bounds__(64) k_dreamz_draw(const DreamDrawArgs a) {
   }
   const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
   int mcr = 0;
+  // Box-Muller pairs: a chain needs DPAD / 2 pairs per step (pair p -> dimensions 2p, 2p + 1, the RNG contract), its
+  // DPAD lanes can draw DPAD pairs at once: the lower half draws the pairs of step s, the upper half those of step
+  // s + 1, and two shuffles per step hand every dimension its normal -- one normal_pair per lane and TWO steps instead
+  // of one per step (the normals are ~2/3 of this kernel's instructions).
+  // jump scale for every possible subspace size (proposal.py:842-844), lane k - 1 of the chain holds the one for k
+  // dimensions: a shuffle per step instead of a square root and a division
+  const double gam_tab = scaling * 2.38 / sqrt((double)(2 * a.delta * (lane + 1)));
+  constexpr int HALF = DPAD / 2;
+  const bool philox_normals = a.sub_rep == nullptr;  // wave-uniform
+  double zp0 = 0.0, zp1 = 0.0;
   for (int s = 0; s < a.S; ++s) {
     const uint32_t step = (uint32_t)(a.step0 + s);
     const int64_t M = a.M_base + (a.grow ? s : 0);
     const size_t row = (size_t)s * a.N + c;  // replay / export row (real chains only)
+    // The per-chain scalars of a step -- delta row pairs, the crossover draw, the accept uniform -- are delta + 2 Philox
+    // blocks; lanes 0 .. delta + 1 of the chain evaluate one each in a single pass (each used to be a pass of its own
+    // in which all but a few lanes idled), the others repeat the crossover block
+    const bool acc_lane = lane == a.delta + 1;
+    const u32x4 xs = philox4x32_10(u32x4{acc_lane ? 0u : (uint32_t)(lane < a.delta ? lane : a.delta), step, gc,
+                                         acc_lane ? (uint32_t)STREAM_ACCEPT : (uint32_t)STREAM_DREAM}, k0, k1);
     // ---- archive row pairs (proposal.py:823-826) ----
+    int r1 = 0, r2 = 0;
     if (lane < a.delta) {
-      int r1, r2;
       if (a.r_rep && real_chain) {
         r1 = a.r_rep[(row * a.delta + lane) * 2 + 0];
         r2 = a.r_rep[(row * a.delta + lane) * 2 + 1];
       } else {
-        const u32x4 x = philox4x32_10(u32x4{(uint32_t)lane, step, gc, STREAM_DREAM}, k0, k1);
+        const u32x4 x = xs;
         r1 = (int)(((uint64_t)x.x * (uint64_t)M) >> 32);
         r2 = (int)(((uint64_t)x.y * (uint64_t)(M - 1)) >> 32);
         r2 += r2 >= r1 ? 1 : 0;
@@ -96,10 +116,19 @@ __global__ void __launch_bounds__(64) k_dreamz_draw(const DreamDrawArgs a) {
       a.ridx[((size_t)s * a.NP + c) * (2 * MAX_DELTA) + 2 * lane + 0] = r1;
       a.ridx[((size_t)s * a.NP + c) * (2 * MAX_DELTA) + 2 * lane + 1] = r2;
     }
+    double zs1 = 0.0, zs2 = 0.0;
+    if (a.arch_shared) {  // rows in flight under the draws below
+      for (int i = 0; i < a.delta; ++i) {
+        const int r1i = __shfl(r1, seg * DPAD + i), r2i = __shfl(r2, seg * DPAD + i);
+        zs1 += a.arch_shared[(size_t)r1i * DPAD + lane];
+        zs2 += a.arch_shared[(size_t)r2i * DPAD + lane];
+      }
+    }
     // ---- crossover index and the index forced when the subspace is empty (proposal.py:829-839) ----
     int forced;
     {
-      const u32x4 x = philox4x32_10(u32x4{(uint32_t)a.delta, step, gc, STREAM_DREAM}, k0, k1);
+      const int src = seg * DPAD + a.delta;  // the lane that evaluated the crossover block
+      const u32x4 x = u32x4{(uint32_t)__shfl((int)xs.x, src), (uint32_t)__shfl((int)xs.y, src), (uint32_t)__shfl((int)xs.z, src), 0u};
       if (a.mcr_rep && real_chain) {
         mcr = a.mcr_rep[row];
         forced = a.forced_rep[row];
@@ -113,19 +142,26 @@ __global__ void __launch_bounds__(64) k_dreamz_draw(const DreamDrawArgs a) {
     }
     const double CR = (double)(mcr + 1) / (double)a.nCR;
     // ---- per-parameter draws ----
+    double en_philox = 0.0;
+    if (philox_normals) {
+      if ((s & 1) == 0) normal_pair(a.seed, gc, step + (lane >= HALF ? 1u : 0u), STREAM_PROPOSAL, (uint32_t)(lane % HALF), zp0, zp1);
+      const int src = seg * DPAD + ((s & 1) ? HALF : 0) + (lane >> 1);
+      const double g0 = __shfl(zp0, src), g1 = __shfl(zp1, src);
+      en_philox = (lane & 1) ? g1 : g0;
+    }
     double su = 2.0, eu = 0.5, en = 0.0;
     if (lj) {
-      if (a.sub_rep && real_chain) {
-        su = a.sub_rep[row * a.d + lane];
-        eu = a.e_rep[row * a.d + lane];
-        en = a.eps_rep[row * a.d + lane];
+      if (!philox_normals) {
+        if (real_chain) {
+          su = a.sub_rep[row * a.d + lane];
+          eu = a.e_rep[row * a.d + lane];
+          en = a.eps_rep[row * a.d + lane];
+        }
       } else {
         const u32x4 x = philox4x32_10(u32x4{(uint32_t)(a.delta + 1 + lane), step, gc, STREAM_DREAM}, k0, k1);
         su = u53(x.x, x.y);
         eu = u53(x.z, x.w);
-        double z0, z1;
-        normal_pair(a.seed, gc, step, STREAM_PROPOSAL, (uint32_t)(lane >> 1), z0, z1);
-        en = (lane & 1) ? z1 : z0;
+        en = en_philox;
       }
       if (a.eps_export && real_chain) a.eps_export[row * a.d + lane] = en;
     }
@@ -137,17 +173,23 @@ __global__ void __launch_bounds__(64) k_dreamz_draw(const DreamDrawArgs a) {
       ind = lane == forced;
       dsub = 1;
     }
-    const double gam = scaling * 2.38 / sqrt((double)(2 * a.delta * dsub));  // proposal.py:842-844
+    const double gam = __shfl(gam_tab, seg * DPAD + dsub - 1);  // scaling * 2.38 / sqrt(2 delta d'), proposal.py:842-844
     const double e = -a.b + (a.b - (-a.b)) * eu;
     const double eps = 0.0 + a.b_star * en;
     if (lane < DPAD) {
-      a.coef[((size_t)s * a.NP + c) * DPAD + lane] = ind ? (1.0 + e) * gam : 0.0;
-      a.epsm[((size_t)s * a.NP + c) * DPAD + lane] = ind ? eps : 0.0;
+      const double cf = ind ? (1.0 + e) * gam : 0.0, em = ind ? eps : 0.0;
+      const size_t o = ((size_t)s * a.NP + c) * DPAD + lane;
+      if (a.arch_shared) {
+        a.coef[o] = cf * (zs1 - zs2) + em;  // the jump itself (proposal.py:850-852)
+      } else {
+        a.coef[o] = cf;
+        a.epsm[o] = em;
+      }
     }
-    if (lane == 0) {
+    if (acc_lane) {  // accept_uniform(seed, chain, step, level 0): u53 of the first two words of that block
       double u = 0.5;
       if (real_chain) {
-        u = a.u_rep ? a.u_rep[row] : accept_uniform(a.seed, gc, step, 0u);
+        u = a.u_rep ? a.u_rep[row] : u53(xs.x, xs.y);
         if (a.u_export) a.u_export[row] = u;
       }
       a.u[(size_t)s * a.NP + c] = u;
@@ -182,10 +224,11 @@ struct DreamStepArgs {
   double* rec_stats;
   uint8_t* rec_acc;
   double* blk_states;  // [S][NP][DPAD] states of this block (shared mode: appended to the archive afterwards)
+  int jump_ready;      // 1: `coef` holds the finished jumps (k_dreamz_draw gathered the shared archive), no gathers here
 };
 
 template <int DPAD>
-__global__ void __launch_bounds__(256, 1) k_dreamz_steps(const DreamStepArgs a) {
+__global__ void __launch_bounds__(256, 2) k_dreamz_steps(const DreamStepArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int KS = DPAD / 4;
   constexpr int LDP = DPAD + 2;
@@ -232,6 +275,9 @@ __global__ void __launch_bounds__(256, 1) k_dreamz_steps(const DreamStepArgs a) 
   }
   double lp = a.lp[gcl], ll = a.ll[gcl];
   int nacc = 0;
+  double jnext[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) jnext[e] = (a.jump_ready && active) ? a.coef[(size_t)gct * DPAD + q_ * EPT + e] : 0.0;
   double* arch_c = a.shared ? a.arch : a.arch + (size_t)gct * a.cap * DPAD;
   const FragSrc fbase = frag_src(a.lv.Apk, lane);
   __syncthreads();
@@ -243,7 +289,16 @@ __global__ void __launch_bounds__(256, 1) k_dreamz_steps(const DreamStepArgs a) 
       frag_load<DPAD>(fbase, wave + 4, a.lv.ncb, f1);
     }
     // ---- proposal (proposal.py:850-852) ----
-    if (active) {
+    if (a.jump_ready) {
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          prp[e] = cur[e] + jnext[e];
+          s_prop[c * LDP + q_ * EPT + e] = prp[e];
+          if (s + 1 < a.S) jnext[e] = a.coef[((size_t)(s + 1) * a.NP + gct) * DPAD + q_ * EPT + e];  // flies under this step
+        }
+      }
+    } else if (active) {
       double z1[EPT], z2[EPT];
 #pragma unroll
       for (int e = 0; e < EPT; ++e) z1[e] = z2[e] = 0.0;
@@ -301,12 +356,14 @@ __global__ void __launch_bounds__(256, 1) k_dreamz_steps(const DreamStepArgs a) 
       ll_n = diag ? -0.5 * tot : -0.5 * tot / a.lv.var;
     } else {
       // Rosenbrock chain: f = sum_i (a - x_i)^2 + b (x_{i+1} - x_i^2)^2 ; loglike = -0.5 (f - data)^2 / var
+      // the four lanes (lc, hi) of a chain take every fourth term; sum_rows adds the partial sums
       double f = 0.0;
-      for (int i = 0; i + 1 < a.d; ++i) {
+      for (int i = hi; i + 1 < a.d; i += 4) {
         const double x0 = s_prop[lc * LDP + i], x1 = s_prop[lc * LDP + i + 1];
         const double t0 = a.ros_a - x0, t1 = x1 - x0 * x0;
         f += t0 * t0 + a.ros_b * (t1 * t1);
       }
+      f = sum_rows(f);
       const double r = f - a.ros_data;
       ll_n = -0.5 * (r * r) / a.lv.var;
       __syncthreads();

@@ -93,7 +93,17 @@ def run_shared_dream(engine, n_iterations, sync_every, params=None, stats=None, 
     """Drive a shared-archive DREAM engine under a process group: `sync_every` steps, then one all_gather of the new
     rows, appended identically on every rank (tests/test_gpu_dreamz.py checks the result is independent of sharding)."""
     import torch
+    import torch.distributed as dist
 
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        # one process: its rows are all rows; the engine appends each `sync_every`-step block in place (same archive
+        # contents and order as the exchange below produces with one rank), no copies, no host synchronisation
+        engine.set_archive_auto_append(True)
+        for done in range(0, n_iterations, sync_every):
+            sl = slice(done, min(done + sync_every, n_iterations))
+            engine.run(sl.stop - sl.start, None if params is None else params[sl], None if stats is None else stats[sl],
+                       None if accepted is None else accepted[sl])
+        return
     engine.set_archive_auto_append(False)
     done = 0
     while done < n_iterations:

@@ -19,7 +19,7 @@ for K in (16, 64, 128):
     e = Engine(N, d, seed=4)
     e.set_prior(np.zeros(d), np.eye(d))
     e.set_level_rosenbrock(0, 1.0, 10.0, 0.0, 1.0)
-    e.set_proposal_dreamz(M0, delta=1, nCR=3, adaptive=True, period=128, shared=True, sync_every=K, capacity=M0 + (T + 2 * K + 16) * N)
+    e.set_proposal_dreamz(M0, delta=1, nCR=3, adaptive=True, period=128, shared=True, sync_every=K, capacity=M0 + (T + 3 * K + 16) * N)
     e.set_archive(None)
     e.init(None)
     params = torch.empty((T, N, d), dtype=torch.float64, device="cuda")
