@@ -139,7 +139,7 @@ def main():
         avg_launch_s = ms_st * 1e-3 / max(n_st, 1)
         evals_per_launch = ev_rank / max(n_st, 1)
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "r01_i_pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get("k_mh_steps_hbm_bytes_per_launch")
