@@ -2510,13 +2510,17 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
         }
         iv.P = e->aem_covinv[qq - 1].p;
         const size_t inv_lds = aem_inverse_lds_bytes(iv.nb);
+        const bool inv8 = iv.nb > 4;  // eight waves per chain pay from five block rows on (tools/aem_inverse_probe.hip)
         if (inv_lds > 64 * 1024)  // beyond the default dynamic-LDS window
-          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aem_inverse<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)inv_lds));
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aem_inverse<0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)inv_lds));
         for (int phase = 0; phase < 2; ++phase) {
           ag.phase = phase;
           if (e->aem_ld == 64) hipLaunchKernelGGL(k_aem_action<64>, dim3((unsigned)N), dim3(64), 0, e->stream, ag);
           else hipLaunchKernelGGL(k_aem_action<128>, dim3((unsigned)N), dim3(128), 0, e->stream, ag);
-          if (phase == 0) hipLaunchKernelGGL(k_aem_inverse<0>, dim3((unsigned)N), dim3(256), inv_lds, e->stream, iv);
+          if (phase == 0) {
+            if (inv8) hipLaunchKernelGGL((k_aem_inverse<0, 8>), dim3((unsigned)N), dim3(512), inv_lds, e->stream, iv);
+            else hipLaunchKernelGGL((k_aem_inverse<0, 4>), dim3((unsigned)N), dim3(256), inv_lds, e->stream, iv);
+          }
         }
         e->aem_bt[qq] += 1;
         extra += 1;

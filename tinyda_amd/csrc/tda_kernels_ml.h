@@ -800,8 +800,9 @@ __device__ __forceinline__ void aem_diag_block(double* __restrict__ blkp, int la
 // SKIP (tools/aem_inverse_probe.hip only; the library instantiates 0): 1 = no diagonal-block factorisation, 2 = return
 // after the matrix is staged, 4 = no P = W^T W, 8 = no triangular inverse, 16 = P computed but not stored -- wrong
 // results, stage timings.
-template <int SKIP = 0>
-__global__ void __launch_bounds__(256) k_aem_inverse(const AemInvArgs a) {
+// NWV = waves per chain (4 or 8): the matrix stages have up to eight independent block rows per step.
+template <int SKIP = 0, int NWV = 8>
+__global__ void __launch_bounds__(64 * NWV) k_aem_inverse(const AemInvArgs a) {
   extern __shared__ __attribute__((aligned(16))) double aem_blocks[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -816,7 +817,7 @@ __global__ void __launch_bounds__(256) k_aem_inverse(const AemInvArgs a) {
   const int cdp = hi * 17 + lc;   // + 68 r: C/D element [hi + 4 r][lc]
 
   // ---- Sigma_e + Sigma_bias into the blocks, and the 1e-9 rule ----
-  // thread (r, cc) = element [r][cc] of every block; twelve blocks in flight (the stage is bound by the latency of
+  // thread (r, cc) = element [r][cc] of every (NWV / 4)-th block; twelve blocks in flight (the stage is bound by the latency of
   // the global loads at two workgroups per CU, not by their volume)
   bool big = false;
   const size_t cbase = (size_t)c * MP * MP;
@@ -824,12 +825,14 @@ __global__ void __launch_bounds__(256) k_aem_inverse(const AemInvArgs a) {
   const double* __restrict__ sg1 = a.nsum > 1 ? a.sig[1] + cbase : sg0;
   const double* __restrict__ sg2 = a.nsum > 2 ? a.sig[2] + cbase : sg0;
   const int nblk = nb * (nb + 1) / 2;
-  const int er = tid >> 4, ec = tid & 15;
-  for (int b0 = 0; b0 < nblk; b0 += 12) {
+  constexpr int BPP = NWV / 4;  // blocks covered by one pass of the workgroup
+  const int er = (tid & 255) >> 4, ec = tid & 15, bsel = tid >> 8;
+  for (int b0 = 0; b0 < nblk; b0 += 12 * BPP) {
     double v0[12], v1[12], v2[12], ce[12];
 #pragma unroll
     for (int u = 0; u < 12; ++u) {
-      const int b = b0 + u < nblk ? b0 + u : nblk - 1;
+      const int bq = b0 + BPP * u + bsel;
+      const int b = bq < nblk ? bq : nblk - 1;
       int bi = 0;
       while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
       const int bj = b - bi * (bi + 1) / 2;
@@ -843,8 +846,8 @@ __global__ void __launch_bounds__(256) k_aem_inverse(const AemInvArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < 12; ++u) {
-      if (b0 + u < nblk) {
-        const int b = b0 + u;
+      if (b0 + BPP * u + bsel < nblk) {
+        const int b = b0 + BPP * u + bsel;
         int bi = 0;
         while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
         const int bj = b - bi * (bi + 1) / 2;
@@ -868,7 +871,7 @@ __global__ void __launch_bounds__(256) k_aem_inverse(const AemInvArgs a) {
 
   // ---- 1. blocked Cholesky; the diagonal blocks end up holding the inverses of their factors ----
   for (int j = 0; j < nb; ++j) {
-    for (int i = j + wave; i < nb; i += 4) {
+    for (int i = j + wave; i < nb; i += NWV) {
       double* Cij = blk(i, j);
       double4_t acc;
 #pragma unroll
@@ -883,10 +886,10 @@ __global__ void __launch_bounds__(256) k_aem_inverse(const AemInvArgs a) {
       for (int r = 0; r < 4; ++r) Cij[cdp + 68 * r] = acc[r];
     }
     __syncthreads();
-    if ((SKIP & 1) == 0 && wave == ((j + (int)c) & 3)) aem_diag_block(blk(j, j), lane);  // rotated over the SIMDs
+    if ((SKIP & 1) == 0 && wave == ((j + (int)c) & (NWV - 1))) aem_diag_block(blk(j, j), lane);  // rotated over the SIMDs
     __syncthreads();
     const double* Wjj = blk(j, j);
-    for (int i = j + 1 + wave; i < nb; i += 4) {  // L[i][j] = A[i][j] W[j][j]^T
+    for (int i = j + 1 + wave; i < nb; i += NWV) {  // L[i][j] = A[i][j] W[j][j]^T
       double* Cij = blk(i, j);
       double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -899,10 +902,11 @@ __global__ void __launch_bounds__(256) k_aem_inverse(const AemInvArgs a) {
 
   // ---- 2. W = L^-1 in place ----
   for (int j = (SKIP & 8) ? -1 : nb - 2; j >= 0; --j) {
-    double4_t t[2];
+    constexpr int TS = NWV >= 8 ? 1 : 2;  // block rows per wave (at most seven rows below the diagonal)
+    double4_t t[TS];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int i = j + 1 + wave + 4 * s;
+    for (int s = 0; s < TS; ++s) {
+      const int i = j + 1 + wave + NWV * s;
       t[s] = double4_t{0.0, 0.0, 0.0, 0.0};
       if (i < nb)
         for (int k = j + 1; k <= i; ++k) {
@@ -914,8 +918,8 @@ __global__ void __launch_bounds__(256) k_aem_inverse(const AemInvArgs a) {
     }
     __syncthreads();  // every L[k][j] of this block column has been read
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int i = j + 1 + wave + 4 * s;
+    for (int s = 0; s < TS; ++s) {
+      const int i = j + 1 + wave + NWV * s;
       if (i < nb) {
         double* Tij = blk(i, j);
 #pragma unroll
@@ -925,8 +929,8 @@ __global__ void __launch_bounds__(256) k_aem_inverse(const AemInvArgs a) {
     __syncthreads();
     const double* Wjj = blk(j, j);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int i = j + 1 + wave + 4 * s;
+    for (int s = 0; s < TS; ++s) {
+      const int i = j + 1 + wave + NWV * s;
       if (i < nb) {
         double* Tij = blk(i, j);
         double4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -945,7 +949,7 @@ __global__ void __launch_bounds__(256) k_aem_inverse(const AemInvArgs a) {
   int idx = 0;
   for (int i = 0; i < nb; ++i)
     for (int jj = 0; jj <= i; ++jj, ++idx) {
-      if ((idx & 3) != wave) continue;
+      if ((idx & (NWV - 1)) != wave) continue;
       double4_t acc = {0.0, 0.0, 0.0, 0.0};
       for (int k = i; k < nb; ++k) {
         const double* Wki = blk(k, i);

@@ -12,15 +12,15 @@ using namespace tda;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
-template <int SKIP>
+template <int SKIP, int NWV = 8>
 static float time_variant(const AemInvArgs& a, size_t lds, int reps) {
-  hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aem_inverse<SKIP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aem_inverse<SKIP, NWV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  hipLaunchKernelGGL(k_aem_inverse<SKIP>, dim3((unsigned)a.N), dim3(256), lds, 0, a);
+  hipLaunchKernelGGL((k_aem_inverse<SKIP, NWV>), dim3((unsigned)a.N), dim3(64 * NWV), lds, 0, a);
   hipEventRecord(e0, 0);
-  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_aem_inverse<SKIP>, dim3((unsigned)a.N), dim3(256), lds, 0, a);
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k_aem_inverse<SKIP, NWV>), dim3((unsigned)a.N), dim3(64 * NWV), lds, 0, a);
   hipEventRecord(e1, 0);
   hipEventSynchronize(e1);
   float ms = 0;
@@ -51,6 +51,7 @@ int main(int argc, char** argv) {
   a.N = N; a.m = m; a.MP = MP; a.nb = nb; a.nsum = 1; a.cov = dcov; a.sig[0] = dsig; a.P = dP;
   const size_t lds = (size_t)(nb * (nb + 1) / 2) * AEM_BS * sizeof(double);
   printf("m=%d N=%lld nb=%d lds=%zu B\n", m, (long long)N, nb, lds);
+  printf("full, 4 waves per chain      %9.1f us\n", time_variant<0, 4>(a, lds, 10));
   printf("full                         %9.1f us\n", time_variant<0>(a, lds, 10));
   printf("staging only                 %9.1f us\n", time_variant<2>(a, lds, 10));
   printf("no diagonal blocks           %9.1f us\n", time_variant<1>(a, lds, 10));
@@ -59,7 +60,7 @@ int main(int argc, char** argv) {
   printf("no tri-inverse, no P         %9.1f us\n", time_variant<12>(a, lds, 10));
   printf("no diag, no tri-inv, no P    %9.1f us\n", time_variant<13>(a, lds, 10));
   // check of the full variant against a host inverse of chain 0
-  hipLaunchKernelGGL(k_aem_inverse<0>, dim3((unsigned)N), dim3(256), lds, 0, a);
+  hipLaunchKernelGGL((k_aem_inverse<0, 8>), dim3((unsigned)N), dim3(512), lds, 0, a);
   std::vector<double> P((size_t)MP * MP);
   CK(hipMemcpy(P.data(), dP, P.size() * 8, hipMemcpyDeviceToHost));
   double err = 0;
