@@ -145,6 +145,19 @@ def test_config1_basic_sampler_host_path():
     cov = np.linalg.inv(Ad.T @ Ad / 0.04 + np.eye(2))
     mean = cov @ (Ad.T @ y / 0.04)
     assert np.all(np.abs(pooled.mean(axis=0) - mean) < 5 * np.sqrt(np.diag(cov)) / np.sqrt(30)), (pooled.mean(axis=0), mean)
+    # to_inference_data (diagnostics.py:6-70): groups, variable names and (chain, draw) layout; ArviZ objects when installed,
+    # the light container otherwise
+    idata = tda.to_inference_data(res, burnin=500, parameter_names=["intercept", "slope"])
+    assert list(idata.posterior) == ["intercept", "slope"] or set(idata.posterior.data_vars) == {"intercept", "slope"}
+    assert np.asarray(idata.posterior["slope"]).shape == (2, 1501)
+    np.testing.assert_array_equal(np.asarray(idata.posterior["slope"])[1], s["chain_1"][:, 1])
+    assert np.asarray(idata.posterior_predictive["obs_49"]).shape == (2, 1501)
+    np.testing.assert_allclose(np.asarray(idata.sample_stats["posterior"]),
+                               np.asarray(idata.sample_stats["prior"]) + np.asarray(idata.sample_stats["likelihood"]))
+    assert len(idata.qoi) == 0  # the model returns no quantity of interest
+    if hasattr(idata, "summary"):
+        row = idata.summary()["slope"]
+        assert abs(row["mean"] - mean[1]) < 0.2 and row["ess_bulk"] > 20 and 0.9 < row["r_hat"] < 1.5
 
 
 def test_lowering_pass():

@@ -1,7 +1,7 @@
 """Post-processing: get_samples (tinyDA/diagnostics.py:114-209) and the ESS / R-hat used for ESS/s.
 
-ArviZ / xarray are not importable in this image, so `to_inference_data` raises unless they are installed;
-`ess_bulk` / `rhat` implement the rank-normalised split-chain estimators of Vehtari et al. (2021), the
+ArviZ / xarray are not importable in this image: `to_inference_data` returns real ArviZ objects when they are installed
+and a light container with the same groups / names / layout otherwise; `ess_bulk` / `rhat` implement the rank-normalised split-chain estimators of Vehtari et al. (2021), the
 definition ArviZ's `summary` (called in the reference's notebooks) uses.
 """
 import numpy as np
@@ -45,25 +45,97 @@ def get_samples(chain, attribute="parameters", level="fine", burnin=0):
     return out
 
 
+class DatasetLite:
+    """Stand-in for the xarray.Dataset of one InferenceData group when xarray is not installed: `data_vars` maps a
+    variable name to its (chain, draw) array, `coords` holds the two index vectors (diagnostics.py:73-111)."""
+
+    dims = ("chain", "draw")
+
+    def __init__(self, data_vars, n_chains, n_draws):
+        self.data_vars = dict(data_vars)
+        self.coords = {"chain": np.arange(n_chains), "draw": np.arange(n_draws)}
+
+    def __getitem__(self, name):
+        return self.data_vars[name]
+
+    def __contains__(self, name):
+        return name in self.data_vars
+
+    def __iter__(self):
+        return iter(self.data_vars)
+
+    def __len__(self):
+        return len(self.data_vars)
+
+    def to_array(self):
+        """[variable, chain, draw]"""
+        return np.stack([self.data_vars[k] for k in self.data_vars]) if self.data_vars else np.empty((0, 0, 0))
+
+
+class InferenceDataLite:
+    """What to_inference_data returns when ArviZ is not installed: the same four groups under the same names
+    (`posterior`, `posterior_predictive`, `qoi`, `sample_stats`; diagnostics.py:60-66) as DatasetLite objects, and
+    `summary()` with the columns of `arviz.summary` this package can compute itself (mean, sd, ess_bulk, r_hat)."""
+
+    def __init__(self, **groups):
+        self._groups = list(groups)
+        for k, v in groups.items():
+            setattr(self, k, v)
+
+    def groups(self):
+        return list(self._groups)
+
+    def summary(self, group="posterior"):
+        ds = getattr(self, group)
+        rows = {}
+        for name in ds:
+            x = np.asarray(ds[name], dtype=np.float64)
+            split_ok = x.shape[1] >= 4
+            rows[name] = {"mean": float(x.mean()), "sd": float(x.std(ddof=1)) if x.size > 1 else float("nan"),
+                          "ess_bulk": float(ess_bulk(x)) if split_ok else float("nan"),
+                          "r_hat": float(rhat(x)) if split_ok else float("nan")}
+        return rows
+
+
 def to_inference_data(chain, level="fine", burnin=0, parameter_names=None):
+    """Result dict of sample() -> arviz.InferenceData with the groups and variable names of diagnostics.py:6-70; without
+    ArviZ / xarray (not installable here) an InferenceDataLite with the same groups, names and (chain, draw) layout.
+    Groups whose attribute the chain does not carry (no model output kept, no qoi) are left empty."""
     try:
         import arviz as az
         import xarray as xr
-    except ImportError as exc:
-        raise ImportError("to_inference_data needs arviz and xarray; use get_samples / ess_bulk / rhat") from exc
+    except ImportError:
+        az = xr = None
     groups = []
     for attr in ("parameters", "model_output", "qoi", "stats"):
-        s = get_samples(chain, attr, level, burnin)
+        try:
+            s = get_samples(chain, attr, level, burnin)
+            dim = s["dimension"]
+            first = np.asarray(s["chain_0"])
+            if first.dtype == object or first.size == 0:  # every link carries None (no qoi / no model output)
+                raise TypeError
+        except (TypeError, ValueError, AttributeError):
+            s, dim = None, 0
         if attr == "parameters":
-            names = parameter_names or ["x{}".format(i) for i in range(s["dimension"])]
+            names = list(parameter_names) if parameter_names is not None else ["x{}".format(i) for i in range(dim)]
         elif attr == "stats":
             names = ["prior", "likelihood", "posterior"]
         else:
-            names = ["{}_{}".format("obs" if attr == "model_output" else "qoi", i) for i in range(s["dimension"])]
-        data = {n: (["chain", "draw"], np.array([s["chain_{}".format(j)][:, i] for j in range(s["n_chains"])]))
-                for i, n in enumerate(names)}
-        groups.append(xr.Dataset(data, coords=dict(chain=list(range(s["n_chains"])), draw=list(range(s["iterations"])))))
-    return az.InferenceData(posterior=groups[0], posterior_predictive=groups[1], qoi=groups[2], sample_stats=groups[3])
+            names = ["{}_{}".format("obs" if attr == "model_output" else "qoi", i) for i in range(dim)]
+        n_chains = chain["n_chains"]
+        n_draws = s["iterations"] if s is not None else 0
+        data = {}
+        if s is not None:
+            for i, n in enumerate(names[:dim]):
+                data[n] = np.array([np.asarray(s["chain_{}".format(j)], dtype=np.float64)[:, i] for j in range(n_chains)])
+        if xr is not None:
+            groups.append(xr.Dataset({n: (["chain", "draw"], v) for n, v in data.items()},
+                                     coords=dict(chain=list(range(n_chains)), draw=list(range(n_draws)))))
+        else:
+            groups.append(DatasetLite(data, n_chains, n_draws))
+    if az is not None:
+        return az.InferenceData(posterior=groups[0], posterior_predictive=groups[1], qoi=groups[2], sample_stats=groups[3])
+    return InferenceDataLite(posterior=groups[0], posterior_predictive=groups[1], qoi=groups[2], sample_stats=groups[3])
 
 
 # ---------------------------------------------------------------------------------------------
