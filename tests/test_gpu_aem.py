@@ -85,3 +85,38 @@ def test_mlda_error_model_replay(eng_mod, golden, name):
     outs = e.run_levels_host(n_fine)
     _check(outs, g, nl, stf)
     e.close()
+
+
+def test_sample_api_with_error_model_beyond_64_outputs():
+    """tda.sample(..., adaptive_error_model=...) lowers AdaptiveGaussianLogLike levels with up to 128 outputs (two-wave
+    error-model kernels); the finest-level links carry the posterior of the finest model."""
+    import scipy.stats as st
+
+    import tinyda_amd as tda
+
+    d, m, N = 6, 100, 12
+    rng = np.random.default_rng(5)
+    Af = rng.standard_normal((m, d)) / np.sqrt(d)
+    truth = rng.standard_normal(d)
+    y = Af @ truth + 0.3 * rng.standard_normal(m)
+    prior = st.multivariate_normal(np.zeros(d), np.eye(d))
+    cov = 0.09 * np.eye(m)
+    posts = [tda.Posterior(prior, tda.AdaptiveGaussianLogLike(y, cov), tda.LinearModel(Af + 0.1 * rng.standard_normal((m, d)) / np.sqrt(d))),
+             tda.Posterior(prior, tda.AdaptiveGaussianLogLike(y, cov), tda.LinearModel(Af + 0.05 * rng.standard_normal((m, d)) / np.sqrt(d))),
+             tda.Posterior(prior, tda.GaussianLogLike(y, cov), tda.LinearModel(Af))]
+    th0 = [truth + 0.1 * rng.standard_normal(d) for _ in range(N)]
+    res = tda.sample(posts, tda.GaussianRandomWalk(0.004 * np.eye(d)), 25, n_chains=N, initial_parameters=th0, subchain_length=[3, 2],
+                     adaptive_error_model="state-independent", seed=11)
+    assert res["sampler"] == "MLDA" and res.get("backend", "hip") != "host"
+    fine = res["chain_l2_3"]
+    assert len(fine) == 26
+    link = fine[-1]
+    ref = posts[2].create_link(link.parameters)
+    assert np.isclose(link.posterior, ref.posterior, rtol=1e-10)
+    acc = np.mean([np.mean(res["chain_l2_%d" % i].accepted[1:]) for i in range(N)])
+    assert 0.05 < acc <= 1.0
+    da = tda.sample(posts[1:], tda.CrankNicolson(scaling=0.05), 20, n_chains=N, initial_parameters=th0, subchain_length=1,
+                    adaptive_error_model="state-dependent", seed=12)
+    assert da["sampler"] == "DA" and da.get("backend", "hip") != "host"
+    lk = da["chain_fine_0"][-1]
+    assert np.isclose(lk.posterior, posts[2].create_link(lk.parameters).posterior, rtol=1e-10)
