@@ -137,3 +137,94 @@ def test_callback_nonfinite_outputs_are_rejections():
     assert not acc[:, ::2].any() and acc[:, 1::2].any()
     assert np.array_equal(params[:, ::2], np.broadcast_to(theta0[::2], (T,) + theta0[::2].shape))
     assert np.isfinite(stats).all()
+
+
+def _level_model(k):
+    """Three fidelities of the same non-linear model: coarser levels drop part of the interaction term and perturb W."""
+    def fn(theta):
+        theta = np.atleast_2d(theta)
+        W = 0.1 + 0.01 * ((np.arange(M)[:, None] * 7 + np.arange(theta.shape[1])[None, :] * 3) % 11) + 0.004 * (2 - k)
+        return np.tanh(theta @ W.T) + 0.25 * (0.6 + 0.2 * k) * theta[:, [0]] * theta[:, [-1]]
+    return fn
+
+
+@pytest.mark.parametrize("case", ["da_pcn", "da_grw_diag", "mlda_am"])
+def test_callback_hierarchy_matches_oracle(case):
+    """Delayed Acceptance / MLDA with every level behind a batched host callback (host-sequenced level actions,
+    k_ext_level_action) against the oracle's DAChain / MLDAChain restatement running the same NumPy models; engine on its
+    own Philox stream, base-level normals exported, uniforms regenerated by the oracle's Philox."""
+    from tests.test_gpu_multilevel import _oracle_uniforms
+    from tinyda_amd.engine import Engine
+
+    d, N = 6, 19
+    rng = np.random.default_rng(15)
+    truth = 0.5 * rng.standard_normal(d)
+    if case == "mlda_am":
+        nl, sl, n_fine, block = 3, [3, 2], 14, 7
+    else:
+        nl, sl, n_fine, block = 2, [4], 25, 0
+    models = [_level_model(k + (3 - nl)) for k in range(nl)]
+    y = models[-1](truth)[0] + 0.05 * rng.standard_normal(M)
+    theta0 = truth + 0.05 * rng.standard_normal((N, d))
+    pm, pv = np.zeros(d), np.ones(d)
+    diag = case == "da_grw_diag"
+    noise = 0.05 ** 2 * (1.0 + 0.1 * np.arange(M)) if diag else 0.05 ** 2
+    seed = 4711
+    calls = [[] for _ in range(nl)]
+    e = Engine(N, d, seed=seed, n_levels=nl, block_steps=block)
+    e.set_prior(pm, np.diag(pv))
+    for k in range(nl):
+        def fn(thetas, k=k):
+            calls[k].append(thetas.shape)
+            return models[k](thetas)
+        e.set_level_callback(k, fn, y, 1 if diag else 0, noise if diag else [noise])
+    if case == "da_pcn":
+        e.set_proposal(1, None, scaling=0.04)
+        prop = dict(kind="pcn", scaling=0.04)
+    elif case == "da_grw_diag":
+        e.set_proposal(0, 2e-3 * np.eye(d), scaling=1.0)
+        prop = dict(kind="grw", C=2e-3 * np.eye(d), scaling=1.0)
+    else:
+        e.set_proposal(2, 2e-3 * np.eye(d), t0=20, period=10)
+        prop = dict(kind="am", C0=2e-3 * np.eye(d), t0=20, period=10)
+    e.set_subchains(sl, False)
+    e.init(theta0)
+    rows = e.rows_per_level(n_fine)
+    z, _ = e.set_export(rows[0])
+    outs = e.run_levels_host(n_fine)
+    e.close()
+    # one call per level for the initial links (level 0 twice: the single-level and the hierarchy initialisation), then one per local step
+    for k in range(nl):
+        assert all(c == (N, d) for c in calls[k]) and len(calls[k]) >= rows[k] + 1
+    us, _ = _oracle_uniforms(seed, N, rows, sl)
+    prior = orc.MVNPrior(pm, np.diag(pv))
+    levels = [orc.CallableGaussianLevel(models[k], y, "diag" if diag else "iso", noise, prior) for k in range(nl)]
+    res, _ = orc.run_multilevel(levels, prop, sl, theta0, np.swapaxes(z, 0, 1), us, n_fine, None)
+    for k in range(nl):
+        ref = res[k]
+        sk = slice(1, None) if k == nl - 1 else slice(None)
+        assert np.array_equal(outs[k][2], ref["accepted"][:, sk].T), "level %d accept masks differ" % k
+        np.testing.assert_allclose(outs[k][1][:, :, 2], ref["logpost"][:, sk].T, rtol=1e-10)
+        np.testing.assert_allclose(outs[k][0], np.swapaxes(ref["theta"][:, sk], 0, 1), rtol=1e-9, atol=1e-11)
+    assert 0.05 < outs[nl - 1][2].mean() < 0.98
+
+
+def test_callback_hierarchy_through_sample_api():
+    import tinyda_amd as tda
+
+    d = 6
+    rng = np.random.default_rng(3)
+    truth = 0.3 * rng.standard_normal(d)
+    y = _level_model(2)(truth)[0] + 0.05 * rng.standard_normal(M)
+    prior = st.multivariate_normal(np.zeros(d), np.eye(d))
+    like = tda.GaussianLogLike(y, 0.05 ** 2 * np.eye(M))
+    posts = [tda.Posterior(prior, like, tda.BatchedModel(_level_model(k), M)) for k in (1, 2)]
+    th0 = [truth + 0.05 * rng.standard_normal(d) for _ in range(8)]
+    res = tda.sample(posts, tda.CrankNicolson(scaling=0.04), 30, n_chains=8, initial_parameters=th0, subchain_length=3, seed=9)
+    assert res["sampler"] == "DA" and res.get("backend", "hip") != "host"
+    assert len(res["chain_fine_2"]) == 31 and len(res["chain_coarse_2"]) == 90
+    link = res["chain_fine_5"][-1]
+    assert np.isclose(link.posterior, posts[1].create_link(link.parameters).posterior, rtol=1e-10)
+    with pytest.raises(tda.EngineError):  # the adaptive error model is not lowered for callback hierarchies: the engine says so
+        tda.sample([tda.Posterior(prior, tda.AdaptiveGaussianLogLike(y, 0.05 ** 2 * np.eye(M)), tda.BatchedModel(_level_model(1), M)), posts[1]],
+                   tda.CrankNicolson(scaling=0.04), 5, n_chains=4, subchain_length=2, adaptive_error_model="state-independent", backend="hip")

@@ -46,12 +46,20 @@ def _device_plan(posteriors, proposal):
         if (len(posteriors) != 1 or isinstance(proposal, (DREAMZ, CrankNicolson)) or "rosenbrock" in low
                 or low["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG)):
             return None
-    if any("source" in low or "batched" in low for low in lows):  # source-defined / batched host models: single level, GRW / pCN / AM, iso / diag noise, diagonal prior
-        low = lows[0]
-        if len(posteriors) != 1 or isinstance(proposal, DREAMZ) or low["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG):
+    if any("source" in low or "batched" in low for low in lows):
+        # source-defined models: single level.  Batched host models: single level, or a whole hierarchy of them (Delayed
+        # Acceptance / MLDA with host-sequenced level actions: GRW / pCN / AM without adaptive scaling).  iso / diag noise,
+        # diagonal prior.
+        if isinstance(proposal, DREAMZ):
             return None
-        if np.count_nonzero(low["prior_cov"] - np.diag(np.diag(low["prior_cov"]))):
-            return None
+        if len(posteriors) > 1:
+            if not all("batched" in low for low in lows) or type(proposal) not in (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis):
+                return None
+            if getattr(proposal, "adaptive", False):
+                return None
+        for low in lows:
+            if low["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG) or np.count_nonzero(low["prior_cov"] - np.diag(np.diag(low["prior_cov"]))):
+                return None
     if isinstance(proposal, MALA):  # exact gradient of a linear-Gaussian posterior: single level, linear model, Gaussian prior
         if len(posteriors) != 1 or "source" in lows[0] or "batched" in lows[0] or "rosenbrock" in lows[0] or "prior_joint" in lows[0]:
             return None
@@ -247,7 +255,10 @@ def _sample_device_multilevel(plan, posteriors, iterations, n_chains, initial_pa
     try:
         eng.set_prior(lows[0]["prior_mean"], lows[0]["prior_cov"])
         for k, low in enumerate(lows):
-            eng.set_level(k, low["A"], low["data"], low["noise_kind"], low["noise"], b=low["b"])
+            if "batched" in low:
+                eng.set_level_callback(k, low["batched"], low["data"], low["noise_kind"], low["noise"], inplace=True)
+            else:
+                eng.set_level(k, low["A"], low["data"], low["noise_kind"], low["noise"], b=low["b"])
         eng.set_proposal(**prop)
         eng.set_subchains(subchain_lengths, randomize)
         if aem is not None:

@@ -939,7 +939,7 @@ int tda_engine_set_level_source(tda_engine* e, int level, const char* source, in
 int tda_engine_set_level_callback(tda_engine* e, int level, tda_forward_batch_fn fn, void* user, int32_t m, const double* data,
                                   int32_t noise_kind, const double* noise) {
   if (!e || !fn || !data || !noise) return fail(TDA_ERR_INVALID, "null argument");
-  if (level != 0 || e->nlev != 1) return fail(TDA_ERR_UNSUPPORTED, "callback forward models are lowered for single-level chains only");
+  if (level < 0 || level >= (int)e->levels.size()) return fail(TDA_ERR_INVALID, "level %d out of range", level);
   if (m < 1) return fail(TDA_ERR_INVALID, "m must be >= 1");
   if (noise_kind != TDA_NOISE_ISO && noise_kind != TDA_NOISE_DIAG)
     return fail(TDA_ERR_UNSUPPORTED, "callback forward models take isotropic or diagonal noise");
@@ -1400,6 +1400,19 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
     if (e->levels[0].model != MODEL_LINEAR) return fail(TDA_ERR_UNSUPPORTED, "MALA is lowered for linear forward models only (exact gradient)");
     if (e->prior_bounded) return fail(TDA_ERR_UNSUPPORTED, "MALA needs a Gaussian prior");
     if (e->levels[0].noise_kind == TDA_NOISE_ADAPTIVE) return fail(TDA_ERR_UNSUPPORTED, "MALA: adaptive likelihoods are not lowered");
+  }
+  {
+    int n_cb = 0;
+    for (auto& lv : e->levels) n_cb += lv.model == MODEL_CALLBACK ? 1 : 0;
+    if (n_cb && e->nlev > 1) {  // Delayed Acceptance / MLDA behind host callbacks (host-sequenced level actions)
+      if (n_cb != e->nlev) return fail(TDA_ERR_UNSUPPORTED, "a hierarchy mixes callback and device forward models");
+      if (e->randomize) return fail(TDA_ERR_UNSUPPORTED, "callback hierarchies: randomize_subchain_length is not lowered");
+      if (e->aem) return fail(TDA_ERR_UNSUPPORTED, "callback hierarchies: the adaptive error model is not lowered");
+      if (e->pp.adaptive) return fail(TDA_ERR_UNSUPPORTED, "callback hierarchies: adaptive scaling is not lowered (AdaptiveMetropolis is)");
+      if (e->pp.kind != TDA_PROP_GRW && e->pp.kind != TDA_PROP_PCN && e->pp.kind != TDA_PROP_AM)
+        return fail(TDA_ERR_UNSUPPORTED, "callback hierarchies take GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis proposals");
+      if (e->prior_kind == PRIOR_DENSE) return fail(TDA_ERR_UNSUPPORTED, "callback forward models need a diagonal prior covariance");
+    }
   }
   if (e->prior_bounded) {  // JointPrior with uniform components
     if (e->nlev != 1 || e->is_dreamz) return fail(TDA_ERR_UNSUPPORTED, "priors with uniform components: single-level GRW / AM only");
@@ -2392,7 +2405,79 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
       ma.rec_acc[k] = dev_a[k] ? oa + (size_t)rows_out[k] * N : (oa ? (second ? e->ml_rec_acc2[k].p : e->ml_rec_acc[k].p) : nullptr);
     }
     if (async_host && blk_ix >= 2) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_cp[blk_ix & 1], 0));  // buffer set free again
-    {
+    if (e->levels[0].model == MODEL_CALLBACK) {
+      // host-sequenced hierarchy: every base step is propose -> callback(level 0) -> accept; when the subchain of level
+      // k completes, level k + 1's model is evaluated at the states of level k (one callback for all chains) and
+      // k_ext_level_action decides, aligns and records (the cascade of k_ml_steps, one level at a time)
+      const unsigned grid = (unsigned)((N + EXT_WAVES - 1) / EXT_WAVES);
+      int cc[MAXLEV];
+      int64_t row[MAXLEV] = {0, 0, 0, 0};
+      for (int k = 0; k < MAXLEV; ++k) cc[k] = e->cnt[k];
+      for (int64_t s = 0; s < S; ++s) {
+        ExtArgs xa{};
+        fill_ext_args(e, e->levels[0], xa);
+        xa.mode = 0;
+        xa.prop_kind = e->pp.kind;
+        xa.theta = e->ml_theta.p;
+        xa.lp = e->ml_lp.p;
+        xa.ll = e->ml_ll.p;
+        xa.scaling = e->scaling.p;
+        xa.acc_count = nullptr;
+        xa.anyacc = e->ml_anyacc.p;
+        xa.inc = e->inc.p;
+        xa.u = e->ublk.p;
+        xa.s = (int)s;
+        xa.rec_params = ma.rec_params[0];
+        xa.rec_stats = ma.rec_stats[0];
+        xa.rec_acc = ma.rec_acc[0];
+        int xrc = ext_step(e, e->levels[0], xa);
+        if (xrc) return xrc;
+        cc[0] += 1;
+        for (int k = 0; k < nl - 1 && cc[k] == e->sl[k]; ++k) {
+          const int q = k + 1;
+          const Level& lq = e->levels[q];
+          ExtArgs ya{};
+          fill_ext_args(e, lq, ya);
+          ya.mode = 1;  // "proposals" = the current states of level k
+          ya.theta = e->ml_theta.p + (size_t)k * NP * DP;
+          hipLaunchKernelGGL(k_ext_propose, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, ya);
+          HIP_TRY(hipMemcpyAsync(lq.cb_theta_h, lq.cb_prop.p, (size_t)N * d * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+          HIP_TRY(hipStreamSynchronize(e->stream));
+          const int crc = lq.cb_fn(lq.cb_user, lq.cb_theta_h, lq.cb_F_h, N, d, lq.m);
+          if (crc != 0) return fail(TDA_ERR_CALLBACK, "the forward-model callback of level %d returned %d", q, crc);
+          HIP_TRY(hipMemcpyAsync(lq.cb_F.p, lq.cb_F_h, (size_t)N * lq.m * sizeof(double), hipMemcpyHostToDevice, e->stream));
+          ExtLevelArgs la{};
+          la.N = N;
+          la.NP = NP;
+          la.chain_offset = e->cfg.chain_offset;
+          la.d = d;
+          la.DP = DP;
+          la.m = lq.m;
+          la.nlev = nl;
+          la.q = q;
+          la.seed = e->cfg.seed;
+          la.step = e->done[q] + row[q];
+          la.F = lq.cb_F.p;
+          la.data = lq.udata.p;
+          la.w = lq.noise_kind == TDA_NOISE_DIAG ? lq.uw.p : nullptr;
+          la.var = lq.var;
+          la.theta = e->ml_theta.p;
+          la.lp = e->ml_lp.p;
+          la.ll = e->ml_ll.p;
+          la.Sst = e->ml_S.p;
+          la.anyacc = e->ml_anyacc.p;
+          la.u_rep = ma.u_rep[q] ? ma.u_rep[q] + (size_t)row[q] * N : nullptr;
+          la.rec_params = ma.rec_params[q] ? ma.rec_params[q] + (size_t)row[q] * N * d : nullptr;
+          la.rec_stats = ma.rec_stats[q] ? ma.rec_stats[q] + (size_t)row[q] * N * 3 : nullptr;
+          la.rec_acc = ma.rec_acc[q] ? ma.rec_acc[q] + (size_t)row[q] * N : nullptr;
+          hipLaunchKernelGGL(k_ext_level_action, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, la);
+          HIP_TRY(hipGetLastError());
+          cc[k] = 0;
+          cc[q] += 1;
+          row[q] += 1;
+        }
+      }
+    } else {
       ScopedTimer tm(e, 1);
       DISPATCH_DPAD(DP, launch_ml<DPAD>(ma, NP / 16, lds, e->stream));
     }

@@ -11,6 +11,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "tda_philox.h"
+
 namespace tda {
 
 struct ExtArgs {
@@ -37,6 +39,7 @@ struct ExtArgs {
   double* rec_params;
   double* rec_stats;
   unsigned char* rec_acc;
+  int* anyacc;  // multi-level: set when this (base-level) step accepted -- "the subchain moved" (chain.py:357-364); may be null
 };
 
 constexpr int EXT_WAVES = 4;
@@ -108,6 +111,7 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_accept(const ExtArgs a) 
     const size_t r = (size_t)a.s * a.N + c;
     if (lane == 0) {
       if (acc && a.acc_count) a.acc_count[c] += 1;
+      if (acc && a.anyacc) a.anyacc[c] = 1;
       if (a.rec_stats) {
         a.rec_stats[r * 3 + 0] = lp;
         a.rec_stats[r * 3 + 1] = ll;
@@ -117,6 +121,100 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_accept(const ExtArgs a) 
     }
     if (a.rec_params && lj) a.rec_params[r * a.d + lane] = cur;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Delayed Acceptance / MLDA with callback models: one step of level q >= 1 for every chain once the subchain of level
+// q - 1 has finished (DAChain.sample, chain.py:353-402; MLDA.make_mlda_proposal, proposal.py:1515-1545; MLDAChain.sample,
+// chain.py:711-737).  The host has evaluated level q's model at the states of level q - 1 (F); this kernel does what
+// the cascade of k_ml_steps does for linear levels: two-stage acceptance with the densities kept from the subchain
+// start, the skip rule (nothing accepted below -> rejection), alignment of the levels below, records.
+// ------------------------------------------------------------------------------------------------
+struct ExtLevelArgs {
+  long long N, NP, chain_offset;
+  int d, DP, m, nlev, q;
+  unsigned long long seed;
+  long long step;       // index of this level-q step (RNG / replay row)
+  const double* F;      // [N][m] level-q model at theta_{q-1}
+  const double* data;   // [m]
+  const double* w;      // 1 / diag(noise) or null
+  double var;
+  double* theta;        // [nlev][NP][DP]
+  double* lp;           // [nlev][NP]
+  double* ll;
+  double* Sst;          // [npairs][2][NP], pair (j, q) at q (q - 1) / 2 + j
+  int* anyacc;          // [nlev][NP]
+  const double* u_rep;  // [N] replay uniforms of this step (NaN = none drawn) or null
+  double* rec_params;   // row of this step (may be null)
+  double* rec_stats;
+  unsigned char* rec_acc;
+};
+
+__global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_level_action(const ExtLevelArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long long c = (long long)blockIdx.x * EXT_WAVES + (threadIdx.x >> 6);
+  if (c >= a.N) return;  // whole waves leave together
+  const int q = a.q, k = a.q - 1;
+  const bool lj = lane < a.d;
+  auto TH = [&](int lev) { return a.theta + ((size_t)lev * a.NP + c) * a.DP; };
+  auto PI = [](int j, int qq) { return qq * (qq - 1) / 2 + j; };
+  double sse = 0.0;
+  const double* Fc = a.F + (size_t)c * a.m;
+  for (int o = lane; o < a.m; o += 64) {
+    const double r = Fc[o] - a.data[o];
+    double sq = r * r;
+    if (a.w) sq *= a.w[o];
+    sse += sq;
+  }
+  sse = ext_wave_sum(sse);
+  const double lln = a.w ? -0.5 * sse : -0.5 * sse / a.var;
+  const double yj = lj ? TH(k)[lane] : 0.0, xj = lj ? TH(q)[lane] : 0.0;
+  const double y_lp = a.lp[(size_t)k * a.NP + c], y_ll = a.ll[(size_t)k * a.NP + c];
+  const double x_lp = a.lp[(size_t)q * a.NP + c], x_ll = a.ll[(size_t)q * a.NP + c];
+  const int pkq = PI(k, q);
+  const double st_lp = a.Sst[((size_t)pkq * 2 + 0) * a.NP + c], st_ll = a.Sst[((size_t)pkq * 2 + 1) * a.NP + c];
+  const bool any = a.anyacc[(size_t)k * a.NP + c] != 0;
+  const double lpn = y_lp;  // same prior, same parameters (posterior.py:92)
+  const double alpha = exp(((lpn + lln) - (x_lp + x_ll)) + (st_lp + st_ll) - (y_lp + y_ll));  // chain.py:475-483, proposal.py:1615-1624
+  double u;
+  if (a.u_rep) u = a.u_rep[c];
+  else u = accept_uniform(a.seed, (uint32_t)(a.chain_offset + c), (uint32_t)a.step, (uint32_t)q);
+  const bool acc = any && (u < alpha);
+  // alignment (chain.py:357-398; proposal.py:1469-1493): accept -> level q takes y; reject -> the levels below return to theta_q
+  if (acc) {
+    if (lane < a.DP) TH(q)[lane] = lj ? yj : 0.0;
+  } else {
+    for (int j = 0; j < q; ++j)
+      if (lane < a.DP) TH(j)[lane] = lj ? xj : 0.0;
+  }
+  if (lane == 0) {
+    if (acc) {
+      a.lp[(size_t)q * a.NP + c] = lpn;
+      a.ll[(size_t)q * a.NP + c] = lln;
+    } else {
+      for (int j = 0; j < q; ++j) {
+        const int p = PI(j, q);
+        a.lp[(size_t)j * a.NP + c] = a.Sst[((size_t)p * 2 + 0) * a.NP + c];
+        a.ll[(size_t)j * a.NP + c] = a.Sst[((size_t)p * 2 + 1) * a.NP + c];
+      }
+    }
+    for (int j = 0; j < q; ++j)
+      for (int q2 = j + 1; q2 <= q; ++q2) {
+        const int p = PI(j, q2);
+        a.Sst[((size_t)p * 2 + 0) * a.NP + c] = a.lp[(size_t)j * a.NP + c];
+        a.Sst[((size_t)p * 2 + 1) * a.NP + c] = a.ll[(size_t)j * a.NP + c];
+      }
+    a.anyacc[(size_t)k * a.NP + c] = 0;
+    if (q < a.nlev - 1 && acc) a.anyacc[(size_t)q * a.NP + c] = 1;
+    if (a.rec_stats) {
+      const double l1 = a.lp[(size_t)q * a.NP + c], l2 = a.ll[(size_t)q * a.NP + c];
+      a.rec_stats[c * 3 + 0] = l1;
+      a.rec_stats[c * 3 + 1] = l2;
+      a.rec_stats[c * 3 + 2] = l1 + l2;
+    }
+    if (a.rec_acc) a.rec_acc[c] = acc ? 1 : 0;
+  }
+  if (a.rec_params && lj) a.rec_params[c * a.d + lane] = acc ? yj : xj;
 }
 
 }  // namespace tda

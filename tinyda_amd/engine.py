@@ -126,8 +126,10 @@ class Engine:
                 self._cb_exc = exc
                 return 1
 
-        self._cb = _lib.FORWARD_BATCH_FN(trampoline)  # keep the thunk alive as long as the engine
-        check(self.lib.tda_engine_set_level_callback(self.h, level, C.cast(self._cb, C.c_void_p), None, m, _ptr(data),
+        if not hasattr(self, "_cbs"):
+            self._cbs = {}
+        self._cbs[level] = _lib.FORWARD_BATCH_FN(trampoline)  # keep the thunks alive as long as the engine
+        check(self.lib.tda_engine_set_level_callback(self.h, level, C.cast(self._cbs[level], C.c_void_p), None, m, _ptr(data),
                                                      noise_kind, _ptr(noise)))
 
     def _check_run(self, rc):
