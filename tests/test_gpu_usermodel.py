@@ -126,3 +126,105 @@ def test_source_model_with_joint_prior_bounds():
     lo, hi = np.where(kinds == 1, loc, -np.inf), np.where(kinds == 1, loc + scale, np.inf)
     assert np.all(params >= lo) and np.all(params <= hi)
     assert (acc == 0).sum() > 0
+
+
+SRC_LEVEL = """
+__device__ double tda_forward(const double* theta, int dim, int o) {
+  // fidelity %(k)d of the model above: coarser levels weaken the quadratic coupling and shift the weights
+  double s = 0.0;
+  for (int j = 0; j < dim; ++j) s += (0.1 + 0.01 * ((o * 7 + j * 3) %% 11) + %(shift).4f) * theta[j];
+  const double q = theta[o %% dim] * theta[(o + 1) %% dim];
+  return sin(s) + %(coup).4f * q;
+}
+"""
+
+
+def _level_cfg(k):
+    return dict(k=k, shift=0.004 * (2 - k), coup=0.5 * (0.6 + 0.2 * k))
+
+
+def np_level_model(k):
+    cfg = _level_cfg(k)
+
+    def fn(theta):
+        theta = np.atleast_2d(theta)
+        N, d = theta.shape
+        m = 23
+        out = np.empty((N, m))
+        for o in range(m):
+            s = np.zeros(N)
+            for j in range(d):
+                s = s + (0.1 + 0.01 * ((o * 7 + j * 3) % 11) + float("%.4f" % cfg["shift"])) * theta[:, j]
+            out[:, o] = np.sin(s) + float("%.4f" % cfg["coup"]) * (theta[:, o % d] * theta[:, (o + 1) % d])
+        return out
+    return fn
+
+
+@pytest.mark.parametrize("case", ["da_pcn", "mlda_am", "da_mixed"])
+def test_source_model_hierarchy_matches_oracle(case):
+    """Delayed Acceptance / MLDA with source-defined (hiprtc) models at every level -- no host round trip per step -- and a
+    hierarchy mixing a batched host callback (coarse) with a source-defined fine model, against the oracle's DAChain /
+    MLDAChain restatement running the NumPy twins of the models."""
+    from tests.test_gpu_multilevel import _oracle_uniforms
+    from tinyda_amd.engine import Engine
+
+    d, m, N = 5, 23, 21
+    rng = np.random.default_rng(8)
+    truth = 0.5 * rng.standard_normal(d)
+    if case == "mlda_am":
+        ks, sl, n_fine, block = [0, 1, 2], [3, 2], 14, 7
+    else:
+        ks, sl, n_fine, block = [1, 2], [4], 25, 0
+    nl = len(ks)
+    twins = [np_level_model(k) for k in ks]
+    y = twins[-1](truth)[0] + 0.05 * rng.standard_normal(m)
+    theta0 = truth + 0.05 * rng.standard_normal((N, d))
+    pm, pv = np.zeros(d), np.ones(d)
+    seed = 991
+    e = Engine(N, d, seed=seed, n_levels=nl, block_steps=block)
+    e.set_prior(pm, np.diag(pv))
+    for i, k in enumerate(ks):
+        if case == "da_mixed" and i == 0:
+            e.set_level_callback(0, twins[0], y, 0, [0.05 ** 2])
+        else:
+            e.set_level_source(i, SRC_LEVEL % _level_cfg(k), y, 0, [0.05 ** 2])
+    if case == "mlda_am":
+        e.set_proposal(2, 2e-3 * np.eye(d), t0=20, period=10)
+        prop = dict(kind="am", C0=2e-3 * np.eye(d), t0=20, period=10)
+    else:
+        e.set_proposal(1, None, scaling=0.04)
+        prop = dict(kind="pcn", scaling=0.04)
+    e.set_subchains(sl, False)
+    e.init(theta0)
+    rows = e.rows_per_level(n_fine)
+    z, _ = e.set_export(rows[0])
+    outs = e.run_levels_host(n_fine)
+    e.close()
+    us, _ = _oracle_uniforms(seed, N, rows, sl)
+    prior = orc.MVNPrior(pm, np.diag(pv))
+    levels = [orc.CallableGaussianLevel(twins[i], y, "iso", 0.05 ** 2, prior) for i in range(nl)]
+    res, _ = orc.run_multilevel(levels, prop, sl, theta0, np.swapaxes(z, 0, 1), us, n_fine, None)
+    for i in range(nl):
+        ref = res[i]
+        sk = slice(1, None) if i == nl - 1 else slice(None)
+        assert np.array_equal(outs[i][2], ref["accepted"][:, sk].T), "level %d accept masks differ" % i
+        np.testing.assert_allclose(outs[i][1][:, :, 2], ref["logpost"][:, sk].T, rtol=1e-10)
+    assert 0.05 < outs[nl - 1][2].mean() < 0.98
+
+
+def test_source_model_hierarchy_through_sample_api():
+    import tinyda_amd as tda
+
+    d, m = 5, 23
+    rng = np.random.default_rng(12)
+    truth = 0.4 * rng.standard_normal(d)
+    y = np_level_model(2)(truth)[0] + 0.05 * rng.standard_normal(m)
+    prior = st.multivariate_normal(np.zeros(d), np.eye(d))
+    like = tda.GaussianLogLike(y, 0.05 ** 2 * np.eye(m))
+    posts = [tda.Posterior(prior, like, tda.DeviceModel(SRC_LEVEL % _level_cfg(k), m, reference=lambda th, k=k: np_level_model(k)(th)[0]))
+             for k in (1, 2)]
+    th0 = [truth + 0.05 * rng.standard_normal(d) for _ in range(8)]
+    res = tda.sample(posts, tda.GaussianRandomWalk(2e-3 * np.eye(d)), 30, n_chains=8, initial_parameters=th0, subchain_length=3, seed=5)
+    assert res["sampler"] == "DA" and res.get("backend", "hip") != "host"
+    link = res["chain_fine_5"][-1]
+    assert np.isclose(link.posterior, posts[1].create_link(link.parameters).posterior, rtol=1e-10)

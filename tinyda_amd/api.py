@@ -47,13 +47,13 @@ def _device_plan(posteriors, proposal):
                 or low["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG)):
             return None
     if any("source" in low or "batched" in low for low in lows):
-        # source-defined models: single level.  Batched host models: single level, or a whole hierarchy of them (Delayed
-        # Acceptance / MLDA with host-sequenced level actions: GRW / pCN / AM without adaptive scaling).  iso / diag noise,
-        # diagonal prior.
+        # source-defined and batched host models: single level, or a whole hierarchy of them (Delayed Acceptance / MLDA with
+        # host-sequenced level actions: GRW / pCN / AM without adaptive scaling).  iso / diag noise, diagonal prior.
         if isinstance(proposal, DREAMZ):
             return None
         if len(posteriors) > 1:
-            if not all("batched" in low for low in lows) or type(proposal) not in (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis):
+            if (not all("batched" in low or "source" in low for low in lows)
+                    or type(proposal) not in (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis)):
                 return None
             if getattr(proposal, "adaptive", False):
                 return None
@@ -257,6 +257,8 @@ def _sample_device_multilevel(plan, posteriors, iterations, n_chains, initial_pa
         for k, low in enumerate(lows):
             if "batched" in low:
                 eng.set_level_callback(k, low["batched"], low["data"], low["noise_kind"], low["noise"], inplace=True)
+            elif "source" in low:
+                eng.set_level_source(k, low["source"], low["data"], low["noise_kind"], low["noise"])
             else:
                 eng.set_level(k, low["A"], low["data"], low["noise_kind"], low["noise"], b=low["b"])
         eng.set_proposal(**prop)

@@ -155,7 +155,7 @@ struct Level {
     cb_theta_h = cb_F_h = nullptr;
   }
   hipModule_t umod = nullptr;
-  hipFunction_t ufn = nullptr;
+  hipFunction_t ufn = nullptr, ufn_eval = nullptr;
   DevBuf<double> udata, uw;
   double ros_a = 1.0, ros_b = 10.0, ros_data = 0.0;
   DevBuf<double> Apk, ytil, w, Ppk;
@@ -478,16 +478,25 @@ void fill_ext_args(tda_engine* e, const Level& lv, ExtArgs& xa) {
   xa.logconst = e->prior_logconst;
 }
 
-// one step of a callback level: proposals -> host -> callback -> model outputs -> device -> accept (xa.s, xa.mode set)
-int ext_step(tda_engine* e, const Level& lv, const ExtArgs& xa) {
-  if (e->prior_kind == PRIOR_DENSE) return fail(TDA_ERR_UNSUPPORTED, "callback forward models need a diagonal prior covariance");
-  const unsigned grid = (unsigned)((e->N + EXT_WAVES - 1) / EXT_WAVES);
-  hipLaunchKernelGGL(k_ext_propose, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, xa);
+// F[N][m] <- model(prop[N][d]) of a level whose model lives outside the engine's kernels: a batched host callback (through
+// page-locked staging buffers, one synchronisation) or a source-defined model (tda_user_eval, stays on the stream)
+int ext_model_outputs(tda_engine* e, const Level& lv) {
+  if (lv.model == MODEL_USER) return launch_user_eval(lv.ufn_eval, e->N, e->d, lv.m, lv.cb_prop.p, lv.cb_F.p, e->stream);
   HIP_TRY(hipMemcpyAsync(lv.cb_theta_h, lv.cb_prop.p, (size_t)e->N * e->d * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   const int crc = lv.cb_fn(lv.cb_user, lv.cb_theta_h, lv.cb_F_h, e->N, e->d, lv.m);
   if (crc != 0) return fail(TDA_ERR_CALLBACK, "the forward-model callback returned %d", crc);
   HIP_TRY(hipMemcpyAsync(lv.cb_F.p, lv.cb_F_h, (size_t)e->N * lv.m * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  return TDA_OK;
+}
+
+// one step of such a level: proposals -> model outputs -> accept (xa.s, xa.mode set)
+int ext_step(tda_engine* e, const Level& lv, const ExtArgs& xa) {
+  if (e->prior_kind == PRIOR_DENSE) return fail(TDA_ERR_UNSUPPORTED, "callback forward models need a diagonal prior covariance");
+  const unsigned grid = (unsigned)((e->N + EXT_WAVES - 1) / EXT_WAVES);
+  hipLaunchKernelGGL(k_ext_propose, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, xa);
+  int mrc = ext_model_outputs(e, lv);
+  if (mrc) return mrc;
   hipLaunchKernelGGL(k_ext_accept, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, xa);
   HIP_TRY(hipGetLastError());
   return TDA_OK;
@@ -899,7 +908,7 @@ int tda_engine_set_level_rosenbrock(tda_engine* e, int level, double a, double b
 int tda_engine_set_level_source(tda_engine* e, int level, const char* source, int32_t m, const double* data, int32_t noise_kind,
                                 const double* noise) {
   if (!e || !source || !data || !noise) return fail(TDA_ERR_INVALID, "null argument");
-  if (level != 0 || e->nlev != 1) return fail(TDA_ERR_UNSUPPORTED, "source-defined forward models are lowered for single-level chains only");
+  if (level < 0 || level >= (int)e->levels.size()) return fail(TDA_ERR_INVALID, "level %d out of range", level);
   if (m < 1) return fail(TDA_ERR_INVALID, "m must be >= 1");
   if (noise_kind != TDA_NOISE_ISO && noise_kind != TDA_NOISE_DIAG)
     return fail(TDA_ERR_UNSUPPORTED, "source-defined forward models take isotropic or diagonal noise");
@@ -909,8 +918,9 @@ int tda_engine_set_level_source(tda_engine* e, int level, const char* source, in
     (void)hipModuleUnload(lv.umod);
     lv.umod = nullptr;
     lv.ufn = nullptr;
+    lv.ufn_eval = nullptr;
   }
-  int rc = compile_user_model(source, &lv.umod, &lv.ufn);
+  int rc = compile_user_model(source, &lv.umod, &lv.ufn, &lv.ufn_eval);
   if (rc) return rc;
   std::vector<double> y(data, data + m), w;
   if (noise_kind == TDA_NOISE_ISO) {
@@ -926,6 +936,10 @@ int tda_engine_set_level_source(tda_engine* e, int level, const char* source, in
     if ((rc = lv.uw.upload(w))) return rc;
   }
   if ((rc = lv.udata.upload(y))) return rc;
+  if (e->nlev > 1) {  // hierarchy: proposals / outputs of a level step pass through device buffers (tda_user_eval)
+    if ((rc = lv.cb_prop.alloc((size_t)e->N * e->d))) return rc;
+    if ((rc = lv.cb_F.alloc((size_t)e->N * m))) return rc;
+  }
   lv.model = MODEL_USER;
   lv.m = m;
   lv.m_pad = 16;  // (no MFMA staging; keeps the shared LDS-size arithmetic of the run loop valid)
@@ -1403,9 +1417,9 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
   }
   {
     int n_cb = 0;
-    for (auto& lv : e->levels) n_cb += lv.model == MODEL_CALLBACK ? 1 : 0;
-    if (n_cb && e->nlev > 1) {  // Delayed Acceptance / MLDA behind host callbacks (host-sequenced level actions)
-      if (n_cb != e->nlev) return fail(TDA_ERR_UNSUPPORTED, "a hierarchy mixes callback and device forward models");
+    for (auto& lv : e->levels) n_cb += (lv.model == MODEL_CALLBACK || lv.model == MODEL_USER) ? 1 : 0;
+    if (n_cb && e->nlev > 1) {  // Delayed Acceptance / MLDA with callback / source-defined models (host-sequenced level actions)
+      if (n_cb != e->nlev) return fail(TDA_ERR_UNSUPPORTED, "a hierarchy mixes callback / source-defined and linear forward models");
       if (e->randomize) return fail(TDA_ERR_UNSUPPORTED, "callback hierarchies: randomize_subchain_length is not lowered");
       if (e->aem) return fail(TDA_ERR_UNSUPPORTED, "callback hierarchies: the adaptive error model is not lowered");
       if (e->pp.adaptive) return fail(TDA_ERR_UNSUPPORTED, "callback hierarchies: adaptive scaling is not lowered (AdaptiveMetropolis is)");
@@ -2405,8 +2419,8 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
       ma.rec_acc[k] = dev_a[k] ? oa + (size_t)rows_out[k] * N : (oa ? (second ? e->ml_rec_acc2[k].p : e->ml_rec_acc[k].p) : nullptr);
     }
     if (async_host && blk_ix >= 2) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_cp[blk_ix & 1], 0));  // buffer set free again
-    if (e->levels[0].model == MODEL_CALLBACK) {
-      // host-sequenced hierarchy: every base step is propose -> callback(level 0) -> accept; when the subchain of level
+    if (e->levels[0].model == MODEL_CALLBACK || e->levels[0].model == MODEL_USER) {
+      // host-sequenced hierarchy (batched host callbacks and / or source-defined models): every base step is propose -> callback(level 0) -> accept; when the subchain of level
       // k completes, level k + 1's model is evaluated at the states of level k (one callback for all chains) and
       // k_ext_level_action decides, aligns and records (the cascade of k_ml_steps, one level at a time)
       const unsigned grid = (unsigned)((N + EXT_WAVES - 1) / EXT_WAVES);
@@ -2441,11 +2455,8 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
           ya.mode = 1;  // "proposals" = the current states of level k
           ya.theta = e->ml_theta.p + (size_t)k * NP * DP;
           hipLaunchKernelGGL(k_ext_propose, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, ya);
-          HIP_TRY(hipMemcpyAsync(lq.cb_theta_h, lq.cb_prop.p, (size_t)N * d * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-          HIP_TRY(hipStreamSynchronize(e->stream));
-          const int crc = lq.cb_fn(lq.cb_user, lq.cb_theta_h, lq.cb_F_h, N, d, lq.m);
-          if (crc != 0) return fail(TDA_ERR_CALLBACK, "the forward-model callback of level %d returned %d", q, crc);
-          HIP_TRY(hipMemcpyAsync(lq.cb_F.p, lq.cb_F_h, (size_t)N * lq.m * sizeof(double), hipMemcpyHostToDevice, e->stream));
+          const int mrc = ext_model_outputs(e, lq);
+          if (mrc) return mrc;
           ExtLevelArgs la{};
           la.N = N;
           la.NP = NP;
