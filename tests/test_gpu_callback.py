@@ -181,17 +181,18 @@ def test_callback_hierarchy_matches_oracle(case):
     if case == "da_pcn":
         e.set_proposal(1, None, scaling=0.04)
         prop = dict(kind="pcn", scaling=0.04)
-    elif case == "da_grw_diag":
-        e.set_proposal(0, 2e-3 * np.eye(d), scaling=1.0)
-        prop = dict(kind="grw", C=2e-3 * np.eye(d), scaling=1.0)
+    elif case == "da_grw_diag":  # adaptive scaling: the window of accept flags contains the alignment entries of the fine level
+        e.set_proposal(0, 2e-3 * np.eye(d), scaling=1.0, adaptive=True, gamma=1.02, period=15)
+        prop = dict(kind="grw", C=2e-3 * np.eye(d), scaling=1.0, adaptive=True, gamma=1.02, period=15)
     else:
-        e.set_proposal(2, 2e-3 * np.eye(d), t0=20, period=10)
-        prop = dict(kind="am", C0=2e-3 * np.eye(d), t0=20, period=10)
+        e.set_proposal(2, 2e-3 * np.eye(d), t0=20, period=10, adaptive=True, gamma=1.02)
+        prop = dict(kind="am", C0=2e-3 * np.eye(d), t0=20, period=10, adaptive=True, gamma=1.02)
     e.set_subchains(sl, False)
     e.init(theta0)
     rows = e.rows_per_level(n_fine)
     z, _ = e.set_export(rows[0])
     outs = e.run_levels_host(n_fine)
+    scal = e.proposal_state()["scaling"]
     e.close()
     # one call per level for the initial links (level 0 twice: the single-level and the hierarchy initialisation), then one per local step
     for k in range(nl):
@@ -199,13 +200,14 @@ def test_callback_hierarchy_matches_oracle(case):
     us, _ = _oracle_uniforms(seed, N, rows, sl)
     prior = orc.MVNPrior(pm, np.diag(pv))
     levels = [orc.CallableGaussianLevel(models[k], y, "diag" if diag else "iso", noise, prior) for k in range(nl)]
-    res, _ = orc.run_multilevel(levels, prop, sl, theta0, np.swapaxes(z, 0, 1), us, n_fine, None)
+    res, pstate = orc.run_multilevel(levels, prop, sl, theta0, np.swapaxes(z, 0, 1), us, n_fine, None)
     for k in range(nl):
         ref = res[k]
         sk = slice(1, None) if k == nl - 1 else slice(None)
         assert np.array_equal(outs[k][2], ref["accepted"][:, sk].T), "level %d accept masks differ" % k
         np.testing.assert_allclose(outs[k][1][:, :, 2], ref["logpost"][:, sk].T, rtol=1e-10)
         np.testing.assert_allclose(outs[k][0], np.swapaxes(ref["theta"][:, sk], 0, 1), rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(scal, pstate.scaling, rtol=1e-12)
     assert 0.05 < outs[nl - 1][2].mean() < 0.98
 
 

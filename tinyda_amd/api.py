@@ -48,14 +48,12 @@ def _device_plan(posteriors, proposal):
             return None
     if any("source" in low or "batched" in low for low in lows):
         # source-defined and batched host models: single level, or a whole hierarchy of them (Delayed Acceptance / MLDA with
-        # host-sequenced level actions: GRW / pCN / AM without adaptive scaling).  iso / diag noise, diagonal prior.
+        # host-sequenced level actions: GRW / pCN / AM).  iso / diag noise, diagonal prior.
         if isinstance(proposal, DREAMZ):
             return None
         if len(posteriors) > 1:
             if (not all("batched" in low or "source" in low for low in lows)
                     or type(proposal) not in (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis)):
-                return None
-            if getattr(proposal, "adaptive", False):
                 return None
         for low in lows:
             if low["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG) or np.count_nonzero(low["prior_cov"] - np.diag(np.diag(low["prior_cov"]))):

@@ -1422,7 +1422,6 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
       if (n_cb != e->nlev) return fail(TDA_ERR_UNSUPPORTED, "a hierarchy mixes callback / source-defined and linear forward models");
       if (e->randomize) return fail(TDA_ERR_UNSUPPORTED, "callback hierarchies: randomize_subchain_length is not lowered");
       if (e->aem) return fail(TDA_ERR_UNSUPPORTED, "callback hierarchies: the adaptive error model is not lowered");
-      if (e->pp.adaptive) return fail(TDA_ERR_UNSUPPORTED, "callback hierarchies: adaptive scaling is not lowered (AdaptiveMetropolis is)");
       if (e->pp.kind != TDA_PROP_GRW && e->pp.kind != TDA_PROP_PCN && e->pp.kind != TDA_PROP_AM)
         return fail(TDA_ERR_UNSUPPORTED, "callback hierarchies take GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis proposals");
       if (e->prior_kind == PRIOR_DENSE) return fail(TDA_ERR_UNSUPPORTED, "callback forward models need a diagonal prior covariance");
@@ -2426,6 +2425,7 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
       const unsigned grid = (unsigned)((N + EXT_WAVES - 1) / EXT_WAVES);
       int cc[MAXLEV];
       int64_t row[MAXLEV] = {0, 0, 0, 0};
+      int64_t rp = e->ring_pos;  // position in the base proposal's accepted list: one entry per base step and per level action
       for (int k = 0; k < MAXLEV; ++k) cc[k] = e->cnt[k];
       for (int64_t s = 0; s < S; ++s) {
         ExtArgs xa{};
@@ -2444,6 +2444,9 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
         xa.rec_params = ma.rec_params[0];
         xa.rec_stats = ma.rec_stats[0];
         xa.rec_acc = ma.rec_acc[0];
+        xa.ring = adaptive ? e->ml_ring.p : nullptr;
+        xa.ring_P = e->ring_P;
+        xa.ring_pos = rp++;
         int xrc = ext_step(e, e->levels[0], xa);
         if (xrc) return xrc;
         cc[0] += 1;
@@ -2481,6 +2484,9 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
           la.rec_params = ma.rec_params[q] ? ma.rec_params[q] + (size_t)row[q] * N * d : nullptr;
           la.rec_stats = ma.rec_stats[q] ? ma.rec_stats[q] + (size_t)row[q] * N * 3 : nullptr;
           la.rec_acc = ma.rec_acc[q] ? ma.rec_acc[q] + (size_t)row[q] * N : nullptr;
+          la.ring = adaptive ? e->ml_ring.p : nullptr;
+          la.ring_P = e->ring_P;
+          la.ring_pos = rp++;
           hipLaunchKernelGGL(k_ext_level_action, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, la);
           HIP_TRY(hipGetLastError());
           cc[k] = 0;

@@ -40,6 +40,9 @@ struct ExtArgs {
   double* rec_stats;
   unsigned char* rec_acc;
   int* anyacc;  // multi-level: set when this (base-level) step accepted -- "the subchain moved" (chain.py:357-364); may be null
+  unsigned char* ring;  // multi-level: the base proposal's `accepted` list as a ring [ring_P][NP] (scaling adaptation window,
+  int ring_P;           // proposal.py:236; it also receives the alignment entries of the levels above); may be null
+  long long ring_pos;   // absolute list position of this step's entry
 };
 
 constexpr int EXT_WAVES = 4;
@@ -112,6 +115,7 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_accept(const ExtArgs a) 
     if (lane == 0) {
       if (acc && a.acc_count) a.acc_count[c] += 1;
       if (acc && a.anyacc) a.anyacc[c] = 1;
+      if (a.ring) a.ring[(size_t)(a.ring_pos % a.ring_P) * a.NP + c] = acc ? 1 : 0;
       if (a.rec_stats) {
         a.rec_stats[r * 3 + 0] = lp;
         a.rec_stats[r * 3 + 1] = ll;
@@ -148,6 +152,9 @@ struct ExtLevelArgs {
   double* rec_params;   // row of this step (may be null)
   double* rec_stats;
   unsigned char* rec_acc;
+  unsigned char* ring;  // alignment entry in the base proposal's accepted window (chain.py:363,389,397; proposal.py:1486); may be null
+  int ring_P;
+  long long ring_pos;
 };
 
 __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_level_action(const ExtLevelArgs a) {
@@ -213,6 +220,7 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_level_action(const ExtLe
       a.rec_stats[c * 3 + 2] = l1 + l2;
     }
     if (a.rec_acc) a.rec_acc[c] = acc ? 1 : 0;
+    if (a.ring) a.ring[(size_t)(a.ring_pos % a.ring_P) * a.NP + c] = acc ? 1 : 0;
   }
   if (a.rec_params && lj) a.rec_params[c * a.d + lane] = acc ? yj : xj;
 }
