@@ -189,21 +189,23 @@ def test_source_model_hierarchy_matches_oracle(case):
         else:
             e.set_level_source(i, SRC_LEVEL % _level_cfg(k), y, 0, [0.05 ** 2])
     if case == "mlda_am":
-        e.set_proposal(2, 2e-3 * np.eye(d), t0=20, period=10)
-        prop = dict(kind="am", C0=2e-3 * np.eye(d), t0=20, period=10)
-    else:
-        e.set_proposal(1, None, scaling=0.04)
-        prop = dict(kind="pcn", scaling=0.04)
+        e.set_proposal(2, 2e-3 * np.eye(d), t0=20, period=10, adaptive=True, gamma=1.02)
+        prop = dict(kind="am", C0=2e-3 * np.eye(d), t0=20, period=10, adaptive=True, gamma=1.02)
+    else:  # adaptive scaling: the accept-flag window holds the base steps of the fused launches and the alignment entries
+        e.set_proposal(1, None, scaling=0.04, adaptive=True, gamma=1.02, period=15)
+        prop = dict(kind="pcn", scaling=0.04, adaptive=True, gamma=1.02, period=15)
     e.set_subchains(sl, False)
     e.init(theta0)
     rows = e.rows_per_level(n_fine)
     z, _ = e.set_export(rows[0])
     outs = e.run_levels_host(n_fine)
+    scal = e.proposal_state()["scaling"]
     e.close()
     us, _ = _oracle_uniforms(seed, N, rows, sl)
     prior = orc.MVNPrior(pm, np.diag(pv))
     levels = [orc.CallableGaussianLevel(twins[i], y, "iso", 0.05 ** 2, prior) for i in range(nl)]
-    res, _ = orc.run_multilevel(levels, prop, sl, theta0, np.swapaxes(z, 0, 1), us, n_fine, None)
+    res, pstate = orc.run_multilevel(levels, prop, sl, theta0, np.swapaxes(z, 0, 1), us, n_fine, None)
+    np.testing.assert_allclose(scal, pstate.scaling, rtol=1e-12)
     for i in range(nl):
         ref = res[i]
         sk = slice(1, None) if i == nl - 1 else slice(None)

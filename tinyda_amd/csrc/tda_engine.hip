@@ -2427,7 +2427,36 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
       int64_t row[MAXLEV] = {0, 0, 0, 0};
       int64_t rp = e->ring_pos;  // position in the base proposal's accepted list: one entry per base step and per level action
       for (int k = 0; k < MAXLEV; ++k) cc[k] = e->cnt[k];
-      for (int64_t s = 0; s < S; ++s) {
+      for (int64_t s = 0; s < S;) {
+        if (e->levels[0].model == MODEL_USER) {
+          // source-defined base level: the rest of the running subchain (inside this block) is ONE launch of the fused
+          // step kernel compiled with the model
+          const int64_t n = std::min<int64_t>(S - s, (int64_t)e->sl[0] - cc[0]);
+          UserStepArgs ua{};
+          int urc = fill_user_args(e, e->levels[0], ua);
+          if (urc) return urc;
+          ua.S = (int)n;
+          ua.mode = 0;
+          ua.prop_kind = e->pp.kind;
+          ua.theta = e->ml_theta.p;
+          ua.lp = e->ml_lp.p;
+          ua.ll = e->ml_ll.p;
+          ua.scaling = e->scaling.p;
+          ua.acc_count = nullptr;
+          ua.inc = e->inc.p + (size_t)s * NP * DP;
+          ua.u = e->ublk.p + (size_t)s * NP;
+          ua.rec_params = ma.rec_params[0] ? ma.rec_params[0] + (size_t)s * N * d : nullptr;
+          ua.rec_stats = ma.rec_stats[0] ? ma.rec_stats[0] + (size_t)s * N * 3 : nullptr;
+          ua.rec_acc = ma.rec_acc[0] ? ma.rec_acc[0] + (size_t)s * N : nullptr;
+          ua.anyacc = e->ml_anyacc.p;
+          ua.ring = adaptive ? e->ml_ring.p : nullptr;
+          ua.ring_P = e->ring_P;
+          ua.ring_pos = rp;
+          if ((urc = launch_user_steps(e->levels[0].ufn, ua, e->stream))) return urc;
+          rp += n;
+          s += n;
+          cc[0] += (int)n;
+        } else {
         ExtArgs xa{};
         fill_ext_args(e, e->levels[0], xa);
         xa.mode = 0;
@@ -2450,6 +2479,8 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
         int xrc = ext_step(e, e->levels[0], xa);
         if (xrc) return xrc;
         cc[0] += 1;
+        s += 1;
+        }
         for (int k = 0; k < nl - 1 && cc[k] == e->sl[k]; ++k) {
           const int q = k + 1;
           const Level& lq = e->levels[q];
