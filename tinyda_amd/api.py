@@ -52,9 +52,8 @@ def _device_plan(posteriors, proposal):
         if isinstance(proposal, DREAMZ):
             return None
         if len(posteriors) > 1:
-            if (not all("batched" in low or "source" in low for low in lows)
-                    or type(proposal) not in (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis)):
-                return None
+            if any("rosenbrock" in low or "prior_joint" in low for low in lows) or type(proposal) not in (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis):
+                return None  # (linear levels may be mixed in, e.g. a linear surrogate below a non-linear model)
         for low in lows:
             if low["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG) or np.count_nonzero(low["prior_cov"] - np.diag(np.diag(low["prior_cov"]))):
                 return None

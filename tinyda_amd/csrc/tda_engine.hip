@@ -163,6 +163,7 @@ struct Level {
   std::vector<double> A_h, ytil_h, data_h, cov_h;
   std::vector<double> w_h, Pinv_h;  // diagonal weights 1 / sigma_i^2, dense Sigma_e^-1 [m][m] (MALA's gradient operator)
   DevBuf<double> A_rm, ytil64, data64, cov64;  // error-model copies, row stride em_ld
+  DevBuf<double> A_dev;                        // hierarchies: row-major [m][d] for k_ext_linear_eval (host-sequenced mode)
   int em_ld = 0;                               // 64 (m <= 64) or 128 (m <= 128); 0: level too large for an error model
 };
 
@@ -246,6 +247,7 @@ struct tda_engine {
   // adaptive error model
   int aem = 0;
   int aem_m = 0, aem_ld = 64;
+  bool ext_hier = false;  // hierarchy with callback / source-defined levels: sequenced by the host (run_multilevel)
   DevBuf<double> aem_bias[tda::MAXLEV], aem_covinv[tda::MAXLEV], aem_bmu[tda::MAXLEV], aem_bsig[tda::MAXLEV], aem_mdiff[tda::MAXLEV];
   int64_t aem_bt[tda::MAXLEV] = {1, 1, 1, 1};
   DevBuf<int64_t> ml_sid;
@@ -482,6 +484,11 @@ void fill_ext_args(tda_engine* e, const Level& lv, ExtArgs& xa) {
 // page-locked staging buffers, one synchronisation) or a source-defined model (tda_user_eval, stays on the stream)
 int ext_model_outputs(tda_engine* e, const Level& lv) {
   if (lv.model == MODEL_USER) return launch_user_eval(lv.ufn_eval, e->N, e->d, lv.m, lv.cb_prop.p, lv.cb_F.p, e->stream);
+  if (lv.model == MODEL_LINEAR) {
+    hipLaunchKernelGGL(k_ext_linear_eval, dim3((unsigned)((e->N + EXT_WAVES - 1) / EXT_WAVES)), dim3(64 * EXT_WAVES), 0, e->stream,
+                       (long long)e->N, e->d, lv.m, lv.A_dev.p, lv.cb_prop.p, lv.cb_F.p);
+    return TDA_OK;
+  }
   HIP_TRY(hipMemcpyAsync(lv.cb_theta_h, lv.cb_prop.p, (size_t)e->N * e->d * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   const int crc = lv.cb_fn(lv.cb_user, lv.cb_theta_h, lv.cb_F_h, e->N, e->d, lv.m);
@@ -832,6 +839,19 @@ int tda_engine_set_level(tda_engine* e, int level, int m, const double* A, const
         for (int j = 0; j < m; ++j) c64[(size_t)i * AEM_MP + j] = lv.cov_h[(size_t)i * m + j];
       if ((rc = lv.cov64.upload(c64))) return rc;
     }
+  }
+  if (e->nlev > 1 && noise_kind != TDA_NOISE_DENSE && noise_kind != TDA_NOISE_ADAPTIVE) {
+    // a linear level may sit in a hierarchy with callback / source-defined levels, which is sequenced by the host: the
+    // level kernels of that mode take model outputs, residual data and weights from these buffers
+    std::vector<double> yd(lv.ytil_h.begin(), lv.ytil_h.begin() + m);
+    if ((rc = lv.A_dev.upload(lv.A_h))) return rc;
+    if ((rc = lv.udata.upload(yd))) return rc;
+    if (noise_kind == TDA_NOISE_DIAG) {
+      std::vector<double> wd(w.begin(), w.begin() + m);
+      if ((rc = lv.uw.upload(wd))) return rc;
+    }
+    if ((rc = lv.cb_prop.alloc((size_t)e->N * e->d))) return rc;
+    if ((rc = lv.cb_F.alloc((size_t)e->N * m))) return rc;
   }
   if ((rc = lv.Ppk.upload(Ppk))) return rc;
   if ((rc = lv.Apk.upload(Apk))) return rc;
@@ -1418,8 +1438,11 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
   {
     int n_cb = 0;
     for (auto& lv : e->levels) n_cb += (lv.model == MODEL_CALLBACK || lv.model == MODEL_USER) ? 1 : 0;
+    e->ext_hier = n_cb && e->nlev > 1;
     if (n_cb && e->nlev > 1) {  // Delayed Acceptance / MLDA with callback / source-defined models (host-sequenced level actions)
-      if (n_cb != e->nlev) return fail(TDA_ERR_UNSUPPORTED, "a hierarchy mixes callback / source-defined and linear forward models");
+      for (auto& lv : e->levels)  // linear levels may be mixed in (k_ext_linear_eval); anything else may not
+        if (lv.model != MODEL_CALLBACK && lv.model != MODEL_USER && (lv.model != MODEL_LINEAR || !lv.A_dev.p))
+          return fail(TDA_ERR_UNSUPPORTED, "hierarchies with callback / source-defined levels take linear levels with isotropic or diagonal noise beside them");
       if (e->randomize) return fail(TDA_ERR_UNSUPPORTED, "callback hierarchies: randomize_subchain_length is not lowered");
       if (e->aem) return fail(TDA_ERR_UNSUPPORTED, "callback hierarchies: the adaptive error model is not lowered");
       if (e->pp.kind != TDA_PROP_GRW && e->pp.kind != TDA_PROP_PCN && e->pp.kind != TDA_PROP_AM)
@@ -2418,7 +2441,7 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
       ma.rec_acc[k] = dev_a[k] ? oa + (size_t)rows_out[k] * N : (oa ? (second ? e->ml_rec_acc2[k].p : e->ml_rec_acc[k].p) : nullptr);
     }
     if (async_host && blk_ix >= 2) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_cp[blk_ix & 1], 0));  // buffer set free again
-    if (e->levels[0].model == MODEL_CALLBACK || e->levels[0].model == MODEL_USER) {
+    if (e->ext_hier) {
       // host-sequenced hierarchy (batched host callbacks and / or source-defined models): every base step is propose -> callback(level 0) -> accept; when the subchain of level
       // k completes, level k + 1's model is evaluated at the states of level k (one callback for all chains) and
       // k_ext_level_action decides, aligns and records (the cascade of k_ml_steps, one level at a time)

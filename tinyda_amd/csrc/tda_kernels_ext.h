@@ -127,6 +127,24 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_accept(const ExtArgs a) 
   }
 }
 
+// A linear level inside a host-sequenced hierarchy (e.g. a linear surrogate below a non-linear model): F = A prop for all
+// chains, one wave per chain, the lanes stride over the outputs (b is folded into the data vector the accept kernels subtract)
+__global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_linear_eval(long long N, int d, int m, const double* __restrict__ A,
+                                                                    const double* __restrict__ prop, double* __restrict__ F) {
+  __shared__ double s_th[EXT_WAVES][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long c = (long long)blockIdx.x * EXT_WAVES + wv;
+  if (c >= N) return;  // whole waves leave together
+  s_th[wv][lane] = lane < d ? prop[c * d + lane] : 0.0;
+  __builtin_amdgcn_wave_barrier();
+  for (int o = lane; o < m; o += 64) {
+    const double* __restrict__ Ao = A + (size_t)o * d;
+    double f = 0.0;
+    for (int j = 0; j < d; ++j) f = fma(Ao[j], s_th[wv][j], f);
+    F[c * m + o] = f;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Delayed Acceptance / MLDA with callback models: one step of level q >= 1 for every chain once the subchain of level
 // q - 1 has finished (DAChain.sample, chain.py:353-402; MLDA.make_mlda_proposal, proposal.py:1515-1545; MLDAChain.sample,
