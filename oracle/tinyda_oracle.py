@@ -707,7 +707,7 @@ def run_multilevel_aem(levels, proposal, subchain_lengths, theta0, z, u_levels, 
     N, d = theta0.shape
     nl = len(levels)
     sl = list(subchain_lengths)
-    m = levels[0]["A"].shape[0]
+    m = len(levels[0]["y"])  # a level is linear (A, optional b) or any batched callable theta[N, d] -> F[N, m] under "fn"
     prior = levels[0]["prior"]
     prop = _BaseProposalState(proposal, theta0, prior.cov)
     dependent = aem == "state-dependent"
@@ -715,6 +715,8 @@ def run_multilevel_aem(levels, proposal, subchain_lengths, theta0, z, u_levels, 
     is_da = nl == 2
 
     def forward(k, theta):
+        if levels[k].get("fn") is not None:
+            return np.asarray(levels[k]["fn"](theta), dtype=float)
         F = theta @ levels[k]["A"].T
         return F if levels[k].get("b") is None else F + levels[k]["b"]
 

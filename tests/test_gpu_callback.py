@@ -227,6 +227,10 @@ def test_callback_hierarchy_through_sample_api():
     assert len(res["chain_fine_2"]) == 31 and len(res["chain_coarse_2"]) == 90
     link = res["chain_fine_5"][-1]
     assert np.isclose(link.posterior, posts[1].create_link(link.parameters).posterior, rtol=1e-10)
-    with pytest.raises(tda.EngineError):  # the adaptive error model is not lowered for callback hierarchies: the engine says so
-        tda.sample([tda.Posterior(prior, tda.AdaptiveGaussianLogLike(y, 0.05 ** 2 * np.eye(M)), tda.BatchedModel(_level_model(1), M)), posts[1]],
-                   tda.CrankNicolson(scaling=0.04), 5, n_chains=4, subchain_length=2, adaptive_error_model="state-independent", backend="hip")
+    ada = [tda.Posterior(prior, tda.AdaptiveGaussianLogLike(y, 0.05 ** 2 * np.eye(M)), tda.BatchedModel(_level_model(1), M)), posts[1]]
+    aem = tda.sample(ada, tda.CrankNicolson(scaling=0.04), 12, n_chains=4, subchain_length=2, adaptive_error_model="state-independent",
+                     initial_parameters=th0[:4], seed=2, backend="hip")  # the state-independent error model runs behind callbacks too
+    lk = aem["chain_fine_1"][-1]
+    assert np.isclose(lk.posterior, posts[1].create_link(lk.parameters).posterior, rtol=1e-10)
+    with pytest.raises(tda.EngineError):  # the state-dependent one is not lowered for callback hierarchies: the engine says so
+        tda.sample(ada, tda.CrankNicolson(scaling=0.04), 5, n_chains=4, subchain_length=1, adaptive_error_model="state-dependent", backend="hip")

@@ -236,3 +236,89 @@ def test_source_model_hierarchy_through_sample_api():
     assert res["sampler"] == "DA" and res.get("backend", "hip") != "host"
     link = res["chain_fine_5"][-1]
     assert np.isclose(link.posterior, posts[1].create_link(link.parameters).posterior, rtol=1e-10)
+
+
+@pytest.mark.parametrize("case", ["da_source", "mlda_mixed"])
+def test_hierarchy_with_error_model_matches_oracle(case):
+    """State-independent adaptive error model over non-linear models: source-defined levels (DA), and a 3-level MLDA
+    hierarchy of a linear surrogate, a batched host callback and a source-defined finest level -- against the oracle's
+    restatement of the reference's error-model chains running the NumPy twins."""
+    from tests.test_gpu_multilevel import _oracle_uniforms
+    from tinyda_amd.engine import Engine
+
+    d, m, N = 5, 23, 17
+    rng = np.random.default_rng(21)
+    truth = 0.5 * rng.standard_normal(d)
+    if case == "mlda_mixed":
+        ks, sl, n_fine = [0, 1, 2], [3, 2], 12
+    else:
+        ks, sl, n_fine = [1, 2], [3], 22
+    nl = len(ks)
+    twins = [np_level_model(k) for k in ks]
+    Alin = np.array([[(0.1 + 0.01 * ((o * 7 + j * 3) % 11)) for j in range(d)] for o in range(m)])
+    blin = 0.01 * np.arange(m)
+    if case == "mlda_mixed":
+        twins[0] = lambda th: np.atleast_2d(th) @ Alin.T + blin
+    y = twins[-1](truth)[0] + 0.05 * rng.standard_normal(m)
+    theta0 = truth + 0.05 * rng.standard_normal((N, d))
+    pm, pv = np.zeros(d), np.ones(d)
+    var = 0.05 ** 2
+    cov = var * np.eye(m)
+    seed = 313
+    e = Engine(N, d, seed=seed, n_levels=nl)
+    e.set_prior(pm, np.diag(pv))
+    for i, k in enumerate(ks):
+        last = i == nl - 1
+        if case == "mlda_mixed" and i == 0:
+            e.set_level(0, Alin, y, 3, cov, b=blin)
+        elif case == "mlda_mixed" and i == 1:
+            e.set_level_callback(1, twins[1], y, 3, cov)
+        else:
+            e.set_level_source(i, SRC_LEVEL % _level_cfg(k), y, 0 if last else 3, [var] if last else cov)
+    e.set_proposal(0, 2e-3 * np.eye(d), scaling=1.0)
+    prop = dict(kind="grw", C=2e-3 * np.eye(d), scaling=1.0)
+    e.set_subchains(sl, False)
+    e.set_error_model("state-independent")
+    e.init(theta0)
+    rows = e.rows_per_level(n_fine)
+    z, _ = e.set_export(rows[0])
+    _, st_init = e.level_state(nl - 1)
+    outs = e.run_levels_host(n_fine)
+    bias, P = e.error_model_state(0, m)
+    e.close()
+    us, _ = _oracle_uniforms(seed, N, rows, sl)
+    prior = orc.MVNPrior(pm, np.diag(pv))
+    levels = [dict(fn=twins[i], y=y, prior=prior, **(dict(var=var) if i == nl - 1 else dict(cov=cov))) for i in range(nl)]
+    res = orc.run_multilevel_aem(levels, prop, sl, theta0, np.swapaxes(z, 0, 1), us, n_fine, "state-independent")
+    res = res[0] if isinstance(res, tuple) else res
+    for i in range(nl):
+        ref = res[i]
+        sk = slice(1, None) if i == nl - 1 else slice(None)
+        assert np.array_equal(outs[i][2], np.asarray(ref["accepted"])[:, sk].T), "level %d accept masks differ" % i
+        np.testing.assert_allclose(outs[i][0], np.swapaxes(np.asarray(ref["theta"])[:, sk], 0, 1), rtol=1e-9, atol=1e-11)
+        if i == nl - 1:  # coarse links are refreshed after they were recorded (update_link), the finest never is
+            np.testing.assert_allclose(outs[i][1][:, :, 2], (np.asarray(ref["logprior"]) + np.asarray(ref["loglike"]))[:, sk].T, rtol=1e-10)
+    assert 0.05 < outs[nl - 1][2].mean() < 0.98 and np.all(np.isfinite(bias)) and np.all(np.isfinite(P))
+
+
+def test_sample_api_hierarchy_with_error_model():
+    """tda.sample([...], adaptive_error_model='state-independent') with AdaptiveGaussianLogLike over a batched host model
+    (coarse) and a source-defined model (fine)."""
+    import tinyda_amd as tda
+
+    d, m = 5, 23
+    rng = np.random.default_rng(31)
+    truth = 0.4 * rng.standard_normal(d)
+    y = np_level_model(2)(truth)[0] + 0.05 * rng.standard_normal(m)
+    prior = st.multivariate_normal(np.zeros(d), np.eye(d))
+    cov = 0.05 ** 2 * np.eye(m)
+    posts = [tda.Posterior(prior, tda.AdaptiveGaussianLogLike(y, cov), tda.BatchedModel(np_level_model(1), m)),
+             tda.Posterior(prior, tda.GaussianLogLike(y, cov),
+                           tda.DeviceModel(SRC_LEVEL % _level_cfg(2), m, reference=lambda th: np_level_model(2)(th)[0]))]
+    th0 = [truth + 0.05 * rng.standard_normal(d) for _ in range(8)]
+    res = tda.sample(posts, tda.GaussianRandomWalk(2e-3 * np.eye(d)), 25, n_chains=8, initial_parameters=th0, subchain_length=3,
+                     adaptive_error_model="state-independent", seed=5)
+    assert res["sampler"] == "DA" and res.get("backend", "hip") != "host"
+    link = res["chain_fine_3"][-1]
+    assert np.isclose(link.posterior, posts[1].create_link(link.parameters).posterior, rtol=1e-10)
+    assert np.mean([np.mean(res["chain_fine_%d" % i].accepted[1:]) for i in range(8)]) > 0.05

@@ -31,7 +31,7 @@ def _device_plan(posteriors, proposal):
         low = getattr(post, "_lowering", lambda: None)()
         if low is None or low["prior_mean"].shape[0] > 64:
             return None
-        if low["noise_kind"] == _lib.NOISE_ADAPTIVE and (len(posteriors) < 2 or low["A"] is None or low["A"].shape[0] > 128):
+        if low["noise_kind"] == _lib.NOISE_ADAPTIVE and (len(posteriors) < 2 or np.asarray(low["data"]).shape[0] > 128):
             return None  # AdaptiveGaussianLogLike: coarse levels of a hierarchy, m <= 128 on the device
         if low["noise_kind"] == _lib.NOISE_DENSE and (len(posteriors) != 1 or isinstance(proposal, DREAMZ)
                                                       or low["A"] is None or low["A"].shape[0] > 1024):
@@ -54,8 +54,9 @@ def _device_plan(posteriors, proposal):
         if len(posteriors) > 1:
             if any("rosenbrock" in low or "prior_joint" in low for low in lows) or type(proposal) not in (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis):
                 return None  # (linear levels may be mixed in, e.g. a linear surrogate below a non-linear model)
-        for low in lows:
-            if low["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG) or np.count_nonzero(low["prior_cov"] - np.diag(np.diag(low["prior_cov"]))):
+        for i, low in enumerate(lows):
+            ok_noise = low["noise_kind"] in (_lib.NOISE_ISO, _lib.NOISE_DIAG) or (low["noise_kind"] == _lib.NOISE_ADAPTIVE and i < len(lows) - 1)
+            if not ok_noise or np.count_nonzero(low["prior_cov"] - np.diag(np.diag(low["prior_cov"]))):
                 return None
     if isinstance(proposal, MALA):  # exact gradient of a linear-Gaussian posterior: single level, linear model, Gaussian prior
         if len(posteriors) != 1 or "source" in lows[0] or "batched" in lows[0] or "rosenbrock" in lows[0] or "prior_joint" in lows[0]:

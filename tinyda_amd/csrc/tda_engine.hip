@@ -163,7 +163,7 @@ struct Level {
   std::vector<double> A_h, ytil_h, data_h, cov_h;
   std::vector<double> w_h, Pinv_h;  // diagonal weights 1 / sigma_i^2, dense Sigma_e^-1 [m][m] (MALA's gradient operator)
   DevBuf<double> A_rm, ytil64, data64, cov64;  // error-model copies, row stride em_ld
-  DevBuf<double> A_dev;                        // hierarchies: row-major [m][d] for k_ext_linear_eval (host-sequenced mode)
+  DevBuf<double> A_dev, b_dev;                 // hierarchies: row-major [m][d] and offset [m] for k_ext_linear_eval (host-sequenced mode)
   int em_ld = 0;                               // 64 (m <= 64) or 128 (m <= 128); 0: level too large for an error model
 };
 
@@ -248,6 +248,7 @@ struct tda_engine {
   int aem = 0;
   int aem_m = 0, aem_ld = 64;
   bool ext_hier = false;  // hierarchy with callback / source-defined levels: sequenced by the host (run_multilevel)
+  DevBuf<double> ext_Fcur[tda::MAXLEV], ext_Fst;  // error model there: outputs of the current links [NP][MP], of level j at theta_q [npairs][NP][MP]
   DevBuf<double> aem_bias[tda::MAXLEV], aem_covinv[tda::MAXLEV], aem_bmu[tda::MAXLEV], aem_bsig[tda::MAXLEV], aem_mdiff[tda::MAXLEV];
   int64_t aem_bt[tda::MAXLEV] = {1, 1, 1, 1};
   DevBuf<int64_t> ml_sid;
@@ -480,13 +481,36 @@ void fill_ext_args(tda_engine* e, const Level& lv, ExtArgs& xa) {
   xa.logconst = e->prior_logconst;
 }
 
+// AdaptiveGaussianLogLike on a callback / source-defined level: host and device copies of Sigma_e and the data vector in
+// the error-model layout (row stride 64 / 128), as tda_engine_set_level keeps them for linear levels
+int ext_level_adaptive(tda_engine* e, Level& lv, int m, const double* data, const double* cov) {
+  if (m > AEM_MP_MAX) return fail(TDA_ERR_UNSUPPORTED, "AdaptiveGaussianLogLike on the device is limited to m <= %d observations", (int)AEM_MP_MAX);
+  std::vector<double> Lc;
+  if (!cholesky_host(cov, m, Lc)) return fail(TDA_ERR_NUMERIC, "noise covariance is not positive definite");
+  const int MP = m <= 64 ? 64 : 128;
+  lv.em_ld = MP;
+  lv.cov_h.assign(cov, cov + (size_t)m * m);
+  lv.ytil_h.assign(MP, 0.0);
+  lv.data_h.assign(MP, 0.0);
+  for (int i = 0; i < m; ++i) lv.ytil_h[i] = lv.data_h[i] = data[i];
+  std::vector<double> c64((size_t)MP * MP, 0.0);
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < m; ++j) c64[(size_t)i * MP + j] = cov[(size_t)i * m + j];
+  int rc;
+  if ((rc = lv.cov64.upload(c64))) return rc;
+  if ((rc = lv.data64.upload(lv.data_h))) return rc;
+  if ((rc = lv.ytil64.upload(lv.ytil_h))) return rc;
+  lv.var = 1.0;
+  return TDA_OK;
+}
+
 // F[N][m] <- model(prop[N][d]) of a level whose model lives outside the engine's kernels: a batched host callback (through
 // page-locked staging buffers, one synchronisation) or a source-defined model (tda_user_eval, stays on the stream)
 int ext_model_outputs(tda_engine* e, const Level& lv) {
   if (lv.model == MODEL_USER) return launch_user_eval(lv.ufn_eval, e->N, e->d, lv.m, lv.cb_prop.p, lv.cb_F.p, e->stream);
   if (lv.model == MODEL_LINEAR) {
     hipLaunchKernelGGL(k_ext_linear_eval, dim3((unsigned)((e->N + EXT_WAVES - 1) / EXT_WAVES)), dim3(64 * EXT_WAVES), 0, e->stream,
-                       (long long)e->N, e->d, lv.m, lv.A_dev.p, lv.cb_prop.p, lv.cb_F.p);
+                       (long long)e->N, e->d, lv.m, lv.A_dev.p, lv.b_dev.p, lv.cb_prop.p, lv.cb_F.p);
     return TDA_OK;
   }
   HIP_TRY(hipMemcpyAsync(lv.cb_theta_h, lv.cb_prop.p, (size_t)e->N * e->d * sizeof(double), hipMemcpyDeviceToHost, e->stream));
@@ -840,11 +864,13 @@ int tda_engine_set_level(tda_engine* e, int level, int m, const double* A, const
       if ((rc = lv.cov64.upload(c64))) return rc;
     }
   }
-  if (e->nlev > 1 && noise_kind != TDA_NOISE_DENSE && noise_kind != TDA_NOISE_ADAPTIVE) {
+  if (e->nlev > 1 && noise_kind != TDA_NOISE_DENSE) {
     // a linear level may sit in a hierarchy with callback / source-defined levels, which is sequenced by the host: the
     // level kernels of that mode take model outputs, residual data and weights from these buffers
-    std::vector<double> yd(lv.ytil_h.begin(), lv.ytil_h.begin() + m);
+    std::vector<double> yd(lv.data_h.begin(), lv.data_h.begin() + m), bd(m, 0.0);
+    for (int i = 0; i < m; ++i) bd[i] = b ? b[i] : 0.0;
     if ((rc = lv.A_dev.upload(lv.A_h))) return rc;
+    if ((rc = lv.b_dev.upload(bd))) return rc;
     if ((rc = lv.udata.upload(yd))) return rc;
     if (noise_kind == TDA_NOISE_DIAG) {
       std::vector<double> wd(w.begin(), w.begin() + m);
@@ -930,8 +956,8 @@ int tda_engine_set_level_source(tda_engine* e, int level, const char* source, in
   if (!e || !source || !data || !noise) return fail(TDA_ERR_INVALID, "null argument");
   if (level < 0 || level >= (int)e->levels.size()) return fail(TDA_ERR_INVALID, "level %d out of range", level);
   if (m < 1) return fail(TDA_ERR_INVALID, "m must be >= 1");
-  if (noise_kind != TDA_NOISE_ISO && noise_kind != TDA_NOISE_DIAG)
-    return fail(TDA_ERR_UNSUPPORTED, "source-defined forward models take isotropic or diagonal noise");
+  if (noise_kind != TDA_NOISE_ISO && noise_kind != TDA_NOISE_DIAG && !(noise_kind == TDA_NOISE_ADAPTIVE && e->nlev > 1))
+    return fail(TDA_ERR_UNSUPPORTED, "source-defined forward models take isotropic or diagonal noise (AdaptiveGaussianLogLike below the finest level of a hierarchy)");
   HIP_TRY(hipSetDevice(e->cfg.device));
   Level& lv = e->levels[level];
   if (lv.umod) {
@@ -943,7 +969,9 @@ int tda_engine_set_level_source(tda_engine* e, int level, const char* source, in
   int rc = compile_user_model(source, &lv.umod, &lv.ufn, &lv.ufn_eval);
   if (rc) return rc;
   std::vector<double> y(data, data + m), w;
-  if (noise_kind == TDA_NOISE_ISO) {
+  if (noise_kind == TDA_NOISE_ADAPTIVE) {
+    if ((rc = ext_level_adaptive(e, lv, m, data, noise))) return rc;
+  } else if (noise_kind == TDA_NOISE_ISO) {
     if (!(noise[0] > 0.0)) return fail(TDA_ERR_NUMERIC, "noise variance must be positive");
     lv.var = noise[0];
   } else {
@@ -956,6 +984,13 @@ int tda_engine_set_level_source(tda_engine* e, int level, const char* source, in
     if ((rc = lv.uw.upload(w))) return rc;
   }
   if ((rc = lv.udata.upload(y))) return rc;
+  if (noise_kind != TDA_NOISE_ADAPTIVE) {  // host / padded device copies of the data (error-model initialisation and kernels)
+    const int mp = m > 128 ? m : 128;
+    lv.ytil_h.assign(mp, 0.0);
+    lv.data_h.assign(mp, 0.0);
+    for (int i = 0; i < m; ++i) lv.ytil_h[i] = lv.data_h[i] = data[i];
+    if ((rc = lv.data64.upload(lv.data_h))) return rc;
+  }
   if (e->nlev > 1) {  // hierarchy: proposals / outputs of a level step pass through device buffers (tda_user_eval)
     if ((rc = lv.cb_prop.alloc((size_t)e->N * e->d))) return rc;
     if ((rc = lv.cb_F.alloc((size_t)e->N * m))) return rc;
@@ -975,13 +1010,15 @@ int tda_engine_set_level_callback(tda_engine* e, int level, tda_forward_batch_fn
   if (!e || !fn || !data || !noise) return fail(TDA_ERR_INVALID, "null argument");
   if (level < 0 || level >= (int)e->levels.size()) return fail(TDA_ERR_INVALID, "level %d out of range", level);
   if (m < 1) return fail(TDA_ERR_INVALID, "m must be >= 1");
-  if (noise_kind != TDA_NOISE_ISO && noise_kind != TDA_NOISE_DIAG)
-    return fail(TDA_ERR_UNSUPPORTED, "callback forward models take isotropic or diagonal noise");
+  if (noise_kind != TDA_NOISE_ISO && noise_kind != TDA_NOISE_DIAG && !(noise_kind == TDA_NOISE_ADAPTIVE && e->nlev > 1))
+    return fail(TDA_ERR_UNSUPPORTED, "callback forward models take isotropic or diagonal noise (AdaptiveGaussianLogLike below the finest level of a hierarchy)");
   HIP_TRY(hipSetDevice(e->cfg.device));
   Level& lv = e->levels[level];
   std::vector<double> y(data, data + m), w;
   int rc;
-  if (noise_kind == TDA_NOISE_ISO) {
+  if (noise_kind == TDA_NOISE_ADAPTIVE) {
+    if ((rc = ext_level_adaptive(e, lv, m, data, noise))) return rc;
+  } else if (noise_kind == TDA_NOISE_ISO) {
     if (!(noise[0] > 0.0)) return fail(TDA_ERR_NUMERIC, "noise variance must be positive");
     lv.var = noise[0];
   } else {
@@ -994,6 +1031,13 @@ int tda_engine_set_level_callback(tda_engine* e, int level, tda_forward_batch_fn
     if ((rc = lv.uw.upload(w))) return rc;
   }
   if ((rc = lv.udata.upload(y))) return rc;
+  if (noise_kind != TDA_NOISE_ADAPTIVE) {  // host / padded device copies of the data (error-model initialisation and kernels)
+    const int mp = m > 128 ? m : 128;
+    lv.ytil_h.assign(mp, 0.0);
+    lv.data_h.assign(mp, 0.0);
+    for (int i = 0; i < m; ++i) lv.ytil_h[i] = lv.data_h[i] = data[i];
+    if ((rc = lv.data64.upload(lv.data_h))) return rc;
+  }
   lv.release_callback_buffers();
   HIP_TRY(hipHostMalloc((void**)&lv.cb_theta_h, (size_t)e->N * e->d * sizeof(double), hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&lv.cb_F_h, (size_t)e->N * m * sizeof(double), hipHostMallocDefault));
@@ -1237,6 +1281,7 @@ void enumerate_state(tda_engine* e, std::vector<StateItem>& v) {
       dev(e->aem_bmu[k]);
       dev(e->aem_bsig[k]);
       dev(e->aem_mdiff[k]);
+      dev(e->ext_Fcur[k]);
     }
   }
   if (e->is_dreamz) {
@@ -1444,7 +1489,7 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
         if (lv.model != MODEL_CALLBACK && lv.model != MODEL_USER && (lv.model != MODEL_LINEAR || !lv.A_dev.p))
           return fail(TDA_ERR_UNSUPPORTED, "hierarchies with callback / source-defined levels take linear levels with isotropic or diagonal noise beside them");
       if (e->randomize) return fail(TDA_ERR_UNSUPPORTED, "callback hierarchies: randomize_subchain_length is not lowered");
-      if (e->aem) return fail(TDA_ERR_UNSUPPORTED, "callback hierarchies: the adaptive error model is not lowered");
+      if (e->aem == TDA_AEM_STATE_DEPENDENT) return fail(TDA_ERR_UNSUPPORTED, "callback / source-defined hierarchies: the state-dependent error model is not lowered");
       if (e->pp.kind != TDA_PROP_GRW && e->pp.kind != TDA_PROP_PCN && e->pp.kind != TDA_PROP_AM)
         return fail(TDA_ERR_UNSUPPORTED, "callback hierarchies take GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis proposals");
       if (e->prior_kind == PRIOR_DENSE) return fail(TDA_ERR_UNSUPPORTED, "callback forward models need a diagonal prior covariance");
@@ -1763,6 +1808,24 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
       std::vector<double> th((size_t)NP * DP), lph(NP);
       HIP_TRY(hipMemcpy(th.data(), e->theta.p, th.size() * sizeof(double), hipMemcpyDeviceToHost));
       std::vector<std::vector<double>> F(nl, std::vector<double>((size_t)N * m));
+      if (e->ext_hier) {
+        // callback / source-defined (and linear) levels of a host-sequenced hierarchy: the model outputs at theta0 come
+        // from the same evaluation path the steps use
+        for (int k = 0; k < nl; ++k) {
+          const Level& lvk = e->levels[k];
+          ExtArgs ya{};
+          fill_ext_args(e, lvk, ya);
+          ya.mode = 1;
+          ya.theta = e->theta.p;
+          ya.scaling = e->scaling.p;
+          hipLaunchKernelGGL(k_ext_propose, dim3((unsigned)((N + EXT_WAVES - 1) / EXT_WAVES)), dim3(64 * EXT_WAVES), 0, e->stream, ya);
+          if ((rc = ext_model_outputs(e, lvk))) return rc;
+          HIP_TRY(hipStreamSynchronize(e->stream));
+          HIP_TRY(hipMemcpy(F[k].data(), lvk.cb_F.p, F[k].size() * sizeof(double), hipMemcpyDeviceToHost));
+          for (int64_t c = 0; c < N; ++c)
+            for (int o = 0; o < m; ++o) F[k][(size_t)c * m + o] -= lvk.data_h[o];  // residual form; Fout() adds the data back
+        }
+      } else
       for (int k = 0; k < nl; ++k)
         for (int64_t c = 0; c < N; ++c)
           for (int o = 0; o < m; ++o) {
@@ -1832,6 +1895,19 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
           HIP_TRY(hipMemcpy(e->ml_S.p + ((size_t)p * 2 + 0) * NP, e->ml_lp.p + (size_t)j * NP, NP * sizeof(double), hipMemcpyDeviceToDevice));
           HIP_TRY(hipMemcpy(e->ml_S.p + ((size_t)p * 2 + 1) * NP, e->ml_ll.p + (size_t)j * NP, NP * sizeof(double), hipMemcpyDeviceToDevice));
         }
+      if (e->ext_hier) {  // model outputs of the current links and of level j at theta_q: all at theta0
+        const int npair = nl * (nl - 1) / 2;
+        std::vector<std::vector<double>> Fo(nl, std::vector<double>((size_t)NP * AEM_MP, 0.0));
+        for (int k = 0; k < nl; ++k) {
+          for (int64_t c = 0; c < N; ++c)
+            for (int o = 0; o < m; ++o) Fo[k][(size_t)c * AEM_MP + o] = Fout(k, c, o);
+          if ((rc = e->ext_Fcur[k].upload(Fo[k]))) return rc;
+        }
+        if ((rc = e->ext_Fst.alloc((size_t)npair * NP * AEM_MP))) return rc;
+        for (int qq = 1; qq < nl; ++qq)
+          for (int j = 0; j < qq; ++j)
+            HIP_TRY(hipMemcpy(e->ext_Fst.p + (size_t)(qq * (qq - 1) / 2 + j) * NP * AEM_MP, Fo[j].data(), Fo[j].size() * sizeof(double), hipMemcpyHostToDevice));
+      }
       // whitening matrix of the prior, row-major (pCN transition densities of the state-dependent acceptance)
       std::vector<double> Wp;
       tri_inverse_host(e->prior_L_h, d, Wp);
@@ -2451,7 +2527,7 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
       int64_t rp = e->ring_pos;  // position in the base proposal's accepted list: one entry per base step and per level action
       for (int k = 0; k < MAXLEV; ++k) cc[k] = e->cnt[k];
       for (int64_t s = 0; s < S;) {
-        if (e->levels[0].model == MODEL_USER) {
+        if (e->levels[0].model == MODEL_USER && !e->aem) {
           // source-defined base level: the rest of the running subchain (inside this block) is ONE launch of the fused
           // step kernel compiled with the model
           const int64_t n = std::min<int64_t>(S - s, (int64_t)e->sl[0] - cc[0]);
@@ -2479,6 +2555,56 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
           rp += n;
           s += n;
           cc[0] += (int)n;
+        } else if (e->aem) {
+          // base step under the bias-corrected likelihood of the error model (per-chain bias and inverse)
+          const Level& l0 = e->levels[0];
+          ExtArgs pa2{};
+          fill_ext_args(e, l0, pa2);
+          pa2.mode = 0;
+          pa2.prop_kind = e->pp.kind;
+          pa2.theta = e->ml_theta.p;
+          pa2.scaling = e->scaling.p;
+          pa2.inc = e->inc.p;
+          pa2.s = (int)s;
+          hipLaunchKernelGGL(k_ext_propose, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, pa2);
+          int mrc0 = ext_model_outputs(e, l0);
+          if (mrc0) return mrc0;
+          ExtAemAcceptArgs ea{};
+          ea.N = N;
+          ea.NP = NP;
+          ea.d = d;
+          ea.DP = DP;
+          ea.m = e->aem_m;
+          ea.MP = e->aem_ld;
+          ea.s = (int)s;
+          ea.prop_kind = e->pp.kind;
+          ea.theta = e->ml_theta.p;
+          ea.lp = e->ml_lp.p;
+          ea.ll = e->ml_ll.p;
+          ea.u = e->ublk.p;
+          ea.prop = l0.cb_prop.p;
+          ea.F = l0.cb_F.p;
+          ea.data = l0.data64.p;
+          ea.bias = e->aem_bias[0].p;
+          ea.P = e->aem_covinv[0].p;
+          ea.Fcur = e->ext_Fcur[0].p;
+          ea.pr_mean = e->prior_mean.p;
+          ea.pr_pinv = e->prior_pinv.p;
+          ea.logconst = e->prior_logconst;
+          ea.anyacc = e->ml_anyacc.p;
+          ea.sid = e->ml_sid.p;
+          ea.sid_value = e->done[0] + s + 1;
+          ea.ring = adaptive ? e->ml_ring.p : nullptr;
+          ea.ring_P = e->ring_P;
+          ea.ring_pos = rp++;
+          ea.rec_params = ma.rec_params[0];
+          ea.rec_stats = ma.rec_stats[0];
+          ea.rec_acc = ma.rec_acc[0];
+          if (e->aem_ld == 64) hipLaunchKernelGGL(k_ext_aem_accept<64>, dim3((unsigned)N), dim3(64), 0, e->stream, ea);
+          else hipLaunchKernelGGL(k_ext_aem_accept<128>, dim3((unsigned)N), dim3(128), 0, e->stream, ea);
+          HIP_TRY(hipGetLastError());
+          cc[0] += 1;
+          s += 1;
         } else {
         ExtArgs xa{};
         fill_ext_args(e, e->levels[0], xa);
@@ -2514,6 +2640,74 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
           hipLaunchKernelGGL(k_ext_propose, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, ya);
           const int mrc = ext_model_outputs(e, lq);
           if (mrc) return mrc;
+          if (e->aem) {
+            ExtAemArgs ga{};
+            ga.N = N;
+            ga.NP = NP;
+            ga.chain_offset = e->cfg.chain_offset;
+            ga.d = d;
+            ga.DP = DP;
+            ga.m = e->aem_m;
+            ga.MP = e->aem_ld;
+            ga.nlev = nl;
+            ga.q = q;
+            ga.is_da = nl == 2;
+            ga.seed = e->cfg.seed;
+            ga.step = e->done[q] + row[q];
+            ga.Fnew = lq.cb_F.p;
+            for (int k2 = 0; k2 < nl; ++k2) {
+              ga.data[k2] = e->levels[k2].data64.p;
+              ga.Fcur[k2] = e->ext_Fcur[k2].p;
+              ga.bias_tot[k2] = e->aem_bias[k2].p;
+              ga.cov_inv[k2] = e->aem_covinv[k2].p;
+              ga.b_mu[k2] = e->aem_bmu[k2].p;
+              ga.b_sig[k2] = e->aem_bsig[k2].p;
+              ga.mdiff[k2] = e->aem_mdiff[k2].p;
+            }
+            ga.var_finest = e->levels[nl - 1].var;
+            ga.Fst = e->ext_Fst.p;
+            ga.theta = e->ml_theta.p;
+            ga.lp = e->ml_lp.p;
+            ga.ll = e->ml_ll.p;
+            ga.Sst = e->ml_S.p;
+            ga.anyacc = e->ml_anyacc.p;
+            ga.sid = e->ml_sid.p;
+            ga.b_t = e->aem_bt[q];
+            ga.u_rep = ma.u_rep[q] ? ma.u_rep[q] + (size_t)row[q] * N : nullptr;
+            ga.ring = adaptive ? e->ml_ring.p : nullptr;
+            ga.ring_P = e->ring_P;
+            ga.ring_pos = rp++;
+            ga.rec_params = ma.rec_params[q] ? ma.rec_params[q] + (size_t)row[q] * N * d : nullptr;
+            ga.rec_stats = ma.rec_stats[q] ? ma.rec_stats[q] + (size_t)row[q] * N * 3 : nullptr;
+            ga.rec_acc = ma.rec_acc[q] ? ma.rec_acc[q] + (size_t)row[q] * N : nullptr;
+            AemInvArgs iv{};
+            iv.N = N;
+            iv.m = e->aem_m;
+            iv.MP = e->aem_ld;
+            iv.nb = (e->aem_m + 15) / 16;
+            iv.cov = e->levels[k].cov64.p;
+            iv.nsum = nl - q;
+            for (int p2 = q; p2 < nl; ++p2) iv.sig[p2 - q] = e->aem_bsig[p2].p;
+            iv.P = e->aem_covinv[k].p;
+            const size_t inv_lds = aem_inverse_lds_bytes(iv.nb);
+            if (inv_lds > 64 * 1024)
+              HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aem_inverse<0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)inv_lds));
+            for (int phase = 0; phase < 2; ++phase) {
+              ga.phase = phase;
+              if (e->aem_ld == 64) hipLaunchKernelGGL(k_ext_aem_action<64>, dim3((unsigned)N), dim3(64), 0, e->stream, ga);
+              else hipLaunchKernelGGL(k_ext_aem_action<128>, dim3((unsigned)N), dim3(128), 0, e->stream, ga);
+              if (phase == 0) {
+                if (iv.nb > 4) hipLaunchKernelGGL((k_aem_inverse<0, 8>), dim3((unsigned)N), dim3(512), inv_lds, e->stream, iv);
+                else hipLaunchKernelGGL((k_aem_inverse<0, 4>), dim3((unsigned)N), dim3(256), inv_lds, e->stream, iv);
+              }
+            }
+            HIP_TRY(hipGetLastError());
+            e->aem_bt[q] += 1;
+            cc[k] = 0;
+            cc[q] += 1;
+            row[q] += 1;
+            continue;
+          }
           ExtLevelArgs la{};
           la.N = N;
           la.NP = NP;
@@ -2600,7 +2794,7 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
     HIP_TRY(hipGetLastError());
     if (boundary && adaptive) e->k_adapt += 1;
 
-    if (e->aem) {
+    if (e->aem && !e->ext_hier) {
       // host-sequenced upper levels: decision of level q, then the error-model update of level q-1, in ascending q
       int64_t extra = 0;
       for (int qq = 1; qq < nl; ++qq) {

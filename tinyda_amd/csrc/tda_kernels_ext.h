@@ -128,8 +128,9 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_accept(const ExtArgs a) 
 }
 
 // A linear level inside a host-sequenced hierarchy (e.g. a linear surrogate below a non-linear model): F = A prop for all
-// chains, one wave per chain, the lanes stride over the outputs (b is folded into the data vector the accept kernels subtract)
+// chains (F = A prop + b), one wave per chain, the lanes stride over the outputs
 __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_linear_eval(long long N, int d, int m, const double* __restrict__ A,
+                                                                    const double* __restrict__ bvec,
                                                                     const double* __restrict__ prop, double* __restrict__ F) {
   __shared__ double s_th[EXT_WAVES][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -141,7 +142,7 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_linear_eval(long long N,
     const double* __restrict__ Ao = A + (size_t)o * d;
     double f = 0.0;
     for (int j = 0; j < d; ++j) f = fma(Ao[j], s_th[wv][j], f);
-    F[c * m + o] = f;
+    F[c * m + o] = f + bvec[o];
   }
 }
 

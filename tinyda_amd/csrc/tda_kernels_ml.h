@@ -735,6 +735,311 @@ __global__ void __launch_bounds__(MPT) k_aem_action(const AemArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The state-independent error model for hierarchies whose models live outside the engine's kernels (batched host
+// callbacks, source-defined models, linear levels beside them).  Same algorithm as k_aem_action, but a model output is
+// never recomputed from a matrix: every level keeps the output of its current link (Fcur), every pair (j, q) the output
+// of level j at theta_q (Fst, the companion of the densities in Sst), and the host hands in level q's fresh evaluation
+// at theta_{q-1} (Fnew).  Phase 0: decision, alignment, tracker update, total bias, output bookkeeping; k_aem_inverse;
+// phase 1: update_link of level q - 1.  k_ext_aem_accept is the base-level step under the bias-corrected likelihood.
+// ------------------------------------------------------------------------------------------------
+struct ExtAemArgs {
+  int64_t N, NP, chain_offset;
+  int d, DP, m, MP, nlev, q, is_da, phase;
+  uint64_t seed;
+  int64_t step;
+  const double* Fnew;          // [N][m] level q at theta_{q-1}
+  const double* data[MAXLEV];  // [MP]
+  double var_finest;
+  double* Fcur[MAXLEV];        // [NP][MP]
+  double* Fst;                 // [npairs][NP][MP]
+  double* theta;               // [nlev][NP][DP]
+  double* lp;
+  double* ll;
+  double* Sst;
+  int32_t* anyacc;
+  int64_t* sid;
+  double* bias_tot[MAXLEV];
+  double* cov_inv[MAXLEV];
+  double* b_mu[MAXLEV];
+  double* b_sig[MAXLEV];
+  double* mdiff[MAXLEV];
+  int64_t b_t;
+  const double* u_rep;
+  uint8_t* ring;
+  int ring_P;
+  int64_t ring_pos;
+  double* rec_params;
+  double* rec_stats;
+  uint8_t* rec_acc;
+};
+
+template <int MPT>
+__global__ void __launch_bounds__(MPT) k_ext_aem_action(const ExtAemArgs a) {
+  constexpr int NW = MPT / 64;
+  __shared__ double s_v[4 * MPT];
+  __shared__ double s_x[8];
+  const int lane = threadIdx.x;
+  const int64_t c = blockIdx.x;
+  if (c >= a.N) return;
+  const int q = a.q, k = a.q - 1, nl = a.nlev, MP = a.MP, d = a.d;
+  const bool lo = lane < a.m, lj = lane < d;
+  auto TH = [&](int lev) { return a.theta + ((size_t)lev * a.NP + c) * a.DP; };
+  auto FS = [&](int j, int qq) { return a.Fst + ((size_t)pair_index(j, qq) * a.NP + c) * MP; };
+  auto bsum = [&](double v) {
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    if constexpr (NW > 1) {
+      __syncthreads();
+      if ((lane & 63) == 0) s_x[lane >> 6] = v;
+      __syncthreads();
+      v = s_x[0] + s_x[1];
+    }
+    return v;
+  };
+  auto quad = [&](int lev, double r) {  // -1/2 r^T P r with chain c's inverse of adaptive level lev
+    __syncthreads();
+    s_v[MPT + lane] = lo ? r : 0.0;
+    __syncthreads();
+    double s = 0.0;
+    if (lo) {
+      const double* __restrict__ Pc = a.cov_inv[lev] + (size_t)c * MP * MP + lane;
+#pragma unroll 8
+      for (int o = 0; o < a.m; ++o) s = fma(Pc[(size_t)o * MP], s_v[MPT + o], s);
+      s *= r;
+    }
+    return -0.5 * bsum(s);
+  };
+  auto loglike_of = [&](int lev, double r0) {  // r0 = F - data without bias
+    if (lev == nl - 1) return -0.5 * bsum(lo ? r0 * r0 : 0.0) / a.var_finest;
+    return quad(lev, lo ? r0 + a.bias_tot[lev][c * MP + lane] : 0.0);
+  };
+
+  if (a.phase == 1) {  // update_link of level k's latest link (posterior.py:112-134)
+    const double rk = lo ? a.Fcur[k][c * MP + lane] - a.data[k][lane] : 0.0;
+    const double bt = lo ? a.bias_tot[k][c * MP + lane] : 0.0;
+    const double llk = quad(k, lo ? rk + bt : 0.0);
+    if (lane == 0) {
+      a.ll[(size_t)k * a.NP + c] = llk;
+      const int64_t idk = a.sid[(size_t)k * a.NP + c];
+      for (int q2 = q; q2 < nl; ++q2)
+        if (a.sid[(size_t)q2 * a.NP + c] == idk) a.Sst[((size_t)pair_index(k, q2) * 2 + 1) * a.NP + c] = llk;
+    }
+    return;
+  }
+
+  // ---------------- the level-q decision (chain.py:475-483, proposal.py:1615-1624) ----------------
+  const double yj = lj ? TH(k)[lane] : 0.0, xj = lj ? TH(q)[lane] : 0.0;
+  const double y_lp = a.lp[(size_t)k * a.NP + c], y_ll = a.ll[(size_t)k * a.NP + c];
+  const double x_lp = a.lp[(size_t)q * a.NP + c], x_ll = a.ll[(size_t)q * a.NP + c];
+  const int pkq = pair_index(k, q);
+  const double st_lp = a.Sst[((size_t)pkq * 2 + 0) * a.NP + c], st_ll = a.Sst[((size_t)pkq * 2 + 1) * a.NP + c];
+  const bool any = a.anyacc[(size_t)k * a.NP + c] != 0;
+  const double fnew = lo ? a.Fnew[(size_t)c * a.m + lane] : 0.0;
+  const double lpn = y_lp;
+  const double lln = loglike_of(q, lo ? fnew - a.data[q][lane] : 0.0);
+  const double alpha = exp(((lpn + lln) - (x_lp + x_ll)) + (st_lp + st_ll) - (y_lp + y_ll));
+  double u;
+  if (a.u_rep) u = a.u_rep[c];
+  else u = accept_uniform(a.seed, (uint32_t)(a.chain_offset + c), (uint32_t)a.step, (uint32_t)q);
+  const bool acc = any && (u < alpha);
+
+  // ---------------- alignment (chain.py:357-398; proposal.py:1469-1493) ----------------
+  if (acc) {
+    if (lane < a.DP) TH(q)[lane] = lj ? yj : 0.0;
+  } else {
+    for (int j = 0; j < q; ++j)
+      if (lane < a.DP) TH(j)[lane] = lj ? xj : 0.0;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    if (acc) {
+      a.lp[(size_t)q * a.NP + c] = lpn;
+      a.ll[(size_t)q * a.NP + c] = lln;
+      a.sid[(size_t)q * a.NP + c] = a.sid[(size_t)k * a.NP + c];
+    } else {
+      for (int j = 0; j < q; ++j) {
+        const int p = pair_index(j, q);
+        a.lp[(size_t)j * a.NP + c] = a.Sst[((size_t)p * 2 + 0) * a.NP + c];
+        a.ll[(size_t)j * a.NP + c] = a.Sst[((size_t)p * 2 + 1) * a.NP + c];
+        a.sid[(size_t)j * a.NP + c] = a.sid[(size_t)q * a.NP + c];
+      }
+    }
+    for (int j = 0; j < q; ++j)
+      for (int q2 = j + 1; q2 <= q; ++q2) {
+        const int p = pair_index(j, q2);
+        a.Sst[((size_t)p * 2 + 0) * a.NP + c] = a.lp[(size_t)j * a.NP + c];
+        a.Sst[((size_t)p * 2 + 1) * a.NP + c] = a.ll[(size_t)j * a.NP + c];
+      }
+    a.anyacc[(size_t)k * a.NP + c] = 0;
+    if (q < nl - 1) a.anyacc[(size_t)q * a.NP + c] |= acc ? 1 : 0;
+    if (a.ring) a.ring[(size_t)(a.ring_pos % a.ring_P) * a.NP + c] = acc ? 1 : 0;
+    if (a.rec_stats) {
+      const double l1 = a.lp[(size_t)q * a.NP + c], l2 = a.ll[(size_t)q * a.NP + c];
+      a.rec_stats[c * 3 + 0] = l1;
+      a.rec_stats[c * 3 + 1] = l2;
+      a.rec_stats[c * 3 + 2] = l1 + l2;
+    }
+    if (a.rec_acc) a.rec_acc[c] = acc ? 1 : 0;
+  }
+  if (a.rec_params && lj) a.rec_params[c * d + lane] = acc ? yj : xj;
+
+  // ---------------- model outputs of the aligned links ----------------
+  const double fq_cur = lo ? (acc ? fnew : a.Fcur[q][c * MP + lane]) : 0.0;
+  const double fk_cur = lo ? (acc ? a.Fcur[k][c * MP + lane] : FS(k, q)[lane]) : 0.0;
+  if (lo) {
+    if (acc) {
+      a.Fcur[q][c * MP + lane] = fnew;
+    } else {
+      for (int j = 0; j < q; ++j) a.Fcur[j][c * MP + lane] = FS(j, q)[lane];
+    }
+    for (int j = 0; j < q; ++j) {
+      const double fj = a.Fcur[j][c * MP + lane];  // this very lane wrote / owns the entry
+      for (int q2 = j + 1; q2 <= q; ++q2) FS(j, q2)[lane] = fj;
+    }
+  }
+
+  // ---------------- error model update (chain.py:485-499, :739-753; proposal.py:1547-1578; utils.py:113-122) ----------------
+  const double diff_new = fq_cur - fk_cur;
+  double* md = a.mdiff[q] + c * MP;
+  double* Sg = a.b_sig[q] + (size_t)c * MP * MP;
+  const double t = (double)a.b_t;
+  const double dm = (a.is_da || acc) ? diff_new : (lo ? md[lane] : 0.0);  // MLDA refreshes the difference on accept only
+  if (lo) md[lane] = dm;
+  double* mu = a.b_mu[q] + c * MP;
+  const double mu_o = lo ? mu[lane] : 0.0;
+  const double mu_n = (1.0 / (t + 1.0)) * (t * mu_o + dm);
+  __syncthreads();
+  s_v[MPT + lane] = dm;
+  s_v[2 * MPT + lane] = mu_o;
+  s_v[3 * MPT + lane] = mu_n;
+  __syncthreads();
+  if (lo) {
+    const double ca = (t - 1.0) / t, cb = 1.0 / t;
+    for (int i0 = 0; i0 < a.m; i0 += 8) {
+      double old[8];
+#pragma unroll
+      for (int uu = 0; uu < 8; ++uu) old[uu] = i0 + uu < a.m ? Sg[(size_t)(i0 + uu) * MP + lane] : 0.0;
+#pragma unroll
+      for (int uu = 0; uu < 8; ++uu)
+        if (i0 + uu < a.m) {
+          const int i = i0 + uu;
+          const double M = (t * (s_v[2 * MPT + i] * mu_o) - (t + 1.0) * (s_v[3 * MPT + i] * mu_n)) + s_v[MPT + i] * dm;
+          Sg[(size_t)i * MP + lane] = ca * old[uu] + cb * M;
+        }
+    }
+    mu[lane] = mu_n;
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (lo) {  // total bias of level k: sum over the trackers of the levels above
+    double bt = 0.0;
+    for (int p = q; p < nl; ++p) bt += a.b_mu[p][c * MP + lane];
+    a.bias_tot[k][c * MP + lane] = bt;
+  }
+}
+
+// base-level step of such a hierarchy: like k_ext_accept, with the bias-corrected dense likelihood of
+// AdaptiveGaussianLogLike (distributions.py:404-425) under chain c's bias and inverse; keeps the output of the current link
+struct ExtAemAcceptArgs {
+  int64_t N, NP;
+  int d, DP, m, MP, s, prop_kind;
+  double* theta;  // level 0: [NP][DP]
+  double* lp;
+  double* ll;
+  const double* u;     // [S][NP]
+  const double* prop;  // [N][d]
+  const double* F;     // [N][m]
+  const double* data;  // [MP]
+  const double* bias;  // [NP][MP]
+  const double* P;     // [NP][MP][MP]
+  double* Fcur;        // [NP][MP]
+  const double* pr_mean;
+  const double* pr_pinv;
+  double logconst;
+  int32_t* anyacc;
+  int64_t* sid;
+  int64_t sid_value;  // identity given to the parameter vector this step creates
+  uint8_t* ring;
+  int ring_P;
+  int64_t ring_pos;
+  double* rec_params;
+  double* rec_stats;
+  uint8_t* rec_acc;
+};
+
+template <int MPT>
+__global__ void __launch_bounds__(MPT) k_ext_aem_accept(const ExtAemAcceptArgs a) {
+  constexpr int NW = MPT / 64;
+  __shared__ double s_r[MPT];
+  __shared__ double s_x[8];
+  const int lane = threadIdx.x;
+  const int64_t c = blockIdx.x;
+  if (c >= a.N) return;
+  const int MP = a.MP;
+  const bool lo = lane < a.m, lj = lane < a.d;
+  auto bsum = [&](double v) {
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    if constexpr (NW > 1) {
+      __syncthreads();
+      if ((lane & 63) == 0) s_x[lane >> 6] = v;
+      __syncthreads();
+      v = s_x[0] + s_x[1];
+    }
+    return v;
+  };
+  const double f = lo ? a.F[(size_t)c * a.m + lane] : 0.0;
+  const double r = lo ? (f + a.bias[c * MP + lane]) - a.data[lane] : 0.0;
+  s_r[lane] = r;
+  __syncthreads();
+  double sq = 0.0;
+  if (lo) {
+    const double* __restrict__ Pc = a.P + (size_t)c * MP * MP + lane;
+#pragma unroll 8
+    for (int o = 0; o < a.m; ++o) sq = fma(Pc[(size_t)o * MP], s_r[o], sq);
+    sq *= r;
+  }
+  const double ll_n = -0.5 * bsum(sq);
+  const double prp = lj ? a.prop[c * a.d + lane] : 0.0;
+  double pj = 0.0;
+  if (lj) {
+    const double dv = prp - a.pr_mean[lane];
+    pj = dv * dv * a.pr_pinv[lane];
+  }
+  const double maha = bsum(pj);
+  const double lp_n = -0.5 * (a.logconst + maha);
+  const double post_n = lp_n + ll_n;
+  double lp = a.lp[c], ll = a.ll[c];
+  const double delta = a.prop_kind == 1 ? ll_n - ll : post_n - (lp + ll);
+  double alpha = exp(delta);
+  if (post_n != post_n) alpha = 0.0;
+  const bool acc = a.u[(size_t)a.s * a.NP + c] < alpha;
+  double cur = lj ? a.theta[c * a.DP + lane] : 0.0;
+  if (acc) {
+    lp = lp_n;
+    ll = ll_n;
+    cur = prp;
+    if (lj) a.theta[c * a.DP + lane] = cur;
+    if (lo) a.Fcur[c * MP + lane] = f;
+    if (lane == 0) {
+      a.lp[c] = lp;
+      a.ll[c] = ll;
+      a.anyacc[c] = 1;
+      a.sid[c] = a.sid_value;
+    }
+  }
+  const size_t rr = (size_t)a.s * a.N + c;
+  if (lane == 0) {
+    if (a.ring) a.ring[(size_t)(a.ring_pos % a.ring_P) * a.NP + c] = acc ? 1 : 0;
+    if (a.rec_stats) {
+      a.rec_stats[rr * 3 + 0] = lp;
+      a.rec_stats[rr * 3 + 1] = ll;
+      a.rec_stats[rr * 3 + 2] = lp + ll;
+    }
+    if (a.rec_acc) a.rec_acc[rr] = acc ? 1 : 0;
+  }
+  if (a.rec_params && lj) a.rec_params[rr * a.d + lane] = cur;
+}
+
+// ------------------------------------------------------------------------------------------------
 // (Sigma_e + Sigma_bias)^-1 for every chain (distributions.py:399-402: set_bias re-inverts unless every entry of
 // Sigma_bias is < 1e-9), one workgroup of four waves per chain, on the matrix cores.  The matrix lives in LDS as the
 // 16 x 16 blocks on or below the diagonal (row stride 17):
