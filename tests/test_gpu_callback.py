@@ -232,5 +232,9 @@ def test_callback_hierarchy_through_sample_api():
                      initial_parameters=th0[:4], seed=2, backend="hip")  # the state-independent error model runs behind callbacks too
     lk = aem["chain_fine_1"][-1]
     assert np.isclose(lk.posterior, posts[1].create_link(lk.parameters).posterior, rtol=1e-10)
-    with pytest.raises(tda.EngineError):  # the state-dependent one is not lowered for callback hierarchies: the engine says so
-        tda.sample(ada, tda.CrankNicolson(scaling=0.04), 5, n_chains=4, subchain_length=1, adaptive_error_model="state-dependent", backend="hip")
+    dep = tda.sample(ada, tda.CrankNicolson(scaling=0.04), 12, n_chains=4, subchain_length=1, adaptive_error_model="state-dependent",
+                     initial_parameters=th0[:4], seed=3, backend="hip")
+    lk = dep["chain_fine_2"][-1]
+    assert np.isclose(lk.posterior, posts[1].create_link(lk.parameters).posterior, rtol=1e-10)
+    with pytest.raises(tda.EngineError):  # randomised subchain lengths are not lowered for callback hierarchies: the engine says so
+        tda.sample(posts, tda.CrankNicolson(scaling=0.04), 5, n_chains=4, subchain_length=3, randomize_subchain_length=True, backend="hip")

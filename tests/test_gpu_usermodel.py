@@ -238,7 +238,7 @@ def test_source_model_hierarchy_through_sample_api():
     assert np.isclose(link.posterior, posts[1].create_link(link.parameters).posterior, rtol=1e-10)
 
 
-@pytest.mark.parametrize("case", ["da_source", "mlda_mixed"])
+@pytest.mark.parametrize("case", ["da_source", "mlda_mixed", "da_dep_pcn", "da_dep_grw"])
 def test_hierarchy_with_error_model_matches_oracle(case):
     """State-independent adaptive error model over non-linear models: source-defined levels (DA), and a 3-level MLDA
     hierarchy of a linear surrogate, a batched host callback and a source-defined finest level -- against the oracle's
@@ -251,8 +251,11 @@ def test_hierarchy_with_error_model_matches_oracle(case):
     truth = 0.5 * rng.standard_normal(d)
     if case == "mlda_mixed":
         ks, sl, n_fine = [0, 1, 2], [3, 2], 12
+    elif case.startswith("da_dep"):
+        ks, sl, n_fine = [1, 2], [1 if case == "da_dep_pcn" else 2], 40
     else:
         ks, sl, n_fine = [1, 2], [3], 22
+    aem = "state-dependent" if case.startswith("da_dep") else "state-independent"
     nl = len(ks)
     twins = [np_level_model(k) for k in ks]
     Alin = np.array([[(0.1 + 0.01 * ((o * 7 + j * 3) % 11)) for j in range(d)] for o in range(m)])
@@ -275,10 +278,14 @@ def test_hierarchy_with_error_model_matches_oracle(case):
             e.set_level_callback(1, twins[1], y, 3, cov)
         else:
             e.set_level_source(i, SRC_LEVEL % _level_cfg(k), y, 0 if last else 3, [var] if last else cov)
-    e.set_proposal(0, 2e-3 * np.eye(d), scaling=1.0)
-    prop = dict(kind="grw", C=2e-3 * np.eye(d), scaling=1.0)
+    if case == "da_dep_pcn":
+        e.set_proposal(1, None, scaling=0.05)
+        prop = dict(kind="pcn", scaling=0.05)
+    else:
+        e.set_proposal(0, 2e-3 * np.eye(d), scaling=1.0)
+        prop = dict(kind="grw", C=2e-3 * np.eye(d), scaling=1.0)
     e.set_subchains(sl, False)
-    e.set_error_model("state-independent")
+    e.set_error_model(aem)
     e.init(theta0)
     rows = e.rows_per_level(n_fine)
     z, _ = e.set_export(rows[0])
@@ -289,7 +296,7 @@ def test_hierarchy_with_error_model_matches_oracle(case):
     us, _ = _oracle_uniforms(seed, N, rows, sl)
     prior = orc.MVNPrior(pm, np.diag(pv))
     levels = [dict(fn=twins[i], y=y, prior=prior, **(dict(var=var) if i == nl - 1 else dict(cov=cov))) for i in range(nl)]
-    res = orc.run_multilevel_aem(levels, prop, sl, theta0, np.swapaxes(z, 0, 1), us, n_fine, "state-independent")
+    res = orc.run_multilevel_aem(levels, prop, sl, theta0, np.swapaxes(z, 0, 1), us, n_fine, aem)
     res = res[0] if isinstance(res, tuple) else res
     for i in range(nl):
         ref = res[i]

@@ -1489,7 +1489,6 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
         if (lv.model != MODEL_CALLBACK && lv.model != MODEL_USER && (lv.model != MODEL_LINEAR || !lv.A_dev.p))
           return fail(TDA_ERR_UNSUPPORTED, "hierarchies with callback / source-defined levels take linear levels with isotropic or diagonal noise beside them");
       if (e->randomize) return fail(TDA_ERR_UNSUPPORTED, "callback hierarchies: randomize_subchain_length is not lowered");
-      if (e->aem == TDA_AEM_STATE_DEPENDENT) return fail(TDA_ERR_UNSUPPORTED, "callback / source-defined hierarchies: the state-dependent error model is not lowered");
       if (e->pp.kind != TDA_PROP_GRW && e->pp.kind != TDA_PROP_PCN && e->pp.kind != TDA_PROP_AM)
         return fail(TDA_ERR_UNSUPPORTED, "callback hierarchies take GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis proposals");
       if (e->prior_kind == PRIOR_DENSE) return fail(TDA_ERR_UNSUPPORTED, "callback forward models need a diagonal prior covariance");
@@ -2652,6 +2651,11 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
             ga.nlev = nl;
             ga.q = q;
             ga.is_da = nl == 2;
+            ga.dependent = e->aem == TDA_AEM_STATE_DEPENDENT;
+            ga.prop_kind = e->pp.kind;
+            ga.pr_W = e->prior_W_rm.p;
+            ga.pr_logdet = e->prior_logconst - d * std::log(2.0 * M_PI);
+            ga.scaling = e->scaling.p;
             ga.seed = e->cfg.seed;
             ga.step = e->done[q] + row[q];
             ga.Fnew = lq.cb_F.p;
@@ -2686,8 +2690,13 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
             iv.MP = e->aem_ld;
             iv.nb = (e->aem_m + 15) / 16;
             iv.cov = e->levels[k].cov64.p;
-            iv.nsum = nl - q;
-            for (int p2 = q; p2 < nl; ++p2) iv.sig[p2 - q] = e->aem_bsig[p2].p;
+            if (ga.dependent) {
+              iv.nsum = 1;
+              iv.sig[0] = e->aem_bsig[q].p;
+            } else {
+              iv.nsum = nl - q;
+              for (int p2 = q; p2 < nl; ++p2) iv.sig[p2 - q] = e->aem_bsig[p2].p;
+            }
             iv.P = e->aem_covinv[k].p;
             const size_t inv_lds = aem_inverse_lds_bytes(iv.nb);
             if (inv_lds > 64 * 1024)

@@ -745,6 +745,10 @@ __global__ void __launch_bounds__(MPT) k_aem_action(const AemArgs a) {
 struct ExtAemArgs {
   int64_t N, NP, chain_offset;
   int d, DP, m, MP, nlev, q, is_da, phase;
+  int dependent, prop_kind;    // state-dependent error model (DA only, chain.py:446-473, :501-523); pCN needs the q terms
+  const double* pr_W;          // [d][d] whitening matrix of the prior, row-major
+  double pr_logdet;
+  const double* scaling;       // [NP] pCN beta
   uint64_t seed;
   int64_t step;
   const double* Fnew;          // [N][m] level q at theta_{q-1}
@@ -836,7 +840,34 @@ __global__ void __launch_bounds__(MPT) k_ext_aem_action(const ExtAemArgs a) {
   const double fnew = lo ? a.Fnew[(size_t)c * a.m + lane] : 0.0;
   const double lpn = y_lp;
   const double lln = loglike_of(q, lo ? fnew - a.data[q][lane] : 0.0);
-  const double alpha = exp(((lpn + lln) - (x_lp + x_ll)) + (st_lp + st_ll) - (y_lp + y_ll));
+  double alpha;
+  if (a.dependent) {  // chain.py:446-473: the bias at the proposal, the coarse density of the subchain start under it
+    const double bias_next = lo ? fnew - a.Fcur[k][c * MP + lane] : 0.0;
+    const double rk_x = lo ? FS(k, q)[lane] - a.data[k][lane] : 0.0;
+    const double ll_b = quad(k, lo ? rk_x + bias_next : 0.0);
+    double q_xy = 0.0, q_yx = 0.0;
+    if (a.prop_kind == 1) {  // pCN transition densities (proposal.py:364-369) between the fine links
+      const double beta = a.scaling[c], kp = sqrt(1.0 - beta * beta);
+      for (int dir = 0; dir < 2; ++dir) {
+        __syncthreads();
+        s_v[2 * MPT + lane] = dir == 0 ? yj - kp * xj : xj - kp * yj;
+        __syncthreads();
+        double w = 0.0;
+        if (lj) {
+          const double* Wr = a.pr_W + (size_t)lane * d;
+          for (int j = 0; j <= lane; ++j) w = fma(Wr[j], s_v[2 * MPT + j], w);
+        }
+        const double maha = bsum(lj ? w * w : 0.0) / (beta * beta);
+        const double v = -0.5 * (d * 1.8378770664093453 + a.pr_logdet + d * log(beta * beta) + maha);
+        if (dir == 0) q_xy = v; else q_yx = v;
+      }
+    }
+    const double n1 = (lpn + lln) + q_yx, n2 = (st_lp + ll_b) + q_xy;
+    const double d1 = (x_lp + x_ll) + q_xy, d2 = (y_lp + y_ll) + q_yx;
+    alpha = exp((n1 < n2 ? n1 : n2) - (d1 < d2 ? d1 : d2));
+  } else {
+    alpha = exp(((lpn + lln) - (x_lp + x_ll)) + (st_lp + st_ll) - (y_lp + y_ll));
+  }
   double u;
   if (a.u_rep) u = a.u_rep[c];
   else u = accept_uniform(a.seed, (uint32_t)(a.chain_offset + c), (uint32_t)a.step, (uint32_t)q);
@@ -902,6 +933,28 @@ __global__ void __launch_bounds__(MPT) k_ext_aem_action(const ExtAemArgs a) {
   double* md = a.mdiff[q] + c * MP;
   double* Sg = a.b_sig[q] + (size_t)c * MP * MP;
   const double t = (double)a.b_t;
+  if (a.dependent) {  // chain.py:501-523; utils.py:199: zero-mean moments of the change of the difference
+    const double xupd = lo ? fq_cur - (fk_cur + md[lane]) : 0.0;
+    if (lo) md[lane] = diff_new;
+    __syncthreads();
+    s_v[MPT + lane] = xupd;
+    __syncthreads();
+    if (lo) {
+      for (int i0 = 0; i0 < a.m; i0 += 8) {
+        double old[8];
+#pragma unroll
+        for (int uu = 0; uu < 8; ++uu) old[uu] = i0 + uu < a.m ? Sg[(size_t)(i0 + uu) * MP + lane] : 0.0;
+#pragma unroll
+        for (int uu = 0; uu < 8; ++uu)
+          if (i0 + uu < a.m) {
+            const double xi = s_v[MPT + i0 + uu];
+            Sg[(size_t)(i0 + uu) * MP + lane] = (t - 1.0) / t * old[uu] + 1.0 / t * (xi * xupd);
+          }
+      }
+      a.bias_tot[k][c * MP + lane] = diff_new;  // the bias of the coarse level is the last difference
+    }
+    return;
+  }
   const double dm = (a.is_da || acc) ? diff_new : (lo ? md[lane] : 0.0);  // MLDA refreshes the difference on accept only
   if (lo) md[lane] = dm;
   double* mu = a.b_mu[q] + c * MP;
