@@ -236,5 +236,10 @@ def test_callback_hierarchy_through_sample_api():
                      initial_parameters=th0[:4], seed=3, backend="hip")
     lk = dep["chain_fine_2"][-1]
     assert np.isclose(lk.posterior, posts[1].create_link(lk.parameters).posterior, rtol=1e-10)
-    with pytest.raises(tda.EngineError):  # randomised subchain lengths are not lowered for callback hierarchies: the engine says so
-        tda.sample(posts, tda.CrankNicolson(scaling=0.04), 5, n_chains=4, subchain_length=3, randomize_subchain_length=True, backend="hip")
+    rnd = tda.sample(posts, tda.CrankNicolson(scaling=0.04), 12, n_chains=4, subchain_length=3, randomize_subchain_length=True,
+                     initial_parameters=th0[:4], seed=4, backend="hip")
+    lk = rnd["chain_fine_0"][-1]
+    assert np.isclose(lk.posterior, posts[1].create_link(lk.parameters).posterior, rtol=1e-10)
+    with pytest.raises(tda.EngineError):  # ... but not together with an error model (nor is it for linear levels): the engine says so
+        tda.sample(ada, tda.CrankNicolson(scaling=0.04), 5, n_chains=4, subchain_length=3, randomize_subchain_length=True,
+                   adaptive_error_model="state-independent", backend="hip")

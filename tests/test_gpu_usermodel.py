@@ -160,7 +160,7 @@ def np_level_model(k):
     return fn
 
 
-@pytest.mark.parametrize("case", ["da_pcn", "mlda_am", "da_mixed", "da_linear_coarse"])
+@pytest.mark.parametrize("case", ["da_pcn", "mlda_am", "da_mixed", "da_linear_coarse", "da_random"])
 def test_source_model_hierarchy_matches_oracle(case):
     """Delayed Acceptance / MLDA with source-defined (hiprtc) models at every level -- no host round trip per step -- and a
     hierarchy mixing a batched host callback (coarse) with a source-defined fine model, against the oracle's DAChain /
@@ -199,18 +199,18 @@ def test_source_model_hierarchy_matches_oracle(case):
     else:  # adaptive scaling: the accept-flag window holds the base steps of the fused launches and the alignment entries
         e.set_proposal(1, None, scaling=0.04, adaptive=True, gamma=1.02, period=15)
         prop = dict(kind="pcn", scaling=0.04, adaptive=True, gamma=1.02, period=15)
-    e.set_subchains(sl, False)
+    e.set_subchains(sl, case == "da_random")  # randomize_subchain_length: a random state of the subchain is promoted
     e.init(theta0)
     rows = e.rows_per_level(n_fine)
     z, _ = e.set_export(rows[0])
     outs = e.run_levels_host(n_fine)
     scal = e.proposal_state()["scaling"]
     e.close()
-    us, _ = _oracle_uniforms(seed, N, rows, sl)
+    us, ridx = _oracle_uniforms(seed, N, rows, sl, sl[0] if case == "da_random" else None)
     prior = orc.MVNPrior(pm, np.diag(pv))
     nvar = [0.25 ** 2 if (case == "da_linear_coarse" and i == 0) else 0.05 ** 2 for i in range(nl)]
     levels = [orc.CallableGaussianLevel(twins[i], y, "iso", nvar[i], prior) for i in range(nl)]
-    res, pstate = orc.run_multilevel(levels, prop, sl, theta0, np.swapaxes(z, 0, 1), us, n_fine, None)
+    res, pstate = orc.run_multilevel(levels, prop, sl, theta0, np.swapaxes(z, 0, 1), us, n_fine, ridx)
     np.testing.assert_allclose(scal, pstate.scaling, rtol=1e-12)
     for i in range(nl):
         ref = res[i]

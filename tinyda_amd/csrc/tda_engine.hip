@@ -1488,7 +1488,6 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
       for (auto& lv : e->levels)  // linear levels may be mixed in (k_ext_linear_eval); anything else may not
         if (lv.model != MODEL_CALLBACK && lv.model != MODEL_USER && (lv.model != MODEL_LINEAR || !lv.A_dev.p))
           return fail(TDA_ERR_UNSUPPORTED, "hierarchies with callback / source-defined levels take linear levels with isotropic or diagonal noise beside them");
-      if (e->randomize) return fail(TDA_ERR_UNSUPPORTED, "callback hierarchies: randomize_subchain_length is not lowered");
       if (e->pp.kind != TDA_PROP_GRW && e->pp.kind != TDA_PROP_PCN && e->pp.kind != TDA_PROP_AM)
         return fail(TDA_ERR_UNSUPPORTED, "callback hierarchies take GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis proposals");
       if (e->prior_kind == PRIOR_DENSE) return fail(TDA_ERR_UNSUPPORTED, "callback forward models need a diagonal prior covariance");
@@ -2526,7 +2525,12 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
       int64_t rp = e->ring_pos;  // position in the base proposal's accepted list: one entry per base step and per level action
       for (int k = 0; k < MAXLEV; ++k) cc[k] = e->cnt[k];
       for (int64_t s = 0; s < S;) {
-        if (e->levels[0].model == MODEL_USER && !e->aem) {
+        if (e->randomize && cc[0] == 0) {  // Delayed Acceptance: draw the promoted index of the subchain that starts now
+          hipLaunchKernelGGL(k_ext_pick, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, e->stream, (long long)N, e->sl[0],
+                             (unsigned long long)e->cfg.seed, (long long)e->cfg.chain_offset, (long long)(e->done[1] + row[1]),
+                             ma.ridx_rep ? ma.ridx_rep + (size_t)row[1] * N : nullptr, e->ml_pick.p);
+        }
+        if (e->levels[0].model == MODEL_USER && !e->aem && !e->randomize) {
           // source-defined base level: the rest of the running subchain (inside this block) is ONE launch of the fused
           // step kernel compiled with the model
           const int64_t n = std::min<int64_t>(S - s, (int64_t)e->sl[0] - cc[0]);
@@ -2624,6 +2628,11 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
         xa.ring = adaptive ? e->ml_ring.p : nullptr;
         xa.ring_P = e->ring_P;
         xa.ring_pos = rp++;
+        if (e->randomize) {
+          xa.pick = e->ml_pick.p;
+          xa.cnt = cc[0];
+          xa.ysnap = e->ml_ysnap.p;
+        }
         int xrc = ext_step(e, e->levels[0], xa);
         if (xrc) return xrc;
         cc[0] += 1;
@@ -2634,8 +2643,10 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
           const Level& lq = e->levels[q];
           ExtArgs ya{};
           fill_ext_args(e, lq, ya);
-          ya.mode = 1;  // "proposals" = the current states of level k
-          ya.theta = e->ml_theta.p + (size_t)k * NP * DP;
+          ya.mode = 1;  // "proposals" = the current states of level k (the promoted states of a randomised subchain)
+          const bool snap = e->randomize && k == 0;
+          ya.theta = snap ? e->ml_ysnap.p : e->ml_theta.p + (size_t)k * NP * DP;
+          ya.theta_ld = snap ? DP + 2 : 0;
           hipLaunchKernelGGL(k_ext_propose, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, ya);
           const int mrc = ext_model_outputs(e, lq);
           if (mrc) return mrc;
@@ -2744,6 +2755,7 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
           la.ring = adaptive ? e->ml_ring.p : nullptr;
           la.ring_P = e->ring_P;
           la.ring_pos = rp++;
+          la.ysnap = (e->randomize && k == 0) ? e->ml_ysnap.p : nullptr;
           hipLaunchKernelGGL(k_ext_level_action, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, la);
           HIP_TRY(hipGetLastError());
           cc[k] = 0;

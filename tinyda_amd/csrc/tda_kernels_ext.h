@@ -43,6 +43,12 @@ struct ExtArgs {
   unsigned char* ring;  // multi-level: the base proposal's `accepted` list as a ring [ring_P][NP] (scaling adaptation window,
   int ring_P;           // proposal.py:236; it also receives the alignment entries of the levels above); may be null
   long long ring_pos;   // absolute list position of this step's entry
+  int theta_ld;         // k_ext_propose, mode 1: row stride of `theta` (0 = DP); the promoted states of a randomised subchain live in ysnap
+  // Delayed Acceptance with randomize_subchain_length (chain.py:525-527): the state after step `pick[c]` of the running
+  // subchain is the one promoted to the fine level; k_ext_accept snapshots it (parameters, log-prior, log-likelihood)
+  const int* pick;      // [NP] or null
+  int cnt;              // position of this step inside the subchain
+  double* ysnap;        // [NP][DP + 2]
 };
 
 constexpr int EXT_WAVES = 4;
@@ -51,7 +57,7 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_propose(const ExtArgs a)
   const int lane = threadIdx.x & 63;
   const long long c = (long long)blockIdx.x * EXT_WAVES + (threadIdx.x >> 6);
   if (c >= a.N || lane >= a.d) return;
-  const double cur = a.theta[c * a.DP + lane];
+  const double cur = a.theta[c * (a.theta_ld ? a.theta_ld : a.DP) + lane];
   double prp = cur;
   if (a.mode != 1) {  // proposal.py:249-251 / :351-355
     const double scal = a.scaling[c];
@@ -124,7 +130,32 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_accept(const ExtArgs a) 
       if (a.rec_acc) a.rec_acc[r] = acc ? 1 : 0;
     }
     if (a.rec_params && lj) a.rec_params[r * a.d + lane] = cur;
+    if (a.pick && a.cnt == a.pick[c]) {  // the promoted state of this subchain
+      double* ys = a.ysnap + (size_t)c * (a.DP + 2);
+      if (lane < a.DP) ys[lane] = lj ? cur : 0.0;
+      if (lane == 0) {
+        ys[a.DP] = lp;
+        ys[a.DP + 1] = ll;
+      }
+    }
   }
+}
+
+// promoted index of the subchain that starts now (chain.py:525-527): replayed reference index in [-L, -1] or Philox
+__global__ void k_ext_pick(long long N, int L, unsigned long long seed, long long chain_offset, long long step,
+                           const double* __restrict__ ridx_rep, int* __restrict__ pick) {
+  const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  int p;
+  if (ridx_rep) {
+    const double r = ridx_rep[c];
+    p = (r != r) ? L - 1 : (int)r + L;
+  } else {
+    const u32x4 x = philox4x32_10(u32x4{0u, (uint32_t)step, (uint32_t)(chain_offset + c), 3u /* STREAM_INDEX */}, (uint32_t)seed,
+                                  (uint32_t)(seed >> 32));
+    p = (int)(((uint64_t)x.x * (uint64_t)L) >> 32);
+  }
+  pick[c] = p;
 }
 
 // A linear level inside a host-sequenced hierarchy (e.g. a linear surrogate below a non-linear model): F = A prop for all
@@ -174,6 +205,7 @@ struct ExtLevelArgs {
   unsigned char* ring;  // alignment entry in the base proposal's accepted window (chain.py:363,389,397; proposal.py:1486); may be null
   int ring_P;
   long long ring_pos;
+  const double* ysnap;  // randomised subchain (DA): the promoted state [NP][DP + 2] instead of level q - 1's last state; or null
 };
 
 __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_level_action(const ExtLevelArgs a) {
@@ -194,8 +226,9 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_level_action(const ExtLe
   }
   sse = ext_wave_sum(sse);
   const double lln = a.w ? -0.5 * sse : -0.5 * sse / a.var;
-  const double yj = lj ? TH(k)[lane] : 0.0, xj = lj ? TH(q)[lane] : 0.0;
-  const double y_lp = a.lp[(size_t)k * a.NP + c], y_ll = a.ll[(size_t)k * a.NP + c];
+  const double* ys = a.ysnap ? a.ysnap + (size_t)c * (a.DP + 2) : nullptr;
+  const double yj = lj ? (ys ? ys[lane] : TH(k)[lane]) : 0.0, xj = lj ? TH(q)[lane] : 0.0;
+  const double y_lp = ys ? ys[a.DP] : a.lp[(size_t)k * a.NP + c], y_ll = ys ? ys[a.DP + 1] : a.ll[(size_t)k * a.NP + c];
   const double x_lp = a.lp[(size_t)q * a.NP + c], x_ll = a.ll[(size_t)q * a.NP + c];
   const int pkq = PI(k, q);
   const double st_lp = a.Sst[((size_t)pkq * 2 + 0) * a.NP + c], st_ll = a.Sst[((size_t)pkq * 2 + 1) * a.NP + c];
@@ -207,8 +240,9 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_level_action(const ExtLe
   else u = accept_uniform(a.seed, (uint32_t)(a.chain_offset + c), (uint32_t)a.step, (uint32_t)q);
   const bool acc = any && (u < alpha);
   // alignment (chain.py:357-398; proposal.py:1469-1493): accept -> level q takes y; reject -> the levels below return to theta_q
-  if (acc) {
+  if (acc) {  // level q takes y -- and level q - 1 too, if y is a promoted intermediate state
     if (lane < a.DP) TH(q)[lane] = lj ? yj : 0.0;
+    if (ys && lane < a.DP) TH(k)[lane] = lj ? yj : 0.0;
   } else {
     for (int j = 0; j < q; ++j)
       if (lane < a.DP) TH(j)[lane] = lj ? xj : 0.0;
@@ -217,6 +251,8 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_level_action(const ExtLe
     if (acc) {
       a.lp[(size_t)q * a.NP + c] = lpn;
       a.ll[(size_t)q * a.NP + c] = lln;
+      a.lp[(size_t)k * a.NP + c] = y_lp;
+      a.ll[(size_t)k * a.NP + c] = y_ll;
     } else {
       for (int j = 0; j < q; ++j) {
         const int p = PI(j, q);
