@@ -158,3 +158,62 @@ def test_dream_shared_archive_sharding_invariance(eng_mod):
     np.testing.assert_array_equal(np.concatenate([e0.dreamz_state()["pCR"], e1.dreamz_state()["pCR"]]), ref_state["pCR"])
     e0.close()
     e1.close()
+
+
+@pytest.mark.parametrize("model_kind", ["source", "callback"])
+def test_dreamz_over_external_model_forward(eng_mod, model_kind):
+    """DREAM(Z) over a non-linear model that lives outside the engine's kernels (source-defined / batched host callback):
+    per step jump -> model -> accept -> archive append, against the oracle on the engine's own Philox stream."""
+    from tests.test_gpu_usermodel import SRC, np_model
+
+    d, m, N, T, M0, delta, nCR, seed = 5, 23, 19, 90, 24, 2, 3, 1357
+    rng = np.random.default_rng(6)
+    truth = 0.5 * rng.standard_normal(d)
+    y = np_model(truth)[0] + 0.05 * rng.standard_normal(m)
+    pm, pv = np.zeros(d), np.ones(d)
+    e = eng_mod.Engine(N, d, seed=seed, block_steps=16)
+    e.set_prior(pm, np.diag(pv))
+    if model_kind == "source":
+        e.set_level_source(0, SRC, y, 0, [0.05 ** 2])
+    else:
+        e.set_level_callback(0, np_model, y, 0, [0.05 ** 2])
+    e.set_proposal_dreamz(M0, delta=delta, nCR=nCR, capacity=M0 + T)
+    Z0 = truth + 0.3 * rng.standard_normal((N, M0, d))
+    theta0 = truth + 0.1 * rng.standard_normal((N, d))
+    e.set_archive(Z0)
+    e.init(theta0)
+    eps, _ = e.set_export(T)
+    params, stats, acc = e.run_host(T)
+    v = _philox_dreamz_variates(seed, N, T, d, delta, nCR, M0, None)
+    cdf = np.cumsum(np.full(nCR, 1.0 / nCR))
+    mcr = np.minimum((v["u_mcr"][..., None] >= cdf).sum(-1), nCR - 1)
+    var = dict(r=v["r"], mcr=mcr, sub_u=v["sub_u"], forced=v["forced"], e_u=v["e_u"], eps_n=np.swapaxes(eps, 0, 1), u=v["u"])
+    level = orc.CallableGaussianLevel(np_model, y, "iso", 0.05 ** 2, orc.MVNPrior(pm, np.diag(pv)))
+    cfg = dict(M0=M0, delta=delta, nCR=nCR, adaptive=False, period=100, gamma=1.01, b=5e-2, b_star=1e-6)
+    res = orc.run_dreamz(level, cfg, theta0, Z0, var)
+    assert np.array_equal(acc, res["accepted"][:, 1:].T)
+    np.testing.assert_allclose(stats[:, :, 2], res["logpost"][:, 1:].T, rtol=RTOL)
+    assert 0.02 < acc.mean() < 0.95
+    e.close()
+
+
+def test_sample_api_dreamz_over_external_models():
+    import scipy.stats as st
+
+    import tinyda_amd as tda
+    from tests.test_gpu_usermodel import SRC, np_model
+
+    d, m = 5, 23
+    rng = np.random.default_rng(9)
+    truth = 0.5 * rng.standard_normal(d)
+    y = np_model(truth)[0] + 0.05 * rng.standard_normal(m)
+    prior = st.multivariate_normal(np.zeros(d), np.eye(d))
+    like = tda.GaussianLogLike(y, 0.05 ** 2 * np.eye(m))
+    for model, prop in ((tda.DeviceModel(SRC, m, reference=lambda th: np_model(th)[0]), tda.DREAMZ(30, delta=1, adaptive=True, period=25)),
+                        (tda.BatchedModel(np_model, m), tda.DREAM(30, delta=2))):
+        post = tda.Posterior(prior, like, model)
+        res = tda.sample(post, prop, 120, n_chains=12, seed=3)
+        assert res["sampler"] == "MH" and res.get("backend", "hip") != "host"
+        link = res["chain_7"][-1]
+        assert np.isclose(link.posterior, post.create_link(link.parameters).posterior, rtol=1e-10)
+        assert np.mean(res["chain_7"].accepted[1:]) > 0.0

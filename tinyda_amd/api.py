@@ -49,7 +49,7 @@ def _device_plan(posteriors, proposal):
     if any("source" in low or "batched" in low for low in lows):
         # source-defined and batched host models: single level, or a whole hierarchy of them (Delayed Acceptance / MLDA with
         # host-sequenced level actions: GRW / pCN / AM).  iso / diag noise, diagonal prior.
-        if isinstance(proposal, DREAMZ):
+        if isinstance(proposal, DREAMZ) and len(posteriors) != 1:
             return None
         if len(posteriors) > 1:
             if any("rosenbrock" in low or "prior_joint" in low for low in lows) or type(proposal) not in (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis):

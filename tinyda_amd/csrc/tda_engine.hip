@@ -991,10 +991,9 @@ int tda_engine_set_level_source(tda_engine* e, int level, const char* source, in
     for (int i = 0; i < m; ++i) lv.ytil_h[i] = lv.data_h[i] = data[i];
     if ((rc = lv.data64.upload(lv.data_h))) return rc;
   }
-  if (e->nlev > 1) {  // hierarchy: proposals / outputs of a level step pass through device buffers (tda_user_eval)
-    if ((rc = lv.cb_prop.alloc((size_t)e->N * e->d))) return rc;
-    if ((rc = lv.cb_F.alloc((size_t)e->N * m))) return rc;
-  }
+  // hierarchies and DREAM(Z): proposals / outputs of a step pass through device buffers (tda_user_eval)
+  if ((rc = lv.cb_prop.alloc((size_t)e->N * e->d))) return rc;
+  if ((rc = lv.cb_F.alloc((size_t)e->N * m))) return rc;
   lv.model = MODEL_USER;
   lv.m = m;
   lv.m_pad = 16;  // (no MFMA staging; keeps the shared LDS-size arithmetic of the run loop valid)
@@ -1611,7 +1610,7 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
     e->inited = true;  // dreamz_sums_catchup checks nothing else
     if ((rc = dreamz_sums_catchup(e, 0, M0, false, false, 1.0))) return rc;
     // initial link (chain.py:70)
-    if (e->levels[0].model == MODEL_LINEAR) {
+    if (e->levels[0].model == MODEL_LINEAR || e->levels[0].model == MODEL_CALLBACK || e->levels[0].model == MODEL_USER) {
       if ((rc = launch_eval(e, 0, e->theta.p, e->lp.p, e->ll.p))) return rc;
     } else {
       // Rosenbrock level: evaluate theta0 with a zero-jump DREAMZ step (coef = eps = 0, u = 0 -> accepted)
@@ -3130,6 +3129,7 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     fill_dreamz_step_args(e, sa);
     sa.S = (int)S;
     sa.jump_ready = sh ? 1 : 0;
+    const bool ext_model = lv.model == MODEL_CALLBACK || lv.model == MODEL_USER;
     sa.rec_params = p_dev ? o_params + (size_t)done * N * d : (o_params ? e->rec_params.p : nullptr);
     sa.rec_stats = s_dev ? o_stats + (size_t)done * N * 3 : (o_stats ? e->rec_stats.p : nullptr);
     sa.rec_acc = a_dev ? o_acc + (size_t)done * N : (o_acc ? e->rec_acc.p : nullptr);
@@ -3137,7 +3137,53 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     // chain minor), the kernel appends them in place (the jumps of this block were gathered before it started)
     const bool direct = sh && e->auto_append && N == NP && e->pending_steps == 0;
     sa.blk_states = sh ? (direct ? e->arch.p + (size_t)e->arch_rows * DP : e->blk_states.p) : nullptr;
-    {
+    if (ext_model) {
+      // model outside the engine's kernels: per step apply the jump, evaluate (callback: one host call for all chains;
+      // source-defined: tda_user_eval on the stream), accept, append
+      if (e->prior_kind == PRIOR_DENSE) return fail(TDA_ERR_UNSUPPORTED, "callback / source-defined forward models need a diagonal prior covariance");
+      const unsigned grid = (unsigned)((N + EXT_WAVES - 1) / EXT_WAVES), gridp = (unsigned)((NP + EXT_WAVES - 1) / EXT_WAVES);
+      for (int64_t s = 0; s < S; ++s) {
+        if (s == S - 1)  // jumping distance of the adaptation: the state before the block's last step (proposal.py:800)
+          HIP_TRY(hipMemcpyAsync(e->theta_prev.p, e->theta.p, (size_t)NP * DP * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+        DzExtArgs za{};
+        za.N = N;
+        za.NP = NP;
+        za.d = d;
+        za.DP = DP;
+        za.delta = e->dz.delta;
+        za.s = (int)s;
+        za.shared = sh ? 1 : 0;
+        za.jump_ready = sa.jump_ready;
+        za.M_base = e->arch_rows;
+        za.cap = e->arch_cap;
+        za.arch = e->arch.p;
+        za.theta = e->theta.p;
+        za.coef = e->dz_coef.p;
+        za.epsm = e->dz_epsm.p;
+        za.ridx = e->dz_ridx.p;
+        za.prop = lv.cb_prop.p;
+        za.blk_states = sa.blk_states;
+        hipLaunchKernelGGL(k_dz_ext_propose, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, za);
+        int mrc = ext_model_outputs(e, lv);
+        if (mrc) return mrc;
+        ExtArgs xa{};
+        fill_ext_args(e, lv, xa);
+        xa.mode = 0;
+        xa.prop_kind = TDA_PROP_GRW;  // posterior ratio (proposal.py:253-258)
+        xa.theta = e->theta.p;
+        xa.lp = e->lp.p;
+        xa.ll = e->ll.p;
+        xa.scaling = e->scaling.p;
+        xa.acc_count = e->acc_count.p;
+        xa.u = e->ublk.p;
+        xa.s = (int)s;
+        xa.rec_params = sa.rec_params;
+        xa.rec_stats = sa.rec_stats;
+        xa.rec_acc = sa.rec_acc;
+        hipLaunchKernelGGL(k_ext_accept, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, xa);
+        hipLaunchKernelGGL(k_dz_ext_append, dim3(gridp), dim3(64 * EXT_WAVES), 0, e->stream, za);
+      }
+    } else {
       ScopedTimer tm(e, 1);
       DISPATCH_DPAD(DP, launch_dz_steps<DPAD>(sa, lds, e->stream));
     }

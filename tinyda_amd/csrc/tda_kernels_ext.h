@@ -158,6 +158,53 @@ __global__ void k_ext_pick(long long N, int L, unsigned long long seed, long lon
   pick[c] = p;
 }
 
+// DREAM(Z) over a callback / source-defined model (proposal.py:663-852): the draws of a block come from k_dreamz_draw as
+// usual; per step the jump is applied here (gathering the archive rows unless the draw kernel already did), the model is
+// evaluated outside, k_ext_accept decides, and k_dz_ext_append grows the archive.  One wave per chain.
+struct DzExtArgs {
+  long long N, NP;
+  int d, DP, delta, s, shared, jump_ready;
+  long long M_base, cap;
+  double* arch;           // per chain [NP][cap][DP] / shared [cap][DP]
+  const double* theta;    // [NP][DP]
+  const double* coef;     // [S][NP][DP]
+  const double* epsm;
+  const int* ridx;        // [S][NP][2 * 4]
+  double* prop;           // [N][d]
+  double* blk_states;     // [S][NP][DP] (shared archive: the block's states) or null
+};
+
+__global__ void __launch_bounds__(64 * EXT_WAVES) k_dz_ext_propose(const DzExtArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long long c = (long long)blockIdx.x * EXT_WAVES + (threadIdx.x >> 6);
+  if (c >= a.N || lane >= a.d) return;
+  const size_t o = ((size_t)a.s * a.NP + c) * a.DP + lane;
+  double jump;
+  if (a.jump_ready) {
+    jump = a.coef[o];
+  } else {  // proposal.py:823-826, :850-852
+    const double* arch_c = a.shared ? a.arch : a.arch + (size_t)c * a.cap * a.DP;
+    double z1 = 0.0, z2 = 0.0;
+    for (int i = 0; i < a.delta; ++i) {
+      const int r1 = a.ridx[((size_t)a.s * a.NP + c) * 8 + 2 * i + 0];
+      const int r2 = a.ridx[((size_t)a.s * a.NP + c) * 8 + 2 * i + 1];
+      z1 += arch_c[(size_t)r1 * a.DP + lane];
+      z2 += arch_c[(size_t)r2 * a.DP + lane];
+    }
+    jump = a.coef[o] * (z1 - z2) + a.epsm[o];
+  }
+  a.prop[c * a.d + lane] = a.theta[c * a.DP + lane] + jump;
+}
+
+__global__ void __launch_bounds__(64 * EXT_WAVES) k_dz_ext_append(const DzExtArgs a) {  // proposal.py:794-795
+  const int lane = threadIdx.x & 63;
+  const long long c = (long long)blockIdx.x * EXT_WAVES + (threadIdx.x >> 6);
+  if (c >= a.NP || lane >= a.DP) return;
+  const double cur = a.theta[c * a.DP + lane];
+  if (!a.shared && c < a.N) a.arch[((size_t)c * a.cap + a.M_base + a.s) * a.DP + lane] = cur;
+  if (a.blk_states) a.blk_states[((size_t)a.s * a.NP + c) * a.DP + lane] = cur;
+}
+
 // A linear level inside a host-sequenced hierarchy (e.g. a linear surrogate below a non-linear model): F = A prop for all
 // chains (F = A prop + b), one wave per chain, the lanes stride over the outputs
 __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_linear_eval(long long N, int d, int m, const double* __restrict__ A,
