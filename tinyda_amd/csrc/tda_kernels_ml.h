@@ -206,8 +206,11 @@ __global__ void __launch_bounds__(256, 1) k_ml_steps(const MLArgs a) {
         __builtin_amdgcn_wave_barrier();
         double sacc = 0.0;
         const double* Pc = a.aem_P + (size_t)gc * LD * LD + lane;
-        // MP is a multiple of 16: eight rows of P in flight per lane (same summation order as a plain loop)
-        if (MP <= 64) {
+        // Beyond 64 outputs: P is symmetric, only the 16 x 16 blocks on or below the block diagonal are read (36 of 64 at
+        // m = 128; this loop runs at the HBM roofline).  Per group of 16 rows every lane has ONE weight: 1 in the diagonal block, 2 below it
+        // (the mirrored block above counts with it), 0 beyond -- no per-element predicates:
+        //   r^T P r = sum_j r_j sum_groups w_gj sum_{o in group} P_oj r_o
+        if (MP <= 64) {  // up to 64 outputs the plain loop over full rows is faster (measured): eight rows in flight per lane
           if (l0) {
             for (int o = 0; o < MP; o += 8) {
               double pv[8];
@@ -219,22 +222,32 @@ __global__ void __launch_bounds__(256, 1) k_ml_steps(const MLArgs a) {
             sacc *= rb0;
           }
         } else {
-          double s0 = 0.0, s1 = 0.0;
-          for (int o = 0; o < MP; o += 8) {
-            double pv[8], pw[8];
+          double a0 = 0.0, a1 = 0.0;
+          for (int g = 0; g < MP / 16; ++g) {
+            const int bound = 16 * (g + 1);  // columns of this row group that are read
+            const bool c0 = l0 && lane < bound, c1 = l1 && lane + 64 < bound;
+            const double w0 = (lane >> 4) == g ? 1.0 : 2.0, w1 = ((lane + 64) >> 4) == g ? 1.0 : 2.0;
+            double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              pv[u] = Pc[(size_t)(o + u) * LD];  // l0 holds for every lane here
-              pw[u] = l1 ? Pc[(size_t)(o + u) * LD + 64] : 0.0;
-            }
+            for (int h = 0; h < 2; ++h) {
+              double pv[8], pw[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const double ro = rrow[o + u];
-              s0 = fma(pv[u], ro, s0);
-              s1 = fma(pw[u], ro, s1);
+              for (int u = 0; u < 8; ++u) {
+                const int o = 16 * g + 8 * h + u;
+                pv[u] = c0 ? Pc[(size_t)o * LD] : 0.0;
+                pw[u] = c1 ? Pc[(size_t)o * LD + 64] : 0.0;
+              }
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                const double ro = rrow[16 * g + 8 * h + u];
+                s0 = fma(pv[u], ro, s0);
+                s1 = fma(pw[u], ro, s1);
+              }
             }
+            a0 = fma(w0, s0, a0);
+            a1 = fma(w1, s1, a1);
           }
-          sacc = s0 * rb0 + s1 * rb1;
+          sacc = a0 * rb0 + a1 * rb1;
         }
         for (int off = 32; off >= 1; off >>= 1) sacc += __shfl_xor(sacc, off);
         if (lane == 0) s_R[16 * RSa + cc] = -0.5 * sacc;
@@ -543,7 +556,24 @@ __global__ void __launch_bounds__(MPT) k_aem_action(const AemArgs a) {
     s_v[MPT + lane] = lo ? r : 0.0;
     __syncthreads();
     double s = 0.0;
-    if (lo) {
+    if constexpr (MPT > 64) {
+      // P is symmetric: only the 16 x 16 blocks on or below the block diagonal are read; per group of 16 rows a thread's
+      // column weighs 1 (diagonal block), 2 (below: the mirrored block counts with it) or is not read at all
+      const double* __restrict__ Pc = a.cov_inv[lev] + (size_t)c * MP * MP + lane;
+      double acc = 0.0;
+      for (int g = (lane & ~63) >> 4; 16 * g < a.m; ++g) {  // wave-uniform start: the second wave needs the row groups >= 4 only
+        if (lo && lane < 16 * (g + 1)) {
+          double pv[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) pv[u] = 16 * g + u < a.m ? Pc[(size_t)(16 * g + u) * MP] : 0.0;
+          double sg = 0.0;
+#pragma unroll
+          for (int u = 0; u < 16; ++u) sg = fma(pv[u], s_v[MPT + 16 * g + u], sg);
+          acc = fma((lane >> 4) == g ? 1.0 : 2.0, sg, acc);
+        }
+      }
+      s = acc * r;
+    } else if (lo) {
       const double* __restrict__ Pc = a.cov_inv[lev] + (size_t)c * MP * MP + lane;
 #pragma unroll 8
       for (int o = 0; o < a.m; ++o) s = fma(Pc[(size_t)o * MP], s_v[MPT + o], s);
@@ -804,7 +834,24 @@ __global__ void __launch_bounds__(MPT) k_ext_aem_action(const ExtAemArgs a) {
     s_v[MPT + lane] = lo ? r : 0.0;
     __syncthreads();
     double s = 0.0;
-    if (lo) {
+    if constexpr (MPT > 64) {
+      // P is symmetric: only the 16 x 16 blocks on or below the block diagonal are read; per group of 16 rows a thread's
+      // column weighs 1 (diagonal block), 2 (below: the mirrored block counts with it) or is not read at all
+      const double* __restrict__ Pc = a.cov_inv[lev] + (size_t)c * MP * MP + lane;
+      double acc = 0.0;
+      for (int g = (lane & ~63) >> 4; 16 * g < a.m; ++g) {  // wave-uniform start: the second wave needs the row groups >= 4 only
+        if (lo && lane < 16 * (g + 1)) {
+          double pv[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) pv[u] = 16 * g + u < a.m ? Pc[(size_t)(16 * g + u) * MP] : 0.0;
+          double sg = 0.0;
+#pragma unroll
+          for (int u = 0; u < 16; ++u) sg = fma(pv[u], s_v[MPT + 16 * g + u], sg);
+          acc = fma((lane >> 4) == g ? 1.0 : 2.0, sg, acc);
+        }
+      }
+      s = acc * r;
+    } else if (lo) {
       const double* __restrict__ Pc = a.cov_inv[lev] + (size_t)c * MP * MP + lane;
 #pragma unroll 8
       for (int o = 0; o < a.m; ++o) s = fma(Pc[(size_t)o * MP], s_v[MPT + o], s);
