@@ -2325,6 +2325,262 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
   return TDA_OK;
 }
 
+// One block of S base steps of a hierarchy whose levels live outside the fused level kernel (run_multilevel): batched host
+// callbacks, source-defined models, linear levels beside them.  `ma` carries the block's buffers (increments, uniforms,
+// record rows per level, replay pointers) exactly as the fused kernel would get them.
+static int run_ext_hierarchy_block(tda_engine* e, const MLArgs& ma, int64_t S, bool adaptive) {
+  const int nl = e->nlev, d = e->d, DP = e->DP;
+  const int64_t N = e->N, NP = e->NP;
+  // every base step is propose -> model(level 0) -> accept; when the subchain of level k completes, level k + 1's model is
+  // evaluated at the states of level k (one evaluation for all chains) and k_ext_level_action decides, aligns and records
+  // (the cascade of k_ml_steps, one level at a time)
+  const unsigned grid = (unsigned)((N + EXT_WAVES - 1) / EXT_WAVES);
+  int cc[MAXLEV];
+  int64_t row[MAXLEV] = {0, 0, 0, 0};
+  int64_t rp = e->ring_pos;  // position in the base proposal's accepted list: one entry per base step and per level action
+  for (int k = 0; k < MAXLEV; ++k) cc[k] = e->cnt[k];
+  for (int64_t s = 0; s < S;) {
+    if (e->randomize && cc[0] == 0) {  // Delayed Acceptance: draw the promoted index of the subchain that starts now
+      hipLaunchKernelGGL(k_ext_pick, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, e->stream, (long long)N, e->sl[0],
+                         (unsigned long long)e->cfg.seed, (long long)e->cfg.chain_offset, (long long)(e->done[1] + row[1]),
+                         ma.ridx_rep ? ma.ridx_rep + (size_t)row[1] * N : nullptr, e->ml_pick.p);
+    }
+    if (e->levels[0].model == MODEL_USER && !e->aem && !e->randomize) {
+      // source-defined base level: the rest of the running subchain (inside this block) is ONE launch of the fused
+      // step kernel compiled with the model
+      const int64_t n = std::min<int64_t>(S - s, (int64_t)e->sl[0] - cc[0]);
+      UserStepArgs ua{};
+      int urc = fill_user_args(e, e->levels[0], ua);
+      if (urc) return urc;
+      ua.S = (int)n;
+      ua.mode = 0;
+      ua.prop_kind = e->pp.kind;
+      ua.theta = e->ml_theta.p;
+      ua.lp = e->ml_lp.p;
+      ua.ll = e->ml_ll.p;
+      ua.scaling = e->scaling.p;
+      ua.acc_count = nullptr;
+      ua.inc = e->inc.p + (size_t)s * NP * DP;
+      ua.u = e->ublk.p + (size_t)s * NP;
+      ua.rec_params = ma.rec_params[0] ? ma.rec_params[0] + (size_t)s * N * d : nullptr;
+      ua.rec_stats = ma.rec_stats[0] ? ma.rec_stats[0] + (size_t)s * N * 3 : nullptr;
+      ua.rec_acc = ma.rec_acc[0] ? ma.rec_acc[0] + (size_t)s * N : nullptr;
+      ua.anyacc = e->ml_anyacc.p;
+      ua.ring = adaptive ? e->ml_ring.p : nullptr;
+      ua.ring_P = e->ring_P;
+      ua.ring_pos = rp;
+      if ((urc = launch_user_steps(e->levels[0].ufn, ua, e->stream))) return urc;
+      rp += n;
+      s += n;
+      cc[0] += (int)n;
+    } else if (e->aem) {
+      // base step under the bias-corrected likelihood of the error model (per-chain bias and inverse)
+      const Level& l0 = e->levels[0];
+      ExtArgs pa2{};
+      fill_ext_args(e, l0, pa2);
+      pa2.mode = 0;
+      pa2.prop_kind = e->pp.kind;
+      pa2.theta = e->ml_theta.p;
+      pa2.scaling = e->scaling.p;
+      pa2.inc = e->inc.p;
+      pa2.s = (int)s;
+      hipLaunchKernelGGL(k_ext_propose, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, pa2);
+      int mrc0 = ext_model_outputs(e, l0);
+      if (mrc0) return mrc0;
+      ExtAemAcceptArgs ea{};
+      ea.N = N;
+      ea.NP = NP;
+      ea.d = d;
+      ea.DP = DP;
+      ea.m = e->aem_m;
+      ea.MP = e->aem_ld;
+      ea.s = (int)s;
+      ea.prop_kind = e->pp.kind;
+      ea.theta = e->ml_theta.p;
+      ea.lp = e->ml_lp.p;
+      ea.ll = e->ml_ll.p;
+      ea.u = e->ublk.p;
+      ea.prop = l0.cb_prop.p;
+      ea.F = l0.cb_F.p;
+      ea.data = l0.data64.p;
+      ea.bias = e->aem_bias[0].p;
+      ea.P = e->aem_covinv[0].p;
+      ea.Fcur = e->ext_Fcur[0].p;
+      ea.pr_mean = e->prior_mean.p;
+      ea.pr_pinv = e->prior_pinv.p;
+      ea.logconst = e->prior_logconst;
+      ea.anyacc = e->ml_anyacc.p;
+      ea.sid = e->ml_sid.p;
+      ea.sid_value = e->done[0] + s + 1;
+      ea.ring = adaptive ? e->ml_ring.p : nullptr;
+      ea.ring_P = e->ring_P;
+      ea.ring_pos = rp++;
+      ea.rec_params = ma.rec_params[0];
+      ea.rec_stats = ma.rec_stats[0];
+      ea.rec_acc = ma.rec_acc[0];
+      if (e->aem_ld == 64) hipLaunchKernelGGL(k_ext_aem_accept<64>, dim3((unsigned)N), dim3(64), 0, e->stream, ea);
+      else hipLaunchKernelGGL(k_ext_aem_accept<128>, dim3((unsigned)N), dim3(128), 0, e->stream, ea);
+      HIP_TRY(hipGetLastError());
+      cc[0] += 1;
+      s += 1;
+    } else {
+    ExtArgs xa{};
+    fill_ext_args(e, e->levels[0], xa);
+    xa.mode = 0;
+    xa.prop_kind = e->pp.kind;
+    xa.theta = e->ml_theta.p;
+    xa.lp = e->ml_lp.p;
+    xa.ll = e->ml_ll.p;
+    xa.scaling = e->scaling.p;
+    xa.acc_count = nullptr;
+    xa.anyacc = e->ml_anyacc.p;
+    xa.inc = e->inc.p;
+    xa.u = e->ublk.p;
+    xa.s = (int)s;
+    xa.rec_params = ma.rec_params[0];
+    xa.rec_stats = ma.rec_stats[0];
+    xa.rec_acc = ma.rec_acc[0];
+    xa.ring = adaptive ? e->ml_ring.p : nullptr;
+    xa.ring_P = e->ring_P;
+    xa.ring_pos = rp++;
+    if (e->randomize) {
+      xa.pick = e->ml_pick.p;
+      xa.cnt = cc[0];
+      xa.ysnap = e->ml_ysnap.p;
+    }
+    int xrc = ext_step(e, e->levels[0], xa);
+    if (xrc) return xrc;
+    cc[0] += 1;
+    s += 1;
+    }
+    for (int k = 0; k < nl - 1 && cc[k] == e->sl[k]; ++k) {
+      const int q = k + 1;
+      const Level& lq = e->levels[q];
+      ExtArgs ya{};
+      fill_ext_args(e, lq, ya);
+      ya.mode = 1;  // "proposals" = the current states of level k (the promoted states of a randomised subchain)
+      const bool snap = e->randomize && k == 0;
+      ya.theta = snap ? e->ml_ysnap.p : e->ml_theta.p + (size_t)k * NP * DP;
+      ya.theta_ld = snap ? DP + 2 : 0;
+      hipLaunchKernelGGL(k_ext_propose, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, ya);
+      const int mrc = ext_model_outputs(e, lq);
+      if (mrc) return mrc;
+      if (e->aem) {
+        ExtAemArgs ga{};
+        ga.N = N;
+        ga.NP = NP;
+        ga.chain_offset = e->cfg.chain_offset;
+        ga.d = d;
+        ga.DP = DP;
+        ga.m = e->aem_m;
+        ga.MP = e->aem_ld;
+        ga.nlev = nl;
+        ga.q = q;
+        ga.is_da = nl == 2;
+        ga.dependent = e->aem == TDA_AEM_STATE_DEPENDENT;
+        ga.prop_kind = e->pp.kind;
+        ga.pr_W = e->prior_W_rm.p;
+        ga.pr_logdet = e->prior_logconst - d * std::log(2.0 * M_PI);
+        ga.scaling = e->scaling.p;
+        ga.seed = e->cfg.seed;
+        ga.step = e->done[q] + row[q];
+        ga.Fnew = lq.cb_F.p;
+        for (int k2 = 0; k2 < nl; ++k2) {
+          ga.data[k2] = e->levels[k2].data64.p;
+          ga.Fcur[k2] = e->ext_Fcur[k2].p;
+          ga.bias_tot[k2] = e->aem_bias[k2].p;
+          ga.cov_inv[k2] = e->aem_covinv[k2].p;
+          ga.b_mu[k2] = e->aem_bmu[k2].p;
+          ga.b_sig[k2] = e->aem_bsig[k2].p;
+          ga.mdiff[k2] = e->aem_mdiff[k2].p;
+        }
+        ga.var_finest = e->levels[nl - 1].var;
+        ga.Fst = e->ext_Fst.p;
+        ga.theta = e->ml_theta.p;
+        ga.lp = e->ml_lp.p;
+        ga.ll = e->ml_ll.p;
+        ga.Sst = e->ml_S.p;
+        ga.anyacc = e->ml_anyacc.p;
+        ga.sid = e->ml_sid.p;
+        ga.b_t = e->aem_bt[q];
+        ga.u_rep = ma.u_rep[q] ? ma.u_rep[q] + (size_t)row[q] * N : nullptr;
+        ga.ring = adaptive ? e->ml_ring.p : nullptr;
+        ga.ring_P = e->ring_P;
+        ga.ring_pos = rp++;
+        ga.rec_params = ma.rec_params[q] ? ma.rec_params[q] + (size_t)row[q] * N * d : nullptr;
+        ga.rec_stats = ma.rec_stats[q] ? ma.rec_stats[q] + (size_t)row[q] * N * 3 : nullptr;
+        ga.rec_acc = ma.rec_acc[q] ? ma.rec_acc[q] + (size_t)row[q] * N : nullptr;
+        AemInvArgs iv{};
+        iv.N = N;
+        iv.m = e->aem_m;
+        iv.MP = e->aem_ld;
+        iv.nb = (e->aem_m + 15) / 16;
+        iv.cov = e->levels[k].cov64.p;
+        if (ga.dependent) {
+          iv.nsum = 1;
+          iv.sig[0] = e->aem_bsig[q].p;
+        } else {
+          iv.nsum = nl - q;
+          for (int p2 = q; p2 < nl; ++p2) iv.sig[p2 - q] = e->aem_bsig[p2].p;
+        }
+        iv.P = e->aem_covinv[k].p;
+        const size_t inv_lds = aem_inverse_lds_bytes(iv.nb);
+        if (inv_lds > 64 * 1024)
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aem_inverse<0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)inv_lds));
+        for (int phase = 0; phase < 2; ++phase) {
+          ga.phase = phase;
+          if (e->aem_ld == 64) hipLaunchKernelGGL(k_ext_aem_action<64>, dim3((unsigned)N), dim3(64), 0, e->stream, ga);
+          else hipLaunchKernelGGL(k_ext_aem_action<128>, dim3((unsigned)N), dim3(128), 0, e->stream, ga);
+          if (phase == 0) {
+            if (iv.nb > 4) hipLaunchKernelGGL((k_aem_inverse<0, 8>), dim3((unsigned)N), dim3(512), inv_lds, e->stream, iv);
+            else hipLaunchKernelGGL((k_aem_inverse<0, 4>), dim3((unsigned)N), dim3(256), inv_lds, e->stream, iv);
+          }
+        }
+        HIP_TRY(hipGetLastError());
+        e->aem_bt[q] += 1;
+        cc[k] = 0;
+        cc[q] += 1;
+        row[q] += 1;
+        continue;
+      }
+      ExtLevelArgs la{};
+      la.N = N;
+      la.NP = NP;
+      la.chain_offset = e->cfg.chain_offset;
+      la.d = d;
+      la.DP = DP;
+      la.m = lq.m;
+      la.nlev = nl;
+      la.q = q;
+      la.seed = e->cfg.seed;
+      la.step = e->done[q] + row[q];
+      la.F = lq.cb_F.p;
+      la.data = lq.udata.p;
+      la.w = lq.noise_kind == TDA_NOISE_DIAG ? lq.uw.p : nullptr;
+      la.var = lq.var;
+      la.theta = e->ml_theta.p;
+      la.lp = e->ml_lp.p;
+      la.ll = e->ml_ll.p;
+      la.Sst = e->ml_S.p;
+      la.anyacc = e->ml_anyacc.p;
+      la.u_rep = ma.u_rep[q] ? ma.u_rep[q] + (size_t)row[q] * N : nullptr;
+      la.rec_params = ma.rec_params[q] ? ma.rec_params[q] + (size_t)row[q] * N * d : nullptr;
+      la.rec_stats = ma.rec_stats[q] ? ma.rec_stats[q] + (size_t)row[q] * N * 3 : nullptr;
+      la.rec_acc = ma.rec_acc[q] ? ma.rec_acc[q] + (size_t)row[q] * N : nullptr;
+      la.ring = adaptive ? e->ml_ring.p : nullptr;
+      la.ring_P = e->ring_P;
+      la.ring_pos = rp++;
+      la.ysnap = (e->randomize && k == 0) ? e->ml_ysnap.p : nullptr;
+      hipLaunchKernelGGL(k_ext_level_action, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, la);
+      HIP_TRY(hipGetLastError());
+      cc[k] = 0;
+      cc[q] += 1;
+      row[q] += 1;
+    }
+  }
+  return TDA_OK;
+}
+
 static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs) {
   HIP_TRY(hipSetDevice(e->cfg.device));
   const int nl = e->nlev, d = e->d, DP = e->DP;
@@ -2515,253 +2771,8 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
     }
     if (async_host && blk_ix >= 2) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_cp[blk_ix & 1], 0));  // buffer set free again
     if (e->ext_hier) {
-      // host-sequenced hierarchy (batched host callbacks and / or source-defined models): every base step is propose -> callback(level 0) -> accept; when the subchain of level
-      // k completes, level k + 1's model is evaluated at the states of level k (one callback for all chains) and
-      // k_ext_level_action decides, aligns and records (the cascade of k_ml_steps, one level at a time)
-      const unsigned grid = (unsigned)((N + EXT_WAVES - 1) / EXT_WAVES);
-      int cc[MAXLEV];
-      int64_t row[MAXLEV] = {0, 0, 0, 0};
-      int64_t rp = e->ring_pos;  // position in the base proposal's accepted list: one entry per base step and per level action
-      for (int k = 0; k < MAXLEV; ++k) cc[k] = e->cnt[k];
-      for (int64_t s = 0; s < S;) {
-        if (e->randomize && cc[0] == 0) {  // Delayed Acceptance: draw the promoted index of the subchain that starts now
-          hipLaunchKernelGGL(k_ext_pick, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, e->stream, (long long)N, e->sl[0],
-                             (unsigned long long)e->cfg.seed, (long long)e->cfg.chain_offset, (long long)(e->done[1] + row[1]),
-                             ma.ridx_rep ? ma.ridx_rep + (size_t)row[1] * N : nullptr, e->ml_pick.p);
-        }
-        if (e->levels[0].model == MODEL_USER && !e->aem && !e->randomize) {
-          // source-defined base level: the rest of the running subchain (inside this block) is ONE launch of the fused
-          // step kernel compiled with the model
-          const int64_t n = std::min<int64_t>(S - s, (int64_t)e->sl[0] - cc[0]);
-          UserStepArgs ua{};
-          int urc = fill_user_args(e, e->levels[0], ua);
-          if (urc) return urc;
-          ua.S = (int)n;
-          ua.mode = 0;
-          ua.prop_kind = e->pp.kind;
-          ua.theta = e->ml_theta.p;
-          ua.lp = e->ml_lp.p;
-          ua.ll = e->ml_ll.p;
-          ua.scaling = e->scaling.p;
-          ua.acc_count = nullptr;
-          ua.inc = e->inc.p + (size_t)s * NP * DP;
-          ua.u = e->ublk.p + (size_t)s * NP;
-          ua.rec_params = ma.rec_params[0] ? ma.rec_params[0] + (size_t)s * N * d : nullptr;
-          ua.rec_stats = ma.rec_stats[0] ? ma.rec_stats[0] + (size_t)s * N * 3 : nullptr;
-          ua.rec_acc = ma.rec_acc[0] ? ma.rec_acc[0] + (size_t)s * N : nullptr;
-          ua.anyacc = e->ml_anyacc.p;
-          ua.ring = adaptive ? e->ml_ring.p : nullptr;
-          ua.ring_P = e->ring_P;
-          ua.ring_pos = rp;
-          if ((urc = launch_user_steps(e->levels[0].ufn, ua, e->stream))) return urc;
-          rp += n;
-          s += n;
-          cc[0] += (int)n;
-        } else if (e->aem) {
-          // base step under the bias-corrected likelihood of the error model (per-chain bias and inverse)
-          const Level& l0 = e->levels[0];
-          ExtArgs pa2{};
-          fill_ext_args(e, l0, pa2);
-          pa2.mode = 0;
-          pa2.prop_kind = e->pp.kind;
-          pa2.theta = e->ml_theta.p;
-          pa2.scaling = e->scaling.p;
-          pa2.inc = e->inc.p;
-          pa2.s = (int)s;
-          hipLaunchKernelGGL(k_ext_propose, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, pa2);
-          int mrc0 = ext_model_outputs(e, l0);
-          if (mrc0) return mrc0;
-          ExtAemAcceptArgs ea{};
-          ea.N = N;
-          ea.NP = NP;
-          ea.d = d;
-          ea.DP = DP;
-          ea.m = e->aem_m;
-          ea.MP = e->aem_ld;
-          ea.s = (int)s;
-          ea.prop_kind = e->pp.kind;
-          ea.theta = e->ml_theta.p;
-          ea.lp = e->ml_lp.p;
-          ea.ll = e->ml_ll.p;
-          ea.u = e->ublk.p;
-          ea.prop = l0.cb_prop.p;
-          ea.F = l0.cb_F.p;
-          ea.data = l0.data64.p;
-          ea.bias = e->aem_bias[0].p;
-          ea.P = e->aem_covinv[0].p;
-          ea.Fcur = e->ext_Fcur[0].p;
-          ea.pr_mean = e->prior_mean.p;
-          ea.pr_pinv = e->prior_pinv.p;
-          ea.logconst = e->prior_logconst;
-          ea.anyacc = e->ml_anyacc.p;
-          ea.sid = e->ml_sid.p;
-          ea.sid_value = e->done[0] + s + 1;
-          ea.ring = adaptive ? e->ml_ring.p : nullptr;
-          ea.ring_P = e->ring_P;
-          ea.ring_pos = rp++;
-          ea.rec_params = ma.rec_params[0];
-          ea.rec_stats = ma.rec_stats[0];
-          ea.rec_acc = ma.rec_acc[0];
-          if (e->aem_ld == 64) hipLaunchKernelGGL(k_ext_aem_accept<64>, dim3((unsigned)N), dim3(64), 0, e->stream, ea);
-          else hipLaunchKernelGGL(k_ext_aem_accept<128>, dim3((unsigned)N), dim3(128), 0, e->stream, ea);
-          HIP_TRY(hipGetLastError());
-          cc[0] += 1;
-          s += 1;
-        } else {
-        ExtArgs xa{};
-        fill_ext_args(e, e->levels[0], xa);
-        xa.mode = 0;
-        xa.prop_kind = e->pp.kind;
-        xa.theta = e->ml_theta.p;
-        xa.lp = e->ml_lp.p;
-        xa.ll = e->ml_ll.p;
-        xa.scaling = e->scaling.p;
-        xa.acc_count = nullptr;
-        xa.anyacc = e->ml_anyacc.p;
-        xa.inc = e->inc.p;
-        xa.u = e->ublk.p;
-        xa.s = (int)s;
-        xa.rec_params = ma.rec_params[0];
-        xa.rec_stats = ma.rec_stats[0];
-        xa.rec_acc = ma.rec_acc[0];
-        xa.ring = adaptive ? e->ml_ring.p : nullptr;
-        xa.ring_P = e->ring_P;
-        xa.ring_pos = rp++;
-        if (e->randomize) {
-          xa.pick = e->ml_pick.p;
-          xa.cnt = cc[0];
-          xa.ysnap = e->ml_ysnap.p;
-        }
-        int xrc = ext_step(e, e->levels[0], xa);
-        if (xrc) return xrc;
-        cc[0] += 1;
-        s += 1;
-        }
-        for (int k = 0; k < nl - 1 && cc[k] == e->sl[k]; ++k) {
-          const int q = k + 1;
-          const Level& lq = e->levels[q];
-          ExtArgs ya{};
-          fill_ext_args(e, lq, ya);
-          ya.mode = 1;  // "proposals" = the current states of level k (the promoted states of a randomised subchain)
-          const bool snap = e->randomize && k == 0;
-          ya.theta = snap ? e->ml_ysnap.p : e->ml_theta.p + (size_t)k * NP * DP;
-          ya.theta_ld = snap ? DP + 2 : 0;
-          hipLaunchKernelGGL(k_ext_propose, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, ya);
-          const int mrc = ext_model_outputs(e, lq);
-          if (mrc) return mrc;
-          if (e->aem) {
-            ExtAemArgs ga{};
-            ga.N = N;
-            ga.NP = NP;
-            ga.chain_offset = e->cfg.chain_offset;
-            ga.d = d;
-            ga.DP = DP;
-            ga.m = e->aem_m;
-            ga.MP = e->aem_ld;
-            ga.nlev = nl;
-            ga.q = q;
-            ga.is_da = nl == 2;
-            ga.dependent = e->aem == TDA_AEM_STATE_DEPENDENT;
-            ga.prop_kind = e->pp.kind;
-            ga.pr_W = e->prior_W_rm.p;
-            ga.pr_logdet = e->prior_logconst - d * std::log(2.0 * M_PI);
-            ga.scaling = e->scaling.p;
-            ga.seed = e->cfg.seed;
-            ga.step = e->done[q] + row[q];
-            ga.Fnew = lq.cb_F.p;
-            for (int k2 = 0; k2 < nl; ++k2) {
-              ga.data[k2] = e->levels[k2].data64.p;
-              ga.Fcur[k2] = e->ext_Fcur[k2].p;
-              ga.bias_tot[k2] = e->aem_bias[k2].p;
-              ga.cov_inv[k2] = e->aem_covinv[k2].p;
-              ga.b_mu[k2] = e->aem_bmu[k2].p;
-              ga.b_sig[k2] = e->aem_bsig[k2].p;
-              ga.mdiff[k2] = e->aem_mdiff[k2].p;
-            }
-            ga.var_finest = e->levels[nl - 1].var;
-            ga.Fst = e->ext_Fst.p;
-            ga.theta = e->ml_theta.p;
-            ga.lp = e->ml_lp.p;
-            ga.ll = e->ml_ll.p;
-            ga.Sst = e->ml_S.p;
-            ga.anyacc = e->ml_anyacc.p;
-            ga.sid = e->ml_sid.p;
-            ga.b_t = e->aem_bt[q];
-            ga.u_rep = ma.u_rep[q] ? ma.u_rep[q] + (size_t)row[q] * N : nullptr;
-            ga.ring = adaptive ? e->ml_ring.p : nullptr;
-            ga.ring_P = e->ring_P;
-            ga.ring_pos = rp++;
-            ga.rec_params = ma.rec_params[q] ? ma.rec_params[q] + (size_t)row[q] * N * d : nullptr;
-            ga.rec_stats = ma.rec_stats[q] ? ma.rec_stats[q] + (size_t)row[q] * N * 3 : nullptr;
-            ga.rec_acc = ma.rec_acc[q] ? ma.rec_acc[q] + (size_t)row[q] * N : nullptr;
-            AemInvArgs iv{};
-            iv.N = N;
-            iv.m = e->aem_m;
-            iv.MP = e->aem_ld;
-            iv.nb = (e->aem_m + 15) / 16;
-            iv.cov = e->levels[k].cov64.p;
-            if (ga.dependent) {
-              iv.nsum = 1;
-              iv.sig[0] = e->aem_bsig[q].p;
-            } else {
-              iv.nsum = nl - q;
-              for (int p2 = q; p2 < nl; ++p2) iv.sig[p2 - q] = e->aem_bsig[p2].p;
-            }
-            iv.P = e->aem_covinv[k].p;
-            const size_t inv_lds = aem_inverse_lds_bytes(iv.nb);
-            if (inv_lds > 64 * 1024)
-              HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aem_inverse<0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)inv_lds));
-            for (int phase = 0; phase < 2; ++phase) {
-              ga.phase = phase;
-              if (e->aem_ld == 64) hipLaunchKernelGGL(k_ext_aem_action<64>, dim3((unsigned)N), dim3(64), 0, e->stream, ga);
-              else hipLaunchKernelGGL(k_ext_aem_action<128>, dim3((unsigned)N), dim3(128), 0, e->stream, ga);
-              if (phase == 0) {
-                if (iv.nb > 4) hipLaunchKernelGGL((k_aem_inverse<0, 8>), dim3((unsigned)N), dim3(512), inv_lds, e->stream, iv);
-                else hipLaunchKernelGGL((k_aem_inverse<0, 4>), dim3((unsigned)N), dim3(256), inv_lds, e->stream, iv);
-              }
-            }
-            HIP_TRY(hipGetLastError());
-            e->aem_bt[q] += 1;
-            cc[k] = 0;
-            cc[q] += 1;
-            row[q] += 1;
-            continue;
-          }
-          ExtLevelArgs la{};
-          la.N = N;
-          la.NP = NP;
-          la.chain_offset = e->cfg.chain_offset;
-          la.d = d;
-          la.DP = DP;
-          la.m = lq.m;
-          la.nlev = nl;
-          la.q = q;
-          la.seed = e->cfg.seed;
-          la.step = e->done[q] + row[q];
-          la.F = lq.cb_F.p;
-          la.data = lq.udata.p;
-          la.w = lq.noise_kind == TDA_NOISE_DIAG ? lq.uw.p : nullptr;
-          la.var = lq.var;
-          la.theta = e->ml_theta.p;
-          la.lp = e->ml_lp.p;
-          la.ll = e->ml_ll.p;
-          la.Sst = e->ml_S.p;
-          la.anyacc = e->ml_anyacc.p;
-          la.u_rep = ma.u_rep[q] ? ma.u_rep[q] + (size_t)row[q] * N : nullptr;
-          la.rec_params = ma.rec_params[q] ? ma.rec_params[q] + (size_t)row[q] * N * d : nullptr;
-          la.rec_stats = ma.rec_stats[q] ? ma.rec_stats[q] + (size_t)row[q] * N * 3 : nullptr;
-          la.rec_acc = ma.rec_acc[q] ? ma.rec_acc[q] + (size_t)row[q] * N : nullptr;
-          la.ring = adaptive ? e->ml_ring.p : nullptr;
-          la.ring_P = e->ring_P;
-          la.ring_pos = rp++;
-          la.ysnap = (e->randomize && k == 0) ? e->ml_ysnap.p : nullptr;
-          hipLaunchKernelGGL(k_ext_level_action, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, la);
-          HIP_TRY(hipGetLastError());
-          cc[k] = 0;
-          cc[q] += 1;
-          row[q] += 1;
-        }
-      }
+      const int xrc = run_ext_hierarchy_block(e, ma, S, adaptive);
+      if (xrc) return xrc;
     } else {
       ScopedTimer tm(e, 1);
       DISPATCH_DPAD(DP, launch_ml<DPAD>(ma, NP / 16, lds, e->stream));
