@@ -1282,6 +1282,7 @@ void enumerate_state(tda_engine* e, std::vector<StateItem>& v) {
       dev(e->aem_mdiff[k]);
       dev(e->ext_Fcur[k]);
     }
+    dev(e->ext_Fst);
   }
   if (e->is_dreamz) {
     host(&e->arch_rows, sizeof e->arch_rows);
