@@ -155,7 +155,7 @@ struct Level {
     cb_theta_h = cb_F_h = nullptr;
   }
   hipModule_t umod = nullptr;
-  hipFunction_t ufn = nullptr, ufn_eval = nullptr;
+  hipFunction_t ufn = nullptr, ufn_eval = nullptr, ufn_level = nullptr;
   DevBuf<double> udata, uw;
   double ros_a = 1.0, ros_b = 10.0, ros_data = 0.0;
   DevBuf<double> Apk, ytil, w, Ppk;
@@ -965,8 +965,9 @@ int tda_engine_set_level_source(tda_engine* e, int level, const char* source, in
     lv.umod = nullptr;
     lv.ufn = nullptr;
     lv.ufn_eval = nullptr;
+    lv.ufn_level = nullptr;
   }
-  int rc = compile_user_model(source, &lv.umod, &lv.ufn, &lv.ufn_eval);
+  int rc = compile_user_model(source, &lv.umod, &lv.ufn, &lv.ufn_eval, &lv.ufn_level);
   if (rc) return rc;
   std::vector<double> y(data, data + m), w;
   if (noise_kind == TDA_NOISE_ADAPTIVE) {
@@ -2457,6 +2458,44 @@ static int run_ext_hierarchy_block(tda_engine* e, const MLArgs& ma, int64_t S, b
     for (int k = 0; k < nl - 1 && cc[k] == e->sl[k]; ++k) {
       const int q = k + 1;
       const Level& lq = e->levels[q];
+      if (lq.model == MODEL_USER && !e->aem) {
+        // source-defined level without error model: evaluation, decision, alignment and records in one launch of the
+        // kernel compiled with the model (+ the step's uniforms)
+        double* ul = e->lublk.p;  // scratch of the single-level path, at least SMAX * NP doubles
+        hipLaunchKernelGGL(k_ext_level_uniforms, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, e->stream, (long long)N,
+                           (unsigned long long)e->cfg.seed, (long long)e->cfg.chain_offset, (long long)(e->done[q] + row[q]), q,
+                           ma.u_rep[q] ? ma.u_rep[q] + (size_t)row[q] * N : nullptr, ul);
+        UserLevelArgs ua{};
+        ua.N = N;
+        ua.NP = NP;
+        ua.d = d;
+        ua.DP = DP;
+        ua.m = lq.m;
+        ua.nlev = nl;
+        ua.q = q;
+        ua.data = lq.udata.p;
+        ua.w = lq.noise_kind == TDA_NOISE_DIAG ? lq.uw.p : nullptr;
+        ua.var = lq.var;
+        ua.theta = e->ml_theta.p;
+        ua.lp = e->ml_lp.p;
+        ua.ll = e->ml_ll.p;
+        ua.Sst = e->ml_S.p;
+        ua.anyacc = e->ml_anyacc.p;
+        ua.u = ul;
+        ua.rec_params = ma.rec_params[q] ? ma.rec_params[q] + (size_t)row[q] * N * d : nullptr;
+        ua.rec_stats = ma.rec_stats[q] ? ma.rec_stats[q] + (size_t)row[q] * N * 3 : nullptr;
+        ua.rec_acc = ma.rec_acc[q] ? ma.rec_acc[q] + (size_t)row[q] * N : nullptr;
+        ua.ring = adaptive ? e->ml_ring.p : nullptr;
+        ua.ring_P = e->ring_P;
+        ua.ring_pos = rp++;
+        ua.ysnap = (e->randomize && k == 0) ? e->ml_ysnap.p : nullptr;
+        int lrc = launch_user_level(lq.ufn_level, ua, e->stream);
+        if (lrc) return lrc;
+        cc[k] = 0;
+        cc[q] += 1;
+        row[q] += 1;
+        continue;
+      }
       ExtArgs ya{};
       fill_ext_args(e, lq, ya);
       ya.mode = 1;  // "proposals" = the current states of level k (the promoted states of a randomised subchain)

@@ -205,6 +205,15 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_dz_ext_append(const DzExtArg
   if (a.blk_states) a.blk_states[((size_t)a.s * a.NP + c) * a.DP + lane] = cur;
 }
 
+// accept uniforms of one level-q step for all chains (accept_uniform of the RNG contract), for level kernels that are
+// compiled with a user's model source and know nothing of the engine's Philox
+__global__ void k_ext_level_uniforms(long long N, unsigned long long seed, long long chain_offset, long long step, int level,
+                                     const double* __restrict__ u_rep, double* __restrict__ u) {
+  const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  u[c] = u_rep ? u_rep[c] : accept_uniform(seed, (uint32_t)(chain_offset + c), (uint32_t)step, (uint32_t)level);
+}
+
 // A linear level inside a host-sequenced hierarchy (e.g. a linear surrogate below a non-linear model): F = A prop for all
 // chains (F = A prop + b), one wave per chain, the lanes stride over the outputs
 __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_linear_eval(long long N, int d, int m, const double* __restrict__ A,
