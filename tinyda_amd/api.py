@@ -4,6 +4,7 @@ with the per-chain Python loop replaced by the HIP engine for every configuratio
 Extra keyword-only arguments (not in the reference): seed, backend, device, chain_offset.
 """
 import copy
+import os
 import warnings
 
 import numpy as np
@@ -85,10 +86,11 @@ def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None
     if distributed:
         from . import distributed as tdist
 
-        rank, local_rank, world = tdist.init_process_group()
+        one_gpu = os.environ.get("TINYDA_BENCH_ONE_GPU") == "1"  # rehearsal of the N > 1 path on a one-GPU box: every rank on cuda:0, gloo
+        rank, local_rank, world = tdist.init_process_group("gloo" if one_gpu else None)
         total = n_chains
         chain_offset, n_chains = tdist.shard_chains(total, rank, world)
-        device = local_rank
+        device = 0 if one_gpu else local_rank
         if isinstance(initial_parameters, list):
             initial_parameters = initial_parameters[chain_offset:chain_offset + n_chains]
         if seed is None:

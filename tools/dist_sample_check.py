@@ -1,3 +1,4 @@
+"""Rehearsal of sample(distributed=True) on a one-GPU box: TINYDA_BENCH_ONE_GPU=1 python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tools/dist_sample_check.py"""
 import sys, numpy as np, scipy.stats as st
 sys.path.insert(0, "/root/repo")
 import tinyda_amd as tda
@@ -7,4 +8,4 @@ post = tda.Posterior(st.multivariate_normal(np.zeros(6), np.eye(6)), tda.Gaussia
 res = tda.sample(post, tda.DREAM(24, adaptive=True, period=20), 40, n_chains=32, seed=5, distributed=True)
 print("DIST_OK", res["n_chains"], res["chain_offset"], len(res["chain_0"]), res["proposal_state"]["archive_rows"])
 res = tda.sample(post, tda.AdaptiveMetropolis(0.05 * np.eye(6), t0=10, period=10), 40, n_chains=32, seed=5, distributed=True)
-print("DIST_OK", res["n_chains"], res["chain_offset"], len(res["chain_31"]))
+print("DIST_OK", res["n_chains"], res["chain_offset"], len(res["chain_%d" % (res["n_chains"] - 1)]))
