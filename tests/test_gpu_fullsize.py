@@ -126,3 +126,35 @@ def test_c4_dream_full_size(eng_mod):
     assert st["archive_rows"] == M0 + T * N
     np.testing.assert_allclose(st["pCR"].sum(axis=1), 1.0, rtol=1e-12)
     e.close()
+
+
+def test_c5_error_model_full_size(eng_mod):
+    """SURVEY's C5 with the state-independent error model: 4096 chains, d = 64, three linear levels with a common output
+    dimension of 128, AdaptiveMetropolis, subchains [5, 3].  Invariants: the finest records carry the finest posterior
+    (re-evaluated by the oracle), every chain's (Sigma_e + Sigma_bias)^-1 is finite, symmetric and positive on the
+    diagonal, biases are finite, the levels move."""
+    N, d, m, n_fine = 4096, 64, 128, 4
+    rng = np.random.default_rng(6)
+    truth = rng.standard_normal(d)
+    Af = rng.standard_normal((m, d)) / 8
+    y = Af @ truth + 0.1 * rng.standard_normal(m)
+    As = [Af + 0.02 * (2 - k) * rng.standard_normal((m, d)) / 8 for k in range(3)]
+    e = eng_mod.Engine(N, d, seed=10, n_levels=3)
+    e.set_prior(np.zeros(d), np.eye(d))
+    for k in range(3):
+        e.set_level(k, As[k], y, 3 if k < 2 else 0, 0.01 * np.eye(m) if k < 2 else 0.01)
+    e.set_proposal(2, 1e-4 * np.eye(d), t0=100, period=100)
+    e.set_subchains([5, 3])
+    e.set_error_model("state-independent")
+    e.init(truth + 0.02 * rng.standard_normal((N, d)))
+    outs = e.run_levels_host(n_fine)
+    bias, P = e.error_model_state(0, m)
+    e.close()
+    Pf, Sf, Af_ = outs[2]
+    assert np.isfinite(Pf).all() and np.isfinite(Sf).all() and np.isfinite(bias).all() and np.isfinite(P).all()
+    lvl = orc.LinearGaussianLevel(As[2], y, "iso", 0.01, orc.MVNPrior(np.zeros(d), np.eye(d)))
+    idx = rng.choice(N, 64, replace=False)
+    lp, ll, _ = lvl.evaluate(Pf[-1, idx])
+    np.testing.assert_allclose(Sf[-1, idx, 2], lp + ll, rtol=1e-10)
+    assert np.allclose(P, np.swapaxes(P, 1, 2), rtol=1e-9, atol=1e-9) and (np.einsum("cii->ci", P) > 0).all()
+    assert 0.02 < outs[0][2].mean() < 0.98 and 0.02 < Af_.mean() <= 1.0
