@@ -72,20 +72,25 @@ struct MLArgs {
 
 __device__ __forceinline__ constexpr int pair_index(int j, int q) { return q * (q - 1) / 2 + j; }
 
-template <int DPAD, int NLEV>
-__global__ void __launch_bounds__(256, 1) k_ml_steps(const MLArgs a) {
+// NW = waves sharing the tile: 4 (one per SIMD, up to 512 registers, pairs of observation blocks in flight) or 8 (two per
+// SIMD with 256 registers each, the single-block pipeline of the 8-wave single-level tile; 17-30 % faster at every m,
+// tools/waves_vs_m.py) where the level count leaves the registers for it.
+template <int DPAD, int NLEV, int NW = 4>
+__global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
+  constexpr int NT = 64 * NW;
+  constexpr int TPC = 4 * NW;  // threads per chain in the thread-mapped phases
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int KS = DPAD / 4;
   constexpr int LDP = DPAD + 2;
-  constexpr int EPT = DPAD >= 16 ? DPAD / 16 : 1;
+  constexpr int EPT = DPAD >= TPC ? DPAD / TPC : 1;
   constexpr int QACT = DPAD / EPT;
   constexpr int NPAIR = NLEV * (NLEV - 1) / 2;
 
   const bool prior_dense = a.pr.kind == PRIOR_DENSE;
   double* s_prop = smem;
   double* s_red = s_prop + 16 * LDP;
-  double* s_redp = s_red + 64;
-  double* s_stage = s_redp + 64;           // ytil / w of every level
+  double* s_redp = s_red + 16 * NW;
+  double* s_stage = s_redp + 16 * NW;      // ytil / w of every level
   double* s_py = s_stage + a.lds_total;    // dense prior: W mu
   double* s_R = s_py + (prior_dense ? a.pr.ncb * 16 : 0);  // AEM: residual tile [16][aem_mp + 2], then [16] ll slots
   const int RSa = a.aem_mp + 2;
@@ -94,7 +99,7 @@ __global__ void __launch_bounds__(256, 1) k_ml_steps(const MLArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t tile = blockIdx.x;
-  const int c = tid >> 4, q_ = tid & 15;
+  const int c = tid / TPC, q_ = tid % TPC;
   const int lc = lane & 15, hi = lane >> 4;
   const int64_t gct = tile * 16 + c;
   const int64_t gcl = tile * 16 + lc;
@@ -103,13 +108,13 @@ __global__ void __launch_bounds__(256, 1) k_ml_steps(const MLArgs a) {
 
 #pragma unroll
   for (int k = 0; k < NLEV; ++k) {
-    for (int i = tid; i < a.lv[k].m_pad; i += 256) {
+    for (int i = tid; i < a.lv[k].m_pad; i += NT) {
       s_stage[a.lds_y[k] + i] = a.lv[k].ytil[i];
       if (a.lv[k].noise_kind == 1) s_stage[a.lds_w[k] + i] = a.lv[k].w[i];
     }
   }
   if (prior_dense)
-    for (int i = tid; i < a.pr.ncb * 16; i += 256) s_py[i] = a.pr.wmu[i];
+    for (int i = tid; i < a.pr.ncb * 16; i += NT) s_py[i] = a.pr.wmu[i];
 
   double pm[KS], pinv[KS];
 #pragma unroll
@@ -159,11 +164,13 @@ __global__ void __launch_bounds__(256, 1) k_ml_steps(const MLArgs a) {
   }
   int64_t ringpos = a.ring_pos;
   const FragSrc fbase = frag_src(a.lv[0].Apk, lane);
-  double2 f0[KS / 2], f1[KS / 2];
+  constexpr bool PAIRS = NW == 4;
+  double2 f0[KS / 2], f1[PAIRS ? KS / 2 : 1];
+  if constexpr (!PAIRS) frag_load_buf<DPAD>(fbase, wave < a.lv[0].ncb ? wave : a.lv[0].ncb - 1, f0);  // later steps: prefetched by the previous one
   __syncthreads();
 
   // evaluate level `k` at the state currently in s_prop (all 4 waves); returns (lp_n, ll_n) lane-mapped
-  auto evaluate = [&](int k, double2 (&g0)[KS / 2], double2 (&g1)[KS / 2], double& lp_n, double& ll_n) {
+  auto evaluate = [&](int k, double2 (&g0)[KS / 2], double2 (&g1)[PAIRS ? KS / 2 : 1], double& lp_n, double& ll_n) {
     double th[KS];
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) th[kk] = s_prop[lc * LDP + 4 * kk + hi];
@@ -179,10 +186,17 @@ __global__ void __launch_bounds__(256, 1) k_ml_steps(const MLArgs a) {
       maha = p;
     } else {
       const FragSrc pbase = frag_src(a.pr.Wpk, lane);
-      double2 p0[KS / 2], p1[KS / 2];
-      frag_load<DPAD>(pbase, wave, a.pr.ncb, p0);
-      frag_load<DPAD>(pbase, wave + 4, a.pr.ncb, p1);
-      double p = level_sse_partial<DPAD, 0>(a.pr.Wpk, a.pr.ncb, s_py, nullptr, th, wave, lane, p0, p1);
+      double p;
+      if constexpr (PAIRS) {
+        double2 p0[KS / 2], p1[KS / 2];
+        frag_load<DPAD>(pbase, wave, a.pr.ncb, p0);
+        frag_load<DPAD>(pbase, wave + 4, a.pr.ncb, p1);
+        p = level_sse_partial<DPAD, 0>(a.pr.Wpk, a.pr.ncb, s_py, nullptr, th, wave, lane, p0, p1);
+      } else {
+        double2 p0[KS / 2];
+        frag_load_buf<DPAD>(pbase, wave < a.pr.ncb ? wave : a.pr.ncb - 1, p0);
+        p = level_sse_single<DPAD, 0, NW>(a.pr.Wpk, a.pr.ncb, s_py, nullptr, th, wave, lane, p0);
+      }
       p = sum_rows(p);
       if (lane < 16) s_redp[wave * 16 + lane] = p;
     }
@@ -190,10 +204,11 @@ __global__ void __launch_bounds__(256, 1) k_ml_steps(const MLArgs a) {
     const bool dg = L.noise_kind == 1;
     if (a.aem_on && k == 0) {
       // residual tile, then per chain  -1/2 (F + bias - y)^T P (F + bias - y)  with that chain's bias and P
-      (void)level_sse_partial<DPAD, 2>(L.Apk, L.ncb, s_stage + a.lds_y[k], s_R + lc * RSa, th, wave, lane, g0, g1);
+      if constexpr (PAIRS) (void)level_sse_partial<DPAD, 2>(L.Apk, L.ncb, s_stage + a.lds_y[k], s_R + lc * RSa, th, wave, lane, g0, g1);
+      else (void)level_sse_single<DPAD, 2, NW>(L.Apk, L.ncb, s_stage + a.lds_y[k], s_R + lc * RSa, th, wave, lane, g0);
       __syncthreads();
       const int MP = a.aem_mp, LD = a.aem_ld;
-      for (int cc = wave; cc < 16; cc += 4) {  // lane = observation (and observation + 64 beyond 64 outputs)
+      for (int cc = wave; cc < 16; cc += NW) {  // lane = observation (and observation + 64 beyond 64 outputs)
         const int64_t gc = tile * 16 + cc;
         double* rrow = s_R + cc * RSa;
         const bool l0 = lane < MP, l1 = lane + 64 < MP;
@@ -255,25 +270,43 @@ __global__ void __launch_bounds__(256, 1) k_ml_steps(const MLArgs a) {
       if (prior_dense && lane < 16) {}  // (s_redp already written above)
       __syncthreads();
       ll_n = s_R[16 * RSa + lc];
-      if (prior_dense) maha = ((s_redp[lc] + s_redp[16 + lc]) + s_redp[32 + lc]) + s_redp[48 + lc];
+      if (prior_dense) {
+        maha = s_redp[lc];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) maha += s_redp[w * 16 + lc];
+      }
       lp_n = -0.5 * (a.pr.logconst + maha);
       return;
     }
-    double sse = dg ? level_sse_partial<DPAD, 1>(L.Apk, L.ncb, s_stage + a.lds_y[k], s_stage + a.lds_w[k], th, wave, lane, g0, g1)
-                    : level_sse_partial<DPAD, 0>(L.Apk, L.ncb, s_stage + a.lds_y[k], nullptr, th, wave, lane, g0, g1);
+    double sse;
+    if constexpr (PAIRS) {
+      sse = dg ? level_sse_partial<DPAD, 1>(L.Apk, L.ncb, s_stage + a.lds_y[k], s_stage + a.lds_w[k], th, wave, lane, g0, g1)
+               : level_sse_partial<DPAD, 0>(L.Apk, L.ncb, s_stage + a.lds_y[k], nullptr, th, wave, lane, g0, g1);
+    } else {
+      sse = dg ? level_sse_single<DPAD, 1, NW>(L.Apk, L.ncb, s_stage + a.lds_y[k], s_stage + a.lds_w[k], th, wave, lane, g0)
+               : level_sse_single<DPAD, 0, NW>(L.Apk, L.ncb, s_stage + a.lds_y[k], nullptr, th, wave, lane, g0);
+    }
     sse = sum_rows(sse);
     if (lane < 16) s_red[wave * 16 + lane] = sse;
     __syncthreads();
-    const double tot = ((s_red[lc] + s_red[16 + lc]) + s_red[32 + lc]) + s_red[48 + lc];
-    if (prior_dense) maha = ((s_redp[lc] + s_redp[16 + lc]) + s_redp[32 + lc]) + s_redp[48 + lc];
+    double tot = s_red[lc];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) tot += s_red[w * 16 + lc];
+    if (prior_dense) {
+      maha = s_redp[lc];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) maha += s_redp[w * 16 + lc];
+    }
     ll_n = dg ? -0.5 * tot : -0.5 * tot / L.var;
     lp_n = -0.5 * (a.pr.logconst + maha);
   };
 
   for (int s = 0; s < a.S; ++s) {
     // ================= level 0: one Metropolis-Hastings step =================
-    frag_load<DPAD>(fbase, wave, a.lv[0].ncb, f0);
-    frag_load<DPAD>(fbase, wave + 4, a.lv[0].ncb, f1);
+    if constexpr (PAIRS) {
+      frag_load<DPAD>(fbase, wave, a.lv[0].ncb, f0);
+      frag_load<DPAD>(fbase, wave + 4, a.lv[0].ncb, f1);
+    }
     if (a.randomize && cnt[0] == 0) {  // DA: draw the promoted index of the subchain that starts now
       const int L0 = a.sl[0];
       if (a.ridx_rep) {
@@ -362,9 +395,13 @@ __global__ void __launch_bounds__(256, 1) k_ml_steps(const MLArgs a) {
         for (int e = 0; e < EPT; ++e) s_prop[c * LDP + q_ * EPT + e] = use_snap ? snp[e] : cur[k][e];
       }
       const FragSrc gb = frag_src(a.lv[q].Apk, lane);
-      double2 g0[KS / 2], g1[KS / 2];
-      frag_load<DPAD>(gb, wave, a.lv[q].ncb, g0);
-      frag_load<DPAD>(gb, wave + 4, a.lv[q].ncb, g1);
+      double2 g0[KS / 2], g1[PAIRS ? KS / 2 : 1];
+      if constexpr (PAIRS) {
+        frag_load<DPAD>(gb, wave, a.lv[q].ncb, g0);
+        frag_load<DPAD>(gb, wave + 4, a.lv[q].ncb, g1);
+      } else {
+        frag_load_buf<DPAD>(gb, wave < a.lv[q].ncb ? wave : a.lv[q].ncb - 1, g0);
+      }
       __syncthreads();
       double lpq, llq;
       evaluate(q, g0, g1, lpq, llq);

@@ -154,6 +154,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "c5aem":  # python tools/bench_configs.py c5aem 128 [n_fine]
         run_c5_aem(m=int(sys.argv[2]), n_fine=int(sys.argv[3]) if len(sys.argv) > 3 else 20)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "c3":
+        run("C3: DA pCN(0.02) 256/2048 obs, subsampling_rate=10", (256, 2048), [10], dict(kind=1, scaling=0.02), 200)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "c4":
         run_c4(K=int(sys.argv[2]) if len(sys.argv) > 2 else 16)
         sys.exit(0)
