@@ -354,8 +354,8 @@ constexpr size_t aem_inverse_lds_bytes(int nb) { return (size_t)(nb * (nb + 1) /
 
 template <int DPAD>
 void launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st) {
-  // TINYDA_ML_WAVES=8 (experiment): the 8-wave tile for two levels.  Measured on C3: 2.1e8 against 4.2e8 coarse evals/s of
-  // the 4-wave tile -- the level state machine needs ~450 registers, at 256 it spills 198 of them
+  // TINYDA_ML_WAVES=8 (experiment): the 8-wave tile for two levels.  Measured on C3: 3.4e8 against 4.3e8 coarse evals/s of
+  // the 4-wave tile -- at 256 registers the level state machine still spills 61 (loop invariants reloaded every step)
   static const bool ml8 = getenv("TINYDA_ML_WAVES") && atoi(getenv("TINYDA_ML_WAVES")) == 8;
   if (a.nlev == 2 && !a.aem_on && ml8) {
     hipLaunchKernelGGL((k_ml_steps<DPAD, 2, 8>), dim3((unsigned)tiles), dim3(512), lds + 128 * sizeof(double), st, a);  // + two [4][16] slabs

@@ -166,7 +166,6 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
   const FragSrc fbase = frag_src(a.lv[0].Apk, lane);
   constexpr bool PAIRS = NW == 4;
   double2 f0[KS / 2], f1[PAIRS ? KS / 2 : 1];
-  if constexpr (!PAIRS) frag_load_buf<DPAD>(fbase, wave < a.lv[0].ncb ? wave : a.lv[0].ncb - 1, f0);  // later steps: prefetched by the previous one
   __syncthreads();
 
   // evaluate level `k` at the state currently in s_prop (all 4 waves); returns (lp_n, ll_n) lane-mapped
@@ -179,8 +178,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
       double p = 0.0;
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) {
-        const double dv = th[kk] - pm[kk];
-        p += dv * dv * pinv[kk];
+        const double dv = th[kk] - (PAIRS ? pm[kk] : a.pr.mean[4 * kk + hi]);
+        p += dv * dv * (PAIRS ? pinv[kk] : a.pr.pinv[4 * kk + hi]);
       }
       p = sum_rows(p);
       maha = p;
@@ -306,6 +305,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
     if constexpr (PAIRS) {
       frag_load<DPAD>(fbase, wave, a.lv[0].ncb, f0);
       frag_load<DPAD>(fbase, wave + 4, a.lv[0].ncb, f1);
+    } else {
+      frag_load_buf<DPAD>(fbase, wave < a.lv[0].ncb ? wave : a.lv[0].ncb - 1, f0);
     }
     if (a.randomize && cnt[0] == 0) {  // DA: draw the promoted index of the subchain that starts now
       const int L0 = a.sl[0];
