@@ -243,3 +243,27 @@ def test_callback_hierarchy_through_sample_api():
     with pytest.raises(tda.EngineError):  # ... but not together with an error model (nor is it for linear levels): the engine says so
         tda.sample(ada, tda.CrankNicolson(scaling=0.04), 5, n_chains=4, subchain_length=3, randomize_subchain_length=True,
                    adaptive_error_model="state-independent", backend="hip")
+
+
+def test_multilevel_sampling_with_plain_python_models():
+    """The reference's everyday call -- sample([coarse, fine], ...) with plain Python callables as models -- runs on the
+    device engine: the callables are evaluated chain by chain behind the batched-callback interface."""
+    import tinyda_amd as tda
+
+    d = 6
+    rng = np.random.default_rng(7)
+    truth = 0.3 * rng.standard_normal(d)
+    fine = lambda th: _level_model(2)(th)[0]  # noqa: E731  theta -> ndarray, one chain at a time
+    coarse = lambda th: _level_model(1)(th)[0]  # noqa: E731
+    y = fine(truth) + 0.05 * rng.standard_normal(M)
+    prior = st.multivariate_normal(np.zeros(d), np.eye(d))
+    cov = 0.05 ** 2 * np.eye(M)
+    posts = [tda.Posterior(prior, tda.AdaptiveGaussianLogLike(y, cov), coarse), tda.Posterior(prior, tda.GaussianLogLike(y, cov), fine)]
+    th0 = [truth + 0.05 * rng.standard_normal(d) for _ in range(6)]
+    res = tda.sample(posts, tda.GaussianRandomWalk(2e-3 * np.eye(d), adaptive=True, period=20), 40, n_chains=6, initial_parameters=th0,
+                     subchain_length=3, adaptive_error_model="state-independent", seed=8)
+    assert res["sampler"] == "DA" and res.get("backend", "hip") != "host"
+    link = res["chain_fine_4"][-1]
+    assert np.isclose(link.posterior, posts[1].create_link(link.parameters).posterior, rtol=1e-10)
+    assert np.allclose(link.model_output, fine(link.parameters))
+    assert np.mean([np.mean(res["chain_fine_%d" % i].accepted[1:]) for i in range(6)]) > 0.05

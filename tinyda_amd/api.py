@@ -75,6 +75,36 @@ def _device_plan(posteriors, proposal):
     return lows, proposal._lowering()
 
 
+def _wrap_opaque_models(posteriors):
+    """Posteriors whose model is a plain callable -> copies with a BatchedModel looping over the chains; None if a model
+    does not return a plain 1-D array (e.g. the reference's (output, qoi) tuples) or the likelihood has no data vector."""
+    from .models import BatchedModel, DeviceModel, LinearModel, Rosenbrock
+    from .target import Posterior
+
+    out = []
+    for post in posteriors:
+        if isinstance(post.model, (LinearModel, Rosenbrock, DeviceModel, BatchedModel)):
+            out.append(post)
+            continue
+        data = getattr(post.likelihood, "data", None)
+        if not callable(post.model) or data is None:
+            return None
+        m = int(np.atleast_1d(np.asarray(data)).shape[0])
+        fn = post.model
+
+        def batch(thetas, fn=fn, m=m):
+            res = np.empty((thetas.shape[0], m))
+            for i in range(thetas.shape[0]):
+                f = fn(thetas[i])
+                if isinstance(f, tuple):
+                    raise TypeError("models returning (output, qoi) are not lowered to the device engine")
+                res[i] = np.asarray(f, dtype=np.float64).reshape(m)
+            return res
+
+        out.append(Posterior(post.prior, post.likelihood, BatchedModel(batch, m)))
+    return out
+
+
 def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None, subchain_length=1,
            randomize_subchain_length=False, adaptive_error_model=None, store_coarse_chain=True,
            force_sequential=False, force_progress_bar=False, subsampling_rate=None, *, seed=None,
@@ -145,6 +175,16 @@ def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None
             raise TypeError("Initial paramaters must be list, numpy array or None")
 
     plan = None if backend == "host" else _device_plan(posteriors, proposal)
+    if plan is None and backend != "host" and n_levels > 1:
+        # Delayed Acceptance / MLDA over opaque Python models (plain callables theta -> ndarray, the reference's everyday
+        # case): the engine needs the outputs of all chains per level step, so a plain callable is evaluated chain by chain
+        # behind the batched-callback interface -- what the reference's one-chain-at-a-time loop costs per evaluation, with
+        # proposals, level logic, error model, adaptation and records on the device
+        wrapped = _wrap_opaque_models(posteriors)
+        if wrapped is not None:
+            plan = _device_plan(wrapped, proposal)
+            if plan is not None:
+                posteriors = wrapped
     if backend == "hip" and plan is None:
         raise _lib.EngineError("this posterior / proposal combination cannot be lowered to the HIP engine")
     if plan is not None:
