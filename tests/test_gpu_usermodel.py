@@ -359,3 +359,46 @@ def test_hierarchy_with_error_model_checkpoint_resume():
     e.close()
     for la, lb in zip(a, b):
         assert all(np.array_equal(x, y_) for x, y_ in zip(la, lb))
+
+
+def test_hierarchy_with_uniform_prior_components():
+    """JointPrior of uniform and normal components over a Delayed-Acceptance pair of source-defined models, with the error
+    model: proposals outside a uniform support are rejected by the base-level kernels; against the oracle."""
+    from tests.test_gpu_multilevel import _oracle_uniforms
+    from tinyda_amd.engine import Engine
+
+    d, m, N, sl, n_fine = 5, 23, 17, [3], 24
+    rng = np.random.default_rng(51)
+    kinds = np.array([1, 0, 1, 0, 0])
+    loc = np.array([-0.6, 0.0, -0.5, 0.1, 0.0])
+    scale = np.array([1.2, 1.0, 1.0, 0.8, 1.0])  # uniform on [loc, loc + scale]
+    truth = np.array([0.45, 0.3, 0.42, -0.2, 0.1])  # two components close to the upper edge of their support
+    twins = [np_level_model(1), np_level_model(2)]
+    y = twins[1](truth)[0] + 0.05 * rng.standard_normal(m)
+    theta0 = truth + 0.03 * rng.standard_normal((N, d))
+    var, cov, seed = 0.05 ** 2, 0.05 ** 2 * np.eye(m), 515
+    e = Engine(N, d, seed=seed, n_levels=2)
+    e.set_prior_joint(kinds, loc, scale)
+    e.set_level_source(0, SRC_LEVEL % _level_cfg(1), y, 3, cov)
+    e.set_level_source(1, SRC_LEVEL % _level_cfg(2), y, 0, [var])
+    e.set_proposal(0, 6e-3 * np.eye(d), scaling=1.0)
+    e.set_subchains(sl, False)
+    e.set_error_model("state-independent")
+    e.init(theta0)
+    rows = e.rows_per_level(n_fine)
+    z, _ = e.set_export(rows[0])
+    outs = e.run_levels_host(n_fine)
+    e.close()
+    us, _ = _oracle_uniforms(seed, N, rows, sl)
+    prior = orc.JointPriorOracle(kinds, loc, scale)
+    levels = [dict(fn=twins[0], y=y, prior=prior, cov=cov), dict(fn=twins[1], y=y, prior=prior, var=var)]
+    res = orc.run_multilevel_aem(levels, dict(kind="grw", C=6e-3 * np.eye(d), scaling=1.0), sl, theta0, np.swapaxes(z, 0, 1), us, n_fine,
+                                 "state-independent")
+    res = res[0] if isinstance(res, tuple) else res
+    for i in range(2):
+        sk = slice(1, None) if i == 1 else slice(None)
+        assert np.array_equal(outs[i][2], np.asarray(res[i]["accepted"])[:, sk].T), "level %d accept masks differ" % i
+        np.testing.assert_allclose(outs[i][0], np.swapaxes(np.asarray(res[i]["theta"])[:, sk], 0, 1), rtol=1e-9, atol=1e-11)
+    th = outs[1][0]
+    assert (th[:, :, 0] <= loc[0] + scale[0]).all() and (th[:, :, 2] <= loc[2] + scale[2]).all() and (th[:, :, 0] >= loc[0]).all()
+    assert 0.05 < outs[1][2].mean() < 0.98

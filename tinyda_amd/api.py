@@ -42,10 +42,14 @@ def _device_plan(posteriors, proposal):
         return None  # DREAMZ below an MLDA hierarchy is not lowered yet
     if any("rosenbrock" in low for low in lows) and not isinstance(proposal, DREAMZ):
         return None  # the Rosenbrock model is fused into the DREAMZ kernel only
-    if any("prior_joint" in low for low in lows):  # JointPrior: single level, GRW / AM, iso / diag noise, linear or source model
+    if any("prior_joint" in low for low in lows):
+        # JointPrior: GRW / AM; single level (linear, source-defined or callback model, iso / diag noise) or a hierarchy that
+        # contains a callback / source-defined level (host-sequenced: the base-level kernels test the support bounds)
         low = lows[0]
-        if (len(posteriors) != 1 or isinstance(proposal, (DREAMZ, CrankNicolson)) or "rosenbrock" in low
-                or low["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG)):
+        ext = any("source" in lw or "batched" in lw for lw in lows)
+        if isinstance(proposal, (DREAMZ, CrankNicolson)) or any("rosenbrock" in lw for lw in lows) or (len(posteriors) != 1 and not ext):
+            return None
+        if len(posteriors) == 1 and low["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG):
             return None
     if any("source" in low or "batched" in low for low in lows):
         # source-defined and batched host models: single level, or a whole hierarchy of them (Delayed Acceptance / MLDA with
@@ -53,7 +57,7 @@ def _device_plan(posteriors, proposal):
         if isinstance(proposal, DREAMZ) and len(posteriors) != 1:
             return None
         if len(posteriors) > 1:
-            if any("rosenbrock" in low or "prior_joint" in low for low in lows) or type(proposal) not in (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis):
+            if any("rosenbrock" in low for low in lows) or type(proposal) not in (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis):
                 return None  # (linear levels may be mixed in, e.g. a linear surrogate below a non-linear model)
         for i, low in enumerate(lows):
             ok_noise = low["noise_kind"] in (_lib.NOISE_ISO, _lib.NOISE_DIAG) or (low["noise_kind"] == _lib.NOISE_ADAPTIVE and i < len(lows) - 1)
@@ -293,7 +297,10 @@ def _sample_device_multilevel(plan, posteriors, iterations, n_chains, initial_pa
         seed = int(np.random.randint(0, 2 ** 31 - 1))
     eng = Engine(n_chains, d, seed=seed, device=device, chain_offset=chain_offset, n_levels=nl)
     try:
-        eng.set_prior(lows[0]["prior_mean"], lows[0]["prior_cov"])
+        if "prior_joint" in lows[0]:
+            eng.set_prior_joint(*lows[0]["prior_joint"])
+        else:
+            eng.set_prior(lows[0]["prior_mean"], lows[0]["prior_cov"])
         for k, low in enumerate(lows):
             if "batched" in low:
                 eng.set_level_callback(k, low["batched"], low["data"], low["noise_kind"], low["noise"], inplace=True)

@@ -743,7 +743,6 @@ int tda_engine_set_prior(tda_engine* e, const double* mean, const double* cov) {
 
 int tda_engine_set_prior_joint(tda_engine* e, const int32_t* kind, const double* loc, const double* scale) {
   if (!e || !kind || !loc || !scale) return fail(TDA_ERR_INVALID, "null argument");
-  if (e->nlev != 1) return fail(TDA_ERR_UNSUPPORTED, "joint priors are lowered for single-level chains only");
   HIP_TRY(hipSetDevice(e->cfg.device));
   const int d = e->d, DP = e->DP;
   std::vector<double> mh(DP, 0.0), ph(DP, 0.0), lo(DP, -INFINITY), hi(DP, INFINITY);
@@ -1502,7 +1501,10 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
     }
   }
   if (e->prior_bounded) {  // JointPrior with uniform components
-    if (e->nlev != 1 || e->is_dreamz) return fail(TDA_ERR_UNSUPPORTED, "priors with uniform components: single-level GRW / AM only");
+    // single-level GRW / AM (fused), or a host-sequenced hierarchy (callback / source-defined levels): there the base-level
+    // kernels test the support bounds and the upper levels carry the log-prior of the states they promote
+    if ((e->nlev != 1 && !e->ext_hier) || e->is_dreamz)
+      return fail(TDA_ERR_UNSUPPORTED, "priors with uniform components: single-level GRW / AM, or hierarchies of callback / source-defined models");
     if (e->pp.kind == TDA_PROP_PCN) return fail(TDA_ERR_UNSUPPORTED, "pCN needs a Gaussian prior");
     if (e->levels[0].noise_kind == TDA_NOISE_DENSE) return fail(TDA_ERR_UNSUPPORTED, "priors with uniform components: iso / diag noise only");
     if (!theta0) return fail(TDA_ERR_INVALID, "priors with uniform components need explicit initial parameters");
@@ -2417,6 +2419,8 @@ static int run_ext_hierarchy_block(tda_engine* e, const MLArgs& ma, int64_t S, b
       ea.Fcur = e->ext_Fcur[0].p;
       ea.pr_mean = e->prior_mean.p;
       ea.pr_pinv = e->prior_pinv.p;
+      ea.pr_lo = e->prior_bounded ? e->prior_lo.p : nullptr;
+      ea.pr_hi = e->prior_bounded ? e->prior_hi.p : nullptr;
       ea.logconst = e->prior_logconst;
       ea.anyacc = e->ml_anyacc.p;
       ea.sid = e->ml_sid.p;

@@ -1092,6 +1092,8 @@ struct ExtAemAcceptArgs {
   double* Fcur;        // [NP][MP]
   const double* pr_mean;
   const double* pr_pinv;
+  const double* pr_lo;  // support bounds of uniform prior components, or null
+  const double* pr_hi;
   double logconst;
   int32_t* anyacc;
   int64_t* sid;
@@ -1141,6 +1143,7 @@ __global__ void __launch_bounds__(MPT) k_ext_aem_accept(const ExtAemAcceptArgs a
   if (lj) {
     const double dv = prp - a.pr_mean[lane];
     pj = dv * dv * a.pr_pinv[lane];
+    if (a.pr_lo && (prp < a.pr_lo[lane] || prp > a.pr_hi[lane])) pj = __builtin_inf();  // uniform prior components
   }
   const double maha = bsum(pj);
   const double lp_n = -0.5 * (a.logconst + maha);
