@@ -272,7 +272,7 @@ int tda_engine_set_prior_joint(tda_engine* e, const int32_t* kind, const double*
  * posterior.py:95-96).  The source must define
  *     __device__ double tda_forward(const double* theta, int dim, int o);     // output o of F(theta), o in [0, m)
  * and is compiled at run time (hiprtc, gfx950) into a fused step kernel: one wave per chain, the lanes stride over the
- * outputs.  data: HOST [m]; noise: ISO (noise[0] = variance) or DIAG (HOST [m]); below the finest level of a hierarchy also
+ * outputs.  data: HOST [m]; noise: ISO (noise[0] = variance), DIAG (HOST [m]) or DENSE (HOST [m][m], m <= 2048); below the finest level of a hierarchy also
  * TDA_NOISE_ADAPTIVE (HOST [m][m] covariance, m <= 128) for the adaptive error model.  Diagonal prior.  Single-level chains
  * (GRW / pCN / AM fused; DREAM(Z) step by step), and any level of a Delayed Acceptance / MLDA hierarchy: there the engine
  * sequences the levels from the host and a level step is propose -> tda_user_eval (compiled with the model) -> accept on
@@ -287,7 +287,7 @@ int tda_engine_set_level_source(tda_engine* e, int level, const char* source, in
  * buffers owned by the engine and valid during the call only.  Proposals, log-densities, the accept test, adaptation and the
  * records stay on the device.  The callback returns 0, or non-zero to abort the run (tda_engine_init / tda_engine_run then
  * return TDA_ERR_CALLBACK).  It is called on the thread that calls init / run; it must not call into the same engine.
- * data: HOST [m]; noise: ISO (noise[0] = variance), DIAG (HOST [m]) or, below the finest level of a hierarchy,
+ * data: HOST [m]; noise: ISO (noise[0] = variance), DIAG (HOST [m]), DENSE (HOST [m][m], m <= 2048) or, below the finest level of a hierarchy,
  * TDA_NOISE_ADAPTIVE (HOST [m][m], m <= 128).  Diagonal prior (also tda_engine_set_prior_joint).  Single-level chains with
  * GRW / pCN / AM / DREAM(Z), and any level of a Delayed Acceptance / MLDA hierarchy (one call per level step for all chains;
  * error model of both kinds, adaptive scaling, randomised DA subchains as for linear levels). */

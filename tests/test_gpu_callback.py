@@ -267,3 +267,66 @@ def test_multilevel_sampling_with_plain_python_models():
     assert np.isclose(link.posterior, posts[1].create_link(link.parameters).posterior, rtol=1e-10)
     assert np.allclose(link.model_output, fine(link.parameters))
     assert np.mean([np.mean(res["chain_fine_%d" % i].accepted[1:]) for i in range(6)]) > 0.05
+
+
+@pytest.mark.parametrize("model_kind", ["callback", "source"])
+def test_dense_noise_over_external_models(model_kind):
+    """DefaultGaussianLogLike (correlated data noise) over a callback and over a source-defined model: single-level AM against
+    the oracle, and as the fine level of a Delayed-Acceptance pair."""
+    from tests.test_gpu_multilevel import _oracle_uniforms
+    from tests.test_gpu_usermodel import SRC, np_model as src_model
+    from tinyda_amd.engine import Engine
+
+    if model_kind == "callback":
+        d, m, model = 6, M, np_model
+    else:
+        d, m, model = 5, 23, src_model
+    N, T = 19, 120
+    rng = np.random.default_rng(33)
+    truth = 0.5 * rng.standard_normal(d)
+    y = model(truth)[0] + 0.05 * rng.standard_normal(m)
+    Ln = 0.05 * np.eye(m) + 0.01 * np.tril(rng.standard_normal((m, m)))
+    cov = Ln @ Ln.T
+    theta0 = truth + 0.05 * rng.standard_normal((N, d))
+    pm, pv = np.zeros(d), np.ones(d)
+    e = Engine(N, d, seed=17, block_steps=32)
+    e.set_prior(pm, np.diag(pv))
+    if model_kind == "callback":
+        e.set_level_callback(0, model, y, 2, cov)
+    else:
+        e.set_level_source(0, SRC, y, 2, cov)
+    e.set_proposal(2, 2e-3 * np.eye(d), t0=40, period=20)
+    e.init(theta0)
+    z, u = e.set_export(T)
+    params, stats, acc = e.run_host(T)
+    e.close()
+    prior = orc.MVNPrior(pm, np.diag(pv))
+    lvl = orc.CallableGaussianLevel(model, y, "dense", cov, prior)
+    ref = orc.run_mh(lvl, dict(kind="am", C0=2e-3 * np.eye(d), t0=40, period=20), theta0, np.swapaxes(z, 0, 1), np.swapaxes(u, 0, 1))
+    assert np.array_equal(acc, np.swapaxes(ref["accepted"][:, 1:], 0, 1))
+    np.testing.assert_allclose(stats[:, :, 2], np.swapaxes(ref["logpost"][:, 1:], 0, 1), rtol=1e-10)
+    assert 0.05 < acc.mean() < 0.95
+    # Delayed Acceptance: isotropic coarse level, dense fine level
+    seed, sl, n_fine = 29, [3], 20
+    e = Engine(N, d, seed=seed, n_levels=2)
+    e.set_prior(pm, np.diag(pv))
+    for k in range(2):
+        kind, nz = (0, [0.08 ** 2]) if k == 0 else (2, cov)
+        if model_kind == "callback":
+            e.set_level_callback(k, model, y, kind, nz)
+        else:
+            e.set_level_source(k, SRC, y, kind, nz)
+    e.set_proposal(1, None, scaling=0.04)
+    e.set_subchains(sl, False)
+    e.init(theta0)
+    rows = e.rows_per_level(n_fine)
+    z, _ = e.set_export(rows[0])
+    outs = e.run_levels_host(n_fine)
+    e.close()
+    us, _ = _oracle_uniforms(seed, N, rows, sl)
+    levels = [orc.CallableGaussianLevel(model, y, "iso", 0.08 ** 2, prior), orc.CallableGaussianLevel(model, y, "dense", cov, prior)]
+    res, _ = orc.run_multilevel(levels, dict(kind="pcn", scaling=0.04), sl, theta0, np.swapaxes(z, 0, 1), us, n_fine, None)
+    for i in range(2):
+        sk = slice(1, None) if i == 1 else slice(None)
+        assert np.array_equal(outs[i][2], res[i]["accepted"][:, sk].T), "level %d accept masks differ" % i
+        np.testing.assert_allclose(outs[i][1][:, :, 2], res[i]["logpost"][:, sk].T, rtol=1e-10)

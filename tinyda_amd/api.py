@@ -34,9 +34,12 @@ def _device_plan(posteriors, proposal):
             return None
         if low["noise_kind"] == _lib.NOISE_ADAPTIVE and (len(posteriors) < 2 or np.asarray(low["data"]).shape[0] > 128):
             return None  # AdaptiveGaussianLogLike: coarse levels of a hierarchy, m <= 128 on the device
-        if low["noise_kind"] == _lib.NOISE_DENSE and (len(posteriors) != 1 or isinstance(proposal, DREAMZ)
-                                                      or low["A"] is None or low["A"].shape[0] > 1024):
-            return None  # dense data covariance: single-level GRW / pCN / AM with m <= 1024 on the device so far
+        if low["noise_kind"] == _lib.NOISE_DENSE:
+            if low["A"] is None:  # callback / source-defined model: any sampler they run under, m <= 2048
+                if np.asarray(low["data"]).shape[0] > 2048:
+                    return None
+            elif len(posteriors) != 1 or isinstance(proposal, DREAMZ) or low["A"].shape[0] > 1024:
+                return None  # linear model: single-level GRW / pCN / AM with m <= 1024 (MFMA quadratic form)
         lows.append(low)
     if isinstance(proposal, DREAMZ) and len(posteriors) != 1:
         return None  # DREAMZ below an MLDA hierarchy is not lowered yet
@@ -60,7 +63,8 @@ def _device_plan(posteriors, proposal):
             if any("rosenbrock" in low for low in lows) or type(proposal) not in (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis):
                 return None  # (linear levels may be mixed in, e.g. a linear surrogate below a non-linear model)
         for i, low in enumerate(lows):
-            ok_noise = low["noise_kind"] in (_lib.NOISE_ISO, _lib.NOISE_DIAG) or (low["noise_kind"] == _lib.NOISE_ADAPTIVE and i < len(lows) - 1)
+            ok_noise = (low["noise_kind"] in (_lib.NOISE_ISO, _lib.NOISE_DIAG) or (low["noise_kind"] == _lib.NOISE_DENSE and low["A"] is None)
+                        or (low["noise_kind"] == _lib.NOISE_ADAPTIVE and i < len(lows) - 1))
             if not ok_noise or np.count_nonzero(low["prior_cov"] - np.diag(np.diag(low["prior_cov"]))):
                 return None
     if isinstance(proposal, MALA):  # exact gradient of a linear-Gaussian posterior: single level, linear model, Gaussian prior

@@ -163,6 +163,7 @@ struct Level {
   std::vector<double> A_h, ytil_h, data_h, cov_h;
   std::vector<double> w_h, Pinv_h;  // diagonal weights 1 / sigma_i^2, dense Sigma_e^-1 [m][m] (MALA's gradient operator)
   DevBuf<double> A_rm, ytil64, data64, cov64;  // error-model copies, row stride em_ld
+  DevBuf<double> Pd;                           // callback / source-defined level with dense noise: Sigma^-1 [m][m]
   DevBuf<double> A_dev, b_dev;                 // hierarchies: row-major [m][d] and offset [m] for k_ext_linear_eval (host-sequenced mode)
   int em_ld = 0;                               // 64 (m <= 64) or 128 (m <= 128); 0: level too large for an error model
 };
@@ -480,6 +481,7 @@ void fill_ext_args(tda_engine* e, const Level& lv, ExtArgs& xa) {
   xa.F = lv.cb_F.p;
   xa.data = lv.udata.p;
   xa.w = lv.noise_kind == TDA_NOISE_DIAG ? lv.uw.p : nullptr;
+  xa.Pd = lv.noise_kind == TDA_NOISE_DENSE ? lv.Pd.p : nullptr;
   xa.var = lv.var;
   xa.pr_mean = e->prior_mean.p;
   xa.pr_pinv = e->prior_pinv.p;
@@ -511,6 +513,22 @@ int ext_level_adaptive(tda_engine* e, Level& lv, int m, const double* data, cons
   return TDA_OK;
 }
 
+// DefaultGaussianLogLike (dense data covariance) on a callback / source-defined level: Sigma^-1 through the Cholesky factor
+int ext_level_dense(tda_engine* e, Level& lv, int m, const double* cov) {
+  if (m > 2048) return fail(TDA_ERR_UNSUPPORTED, "dense noise on callback / source-defined levels: m <= 2048");
+  std::vector<double> Lc, W, P((size_t)m * m, 0.0);
+  if (!cholesky_host(cov, m, Lc)) return fail(TDA_ERR_NUMERIC, "noise covariance is not positive definite");
+  tri_inverse_host(Lc, m, W);
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double sacc = 0.0;
+      for (int k = i; k < m; ++k) sacc += W[(size_t)k * m + i] * W[(size_t)k * m + j];
+      P[(size_t)i * m + j] = P[(size_t)j * m + i] = sacc;
+    }
+  lv.var = 1.0;
+  return lv.Pd.upload(P);
+}
+
 // F[N][m] <- model(prop[N][d]) of a level whose model lives outside the engine's kernels: a batched host callback (through
 // page-locked staging buffers, one synchronisation) or a source-defined model (tda_user_eval, stays on the stream)
 int ext_model_outputs(tda_engine* e, const Level& lv) {
@@ -535,13 +553,13 @@ int ext_step(tda_engine* e, const Level& lv, const ExtArgs& xa) {
   hipLaunchKernelGGL(k_ext_propose, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, xa);
   int mrc = ext_model_outputs(e, lv);
   if (mrc) return mrc;
-  hipLaunchKernelGGL(k_ext_accept, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, xa);
+  hipLaunchKernelGGL(k_ext_accept, dim3(grid), dim3(64 * EXT_WAVES), xa.Pd ? (size_t)EXT_WAVES * lv.m * sizeof(double) : 0, e->stream, xa);
   HIP_TRY(hipGetLastError());
   return TDA_OK;
 }
 
 int launch_eval(tda_engine* e, int level, double* theta, double* lp, double* ll) {
-  if (e->levels[level].model == MODEL_CALLBACK) {
+  if (e->levels[level].model == MODEL_CALLBACK || (e->levels[level].model == MODEL_USER && e->levels[level].noise_kind == TDA_NOISE_DENSE)) {
     ExtArgs xa{};
     fill_ext_args(e, e->levels[level], xa);
     xa.mode = 1;
@@ -962,8 +980,8 @@ int tda_engine_set_level_source(tda_engine* e, int level, const char* source, in
   if (!e || !source || !data || !noise) return fail(TDA_ERR_INVALID, "null argument");
   if (level < 0 || level >= (int)e->levels.size()) return fail(TDA_ERR_INVALID, "level %d out of range", level);
   if (m < 1) return fail(TDA_ERR_INVALID, "m must be >= 1");
-  if (noise_kind != TDA_NOISE_ISO && noise_kind != TDA_NOISE_DIAG && !(noise_kind == TDA_NOISE_ADAPTIVE && e->nlev > 1))
-    return fail(TDA_ERR_UNSUPPORTED, "source-defined forward models take isotropic or diagonal noise (AdaptiveGaussianLogLike below the finest level of a hierarchy)");
+  if (noise_kind != TDA_NOISE_ISO && noise_kind != TDA_NOISE_DIAG && noise_kind != TDA_NOISE_DENSE && !(noise_kind == TDA_NOISE_ADAPTIVE && e->nlev > 1))
+    return fail(TDA_ERR_UNSUPPORTED, "noise kind %d (AdaptiveGaussianLogLike only below the finest level of a hierarchy)", noise_kind);
   HIP_TRY(hipSetDevice(e->cfg.device));
   Level& lv = e->levels[level];
   if (lv.umod) {
@@ -978,6 +996,8 @@ int tda_engine_set_level_source(tda_engine* e, int level, const char* source, in
   std::vector<double> y(data, data + m), w;
   if (noise_kind == TDA_NOISE_ADAPTIVE) {
     if ((rc = ext_level_adaptive(e, lv, m, data, noise))) return rc;
+  } else if (noise_kind == TDA_NOISE_DENSE) {
+    if ((rc = ext_level_dense(e, lv, m, noise))) return rc;
   } else if (noise_kind == TDA_NOISE_ISO) {
     if (!(noise[0] > 0.0)) return fail(TDA_ERR_NUMERIC, "noise variance must be positive");
     lv.var = noise[0];
@@ -1016,14 +1036,16 @@ int tda_engine_set_level_callback(tda_engine* e, int level, tda_forward_batch_fn
   if (!e || !fn || !data || !noise) return fail(TDA_ERR_INVALID, "null argument");
   if (level < 0 || level >= (int)e->levels.size()) return fail(TDA_ERR_INVALID, "level %d out of range", level);
   if (m < 1) return fail(TDA_ERR_INVALID, "m must be >= 1");
-  if (noise_kind != TDA_NOISE_ISO && noise_kind != TDA_NOISE_DIAG && !(noise_kind == TDA_NOISE_ADAPTIVE && e->nlev > 1))
-    return fail(TDA_ERR_UNSUPPORTED, "callback forward models take isotropic or diagonal noise (AdaptiveGaussianLogLike below the finest level of a hierarchy)");
+  if (noise_kind != TDA_NOISE_ISO && noise_kind != TDA_NOISE_DIAG && noise_kind != TDA_NOISE_DENSE && !(noise_kind == TDA_NOISE_ADAPTIVE && e->nlev > 1))
+    return fail(TDA_ERR_UNSUPPORTED, "noise kind %d (AdaptiveGaussianLogLike only below the finest level of a hierarchy)", noise_kind);
   HIP_TRY(hipSetDevice(e->cfg.device));
   Level& lv = e->levels[level];
   std::vector<double> y(data, data + m), w;
   int rc;
   if (noise_kind == TDA_NOISE_ADAPTIVE) {
     if ((rc = ext_level_adaptive(e, lv, m, data, noise))) return rc;
+  } else if (noise_kind == TDA_NOISE_DENSE) {
+    if ((rc = ext_level_dense(e, lv, m, noise))) return rc;
   } else if (noise_kind == TDA_NOISE_ISO) {
     if (!(noise[0] > 0.0)) return fail(TDA_ERR_NUMERIC, "noise variance must be positive");
     lv.var = noise[0];
@@ -2199,7 +2221,7 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     sa.rec_params = p_dev ? o_params + (size_t)done * N * d : ((o_params || is_am) ? blk_params : nullptr);
     sa.rec_stats = s_dev ? o_stats + (size_t)done * N * 3 : (o_stats ? blk_stats : nullptr);
     sa.rec_acc = a_dev ? o_acc + (size_t)done * N : (o_acc ? blk_acc : nullptr);
-    if (lv.model == MODEL_CALLBACK) {
+    if (lv.model == MODEL_CALLBACK || (lv.model == MODEL_USER && lv.noise_kind == TDA_NOISE_DENSE)) {
       if (e->pp.kind == TDA_PROP_INDEPENDENCE) return fail(TDA_ERR_UNSUPPORTED, "the independence sampler is not lowered for callback models");
       ExtArgs xa{};
       fill_ext_args(e, lv, xa);
@@ -2356,7 +2378,7 @@ static int run_ext_hierarchy_block(tda_engine* e, const MLArgs& ma, int64_t S, b
                          (unsigned long long)e->cfg.seed, (long long)e->cfg.chain_offset, (long long)(e->done[1] + row[1]),
                          ma.ridx_rep ? ma.ridx_rep + (size_t)row[1] * N : nullptr, e->ml_pick.p);
     }
-    if (e->levels[0].model == MODEL_USER && !e->aem && !e->randomize) {
+    if (e->levels[0].model == MODEL_USER && !e->aem && !e->randomize && e->levels[0].noise_kind != TDA_NOISE_DENSE) {
       // source-defined base level: the rest of the running subchain (inside this block) is ONE launch of the fused
       // step kernel compiled with the model
       const int64_t n = std::min<int64_t>(S - s, (int64_t)e->sl[0] - cc[0]);
@@ -2469,7 +2491,7 @@ static int run_ext_hierarchy_block(tda_engine* e, const MLArgs& ma, int64_t S, b
     for (int k = 0; k < nl - 1 && cc[k] == e->sl[k]; ++k) {
       const int q = k + 1;
       const Level& lq = e->levels[q];
-      if (lq.model == MODEL_USER && !e->aem) {
+      if (lq.model == MODEL_USER && !e->aem && lq.noise_kind != TDA_NOISE_DENSE) {
         // source-defined level without error model: evaluation, decision, alignment and records in one launch of the
         // kernel compiled with the model (+ the step's uniforms)
         double* ul = e->lublk.p;  // scratch of the single-level path, at least SMAX * NP doubles
@@ -2608,6 +2630,7 @@ static int run_ext_hierarchy_block(tda_engine* e, const MLArgs& ma, int64_t S, b
       la.F = lq.cb_F.p;
       la.data = lq.udata.p;
       la.w = lq.noise_kind == TDA_NOISE_DIAG ? lq.uw.p : nullptr;
+      la.Pd = lq.noise_kind == TDA_NOISE_DENSE ? lq.Pd.p : nullptr;
       la.var = lq.var;
       la.theta = e->ml_theta.p;
       la.lp = e->ml_lp.p;
@@ -2622,7 +2645,7 @@ static int run_ext_hierarchy_block(tda_engine* e, const MLArgs& ma, int64_t S, b
       la.ring_P = e->ring_P;
       la.ring_pos = rp++;
       la.ysnap = (e->randomize && k == 0) ? e->ml_ysnap.p : nullptr;
-      hipLaunchKernelGGL(k_ext_level_action, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, la);
+      hipLaunchKernelGGL(k_ext_level_action, dim3(grid), dim3(64 * EXT_WAVES), la.Pd ? (size_t)EXT_WAVES * lq.m * sizeof(double) : 0, e->stream, la);
       HIP_TRY(hipGetLastError());
       cc[k] = 0;
       cc[q] += 1;
@@ -3242,7 +3265,7 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
         xa.rec_params = sa.rec_params;
         xa.rec_stats = sa.rec_stats;
         xa.rec_acc = sa.rec_acc;
-        hipLaunchKernelGGL(k_ext_accept, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, xa);
+        hipLaunchKernelGGL(k_ext_accept, dim3(grid), dim3(64 * EXT_WAVES), xa.Pd ? (size_t)EXT_WAVES * lv.m * sizeof(double) : 0, e->stream, xa);
         hipLaunchKernelGGL(k_dz_ext_append, dim3(gridp), dim3(64 * EXT_WAVES), 0, e->stream, za);
       }
     } else {

@@ -30,6 +30,7 @@ struct ExtArgs {
   const double* F;    // [N][m]  model outputs from the host
   const double* data;
   const double* w;  // 1 / diag(noise) or null (isotropic)
+  const double* Pd; // dense noise: Sigma^-1 [m][m] (DefaultGaussianLogLike, distributions.py:295-298) or null; needs m doubles of dynamic LDS per wave
   double var;
   const double* pr_mean;
   const double* pr_pinv;
@@ -72,21 +73,39 @@ __device__ __forceinline__ double ext_wave_sum(double v) {
   return v;
 }
 
+// sum of squared residuals of one chain's model outputs, weighted as the likelihood says: isotropic / diagonal, or the dense
+// quadratic form r^T Sigma^-1 r (residual staged in this wave's LDS slice, lane = column of Sigma^-1, rows streamed)
+__device__ __forceinline__ double ext_weighted_sse(const double* __restrict__ Fc, const double* __restrict__ data,
+                                                   const double* __restrict__ w, const double* __restrict__ Pd, int m, int lane,
+                                                   double* __restrict__ sr) {
+  double sse = 0.0;
+  if (Pd) {
+    for (int o = lane; o < m; o += 64) sr[o] = Fc[o] - data[o];
+    __builtin_amdgcn_wave_barrier();
+    for (int j = lane; j < m; j += 64) {
+      double t = 0.0;
+      for (int o = 0; o < m; ++o) t = fma(Pd[(size_t)o * m + j], sr[o], t);
+      sse += sr[j] * t;
+    }
+  } else {
+    for (int o = lane; o < m; o += 64) {
+      const double r = Fc[o] - data[o];
+      double sq = r * r;
+      if (w) sq *= w[o];
+      sse += sq;
+    }
+  }
+  return ext_wave_sum(sse);
+}
+
 __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_accept(const ExtArgs a) {
   const int lane = threadIdx.x & 63;
   const long long c = (long long)blockIdx.x * EXT_WAVES + (threadIdx.x >> 6);
   if (c >= a.N) return;  // whole waves leave together
   const bool lj = lane < a.d, eval = a.mode == 1;
   const double prp = lj ? a.prop[c * a.d + lane] : 0.0;
-  double sse = 0.0;  // distributions.py:295-326
-  const double* Fc = a.F + (size_t)c * a.m;
-  for (int o = lane; o < a.m; o += 64) {
-    const double r = Fc[o] - a.data[o];
-    double sq = r * r;
-    if (a.w) sq *= a.w[o];
-    sse += sq;
-  }
-  sse = ext_wave_sum(sse);
+  extern __shared__ double ext_dyn_lds[];  // dense noise only: [EXT_WAVES][m]
+  const double sse = ext_weighted_sse(a.F + (size_t)c * a.m, a.data, a.w, a.Pd, a.m, lane, ext_dyn_lds + (size_t)(threadIdx.x >> 6) * a.m);  // distributions.py:295-326
   double pj = 0.0;
   if (lj) {
     const double dv = prp - a.pr_mean[lane];
@@ -94,7 +113,7 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_accept(const ExtArgs a) 
     if (a.pr_lo && (prp < a.pr_lo[lane] || prp > a.pr_hi[lane])) pj = __builtin_inf();  // uniform prior components
   }
   const double maha = ext_wave_sum(pj);
-  const double ll_n = a.w ? -0.5 * sse : -0.5 * sse / a.var;
+  const double ll_n = (a.w || a.Pd) ? -0.5 * sse : -0.5 * sse / a.var;
   const double lp_n = -0.5 * (a.logconst + maha);  // scipy MVN logpdf, posterior.py:92
   const double post_n = lp_n + ll_n;               // link.py:48
   double lp = a.lp[c], ll = a.ll[c];
@@ -248,6 +267,7 @@ struct ExtLevelArgs {
   const double* F;      // [N][m] level-q model at theta_{q-1}
   const double* data;   // [m]
   const double* w;      // 1 / diag(noise) or null
+  const double* Pd;     // dense Sigma^-1 [m][m] or null (m doubles of dynamic LDS per wave)
   double var;
   double* theta;        // [nlev][NP][DP]
   double* lp;           // [nlev][NP]
@@ -272,16 +292,9 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_level_action(const ExtLe
   const bool lj = lane < a.d;
   auto TH = [&](int lev) { return a.theta + ((size_t)lev * a.NP + c) * a.DP; };
   auto PI = [](int j, int qq) { return qq * (qq - 1) / 2 + j; };
-  double sse = 0.0;
-  const double* Fc = a.F + (size_t)c * a.m;
-  for (int o = lane; o < a.m; o += 64) {
-    const double r = Fc[o] - a.data[o];
-    double sq = r * r;
-    if (a.w) sq *= a.w[o];
-    sse += sq;
-  }
-  sse = ext_wave_sum(sse);
-  const double lln = a.w ? -0.5 * sse : -0.5 * sse / a.var;
+  extern __shared__ double ext_dyn_lds[];  // dense noise only: [EXT_WAVES][m]
+  const double sse = ext_weighted_sse(a.F + (size_t)c * a.m, a.data, a.w, a.Pd, a.m, lane, ext_dyn_lds + (size_t)(threadIdx.x >> 6) * a.m);
+  const double lln = (a.w || a.Pd) ? -0.5 * sse : -0.5 * sse / a.var;
   const double* ys = a.ysnap ? a.ysnap + (size_t)c * (a.DP + 2) : nullptr;
   const double yj = lj ? (ys ? ys[lane] : TH(k)[lane]) : 0.0, xj = lj ? TH(q)[lane] : 0.0;
   const double y_lp = ys ? ys[a.DP] : a.lp[(size_t)k * a.NP + c], y_ll = ys ? ys[a.DP + 1] : a.ll[(size_t)k * a.NP + c];
