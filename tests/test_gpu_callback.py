@@ -330,3 +330,46 @@ def test_dense_noise_over_external_models(model_kind):
         sk = slice(1, None) if i == 1 else slice(None)
         assert np.array_equal(outs[i][2], res[i]["accepted"][:, sk].T), "level %d accept masks differ" % i
         np.testing.assert_allclose(outs[i][1][:, :, 2], res[i]["logpost"][:, sk].T, rtol=1e-10)
+
+
+@pytest.mark.parametrize("kind,model_kind", [("indep", "callback"), ("indep", "source"), ("owcn", "callback"), ("owcn", "source")])
+def test_independence_and_operator_weighted_pcn_over_external_models(kind, model_kind):
+    """IndependenceSampler and OperatorWeightedCrankNicolson proposals over a callback / source-defined model against the oracle."""
+    from tests.test_gpu_usermodel import SRC, np_model as src_model
+    from tinyda_amd.engine import Engine
+
+    if model_kind == "callback":
+        d, m, model = 6, M, np_model
+    else:
+        d, m, model = 5, 23, src_model
+    N, T = 21, 130
+    rng = np.random.default_rng(44)
+    truth = 0.5 * rng.standard_normal(d)
+    y = model(truth)[0] + 0.05 * rng.standard_normal(m)
+    theta0 = truth + 0.03 * rng.standard_normal((N, d))
+    pm, pv = np.zeros(d), np.ones(d)
+    e = Engine(N, d, seed=23, block_steps=40)
+    e.set_prior(pm, np.diag(pv))
+    if model_kind == "callback":
+        e.set_level_callback(0, model, y, 0, [0.05 ** 2])
+    else:
+        e.set_level_source(0, SRC, y, 0, [0.05 ** 2])
+    if kind == "indep":
+        q_mean, q_cov = truth + 0.01 * rng.standard_normal(d), 4e-4 * np.eye(d)
+        e.set_proposal(4, q_cov, q_mean=q_mean)
+        prop = dict(kind="indep", q_mean=q_mean, q_cov=q_cov)
+    else:
+        Q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+        B = Q @ np.diag(np.linspace(0.05, 0.6, d)) @ Q.T
+        S, Nop = orc.owcn_operators(B, 0.004)
+        e.set_proposal(5, None, state_operator=S, noise_operator=Nop)
+        prop = dict(kind="owcn", B=B, scaling=0.004)
+    e.init(theta0)
+    z, u = e.set_export(T)
+    params, stats, acc = e.run_host(T)
+    e.close()
+    lvl = orc.CallableGaussianLevel(model, y, "iso", 0.05 ** 2, orc.MVNPrior(pm, np.diag(pv)))
+    ref = orc.run_mh(lvl, prop, theta0, np.swapaxes(z, 0, 1), np.swapaxes(u, 0, 1))
+    assert np.array_equal(acc, np.swapaxes(ref["accepted"][:, 1:], 0, 1))
+    np.testing.assert_allclose(stats[:, :, 2], np.swapaxes(ref["logpost"][:, 1:], 0, 1), rtol=1e-10)
+    assert 0.02 < acc.mean() < 0.98

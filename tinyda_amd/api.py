@@ -70,12 +70,11 @@ def _device_plan(posteriors, proposal):
     if isinstance(proposal, MALA):  # exact gradient of a linear-Gaussian posterior: single level, linear model, Gaussian prior
         if len(posteriors) != 1 or "source" in lows[0] or "batched" in lows[0] or "rosenbrock" in lows[0] or "prior_joint" in lows[0]:
             return None
-    if isinstance(proposal, OperatorWeightedCrankNicolson):  # fixed operators, single level, linear model
-        if (len(posteriors) != 1 or proposal._lowering() is None or "source" in lows[0] or "batched" in lows[0] or "rosenbrock" in lows[0]
-                or "prior_joint" in lows[0]):
+    if isinstance(proposal, OperatorWeightedCrankNicolson):  # fixed operators, single level; linear, callback or source-defined model
+        if len(posteriors) != 1 or proposal._lowering() is None or "rosenbrock" in lows[0] or "prior_joint" in lows[0]:
             return None
-    if isinstance(proposal, IndependenceSampler):  # Gaussian q, single level, linear model
-        if len(posteriors) != 1 or proposal._lowering() is None or "source" in lows[0] or "batched" in lows[0] or "rosenbrock" in lows[0]:
+    if isinstance(proposal, IndependenceSampler):  # Gaussian q, single level; linear, callback or source-defined model
+        if len(posteriors) != 1 or proposal._lowering() is None or "rosenbrock" in lows[0]:
             return None
     for low in lows[1:]:  # one prior for the hierarchy (every tinyDA example shares it across levels)
         if not (np.array_equal(low["prior_mean"], lows[0]["prior_mean"]) and np.array_equal(low["prior_cov"], lows[0]["prior_cov"])):

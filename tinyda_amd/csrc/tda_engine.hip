@@ -1501,7 +1501,8 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
     if (!lv.set) return fail(TDA_ERR_STATE, "set_level missing");
   if (e->prop_set && !e->is_dreamz && e->pp.kind == TDA_PROP_OWCN) {
     if (e->ow_state_h.empty()) return fail(TDA_ERR_STATE, "operator-weighted pCN: set_proposal_operators missing");
-    if (e->levels[0].model != MODEL_LINEAR) return fail(TDA_ERR_UNSUPPORTED, "operator-weighted pCN is lowered for linear forward models only");
+    if (e->levels[0].model != MODEL_LINEAR && e->levels[0].model != MODEL_CALLBACK && e->levels[0].model != MODEL_USER)
+      return fail(TDA_ERR_UNSUPPORTED, "operator-weighted pCN is lowered for linear, callback and source-defined forward models");
     if (e->prior_bounded) return fail(TDA_ERR_UNSUPPORTED, "operator-weighted pCN needs a Gaussian prior");
   }
   if (e->prop_set && !e->is_dreamz && e->pp.kind == TDA_PROP_MALA) {
@@ -2208,7 +2209,6 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     sa.cvec = e->pp.kind == TDA_PROP_MALA ? e->mala_c.p : nullptr;
     sa.grad = e->pp.kind == TDA_PROP_MALA ? e->mala_grad.p : nullptr;
     if (e->pp.kind == TDA_PROP_INDEPENDENCE) {
-      if (lv.model == MODEL_USER) return fail(TDA_ERR_UNSUPPORTED, "the independence sampler is not lowered for source-defined models");
       sa.q_mean = e->q_mean_d.p;
       sa.qz = qz_blk;
       sa.lq = e->lq.p;
@@ -2221,8 +2221,8 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     sa.rec_params = p_dev ? o_params + (size_t)done * N * d : ((o_params || is_am) ? blk_params : nullptr);
     sa.rec_stats = s_dev ? o_stats + (size_t)done * N * 3 : (o_stats ? blk_stats : nullptr);
     sa.rec_acc = a_dev ? o_acc + (size_t)done * N : (o_acc ? blk_acc : nullptr);
-    if (lv.model == MODEL_CALLBACK || (lv.model == MODEL_USER && lv.noise_kind == TDA_NOISE_DENSE)) {
-      if (e->pp.kind == TDA_PROP_INDEPENDENCE) return fail(TDA_ERR_UNSUPPORTED, "the independence sampler is not lowered for callback models");
+    const bool user_stepwise = lv.model == MODEL_USER && (lv.noise_kind == TDA_NOISE_DENSE || e->pp.kind == TDA_PROP_INDEPENDENCE || e->pp.kind == TDA_PROP_OWCN);
+    if (lv.model == MODEL_CALLBACK || user_stepwise) {  // (the fused source-model kernel knows GRW / pCN steps and iso / diag noise)
       ExtArgs xa{};
       fill_ext_args(e, lv, xa);
       xa.mode = 0;
@@ -2237,6 +2237,10 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
       xa.rec_params = sa.rec_params;
       xa.rec_stats = sa.rec_stats;
       xa.rec_acc = sa.rec_acc;
+      xa.q_mean = sa.q_mean;
+      xa.qz = sa.qz;
+      xa.lq = sa.lq;
+      xa.SopT = sa.SopT;
       for (int s = 0; s < (int)S; ++s) {
         xa.s = s;
         int xrc = ext_step(e, lv, xa);

@@ -44,6 +44,12 @@ struct ExtArgs {
   unsigned char* ring;  // multi-level: the base proposal's `accepted` list as a ring [ring_P][NP] (scaling adaptation window,
   int ring_P;           // proposal.py:236; it also receives the alignment entries of the levels above); may be null
   long long ring_pos;   // absolute list position of this step's entry
+  // IndependenceSampler (prop_kind 4): theta' = q_mean + inc, alpha = exp(post' - post + lq - qz) with log q up to its constant
+  const double* q_mean;  // [DP]
+  const double* qz;      // [S][NP]  -|z|^2 / 2 of the proposal
+  double* lq;            // [NP]     the same for the current state
+  // OperatorWeightedCrankNicolson (prop_kind 5): theta' = S theta + inc, likelihood-ratio acceptance
+  const double* SopT;    // [DP][DP] transposed state operator
   int theta_ld;         // k_ext_propose, mode 1: row stride of `theta` (0 = DP); the promoted states of a randomised subchain live in ysnap
   // Delayed Acceptance with randomize_subchain_length (chain.py:525-527): the state after step `pick[c]` of the running
   // subchain is the one promoted to the fine level; k_ext_accept snapshots it (parameters, log-prior, log-likelihood)
@@ -60,10 +66,19 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_propose(const ExtArgs a)
   if (c >= a.N || lane >= a.d) return;
   const double cur = a.theta[c * (a.theta_ld ? a.theta_ld : a.DP) + lane];
   double prp = cur;
-  if (a.mode != 1) {  // proposal.py:249-251 / :351-355
+  if (a.mode != 1) {  // proposal.py:249-251 / :351-355 / :113-115 / :592-598
     const double scal = a.scaling[c];
-    const double sx = scal * a.inc[((size_t)a.s * a.NP + c) * a.DP + lane];
-    prp = a.prop_kind == 1 ? sqrt(1.0 - scal * scal) * cur + sx : cur + sx;
+    const double inc = a.inc[((size_t)a.s * a.NP + c) * a.DP + lane];
+    const double sx = scal * inc;
+    if (a.prop_kind == 4) {
+      prp = a.q_mean[lane] + inc;
+    } else if (a.prop_kind == 5) {  // (S theta)[lane] = sum_j S^T[j][lane] theta[j] (the lanes >= d left above; the sources j < d are alive)
+      double st = 0.0;
+      for (int j = 0; j < a.d; ++j) st = fma(a.SopT[(size_t)j * a.DP + lane], __shfl(cur, j), st);
+      prp = st + inc;
+    } else {
+      prp = a.prop_kind == 1 ? sqrt(1.0 - scal * scal) * cur + sx : cur + sx;
+    }
   }
   a.prop[c * a.d + lane] = prp;
 }
@@ -118,11 +133,14 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_accept(const ExtArgs a) 
   const double post_n = lp_n + ll_n;               // link.py:48
   double lp = a.lp[c], ll = a.ll[c];
   bool acc = true;
-  if (!eval) {  // chain.py:112
-    const double delta = a.prop_kind == 1 ? ll_n - ll : post_n - (lp + ll);
+  const double qzs = (!eval && a.prop_kind == 4) ? a.qz[(size_t)a.s * a.NP + c] : 0.0;
+  if (!eval) {  // chain.py:112; proposal.py:253-258 / :357-362 / :117-123
+    double delta = (a.prop_kind == 1 || a.prop_kind == 5) ? ll_n - ll : post_n - (lp + ll);
+    if (a.prop_kind == 4) delta = (delta + a.lq[c]) - qzs;
     double alpha = exp(delta);
     if (post_n != post_n) alpha = 0.0;
     acc = a.u[(size_t)a.s * a.NP + c] < alpha;
+    if (acc && a.prop_kind == 4 && lane == 0) a.lq[c] = qzs;
   }
   double cur = lj ? a.theta[c * a.DP + lane] : 0.0;
   if (acc) {
