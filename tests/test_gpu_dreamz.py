@@ -217,3 +217,27 @@ def test_sample_api_dreamz_over_external_models():
         link = res["chain_7"][-1]
         assert np.isclose(link.posterior, post.create_link(link.parameters).posterior, rtol=1e-10)
         assert np.mean(res["chain_7"].accepted[1:]) > 0.0
+
+
+def test_sample_api_dreamz_with_uniform_prior_components():
+    """DREAM(Z) under a JointPrior with uniform components over a callback model: states and archive stay inside the
+    supports, the chains move, records carry the posterior."""
+    import scipy.stats as st
+
+    import tinyda_amd as tda
+    from tests.test_gpu_usermodel import np_model
+
+    d, m = 5, 23
+    rng = np.random.default_rng(13)
+    truth = np.array([0.3, -0.2, 0.25, 0.1, -0.1])
+    y = np_model(truth)[0] + 0.05 * rng.standard_normal(m)
+    prior = tda.JointPrior([st.uniform(-0.5, 1.0), st.norm(0, 1), st.uniform(-0.5, 1.0), st.norm(0, 0.5), st.uniform(-1, 2)])
+    post = tda.Posterior(prior, tda.GaussianLogLike(y, 0.05 ** 2 * np.eye(m)), tda.BatchedModel(np_model, m))
+    np.random.seed(5)
+    res = tda.sample(post, tda.DREAMZ(40, delta=1, adaptive=True, period=25), 150, n_chains=12, seed=3)
+    assert res["sampler"] == "MH" and res.get("backend", "hip") != "host"
+    th = np.stack([np.asarray(res["chain_%d" % i].parameters) for i in range(12)])
+    assert (th[:, :, 0] >= -0.5).all() and (th[:, :, 0] <= 0.5).all() and (th[:, :, 2] >= -0.5).all() and (th[:, :, 2] <= 0.5).all()
+    link = res["chain_7"][-1]
+    assert np.isclose(link.posterior, post.create_link(link.parameters).posterior, rtol=1e-10)
+    assert np.mean([np.mean(res["chain_%d" % i].accepted[1:]) for i in range(12)]) > 0.01

@@ -50,8 +50,10 @@ def _device_plan(posteriors, proposal):
         # contains a callback / source-defined level (host-sequenced: the base-level kernels test the support bounds)
         low = lows[0]
         ext = any("source" in lw or "batched" in lw for lw in lows)
-        if isinstance(proposal, (DREAMZ, CrankNicolson)) or any("rosenbrock" in lw for lw in lows) or (len(posteriors) != 1 and not ext):
+        if isinstance(proposal, CrankNicolson) or any("rosenbrock" in lw for lw in lows) or (len(posteriors) != 1 and not ext):
             return None
+        if isinstance(proposal, DREAMZ) and not ext:
+            return None  # DREAM(Z) under a prior with uniform components: callback / source-defined models (their accept kernel tests the bounds)
         if len(posteriors) == 1 and low["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG):
             return None
     if any("source" in low or "batched" in low for low in lows):
@@ -250,7 +252,12 @@ def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, se
             dz = {k: v for k, v in prop.items() if k != "kind"}
             rows = dz["M0"] + iterations * ((total_chains or n_chains) if dz["shared"] else 1)
             eng.set_proposal_dreamz(capacity=rows, **dz)
-            eng.set_archive(None)
+            if "prior_joint" in low:  # uniform components: the initial archive is drawn on the host like theta0 (proposal.py:745-751)
+                n_arch = 1 if dz["shared"] else n_chains
+                Z0 = np.array([[np.asarray(posterior.prior.rvs(), dtype=np.float64) for _ in range(dz["M0"])] for _ in range(n_arch)])
+                eng.set_archive(Z0[0] if dz["shared"] else Z0)
+            else:
+                eng.set_archive(None)
         else:
             eng.set_proposal(**prop)
         theta0 = None if initial_parameters is None else np.stack([np.asarray(p, float) for p in initial_parameters])

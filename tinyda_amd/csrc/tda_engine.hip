@@ -269,7 +269,7 @@ struct tda_engine {
   // DREAM(Z)
   bool is_dreamz = false;
   tda_dreamz_params dz{};
-  bool arch_set = false, auto_append = true;
+  bool arch_set = false, arch_given = false, auto_append = true;  // arch_given: the caller supplied the initial archive
   std::vector<double> Z0_h;
   int64_t arch_rows = 0;    // rows currently in the archive(s)
   int64_t arch_cap = 0;
@@ -1113,6 +1113,7 @@ int tda_engine_set_archive(tda_engine* e, const double* Z0) {
   const int d = e->d;
   const int64_t rows = (e->dz.shared ? 1 : e->N) * (int64_t)e->dz.M0;
   e->Z0_h.resize((size_t)rows * d);
+  e->arch_given = Z0 != nullptr;
   if (Z0) {
     if (is_device_ptr(Z0))
       HIP_TRY(hipMemcpy(e->Z0_h.data(), Z0, e->Z0_h.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -1526,8 +1527,10 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
   if (e->prior_bounded) {  // JointPrior with uniform components
     // single-level GRW / AM (fused), or a host-sequenced hierarchy (callback / source-defined levels): there the base-level
     // kernels test the support bounds and the upper levels carry the log-prior of the states they promote
-    if ((e->nlev != 1 && !e->ext_hier) || e->is_dreamz)
-      return fail(TDA_ERR_UNSUPPORTED, "priors with uniform components: single-level GRW / AM, or hierarchies of callback / source-defined models");
+    const bool ext0 = e->levels[0].model == MODEL_CALLBACK || e->levels[0].model == MODEL_USER;
+    if ((e->nlev != 1 && !e->ext_hier) || (e->is_dreamz && !ext0))
+      return fail(TDA_ERR_UNSUPPORTED, "priors with uniform components: single-level GRW / AM, hierarchies of callback / source-defined models, DREAM(Z) over such models");
+    if (e->is_dreamz && !(e->arch_set && e->arch_given)) return fail(TDA_ERR_INVALID, "priors with uniform components: DREAM(Z) needs an explicit initial archive");
     if (e->pp.kind == TDA_PROP_PCN) return fail(TDA_ERR_UNSUPPORTED, "pCN needs a Gaussian prior");
     if (e->levels[0].noise_kind == TDA_NOISE_DENSE) return fail(TDA_ERR_UNSUPPORTED, "priors with uniform components: iso / diag noise only");
     if (!theta0) return fail(TDA_ERR_INVALID, "priors with uniform components need explicit initial parameters");
