@@ -46,15 +46,12 @@ def _device_plan(posteriors, proposal):
     if any("rosenbrock" in low for low in lows) and not isinstance(proposal, DREAMZ):
         return None  # the Rosenbrock model is fused into the DREAMZ kernel only
     if any("prior_joint" in low for low in lows):
-        # JointPrior: GRW / AM; single level (linear, source-defined or callback model, iso / diag noise) or a hierarchy that
-        # contains a callback / source-defined level (host-sequenced: the base-level kernels test the support bounds)
+        # JointPrior: GRW / AM / DREAM(Z), single level or hierarchy, every model kind but the Rosenbrock example; the kernels
+        # that evaluate the prior test the support bounds (proposals outside are rejected)
         low = lows[0]
-        ext = any("source" in lw or "batched" in lw for lw in lows)
-        if isinstance(proposal, CrankNicolson) or any("rosenbrock" in lw for lw in lows) or (len(posteriors) != 1 and not ext):
+        if isinstance(proposal, CrankNicolson) or any("rosenbrock" in lw for lw in lows):
             return None
-        if isinstance(proposal, DREAMZ) and not ext:
-            return None  # DREAM(Z) under a prior with uniform components: callback / source-defined models (their accept kernel tests the bounds)
-        if len(posteriors) == 1 and low["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG):
+        if any(lw["noise_kind"] == _lib.NOISE_DENSE for lw in lows):
             return None
     if any("source" in low or "batched" in low for low in lows):
         # source-defined and batched host models: single level, or a whole hierarchy of them (Delayed Acceptance / MLDA with

@@ -1527,9 +1527,8 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
   if (e->prior_bounded) {  // JointPrior with uniform components
     // single-level GRW / AM (fused), or a host-sequenced hierarchy (callback / source-defined levels): there the base-level
     // kernels test the support bounds and the upper levels carry the log-prior of the states they promote
-    const bool ext0 = e->levels[0].model == MODEL_CALLBACK || e->levels[0].model == MODEL_USER;
-    if ((e->nlev != 1 && !e->ext_hier) || (e->is_dreamz && !ext0))
-      return fail(TDA_ERR_UNSUPPORTED, "priors with uniform components: single-level GRW / AM, hierarchies of callback / source-defined models, DREAM(Z) over such models");
+    if (e->is_dreamz && e->levels[0].model == MODEL_ROSENBROCK)
+      return fail(TDA_ERR_UNSUPPORTED, "priors with uniform components are not lowered for the Rosenbrock example model");
     if (e->is_dreamz && !(e->arch_set && e->arch_given)) return fail(TDA_ERR_INVALID, "priors with uniform components: DREAM(Z) needs an explicit initial archive");
     if (e->pp.kind == TDA_PROP_PCN) return fail(TDA_ERR_UNSUPPORTED, "pCN needs a Gaussian prior");
     if (e->levels[0].noise_kind == TDA_NOISE_DENSE) return fail(TDA_ERR_UNSUPPORTED, "priors with uniform components: iso / diag noise only");
@@ -2803,6 +2802,8 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
     ma.pr.wmu = e->prior_wmu.p;
     ma.pr.ncb = e->prior_ncb;
     ma.pr.kind = e->prior_kind;
+    ma.pr.lo = e->prior_bounded ? e->prior_lo.p : nullptr;
+    ma.pr.hi = e->prior_bounded ? e->prior_hi.p : nullptr;
     ma.pr.logconst = e->prior_logconst;
     ma.N = N;
     ma.NP = NP;
@@ -3067,6 +3068,8 @@ void fill_dreamz_step_args(tda_engine* e, DreamStepArgs& sa) {
   sa.pr.wmu = e->prior_wmu.p;
   sa.pr.ncb = e->prior_ncb;
   sa.pr.kind = e->prior_kind;
+  sa.pr.lo = e->prior_bounded ? e->prior_lo.p : nullptr;
+  sa.pr.hi = e->prior_bounded ? e->prior_hi.p : nullptr;
   sa.pr.logconst = e->prior_logconst;
   sa.model = lv.model;
   sa.ros_a = lv.ros_a;

@@ -333,6 +333,11 @@ __global__ void __launch_bounds__(256, 2) k_dreamz_steps(const DreamStepArgs a) 
         const double dv = th[kk] - pm[kk];
         p += dv * dv * pinv[kk];
       }
+      if (a.pr.lo) {  // uniform components: zero density outside their support
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+          if (th[kk] < a.pr.lo[4 * kk + hi] || th[kk] > a.pr.hi[4 * kk + hi]) p = INFINITY;
+      }
       p = sum_rows(p);
       maha = p;
     } else {

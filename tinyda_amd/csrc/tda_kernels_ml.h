@@ -181,6 +181,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
         const double dv = th[kk] - (PAIRS ? pm[kk] : a.pr.mean[4 * kk + hi]);
         p += dv * dv * (PAIRS ? pinv[kk] : a.pr.pinv[4 * kk + hi]);
       }
+      if (a.pr.lo) {  // uniform components: zero density outside their support (rare path, bounds read through L1)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+          if (th[kk] < a.pr.lo[4 * kk + hi] || th[kk] > a.pr.hi[4 * kk + hi]) p = INFINITY;
+      }
       p = sum_rows(p);
       maha = p;
     } else {
