@@ -20,6 +20,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL (set before the HIP runtime loads)
 
 D, M, SIGMA = 64, 1024, 0.1
 CHAINS_PER_GPU = 4096

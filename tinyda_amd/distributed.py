@@ -28,6 +28,8 @@ def init_process_group(backend=None):
     import torch.distributed as dist
 
     rank, local_rank, world = env_rank_world()
+    # the host driver of this pool only supports dmabuf IPC: without it RCCL fails with hipIpcGetMemHandle: invalid argument
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
