@@ -197,3 +197,32 @@ def test_multilevel_lowering_and_argument_checks():
     with pytest.warns(UserWarning):  # deprecated alias still accepted (sampler.py:113-115)
         with pytest.raises(tda.EngineError):
             tda.sample(posts[:2], tda.CrankNicolson(), 5, subsampling_rate=10)
+
+
+def test_multilevel_plan_for_plain_callables_and_external_models():
+    """Lowering rules that need no GPU: plain Python callables in a hierarchy are wrapped behind the batched-callback
+    interface; hierarchies may mix callback, source-defined and linear levels; AdaptiveGaussianLogLike below the finest level."""
+    from tinyda_amd import api
+
+    d, m = 4, 9
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((m, d))
+    y = rng.standard_normal(m)
+    prior = stats.multivariate_normal(np.zeros(d), np.eye(d))
+    cov = 0.1 * np.eye(m)
+    plain = [tda.Posterior(prior, tda.AdaptiveGaussianLogLike(y, cov), lambda th: np.tanh(A @ th)),
+             tda.Posterior(prior, tda.GaussianLogLike(y, cov), lambda th: np.tanh(A @ th) + 0.01)]
+    assert api._device_plan(plain, tda.GaussianRandomWalk(np.eye(d))) is None
+    wrapped = api._wrap_opaque_models(plain)
+    assert wrapped is not None and all(isinstance(p.model, tda.BatchedModel) for p in wrapped)
+    out = wrapped[0].model.batch(np.zeros((3, d)))
+    assert out.shape == (3, m) and np.allclose(out, 0.0)
+    plan = api._device_plan(wrapped, tda.GaussianRandomWalk(np.eye(d), adaptive=True))
+    assert plan is not None and "batched" in plan[0][0] and plan[0][0]["noise_kind"] == 3
+    mixed = [tda.Posterior(prior, tda.GaussianLogLike(y, cov), tda.LinearModel(A)), wrapped[1]]
+    assert api._device_plan(mixed, tda.CrankNicolson(scaling=0.1)) is not None
+    assert api._device_plan(mixed, tda.DREAMZ(10)) is None  # DREAM(Z) below a hierarchy is not lowered
+    qoi = [tda.Posterior(prior, tda.GaussianLogLike(y, cov), lambda th: (A @ th, th.sum())), wrapped[1]]
+    w2 = api._wrap_opaque_models(qoi)
+    with pytest.raises(TypeError):
+        w2[0].model.batch(np.zeros((2, d)))
