@@ -1,22 +1,27 @@
 #!/usr/bin/env python3
-"""Headline benchmark: proposal evaluations / s of the many-chain MH hot path (BASELINE.json configs[1]):
+"""Headline benchmark: proposal evaluations / s (+ ESS / s) of the many-chain MH hot path, BASELINE.json configs[1]:
 64-dim Gaussian-linear posterior, 1024 observations, isotropic noise, AdaptiveMetropolis(t0=100, period=100),
 4096 chains per GPU, synthetic data of SURVEY.md §8(d) "C2 synthetic input".
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" = one Metropolis-Hastings step of every chain on the GPU (propose -> forward model -> log-likelihood
--> log alpha -> accept -> record, with the AdaptiveMetropolis recursion and covariance swaps included).
-For N > 1 launch under torch.distributed.run; chains are sharded by global id, no data-path collective.
+A "step" is one pass of the hot path over one batch: ONE AdaptiveMetropolis PERIOD = 100 Metropolis-Hastings iterations
+of every chain on the GPU (k_apply -> k_mh_steps (100 fused iterations: propose, forward model, log-likelihood,
+log alpha, accept, record) -> k_adapt (the 100 moment updates) -> k_chol (covariance swap)), i.e. 409 600 proposal
+evaluations per GPU.  The driver's `--steps 20 --warmup 5` is SURVEY's C2 run: 2000 iterations per chain after a warm-up.
+
+With --gpus N > 1 and no WORLD_SIZE in the environment this script starts its own N ranks
+(`python -m torch.distributed.run ...` as a child process, before anything here touches the GPU) and relays rank 0's line;
+under torch.distributed.run it is a rank.  Chains are sharded by global id, there is no data-path collective.
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -24,13 +29,59 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL 
 
 D, M, SIGMA = 64, 1024, 0.1
 CHAINS_PER_GPU = 4096
-HBM_PEAK = 8.0e12        # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
-FP64_MFMA_PEAK = 78.6e12  # FLOP/s dense fp64 matrix (AMD MI355X spec; tools/mfma_probe measures 75-77 on the box)
-B_ALG_STEP_SYNC = 40 * D + 25 + 24 * D * D + 8 * (M * D + M) / CHAINS_PER_GPU  # 101 019 B / eval
-FLOPS_STEPS_KERNEL = 2 * M * D + 3 * M + 2 * D  # forward + isotropic log-like + identity prior
+PERIOD = 100              # MH iterations per bench step (one AdaptiveMetropolis period)
+HBM_PEAK = 8.0e12         # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
+FP64_MFMA_PEAK = 78.6e12  # FLOP/s dense fp64 matrix (MI355X_MICROARCH.md / AMD spec; tools/mfma_probe measures 75-77 on the box)
+FLOPS_PER_EVAL = 2 * M * D + 3 * M + 2 * D  # forward + isotropic log-like + identity prior: 134 272
+BYTES_PER_EVAL_STEPS = 8 * D + 8 + (8 * D + 24 + 1)  # k_mh_steps HBM: increment row + uniform in, record out = 1 057 B
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20, help="timed steps (1 step = %d MH iterations of every chain)" % PERIOD)
+    ap.add_argument("--warmup", type=int, default=5, help="untimed steps before the timed window")
+    ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
+    ap.add_argument("--pilot", type=int, default=10000,
+                    help="set-up: MH iterations of a pilot run (GaussianRandomWalk, C = 1e-4 I, theta0 ~ prior) whose final states are "
+                         "the initial_parameters of the AdaptiveMetropolis run; 0 = AM starts from theta0 ~ prior itself (SURVEY's "
+                         "literal recipe: its running covariance then keeps the transient's spread, acceptance falls to 0.5 %% and "
+                         "the chains never equilibrate -- R-hat 20 after 80 000 iterations, measured in round 2)")
+    ap.add_argument("--burnin", type=int, default=80000,
+                    help="set-up: untimed, unrecorded AdaptiveMetropolis iterations before the warm-up steps (the per-chain covariance "
+                         "estimates need them: a 20 000-iteration window has R-hat 1.23 right after the pilot, 1.02 after 80 000)")
+    ap.add_argument("--ess-iterations", type=int, default=20000,
+                    help="length of the separate stationary window ESS/s is measured on (0 = only the timed window)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ess", action="store_true")
+    ap.add_argument("--extras", action="store_true", help="side measurements (other proposals / extensions), never the headline")
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """--gpus N > 1 from a bare shell: run the N ranks as a fresh child process tree (this process has made no GPU call
+    and never replaces itself), relay rank 0's JSON line, exit with the children's status."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line is not None:
+        print(line, flush=True)
+    else:
+        sys.stderr.write(r.stdout[-4000:])
+    sys.exit(r.returncode if r.returncode else (0 if line is not None else 1))
 
 
 def c2_problem(seed=1):
+    import numpy as np
+
     rng = np.random.default_rng(seed)
     A = rng.standard_normal((M, D)) / 8
     theta_true = rng.standard_normal(D)
@@ -40,6 +91,8 @@ def c2_problem(seed=1):
 
 def cpu_baseline(A, y, target_seconds=12.0):
     """The C oracle (oracle/oracle_mh.c, kind 'port') on all host cores, bounded sample of the same workload."""
+    import numpy as np
+
     from oracle import oracle_c
 
     oracle_c.load()
@@ -61,61 +114,107 @@ def cpu_baseline(A, y, target_seconds=12.0):
     n_chains = int(max(cores, min(4096, round(rate * target_seconds / T / cores) * cores)))
     dt = run(n_chains, T)
     return {"value": n_chains * T / dt, "unit": "evals/s", "cores": cores, "kind": "port",
-            "sample": "%d chains x %d steps of the same workload (C oracle, OpenMP over chains, %.1f s)" % (n_chains, T, dt)}
+            "sample": "%d chains x %d MH iterations of the same workload (C oracle, OpenMP over chains, %.1f s)" % (n_chains, T, dt)}
+
+
+def latest_pmc_traffic():
+    """HBM bytes per k_mh_steps launch from the newest committed PMC pass (tools/pmc_traffic.sh), or None"""
+    pdir = os.path.join(ROOT, "profiles")
+    best = None
+    try:
+        for f in sorted(os.listdir(pdir)):
+            if f.endswith("pmc_traffic.json"):
+                v = json.load(open(os.path.join(pdir, f))).get("k_mh_steps_hbm_bytes_per_launch")
+                if v:
+                    best = (f, v)
+    except Exception:
+        return None, None
+    return best if best else (None, None)
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-ess", action="store_true")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
 
+    import numpy as np
     import torch
 
     from tinyda_amd import summaries as diagnostics
     from tinyda_amd import distributed as tdist
     from tinyda_amd.engine import Engine
 
-    # TINYDA_BENCH_ONE_GPU=1 (testing the N > 1 code path on a one-GPU box): every rank on cuda:0, gloo instead of RCCL
+    # TINYDA_BENCH_ONE_GPU=1 (rehearsing the N > 1 code path on a one-GPU box): every rank on cuda:0, gloo instead of RCCL
     one_gpu = os.environ.get("TINYDA_BENCH_ONE_GPU") == "1"
     rank, local_rank, world = tdist.init_process_group("gloo" if one_gpu else None)
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     N, K, W = args.chains, args.steps, args.warmup
+    if K < 1 or W < 0:
+        raise SystemExit("--steps must be >= 1 and --warmup >= 0")
+    burnin, pilot = max(args.burnin, 0), max(args.pilot, 0)
+    T_timed, T_warm = K * PERIOD, W * PERIOD
 
     A, _, y = c2_problem()
-    eng = Engine(N, D, seed=2026, device=local_rank, chain_offset=rank * N)  # weak scaling: N chains per GPU
-    eng.set_prior(np.zeros(D), np.eye(D))
-    eng.set_level(0, A, y, 0, SIGMA ** 2)
-    eng.set_proposal(2, 1e-4 * np.eye(D), t0=100, period=100, sd=None, epsilon=1e-6)
-    eng.init(None)  # theta0 ~ prior, Philox stream 2 keyed by global chain id
 
-    params = torch.empty((max(K, W), N, D), dtype=torch.float64, device=dev)
-    stats = torch.empty((max(K, W), N, 3), dtype=torch.float64, device=dev)
-    acc = torch.empty((max(K, W), N), dtype=torch.uint8, device=dev)
-    if W > 0:
-        eng.run(W, params[:W], stats[:W], acc[:W])
+    def engine(kind, **kw):
+        e = Engine(N, D, seed=2026, device=local_rank, chain_offset=rank * N)  # weak scaling: N chains per GPU
+        e.set_prior(np.zeros(D), np.eye(D))
+        e.set_level(0, A, y, 0, SIGMA ** 2)
+        e.set_proposal(kind, 1e-4 * np.eye(D), **kw)
+        return e
+
+    t_b = time.perf_counter()
+    theta_start = None  # theta0 ~ prior, Philox stream 2 keyed by global chain id
+    if pilot:  # what a user does with the reference: a pilot run, then sample(..., initial_parameters=its last states)
+        pe = engine(0)
+        pe.init(None)
+        pe.run(pilot, None, None, None)
+        theta_start, _ = pe.current()
+        pe.close()
+    eng = engine(2, t0=100, period=PERIOD, sd=None, epsilon=1e-6)
+    eng.init(theta_start)
+
+    # every record buffer is sized for the longest run that writes into it
+    rows = max(T_timed, min(T_warm, T_timed) if T_warm else 0, 1)
+    params = torch.empty((rows, N, D), dtype=torch.float64, device=dev)
+    stats = torch.empty((rows, N, 3), dtype=torch.float64, device=dev)
+    acc = torch.empty((rows, N), dtype=torch.uint8, device=dev)
+
+    def run_chunked(engine, n_iter, record=True):
+        """advance n_iter iterations, writing (and overwriting) records into the first rows of the buffers"""
+        left = n_iter
+        while left > 0:
+            n = min(left, rows)
+            if record:
+                engine.run(n, params[:n], stats[:n], acc[:n], sync=False)
+            else:
+                engine.run(n, None, None, None, sync=False)
+            left -= n
+        engine.sync()
+
+    # set-up: adaptation burn-in (unrecorded), then the W warm-up steps exactly as timed (records on)
+    run_chunked(eng, burnin, record=False)
+    burnin_s = time.perf_counter() - t_b
+    run_chunked(eng, T_warm)
     eng.set_profiling(True)  # HIP events around every kernel launch, on the engine's stream
     torch.cuda.synchronize()
     tdist.barrier()
     t0 = time.perf_counter()
-    eng.run(K, params[:K], stats[:K], acc[:K], sync=True)
+    eng.run(T_timed, params[:T_timed], stats[:T_timed], acc[:T_timed], sync=True)
     torch.cuda.synchronize()
     tdist.barrier()
     dt = tdist.reduce_scalar(time.perf_counter() - t0, "max", dev)
     prof = eng.profile()
+    eng.set_profiling(False)
 
-    evals = world * N * K
+    evals = world * N * T_timed
     out = {
-        "metric": "proposal evals/sec (node), 64-dim AdaptiveMetropolis, 4096 chains/GPU",
+        "metric": "proposal evals/sec (node) + ESS/sec, 64-dim AM 4096 chains/GPU",
         "value": evals / dt,
         "unit": "evals/s",
         "n_gpus": world,
@@ -128,144 +227,156 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[1] / SURVEY C2a: d=64 Gaussian-linear posterior, m=1024 obs, isotropic noise, "
-                               "prior N(0,I), AdaptiveMetropolis(C0=1e-4 I, t0=100, period=100), theta0 ~ prior",
-                   "chains_per_gpu": N, "dim": D, "observations": M, "records": "params+stats+accepted to HBM every step"},
+                               "prior N(0,I), AdaptiveMetropolis(C0=1e-4 I, t0=100, period=100)",
+                   "chains_per_gpu": N, "dim": D, "observations": M,
+                   "step": "one AdaptiveMetropolis period = %d MH iterations of every chain (%d proposal evals per GPU)" % (PERIOD, PERIOD * N),
+                   "mh_iterations_per_step": PERIOD, "timed_mh_iterations_per_chain": T_timed,
+                   "records": "params+stats+accepted of every iteration to HBM",
+                   "setup_untimed": {"pilot_grw_mh_iterations": pilot, "am_burnin_mh_iterations": burnin, "seconds": burnin_s,
+                                     "start": "pilot run's final states" if pilot else "theta0 ~ prior"},
+                   "rccl_ranks": world if (world > 1 and not one_gpu) else (0 if world == 1 else "gloo rehearsal on one GPU")},
     }
     if rank == 0:
-        ev_rank = N * K
-        kern = {"k_mh_steps": (prof["ms_steps"], prof["n_launch_steps"]),
-                "k_adapt": (prof["ms_adapt"], prof["n_launch_adapt"]),
-                "k_apply": (prof["ms_propose"], prof["n_launch_propose"])}  # k_rng runs under k_mh_steps on a 2nd stream
-        ms_st, n_st = kern["k_mh_steps"]
-        avg_launch_s = ms_st * 1e-3 / max(n_st, 1)
-        evals_per_launch = ev_rank / max(n_st, 1)
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_i_pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("k_mh_steps_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        achieved = FLOPS_STEPS_KERNEL * evals_per_launch / avg_launch_s
-        out["roofline"] = {"kernel": "k_mh_steps", "bound": "mfma", "achieved": achieved / 1e12, "peak": FP64_MFMA_PEAK / 1e12,
-                           "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK, "traffic": traffic,
-                           "flops_per_eval": FLOPS_STEPS_KERNEL, "evals_per_launch": evals_per_launch,
-                           "avg_launch_ms": avg_launch_s * 1e3}
-        # the figure north_star quotes: step-synchronous algorithmic bytes against HBM peak, whole pipeline
-        rate_gpu = ev_rank / dt
-        out["roofline_hbm_step_synchronous"] = {"bound": "hbm", "bytes_per_eval": B_ALG_STEP_SYNC,
-                                                "achieved": rate_gpu * B_ALG_STEP_SYNC / 1e9, "peak": HBM_PEAK / 1e9,
-                                                "unit": "GB/s", "frac": rate_gpu * B_ALG_STEP_SYNC / HBM_PEAK,
-                                                "note": "period-blocked pipeline keeps Sigma/L traffic off the per-step path; >1 means the "
-                                                        "step-synchronous HBM model no longer binds"}
-        out["kernel_ms"] = {k: {"total_ms": v[0], "launches": v[1], "ns_per_eval": v[0] * 1e6 / ev_rank} for k, v in kern.items()}
-        out["acceptance_rate"] = float(acc[:K].float().mean().item())
+        ev_rank = N * T_timed
+        try:
+            kern = {"k_mh_steps": (prof["ms_steps"], prof["n_launch_steps"]),
+                    "k_adapt(+k_chol)": (prof["ms_adapt"], prof["n_launch_adapt"]),
+                    "k_apply": (prof["ms_propose"], prof["n_launch_propose"])}  # k_rng runs under k_mh_steps on a 2nd stream
+            ms_st, n_st = kern["k_mh_steps"]
+            avg_launch_s = ms_st * 1e-3 / max(n_st, 1)
+            evals_per_launch = ev_rank / max(n_st, 1)
+            pmc_file, traffic = latest_pmc_traffic()
+            if traffic is not None and abs(evals_per_launch - PERIOD * CHAINS_PER_GPU) > 0.5:
+                traffic = traffic * evals_per_launch / (PERIOD * CHAINS_PER_GPU)  # PMC passes are collected on 100-step launches of 4096 chains
+            achieved = FLOPS_PER_EVAL * evals_per_launch / avg_launch_s
+            rate_gpu = ev_rank / dt
+            out["roofline"] = {"kernel": "k_mh_steps", "bound": "mfma", "achieved": achieved / 1e12, "peak": FP64_MFMA_PEAK / 1e12,
+                               "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK, "traffic": traffic, "traffic_source": pmc_file,
+                               "flops_per_eval": FLOPS_PER_EVAL, "evals_per_launch": evals_per_launch,
+                               "algorithmic_hbm_bytes_per_launch": BYTES_PER_EVAL_STEPS * evals_per_launch,
+                               "avg_launch_ms": avg_launch_s * 1e3,
+                               "whole_pipeline_frac": rate_gpu * FLOPS_PER_EVAL / FP64_MFMA_PEAK,
+                               "whole_pipeline_note": "all kernels of a step (k_apply, k_mh_steps, k_adapt, k_chol; k_rng overlapped) "
+                                                      "priced at the step kernel's flops: wall-clock evals/s x flops/eval / peak"}
+            out["kernel_ms"] = {k: {"total_ms": v[0], "launches": v[1], "ns_per_eval": v[0] * 1e6 / ev_rank} for k, v in kern.items()}
+            out["acceptance_rate"] = float(acc[:T_timed].float().mean().item())
+        except Exception as exc:  # the headline must survive a failed side computation
+            out["roofline_error"] = repr(exc)
         if not args.no_ess:
-            # ESS/s: min-over-parameters bulk ESS (rank-normalised, split chains) of the second half of the timed draws of
-            # ALL chains of this GPU, computed on the device (tda_diag_ess_rhat: hipCUB sort + hipFFT); chains are
-            # independent and identically set up on every GPU, so the node figure is world x the rank-0 figure.
-            dd = diagnostics.ess_rhat_device(params[K // 2:K], device=local_rank)
-            ess_min, ess_med = float(np.nanmin(dd["ess"])), float(np.nanmedian(dd["ess"]))
-            out["ess_per_sec"] = ess_min * world / dt
-            out["ess"] = {"min_bulk_ess_node": ess_min * world, "median_bulk_ess_node": ess_med * world,
-                          "max_rhat": float(np.nanmax(dd["rhat"])), "chains_used": N, "draws_per_chain": K - K // 2,
-                          "computed": "on device, all chains"}
-        extras = world == 1  # the side measurements below are single-GPU figures (and the pooled one holds a collective)
-        if extras and not args.no_ess:
-            # The C2 recipe starts every chain from a prior draw with C0 = 1e-4 I, so the timed window is still burn-in
-            # and its ESS is dominated by between-chain variance.  For reference, the same kernel pipeline started in
-            # stationarity (theta0 ~ exact conjugate posterior, C0 = sd * posterior covariance): ESS/s of the sampler
-            # itself.  Short separate run, outside the timed region, 512 chains' worth of draws scaled like above.
-            cov_post = np.linalg.inv(A.T @ A / SIGMA ** 2 + np.eye(D))
-            mean_post = cov_post @ (A.T @ y / SIGMA ** 2)
-            rs = np.random.default_rng(3)
-            th_st = mean_post + rs.standard_normal((N, D)) @ np.linalg.cholesky(cov_post).T
-            e2 = Engine(N, D, seed=77, device=local_rank)
-            e2.set_prior(np.zeros(D), np.eye(D))
-            e2.set_level(0, A, y, 0, SIGMA ** 2)
-            e2.set_proposal(2, min(1.0, 2.4 ** 2 / D) * cov_post, t0=100, period=100)
-            e2.init(th_st)
-            Ks = min(K, 2000)
-            e2.run(100, params[:100], stats[:100], acc[:100])  # first run() of an engine allocates its block buffers
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            e2.run(Ks, params[:Ks], stats[:Ks], acc[:Ks], sync=True)
-            torch.cuda.synchronize()
-            dts = time.perf_counter() - t1
-            ess2 = {"ess_min": float(np.nanmin(diagnostics.ess_rhat_device(params[:Ks], device=local_rank)["ess"]))}
-            sub = N
-            out["ess_stationary_start"] = {"ess_per_sec_per_gpu": ess2["ess_min"] * (N / sub) / dts, "min_bulk_ess": ess2["ess_min"] * (N / sub),
-                                           "steps": Ks, "seconds": dts, "acceptance_rate": float(acc[:Ks].float().mean().item()),
-                                           "note": "per-chain AM (reference semantics): 100 draws cannot estimate a 64x64 covariance, mixing is slow for any implementation"}
-            e2.close()
-            # extension: ONE covariance pooled over all chains (and GPUs, one all_reduce of 1+d+d^2 doubles per period),
-            # started from C0 = 1e-4 I in stationarity: after the first period it has the posterior covariance
-            from tinyda_amd.distributed import PooledAdaptiveMetropolis
-
-            e3 = Engine(N, D, seed=78, device=local_rank, chain_offset=rank * N)
-            e3.set_prior(np.zeros(D), np.eye(D))
-            e3.set_level(0, A, y, 0, SIGMA ** 2)
-            e3.set_proposal(0, 1e-4 * np.eye(D))
-            e3.init(th_st)  # same stationary start; the pooled covariance is learnt from the chain cloud itself
-            pam = PooledAdaptiveMetropolis(e3, 1e-4 * np.eye(D), t0=100, period=100)
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            pam.run(Ks, params[:Ks], stats[:Ks], acc[:Ks])
-            torch.cuda.synchronize()
-            dtp = time.perf_counter() - t2
-            ess3 = {"ess_min": float(np.nanmin(diagnostics.ess_rhat_device(params[Ks // 2:Ks], device=local_rank)["ess"]))}
-            out["ess_pooled_am_extension"] = {"ess_per_sec_per_gpu": ess3["ess_min"] * (N / sub) / dtp, "min_bulk_ess_second_half": ess3["ess_min"] * (N / sub),
-                                              "evals_per_sec_per_gpu": N * Ks / dtp, "steps": Ks, "seconds": dtp,
-                                              "acceptance_rate_second_half": float(acc[Ks // 2:Ks].float().mean().item())}
-            e3.close()
-        if extras and not args.no_ess:
-            # the same target and start (theta0 ~ prior, same seed) sampled with the reference's MALA proposal
-            # (proposal.py:861-1005), adaptive scaling: what the choice of proposal does to ESS/s on this engine.  Not the headline.
-            e5 = Engine(N, D, seed=2026, device=local_rank, chain_offset=rank * N)
-            e5.set_prior(np.zeros(D), np.eye(D))
-            e5.set_level(0, A, y, 0, SIGMA ** 2)
-            e5.set_proposal(6, None, scaling=0.02, adaptive=True, gamma=1.01, period=50)
-            e5.init(None)
-            if W > 0:
-                e5.run(W, params[:W], stats[:W], acc[:W])
-            torch.cuda.synchronize()
-            t4 = time.perf_counter()
-            e5.run(K, params[:K], stats[:K], acc[:K], sync=True)
-            torch.cuda.synchronize()
-            dtm = time.perf_counter() - t4
-            dm = diagnostics.ess_rhat_device(params[K // 2:K], device=local_rank)
-            out["mala_same_target"] = {"evals_per_sec_per_gpu": N * K / dtm, "ess_per_sec_per_gpu": float(np.nanmin(dm["ess"])) / dtm,
-                                       "min_bulk_ess": float(np.nanmin(dm["ess"])), "max_rhat": float(np.nanmax(dm["rhat"])),
-                                       "acceptance_rate_second_half": float(acc[K // 2:K].float().mean().item()), "seconds": dtm,
-                                       "proposal": "MALA(scaling=0.02, adaptive=True, period=50), exact gradient c - H theta on the device"}
-            e5.close()
-        # extension, not the headline: AdaptiveMetropolis(block_moments=True) -- the running covariance as one rank-S update
-        # per block on the matrix cores instead of the reference's elementwise recursion (parity 1e-8 instead of 1e-10)
-        if extras:
-            e4 = Engine(N, D, seed=2026, device=local_rank, chain_offset=rank * N)
-            e4.set_prior(np.zeros(D), np.eye(D))
-            e4.set_level(0, A, y, 0, SIGMA ** 2)
-            e4.set_proposal(2, 1e-4 * np.eye(D), t0=100, period=100, block_moments=True)
-            e4.init(None)
-            if W > 0:
-                e4.run(W, params[:W], stats[:W], acc[:W])
-            torch.cuda.synchronize()
-            t3 = time.perf_counter()
-            e4.run(K, params[:K], stats[:K], acc[:K], sync=True)
-            torch.cuda.synchronize()
-            dtb = time.perf_counter() - t3
-            out["block_moments_extension"] = {"evals_per_sec_per_gpu": N * K / dtb, "seconds": dtb,
-                                              "acceptance_rate": float(acc[:K].float().mean().item())}
-            e4.close()
+            try:
+                out.update(ess_section(args, eng, diagnostics, params, stats, acc, rows, N, T_timed, dt, world, local_rank, burnin))
+            except Exception as exc:
+                out["ess_error"] = repr(exc)
+    # (the stationary ESS window is a rank-0 side run; the other ranks wait at the final barrier)
+    if rank == 0 and world == 1 and args.extras:
+        try:
+            out["extras"] = extras(Engine, diagnostics, A, y, N, K, W, params, stats, acc, rows, local_rank, rank)
+        except Exception as exc:
+            out["extras_error"] = repr(exc)
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(A, y)
-        print(json.dumps(out))
+            try:
+                out["cpu_baseline"] = cpu_baseline(A, y)
+            except Exception as exc:
+                out["cpu_baseline_error"] = repr(exc)
+        print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:
         import torch.distributed as dist
 
         dist.barrier()
         dist.destroy_process_group()
+
+
+def ess_section(args, eng, diagnostics, params, stats, acc, rows, N, T_timed, dt, world, local_rank, burnin):
+    """ESS/s = min-over-parameters rank-normalised split bulk ESS (Vehtari et al. 2021) of ALL chains of this
+    GPU, on the device (tda_diag_ess_rhat: hipCUB sort + hipFFT).  Chains are independent and identically set up on every GPU,
+    so the node figure is world x the rank-0 figure.  Valid only with max R-hat < 1.05."""
+    import numpy as np
+    import torch
+
+    res = {}
+    # (i) the timed window itself, first half dropped as SURVEY prescribes
+    if T_timed >= 8:
+        dd = diagnostics.ess_rhat_device(params[T_timed // 2:T_timed], device=local_rank)
+        e_min, rh = float(np.nanmin(dd["ess"])), float(np.nanmax(dd["rhat"]))
+        res["ess_timed_window"] = {"ess_per_sec": e_min * world / dt, "min_bulk_ess_node": e_min * world, "max_rhat": rh,
+                                   "valid": bool(rh < 1.05), "draws_per_chain": T_timed - T_timed // 2, "chains_used": N,
+                                   "note": "second half of the timed draws; a random-walk sampler in 64 dimensions decorrelates over "
+                                           "hundreds of iterations, so windows this short leave R-hat above 1.05 even in stationarity"}
+    # (ii) a longer stationary window of the same pipeline continuing the same chains, timed on its own
+    L = int(args.ess_iterations)
+    if L > 0:
+        torch.cuda.synchronize()
+        # a buffer sized for the window when the timed run's is shorter
+        big = params if L <= rows else torch.empty((L, N, D), dtype=torch.float64, device=params.device)
+        t1 = time.perf_counter()
+        eng.run(L, big[:L], None, None, sync=True)
+        torch.cuda.synchronize()
+        dl = time.perf_counter() - t1
+        dd = diagnostics.ess_rhat_device(big[L // 2:L], device=local_rank)
+        e_min, e_med, rh = float(np.nanmin(dd["ess"])), float(np.nanmedian(dd["ess"])), float(np.nanmax(dd["rhat"]))
+        valid = bool(rh < 1.05)
+        res["ess_per_sec"] = e_min * world / dl if valid else None
+        res["ess"] = {"valid": valid, "max_rhat": rh, "min_bulk_ess_node": e_min * world, "median_bulk_ess_node": e_med * world,
+                      "window_mh_iterations": L, "window_seconds": dl, "evals_per_sec_in_window": N * L * world / dl,
+                      "draws_per_chain_used": L - L // 2, "chains_used": N,
+                      "ess_per_sec_if_counted": e_min * world / dl,
+                      "computed": "on device, all chains; first half of the window dropped (SURVEY §8(d)); same engine, same chains, "
+                                  "continuing after the timed window; params records only"}
+        del big
+    elif "ess_timed_window" in res:
+        w = res["ess_timed_window"]
+        res["ess_per_sec"] = w["ess_per_sec"] if w["valid"] else None
+    return res
+
+
+def extras(Engine, diagnostics, A, y, N, K, W, params, stats, acc, rows, local_rank, rank):
+    """Side measurements on the same target (single GPU, --extras only): never `value`."""
+    import numpy as np
+    import torch
+
+    T = min(K * PERIOD, rows)
+    Tw = min(W * PERIOD, rows)
+    res = {}
+
+    def timed(e, n):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        e.run(n, params[:n], stats[:n], acc[:n], sync=True)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t
+
+    def fresh(seed, kind, C0, **kw):
+        e = Engine(N, D, seed=seed, device=local_rank, chain_offset=rank * N)
+        e.set_prior(np.zeros(D), np.eye(D))
+        e.set_level(0, A, y, 0, SIGMA ** 2)
+        e.set_proposal(kind, C0, **kw)
+        return e
+
+    # the reference's MALA proposal (proposal.py:861-1005) on the same target from the same start
+    e5 = fresh(2026, 6, None, scaling=0.02, adaptive=True, gamma=1.01, period=50)
+    e5.init(None)
+    if Tw:
+        e5.run(Tw, params[:Tw], stats[:Tw], acc[:Tw])
+    dtm = timed(e5, T)
+    dm = diagnostics.ess_rhat_device(params[T // 2:T], device=local_rank)
+    res["mala_same_target"] = {"evals_per_sec_per_gpu": N * T / dtm, "ess_per_sec_per_gpu": float(np.nanmin(dm["ess"])) / dtm,
+                               "min_bulk_ess": float(np.nanmin(dm["ess"])), "max_rhat": float(np.nanmax(dm["rhat"])),
+                               "acceptance_rate_second_half": float(acc[T // 2:T].float().mean().item()), "seconds": dtm,
+                               "proposal": "MALA(scaling=0.02, adaptive=True, period=50), exact gradient c - H theta on the device"}
+    e5.close()
+    # extension: AdaptiveMetropolis(block_moments=True) -- the running covariance as one rank-S update per block on the
+    # matrix cores instead of the reference's elementwise recursion (parity 1e-8 instead of 1e-10)
+    e4 = fresh(2026, 2, 1e-4 * np.eye(D), t0=100, period=PERIOD, block_moments=True)
+    e4.init(None)
+    if Tw:
+        e4.run(Tw, params[:Tw], stats[:Tw], acc[:Tw])
+    dtb = timed(e4, T)
+    res["block_moments_extension"] = {"evals_per_sec_per_gpu": N * T / dtb, "seconds": dtb,
+                                      "acceptance_rate": float(acc[:T].float().mean().item())}
+    e4.close()
+    return res
 
 
 if __name__ == "__main__":

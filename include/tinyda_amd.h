@@ -138,7 +138,9 @@ typedef struct tda_dreamz_params {
  *   accepted[ r * n_chains + c]                  1 if the proposal of that step was accepted */
 typedef struct tda_outputs {
   uint32_t struct_size;
-  uint32_t reserved;
+  uint32_t rows;     /* capacity of every non-NULL buffer below, in records (rows of n_chains entries).  run() returns
+                      * TDA_ERR_INVALID before launching anything when the call would produce more records for this level
+                      * than `rows` (it never writes past a caller's buffer); 0 is only valid when all three pointers are NULL */
   double* params;
   double* stats;
   uint8_t* accepted;

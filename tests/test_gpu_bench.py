@@ -1,0 +1,146 @@
+"""bench.py as the driver runs it (fresh subprocess, small arguments), its self-launching multi-rank path rehearsed on one GPU,
+and the record-buffer capacity contract of tda_engine_run (a short buffer is an error code, never an out-of-bounds write)."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_bench(argv, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=timeout)
+    assert r.returncode == 0, "bench.py %s failed (rc %d):\n%s\n%s" % (argv, r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "expected ONE JSON line, got %d" % len(lines)
+    return json.loads(lines[0])
+
+
+def test_bench_with_the_drivers_arguments():
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` (round 1 died here with a GPU memory fault)"""
+    out = _run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5"])
+    assert out["n_gpus"] == 1 and out["steps"] == 20 and out["warmup"] == 5
+    assert out["unit"] == "evals/s" and out["dtype"] == "f64" and out["vs_baseline"] is None and out["scaling"] == "weak"
+    assert "configs[1]" in out["config"]["workload"]
+    per_step = out["config"]["mh_iterations_per_step"] * out["config"]["chains_per_gpu"]
+    np.testing.assert_allclose(out["value"], per_step / (out["ms_per_step"] * 1e-3), rtol=1e-9)
+    assert out["value"] > 5e7  # north_star's per-GPU figure is 4.75e7
+    rf = out["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and 0.2 < rf["frac"] < 1.0
+    np.testing.assert_allclose(rf["frac"], rf["achieved"] / rf["peak"], rtol=1e-9)
+    assert 0.0 < rf["whole_pipeline_frac"] <= rf["frac"]
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    assert "roofline_hbm_step_synchronous" not in out
+    assert "ess" in out and "max_rhat" in out["ess"], out.get("ess_error")
+    if out["ess"]["valid"]:
+        assert out["ess_per_sec"] > 0 and out["ess"]["max_rhat"] < 1.05
+    else:
+        assert out["ess_per_sec"] is None
+
+
+@pytest.mark.parametrize("argv", [["--steps", "1", "--warmup", "0"], ["--steps", "2", "--warmup", "7"]])
+def test_bench_odd_small_arguments(argv):
+    """warm-up longer than the timed run, no warm-up at all: every run() stays inside its buffers"""
+    out = _run_bench(argv + ["--chains", "512", "--pilot", "200", "--burnin", "300", "--ess-iterations", "0", "--no-cpu-baseline"])
+    assert out["steps"] == int(argv[1]) and out["value"] > 0 and "roofline" in out
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` from a bare shell: two ranks on this one GPU (gloo rehearsal of the RCCL path)"""
+    env = {"TINYDA_BENCH_ONE_GPU": "1"}
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    small = ["--steps", "3", "--warmup", "1", "--chains", "1024", "--pilot", "200", "--burnin", "500", "--ess-iterations", "0", "--no-cpu-baseline"]
+    two = _run_bench(["--gpus", "2"] + small, env)
+    assert two["n_gpus"] == 2 and two["config"]["chains_per_gpu"] == 1024 and two["value"] > 0
+    one = _run_bench(["--gpus", "1"] + small)
+    assert one["n_gpus"] == 1
+    # the two ranks share one GPU here, so the pair cannot be faster than twice a single run nor much slower than one
+    assert 0.4 * one["value"] < two["value"] < 2.2 * one["value"]
+
+
+def _small_engine(eng_mod, N=32, d=8, m=16, n_levels=1):
+    rng = np.random.default_rng(3)
+    e = eng_mod.Engine(N, d, seed=5, n_levels=n_levels)
+    e.set_prior(np.zeros(d), np.eye(d))
+    for k in range(n_levels):
+        A = rng.standard_normal((m * (k + 1), d)) / 3
+        e.set_level(k, A, rng.standard_normal(m * (k + 1)), 0, 0.5)
+    e.set_proposal(2, 0.05 * np.eye(d), t0=10, period=10)
+    if n_levels > 1:
+        e.set_subchains([3] * (n_levels - 1))
+    e.init(np.zeros((N, d)))
+    return e
+
+
+def test_short_record_buffers_are_refused():
+    import torch
+
+    from tinyda_amd import _lib, engine
+
+    N, d = 32, 8
+    e = _small_engine(engine, N, d)
+    dev = torch.device("cuda", 0)
+    p = torch.zeros((20, N, d), dtype=torch.float64, device=dev)
+    s = torch.zeros((20, N, 3), dtype=torch.float64, device=dev)
+    a = torch.zeros((20, N), dtype=torch.uint8, device=dev)
+    th0, st0 = e.current()
+    # the round-1 bench bug: a slice that silently stays 20 rows, 100 iterations requested
+    with pytest.raises(ValueError, match="holds 20 records"):
+        e.run(100, p[:100], s[:100], a[:100])
+    with pytest.raises(ValueError, match="float64"):
+        e.run(10, p.float(), s, a)
+    with pytest.raises(ValueError, match="shape"):
+        e.run(10, p[:, :, :4].contiguous(), s, a)
+    with pytest.raises(ValueError, match="holds 5 records"):
+        e.run(10, None, np.zeros((5, N, 3)), None)
+    # straight through the C-ABI: rows too small, and rows overstated against the real device allocation
+    lib = e.lib
+    out = _lib.tda_outputs(C.sizeof(_lib.tda_outputs), 20, C.c_void_p(p.data_ptr()), C.c_void_p(s.data_ptr()), C.c_void_p(a.data_ptr()))
+    assert lib.tda_engine_run(e.h, 21, C.byref(out)) == _lib.TDA_ERR_INVALID
+    assert b"rows" in lib.tda_last_error()
+    out0 = _lib.tda_outputs(C.sizeof(_lib.tda_outputs), 0, C.c_void_p(p.data_ptr()), None, None)
+    assert lib.tda_engine_run(e.h, 1, C.byref(out0)) == _lib.TDA_ERR_INVALID
+    raw = torch.cuda.caching_allocator_alloc(4096, 0)
+    try:
+        lie = _lib.tda_outputs(C.sizeof(_lib.tda_outputs), 1000000, C.c_void_p(raw), None, None)
+        assert lib.tda_engine_run(e.h, 1000000, C.byref(lie)) == _lib.TDA_ERR_INVALID
+        assert b"allocation" in lib.tda_last_error()
+    finally:
+        torch.cuda.caching_allocator_delete(raw)
+    # nothing ran: the chains are where they were, and a correct call still works
+    th1, st1 = e.current()
+    assert np.array_equal(th0, th1) and np.array_equal(st0, st1)
+    e.run(20, p, s, a)
+    assert a.sum().item() > 0
+    e.close()
+
+
+def test_short_multilevel_buffers_are_refused():
+    import torch
+
+    from tinyda_amd import engine
+
+    N, d = 32, 8
+    e = _small_engine(engine, N, d, n_levels=2)
+    dev = torch.device("cuda", 0)
+
+    def bufs(rows):
+        return (torch.zeros((rows, N, d), dtype=torch.float64, device=dev), torch.zeros((rows, N, 3), dtype=torch.float64, device=dev),
+                torch.zeros((rows, N), dtype=torch.uint8, device=dev))
+
+    assert e.rows_per_level(10) == [30, 10]
+    with pytest.raises(ValueError, match="level 0 holds 10 records"):
+        e.run_levels(10, [bufs(10), bufs(10)])  # the coarse level needs 30 rows
+    e.run_levels(10, [bufs(30), bufs(10)])
+    e.close()

@@ -2019,6 +2019,33 @@ int tda_engine_set_export(tda_engine* e, double* z, double* u, int64_t n_steps) 
   return TDA_OK;
 }
 
+
+// A caller's record buffers must hold `need` records of this level (tda_outputs.rows states the capacity); for device
+// pointers the extent of the underlying allocation is checked as well, so a short buffer is an error code, never a fault.
+static int check_out_capacity(const tda_outputs* o, int level, int64_t need, int64_t N, int d) {
+  if (!o || (!o->params && !o->stats && !o->accepted)) return TDA_OK;
+  if ((int64_t)o->rows < need)
+    return fail(TDA_ERR_INVALID, "tda_outputs[%d].rows = %u but this run() produces %lld records for that level", level, o->rows,
+                (long long)need);
+  const void* ptr[3] = {o->params, o->stats, o->accepted};
+  const size_t bytes[3] = {(size_t)need * N * d * sizeof(double), (size_t)need * N * 3 * sizeof(double), (size_t)need * N};
+  static const char* const nm[3] = {"params", "stats", "accepted"};
+  for (int i = 0; i < 3; ++i) {
+    if (!ptr[i] || !is_device_ptr(ptr[i])) continue;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ptr[i]) != hipSuccess) {
+      (void)hipGetLastError();
+      continue;
+    }
+    const size_t room = size - (size_t)((const char*)ptr[i] - (const char*)base);
+    if (room < bytes[i])
+      return fail(TDA_ERR_INVALID, "tda_outputs[%d].%s: device allocation has %zu bytes after the pointer, %zu needed", level, nm[i],
+                  room, bytes[i]);
+  }
+  return TDA_OK;
+}
+
 static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs);
 static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out);
 
@@ -2033,6 +2060,7 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     return fail(TDA_ERR_INVALID, "replay buffer holds %lld steps, %lld requested", (long long)(e->rep_steps - e->rep_pos), (long long)n_iter);
   if (e->exp_steps && e->exp_pos + n_iter > e->exp_steps)
     return fail(TDA_ERR_INVALID, "export buffer too small");
+  if (int crc = check_out_capacity(out, 0, n_iter, e->N, e->d)) return crc;
 
   const int d = e->d;
   const int64_t N = e->N, NP = e->NP;
@@ -2672,6 +2700,9 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
   mult[nl - 1] = 1;
   for (int k = nl - 2; k >= 0; --k) mult[k] = mult[k + 1] * e->sl[k];
   const int64_t total_base = n_fine * mult[0];
+  if (outs)
+    for (int k = 0; k < nl; ++k)
+      if (int crc = check_out_capacity(outs + k, k, n_fine * mult[k], N, d)) return crc;
   if (e->rep_steps && e->rep_pos + total_base > e->rep_steps) return fail(TDA_ERR_INVALID, "replay buffer too short");
   if (e->exp_steps && e->exp_pos + total_base > e->exp_steps) return fail(TDA_ERR_INVALID, "export buffer too small");
   for (int k = 1; k < nl; ++k)
@@ -3148,6 +3179,7 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
   const bool sh = e->dz.shared != 0, adaptive = e->dz.adaptive != 0;
   const int period = e->dz.period;
   if (e->rp_steps && e->rp_pos + n_iter > e->rp_steps) return fail(TDA_ERR_INVALID, "DREAMZ replay buffer too short");
+  if (int crc = check_out_capacity(out, 0, n_iter, N, d)) return crc;
   if (e->exp_steps && e->exp_pos + n_iter > e->exp_steps) return fail(TDA_ERR_INVALID, "export buffer too small");
   if (!sh && e->arch_rows + n_iter > e->arch_cap) return fail(TDA_ERR_INVALID, "archive capacity (%lld rows) exceeded", (long long)e->arch_cap);
   if (sh && e->auto_append && e->arch_rows + n_iter * N > e->arch_cap)

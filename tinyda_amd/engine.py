@@ -263,8 +263,27 @@ class Engine:
         return z, u
 
     # -- running ------------------------------------------------------------------------
+    def _outputs(self, level, need, params, stats, accepted):
+        """tda_outputs for one level after checking every record buffer: dtype, trailing shape and at least `need` rows
+        (the library checks `rows` again and the extent of device allocations; a short buffer is an error, not a fault)"""
+        want = (("params", params, (self.n_chains, self.dim), "float64"), ("stats", stats, (self.n_chains, 3), "float64"),
+                ("accepted", accepted, (self.n_chains,), "uint8"))
+        rows = None
+        for name, a, tail, dt in want:
+            if a is None:
+                continue
+            shape = tuple(int(v) for v in a.shape)
+            if str(a.dtype).replace("torch.", "") != dt:
+                raise ValueError("%s buffer of level %d must be %s, got %s" % (name, level, dt, a.dtype))
+            if len(shape) != len(tail) + 1 or shape[1:] != tail:
+                raise ValueError("%s buffer of level %d must have shape (rows, %s), got %s" % (name, level, ", ".join(map(str, tail)), shape))
+            if shape[0] < need:
+                raise ValueError("%s buffer of level %d holds %d records, this run produces %d" % (name, level, shape[0], need))
+            rows = shape[0] if rows is None else min(rows, shape[0])
+        return _lib.tda_outputs(C.sizeof(_lib.tda_outputs), min(rows or 0, 0xFFFFFFFF), _ptr(params), _ptr(stats), _ptr(accepted))
+
     def run(self, n_iterations, params=None, stats=None, accepted=None, sync=True):
-        out = _lib.tda_outputs(C.sizeof(_lib.tda_outputs), 0, _ptr(params), _ptr(stats), _ptr(accepted))
+        out = self._outputs(0, int(n_iterations), params, stats, accepted)
         self._check_run(self.lib.tda_engine_run(self.h, n_iterations, C.byref(out)))
         if sync:
             self.sync()
@@ -279,9 +298,10 @@ class Engine:
     def run_levels(self, n_iterations, outputs=None, sync=True):
         """Multi-level run.  outputs: list (coarsest first) of (params, stats, accepted) arrays / tensors or None."""
         arr = (_lib.tda_outputs * self.n_levels)()
+        need = self.rows_per_level(int(n_iterations))
         for k in range(self.n_levels):
             p, s_, a = outputs[k] if outputs and outputs[k] is not None else (None, None, None)
-            arr[k] = _lib.tda_outputs(C.sizeof(_lib.tda_outputs), 0, _ptr(p), _ptr(s_), _ptr(a))
+            arr[k] = self._outputs(k, need[k], p, s_, a)
         self._check_run(self.lib.tda_engine_run(self.h, n_iterations, arr))
         if sync:
             self.sync()
