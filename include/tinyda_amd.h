@@ -314,6 +314,11 @@ int tda_engine_evaluate(tda_engine* e, int level, const double* theta, int64_t n
 /* Device RNG probe: fills z [n_chains][dim] and u [n_chains] for the given step from streams 0 / 1. HOST. */
 int tda_engine_rng_probe(tda_engine* e, int64_t step, double* z, double* u);
 
+/* Raw generator probe: one Philox4x32-10 block computed ON THE DEVICE (device >= 0) or by the same source compiled for the
+ * host (device = -1): out[4] = philox4x32_10(counter[4], key[2]).  Ties the engine's integer stream to the published
+ * algorithm: tests compare it with the Random123 known-answer vectors (kat_vectors, philox4x32 10 rounds).  HOST pointers. */
+int tda_rng_philox(int device, const uint32_t* counter, const uint32_t* key, uint32_t* out);
+
 int tda_engine_set_profiling(tda_engine* e, int enable);
 int tda_engine_get_profile(tda_engine* e, tda_profile* p);
 

@@ -137,6 +137,7 @@ SYMBOLS = {
     "tda_engine_get_flags": (C.c_int, [_P, _P]),
     "tda_engine_evaluate": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P]),
     "tda_engine_rng_probe": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "tda_rng_philox": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "tda_engine_set_profiling": (C.c_int, [_P, C.c_int]),
     "tda_engine_get_profile": (C.c_int, [_P, C.POINTER(tda_profile)]),
 }

@@ -492,7 +492,7 @@ void fill_ext_args(tda_engine* e, const Level& lv, ExtArgs& xa) {
 
 // AdaptiveGaussianLogLike on a callback / source-defined level: host and device copies of Sigma_e and the data vector in
 // the error-model layout (row stride 64 / 128), as tda_engine_set_level keeps them for linear levels
-int ext_level_adaptive(tda_engine* e, Level& lv, int m, const double* data, const double* cov) {
+int ext_level_adaptive(tda_engine* /*e*/, Level& lv, int m, const double* data, const double* cov) {
   if (m > AEM_MP_MAX) return fail(TDA_ERR_UNSUPPORTED, "AdaptiveGaussianLogLike on the device is limited to m <= %d observations", (int)AEM_MP_MAX);
   std::vector<double> Lc;
   if (!cholesky_host(cov, m, Lc)) return fail(TDA_ERR_NUMERIC, "noise covariance is not positive definite");
@@ -514,7 +514,7 @@ int ext_level_adaptive(tda_engine* e, Level& lv, int m, const double* data, cons
 }
 
 // DefaultGaussianLogLike (dense data covariance) on a callback / source-defined level: Sigma^-1 through the Cholesky factor
-int ext_level_dense(tda_engine* e, Level& lv, int m, const double* cov) {
+int ext_level_dense(tda_engine* /*e*/, Level& lv, int m, const double* cov) {
   if (m > 2048) return fail(TDA_ERR_UNSUPPORTED, "dense noise on callback / source-defined levels: m <= 2048");
   std::vector<double> Lc, W, P((size_t)m * m, 0.0);
   if (!cholesky_host(cov, m, Lc)) return fail(TDA_ERR_NUMERIC, "noise covariance is not positive definite");
@@ -3533,6 +3533,41 @@ int tda_engine_rng_probe(tda_engine* e, int64_t step, double* z, double* u) {
   HIP_TRY(hipStreamSynchronize(e->stream));
   HIP_TRY(hipMemcpy(z, zd.p, (size_t)N * d * sizeof(double), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(u, ud.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+  return TDA_OK;
+}
+
+namespace {
+__global__ void k_philox_probe(const uint32_t* __restrict__ in, uint32_t* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    const tda::u32x4 r = tda::philox4x32_10(tda::u32x4{in[0], in[1], in[2], in[3]}, in[4], in[5]);
+    out[0] = r.x;
+    out[1] = r.y;
+    out[2] = r.z;
+    out[3] = r.w;
+  }
+}
+}  // namespace
+
+int tda_rng_philox(int device, const uint32_t* counter, const uint32_t* key, uint32_t* out) {
+  if (!counter || !key || !out) return fail(TDA_ERR_INVALID, "null argument");
+  if (device < 0) {  // the same header compiled for the host
+    const tda::u32x4 r = tda::philox4x32_10(tda::u32x4{counter[0], counter[1], counter[2], counter[3]}, key[0], key[1]);
+    out[0] = r.x;
+    out[1] = r.y;
+    out[2] = r.z;
+    out[3] = r.w;
+    return TDA_OK;
+  }
+  HIP_TRY(hipSetDevice(device));
+  DevBuf<uint32_t> in, res;
+  int rc;
+  std::vector<uint32_t> h = {counter[0], counter[1], counter[2], counter[3], key[0], key[1]};
+  if ((rc = in.upload(h))) return rc;
+  if ((rc = res.alloc(4))) return rc;
+  hipLaunchKernelGGL(k_philox_probe, dim3(1), dim3(64), 0, nullptr, in.p, res.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, res.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return TDA_OK;
 }
 

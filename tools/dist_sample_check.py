@@ -1,6 +1,6 @@
 """Rehearsal of sample(distributed=True) on a one-GPU box: TINYDA_BENCH_ONE_GPU=1 python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tools/dist_sample_check.py"""
 import sys, numpy as np, scipy.stats as st
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tinyda_amd as tda
 rng = np.random.default_rng(0)
 A = rng.standard_normal((12, 6)) / 2; y = rng.standard_normal(12)
