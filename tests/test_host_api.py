@@ -223,6 +223,43 @@ def test_multilevel_plan_for_plain_callables_and_external_models():
     assert api._device_plan(mixed, tda.CrankNicolson(scaling=0.1)) is not None
     assert api._device_plan(mixed, tda.DREAMZ(10)) is None  # DREAM(Z) below a hierarchy is not lowered
     qoi = [tda.Posterior(prior, tda.GaussianLogLike(y, cov), lambda th: (A @ th, th.sum())), wrapped[1]]
-    w2 = api._wrap_opaque_models(qoi)
+    w2 = api._wrap_opaque_models(qoi)  # (output, qoi) models (posterior.py:97-101): the engine takes the output ...
+    np.testing.assert_allclose(w2[0].model.batch(np.ones((2, d))), np.tile(A @ np.ones(d), (2, 1)))
+    out, q = w2[0].model(np.ones(d))  # ... and one parameter vector still gives the user's own return value
+    assert q == d and out.shape == (m,)
+    from tinyda_amd.records import DeviceChain
+
+    ln = DeviceChain(np.ones((2, d)), np.zeros((2, 3)), np.ones(2, dtype=np.uint8), w2[0].model)[1]
+    assert ln.qoi == d and ln.model_output.shape == (m,)
+    bad = api._wrap_opaque_models([tda.Posterior(prior, tda.GaussianLogLike(y, cov), lambda th: [1.0] * m), wrapped[1]])
     with pytest.raises(TypeError):
-        w2[0].model.batch(np.zeros((2, d)))
+        bad[0].model.batch(np.zeros((2, d)))
+
+
+def test_host_hierarchy_fallback_runs_the_references_mlda_notebook_shape():
+    """examples/Multilevel Delayed Acceptance.ipynb cells 4-23 in miniature: three levels of an opaque model returning
+    (output, qoi), DREAMZ(Z_method='lhs', adaptive=True) at the base, one subchain length for all levels, an explicit start."""
+    d = 3
+    rng = np.random.default_rng(5)
+    truth = np.array([0.3, -0.2, 0.5])
+    prior = stats.multivariate_normal(np.zeros(d), np.eye(d))
+    posts = []
+    for k, m in enumerate((4, 6, 9)):
+        B = rng.standard_normal((m, d))
+        y = np.tanh(B @ truth) + 0.05 * rng.standard_normal(m)
+        posts.append(tda.Posterior(prior, tda.GaussianLogLike(y, 0.05 ** 2 * np.eye(m)), lambda th, B=B: (np.tanh(B @ th), True)))
+    np.random.seed(3)
+    res = tda.sample(posts, tda.DREAMZ(M0=30, delta=1, Z_method="lhs", adaptive=True, period=5), iterations=12, n_chains=2,
+                     initial_parameters=truth, subchain_length=2, backend="host")
+    assert res["sampler"] == "MLDA" and res["levels"] == 3 and res["iterations"] == 13 and res["backend"] == "host"
+    assert res["subchain_lengths"] == [2, 2]
+    assert len(res["chain_l2_0"]) == 13 and len(res["chain_l1_1"]) == 24 and len(res["chain_l0_0"]) == 48
+    assert all(ln.qoi is True for ln in res["chain_l2_0"])
+    fine = tda.get_samples(res, level=2)
+    assert fine["chain_0"].shape == (13, d)
+    # Delayed Acceptance with the state-dependent error model, MALA-free non-symmetric proposal (pCN): host protocol
+    two = [tda.Posterior(prior, tda.AdaptiveGaussianLogLike(posts[1].likelihood.data, 0.05 ** 2 * np.eye(6)), lambda th: np.tanh(th.sum()) * np.ones(6)),
+           tda.Posterior(prior, tda.GaussianLogLike(posts[1].likelihood.data, 0.05 ** 2 * np.eye(6)), lambda th: np.tanh(th.sum()) * np.ones(6) + 0.01)]
+    res2 = tda.sample(two, tda.CrankNicolson(scaling=0.2), 10, n_chains=1, subchain_length=3, adaptive_error_model="state-dependent",
+                      store_coarse_chain=False, backend="host")
+    assert res2["sampler"] == "DA" and res2["chain_coarse_0"] is None and len(res2["chain_fine_0"]) == 11

@@ -1,0 +1,153 @@
+"""tinyda_amd.hostloop.HierarchyChain (the host Delayed-Acceptance / MLDA driver for what the device engine does not lower)
+replays traces recorded from tinyDA's DAChain / MLDAChain: the reference's variates are fed in the reference's order, so
+accept masks must be equal and log-densities agree to 1e-10 at every level."""
+import copy
+
+import numpy as np
+import pytest
+import scipy.stats as stats
+
+import tinyda_amd as tda
+from tinyda_amd.hostloop import HierarchyChain
+
+
+class _Fed(HierarchyChain):
+    """a HierarchyChain whose uniforms / promoted indices come from per-level queues and whose proposal normals come from z"""
+
+    def feed(self, z, u_levels, ridx=None):
+        self._z, self._iz = z, 0
+        self._u = [list(u[~np.isnan(u)]) for u in u_levels]
+        self._r = None if ridx is None else [int(v) for v in ridx[~np.isnan(ridx)]]
+
+    def _uniform(self, level):
+        return self._u[level].pop(0)
+
+    def _promoted_index(self, length):
+        return self._r.pop(0)
+
+
+class _Normals:
+    def __init__(self, chain):
+        self.chain = chain
+
+    def __enter__(self):
+        self.saved = np.random.standard_normal
+        np.random.standard_normal = self._next
+        return self
+
+    def __exit__(self, *a):
+        np.random.standard_normal = self.saved
+
+    def _next(self, n):
+        self.chain._iz += 1
+        return self.chain._z[self.chain._iz - 1]
+
+
+def _proposal(g):
+    kind = str(g["prop_kind"])
+    get = lambda k, default=None: (g["prop_" + k].item() if g["prop_" + k].ndim == 0 else g["prop_" + k]) if "prop_" + k in g.files else default
+    if kind == "pcn":
+        return tda.CrankNicolson(scaling=float(get("scaling")), adaptive=bool(get("adaptive", False)), gamma=float(get("gamma", 1.01)),
+                                 period=int(get("period", 100)))
+    if kind == "grw":
+        return tda.GaussianRandomWalk(get("C"), scaling=float(get("scaling", 1.0)), adaptive=bool(get("adaptive", False)),
+                                      gamma=float(get("gamma", 1.01)), period=int(get("period", 100)))
+    return tda.AdaptiveMetropolis(get("C0"), sd=float(get("sd")), epsilon=float(get("epsilon", 1e-6)), t0=int(get("t0", 0)),
+                                  period=int(get("period", 100)), adaptive=bool(get("adaptive", False)), gamma=float(get("gamma", 1.01)))
+
+
+def _model(A, b=None):
+    return (lambda th: A @ th) if b is None else (lambda th: A @ th + b)
+
+
+def _trace(links):
+    return (np.array([ln.parameters for ln in links]), np.array([ln.prior for ln in links]), np.array([ln.likelihood for ln in links]))
+
+
+def _run(g, nl, lengths, posteriors_for_chain, aem=None, randomize=False):
+    out = []
+    for c in range(g["theta0"].shape[0]):
+        ch = _Fed.__new__(_Fed)
+        ch.feed(g["z"][c], [g["u%d" % k][c] for k in range(nl)], g["ridx"][c] if randomize else None)
+        with _Normals(ch):
+            HierarchyChain.__init__(ch, posteriors_for_chain(), _proposal(g), lengths, initial_parameters=g["theta0"][c].copy(),
+                                    adaptive_error_model=aem, randomize_subchain_length=randomize)
+            ch.sample(g["th%d" % (nl - 1)].shape[1] - 1)
+        assert all(len(q) == 0 for q in ch._u), "uniforms left over: the driver drew fewer than the reference"
+        assert ch._iz == g["z"].shape[1]
+        out.append(ch)
+    return out
+
+
+def _check(ch, g, c, nl, with_like=True):
+    for k in range(nl):
+        links = ch.level_chain(k)
+        th, lp, ll = _trace(links)
+        took = np.array([t for t, own in zip(ch.rungs[k].took, ch.rungs[k].own) if own] if k < nl - 1 else ch.rungs[k].took, dtype=np.uint8)
+        assert np.array_equal(took, g["acc%d" % k][c]), "level %d accept flags differ" % k
+        np.testing.assert_allclose(th, g["th%d" % k][c], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(lp, g["lp%d" % k][c], rtol=1e-10)
+        if with_like or k == nl - 1:
+            np.testing.assert_allclose(ll, g["ll%d" % k][c], rtol=1e-10)
+
+
+@pytest.mark.parametrize("name", ["g4_da_pcn", "g4_da_grw_adaptive", "g4_da_am_random", "g4_da_pcn_adaptive_c3shape"])
+def test_delayed_acceptance_replay(golden, name):
+    g = golden(name)
+    prior = stats.multivariate_normal(g["prior_mean"], g["prior_cov"])
+    var = float(g["noise_var"])
+
+    def posts():
+        return [tda.Posterior(prior, tda.GaussianLogLike(g["y%d" % k], var * np.eye(len(g["y%d" % k]))), _model(g["A%d" % k])) for k in range(2)]
+
+    chains = _run(g, 2, [int(g["subchain_length"])], posts, randomize=bool(g["randomize"]))
+    for c, ch in enumerate(chains):
+        _check(ch, g, c, 2)
+        np.testing.assert_allclose(ch.proposal.scaling, g["scaling"][c], rtol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["g5_mlda_am", "g5_mlda_grw_adaptive", "g5_mlda_4level"])
+def test_mlda_replay(golden, name):
+    g = golden(name)
+    nl = int(g["n_levels"])
+    prior = stats.multivariate_normal(g["prior_mean"], g["prior_cov"])
+    var = float(g["noise_var"])
+
+    def posts():
+        return [tda.Posterior(prior, tda.GaussianLogLike(g["y%d" % k], var * np.eye(len(g["y%d" % k]))), _model(g["A%d" % k])) for k in range(nl)]
+
+    chains = _run(g, nl, [int(v) for v in g["subchain_lengths"]], posts)
+    for c, ch in enumerate(chains):
+        _check(ch, g, c, nl)
+        np.testing.assert_allclose(ch.proposal.scaling, g["scaling"][c], rtol=1e-12)
+
+
+def _aem_posts(g, nl):
+    prior = stats.multivariate_normal(g["prior_mean"], g["prior_cov"])
+    var = float(g["noise_var"])
+    m = g["A0"].shape[0]
+
+    def posts():
+        out = []
+        for k in range(nl):
+            like = tda.AdaptiveGaussianLogLike(g["y%d" % k], var * np.eye(m)) if k < nl - 1 else tda.GaussianLogLike(g["y%d" % k], var * np.eye(m))
+            out.append(tda.Posterior(prior, like, _model(g["A%d" % k], g["b%d" % k])))
+        return out
+
+    return posts
+
+
+@pytest.mark.parametrize("name", ["g8_da_aem_indep", "g8_da_aem_dep", "g8_da_aem_dep_pcn"])
+def test_delayed_acceptance_with_error_model_replay(golden, name):
+    g = golden(name)
+    chains = _run(g, 2, [int(g["subchain_length"])], _aem_posts(g, 2), aem=str(g["aem"]))
+    for c, ch in enumerate(chains):
+        _check(ch, g, c, 2, with_like=False)  # coarse likelihoods are recorded before later update_link calls replace them
+
+
+def test_mlda_with_error_model_replay(golden):
+    g = golden("g8_mlda_aem")
+    nl = int(g["n_levels"])
+    chains = _run(g, nl, [int(v) for v in g["subchain_lengths"]], _aem_posts(g, nl), aem="state-independent")
+    for c, ch in enumerate(chains):
+        _check(ch, g, c, nl, with_like=False)

@@ -11,7 +11,7 @@ import numpy as np
 import scipy.stats as stats
 
 from . import _lib
-from .hostloop import Chain
+from .hostloop import Chain, HierarchyChain
 from .proposals import (DREAM, DREAMZ, MALA, AdaptiveMetropolis, CrankNicolson, GaussianRandomWalk, IndependenceSampler,
                         OperatorWeightedCrankNicolson)
 from .records import DeviceChain
@@ -78,12 +78,61 @@ def _device_plan(posteriors, proposal):
     for low in lows[1:]:  # one prior for the hierarchy (every tinyDA example shares it across levels)
         if not (np.array_equal(low["prior_mean"], lows[0]["prior_mean"]) and np.array_equal(low["prior_cov"], lows[0]["prior_cov"])):
             return None
-    return lows, proposal._lowering()
+    prop = proposal._lowering()
+    if prop is None:  # an option of a lowerable proposal class that the engine does not know: host protocol under 'auto'
+        return None
+    return lows, prop
+
+
+_TAG_THETA0, _TAG_ARCHIVE = 0x7468, 0x5a30  # sub-streams of the host generators below
+
+
+def _host_rng(seed, tag, gid=None):
+    """NumPy generator for what the HOST has to draw for a device run (JointPrior starts, initial DREAM(Z) archives): keyed
+    by (seed, purpose, global chain id), so a seeded run is reproducible and does not depend on how chains are sharded
+    over ranks; a shared archive (gid None) is keyed by (seed, purpose) alone, so every rank holds the same rows."""
+    return np.random.default_rng([int(seed) & 0xFFFFFFFFFFFFFFFF, tag] + ([] if gid is None else [int(gid)]))
+
+
+def _joint_rvs(joint, n, rng):
+    """n draws of a JointPrior of scalar norm / uniform components (distributions.py:58-78), vectorised: [n, dim]"""
+    kinds, loc, scale = joint
+    u = rng.random((n, kinds.shape[0]))
+    z = rng.standard_normal((n, kinds.shape[0]))
+    return np.where(kinds == 0, loc + scale * z, loc + scale * u)
+
+
+def _initial_archive(prop, low, n_chains, chain_offset, seed):
+    """Initial DREAM(Z) archive(s) the host must draw (DREAMZ.setup_proposal, proposal.py:744-788), or None when the engine
+    draws them itself (Gaussian prior, Z_method='random': RNG stream 2).  Per-chain archives [n_chains][M0][d], a shared one
+    [M0][d].  'lhs': scipy's Latin hypercube mapped through the prior's component quantiles -- for a multivariate normal
+    through independent normals with the prior's means and variances, as the reference does (:766-776)."""
+    from scipy.stats import norm, qmc
+
+    M0, shared, lhs = prop["M0"], prop["shared"], prop.get("Z_method", "random") == "lhs"
+    joint = low.get("prior_joint")
+    if not lhs and joint is None:
+        return None
+    d = low["prior_mean"].shape[0]
+
+    def one(rng):
+        if lhs:
+            u = qmc.LatinHypercube(d=d, seed=rng).random(n=M0)
+            if joint is None:
+                return norm(loc=low["prior_mean"], scale=np.sqrt(np.diag(low["prior_cov"]))).ppf(u)
+            kinds, loc, scale = joint
+            return np.where(kinds == 0, norm(loc=loc, scale=scale).ppf(u), loc + scale * u)
+        return _joint_rvs(joint, M0, rng)
+
+    if shared:
+        return one(_host_rng(seed, _TAG_ARCHIVE))
+    return np.stack([one(_host_rng(seed, _TAG_ARCHIVE, chain_offset + c)) for c in range(n_chains)])
 
 
 def _wrap_opaque_models(posteriors):
-    """Posteriors whose model is a plain callable -> copies with a BatchedModel looping over the chains; None if a model
-    does not return a plain 1-D array (e.g. the reference's (output, qoi) tuples) or the likelihood has no data vector."""
+    """Posteriors whose model is a plain callable -> copies with a BatchedModel looping over the chains (models returning the
+    reference's (output, qoi) tuples included: the engine takes the output, the quantity of interest is produced again when a
+    Link of the result is materialised); None if a likelihood has no data vector."""
     from .models import BatchedModel, DeviceModel, LinearModel, Rosenbrock
     from .target import Posterior
 
@@ -102,12 +151,16 @@ def _wrap_opaque_models(posteriors):
             res = np.empty((thetas.shape[0], m))
             for i in range(thetas.shape[0]):
                 f = fn(thetas[i])
-                if isinstance(f, tuple):
-                    raise TypeError("models returning (output, qoi) are not lowered to the device engine")
+                if isinstance(f, tuple):  # posterior.py:97-101
+                    f = f[0]
+                if not isinstance(f, np.ndarray):
+                    raise TypeError("Model output must be a numpy array!")
                 res[i] = np.asarray(f, dtype=np.float64).reshape(m)
             return res
 
-        out.append(Posterior(post.prior, post.likelihood, BatchedModel(batch, m)))
+        bm = BatchedModel(batch, m)
+        bm.single = fn  # one parameter vector -> the user's own return value (output or (output, qoi))
+        out.append(Posterior(post.prior, post.likelihood, bm))
     return out
 
 
@@ -201,8 +254,8 @@ def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None
                                          subchain_lengths, randomize_subchain_length, store_coarse_chain, seed, device,
                                          chain_offset, adaptive_error_model)
     if n_levels > 1:
-        raise NotImplementedError("Delayed Acceptance / MLDA with opaque Python forward models has no host driver in "
-                                  "tinyda_amd; declare the models as tinyda_amd.LinearModel")
+        return _sample_host_multilevel(posteriors, proposal, iterations, n_chains, initial_parameters, subchain_length,
+                                       subchain_lengths, randomize_subchain_length, adaptive_error_model, store_coarse_chain)
     return _sample_host(posteriors[0], proposal, iterations, n_chains, initial_parameters)
 
 
@@ -220,6 +273,44 @@ def _sample_host(posterior, proposal, iterations, n_chains, initial_parameters):
     return result
 
 
+def _sample_host_multilevel(posteriors, proposal, iterations, n_chains, initial_parameters, subchain_length, subchain_lengths,
+                            randomize, error_model, store_coarse_chain):
+    """Hierarchies the engine does not lower (models returning (output, qoi), proposals outside the engine's set below a
+    hierarchy, more than MAX_LEVELS levels, more than 64 parameters, per-level priors): the reference's protocol on the host,
+    one chain after the other (sampler.py:335-368, :441-473), with the reference's result layout (:406-439, :510-547).
+    Every chain gets its own copies of the posteriors, so that the error model of one chain does not leak into the next
+    (the reference's sequential sampler shares them: SURVEY.md Appendix A.14, not reproduced)."""
+    nl = len(posteriors)
+    if initial_parameters is None:  # sampler.py:209
+        initial_parameters = [posteriors[0].prior.rvs() for _ in range(n_chains)]
+    chains = []
+    for i in range(n_chains):
+        print("Sampling chain {}/{}".format(i + 1, n_chains))
+        posts = list(posteriors)
+        if error_model is not None:  # the bias lives in the likelihood: that is what each chain needs for itself
+            posts = [copy.copy(p) for p in posteriors]
+            for p in posts:
+                p.likelihood = copy.deepcopy(p.likelihood)
+        ch = HierarchyChain(posts, copy.deepcopy(proposal), subchain_lengths, initial_parameters[i], error_model,
+                            store_coarse_chain, randomize)
+        ch.sample(iterations)
+        chains.append(ch)
+    if nl == 2:
+        result = {"sampler": "DA", "n_chains": n_chains, "iterations": iterations + 1, "subchain_length": subchain_length,
+                  "backend": "host"}
+        for i, ch in enumerate(chains):
+            result["chain_coarse_{}".format(i)] = ch.level_chain(0)
+        for i, ch in enumerate(chains):
+            result["chain_fine_{}".format(i)] = ch.level_chain(1)
+        return result
+    result = {"sampler": "MLDA", "n_chains": n_chains, "iterations": iterations + 1, "levels": nl,
+              "subchain_lengths": subchain_lengths, "backend": "host"}
+    for k in reversed(range(nl)):
+        for i, ch in enumerate(chains):
+            result["chain_l{}_{}".format(k, i)] = ch.level_chain(k)
+    return result
+
+
 def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, seed, device, chain_offset,
                    distributed=False, total_chains=None):
     from .engine import Engine  # raises EngineError when libtinyda_hip.so is missing: no CPU fallback
@@ -234,7 +325,8 @@ def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, se
         if "prior_joint" in low:
             eng.set_prior_joint(*low["prior_joint"])
             if initial_parameters is None:  # sampler.py:209: theta0 ~ prior; uniform components are drawn on the host
-                initial_parameters = [posterior.prior.rvs() for _ in range(n_chains)]
+                initial_parameters = [_joint_rvs(low["prior_joint"], 1, _host_rng(seed, _TAG_THETA0, chain_offset + c))[0]
+                                      for c in range(n_chains)]
         else:
             eng.set_prior(low["prior_mean"], low["prior_cov"])
         if "rosenbrock" in low:
@@ -246,15 +338,10 @@ def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, se
         else:
             eng.set_level(0, low["A"], low["data"], low["noise_kind"], low["noise"], b=low["b"])
         if prop["kind"] == _lib.PROP_DREAMZ:
-            dz = {k: v for k, v in prop.items() if k != "kind"}
+            dz = {k: v for k, v in prop.items() if k not in ("kind", "Z_method")}
             rows = dz["M0"] + iterations * ((total_chains or n_chains) if dz["shared"] else 1)
             eng.set_proposal_dreamz(capacity=rows, **dz)
-            if "prior_joint" in low:  # uniform components: the initial archive is drawn on the host like theta0 (proposal.py:745-751)
-                n_arch = 1 if dz["shared"] else n_chains
-                Z0 = np.array([[np.asarray(posterior.prior.rvs(), dtype=np.float64) for _ in range(dz["M0"])] for _ in range(n_arch)])
-                eng.set_archive(Z0[0] if dz["shared"] else Z0)
-            else:
-                eng.set_archive(None)
+            eng.set_archive(_initial_archive(prop, low, n_chains, chain_offset, seed))
         else:
             eng.set_proposal(**prop)
         theta0 = None if initial_parameters is None else np.stack([np.asarray(p, float) for p in initial_parameters])
@@ -272,9 +359,10 @@ def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, se
 
             from . import distributed as tdist
 
-            dp = torch.empty((T, N, d), dtype=torch.float64, device="cuda")
-            ds = torch.empty((T, N, 3), dtype=torch.float64, device="cuda")
-            da = torch.empty((T, N), dtype=torch.uint8, device="cuda")
+            tdev = torch.device("cuda", device)
+            dp = torch.empty((T, N, d), dtype=torch.float64, device=tdev)
+            ds = torch.empty((T, N, 3), dtype=torch.float64, device=tdev)
+            da = torch.empty((T, N), dtype=torch.uint8, device=tdev)
             tdist.run_shared_dream(eng, T, 16, dp, ds, da)  # one all_gather of the new archive rows per 16 steps
             params[1:], stat[1:], acc[1:] = dp.cpu().numpy(), ds.cpu().numpy(), da.cpu().numpy()
         elif T > 0:

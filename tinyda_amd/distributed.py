@@ -113,7 +113,7 @@ def run_shared_dream(engine, n_iterations, sync_every, params=None, stats=None, 
         sl = slice(done, done + k)
         engine.run(k, None if params is None else params[sl], None if stats is None else stats[sl],
                    None if accepted is None else accepted[sl])
-        buf = torch.empty((k, engine.n_chains, engine.dim), dtype=torch.float64, device="cuda")
+        buf = torch.empty((k, engine.n_chains, engine.dim), dtype=torch.float64, device=torch.device("cuda", engine.device))
         engine.archive_take(buf)
         engine.archive_append(gather_archive_rows(buf))
         done += k
@@ -132,7 +132,7 @@ class PooledAdaptiveMetropolis:
         self.sd = min(1.0, 2.4 ** 2 / self.d) if sd is None else sd
         self.eps, self.t0, self.period = epsilon, t0, period
         self.t = 0
-        self.sums = torch.zeros(1 + self.d + self.d * self.d, dtype=torch.float64, device="cuda")
+        self.sums = torch.zeros(1 + self.d + self.d * self.d, dtype=torch.float64, device=torch.device("cuda", engine.device))
         self.C = np.asarray(C0, dtype=np.float64)
 
     def absorb(self, rows):

@@ -44,6 +44,7 @@ class Engine:
     def __init__(self, n_chains, dim, seed=0, device=0, chain_offset=0, n_levels=1, block_steps=0, stream=None):
         self.lib = _lib.load()
         self.n_chains, self.dim, self.n_levels = int(n_chains), int(dim), int(n_levels)
+        self.device = int(device)
         self.subchain_lengths = []
         cfg = _lib.tda_config(C.sizeof(_lib.tda_config), device, n_chains, chain_offset, dim, n_levels, seed,
                               stream, block_steps, 0)

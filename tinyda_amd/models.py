@@ -91,5 +91,9 @@ class BatchedModel:
         self.fn(parameters, out)
         return out
 
+    single = None  # optional one-vector form of the same model (set when a plain callable was wrapped)
+
     def __call__(self, parameters):
+        if self.single is not None:
+            return self.single(parameters)
         return self.batch(np.asarray(parameters, dtype=np.float64)[None, :])[0]

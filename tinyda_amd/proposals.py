@@ -358,9 +358,9 @@ class DREAMZ(GaussianRandomWalk):
     _shared = False
 
     def _lowering(self):
-        if self.Z_method != "random":
-            raise _lib.EngineError("only Z_method='random' is lowered to the device engine")
-        return dict(kind=_lib.PROP_DREAMZ, M0=int(self.M0), delta=int(self.delta), b=float(self.b), b_star=float(self.b_star),
+        if self.Z_method not in ("random", "lhs"):
+            return None
+        return dict(kind=_lib.PROP_DREAMZ, Z_method=self.Z_method, M0=int(self.M0), delta=int(self.delta), b=float(self.b), b_star=float(self.b_star),
                     nCR=int(self.nCR), adaptive=bool(self.adaptive), gamma=float(self.gamma), period=int(self.period),
                     shared=self._shared)
 

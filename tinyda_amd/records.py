@@ -41,4 +41,5 @@ class DeviceChain(Sequence):
             return DeviceChain(self.parameters[i], self.stats[i], self.accepted[i], self._model)
         theta = np.array(self.parameters[i])
         out = self._model(theta) if self._model is not None else None
-        return Link(theta, float(self.stats[i, 0]), out, float(self.stats[i, 1]))
+        out, qoi = out if isinstance(out, tuple) else (out, None)  # posterior.py:97-101
+        return Link(theta, float(self.stats[i, 0]), out, float(self.stats[i, 1]), qoi)
