@@ -353,20 +353,33 @@ void launch_chol(const CholArgs& a, hipStream_t st) {
 // dynamic LDS of k_aem_inverse: the 16 x 16 blocks on or below the diagonal, row stride 17
 constexpr size_t aem_inverse_lds_bytes(int nb) { return (size_t)(nb * (nb + 1) / 2) * AEM_BS * sizeof(double); }
 
+// Two levels with a small coarse model (m0 <= 256), a fixed subchain length, iso / diag noise and a diagonal prior
+// (BASELINE config 3) run on the pipelined 8-wave Delayed-Acceptance kernel; everything else (3-4 levels, error model,
+// randomised subchains, dense prior, larger coarse models) on the generic one.
+inline bool da_lean_eligible(const MLArgs& a) {
+  if (a.nlev != 2 || a.aem_on || !a.cascade || a.randomize || a.pr.kind == PRIOR_DENSE) return false;
+  if (a.lv[0].ncb > 16) return false;  // the coarse operator lives in registers: two 16-row blocks per wave
+  for (int k = 0; k < 2; ++k)
+    if (a.lv[k].noise_kind != 0 && a.lv[k].noise_kind != 1) return false;
+  static const bool off = getenv("TINYDA_DA_LEAN") && atoi(getenv("TINYDA_DA_LEAN")) == 0;  // A/B switch for measurements
+  return !off;
+}
+
 template <int DPAD>
-void launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st) {
-  // TINYDA_ML_WAVES=8 (experiment): the 8-wave tile for two levels.  Measured on C3: 3.4e8 against 4.3e8 coarse evals/s of
-  // the 4-wave tile -- at 256 registers the level state machine still spills 61 (loop invariants reloaded every step)
-  static const bool ml8 = getenv("TINYDA_ML_WAVES") && atoi(getenv("TINYDA_ML_WAVES")) == 8;
-  if (a.nlev == 2 && !a.aem_on && ml8) {
-    hipLaunchKernelGGL((k_ml_steps<DPAD, 2, 8>), dim3((unsigned)tiles), dim3(512), lds + 128 * sizeof(double), st, a);  // + two [4][16] slabs
-    return;
+int launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st) {
+  if (da_lean_eligible(a)) {
+    const size_t lds8 = (size_t)da_lds_doubles<DPAD>(a.lds_total) * sizeof(double);
+    if (lds8 > 64 * 1024)
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_da_steps<DPAD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+    hipLaunchKernelGGL((k_da_steps<DPAD>), dim3((unsigned)tiles), dim3(512), lds8, st, a);
+    return TDA_OK;
   }
   switch (a.nlev) {
     case 2: hipLaunchKernelGGL((k_ml_steps<DPAD, 2>), dim3((unsigned)tiles), dim3(256), lds, st, a); break;
     case 3: hipLaunchKernelGGL((k_ml_steps<DPAD, 3>), dim3((unsigned)tiles), dim3(256), lds, st, a); break;
     default: hipLaunchKernelGGL((k_ml_steps<DPAD, 4>), dim3((unsigned)tiles), dim3(256), lds, st, a); break;
   }
+  return TDA_OK;
 }
 
 template <int DPAD>
@@ -2764,6 +2777,9 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
           return rc;
       }
   }
+  // (The draws of a block could run on a second stream under the previous block's steps as in tda_engine_run, but the level
+  // kernels use the whole register file of a CU -- 2 x 256 or 1 x 512 per SIMD -- so k_rng would not be co-resident: measured
+  // on C3, the split k_rng + k_apply pipeline made the run 8 % SLOWER than the fused k_propose, which therefore stays.)
   int64_t blk_ix = 0;
   int64_t done_base = 0;
   while (done_base < total_base) {
@@ -2797,6 +2813,7 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
     pa.L_stride = e->L_shared ? 0 : (int64_t)DP * DP;
     pa.inc = e->inc.p;
     pa.u = e->ublk.p;
+    pa.logu = e->ext_hier ? nullptr : e->lublk.p;  // (the host-sequenced path uses that buffer as scratch)
     if (e->rep_steps) {
       pa.z_replay = e->z_rep.p + (size_t)e->rep_pos * N * d;
       pa.u_replay = e->u_rep.p + (size_t)e->rep_pos * N;
@@ -2811,6 +2828,7 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
     }
 
     MLArgs ma{};
+    ma.logu0 = pa.logu;
     for (int k = 0; k < nl; ++k) {
       const Level& lv = e->levels[k];
       ma.lv[k].Apk = lv.Apk.p;
@@ -2888,7 +2906,9 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
       if (xrc) return xrc;
     } else {
       ScopedTimer tm(e, 1);
-      DISPATCH_DPAD(DP, launch_ml<DPAD>(ma, NP / 16, lds, e->stream));
+      int lrc = TDA_OK;
+      DISPATCH_DPAD(DP, lrc = launch_ml<DPAD>(ma, NP / 16, lds, e->stream));
+      if (lrc) return lrc;
     }
 
     const bool boundary = periodic && ((e->t + S) % period == 0);
@@ -3570,6 +3590,14 @@ int tda_rng_philox(int device, const uint32_t* counter, const uint32_t* key, uin
   HIP_TRY(hipMemcpy(out, res.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return TDA_OK;
 }
+
+#ifdef TDA_DA_TRACE
+extern "C" int tda_debug_da_trace(long long* out) {  // debug builds only (tools/da_trace.py)
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(tda::g_da_trace), sizeof(long long) * 128 * 8 * 8));
+  return TDA_OK;
+}
+#endif
 
 int tda_engine_set_profiling(tda_engine* e, int enable) {
   if (!e) return fail(TDA_ERR_INVALID, "null engine");

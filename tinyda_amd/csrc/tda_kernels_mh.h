@@ -153,6 +153,27 @@ __device__ __forceinline__ double sum_rows(double v) {
   return __hiloint2double(b.x, a.x) + __hiloint2double(b.y, a.y);
 }
 
+// Sum over the 32 consecutive lanes [32 k, 32 k + 32) that hold one chain in the thread-mapped phases of the 8-wave tile,
+// result in every lane: one v_permlane16_swap stage (rows 16 apart) and four DPP row rotations inside the 16-lane row,
+// instead of five dependent ds_bpermute round trips.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sum_half_wave(double v) {
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  const uint2_t a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const uint2_t b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  double s = __hiloint2double(b.x, a.x) + __hiloint2double(b.y, a.y);  // v + v(lane ^ 16), as in sum_rows
+  s += dpp_move<0x128>(s);  // row_ror:8
+  s += dpp_move<0x124>(s);  // row_ror:4
+  s += dpp_move<0x122>(s);  // row_ror:2
+  s += dpp_move<0x121>(s);  // row_ror:1
+  return s;
+}
+
 __device__ __forceinline__ double4_t mfma_f64(double a, double b, double4_t c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }

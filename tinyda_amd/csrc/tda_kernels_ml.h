@@ -68,6 +68,7 @@ struct MLArgs {
   const double* aem_bias;  // [NP][aem_ld]          total bias of level 0
   const double* aem_P;     // [NP][aem_ld][aem_ld]  (Sigma_e + Sigma_bias)^-1 of level 0
   int64_t* sid;            // [nlev][NP] identity of the parameter vector each level currently holds
+  const double* logu0;     // [S][NP] log of the base-level uniforms (k_propose / k_rng, off the critical path); may be null
 };
 
 __device__ __forceinline__ constexpr int pair_index(int j, int q) { return q * (q - 1) / 2 + j; }
@@ -513,6 +514,431 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
   if (active) {
 #pragma unroll
     for (int e = 0; e < EPT; ++e) a.ysnap[gct * LDP + q_ * EPT + e] = snp[e];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Delayed Acceptance, two levels, on the 8-wave tile (DAChain.sample, chain.py:342-444, acceptance :475-483), for the
+// shape that matters for throughput (BASELINE config 3): a SMALL coarse model (m0 <= 256) stepped many times per fine
+// evaluation, fixed subchain length, iso / diag noise, diagonal prior.  At m0 = 256 a coarse step of the generic kernel
+// is 4 100 cycles of matrix work inside a 9 000-cycle step (tools/steps_microbench.hip): proposal -> LDS -> barrier ->
+// fragment gather -> prior -> MFMA -> reduction -> barrier -> decision is one dependent chain.  This kernel breaks it:
+//   * the coarse forward model is linear, A theta' = keep A theta + A (s inc): every wave keeps the model output F of
+//     its <= 2 observation blocks for the current state in registers, and a step only multiplies the INCREMENT, which does
+//     not depend on the previous decision -- the MFMAs of step s + 1 are issued BEFORE the barrier of step s, the matrix
+//     pipe works while step s is reduced and decided;
+//   * the coarse operator itself is register resident (2 blocks x 32 registers per wave; nothing is streamed per step);
+//   * increments are staged two steps ahead into LDS in fragment order by the threads that also keep the chain state;
+//     the prior of theta' is a thread-mapped partial sum reduced in the shadow of the MFMAs;
+//   * F is re-derived from theta by a direct product at every launch and after every fine step (where rejected chains
+//     return to the fine state anyway), so rounding cannot accumulate beyond one subchain;
+//   * the fine level is evaluated directly (streamed fragments, two waves per SIMD) every sl[0] coarse steps: skip rule,
+//     two-stage acceptance with the densities kept from the subchain start, alignment, records, accept-flag window.
+// Same MLArgs, records and RNG contract as k_ml_steps<DPAD, 2>; log-densities agree with it to rounding (the linear update
+// and the summation order of the prior differ in the last bits), decisions are the same.
+// ------------------------------------------------------------------------------------------------
+template <int DPAD>
+__host__ __device__ constexpr int da_lds_doubles(int stage_total) {
+  return 16 * (DPAD + 2) + 2 * 64 * (DPAD / 4 + 2) + 2 * 16 * 8 + 2 * 16 + 2 * DPAD + stage_total;
+}
+
+#ifdef TDA_DA_TRACE
+__device__ long long g_da_trace[128 * 8 * 8];  // debug builds only: [step][wave][stamp] cycle stamps of tile 0 (tools/da_trace.py)
+#define DA_STAMP(i) \
+  if (blockIdx.x == 0 && lane == 0 && s < 128) g_da_trace[((size_t)s * 8 + wave) * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime()
+#else
+#define DA_STAMP(i)
+#endif
+
+template <int DPAD>
+__global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
+  constexpr int NW = 8, NT = 64 * NW, TPC = 4 * NW, RB = 2;
+  constexpr int KS = DPAD / 4, K2 = DPAD / 8, LDP = DPAD + 2, RSX = KS + 2;
+  constexpr int EPT = DPAD >= TPC ? DPAD / TPC : 1;
+  constexpr int QACT = DPAD / EPT;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* s_prop = smem;                    // [16][LDP] states in natural order (direct evaluations)
+  double* s_inc = s_prop + 16 * LDP;        // [2][64][RSX] scaled increments in fragment order
+  double* s_red = s_inc + 2 * 64 * RSX;     // [2][NW][16]
+  double* s_pri = s_red + 2 * 16 * NW;      // [2][16] prior quadratic form of theta'
+  double* s_pm = s_pri + 2 * 16;
+  double* s_pinv = s_pm + DPAD;
+  double* s_stage = s_pinv + DPAD;
+
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t tile = blockIdx.x;
+  const int c = tid / TPC, q_ = tid % TPC;
+  const int lc = lane & 15, hi = lane >> 4;
+  const int64_t gct = tile * 16 + c;
+  const int64_t gcl = tile * 16 + lc;
+  const bool active = q_ < QACT;
+  const uint32_t gchain = (uint32_t)(a.chain_offset + gcl);
+
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+    for (int i = tid; i < a.lv[k].m_pad; i += NT) {
+      s_stage[a.lds_y[k] + i] = a.lv[k].ytil[i];
+      if (a.lv[k].noise_kind == 1) s_stage[a.lds_w[k] + i] = a.lv[k].w[i];
+    }
+  for (int i = tid; i < DPAD; i += NT) {
+    s_pm[i] = a.pr.mean[i];
+    s_pinv[i] = a.pr.pinv[i];
+  }
+  const bool prior_std = a.pr.kind == PRIOR_STANDARD;
+  const bool dg0 = a.lv[0].noise_kind == 1;
+
+  double cur0[EPT], cur1[EPT], prp[EPT];
+  double sxa[EPT], sxb[EPT], sxc[EPT], sxd[EPT];  // increments of steps s .. s + 3 as loaded (a load has a whole step to arrive)
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    cur0[e] = active ? a.theta[gct * DPAD + q_ * EPT + e] : 0.0;
+    cur1[e] = active ? a.theta[((size_t)a.NP + gct) * DPAD + q_ * EPT + e] : 0.0;
+  }
+  double lp0 = a.lp[gcl], ll0 = a.ll[gcl], lp1 = a.lp[a.NP + gcl], ll1 = a.ll[a.NP + gcl];
+  double Slp = a.Sst[gcl], Sll = a.Sst[a.NP + gcl];  // level 0 at the subchain start (pair (0, 1))
+  int anyacc0 = a.anyacc[gcl];
+  const int anyacc1 = a.anyacc[a.NP + gcl];  // the finest level has no level above that would read it: carried unchanged
+  const double scal_t = a.scaling[gct];
+  const bool is_pcn = a.prop_kind == 1;
+  const double keep_t = is_pcn ? sqrt(1.0 - scal_t * scal_t) : 1.0;
+  const double scal_l = a.scaling[gcl];
+  const double keep_l = is_pcn ? sqrt(1.0 - scal_l * scal_l) : 1.0;  // the same factor for this lane's chain (model outputs)
+  const bool has_logu = a.logu0 != nullptr;
+  int cnt0 = a.cnt[0];
+  int64_t step0 = a.done[0], step1 = a.done[1];
+  int nrec0 = 0, nrec1 = 0;
+  int64_t ringpos = a.ring_pos;
+  const int L0 = a.sl[0];
+  const int ncb0 = a.lv[0].ncb;
+  const bool has_b[RB] = {wave < ncb0, wave + NW < ncb0};
+
+  // where this thread's elements of an increment go in the fragment-ordered tile: row = fragment lane (dim & 3) * 16 + chain
+  int st_dst[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int j = q_ * EPT + e;
+    st_dst[e] = ((j & 3) * 16 + c) * RSX + (j >> 2);
+  }
+  auto stage_load = [&](int s, double (&sx)[EPT]) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) sx[e] = active ? a.inc[((size_t)s * a.NP + gct) * DPAD + q_ * EPT + e] : 0.0;  // raw: no use here,
+  };                                                                                                              // so no wait here
+  auto stage_store = [&](int s, const double (&sx)[EPT]) {
+    double* __restrict__ dst = s_inc + (s & 1) * 64 * RSX;
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) dst[st_dst[e]] = scal_t * sx[e];
+    }
+  };
+  auto chainmm = [&](const double2 (&f)[K2], const double2 (&b)[K2]) {
+    double4_t g = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < K2; ++k) {
+      g = mfma_f64(f[k].x, b[k].x, g);
+      g = mfma_f64(f[k].y, b[k].y, g);
+    }
+    return g;
+  };
+
+  // ---- the coarse operator, data and weights of this wave's blocks: registers for the whole launch ----
+  const FragSrc src0 = frag_src(a.lv[0].Apk, lane);
+  double2 fA[RB][K2];
+  int ob[RB];  // first observation row of this lane in block i (data and weights are read from LDS at use)
+  auto load_coarse_operator = [&]() {
+#pragma unroll
+    for (int i = 0; i < RB; ++i) frag_load_buf<DPAD>(src0, has_b[i] ? wave + i * NW : (ncb0 - 1), fA[i]);
+  };
+  load_coarse_operator();
+  __syncthreads();  // staging region, prior constants
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    ob[i] = (has_b[i] ? wave + i * NW : 0) * 16 + hi;
+  }
+
+  // ---- model outputs of the current coarse state, re-derived from theta at every launch and after every fine step ----
+  double Fc[RB][4], G[RB][4];
+  auto direct_outputs = [&](const double (&state)[EPT], double (&F)[RB][4]) {
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) s_prop[c * LDP + q_ * EPT + e] = state[e];
+    }
+    __syncthreads();
+    double2 b[K2];
+#pragma unroll
+    for (int k = 0; k < K2; ++k) b[k] = double2{s_prop[lc * LDP + 8 * k + hi], s_prop[lc * LDP + 8 * k + 4 + hi]};
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const double4_t g = chainmm(fA[i], b);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) F[i][r] = g[r];
+    }
+    __syncthreads();
+  };
+  direct_outputs(cur0, Fc);
+
+  // ---- pipeline prologue: increments of steps 0 and 1 staged, A (s inc_0) issued ----
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) sxa[e] = sxb[e] = sxc[e] = sxd[e] = 0.0;
+  if (a.S > 0) stage_load(0, sxa);
+  if (a.S > 1) stage_load(1, sxb);
+  if (a.S > 2) stage_load(2, sxc);
+  if (a.S > 0) stage_store(0, sxa);
+  if (a.S > 1) stage_store(1, sxb);
+  double unext = a.S > 0 ? a.u0[gcl] : 0.5, lunext = (has_logu && a.S > 0) ? a.logu0[gcl] : 0.0;
+  __syncthreads();
+  auto issue_products = [&](int s) {  // G = A (s inc_s) for this wave's blocks, from the staged tile of step s
+    const double2* __restrict__ row = reinterpret_cast<const double2*>(s_inc + (s & 1) * 64 * RSX + lane * RSX);
+    double2 b[K2];
+#pragma unroll
+    for (int k = 0; k < K2; ++k) b[k] = row[k];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const double4_t g = chainmm(fA[i], b);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) G[i][r] = g[r];
+    }
+  };
+  if (a.S > 0) issue_products(0);
+
+  // record of the last decided coarse step (state after the decision, its densities, the flag, the accept-flag window) and the
+  // loads of later steps: off the chain decision -> next proposal, issued while the matrix pipe works
+  bool rec_pending = false, rec_acc0 = false;
+  int64_t rec_ring = 0;
+  auto flush_coarse_record = [&]() {
+    if (!rec_pending) return;
+    rec_pending = false;
+    const int row = nrec0 - 1;  // the step's record row; its ring slot is the one before the current position
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int j = q_ * EPT + e;
+        if (a.rec_params[0] && gct < a.N && j < a.d) a.rec_params[0][((size_t)row * a.N + gct) * a.d + j] = cur0[e];
+      }
+    }
+    if (wave == 0 && lane < 16) {
+      if (gcl < a.N) {
+        const size_t r = (size_t)row * a.N + gcl;
+        if (a.rec_stats[0]) {
+          a.rec_stats[0][r * 3 + 0] = lp0;
+          a.rec_stats[0][r * 3 + 1] = ll0;
+          a.rec_stats[0][r * 3 + 2] = lp0 + ll0;
+        }
+        if (a.rec_acc[0]) a.rec_acc[0][r] = rec_acc0 ? 1 : 0;
+      }
+      a.ring[(size_t)(rec_ring % a.ring_P) * a.NP + gcl] = rec_acc0 ? 1 : 0;
+    }
+  };
+
+  for (int s = 0; s < a.S; ++s) {
+    // ================= coarse level: one Metropolis-Hastings step (chain.py:404-444) =================
+    // theta' and its prior (thread-mapped: the 32 threads of a chain are consecutive lanes of one wave)
+    DA_STAMP(0);
+    double pp = 0.0;
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const double sx = scal_t * sxa[e];
+        prp[e] = is_pcn ? keep_t * cur0[e] + sx : cur0[e] + sx;
+        if (prior_std) {
+          pp += prp[e] * prp[e];
+        } else {
+          const double dv = prp[e] - s_pm[q_ * EPT + e];
+          pp += dv * dv * s_pinv[q_ * EPT + e];
+          if (a.pr.lo && (prp[e] < a.pr.lo[q_ * EPT + e] || prp[e] > a.pr.hi[q_ * EPT + e])) pp = INFINITY;
+        }
+      }
+    }
+    // model outputs of theta' and this wave's share of the weighted residual sum (data and weights: all reads first, no branches)
+    double Fp[RB][4], yv[RB][4], wv[RB][4];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        yv[i][r] = s_stage[a.lds_y[0] + ob[i] + 4 * r];
+        wv[i][r] = s_stage[a.lds_w[0] + ob[i] + 4 * r];  // (isotropic noise: an unused read of valid memory)
+      }
+    double sse = 0.0;
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        Fp[i][r] = is_pcn ? keep_l * Fc[i][r] + G[i][r] : Fc[i][r] + G[i][r];
+        const double res = Fp[i][r] - yv[i][r];
+        const double sq = res * res;
+        const double sqw = dg0 ? sq * wv[i][r] : sq;
+        sse += has_b[i] ? sqw : 0.0;
+      }
+    sse = sum_rows(sse);
+    if (lane < 16) s_red[(s & 1) * 16 * NW + wave * 16 + lane] = sse;
+    // the next step's products do not depend on this step's decision: issued now, they run while it is reduced and taken
+    DA_STAMP(1);
+    __builtin_amdgcn_sched_barrier(0);
+    // (measured, tools/da_trace.py: while one wave of a SIMD streams fp64 MFMAs the vector instructions of the other make no
+    // progress at any s_setprio -- the fp64 matrix instruction occupies the fp64 vector lanes -- so the two waves' bursts and
+    // vector sections add up; what this ordering hides is the latency of the reduction, the barrier and the decision)
+    if (s + 1 < a.S) issue_products(s + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    DA_STAMP(2);
+    flush_coarse_record();  // (step s - 1)
+    if (s + 3 < a.S) stage_load(s + 3, sxd);  // staged one step from now, a proposal three steps from now
+    double u_nx = 0.5, lu_nx = 0.0;
+    if (s + 1 < a.S) {
+      u_nx = a.u0[(size_t)(s + 1) * a.NP + gcl];
+      if (has_logu) lu_nx = a.logu0[(size_t)(s + 1) * a.NP + gcl];
+    }
+    pp = sum_half_wave(pp);
+    if (q_ == 0) s_pri[(s & 1) * 16 + c] = pp;
+    if (s + 2 < a.S) stage_store(s + 2, sxc);  // loaded after the previous barrier; its buffer was last read for step s
+    DA_STAMP(3);
+    __syncthreads();
+    DA_STAMP(4);
+
+    double part[NW];  // all partial sums requested before the first is used: one LDS latency, not eight
+#pragma unroll
+    for (int w = 0; w < NW; ++w) part[w] = s_red[(s & 1) * 16 * NW + w * 16 + lc];
+    const double maha = s_pri[(s & 1) * 16 + lc];
+    __builtin_amdgcn_sched_barrier(0);
+    double tot = part[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) tot += part[w];
+    const double ll_n = dg0 ? -0.5 * tot : -0.5 * tot / a.lv[0].var;
+    const double lp_n = -0.5 * (a.pr.logconst + maha);
+    const double post_n = lp_n + ll_n;
+    const double delta = is_pcn ? ll_n - ll0 : post_n - (lp0 + ll0);
+    bool acc0;
+    if (has_logu && (fabs(lunext - delta) > 1e-9 || delta != delta)) acc0 = (post_n == post_n) && (lunext < delta);
+    else acc0 = accept_exact(unext, delta, post_n);
+    if (acc0) {
+      lp0 = lp_n;
+      ll0 = ll_n;
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Fc[i][r] = Fp[i][r];
+    }
+    anyacc0 |= acc0 ? 1 : 0;
+    DA_STAMP(5);
+    if (a.sid && acc0 && wave == 0 && lane < 16) a.sid[gcl] = step0 + 1;
+    {
+      const int accf = __shfl(acc0 ? 1 : 0, c);
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) cur0[e] = accf ? prp[e] : cur0[e];
+      }
+    }
+    unext = u_nx;
+    lunext = lu_nx;
+    rec_ring = ringpos;
+    rec_pending = true;  // the record of this step is written behind the next step's products (or before the fine level acts)
+    rec_acc0 = acc0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      sxa[e] = sxb[e];
+      sxb[e] = sxc[e];
+      sxc[e] = sxd[e];
+    }
+    ringpos += 1;
+    nrec0 += 1;
+    step0 += 1;
+    cnt0 += 1;
+    DA_STAMP(6);
+    if (cnt0 != L0) continue;
+
+    // ================= fine level: the subchain is complete (chain.py:354-402) =================
+    // evaluated directly at y = the coarse state; the registers of the coarse operator serve as its fragment pipeline
+    // (the operator is fetched again afterwards: two block loads per subchain).  One prior for all levels: log-prior(y) = lp0.
+    flush_coarse_record();  // the fine level may move the coarse state: its last step is recorded first
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) s_prop[c * LDP + q_ * EPT + e] = cur0[e];
+    }
+    frag_load_buf<DPAD>(frag_src(a.lv[1].Apk, lane), wave < a.lv[1].ncb ? wave : a.lv[1].ncb - 1, fA[0]);
+    __syncthreads();
+    double llq;
+    {
+      double th[KS];
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) th[kk] = s_prop[lc * LDP + 4 * kk + hi];
+      const LevelDev& L = a.lv[1];
+      const bool dg = L.noise_kind == 1;
+      double sq = dg ? level_sse_single<DPAD, 1, NW>(L.Apk, L.ncb, s_stage + a.lds_y[1], s_stage + a.lds_w[1], th, wave, lane, fA[0])
+                     : level_sse_single<DPAD, 0, NW>(L.Apk, L.ncb, s_stage + a.lds_y[1], nullptr, th, wave, lane, fA[0]);
+      sq = sum_rows(sq);
+      if (lane < 16) s_red[wave * 16 + lane] = sq;  // (both reduction slabs are free here: the step's was read above)
+      __syncthreads();
+      double t1 = s_red[lc];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) t1 += s_red[w * 16 + lc];
+      llq = dg ? -0.5 * t1 : -0.5 * t1 / L.var;
+    }
+    const double lpq = lp0;
+    load_coarse_operator();
+    double uq;
+    if (a.u_rep[1]) uq = a.u_rep[1][(size_t)(step1 - a.done[1]) * a.N + (gcl < a.N ? gcl : 0)];
+    else uq = accept_uniform(a.seed, gchain, (uint32_t)step1, 1u);
+    const double alq = exp(((lpq + llq) - (lp1 + ll1)) + (Slp + Sll) - (lp0 + ll0));  // chain.py:475-483
+    const bool acc1 = (anyacc0 != 0) && (uq < alq);  // skip rule: nothing accepted below -> a recorded rejection (:357-364)
+    {
+      const int accf = __shfl(acc1 ? 1 : 0, c);
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          if (accf) cur1[e] = cur0[e];
+          else cur0[e] = cur1[e];  // the coarse chain restarts from the fine state (:360-362, 394-396)
+          const int j = q_ * EPT + e;
+          if (a.rec_params[1] && gct < a.N && j < a.d) a.rec_params[1][((size_t)nrec1 * a.N + gct) * a.d + j] = cur1[e];
+        }
+      }
+    }
+    if (acc1) {
+      lp1 = lpq;
+      ll1 = llq;
+    } else {
+      lp0 = Slp;
+      ll0 = Sll;
+    }
+    direct_outputs(cur0, Fc);  // rejected chains are back at the fine state: outputs re-derived (and re-anchored) for the tile
+    Slp = lp0;
+    Sll = ll0;
+    anyacc0 = 0;
+    if (wave == 0 && lane < 16) {
+      if (gcl < a.N) {
+        const size_t r = (size_t)nrec1 * a.N + gcl;
+        if (a.rec_stats[1]) {
+          a.rec_stats[1][r * 3 + 0] = lp1;
+          a.rec_stats[1][r * 3 + 1] = ll1;
+          a.rec_stats[1][r * 3 + 2] = lp1 + ll1;
+        }
+        if (a.rec_acc[1]) a.rec_acc[1][r] = acc1 ? 1 : 0;
+      }
+      a.ring[(size_t)(ringpos % a.ring_P) * a.NP + gcl] = acc1 ? 1 : 0;  // alignment entry of the coarse accept list (:363,389,397)
+    }
+    ringpos += 1;
+    nrec1 += 1;
+    step1 += 1;
+    cnt0 = 0;
+  }
+  flush_coarse_record();
+
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      a.theta[gct * DPAD + q_ * EPT + e] = cur0[e];
+      a.theta[((size_t)a.NP + gct) * DPAD + q_ * EPT + e] = cur1[e];
+    }
+  }
+  if (wave == 0 && lane < 16) {
+    a.lp[gcl] = lp0;
+    a.ll[gcl] = ll0;
+    a.lp[a.NP + gcl] = lp1;
+    a.ll[a.NP + gcl] = ll1;
+    a.anyacc[gcl] = anyacc0;
+    a.anyacc[a.NP + gcl] = anyacc1;
+    a.Sst[gcl] = Slp;
+    a.Sst[a.NP + gcl] = Sll;
   }
 }
 
