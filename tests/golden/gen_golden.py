@@ -618,6 +618,118 @@ def g6_dreamz(name, problem, d, M0, delta, nCR, adaptive, period, iters, n_chain
          b_star=np.array(b_star), **extra, **{k: np.array(v) for k, v in out.items()})
 
 
+
+def g15_hier_dreamz(name, ms, sl, d=5, M0=24, delta=1, nCR=3, adaptive=True, period=6, iters=30, n_chains=3, seed=1501):
+    """DREAMZ as the base proposal of Delayed Acceptance (2 levels, DAChain) / MLDA (3 levels, MLDAChain): the configuration of
+    the reference's own MLDA notebook (examples/Multilevel Delayed Acceptance.ipynb cells 20-23)."""
+    sigma = 0.2
+    As, ys, theta_true, pm, pc = _ml_problem(seed, d, ms, sigma)
+    prior = stats.multivariate_normal(pm, pc)
+    posts = [tda.Posterior(prior, tda.GaussianLogLike(y, sigma ** 2 * np.eye(len(y))), make_model(A)) for A, y in zip(As, ys)]
+    rng = np.random.default_rng(seed + 1)
+    theta0 = theta_true[None] + 0.2 * rng.standard_normal((n_chains, d))
+    nl = len(ms)
+    out = {k: [] for k in ("Z0", "r", "mcr", "sub_u", "forced", "e_u", "eps_n", "u0", "pCR", "scaling")}
+    for k in range(nl):
+        for key in ("th", "lp", "ll", "acc"):
+            out["%s%d" % (key, k)] = []
+        if k:
+            out["u%d" % k] = []
+    for c in range(n_chains):
+        np.random.seed(seed + 7 * c)  # prior.rvs(M0) inside DREAMZ.setup_proposal draws from the global stream
+        prop = tda.DREAMZ(M0, delta=delta, Z_method="random", nCR=nCR, adaptive=adaptive, gamma=1.02, period=period)
+        with Tap(seed + 50 * c) as tap:
+            if nl == 2:
+                ch = tda.DAChain(copy.deepcopy(posts[0]), copy.deepcopy(posts[1]), prop, sl[0], initial_parameters=theta0[c].copy())
+            else:
+                ch = tda.MLDAChain([copy.deepcopy(p) for p in posts], prop, list(sl), initial_parameters=theta0[c].copy())
+            base = ch.proposal if nl == 2 else None
+            ch.sample(iters, progressbar=False)
+        if nl == 2:
+            base_prop = ch.proposal
+            loc = np.array(ch.is_coarse, dtype=bool)
+            cth, clp, cll, _ = chain_trace(ch.chain_coarse)
+            acc_c = np.array(ch.accepted_coarse, dtype=np.uint8)
+            traces = [(cth[loc], clp[loc], cll[loc], acc_c[loc])]
+            fth, flp, fll, _ = chain_trace(ch.chain_fine)
+            traces.append((fth, flp, fll, np.array(ch.accepted_fine, dtype=np.uint8)))
+        else:
+            objs = [ch]
+            cur = ch.proposal
+            while True:
+                objs.append(cur)
+                if cur.level == 0:
+                    break
+                cur = cur.proposal
+            objs = objs[::-1]
+            base_prop = objs[0].proposal
+            traces = []
+            for k, ob in enumerate(objs):
+                th, lp, ll, _ = chain_trace(ob.chain)
+                acc = np.array(ob.accepted, dtype=np.uint8)
+                if k < nl - 1:
+                    lc = np.array(ob.is_local, dtype=bool)
+                    th, lp, ll, acc = th[lc], lp[lc], ll[lc], acc[lc]
+                traces.append((th, lp, ll, acc))
+        out["Z0"].append(np.array(base_prop.Z[:M0], copy=True))
+        # the sequential log: a base step is  delta x choice(2), choice(), uniform(d), [choice()], uniform(d), normal(d), u ;
+        # a bare u between base steps belongs to an upper level (kept per level in tap.ulog)
+        it = iter(tap.log)
+        R, MC, SU, FO, EU, EN, U = [], [], [], [], [], [], []
+        for kind, v in it:
+            if kind == "u":
+                continue
+            assert kind == "choice" and np.size(v) == 2
+            rr = [np.array(v)]
+            for _i in range(delta - 1):
+                kind, v = next(it)
+                rr.append(np.array(v))
+            kind, v = next(it)
+            assert kind == "choice" and np.size(v) == 1
+            MC.append(int(v))
+            kind, v = next(it)
+            assert kind == "uniform01"
+            SU.append(v)
+            kind, v = next(it)
+            if kind == "choice":
+                FO.append(int(v))
+                kind, v = next(it)
+            else:
+                FO.append(-1)
+            assert kind == "uniform01"
+            EU.append(v)
+            kind, v = next(it)
+            assert kind == "normal01"
+            EN.append(v)
+            kind, v = next(it)
+            assert kind == "u"
+            U.append(v)
+            R.append(np.array(rr))
+        n_base = iters * int(np.prod(sl))
+        assert len(U) == n_base, (len(U), n_base)
+        us = _split_uniforms(tap.ulog, nl, None)
+        assert np.array_equal(np.array(us[0]), np.array(U))
+        for key, v in zip(("r", "mcr", "sub_u", "forced", "e_u", "eps_n", "u0"), (R, MC, SU, FO, EU, EN, U)):
+            out[key].append(np.array(v))
+        for k, (th, lp, ll, acc) in enumerate(traces):
+            out["th%d" % k].append(th); out["lp%d" % k].append(lp); out["ll%d" % k].append(ll); out["acc%d" % k].append(acc)
+        for k in range(1, nl):
+            below = traces[k - 1][3]
+            nsteps = len(traces[k][3]) - (1 if k == nl - 1 else 0)
+            evaluated = below.reshape(nsteps, sl[k - 1]).sum(axis=1) > 0
+            out["u%d" % k].append(_place(us[k], evaluated))
+        out["pCR"].append(np.array(base_prop.pCR))
+        out["scaling"].append(float(base_prop.scaling))
+    lv = {}
+    for k in range(nl):
+        lv["A%d" % k] = As[k]
+        lv["y%d" % k] = ys[k]
+    save(name, noise_var=np.array(sigma ** 2), prior_mean=pm, prior_cov=pc, theta0=theta0, subchain_lengths=np.array(sl),
+         n_levels=np.array(nl), M0=np.array(M0), delta=np.array(delta), nCR=np.array(nCR), adaptive=np.array(adaptive),
+         period=np.array(period), gamma=np.array(1.02), b=np.array(5e-2), b_star=np.array(1e-6), **lv,
+         **{k: np.array(v) for k, v in out.items()})
+
+
 def _aem_problem(seed, d, m, n_levels, sigma):
     """Levels share the observation vector (AEM subtracts model outputs of adjacent levels, chain.py:274-276)."""
     rng = np.random.default_rng(seed)
@@ -825,6 +937,8 @@ FIXTURES = {
     "g5_mlda_am": lambda: g5_mlda("g5_mlda_am", "am", period=10),
     "g5_mlda_grw_adaptive": lambda: g5_mlda("g5_mlda_grw_adaptive", "grw", adaptive=True, period=7, seed=502),
     "g5_mlda_4level": lambda: g5_mlda("g5_mlda_4level", "am", ms=(6, 10, 16, 24), sl=(3, 2, 2), iters=20, period=10, seed=503),
+    "g15_da_dreamz": lambda: g15_hier_dreamz("g15_da_dreamz", ms=(10, 24), sl=(3,), seed=1501),
+    "g15_mlda_dreamz": lambda: g15_hier_dreamz("g15_mlda_dreamz", ms=(8, 14, 24), sl=(3, 2), iters=20, seed=1502),
     "g7_moments": g7_moments,
     "g9_mvn_logpdf": g9_mvn_logpdf,
     "g10_jointprior": g10_jointprior,

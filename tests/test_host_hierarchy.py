@@ -151,3 +151,66 @@ def test_mlda_with_error_model_replay(golden):
     chains = _run(g, nl, [int(v) for v in g["subchain_lengths"]], _aem_posts(g, nl), aem="state-independent")
     for c, ch in enumerate(chains):
         _check(ch, g, c, nl, with_like=False)
+
+
+class _DreamzTap:
+    """feeds the host DREAMZ class the draws recorded from the reference (np.random.choice / uniform / normal)"""
+
+    def __init__(self, g, c, delta):
+        self.r = [list(map(int, pair)) for step in g["r"][c] for pair in step]
+        self.mcr = [int(v) for v in g["mcr"][c]]
+        self.forced = [int(v) for v in g["forced"][c] if v >= 0]
+        self.sub_u, self.e_u, self.eps = list(g["sub_u"][c]), list(g["e_u"][c]), list(g["eps_n"][c])
+        self._phase = 0
+
+    def __enter__(self):
+        self.saved = (np.random.choice, np.random.uniform, np.random.normal)
+        np.random.choice, np.random.uniform, np.random.normal = self.choice, self.uniform, self.normal
+        return self
+
+    def __exit__(self, *a):
+        np.random.choice, np.random.uniform, np.random.normal = self.saved
+
+    def choice(self, a, size=None, replace=True, p=None):
+        if size == 2:
+            return np.array(self.r.pop(0))
+        if p is not None:
+            return self.mcr.pop(0)
+        return self.forced.pop(0)
+
+    def uniform(self, low=0.0, high=1.0, size=None):
+        if low == 0.0 and high == 1.0:
+            return self.sub_u.pop(0)
+        return low + (high - low) * self.e_u.pop(0)
+
+    def normal(self, loc=0.0, scale=1.0, size=None):
+        return loc + scale * self.eps.pop(0)
+
+
+@pytest.mark.parametrize("name", ["g15_da_dreamz", "g15_mlda_dreamz"])
+def test_dreamz_below_a_hierarchy_replay(golden, name):
+    """DREAMZ as the base proposal of Delayed Acceptance / MLDA (the reference's MLDA notebook configuration) on the host driver"""
+    g = golden(name)
+    nl = int(g["n_levels"])
+    prior = stats.multivariate_normal(g["prior_mean"], g["prior_cov"])
+    var = float(g["noise_var"])
+    for c in range(g["theta0"].shape[0]):
+        Z0 = g["Z0"][c]
+
+        class Seeded(tda.DREAMZ):
+            def setup_proposal(self, **kw):
+                super().setup_proposal(**kw)
+                self.Z = Z0.copy()
+
+        posts = [tda.Posterior(prior, tda.GaussianLogLike(g["y%d" % k], var * np.eye(len(g["y%d" % k]))), _model(g["A%d" % k])) for k in range(nl)]
+        prop = Seeded(int(g["M0"]), delta=int(g["delta"]), nCR=int(g["nCR"]), adaptive=bool(g["adaptive"]), gamma=float(g["gamma"]),
+                      period=int(g["period"]))
+        ch = _Fed.__new__(_Fed)
+        ch.feed(np.zeros((0, 1)), [g["u0"][c]] + [g["u%d" % k][c] for k in range(1, nl)])
+        with _DreamzTap(g, c, int(g["delta"])) as tap:
+            HierarchyChain.__init__(ch, posts, prop, [int(v) for v in g["subchain_lengths"]], initial_parameters=g["theta0"][c].copy())
+            ch.sample(g["th%d" % (nl - 1)].shape[1] - 1)
+        assert not tap.r and not tap.mcr and not tap.eps and all(len(q) == 0 for q in ch._u)
+        _check(ch, g, c, nl)
+        np.testing.assert_allclose(ch.proposal.scaling, g["scaling"][c], rtol=1e-12)
+        np.testing.assert_allclose(ch.proposal.pCR, g["pCR"][c], rtol=1e-10)
