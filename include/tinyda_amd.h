@@ -170,6 +170,10 @@ int tda_engine_set_level(tda_engine* e, int level, int m, const double* A, const
                          const double* data, int noise_kind, const double* noise);
 
 int tda_engine_set_proposal(tda_engine* e, const tda_proposal_params* p);
+/* DREAMZ / DREAM (proposal.py:608-852, :1627-1656).  Single-level chains; DREAMZ (shared = 0) also as the base proposal of a
+ * Delayed Acceptance / MLDA hierarchy (n_levels > 1; the configuration of the reference's MLDA notebook): every chain keeps its
+ * own archive, which grows by the chain's level-0 state after every base step; the hierarchy is then sequenced by the host
+ * (linear, callback and source-defined levels; iso / diag noise; diagonal prior).  capacity >= M0 + number of base steps. */
 int tda_engine_set_proposal_dreamz(tda_engine* e, const tda_dreamz_params* p);
 /* OperatorWeightedCrankNicolson (proposal.py:515-605; kind TDA_PROP_OWCN set by tda_engine_set_proposal with C = NULL, adaptive = 0):
  * theta' = state_operator theta + noise_operator N(0, C_prior), acceptance on the likelihood ratio like pCN.  Both operators

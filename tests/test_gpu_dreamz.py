@@ -241,3 +241,74 @@ def test_sample_api_dreamz_with_uniform_prior_components():
     link = res["chain_7"][-1]
     assert np.isclose(link.posterior, post.create_link(link.parameters).posterior, rtol=1e-10)
     assert np.mean([np.mean(res["chain_%d" % i].accepted[1:]) for i in range(12)]) > 0.01
+
+
+@pytest.mark.parametrize("name,block", [("g15_da_dreamz", 0), ("g15_da_dreamz", 5), ("g15_mlda_dreamz", 0), ("g15_mlda_dreamz", 7)])
+def test_dreamz_below_a_hierarchy_replay(eng_mod, golden, name, block):
+    """DREAMZ as the base proposal of Delayed Acceptance / MLDA (the reference's MLDA notebook configuration,
+    examples/Multilevel Delayed Acceptance.ipynb cells 20-23; proposal.py:1583-1613, chain.py:404-444) on the device: traces
+    recorded from tinyDA's DAChain / MLDAChain with DREAMZ, every draw of DREAMZ.make_proposal and every level's uniforms
+    replayed -- accept flags of every level equal, log-posteriors to 1e-10, adapted scaling and crossover probabilities."""
+    g = golden(name)
+    nl = int(g["n_levels"])
+    N, d = g["theta0"].shape
+    sl = [int(v) for v in g["subchain_lengths"]]
+    n_fine = g["th%d" % (nl - 1)].shape[1] - 1
+    T0 = g["u0"].shape[1]
+    e = eng_mod.Engine(N, d, seed=11, n_levels=nl, block_steps=block)
+    e.set_prior(g["prior_mean"], g["prior_cov"])
+    for k in range(nl):
+        e.set_level(k, g["A%d" % k], g["y%d" % k], 0, float(g["noise_var"]))
+    e.set_proposal_dreamz(int(g["M0"]), delta=int(g["delta"]), b=float(g["b"]), b_star=float(g["b_star"]), nCR=int(g["nCR"]),
+                          adaptive=bool(g["adaptive"]), gamma=float(g["gamma"]), period=int(g["period"]), capacity=int(g["M0"]) + T0)
+    e.set_subchains(sl)
+    e.set_archive(g["Z0"])
+    e.init(g["theta0"])
+    sw = lambda a: np.ascontiguousarray(np.swapaxes(a, 0, 1))
+    e.set_replay_dreamz(sw(g["r"]), sw(g["mcr"]), sw(g["sub_u"]), sw(g["forced"]), sw(g["e_u"]), sw(g["eps_n"]), sw(g["u0"]))
+    for k in range(1, nl):
+        e.set_replay_level(k, sw(g["u%d" % k]))
+    outs = e.run_levels_host(n_fine)
+    for k in range(nl):
+        p, s_, a = outs[k]
+        off = 1 if k == nl - 1 else 0  # the finest trace carries the initial link
+        ref_acc = g["acc%d" % k][:, off:].T
+        assert np.array_equal(a, ref_acc), "level %d: %d accept flips" % (k, int((a != ref_acc).sum()))
+        np.testing.assert_allclose(s_[:, :, 2], (g["lp%d" % k] + g["ll%d" % k])[:, off:].T, rtol=RTOL)
+        np.testing.assert_allclose(p, sw(g["th%d" % k][:, off:]), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(e.proposal_state_scaling(), g["scaling"], rtol=1e-12)
+    st = e.dreamz_state()
+    np.testing.assert_allclose(st["pCR"], g["pCR"], rtol=1e-8)
+    assert st["archive_rows"] == int(g["M0"]) + T0
+    e.close()
+
+
+def test_sample_dreamz_below_mlda_on_device():
+    """tda.sample([3 posteriors], DREAMZ(Z_method='lhs', adaptive=True), subchain_length=...) lowers to the engine: linear
+    levels, and the notebook's kind of model (a plain Python callable returning (output, qoi)) behind the callback path"""
+    import scipy.stats as stats
+
+    import tinyda_amd as tda
+
+    d = 4
+    rng = np.random.default_rng(8)
+    truth = rng.standard_normal(d) * 0.3
+    prior = stats.multivariate_normal(np.zeros(d), np.eye(d))
+    As = [rng.standard_normal((m, d)) / 2 for m in (6, 10, 16)]
+    ys = [A @ truth + 0.05 * rng.standard_normal(A.shape[0]) for A in As]
+    lin = [tda.Posterior(prior, tda.GaussianLogLike(y, 0.05 ** 2 * np.eye(len(y))), tda.LinearModel(A)) for A, y in zip(As, ys)]
+    res = tda.sample(lin, tda.DREAMZ(M0=40, delta=1, Z_method="lhs", adaptive=True, period=10), iterations=30, n_chains=8,
+                     initial_parameters=truth, subchain_length=3, seed=2, backend="hip")
+    assert res["sampler"] == "MLDA" and res["backend"] == "hip" and len(res["chain_l2_0"]) == 31 and len(res["chain_l0_0"]) == 270
+    fine = tda.get_samples(res, level=2)
+    assert np.isfinite(fine["chain_0"]).all()
+    # same seed -> same run (the LHS archive is drawn on the host from a generator keyed by (seed, global chain id))
+    res2 = tda.sample(lin, tda.DREAMZ(M0=40, delta=1, Z_method="lhs", adaptive=True, period=10), iterations=30, n_chains=8,
+                      initial_parameters=truth, subchain_length=3, seed=2, backend="hip")
+    assert np.array_equal(tda.get_samples(res2, level=2)["chain_3"], fine["chain_3"])
+    opaque = [tda.Posterior(prior, tda.GaussianLogLike(y, 0.05 ** 2 * np.eye(len(y))), lambda th, A=A: (np.tanh(A @ th), True))
+              for A, y in zip(As, ys)]
+    res3 = tda.sample(opaque, tda.DREAMZ(M0=40, Z_method="lhs", adaptive=True, period=10), iterations=12, n_chains=4,
+                      initial_parameters=truth, subchain_length=2, seed=3)
+    assert res3["backend"] == "hip" and len(res3["chain_l2_1"]) == 13
+    assert res3["chain_l2_0"][5].qoi is True

@@ -221,7 +221,8 @@ def test_multilevel_plan_for_plain_callables_and_external_models():
     assert plan is not None and "batched" in plan[0][0] and plan[0][0]["noise_kind"] == 3
     mixed = [tda.Posterior(prior, tda.GaussianLogLike(y, cov), tda.LinearModel(A)), wrapped[1]]
     assert api._device_plan(mixed, tda.CrankNicolson(scaling=0.1)) is not None
-    assert api._device_plan(mixed, tda.DREAMZ(10)) is None  # DREAM(Z) below a hierarchy is not lowered
+    assert api._device_plan(mixed, tda.DREAMZ(10)) is not None  # DREAMZ below a hierarchy: host-sequenced, per-chain archives
+    assert api._device_plan(mixed, tda.DREAM(10)) is None  # DREAM's shared archive is single-level
     qoi = [tda.Posterior(prior, tda.GaussianLogLike(y, cov), lambda th: (A @ th, th.sum())), wrapped[1]]
     w2 = api._wrap_opaque_models(qoi)  # (output, qoi) models (posterior.py:97-101): the engine takes the output ...
     np.testing.assert_allclose(w2[0].model.batch(np.ones((2, d))), np.tile(A @ np.ones(d), (2, 1)))

@@ -41,8 +41,8 @@ def _device_plan(posteriors, proposal):
             elif len(posteriors) != 1 or isinstance(proposal, DREAMZ) or low["A"].shape[0] > 1024:
                 return None  # linear model: single-level GRW / pCN / AM with m <= 1024 (MFMA quadratic form)
         lows.append(low)
-    if isinstance(proposal, DREAMZ) and len(posteriors) != 1:
-        return None  # DREAMZ below an MLDA hierarchy is not lowered yet
+    if isinstance(proposal, DREAMZ) and len(posteriors) != 1 and proposal._shared:
+        return None  # below a hierarchy the engine keeps DREAMZ's per-chain archives; DREAM's shared one is single-level
     if any("rosenbrock" in low for low in lows) and not isinstance(proposal, DREAMZ):
         return None  # the Rosenbrock model is fused into the DREAMZ kernel only
     if any("prior_joint" in low for low in lows):
@@ -56,10 +56,8 @@ def _device_plan(posteriors, proposal):
     if any("source" in low or "batched" in low for low in lows):
         # source-defined and batched host models: single level, or a whole hierarchy of them (Delayed Acceptance / MLDA with
         # host-sequenced level actions: GRW / pCN / AM).  iso / diag noise, diagonal prior.
-        if isinstance(proposal, DREAMZ) and len(posteriors) != 1:
-            return None
         if len(posteriors) > 1:
-            if any("rosenbrock" in low for low in lows) or type(proposal) not in (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis):
+            if any("rosenbrock" in low for low in lows) or type(proposal) not in (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis, DREAMZ):
                 return None  # (linear levels may be mixed in, e.g. a linear surrogate below a non-linear model)
         for i, low in enumerate(lows):
             ok_noise = (low["noise_kind"] in (_lib.NOISE_ISO, _lib.NOISE_DIAG) or (low["noise_kind"] == _lib.NOISE_DENSE and low["A"] is None)
@@ -234,6 +232,8 @@ def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None
             raise TypeError("Initial paramaters must be list, numpy array or None")
 
     plan = None if backend == "host" else _device_plan(posteriors, proposal)
+    if plan is not None and isinstance(proposal, DREAMZ) and n_levels > 1 and (adaptive_error_model is not None or randomize_subchain_length):
+        plan = None  # not lowered: host protocol under 'auto'
     if plan is None and backend != "host" and n_levels > 1:
         # Delayed Acceptance / MLDA over opaque Python models (plain callables theta -> ndarray, the reference's everyday
         # case): the engine needs the outputs of all chains per level step, so a plain callable is evaluated chain by chain
@@ -403,7 +403,12 @@ def _sample_device_multilevel(plan, posteriors, iterations, n_chains, initial_pa
                 eng.set_level_source(k, low["source"], low["data"], low["noise_kind"], low["noise"])
             else:
                 eng.set_level(k, low["A"], low["data"], low["noise_kind"], low["noise"], b=low["b"])
-        eng.set_proposal(**prop)
+        if prop["kind"] == _lib.PROP_DREAMZ:  # one archive per chain, one row per base step
+            dz = {k: v for k, v in prop.items() if k not in ("kind", "Z_method")}
+            eng.set_proposal_dreamz(capacity=dz["M0"] + iterations * int(np.prod(subchain_lengths)), **dz)
+            eng.set_archive(_initial_archive(prop, lows[0], n_chains, chain_offset, seed))
+        else:
+            eng.set_proposal(**prop)
         eng.set_subchains(subchain_lengths, randomize)
         if aem is not None:
             eng.set_error_model(aem)

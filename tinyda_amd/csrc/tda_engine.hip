@@ -248,6 +248,7 @@ struct tda_engine {
   // adaptive error model
   int aem = 0;
   int aem_m = 0, aem_ld = 64;
+  DevBuf<double> theta_last;  // DREAMZ below a hierarchy: level-0 state right after a block's last base step (jump distance of the pCR update)
   bool ext_hier = false;  // hierarchy with callback / source-defined levels: sequenced by the host (run_multilevel)
   DevBuf<double> ext_Fcur[tda::MAXLEV], ext_Fst;  // error model there: outputs of the current links [NP][MP], of level j at theta_q [npairs][NP][MP]
   DevBuf<double> aem_bias[tda::MAXLEV], aem_covinv[tda::MAXLEV], aem_bmu[tda::MAXLEV], aem_bsig[tda::MAXLEV], aem_mdiff[tda::MAXLEV];
@@ -1099,7 +1100,8 @@ int tda_engine_set_level_callback(tda_engine* e, int level, tda_forward_batch_fn
 int tda_engine_set_proposal_dreamz(tda_engine* e, const tda_dreamz_params* p) {
   if (!e || !p) return fail(TDA_ERR_INVALID, "null argument");
   if (p->struct_size != sizeof(tda_dreamz_params)) return fail(TDA_ERR_INVALID, "tda_dreamz_params.struct_size mismatch");
-  if (e->nlev != 1) return fail(TDA_ERR_UNSUPPORTED, "DREAMZ is lowered for single-level chains only");
+  if (e->nlev != 1 && p->shared)
+    return fail(TDA_ERR_UNSUPPORTED, "below a Delayed Acceptance / MLDA hierarchy DREAMZ keeps one archive per chain (DREAM's shared archive is single-level)");
   if (p->M0 < 2 * 1 + 1) return fail(TDA_ERR_INVALID, "M0 too small");
   if (p->delta < 1 || p->delta > MAX_DELTA) return fail(TDA_ERR_UNSUPPORTED, "delta=%d outside 1..%d", p->delta, (int)MAX_DELTA);
   if (p->nCR < 1 || p->nCR > MAX_NCR) return fail(TDA_ERR_UNSUPPORTED, "nCR=%d outside 1..%d", p->nCR, (int)MAX_NCR);
@@ -1201,7 +1203,8 @@ int tda_engine_set_archive_auto_append(tda_engine* e, int on) {
   return TDA_OK;
 }
 
-static int dreamz_sums_catchup(tda_engine* e, int64_t row0, int64_t nrows, bool boundary, bool scale, double gamma_pow);
+static int dreamz_sums_catchup(tda_engine* e, int64_t row0, int64_t nrows, bool boundary, bool scale, double gamma_pow,
+                               const double* theta_now = nullptr, const uint8_t* ring = nullptr, int ring_P = 0, int64_t ring_hi = 0);
 
 int tda_engine_archive_take(tda_engine* e, double* rows, int64_t* n_steps) {
   if (!e || !e->inited || !e->is_dreamz || !e->dz.shared) return fail(TDA_ERR_STATE, "no shared-archive engine initialised");
@@ -1527,13 +1530,18 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
   {
     int n_cb = 0;
     for (auto& lv : e->levels) n_cb += (lv.model == MODEL_CALLBACK || lv.model == MODEL_USER) ? 1 : 0;
-    e->ext_hier = n_cb && e->nlev > 1;
-    if (n_cb && e->nlev > 1) {  // Delayed Acceptance / MLDA with callback / source-defined models (host-sequenced level actions)
+    // DREAMZ below a hierarchy (the reference's MLDA notebook): its jump needs the chain's growing archive at every base step,
+    // so such a hierarchy is sequenced by the host like one with callback / source-defined levels, linear levels included
+    const bool dz_hier = e->is_dreamz && e->nlev > 1;
+    e->ext_hier = (n_cb || dz_hier) && e->nlev > 1;
+    if (e->ext_hier) {  // Delayed Acceptance / MLDA with callback / source-defined models (host-sequenced level actions)
       for (auto& lv : e->levels)  // linear levels may be mixed in (k_ext_linear_eval); anything else may not
         if (lv.model != MODEL_CALLBACK && lv.model != MODEL_USER && (lv.model != MODEL_LINEAR || !lv.A_dev.p))
           return fail(TDA_ERR_UNSUPPORTED, "hierarchies with callback / source-defined levels take linear levels with isotropic or diagonal noise beside them");
-      if (e->pp.kind != TDA_PROP_GRW && e->pp.kind != TDA_PROP_PCN && e->pp.kind != TDA_PROP_AM)
-        return fail(TDA_ERR_UNSUPPORTED, "callback hierarchies take GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis proposals");
+      if (e->pp.kind != TDA_PROP_GRW && e->pp.kind != TDA_PROP_PCN && e->pp.kind != TDA_PROP_AM && !dz_hier)
+        return fail(TDA_ERR_UNSUPPORTED, "callback hierarchies take GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis / DREAMZ proposals");
+      if (dz_hier && e->aem) return fail(TDA_ERR_UNSUPPORTED, "DREAMZ below a hierarchy with an adaptive error model is not lowered");
+      if (dz_hier && e->randomize) return fail(TDA_ERR_UNSUPPORTED, "DREAMZ with randomize_subchain_length is not lowered");
       if (e->prior_kind == PRIOR_DENSE) return fail(TDA_ERR_UNSUPPORTED, "callback forward models need a diagonal prior covariance");
     }
   }
@@ -1658,8 +1666,11 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
     e->pending_steps = 0;
     e->inited = true;  // dreamz_sums_catchup checks nothing else
     if ((rc = dreamz_sums_catchup(e, 0, M0, false, false, 1.0))) return rc;
-    // initial link (chain.py:70)
-    if (e->levels[0].model == MODEL_LINEAR || e->levels[0].model == MODEL_CALLBACK || e->levels[0].model == MODEL_USER) {
+    if ((rc = e->theta_last.alloc((size_t)NP * DP))) return rc;
+    // initial link (chain.py:70); below a hierarchy the level set-up further down evaluates every level at theta0
+    if (e->nlev > 1) {
+      if (e->levels[0].model == MODEL_ROSENBROCK) return fail(TDA_ERR_UNSUPPORTED, "the Rosenbrock example model is single-level");
+    } else if (e->levels[0].model == MODEL_LINEAR || e->levels[0].model == MODEL_CALLBACK || e->levels[0].model == MODEL_USER) {
       if ((rc = launch_eval(e, 0, e->theta.p, e->lp.p, e->ll.p))) return rc;
     } else {
       // Rosenbrock level: evaluate theta0 with a zero-jump DREAMZ step (coef = eps = 0, u = 0 -> accepted)
@@ -1685,10 +1696,11 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
       HIP_TRY(hipMemsetAsync(e->acc_count.p, 0, NP * sizeof(int32_t), e->stream));
     }
     HIP_TRY(hipStreamSynchronize(e->stream));
-    return TDA_OK;
+    if (e->nlev == 1) return TDA_OK;
   }
+  const bool owcn = !e->is_dreamz && e->pp.kind == TDA_PROP_OWCN, mala = !e->is_dreamz && e->pp.kind == TDA_PROP_MALA;
+  if (!e->is_dreamz) {  // ---- Gaussian proposals: factor of the proposal covariance (DREAMZ has its archive instead) ----
   std::vector<double> L;
-  const bool owcn = e->pp.kind == TDA_PROP_OWCN, mala = e->pp.kind == TDA_PROP_MALA;
   const double* Cuse = (e->pp.kind == TDA_PROP_PCN || owcn) ? e->prior_cov_h.data() : e->prop_C_h.data();  // proposal.py:336-341
   if (!mala && !cholesky_host(Cuse, d, L)) return fail(TDA_ERR_NUMERIC, "proposal covariance is not positive definite");
   std::vector<double> Lk((size_t)DP * DP, 0.0);
@@ -1771,9 +1783,10 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
     e->L_shared = true;
     if ((rc = e->Lk.upload(Lk))) return rc;
   }
+  }
 
   // block buffers
-  if ((rc = e->inc.alloc((size_t)e->SMAX * NP * DP))) return rc;
+  if (!e->is_dreamz && (rc = e->inc.alloc((size_t)e->SMAX * NP * DP))) return rc;
   if ((rc = e->ublk.alloc((size_t)e->SMAX * NP))) return rc;
   if ((rc = e->lublk.alloc((size_t)e->SMAX * NP))) return rc;
   if ((rc = e->rec_params.alloc((size_t)e->SMAX * N * d))) return rc;
@@ -2425,7 +2438,7 @@ static int run_ext_hierarchy_block(tda_engine* e, const MLArgs& ma, int64_t S, b
                          (unsigned long long)e->cfg.seed, (long long)e->cfg.chain_offset, (long long)(e->done[1] + row[1]),
                          ma.ridx_rep ? ma.ridx_rep + (size_t)row[1] * N : nullptr, e->ml_pick.p);
     }
-    if (e->levels[0].model == MODEL_USER && !e->aem && !e->randomize && e->levels[0].noise_kind != TDA_NOISE_DENSE) {
+    if (e->levels[0].model == MODEL_USER && !e->aem && !e->randomize && !e->is_dreamz && e->levels[0].noise_kind != TDA_NOISE_DENSE) {
       // source-defined base level: the rest of the running subchain (inside this block) is ONE launch of the fused
       // step kernel compiled with the model
       const int64_t n = std::min<int64_t>(S - s, (int64_t)e->sl[0] - cc[0]);
@@ -2530,8 +2543,43 @@ static int run_ext_hierarchy_block(tda_engine* e, const MLArgs& ma, int64_t S, b
       xa.cnt = cc[0];
       xa.ysnap = e->ml_ysnap.p;
     }
+    if (e->is_dreamz) {
+      // DREAMZ base step (proposal.py:811-852 / :790-809): the block's draws are in dz_coef / dz_epsm / dz_ridx (k_dreamz_draw);
+      // apply the jump from the chain's archive, evaluate, decide, append the state the chain is left in to its archive
+      if (s == S - 1)  // jumping distance of the crossover adaptation: the state before the block's last base step
+        HIP_TRY(hipMemcpyAsync(e->theta_prev.p, e->ml_theta.p, (size_t)NP * DP * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+      DzExtArgs za{};
+      za.N = N;
+      za.NP = NP;
+      za.d = d;
+      za.DP = DP;
+      za.delta = e->dz.delta;
+      za.s = (int)s;
+      za.shared = 0;
+      za.jump_ready = 0;
+      za.M_base = e->arch_rows;
+      za.cap = e->arch_cap;
+      za.arch = e->arch.p;
+      za.theta = e->ml_theta.p;
+      za.coef = e->dz_coef.p;
+      za.epsm = e->dz_epsm.p;
+      za.ridx = e->dz_ridx.p;
+      za.prop = e->levels[0].cb_prop.p;
+      za.blk_states = nullptr;
+      hipLaunchKernelGGL(k_dz_ext_propose, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, za);
+      int mrc = ext_model_outputs(e, e->levels[0]);
+      if (mrc) return mrc;
+      xa.prop_kind = TDA_PROP_GRW;  // acceptance on the posterior ratio (proposal.py:253-258)
+      hipLaunchKernelGGL(k_ext_accept, dim3(grid), dim3(64 * EXT_WAVES), xa.Pd ? (size_t)EXT_WAVES * e->levels[0].m * sizeof(double) : 0,
+                         e->stream, xa);
+      hipLaunchKernelGGL(k_dz_ext_append, dim3((unsigned)((NP + EXT_WAVES - 1) / EXT_WAVES)), dim3(64 * EXT_WAVES), 0, e->stream, za);
+      if (s == S - 1)  // ... and the state right after it, before an upper level realigns the chain
+        HIP_TRY(hipMemcpyAsync(e->theta_last.p, e->ml_theta.p, (size_t)NP * DP * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+      HIP_TRY(hipGetLastError());
+    } else {
     int xrc = ext_step(e, e->levels[0], xa);
     if (xrc) return xrc;
+    }
     cc[0] += 1;
     s += 1;
     }
@@ -2718,10 +2766,14 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
       if (int crc = check_out_capacity(outs + k, k, n_fine * mult[k], N, d)) return crc;
   if (e->rep_steps && e->rep_pos + total_base > e->rep_steps) return fail(TDA_ERR_INVALID, "replay buffer too short");
   if (e->exp_steps && e->exp_pos + total_base > e->exp_steps) return fail(TDA_ERR_INVALID, "export buffer too small");
+  if (e->is_dreamz) {
+    if (e->rp_steps && e->rp_pos + total_base > e->rp_steps) return fail(TDA_ERR_INVALID, "DREAMZ replay buffer too short");
+    if (e->arch_rows + total_base > e->arch_cap) return fail(TDA_ERR_INVALID, "archive capacity (%lld rows) exceeded", (long long)e->arch_cap);
+  }
   for (int k = 1; k < nl; ++k)
     if (e->u_rep_lv_n[k] && e->u_rep_lv_pos[k] + n_fine * mult[k] > e->u_rep_lv_n[k])
       return fail(TDA_ERR_INVALID, "replay buffer of level %d too short", k);
-  if (e->rep_steps)
+  if (e->rep_steps || (e->is_dreamz && e->rp_steps))
     for (int k = 1; k < nl; ++k)
       if (!e->u_rep_lv_n[k]) return fail(TDA_ERR_STATE, "replay mode needs uniforms for every level (set_replay_level)");
 
@@ -2822,7 +2874,46 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
       pa.z_export = (e->exp_dev ? e->z_exp : e->z_exp_d.p) + (size_t)e->exp_pos * N * d;
       pa.u_export = (e->exp_dev ? e->u_exp : e->u_exp_d.p) + (size_t)e->exp_pos * N;
     }
-    {
+    if (e->is_dreamz) {  // everything DREAMZ.make_proposal draws for the block's base steps (the archive grows by a row per step)
+      DreamDrawArgs da{};
+      da.N = N;
+      da.NP = NP;
+      da.chain_offset = e->cfg.chain_offset;
+      da.d = d;
+      da.S = (int)S;
+      da.delta = e->dz.delta;
+      da.nCR = e->dz.nCR;
+      da.step0 = e->t;
+      da.M_base = e->arch_rows;
+      da.grow = 1;
+      da.seed = e->cfg.seed;
+      da.b = e->dz.b;
+      da.b_star = e->dz.b_star;
+      da.scaling = e->scaling.p;
+      da.pCR = e->dz_pCR.p;
+      da.coef = e->dz_coef.p;
+      da.epsm = e->dz_epsm.p;
+      da.ridx = e->dz_ridx.p;
+      da.u = e->ublk.p;
+      da.mcr_last = e->dz_mcr_last.p;
+      if (e->rp_steps) {
+        const size_t o = (size_t)e->rp_pos * N;
+        da.r_rep = e->rp_r.p + o * e->dz.delta * 2;
+        da.mcr_rep = e->rp_mcr.p + o;
+        da.forced_rep = e->rp_forced.p + o;
+        da.sub_rep = e->rp_sub.p + o * d;
+        da.e_rep = e->rp_e.p + o * d;
+        da.eps_rep = e->rp_eps.p + o * d;
+        da.u_rep = e->rp_u.p + o;
+      }
+      if (e->exp_steps) {
+        da.eps_export = (e->exp_dev ? e->z_exp : e->z_exp_d.p) + (size_t)e->exp_pos * N * d;
+        da.u_export = (e->exp_dev ? e->u_exp : e->u_exp_d.p) + (size_t)e->exp_pos * N;
+      }
+      da.arch_shared = nullptr;
+      ScopedTimer tm(e, 0);
+      DISPATCH_DPAD(DP, launch_dz_draw<DPAD>(da, e->stream));
+    } else {
       ScopedTimer tm(e, 0);
       DISPATCH_DPAD(DP, launch_propose<DPAD>(pa, e->stream));
     }
@@ -2912,7 +3003,18 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
     }
 
     const bool boundary = periodic && ((e->t + S) % period == 0);
-    if (is_am || (boundary && adaptive)) {
+    if (e->is_dreamz) {
+      // archive column sums of the S rows the block appended; at a period boundary the global scaling (accept-flag window
+      // incl. alignment entries) and the crossover probabilities (proposal.py:797-809)
+      int64_t app = 0;
+      for (int k = 0; k < nl; ++k) app += nblk[k];
+      ScopedTimer tm(e, 2);
+      const int drc = dreamz_sums_catchup(e, e->arch_rows, S, boundary, adaptive, std::pow(e->dz.gamma, -(double)e->k_adapt), e->theta_last.p,
+                                          adaptive ? e->ml_ring.p : nullptr, e->ring_P, e->ring_pos + app - tail_appends);
+      if (drc) return drc;
+      e->arch_rows += S;
+      if (e->rp_steps) e->rp_pos += S;
+    } else if (is_am || (boundary && adaptive)) {
       AdaptArgs aa{};
       aa.N = N;
       aa.NP = NP;
@@ -3145,7 +3247,8 @@ void fill_dreamz_step_args(tda_engine* e, DreamStepArgs& sa) {
   sa.u = e->ublk.p;
 }
 
-static int dreamz_sums_catchup(tda_engine* e, int64_t row0, int64_t nrows, bool boundary, bool scale, double gamma_pow) {
+static int dreamz_sums_catchup(tda_engine* e, int64_t row0, int64_t nrows, bool boundary, bool scale, double gamma_pow,
+                               const double* theta_now, const uint8_t* ring, int ring_P, int64_t ring_hi) {
   DreamAdaptArgs aa{};
   aa.N = e->N;
   aa.NP = e->NP;
@@ -3158,8 +3261,11 @@ static int dreamz_sums_catchup(tda_engine* e, int64_t row0, int64_t nrows, bool 
   aa.arch = e->arch.p;
   aa.zsum = e->zsum.p;
   aa.zsq = e->zsq.p;
-  aa.theta = e->theta.p;
+  aa.theta = theta_now ? theta_now : e->theta.p;
   aa.theta_prev = e->theta_prev.p;
+  aa.ring = ring;
+  aa.ring_P = ring_P;
+  aa.ring_hi = ring_hi;
   aa.mcr_last = e->dz_mcr_last.p;
   aa.pCR = e->dz_pCR.p;
   aa.LCR = e->dz_LCR.p;

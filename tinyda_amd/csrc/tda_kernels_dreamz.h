@@ -443,6 +443,11 @@ struct DreamAdaptArgs {
   double* DeltaCR;         // [NP][MAX_NCR]
   double* scaling;
   int32_t* acc_count;
+  // below a Delayed Acceptance / MLDA hierarchy the accept-flag window of the base proposal also holds the alignment entries
+  // the upper levels append (chain.py:363,389,397; proposal.py:1486): a ring of flags instead of a counter (as k_adapt)
+  const uint8_t* ring;     // [ring_P][NP] or null
+  int ring_P;
+  int64_t ring_hi;         // absolute list position just after the boundary base step's own flag
 };
 
 // column sums / sums of squares of rows [row0 + 256 b, row0 + 256 (b+1)) of a row-major [.][DPAD] matrix
@@ -528,7 +533,13 @@ __global__ void __launch_bounds__(64) k_dreamz_adapt(const DreamAdaptArgs a) {
   if (!a.boundary) return;
   if (a.do_scale) {
     if (lane == 0) {
-      const double rate = (double)a.acc_count[c] / (double)a.period;
+      int hits = 0;
+      if (a.ring) {
+        for (int i = 1; i <= a.period; ++i) hits += a.ring[(size_t)((a.ring_hi - i) % a.ring_P) * a.NP + c];
+      } else {
+        hits = a.acc_count[c];
+      }
+      const double rate = (double)hits / (double)a.period;
       a.scaling[c] = exp(log(a.scaling[c]) + a.gamma_pow * (rate - 0.24));
     }
     // crossover probabilities (proposal.py:797-809)
