@@ -247,7 +247,8 @@ int tda_engine_get_proposal_state(tda_engine* e, double* scaling, double* C, dou
 int tda_engine_get_dreamz_state(tda_engine* e, double* pCR, int64_t* archive_rows);
 
 /* Shared-archive exchange for one process per GPU (DREAM over RCCL): after run() with auto-append off, take the
- * rows this engine produced since the last exchange ([steps][n_chains][dim], device or host pointer) ... */
+ * rows this engine produced since the last exchange ([steps][n_chains][dim], device or host pointer; a device buffer is
+ * filled asynchronously on the engine's stream, so an exchange can be queued behind it without a host wait) ... */
 int tda_engine_archive_take(tda_engine* e, double* rows, int64_t* n_steps);
 /* ... and append rows (any number, [n_rows][dim], canonical order = step-major, global chain id minor). */
 int tda_engine_archive_append(tda_engine* e, const double* rows, int64_t n_rows);

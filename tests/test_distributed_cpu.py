@@ -27,8 +27,32 @@ n, mu, M2 = tdist.gather_moments(cnt, mean, m2)
 # DREAM archive exchange: rank r holds chains [5r, 5r+5) of 3 steps; value encodes (step, global chain)
 loc = torch.tensor([[[100.0 * s + off + c, -1.0] for c in range(cnt)] for s in range(3)], dtype=torch.float64)
 rows = tdist.gather_archive_rows(loc)
+# the overlapped exchange (run_shared_dream(overlap=True)) with a stand-in engine on CPU tensors: what is appended, and when
+class FakeEngine:
+    n_chains, dim, device = cnt, 2, 0
+    def __init__(self):
+        self.log, self.step, self.pending = [], 0, []
+    def set_archive_auto_append(self, on):
+        self.log.append(("auto", bool(on)))
+    def run(self, k, params=None, stats=None, accepted=None, sync=True):
+        self.log.append(("run", k))
+        self.pending = [[[100.0 * (self.step + s) + off + c, float(rank)] for c in range(cnt)] for s in range(k)]
+        self.step += k
+    def archive_take(self, buf):
+        buf.copy_(torch.tensor(self.pending, dtype=torch.float64))
+        return len(self.pending)
+    def archive_append(self, rows):
+        self.log.append(("append", rows[:, 0].tolist()))
+    def sync(self):
+        self.log.append(("sync",))
+_dev = torch.device
+torch.device = lambda *a, **k: _dev("cpu")  # the staging buffers of the pipeline live where the engine does: here the CPU
+fe = FakeEngine()
+tdist.run_shared_dream(fe, 7, 3, overlap=True)
+torch.device = _dev
 with open(os.path.join(%(out)r, "rank%%d.json" %% rank), "w") as fh:
-    json.dump(dict(rank=rank, off=off, cnt=cnt, mx=mx, sm=sm, n=n, mu=mu.tolist(), M2=M2.tolist(), rows=rows[:, 0].tolist()), fh)
+    json.dump(dict(rank=rank, off=off, cnt=cnt, mx=mx, sm=sm, n=n, mu=mu.tolist(), M2=M2.tolist(), rows=rows[:, 0].tolist(),
+                   pipeline=fe.log), fh)
 """
 
 
@@ -55,6 +79,12 @@ def test_world_size_2_gloo(tmp_path):
     assert all(d["mx"] == 2.0 and d["sm"] == 10.0 and d["n"] == 10.0 for d in res)
     expect = [100.0 * s_ + c for s_ in range(3) for c in range(10)]  # step-major, global chain minor, on every rank
     assert res[0]["rows"] == expect and res[1]["rows"] == expect
+    # overlapped exchange: blocks of 3, 3, 1 steps; the rows of block b are appended (canonical order, all ranks alike)
+    # only after block b + 1 has been queued -- i.e. before block b + 2 -- and everything has landed at the end
+    block = lambda s0, k: [100.0 * s_ + c for s_ in range(s0, s0 + k) for c in range(10)]
+    want = [["auto", False], ["run", 3], ["run", 3], ["append", block(0, 3)], ["run", 1], ["append", block(3, 3)],
+            ["append", block(6, 1)], ["sync"]]
+    assert res[0]["pipeline"] == want and res[1]["pipeline"] == want
     import torch
 
     x = torch.randn(10, 3, generator=torch.Generator().manual_seed(5), dtype=torch.float64).numpy()

@@ -312,3 +312,68 @@ def test_sample_dreamz_below_mlda_on_device():
                       initial_parameters=truth, subchain_length=2, seed=3)
     assert res3["backend"] == "hip" and len(res3["chain_l2_1"]) == 13
     assert res3["chain_l2_0"][5].qoi is True
+
+
+def test_dream_overlapped_exchange_is_sharding_invariant(eng_mod):
+    """run_shared_dream(overlap=True): the rows of block b reach the archive before block b + 2 (their exchange runs under
+    block b + 1).  A single engine driven by the pipeline equals two half-size engines exchanging by hand with the same lag,
+    bit for bit; the engine runs on a torch stream, nothing in the loop waits on the host."""
+    import torch
+
+    from tinyda_amd import distributed as tdist
+
+    d, N, T, M0, K, seed = 8, 32, 63, 24, 5, 77  # 63 = 12 full blocks + a ragged one
+    rng = np.random.default_rng(4)
+    A = rng.standard_normal((12, d)) / np.sqrt(d)
+    y = rng.standard_normal(12)
+    Z0 = rng.standard_normal((M0, d))
+    theta0 = 0.3 * rng.standard_normal((N, d))
+
+    def make(n, off, th, stream=None):
+        e = eng_mod.Engine(n, d, seed=seed, chain_offset=off, stream=stream)
+        e.set_prior(np.zeros(d), np.eye(d))
+        e.set_level(0, A, y, 0, 0.25)
+        e.set_proposal_dreamz(M0, delta=2, nCR=3, adaptive=True, period=20, gamma=1.02, shared=True, sync_every=K, capacity=M0 + T * N)
+        e.set_archive(Z0)
+        e.init(th)
+        return e
+
+    ts = torch.cuda.Stream()
+    one = make(N, 0, theta0, ts.cuda_stream)
+    dev = torch.device("cuda", 0)
+    p = torch.zeros((T, N, d), dtype=torch.float64, device=dev)
+    s_ = torch.zeros((T, N, 3), dtype=torch.float64, device=dev)
+    a = torch.zeros((T, N), dtype=torch.uint8, device=dev)
+    tdist.run_shared_dream(one, T, K, p, s_, a, overlap=True, stream=ts)
+    ts.synchronize()
+    assert one.dreamz_state()["archive_rows"] == M0 + T * N
+    ref_pcr = one.dreamz_state()["pCR"]
+    one.close()
+
+    h = N // 2
+    e0, e1 = make(h, 0, theta0[:h]), make(h, h, theta0[h:])
+    for e in (e0, e1):
+        e.set_archive_auto_append(False)
+    pend, got0, got1 = [], [], []
+    done = 0
+    while done < T:
+        k = min(K, T - done)
+        if len(pend) == 2:
+            rows = pend.pop(0)
+            e0.archive_append(rows)
+            e1.archive_append(rows)
+        got0.append(e0.run_host(k))
+        got1.append(e1.run_host(k))
+        r0, r1 = np.empty((k, h, d)), np.empty((k, h, d))
+        assert e0.archive_take(r0) == k and e1.archive_take(r1) == k
+        pend.append(np.concatenate([r0, r1], axis=1).reshape(k * N, d))
+        done += k
+    for rows in pend:
+        e0.archive_append(rows)
+        e1.archive_append(rows)
+    for k, full in enumerate((p, s_, a)):
+        joined = np.concatenate([np.concatenate([g[k] for g in got0]), np.concatenate([g[k] for g in got1])], axis=1)
+        assert np.array_equal(joined, full.cpu().numpy()), "the overlapped exchange depends on the sharding (record %d)" % k
+    np.testing.assert_array_equal(np.concatenate([e0.dreamz_state()["pCR"], e1.dreamz_state()["pCR"]]), ref_pcr)
+    e0.close()
+    e1.close()

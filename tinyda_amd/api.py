@@ -165,11 +165,13 @@ def _wrap_opaque_models(posteriors):
 def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None, subchain_length=1,
            randomize_subchain_length=False, adaptive_error_model=None, store_coarse_chain=True,
            force_sequential=False, force_progress_bar=False, subsampling_rate=None, *, seed=None,
-           backend="auto", device=0, chain_offset=0, distributed=False):
+           backend="auto", device=0, chain_offset=0, distributed=False, overlap_archive_exchange=False):
     """Extra keyword-only arguments (not in tinyDA): seed, backend ('auto' | 'hip' | 'host'), device, chain_offset, and
     distributed=True: under torch.distributed (one process per GPU) `n_chains` is the GLOBAL chain count, this rank
     samples its contiguous shard (tinyda_amd.distributed.shard_chains) on GPU LOCAL_RANK and returns it with
-    'chain_offset' set; chains are keyed by global id, so the union over ranks equals a single-process run."""
+    'chain_offset' set; chains are keyed by global id, so the union over ranks equals a single-process run.
+    overlap_archive_exchange=True (DREAM's shared archive): the all-gather of a block's new archive rows runs under the next
+    block's steps and the rows become visible one block later (tinyda_amd.distributed.run_shared_dream)."""
     if distributed:
         from . import distributed as tdist
 
@@ -249,7 +251,7 @@ def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None
     if plan is not None:
         if n_levels == 1:
             return _sample_device(plan, posteriors[0], iterations, n_chains, initial_parameters, seed, device,
-                                  chain_offset, distributed, total if distributed else None)
+                                  chain_offset, distributed, total if distributed else None, overlap_archive_exchange)
         return _sample_device_multilevel(plan, posteriors, iterations, n_chains, initial_parameters, subchain_length,
                                          subchain_lengths, randomize_subchain_length, store_coarse_chain, seed, device,
                                          chain_offset, adaptive_error_model)
@@ -312,7 +314,7 @@ def _sample_host_multilevel(posteriors, proposal, iterations, n_chains, initial_
 
 
 def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, seed, device, chain_offset,
-                   distributed=False, total_chains=None):
+                   distributed=False, total_chains=None, overlap_exchange=False):
     from .engine import Engine  # raises EngineError when libtinyda_hip.so is missing: no CPU fallback
 
     lows, prop = plan
@@ -320,7 +322,13 @@ def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, se
     d = low["prior_mean"].shape[0]
     if seed is None:
         seed = int(np.random.randint(0, 2 ** 31 - 1))
-    eng = Engine(n_chains, d, seed=seed, device=device, chain_offset=chain_offset)
+    tstream = None
+    if overlap_exchange and prop["kind"] == _lib.PROP_DREAMZ and prop.get("shared"):
+        import torch
+
+        tstream = torch.cuda.Stream(device=torch.device("cuda", device))  # the collective is ordered behind the engine's work on it
+    eng = Engine(n_chains, d, seed=seed, device=device, chain_offset=chain_offset,
+                 stream=None if tstream is None else tstream.cuda_stream)
     try:
         if "prior_joint" in low:
             eng.set_prior_joint(*low["prior_joint"])
@@ -354,7 +362,7 @@ def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, se
         acc = pinned_empty((T + 1, N), dtype=np.uint8)
         acc[0] = 1
         params[0], stat[0] = eng.current()
-        if T > 0 and prop["kind"] == _lib.PROP_DREAMZ and prop.get("shared") and distributed:
+        if T > 0 and prop["kind"] == _lib.PROP_DREAMZ and prop.get("shared") and (distributed or tstream is not None):
             import torch
 
             from . import distributed as tdist
@@ -363,7 +371,10 @@ def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, se
             dp = torch.empty((T, N, d), dtype=torch.float64, device=tdev)
             ds = torch.empty((T, N, 3), dtype=torch.float64, device=tdev)
             da = torch.empty((T, N), dtype=torch.uint8, device=tdev)
-            tdist.run_shared_dream(eng, T, 16, dp, ds, da)  # one all_gather of the new archive rows per 16 steps
+            # one all_gather of the new archive rows per 16 steps
+            tdist.run_shared_dream(eng, T, 16, dp, ds, da, overlap=tstream is not None, stream=tstream)
+            if tstream is not None:
+                tstream.synchronize()
             params[1:], stat[1:], acc[1:] = dp.cpu().numpy(), ds.cpu().numpy(), da.cpu().numpy()
         elif T > 0:
             eng.run(T, params[1:], stat[1:], acc[1:])

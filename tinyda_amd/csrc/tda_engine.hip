@@ -1220,7 +1220,7 @@ int tda_engine_archive_take(tda_engine* e, double* rows, int64_t* n_steps) {
         HIP_TRY(hipMemcpy2DAsync(rows + (size_t)s * e->N * e->d, e->d * sizeof(double), e->blk_hist.p + (size_t)s * e->NP * e->DP,
                                  e->DP * sizeof(double), e->d * sizeof(double), e->N, kind, e->stream));
     }
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (kind == hipMemcpyDeviceToHost) HIP_TRY(hipStreamSynchronize(e->stream));  // device buffers: stream ordered, no host wait
   }
   if (rows) e->pending_steps = 0;  // a NULL buffer only asks how many steps are pending
   return TDA_OK;

@@ -91,32 +91,98 @@ def gather_archive_rows(local_rows):
     return torch.cat(parts, dim=1).reshape(-1, local_rows.shape[-1]).contiguous()
 
 
-def run_shared_dream(engine, n_iterations, sync_every, params=None, stats=None, accepted=None):
-    """Drive a shared-archive DREAM engine under a process group: `sync_every` steps, then one all_gather of the new
-    rows, appended identically on every rank (tests/test_gpu_dreamz.py checks the result is independent of sharding)."""
+def _canonical_rows(gathered, world, k, n_local, dim):
+    """[world][k][n_local][dim] as gathered by rank -> [k * world * n_local][dim] in canonical order (step major, global chain
+    id minor: rank r owns the contiguous global ids [r n_local, (r + 1) n_local))"""
+    return gathered.reshape(world, k, n_local, dim).permute(1, 0, 2, 3).reshape(-1, dim).contiguous()
+
+
+def run_shared_dream(engine, n_iterations, sync_every, params=None, stats=None, accepted=None, overlap=False, stream=None):
+    """Drive a shared-archive DREAM engine under a process group.
+
+    overlap=False: `sync_every` steps, then one all_gather of the new rows, appended identically on every rank before the next
+    block starts (tests/test_gpu_dreamz.py checks the result is independent of sharding); the exchange runs serialised with
+    the compute.
+
+    overlap=True: the exchange of block b runs UNDER the compute of block b + 1.  The rows block b produced become visible to
+    the proposals of block b + 2 (one block later than above; the reference's own archive is updated fire-and-forget by a Ray
+    actor, ray.py:365-384, so what a proposal sees there depends on timing -- here the lag is fixed and the same for any
+    number of ranks, 1 included, so results stay independent of the sharding).  Per block: append the gathered rows of block
+    b - 2 (a stream-side wait on that collective, no host wait), run block b, copy its rows into a staging buffer on the
+    engine's stream, start the all_gather asynchronously.  `stream`: the torch.cuda.Stream the engine was created on
+    (Engine(..., stream=s.cuda_stream)); the collective is ordered behind the engine's work on it."""
+    import contextlib
+
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
-        # one process: its rows are all rows; the engine appends each `sync_every`-step block in place (same archive
-        # contents and order as the exchange below produces with one rank), no copies, no host synchronisation
-        engine.set_archive_auto_append(True)
-        for done in range(0, n_iterations, sync_every):
-            sl = slice(done, min(done + sync_every, n_iterations))
-            engine.run(sl.stop - sl.start, None if params is None else params[sl], None if stats is None else stats[sl],
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    world = dist.get_world_size() if multi else 1
+    N, d = engine.n_chains, engine.dim
+    if not overlap:
+        if not multi:
+            # one process: its rows are all rows; the engine appends each `sync_every`-step block in place (same archive
+            # contents and order as the exchange below produces with one rank), no copies, no host synchronisation
+            engine.set_archive_auto_append(True)
+            for done in range(0, n_iterations, sync_every):
+                sl = slice(done, min(done + sync_every, n_iterations))
+                engine.run(sl.stop - sl.start, None if params is None else params[sl], None if stats is None else stats[sl],
+                           None if accepted is None else accepted[sl])
+            return
+        engine.set_archive_auto_append(False)
+        done = 0
+        while done < n_iterations:
+            k = min(sync_every, n_iterations - done)
+            sl = slice(done, done + k)
+            engine.run(k, None if params is None else params[sl], None if stats is None else stats[sl],
                        None if accepted is None else accepted[sl])
+            buf = torch.empty((k, N, d), dtype=torch.float64, device=torch.device("cuda", engine.device))
+            engine.archive_take(buf)
+            engine.archive_append(gather_archive_rows(buf))
+            done += k
         return
+
+    # ---- overlapped exchange, fixed lag of one block ----
+    dev = torch.device("cuda", engine.device)
+    ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
     engine.set_archive_auto_append(False)
-    done = 0
-    while done < n_iterations:
-        k = min(sync_every, n_iterations - done)
-        sl = slice(done, done + k)
-        engine.run(k, None if params is None else params[sl], None if stats is None else stats[sl],
-                   None if accepted is None else accepted[sl])
-        buf = torch.empty((k, engine.n_chains, engine.dim), dtype=torch.float64, device=torch.device("cuda", engine.device))
-        engine.archive_take(buf)
-        engine.archive_append(gather_archive_rows(buf))
-        done += k
+    stage = [torch.empty((sync_every, N, d), dtype=torch.float64, device=dev) for _ in range(3)]
+    recv = [[torch.empty((sync_every, N, d), dtype=torch.float64, device=dev) for _ in range(world)] for _ in range(3)] if multi else None
+    in_flight = []  # (work or None, block index, steps)
+
+    def land(entry):
+        work, b, k = entry
+        if multi:
+            work.wait()  # orders the current (= the engine's) stream behind the collective
+            rows = _canonical_rows(torch.stack([t[:k] for t in recv[b % 3]]), world, k, N, d)
+        else:
+            rows = stage[b % 3][:k].reshape(-1, d)
+        engine.archive_append(rows)
+
+    with ctx:
+        done, b = 0, 0
+        while done < n_iterations:
+            k = min(sync_every, n_iterations - done)
+            sl = slice(done, done + k)
+            if len(in_flight) == 2:
+                land(in_flight.pop(0))
+            engine.run(k, None if params is None else params[sl], None if stats is None else stats[sl],
+                       None if accepted is None else accepted[sl], sync=False)
+            mine = stage[b % 3][:k]
+            engine.archive_take(mine)
+            work = None
+            if multi:
+                outs = [t[:k] for t in recv[b % 3]] if k == sync_every else None
+                if outs is None:  # ragged last block: exact-size views are required by the collective
+                    recv[b % 3] = [torch.empty((k, N, d), dtype=torch.float64, device=dev) for _ in range(world)]
+                    outs = recv[b % 3]
+                work = dist.all_gather(outs, mine.contiguous(), async_op=True)
+            in_flight.append((work, b, k))
+            done += k
+            b += 1
+        for entry in in_flight:  # the archive ends complete
+            land(entry)
+        engine.sync()
 
 
 class PooledAdaptiveMetropolis:
