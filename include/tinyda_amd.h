@@ -65,7 +65,17 @@ typedef enum tda_noise_kind {
 } tda_noise_kind;
 
 /* adaptive_error_model of sample() (sampler.py:82-87) */
-typedef enum tda_error_model { TDA_AEM_NONE = 0, TDA_AEM_STATE_INDEPENDENT = 1, TDA_AEM_STATE_DEPENDENT = 2 } tda_error_model;
+typedef enum tda_error_model {
+  TDA_AEM_NONE = 0,
+  TDA_AEM_STATE_INDEPENDENT = 1,
+  TDA_AEM_STATE_DEPENDENT = 2,
+  /* extension (the reference keeps a full m x m bias covariance per chain and re-inverts it every level step, which does
+   * not scale): the state-independent model with DIAGONAL tracker covariances and a diagonal noise covariance -- the same
+   * recursion element by element, corrected likelihood -1/2 sum_o (F_o + b_o - y_o)^2 / (sigma_o^2 + s_o^2); O(m) memory
+   * and work per chain, any output dimension.  Levels are set with TDA_NOISE_ISO / TDA_NOISE_DIAG (their variances are
+   * Sigma_e); Delayed Acceptance and MLDA; linear, callback and source-defined levels. */
+  TDA_AEM_STATE_INDEPENDENT_DIAGONAL = 3
+} tda_error_model;
 
 /* tinyDA/proposal.py: GaussianRandomWalk :132, CrankNicolson :261, AdaptiveMetropolis :372, DREAMZ :608 / DREAM :1627 */
 typedef enum tda_proposal_kind {
@@ -198,7 +208,8 @@ int tda_engine_set_subchains(tda_engine* e, const int32_t* lengths, int randomiz
 /* Adaptive error model (chain.py:268-305, 485-523; :643-678, 739-765): every level below the finest must have been set
  * with TDA_NOISE_ADAPTIVE (noise = m x m covariance), all levels share m <= 64.  State-dependent is two-level only. */
 int tda_engine_set_error_model(tda_engine* e, int kind);
-/* Error-model state of adaptive level `level` (HOST, any may be NULL): bias [n_chains][m], cov_inverse [n_chains][m][m]. */
+/* Error-model state of adaptive level `level` (HOST, any may be NULL): bias [n_chains][m], cov_inverse [n_chains][m][m]
+ * (the diagonal model fills the diagonal of each matrix). */
 int tda_engine_get_error_model(tda_engine* e, int level, double* bias, double* cov_inverse);
 
 /* Start the chains: theta0 is n_chains x dim, or NULL to draw theta0 ~ prior from RNG stream 2

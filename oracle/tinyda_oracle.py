@@ -693,12 +693,15 @@ def run_dreamz(level, cfg, theta0, Z0, var):
 #   DAChain: chain.py:268-305 (set-up), :446-473 (state-dependent acceptance), :485-523 (update)
 #   MLDAChain / MLDA: chain.py:643-678, :739-765; proposal.py:1407-1467, :1547-1578
 # ----------------------------------------------------------------------------------------
-def run_multilevel_aem(levels, proposal, subchain_lengths, theta0, z, u_levels, n_fine, aem):
+def run_multilevel_aem(levels, proposal, subchain_lengths, theta0, z, u_levels, n_fine, aem, diagonal=False):
     """Like run_multilevel, with tinyDA's adaptive error model.
 
     levels[k] = dict(A, b, y, cov | var): every level but the finest has an AdaptiveGaussianLogLike (dense `cov`,
     distributions.py:332-449), the finest an isotropic one (`var`).  All levels share the output dimension.
     aem = 'state-independent' (DA and MLDA) or 'state-dependent' (DA only).
+    diagonal=True (extension, not in tinyDA): set_bias receives only the DIAGONAL of the bias covariance -- the scalable
+    variant of the error model (include/tinyda_amd.h, TDA_AEM_STATE_INDEPENDENT_DIAGONAL).  The trackers follow the
+    reference's full recursion; their off-diagonal entries simply never reach the likelihood.
     Book-keeping that differs from run_multilevel: a Link's likelihood can be refreshed later (update_link), and
     align_chain looks links up by *identity* of their parameter array (proposal.py:1481-1483), so every state
     carries an id and S[j][q] means "the latest level-j link whose parameters are theta_q".
@@ -731,6 +734,8 @@ def run_multilevel_aem(levels, proposal, subchain_lengths, theta0, z, u_levels, 
 
     def set_bias(k, mu, sigma):  # distributions.py:385-402, per chain
         bias_tot[k] = mu.copy()
+        if diagonal:
+            sigma = sigma * np.eye(m)
         refresh = ~np.all(sigma < 1e-9, axis=(1, 2))
         if refresh.any():
             cov_inv[k][refresh] = np.linalg.inv(levels[k]["cov"] + sigma[refresh])
@@ -858,4 +863,4 @@ def run_multilevel_aem(levels, proposal, subchain_lengths, theta0, z, u_levels, 
         lpk, llk = np.array(r["logprior"]).T, np.array(r["loglike"]).T
         out.append(dict(theta=np.swapaxes(np.array(r["theta"]), 0, 1), logprior=lpk, loglike=llk, logpost=lpk + llk,
                         accepted=np.array(r["accepted"]).T.astype(np.uint8)))
-    return out, dict(bias=bias_tot, b_mu=b_mu, b_sigma=b_sig)
+    return out, dict(bias=bias_tot, b_mu=b_mu, b_sigma=b_sig, cov_inv=cov_inv)

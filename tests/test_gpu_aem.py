@@ -120,3 +120,108 @@ def test_sample_api_with_error_model_beyond_64_outputs():
     assert da["sampler"] == "DA" and da.get("backend", "hip") != "host"
     lk = da["chain_fine_0"][-1]
     assert np.isclose(lk.posterior, posts[2].create_link(lk.parameters).posterior, rtol=1e-10)
+
+
+def _diag_levels(rng, d, m, nl, sigma, diag_noise):
+    from oracle import tinyda_oracle as orc
+
+    truth = rng.standard_normal(d) * 0.5
+    Af = rng.standard_normal((m, d)) / np.sqrt(d)
+    y = Af @ truth + sigma * rng.standard_normal(m)
+    prior = orc.MVNPrior(np.zeros(d), np.eye(d))
+    var = sigma ** 2 * (1.0 + (rng.random(m) if diag_noise else np.zeros(m)))
+    spec, As, bs = [], [], []
+    for k in range(nl):
+        A = Af + 0.08 * (nl - 1 - k) * rng.standard_normal((m, d)) / np.sqrt(d)
+        b = 0.05 * (nl - 1 - k) * rng.standard_normal(m)
+        As.append(A)
+        bs.append(b)
+        if k < nl - 1:
+            spec.append(dict(A=A, b=b, y=y, prior=prior, cov=np.diag(var)))
+        else:
+            spec.append(dict(A=A, b=b, y=y, prior=prior, var=float(var[0])))
+    return spec, As, bs, y, var, truth
+
+
+@pytest.mark.parametrize("nl,sl,d,m,diag_noise,kind", [(2, [3], 5, 8, False, "grw"), (2, [4], 6, 70, True, "pcn"), (3, [3, 2], 5, 24, False, "grw"),
+                                                        (3, [2, 2], 8, 300, False, "am")])
+def test_diagonal_error_model_vs_oracle(eng_mod, nl, sl, d, m, diag_noise, kind):
+    """TDA_AEM_STATE_INDEPENDENT_DIAGONAL (extension: diagonal bias covariances, any output dimension -- here up to m = 300,
+    beyond the 128 of the dense model): Delayed Acceptance and MLDA on the engine's own Philox stream against the oracle's
+    restatement (run_multilevel_aem(..., diagonal=True)): accept flags of every level equal, finest log-posterior to 1e-10,
+    stacked biases and inverse variances of the coarse levels to 1e-9."""
+    from oracle import tinyda_oracle as orc
+
+    rng = np.random.default_rng(100 * nl + m)
+    N, n_fine = 12, 14
+    sigma = 0.3
+    spec, As, bs, y, var, truth = _diag_levels(rng, d, m, nl, sigma, diag_noise)
+    if diag_noise:  # the finest level of the oracle's error-model chains is isotropic
+        spec[-1]["var"] = float(var[0])
+    theta0 = truth + 0.1 * rng.standard_normal((N, d))
+    e = eng_mod.Engine(N, d, seed=21, n_levels=nl)
+    e.set_prior(np.zeros(d), np.eye(d))
+    for k in range(nl):
+        if k < nl - 1 and diag_noise:
+            e.set_level(k, As[k], y, 1, var, b=bs[k])
+        else:
+            e.set_level(k, As[k], y, 0, float(var[0]), b=bs[k])
+    if kind == "grw":
+        prop = dict(kind="grw", C=0.01 * np.eye(d), scaling=1.0, adaptive=True, gamma=1.02, period=5)
+        e.set_proposal(0, prop["C"], scaling=1.0, adaptive=True, gamma=1.02, period=5)
+    elif kind == "pcn":
+        prop = dict(kind="pcn", scaling=0.15)
+        e.set_proposal(1, None, scaling=0.15)
+    else:
+        prop = dict(kind="am", C0=0.01 * np.eye(d), t0=4, period=4, sd=min(1.0, 2.4 ** 2 / d), epsilon=1e-6)
+        e.set_proposal(2, prop["C0"], t0=4, period=4)
+    e.set_subchains(sl)
+    e.set_error_model("state-independent-diagonal")
+    e.init(theta0)
+    T0 = n_fine * int(np.prod(sl))
+    z, u0 = e.set_export(T0)
+    outs = e.run_levels_host(n_fine)
+    # the oracle on the engine's variates; upper-level uniforms from the RNG contract (stream 1, block = level)
+    st = orc.PhiloxStream(21)
+    rows = e.rows_per_level(n_fine)
+    us = [np.swapaxes(u0, 0, 1)] + [np.stack([st.uniform(np.arange(N), t, level=k) for t in range(rows[k])], axis=1) for k in range(1, nl)]
+    ref, state = orc.run_multilevel_aem(spec, prop, sl, theta0, np.swapaxes(z, 0, 1), us, n_fine, "state-independent", diagonal=True)
+    for k in range(nl):
+        p, s_, a = outs[k]
+        off = 1 if k == nl - 1 else 0
+        assert np.array_equal(a, ref[k]["accepted"][:, off:].T), "level %d: %d accept flips" % (k, int((a != ref[k]["accepted"][:, off:].T).sum()))
+        np.testing.assert_allclose(p, np.swapaxes(ref[k]["theta"][:, off:], 0, 1), rtol=1e-10, atol=1e-12)
+        if k == nl - 1:
+            np.testing.assert_allclose(s_[:, :, 2], ref[k]["logpost"][:, off:].T, rtol=RTOL)
+    for k in range(nl - 1):
+        bias, P = e.error_model_state(k, m)
+        np.testing.assert_allclose(bias, state["bias"][k], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(np.einsum("nii->ni", P), np.einsum("nii->ni", state["cov_inv"][k]), rtol=1e-9)
+    e.close()
+
+
+def test_sample_api_with_diagonal_error_model():
+    """tda.sample(..., adaptive_error_model='state-independent', error_model_covariance='diagonal') with 512 outputs per level"""
+    import scipy.stats as st
+
+    import tinyda_amd as tda
+
+    d, m, N = 6, 512, 16
+    rng = np.random.default_rng(6)
+    Af = rng.standard_normal((m, d)) / np.sqrt(d)
+    truth = rng.standard_normal(d)
+    y = Af @ truth + 0.3 * rng.standard_normal(m)
+    prior = st.multivariate_normal(np.zeros(d), np.eye(d))
+    cov = 0.09 * np.eye(m)
+    posts = [tda.Posterior(prior, tda.AdaptiveGaussianLogLike(y, cov), tda.LinearModel(Af + 0.1 * rng.standard_normal((m, d)) / np.sqrt(d))),
+             tda.Posterior(prior, tda.AdaptiveGaussianLogLike(y, cov), tda.LinearModel(Af + 0.05 * rng.standard_normal((m, d)) / np.sqrt(d))),
+             tda.Posterior(prior, tda.GaussianLogLike(y, cov), tda.LinearModel(Af))]
+    th0 = [truth + 0.05 * rng.standard_normal(d) for _ in range(N)]
+    res = tda.sample(posts, tda.GaussianRandomWalk(0.001 * np.eye(d)), 20, n_chains=N, initial_parameters=th0, subchain_length=[3, 2],
+                     adaptive_error_model="state-independent", error_model_covariance="diagonal", seed=4, backend="hip")
+    assert res["sampler"] == "MLDA" and res["backend"] == "hip" and len(res["chain_l2_0"]) == 21
+    link = res["chain_l2_5"][-1]
+    assert np.isclose(link.posterior, posts[2].create_link(link.parameters).posterior, rtol=1e-10)
+    with pytest.raises(tda.EngineError):  # the dense model stops at 128 outputs on the device
+        tda.sample(posts, tda.GaussianRandomWalk(0.001 * np.eye(d)), 5, n_chains=N, initial_parameters=th0, subchain_length=[3, 2],
+                   adaptive_error_model="state-independent", seed=4, backend="hip")

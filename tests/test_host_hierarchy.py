@@ -214,3 +214,50 @@ def test_dreamz_below_a_hierarchy_replay(golden, name):
         _check(ch, g, c, nl)
         np.testing.assert_allclose(ch.proposal.scaling, g["scaling"][c], rtol=1e-12)
         np.testing.assert_allclose(ch.proposal.pCR, g["pCR"][c], rtol=1e-10)
+
+
+class _FedByIndex(_Fed):
+    """upper-level uniforms by step index (a different model takes different decisions than the recorded run, so the
+    'no uniform drawn here' pattern of a fixture does not apply): full arrays, one value per step of every level"""
+
+    def _uniform(self, level):
+        if level == 0:
+            return self._u[0].pop(0)
+        rung = self.rungs[level]
+        done = len(rung.took) - 1 if level == len(self.rungs) - 1 else sum(rung.own)
+        return self._u_full[level][done]
+
+
+@pytest.mark.parametrize("name,nl", [("g8_da_aem_indep", 2), ("g8_mlda_aem", 3)])
+def test_diagonal_error_model_host_driver_equals_oracle(golden, name, nl):
+    """error_model_covariance='diagonal' (extension: only the diagonal of a bias covariance reaches the likelihood): the host
+    driver with the product's AdaptiveGaussianLogLike and the oracle's restatement agree on the same variates -- accept flags
+    of every level equal, states and finest densities to 1e-10; and the model differs from the dense one."""
+    from oracle import tinyda_oracle as orc
+    from tests.test_oracle_aem import aem_levels
+    from tests.test_oracle_multilevel import _prop
+
+    g = golden(name)
+    sl = [int(g["subchain_length"])] if nl == 2 else [int(v) for v in g["subchain_lengths"]]
+    n_fine = g["th%d" % (nl - 1)].shape[1] - 1
+    rng = np.random.default_rng(17)
+    us = [g["u0"]] + [rng.random(g["u%d" % k].shape) for k in range(1, nl)]  # a uniform for every step of every level
+    ref, _ = orc.run_multilevel_aem(aem_levels(g, nl), _prop(g), sl, g["theta0"], g["z"], us, n_fine, "state-independent", diagonal=True)
+    dense, _ = orc.run_multilevel_aem(aem_levels(g, nl), _prop(g), sl, g["theta0"], g["z"], us, n_fine, "state-independent")
+    assert not np.allclose(ref[nl - 1]["loglike"], dense[nl - 1]["loglike"], rtol=1e-6)
+    posts = _aem_posts(g, nl)
+    for c in range(g["theta0"].shape[0]):
+        ch = _FedByIndex.__new__(_FedByIndex)
+        ch.feed(g["z"][c], [us[0][c]] + [np.zeros(0) for _ in range(1, nl)])
+        ch._u_full = [None] + [us[k][c] for k in range(1, nl)]
+        with _Normals(ch):
+            HierarchyChain.__init__(ch, posts(), _proposal(g), sl, initial_parameters=g["theta0"][c].copy(),
+                                    adaptive_error_model="state-independent", error_model_covariance="diagonal")
+            ch.sample(n_fine)
+        for k in range(nl):
+            links = ch.level_chain(k)
+            took = np.array([t for t, own in zip(ch.rungs[k].took, ch.rungs[k].own) if own] if k < nl - 1 else ch.rungs[k].took, dtype=np.uint8)
+            assert np.array_equal(took, ref[k]["accepted"][c]), "level %d" % k
+            np.testing.assert_allclose(np.array([ln.parameters for ln in links]), ref[k]["theta"][c], rtol=1e-10, atol=1e-12)
+            if k == nl - 1:
+                np.testing.assert_allclose([ln.posterior for ln in links], ref[k]["logpost"][c], rtol=1e-10)

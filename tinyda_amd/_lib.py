@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtinyda_hip.so")
 TDA_OK = 0
 TDA_ERR_INVALID, TDA_ERR_HIP, TDA_ERR_STATE, TDA_ERR_UNSUPPORTED, TDA_ERR_NUMERIC, TDA_ERR_CALLBACK = -1, -2, -3, -4, -5, -6
 NOISE_ISO, NOISE_DIAG, NOISE_DENSE, NOISE_ADAPTIVE = 0, 1, 2, 3
-AEM_NONE, AEM_STATE_INDEPENDENT, AEM_STATE_DEPENDENT = 0, 1, 2
+AEM_NONE, AEM_STATE_INDEPENDENT, AEM_STATE_DEPENDENT, AEM_STATE_INDEPENDENT_DIAGONAL = 0, 1, 2, 3
 PROP_GRW, PROP_PCN, PROP_AM, PROP_DREAMZ, PROP_INDEPENDENCE, PROP_OWCN, PROP_MALA = 0, 1, 2, 3, 4, 5, 6
 
 

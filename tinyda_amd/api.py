@@ -23,7 +23,7 @@ _DEVICE_PROPOSALS = (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis, DREA
 MAX_LEVELS = 4
 
 
-def _device_plan(posteriors, proposal):
+def _device_plan(posteriors, proposal, diagonal_error_model=False):
     """Lowering pass: returns (list of level descriptions, proposal description) or None."""
     if not 1 <= len(posteriors) <= MAX_LEVELS or type(proposal) not in _DEVICE_PROPOSALS:
         return None
@@ -32,6 +32,14 @@ def _device_plan(posteriors, proposal):
         low = getattr(post, "_lowering", lambda: None)()
         if low is None or low["prior_mean"].shape[0] > 64:
             return None
+        if diagonal_error_model and low["noise_kind"] == _lib.NOISE_ADAPTIVE:
+            # diagonal error model: the adaptive likelihood's covariance must be diagonal and travels as its diagonal
+            cov = np.asarray(low["noise"], dtype=np.float64)
+            if np.count_nonzero(cov - np.diag(np.diag(cov))):
+                return None
+            dg = np.diag(cov).copy()
+            low = dict(low, noise_kind=_lib.NOISE_ISO if np.all(dg == dg[0]) else _lib.NOISE_DIAG,
+                       noise=dg[:1].copy() if np.all(dg == dg[0]) else dg)
         if low["noise_kind"] == _lib.NOISE_ADAPTIVE and (len(posteriors) < 2 or np.asarray(low["data"]).shape[0] > 128):
             return None  # AdaptiveGaussianLogLike: coarse levels of a hierarchy, m <= 128 on the device
         if low["noise_kind"] == _lib.NOISE_DENSE:
@@ -41,6 +49,8 @@ def _device_plan(posteriors, proposal):
             elif len(posteriors) != 1 or isinstance(proposal, DREAMZ) or low["A"].shape[0] > 1024:
                 return None  # linear model: single-level GRW / pCN / AM with m <= 1024 (MFMA quadratic form)
         lows.append(low)
+    if diagonal_error_model and any(lw["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG) for lw in lows):
+        return None  # its Sigma_e is the diagonal noise of the levels
     if isinstance(proposal, DREAMZ) and len(posteriors) != 1 and proposal._shared:
         return None  # below a hierarchy the engine keeps DREAMZ's per-chain archives; DREAM's shared one is single-level
     if any("rosenbrock" in low for low in lows) and not isinstance(proposal, DREAMZ):
@@ -165,11 +175,15 @@ def _wrap_opaque_models(posteriors):
 def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None, subchain_length=1,
            randomize_subchain_length=False, adaptive_error_model=None, store_coarse_chain=True,
            force_sequential=False, force_progress_bar=False, subsampling_rate=None, *, seed=None,
-           backend="auto", device=0, chain_offset=0, distributed=False, overlap_archive_exchange=False):
+           backend="auto", device=0, chain_offset=0, distributed=False, overlap_archive_exchange=False,
+           error_model_covariance="dense"):
     """Extra keyword-only arguments (not in tinyDA): seed, backend ('auto' | 'hip' | 'host'), device, chain_offset, and
     distributed=True: under torch.distributed (one process per GPU) `n_chains` is the GLOBAL chain count, this rank
     samples its contiguous shard (tinyda_amd.distributed.shard_chains) on GPU LOCAL_RANK and returns it with
     'chain_offset' set; chains are keyed by global id, so the union over ranks equals a single-process run.
+    error_model_covariance='diagonal' (with adaptive_error_model='state-independent'; extension): the bias trackers keep and
+    use only the diagonal of their covariance -- O(m) instead of O(m^2) memory and O(m^3) work per chain and level step, any
+    output dimension (include/tinyda_amd.h, TDA_AEM_STATE_INDEPENDENT_DIAGONAL); 'dense' is the reference's model.
     overlap_archive_exchange=True (DREAM's shared archive): the all-gather of a block's new archive rows runs under the next
     block's steps and the rows become visible one block later (tinyda_amd.distributed.run_shared_dream)."""
     if distributed:
@@ -233,7 +247,12 @@ def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None
         else:
             raise TypeError("Initial paramaters must be list, numpy array or None")
 
-    plan = None if backend == "host" else _device_plan(posteriors, proposal)
+    if error_model_covariance not in ("dense", "diagonal"):
+        raise ValueError("error_model_covariance must be 'dense' or 'diagonal'")
+    diag_aem = error_model_covariance == "diagonal" and n_levels > 1 and adaptive_error_model is not None
+    if diag_aem and adaptive_error_model != "state-independent":
+        raise ValueError("the diagonal error model is state-independent")
+    plan = None if backend == "host" else _device_plan(posteriors, proposal, diag_aem)
     if plan is not None and isinstance(proposal, DREAMZ) and n_levels > 1 and (adaptive_error_model is not None or randomize_subchain_length):
         plan = None  # not lowered: host protocol under 'auto'
     if plan is None and backend != "host" and n_levels > 1:
@@ -243,7 +262,7 @@ def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None
         # proposals, level logic, error model, adaptation and records on the device
         wrapped = _wrap_opaque_models(posteriors)
         if wrapped is not None:
-            plan = _device_plan(wrapped, proposal)
+            plan = _device_plan(wrapped, proposal, diag_aem)
             if plan is not None:
                 posteriors = wrapped
     if backend == "hip" and plan is None:
@@ -254,10 +273,11 @@ def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None
                                   chain_offset, distributed, total if distributed else None, overlap_archive_exchange)
         return _sample_device_multilevel(plan, posteriors, iterations, n_chains, initial_parameters, subchain_length,
                                          subchain_lengths, randomize_subchain_length, store_coarse_chain, seed, device,
-                                         chain_offset, adaptive_error_model)
+                                         chain_offset, "state-independent-diagonal" if diag_aem else adaptive_error_model)
     if n_levels > 1:
         return _sample_host_multilevel(posteriors, proposal, iterations, n_chains, initial_parameters, subchain_length,
-                                       subchain_lengths, randomize_subchain_length, adaptive_error_model, store_coarse_chain)
+                                       subchain_lengths, randomize_subchain_length, adaptive_error_model, store_coarse_chain,
+                                       error_model_covariance)
     return _sample_host(posteriors[0], proposal, iterations, n_chains, initial_parameters)
 
 
@@ -276,7 +296,7 @@ def _sample_host(posterior, proposal, iterations, n_chains, initial_parameters):
 
 
 def _sample_host_multilevel(posteriors, proposal, iterations, n_chains, initial_parameters, subchain_length, subchain_lengths,
-                            randomize, error_model, store_coarse_chain):
+                            randomize, error_model, store_coarse_chain, error_model_covariance="dense"):
     """Hierarchies the engine does not lower (models returning (output, qoi), proposals outside the engine's set below a
     hierarchy, more than MAX_LEVELS levels, more than 64 parameters, per-level priors): the reference's protocol on the host,
     one chain after the other (sampler.py:335-368, :441-473), with the reference's result layout (:406-439, :510-547).
@@ -294,7 +314,7 @@ def _sample_host_multilevel(posteriors, proposal, iterations, n_chains, initial_
             for p in posts:
                 p.likelihood = copy.deepcopy(p.likelihood)
         ch = HierarchyChain(posts, copy.deepcopy(proposal), subchain_lengths, initial_parameters[i], error_model,
-                            store_coarse_chain, randomize)
+                            store_coarse_chain, randomize, error_model_covariance)
         ch.sample(iterations)
         chains.append(ch)
     if nl == 2:

@@ -248,6 +248,9 @@ struct tda_engine {
   // adaptive error model
   int aem = 0;
   int aem_m = 0, aem_ld = 64;
+  // diagonal error model (TDA_AEM_STATE_INDEPENDENT_DIAGONAL, tda_kernels_aemd.h): everything [N][m]
+  DevBuf<double> aemd_F[tda::MAXLEV], aemd_Fst, aemd_bias[tda::MAXLEV], aemd_w[tda::MAXLEV], aemd_sig2[tda::MAXLEV], aemd_wfin;
+  DevBuf<double> aemd_mu[tda::MAXLEV], aemd_var[tda::MAXLEV], aemd_md[tda::MAXLEV], aemd_data[tda::MAXLEV];
   DevBuf<double> theta_last;  // DREAMZ below a hierarchy: level-0 state right after a block's last base step (jump distance of the pCR update)
   bool ext_hier = false;  // hierarchy with callback / source-defined levels: sequenced by the host (run_multilevel)
   DevBuf<double> ext_Fcur[tda::MAXLEV], ext_Fst;  // error model there: outputs of the current links [NP][MP], of level j at theta_q [npairs][NP][MP]
@@ -1327,8 +1330,15 @@ void enumerate_state(tda_engine* e, std::vector<StateItem>& v) {
       dev(e->aem_bsig[k]);
       dev(e->aem_mdiff[k]);
       dev(e->ext_Fcur[k]);
+      dev(e->aemd_F[k]);
+      dev(e->aemd_bias[k]);
+      dev(e->aemd_w[k]);
+      dev(e->aemd_mu[k]);
+      dev(e->aemd_var[k]);
+      dev(e->aemd_md[k]);
     }
     dev(e->ext_Fst);
+    dev(e->aemd_Fst);
   }
   if (e->is_dreamz) {
     host(&e->arch_rows, sizeof e->arch_rows);
@@ -1405,7 +1415,7 @@ int tda_engine_set_state(tda_engine* e, const void* blob, int64_t bytes) {
 
 int tda_engine_set_error_model(tda_engine* e, int kind) {
   if (!e) return fail(TDA_ERR_INVALID, "null engine");
-  if (kind < TDA_AEM_NONE || kind > TDA_AEM_STATE_DEPENDENT) return fail(TDA_ERR_INVALID, "Adaptive error model can only be state-dependent, state-independent or None.");
+  if (kind < TDA_AEM_NONE || kind > TDA_AEM_STATE_INDEPENDENT_DIAGONAL) return fail(TDA_ERR_INVALID, "Adaptive error model can only be state-dependent, state-independent or None.");
   if (kind != TDA_AEM_NONE && e->nlev < 2) return fail(TDA_ERR_STATE, "the error model needs at least two levels");
   if (kind == TDA_AEM_STATE_DEPENDENT && e->nlev != 2) return fail(TDA_ERR_UNSUPPORTED, "state-dependent error model is two-level (DA) only");
   e->aem = kind;
@@ -1418,6 +1428,18 @@ int tda_engine_get_error_model(tda_engine* e, int level, double* bias, double* c
   if (level < 0 || level >= e->nlev - 1) return fail(TDA_ERR_INVALID, "level %d has no adaptive likelihood", level);
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  if (e->aem == TDA_AEM_STATE_INDEPENDENT_DIAGONAL) {
+    const int m = e->aem_m;
+    if (bias) HIP_TRY(hipMemcpy(bias, e->aemd_bias[level].p, (size_t)e->N * m * sizeof(double), hipMemcpyDeviceToHost));
+    if (cov_inverse) {
+      std::vector<double> hw((size_t)e->N * m);
+      HIP_TRY(hipMemcpy(hw.data(), e->aemd_w[level].p, hw.size() * sizeof(double), hipMemcpyDeviceToHost));
+      std::fill(cov_inverse, cov_inverse + (size_t)e->N * m * m, 0.0);
+      for (int64_t c = 0; c < e->N; ++c)
+        for (int i = 0; i < m; ++i) cov_inverse[((size_t)c * m + i) * m + i] = hw[(size_t)c * m + i];
+    }
+    return TDA_OK;
+  }
   const int m = e->aem_m, AEM_MP = e->aem_ld;
   if (bias) {
     std::vector<double> hb((size_t)e->NP * AEM_MP);
@@ -1511,6 +1533,104 @@ int tda_engine_get_level_state(tda_engine* e, int level, double* theta, double* 
                           e->ml_ll.p + (size_t)level * e->NP, theta, stats);
 }
 
+
+// ---- diagonal error model (tda_kernels_aemd.h): argument block shared by its three kernels ----
+static void fill_aemd_args(tda_engine* e, AemdArgs& a) {
+  const int nl = e->nlev;
+  a.N = e->N;
+  a.NP = e->NP;
+  a.chain_offset = e->cfg.chain_offset;
+  a.d = e->d;
+  a.DP = e->DP;
+  a.m = e->aem_m;
+  a.nlev = nl;
+  a.is_da = nl == 2;
+  a.prop_kind = e->pp.kind;
+  a.seed = e->cfg.seed;
+  for (int k = 0; k < nl; ++k) {
+    a.data[k] = e->aemd_data[k].p;
+    a.sig2[k] = e->aemd_sig2[k].p;
+    a.Fcur[k] = e->aemd_F[k].p;
+    a.bias[k] = e->aemd_bias[k].p;
+    a.w[k] = e->aemd_w[k].p;
+    a.mu[k] = e->aemd_mu[k].p;
+    a.var[k] = e->aemd_var[k].p;
+    a.md[k] = e->aemd_md[k].p;
+  }
+  a.wfin = e->aemd_wfin.p;
+  a.var_finest = e->levels[nl - 1].var;
+  a.Fst = e->aemd_Fst.p;
+  a.theta = e->ml_theta.p;
+  a.lp = e->ml_lp.p;
+  a.ll = e->ml_ll.p;
+  a.Sst = e->ml_S.p;
+  a.anyacc = e->ml_anyacc.p;
+  a.sid = reinterpret_cast<long long*>(e->ml_sid.p);
+  a.pr_mean = e->prior_mean.p;
+  a.pr_pinv = e->prior_pinv.p;
+  a.pr_lo = e->prior_bounded ? e->prior_lo.p : nullptr;
+  a.pr_hi = e->prior_bounded ? e->prior_hi.p : nullptr;
+  a.logconst = e->prior_logconst;
+}
+
+// set-up at theta0: model outputs of every level through the path the steps use, then k_aemd_init
+static int init_error_model_diagonal(tda_engine* e) {
+  const int nl = e->nlev, d = e->d;
+  const int64_t N = e->N;
+  if (e->randomize) return fail(TDA_ERR_UNSUPPORTED, "randomize_subchain_length together with an error model is not lowered");
+  if (e->prior_kind == PRIOR_DENSE) return fail(TDA_ERR_UNSUPPORTED, "the diagonal error model needs a diagonal prior covariance");
+  if (e->is_dreamz) return fail(TDA_ERR_UNSUPPORTED, "DREAMZ below a hierarchy with an adaptive error model is not lowered");
+  const int m = e->levels[0].m;
+  for (int k = 0; k < nl; ++k) {
+    const Level& lv = e->levels[k];
+    if (lv.m != m) return fail(TDA_ERR_INVALID, "error model: all levels must share the output dimension");
+    if (lv.noise_kind != TDA_NOISE_ISO && lv.noise_kind != TDA_NOISE_DIAG)
+      return fail(TDA_ERR_INVALID, "diagonal error model: level %d needs isotropic or diagonal noise (its variances are Sigma_e)", k);
+    if (lv.model == MODEL_LINEAR && !lv.A_dev.p) return fail(TDA_ERR_STATE, "diagonal error model: linear level %d has no row-major operator", k);
+  }
+  e->aem_m = m;
+  int rc;
+  const size_t nm = (size_t)N * m;
+  const unsigned grid = (unsigned)((N + EXT_WAVES - 1) / EXT_WAVES);
+  for (int k = 0; k < nl; ++k) {
+    const Level& lv = e->levels[k];
+    std::vector<double> data(m), s2(m, lv.var), winv(m, 0.0);
+    HIP_TRY(hipMemcpy(data.data(), lv.udata.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost));
+    if (lv.noise_kind == TDA_NOISE_DIAG) {
+      HIP_TRY(hipMemcpy(winv.data(), lv.uw.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost));
+      for (int o = 0; o < m; ++o) s2[o] = 1.0 / winv[o];
+    }
+    if ((rc = e->aemd_data[k].upload(data)) || (rc = e->aemd_sig2[k].upload(s2))) return rc;
+    if (k == nl - 1) {
+      if (lv.noise_kind == TDA_NOISE_DIAG) {
+        if ((rc = e->aemd_wfin.upload(winv))) return rc;
+      } else {
+        e->aemd_wfin.release();
+      }
+    }
+    if ((rc = e->aemd_F[k].alloc(nm)) || (rc = e->aemd_bias[k].alloc(nm)) || (rc = e->aemd_w[k].alloc(nm)) ||
+        (rc = e->aemd_mu[k].alloc(nm)) || (rc = e->aemd_var[k].alloc(nm)) || (rc = e->aemd_md[k].alloc(nm)))
+      return rc;
+    // F_k(theta0): "proposals" = the initial states, outputs through callback / source / linear evaluation
+    ExtArgs ya{};
+    fill_ext_args(e, lv, ya);
+    ya.mode = 1;
+    ya.theta = e->theta.p;
+    ya.scaling = e->scaling.p;
+    hipLaunchKernelGGL(k_ext_propose, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, ya);
+    if ((rc = ext_model_outputs(e, lv))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->aemd_F[k].p, lv.cb_F.p, nm * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    e->aem_bt[k] = 1;
+  }
+  if ((rc = e->aemd_Fst.alloc((size_t)(nl * (nl - 1) / 2) * nm))) return rc;
+  AemdArgs a{};
+  fill_aemd_args(e, a);
+  hipLaunchKernelGGL(k_aemd_init, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, a);
+  HIP_TRY(hipGetLastError());
+  (void)d;
+  return TDA_OK;
+}
+
 int tda_engine_init(tda_engine* e, const double* theta0) {
   if (!e) return fail(TDA_ERR_INVALID, "null engine");
   if (!e->prior_set || !e->prop_set) return fail(TDA_ERR_STATE, "set_prior and set_proposal must precede init");
@@ -1533,7 +1653,8 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
     // DREAMZ below a hierarchy (the reference's MLDA notebook): its jump needs the chain's growing archive at every base step,
     // so such a hierarchy is sequenced by the host like one with callback / source-defined levels, linear levels included
     const bool dz_hier = e->is_dreamz && e->nlev > 1;
-    e->ext_hier = (n_cb || dz_hier) && e->nlev > 1;
+    const bool aemd = e->aem == TDA_AEM_STATE_INDEPENDENT_DIAGONAL;  // the diagonal error model works on model-output arrays
+    e->ext_hier = (n_cb || dz_hier || aemd) && e->nlev > 1;
     if (e->ext_hier) {  // Delayed Acceptance / MLDA with callback / source-defined models (host-sequenced level actions)
       for (auto& lv : e->levels)  // linear levels may be mixed in (k_ext_linear_eval); anything else may not
         if (lv.model != MODEL_CALLBACK && lv.model != MODEL_USER && (lv.model != MODEL_LINEAR || !lv.A_dev.p))
@@ -1847,7 +1968,9 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
     }
     if ((rc = e->ml_sid.alloc((size_t)nl * NP))) return rc;
     HIP_TRY(hipMemsetAsync(e->ml_sid.p, 0, (size_t)nl * NP * sizeof(int64_t), e->stream));
-    if (e->aem) {
+    if (e->aem == TDA_AEM_STATE_INDEPENDENT_DIAGONAL) {
+      if ((rc = init_error_model_diagonal(e))) return rc;
+    } else if (e->aem) {
       // ---- adaptive error model set-up (chain.py:268-305; :643-678; proposal.py:1407-1467) ----
       if (e->randomize) return fail(TDA_ERR_UNSUPPORTED, "randomize_subchain_length together with an error model is not lowered");
       if (e->prior_kind == PRIOR_DENSE && e->aem == TDA_AEM_STATE_DEPENDENT && e->pp.kind != TDA_PROP_PCN) {}
@@ -2466,6 +2589,37 @@ static int run_ext_hierarchy_block(tda_engine* e, const MLArgs& ma, int64_t S, b
       rp += n;
       s += n;
       cc[0] += (int)n;
+    } else if (e->aem == TDA_AEM_STATE_INDEPENDENT_DIAGONAL) {
+      // base step under the corrected diagonal likelihood (per-chain bias and inverse variances, tda_kernels_aemd.h)
+      const Level& l0 = e->levels[0];
+      ExtArgs pa2{};
+      fill_ext_args(e, l0, pa2);
+      pa2.mode = 0;
+      pa2.prop_kind = e->pp.kind;
+      pa2.theta = e->ml_theta.p;
+      pa2.scaling = e->scaling.p;
+      pa2.inc = e->inc.p;
+      pa2.s = (int)s;
+      hipLaunchKernelGGL(k_ext_propose, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, pa2);
+      int mrc0 = ext_model_outputs(e, l0);
+      if (mrc0) return mrc0;
+      AemdArgs da{};
+      fill_aemd_args(e, da);
+      da.s = (int)s;
+      da.F = l0.cb_F.p;
+      da.prop = l0.cb_prop.p;
+      da.u0 = e->ublk.p;
+      da.sid_value = e->done[0] + s + 1;
+      da.ring = adaptive ? e->ml_ring.p : nullptr;
+      da.ring_P = e->ring_P;
+      da.ring_pos = rp++;
+      da.rec_params = ma.rec_params[0];
+      da.rec_stats = ma.rec_stats[0];
+      da.rec_acc = ma.rec_acc[0];
+      hipLaunchKernelGGL(k_aemd_accept, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, da);
+      HIP_TRY(hipGetLastError());
+      cc[0] += 1;
+      s += 1;
     } else if (e->aem) {
       // base step under the bias-corrected likelihood of the error model (per-chain bias and inverse)
       const Level& l0 = e->levels[0];
@@ -2633,6 +2787,28 @@ static int run_ext_hierarchy_block(tda_engine* e, const MLArgs& ma, int64_t S, b
       hipLaunchKernelGGL(k_ext_propose, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, ya);
       const int mrc = ext_model_outputs(e, lq);
       if (mrc) return mrc;
+      if (e->aem == TDA_AEM_STATE_INDEPENDENT_DIAGONAL) {  // decision, alignment, tracker, bias, update_link: one launch
+        AemdArgs da{};
+        fill_aemd_args(e, da);
+        da.q = q;
+        da.step = e->done[q] + row[q];
+        da.F = lq.cb_F.p;
+        da.b_t = e->aem_bt[q];
+        da.u_rep = ma.u_rep[q] ? ma.u_rep[q] + (size_t)row[q] * N : nullptr;
+        da.ring = adaptive ? e->ml_ring.p : nullptr;
+        da.ring_P = e->ring_P;
+        da.ring_pos = rp++;
+        da.rec_params = ma.rec_params[q] ? ma.rec_params[q] + (size_t)row[q] * N * d : nullptr;
+        da.rec_stats = ma.rec_stats[q] ? ma.rec_stats[q] + (size_t)row[q] * N * 3 : nullptr;
+        da.rec_acc = ma.rec_acc[q] ? ma.rec_acc[q] + (size_t)row[q] * N : nullptr;
+        hipLaunchKernelGGL(k_aemd_action, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, da);
+        HIP_TRY(hipGetLastError());
+        e->aem_bt[q] += 1;
+        cc[k] = 0;
+        cc[q] += 1;
+        row[q] += 1;
+        continue;
+      }
       if (e->aem) {
         ExtAemArgs ga{};
         ga.N = N;

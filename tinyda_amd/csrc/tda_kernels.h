@@ -11,3 +11,4 @@
 #include "tda_kernels_dreamz.h"
 #include "tda_kernels_pooled.h"
 #include "tda_kernels_ext.h"
+#include "tda_kernels_aemd.h"

@@ -223,7 +223,7 @@ class Engine:
         check(self.lib.tda_engine_set_state(self.h, _ptr(blob), blob.size))
 
     def set_error_model(self, kind):
-        code = {None: 0, "state-independent": 1, "state-dependent": 2}[kind]
+        code = {None: 0, "state-independent": 1, "state-dependent": 2, "state-independent-diagonal": 3}[kind]
         check(self.lib.tda_engine_set_error_model(self.h, code))
 
     def error_model_state(self, level, m):

@@ -72,8 +72,12 @@ class HierarchyChain:
     tests/test_host_hierarchy.py)."""
 
     def __init__(self, posteriors, proposal, subchain_lengths, initial_parameters=None, adaptive_error_model=None,
-                 store_coarse_chain=True, randomize_subchain_length=False):
+                 store_coarse_chain=True, randomize_subchain_length=False, error_model_covariance="dense"):
         from .moments import RecursiveSampleMoments, ZeroMeanRecursiveSampleMoments
+
+        if error_model_covariance not in ("dense", "diagonal"):
+            raise ValueError("error_model_covariance must be 'dense' (the reference) or 'diagonal'")
+        self.diagonal_bias = error_model_covariance == "diagonal"  # extension: only the diagonal of a bias covariance is used
 
         if adaptive_error_model not in (None, "state-independent", "state-dependent"):
             raise ValueError("Adaptive error model can only be state-dependent, state-independent or None.")
@@ -134,13 +138,14 @@ class HierarchyChain:
         """hand level q - 1 the bias it is corrected with and re-evaluate its latest link (posterior.update_link)"""
         below = self.rungs[q - 1]
         like = below.posterior.likelihood
+        shape = (lambda sig: np.diag(np.diag(sig))) if self.diagonal_bias else (lambda sig: sig)
         if self.error_model == "state-dependent":
-            like.set_bias(self.last_diff[q], self.trackers[q].get_sigma())
+            like.set_bias(self.last_diff[q], shape(self.trackers[q].get_sigma()))
         elif self.two_level or q == len(self.rungs) - 1:
-            like.set_bias(self.trackers[q].get_mu(), self.trackers[q].get_sigma())
+            like.set_bias(self.trackers[q].get_mu(), shape(self.trackers[q].get_sigma()))
         else:  # biases stack upwards: level q - 1 sees the sum of every tracker from q to the finest (proposal.py:1563-1569)
             stack = self.trackers[q:]
-            like.set_bias(np.sum([t.get_mu() for t in stack], axis=0), np.sum([t.get_sigma() for t in stack], axis=0))
+            like.set_bias(np.sum([t.get_mu() for t in stack], axis=0), shape(np.sum([t.get_sigma() for t in stack], axis=0)))
         below.links[-1] = below.posterior.update_link(below.links[-1])
 
     def _learn_bias(self, q):

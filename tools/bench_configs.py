@@ -38,7 +38,7 @@ def run(name, ms, sl, prop, n_fine, N=4096, d=64):
     print(json.dumps(res))
     e.close()
 
-def run_c5_aem(N=4096, d=64, m=64, n_fine=20):
+def run_c5_aem(N=4096, d=64, m=64, n_fine=20, diagonal=False):
     """C5 with the state-independent adaptive error model: levels share the output dimension (m = 128 is SURVEY
     §8(d)'s C5, the device error-model limit); levels 0/1 AdaptiveGaussianLogLike, level 2 isotropic; AM; subchains [5, 3]."""
     rng = np.random.default_rng(6)
@@ -49,13 +49,13 @@ def run_c5_aem(N=4096, d=64, m=64, n_fine=20):
     e.set_prior(np.zeros(d), np.eye(d))
     for k in range(3):
         A = Af + 0.02 * (2 - k) * rng.standard_normal((m, d)) / 8
-        if k < 2:
+        if k < 2 and not diagonal:
             e.set_level(k, A, y, 3, 0.01 * np.eye(m))
         else:
             e.set_level(k, A, y, 0, 0.01)
     e.set_proposal(2, 1e-4 * np.eye(d), t0=100, period=100)
     e.set_subchains([5, 3])
-    e.set_error_model("state-independent")
+    e.set_error_model("state-independent-diagonal" if diagonal else "state-independent")
     e.init(None)
     rows = e.rows_per_level(n_fine)
     outs = [(torch.empty((r, N, d), dtype=torch.float64, device="cuda"), torch.empty((r, N, 3), dtype=torch.float64, device="cuda"),
@@ -65,7 +65,7 @@ def run_c5_aem(N=4096, d=64, m=64, n_fine=20):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     e.run_levels(n_fine, outs)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(json.dumps(dict(config="C5 + state-independent AEM, common m=%d, AM, subchains [5,3]" % m, chains=N, kernel_ms=e.profile(), fine_iterations=n_fine, seconds=dt,
+    print(json.dumps(dict(config="C5 + state-independent AEM (%s), common m=%d, AM, subchains [5,3]" % ("diagonal extension" if diagonal else "dense, reference", m), chains=N, kernel_ms=e.profile(), fine_iterations=n_fine, seconds=dt,
                           coarse_evals_per_s=N * rows[0] / dt, finest_iterations_per_s=N * n_fine / dt,
                           acceptance=[float(o[2].float().mean().item()) for o in outs])))
     e.close()
@@ -151,8 +151,8 @@ def run_c4(N=8192, d=32, T=400, M0=320, K=16):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] == "c5aem":  # python tools/bench_configs.py c5aem 128 [n_fine]
-        run_c5_aem(m=int(sys.argv[2]), n_fine=int(sys.argv[3]) if len(sys.argv) > 3 else 20)
+    if len(sys.argv) > 2 and sys.argv[1] in ("c5aem", "c5aemd"):  # python tools/bench_configs.py c5aem 128 [n_fine]
+        run_c5_aem(m=int(sys.argv[2]), n_fine=int(sys.argv[3]) if len(sys.argv) > 3 else 20, diagonal=sys.argv[1] == "c5aemd")
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "c3":
         run("C3: DA pCN(0.02) 256/2048 obs, subsampling_rate=10", (256, 2048), [10], dict(kind=1, scaling=0.02), 200)
