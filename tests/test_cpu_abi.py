@@ -1,0 +1,100 @@
+"""libtda_cpu.so -- the C-ABI of include/tinyda_amd.h compiled for the CPU (oracle/tda_cpu_abi.cpp; test / baseline
+infrastructure) -- driven through the SAME ctypes binding and Engine wrapper as the GPU library, against traces recorded from
+tinyDA itself.  No GPU needed: this is how the binding layer is exercised in the CPU test tier."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import tinyda_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def cpu():
+    import __graft_entry__ as g
+
+    g.build()
+    from tinyda_amd import _lib
+
+    return _lib.load_from(g.CPU_ABI_SO), g.CPU_ABI_SO
+
+
+def test_cpu_twin_exports_the_whole_abi(cpu):
+    lib, path = cpu
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "tinyda_amd.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(tda_[a-z_]+)\s*\(", text))
+    out = subprocess.run(["nm", "-D", "--defined-only", path], stdout=subprocess.PIPE, text=True).stdout
+    assert declared <= set(re.findall(r"\bT (tda_[a-z_]+)", out))
+    assert b"cpu twin" in lib.tda_version()
+
+
+@pytest.mark.parametrize("name", ["g1_basic_sampler", "g2_am_small", "g2_am_small_adaptive", "g2b_pcn", "g2_am_c2"])
+def test_cpu_twin_replays_reference_traces(cpu, golden, name):
+    from tinyda_amd.engine import Engine
+
+    lib, _ = cpu
+    g = golden(name)
+    N, T1, d = g["theta"].shape
+    T = T1 - 1
+    e = Engine(N, d, seed=1, lib=lib)
+    e.set_prior(g["prior_mean"], g["prior_cov"])
+    if "noise_var" in g.files:
+        e.set_level(0, g["A"], g["data"], 0, float(g["noise_var"]))
+    else:
+        e.set_level(0, g["A"], g["data"], 0, float(g["noise_cov"][0]))
+    if name.startswith("g1"):
+        e.set_proposal(0, g["C"], scaling=float(g["scaling0"]), adaptive=True, gamma=float(g["gamma"]), period=int(g["period"]))
+    elif name.startswith("g2b"):
+        e.set_proposal(1, None, scaling=float(g["scaling0"]), adaptive=True, gamma=float(g["gamma"]), period=int(g["period"]))
+    else:
+        e.set_proposal(2, g["C0"], sd=float(g["sd"]), epsilon=float(g["epsilon"]), t0=int(g["t0"]), period=int(g["period"]),
+                       adaptive=bool(g["adaptive"]), gamma=float(g["gamma"]))
+    e.init(g["theta0"])
+    e.set_replay(np.swapaxes(g["z"], 0, 1), np.swapaxes(g["u"], 0, 1))
+    params, stats, acc = np.empty((T, N, d)), np.empty((T, N, 3)), np.empty((T, N), dtype=np.uint8)
+    half = T // 2  # a run cut in two continues where it stopped
+    e.run(half, params[:half], stats[:half], acc[:half])
+    e.run(T - half, params[half:], stats[half:], acc[half:])
+    assert np.array_equal(acc, np.swapaxes(g["accepted"][:, 1:], 0, 1))
+    np.testing.assert_allclose(stats[:, :, 2], np.swapaxes(g["logpost"][:, 1:], 0, 1), rtol=1e-10)
+    # (after a covariance swap the proposals carry the last-bit differences between this Cholesky and LAPACK's)
+    np.testing.assert_allclose(params, np.swapaxes(g["theta"][:, 1:], 0, 1), rtol=1e-9, atol=1e-11)
+    st = e.proposal_state(want_am=name.startswith("g2_"))
+    if "scaling" in g.files:
+        np.testing.assert_allclose(st["scaling"], np.atleast_1d(g["scaling"])[-N:] if np.ndim(g["scaling"]) == 1 else g["scaling"][:, -1], rtol=1e-12)
+    if name.startswith("g2_"):
+        np.testing.assert_allclose(st["am_sigma"], g["sigma_hist"][:, -1], rtol=1e-9, atol=1e-12)
+    with pytest.raises(ValueError):  # the wrapper's capacity check
+        e.run(5, params[:3], None, None)
+    e.close()
+
+
+def test_cpu_twin_philox_stream_is_the_contract(cpu):
+    """engine-generated variates (RNG contract of the header) = the oracle's independent restatement; theta0 ~ prior"""
+    from tinyda_amd.engine import Engine
+
+    lib, _ = cpu
+    N, d, T = 5, 7, 9
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((11, d))
+    e = Engine(N, d, seed=(7 << 32) | 12345, chain_offset=3, lib=lib)
+    e.set_prior(np.zeros(d), np.eye(d))
+    e.set_level(0, A, rng.standard_normal(11), 1, 0.5 + rng.random(11))
+    e.set_proposal(2, 0.05 * np.eye(d), t0=4, period=4)
+    e.init(None)
+    z, u = e.set_export(T)
+    e.run(T)
+    st = orc.PhiloxStream((7 << 32) | 12345)
+    chains = np.arange(3, 3 + N)
+    for t in range(T):
+        np.testing.assert_allclose(z[t], st.normals(chains, t, d), rtol=1e-13, atol=1e-15)
+        assert np.array_equal(u[t], st.uniform(chains, t))
+    zz, uu = e.rng_probe(4)
+    np.testing.assert_allclose(zz, z[4], rtol=0, atol=0)
+    e.close()
+    with pytest.raises(Exception, match="CPU twin"):
+        Engine(4, 3, n_levels=2, lib=lib)

@@ -190,6 +190,17 @@ def load():
     return lib
 
 
-def check(rc):
+def load_from(path):
+    """Bind ANOTHER library exporting the same C-ABI (tests and bench.py's cpu_baseline load oracle/_build/libtda_cpu.so,
+    the CPU twin of the ABI, this way).  Never used by the package itself: nothing here falls back to it."""
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def check(rc, lib=None):
     if rc != TDA_OK:
-        raise EngineError("tinyda_amd engine error %d: %s" % (rc, load().tda_last_error().decode()))
+        raise EngineError("tinyda_amd engine error %d: %s" % (rc, (lib or load()).tda_last_error().decode()))

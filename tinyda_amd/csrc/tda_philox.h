@@ -2,7 +2,17 @@
 // "RNG stream").  Host + device; integer part is bit-exact everywhere, the Box-Muller map uses the
 // platform's log / sqrt / sincospi.
 #pragma once
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#else  // plain C++ (the CPU twin of the ABI, oracle/tda_cpu_abi.cpp): the same integer generator and variate maps on the host
+#include <cmath>
+#ifndef __host__
+#define __host__
+#endif
+#ifndef __device__
+#define __device__
+#endif
+#endif
 #include <stdint.h>
 
 namespace tda {

@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import check
+from ._lib import check as _check
 
 
 def _ptr(a):
@@ -41,17 +41,22 @@ def pinned_empty(shape, dtype=np.float64):
 class Engine:
     """One many-chain MH engine on one GPU (one per process under torch.distributed)."""
 
-    def __init__(self, n_chains, dim, seed=0, device=0, chain_offset=0, n_levels=1, block_steps=0, stream=None):
-        self.lib = _lib.load()
+    def __init__(self, n_chains, dim, seed=0, device=0, chain_offset=0, n_levels=1, block_steps=0, stream=None, lib=None):
+        # lib: another library exporting the same C-ABI (_lib.load_from): tests and the CPU baseline drive the CPU twin of
+        # the ABI through this very class; the package itself never passes it
+        self.lib = _lib.load() if lib is None else lib
         self.n_chains, self.dim, self.n_levels = int(n_chains), int(dim), int(n_levels)
         self.device = int(device)
         self.subchain_lengths = []
         cfg = _lib.tda_config(C.sizeof(_lib.tda_config), device, n_chains, chain_offset, dim, n_levels, seed,
                               stream, block_steps, 0)
         h = C.c_void_p()
-        check(self.lib.tda_engine_create(C.byref(cfg), C.byref(h)))
+        self._ck(self.lib.tda_engine_create(C.byref(cfg), C.byref(h)))
         self.h = h
         self._keep = []
+
+    def _ck(self, rc):
+        _check(rc, self.lib)
 
     def close(self):
         if getattr(self, "h", None):
@@ -68,14 +73,14 @@ class Engine:
     def set_prior(self, mean, cov):
         mean, cov = _f64(mean), _f64(cov)
         assert mean.shape == (self.dim,) and cov.shape == (self.dim, self.dim)
-        check(self.lib.tda_engine_set_prior(self.h, _ptr(mean), _ptr(cov)))
+        self._ck(self.lib.tda_engine_set_prior(self.h, _ptr(mean), _ptr(cov)))
 
     def set_level(self, level, A, data, noise_kind, noise, b=None):
         A, data, noise = _f64(A), _f64(data), _f64(np.atleast_1d(noise))
         m = A.shape[0]
         assert A.shape == (m, self.dim) and data.shape == (m,)
         b = None if b is None else _f64(b)
-        check(self.lib.tda_engine_set_level(self.h, level, m, _ptr(A), _ptr(b), _ptr(data), noise_kind, _ptr(noise)))
+        self._ck(self.lib.tda_engine_set_level(self.h, level, m, _ptr(A), _ptr(b), _ptr(data), noise_kind, _ptr(noise)))
 
     def set_proposal(self, kind, C_=None, scaling=1.0, adaptive=False, gamma=1.01, period=100, sd=None,
                      epsilon=1e-6, t0=0, block_moments=False, q_mean=None, state_operator=None, noise_operator=None):
@@ -83,24 +88,24 @@ class Engine:
         p = _lib.tda_proposal_params(C.sizeof(_lib.tda_proposal_params), kind, scaling, int(adaptive), period, gamma,
                                      _ptr(Cm), -1.0 if sd is None else sd, epsilon, t0, int(block_moments),
                                      _ptr(None if q_mean is None else _f64(q_mean)))
-        check(self.lib.tda_engine_set_proposal(self.h, C.byref(p)))
+        self._ck(self.lib.tda_engine_set_proposal(self.h, C.byref(p)))
         if state_operator is not None:  # OperatorWeightedCrankNicolson (kind 5): theta' = S theta + N chol(C_prior) z
             So, No = _f64(state_operator), _f64(noise_operator)
             assert So.shape == (self.dim, self.dim) and No.shape == (self.dim, self.dim)
-            check(self.lib.tda_engine_set_proposal_operators(self.h, _ptr(So), _ptr(No)))
+            self._ck(self.lib.tda_engine_set_proposal_operators(self.h, _ptr(So), _ptr(No)))
 
     def set_prior_joint(self, kinds, loc, scale):
         """JointPrior of scalar components: kinds[j] 0 = norm(loc, scale), 1 = uniform(loc, scale)"""
         kinds = np.ascontiguousarray(np.asarray(kinds, dtype=np.int32))
         loc, scale = _f64(loc), _f64(scale)
         assert kinds.shape == loc.shape == scale.shape == (self.dim,)
-        check(self.lib.tda_engine_set_prior_joint(self.h, _ptr(kinds), _ptr(loc), _ptr(scale)))
+        self._ck(self.lib.tda_engine_set_prior_joint(self.h, _ptr(kinds), _ptr(loc), _ptr(scale)))
 
     def set_level_source(self, level, source, data, noise_kind, noise):
         """forward model as HIP source defining `__device__ double tda_forward(const double* theta, int dim, int o)`"""
         data = _f64(np.atleast_1d(data))
         noise = _f64(np.atleast_1d(noise))
-        check(self.lib.tda_engine_set_level_source(self.h, level, source.encode(), data.size, _ptr(data), noise_kind, _ptr(noise)))
+        self._ck(self.lib.tda_engine_set_level_source(self.h, level, source.encode(), data.size, _ptr(data), noise_kind, _ptr(noise)))
 
     def set_level_callback(self, level, fn, data, noise_kind, noise, inplace=False):
         """forward model behind a batched host callback: fn maps the (n_chains, dim) proposals of a step to the
@@ -130,7 +135,7 @@ class Engine:
         if not hasattr(self, "_cbs"):
             self._cbs = {}
         self._cbs[level] = _lib.FORWARD_BATCH_FN(trampoline)  # keep the thunks alive as long as the engine
-        check(self.lib.tda_engine_set_level_callback(self.h, level, C.cast(self._cbs[level], C.c_void_p), None, m, _ptr(data),
+        self._ck(self.lib.tda_engine_set_level_callback(self.h, level, C.cast(self._cbs[level], C.c_void_p), None, m, _ptr(data),
                                                      noise_kind, _ptr(noise)))
 
     def _check_run(self, rc):
@@ -138,10 +143,10 @@ class Engine:
         if rc == _lib.TDA_ERR_CALLBACK and exc is not None:
             self._cb_exc = None
             raise exc
-        check(rc)
+        self._ck(rc)
 
     def set_level_rosenbrock(self, level, a=1.0, b=10.0, data=0.0, noise_var=1.0):
-        check(self.lib.tda_engine_set_level_rosenbrock(self.h, level, a, b, data, noise_var))
+        self._ck(self.lib.tda_engine_set_level_rosenbrock(self.h, level, a, b, data, noise_var))
 
     def set_proposal_dreamz(self, M0, delta=1, b=5e-2, b_star=1e-6, nCR=3, adaptive=False, gamma=1.01, period=100,
                             shared=False, sync_every=0, capacity=None):
@@ -149,14 +154,14 @@ class Engine:
         p = _lib.tda_dreamz_params(C.sizeof(_lib.tda_dreamz_params), M0, delta, nCR, b, b_star, int(adaptive), period, gamma,
                                    int(shared), sync_every, cap)
         self._dz = dict(M0=M0, delta=delta, nCR=nCR, shared=bool(shared))
-        check(self.lib.tda_engine_set_proposal_dreamz(self.h, C.byref(p)))
+        self._ck(self.lib.tda_engine_set_proposal_dreamz(self.h, C.byref(p)))
 
     def set_archive(self, Z0=None):
         if Z0 is not None:
             Z0 = _f64(Z0)
             want = (self._dz["M0"], self.dim) if self._dz["shared"] else (self.n_chains, self._dz["M0"], self.dim)
             assert Z0.shape == want, (Z0.shape, want)
-        check(self.lib.tda_engine_set_archive(self.h, _ptr(Z0)))
+        self._ck(self.lib.tda_engine_set_archive(self.h, _ptr(Z0)))
 
     def set_replay_dreamz(self, r, mcr, sub_u, forced, e_u, eps_n, u):
         """all arrays step-major: r [T,N,delta,2], mcr/forced/u [T,N], sub_u/e_u/eps_n [T,N,d]"""
@@ -165,34 +170,34 @@ class Engine:
         sub_u, e_u, eps_n, u = _f64(sub_u), _f64(e_u), _f64(eps_n), _f64(u)
         T = u.shape[0]
         assert r.shape == (T, self.n_chains, self._dz["delta"], 2) and sub_u.shape == (T, self.n_chains, self.dim)
-        check(self.lib.tda_engine_set_replay_dreamz(self.h, _ptr(r), _ptr(mcr), _ptr(sub_u), _ptr(forced), _ptr(e_u),
+        self._ck(self.lib.tda_engine_set_replay_dreamz(self.h, _ptr(r), _ptr(mcr), _ptr(sub_u), _ptr(forced), _ptr(e_u),
                                                     _ptr(eps_n), _ptr(u), T))
 
     def dreamz_state(self):
         pcr = np.empty((self.n_chains, self._dz["nCR"]))
         rows = np.zeros(1, dtype=np.int64)
-        check(self.lib.tda_engine_get_dreamz_state(self.h, _ptr(pcr), _ptr(rows)))
+        self._ck(self.lib.tda_engine_get_dreamz_state(self.h, _ptr(pcr), _ptr(rows)))
         return dict(pCR=pcr, archive_rows=int(rows[0]))
 
     def set_archive_auto_append(self, on):
-        check(self.lib.tda_engine_set_archive_auto_append(self.h, int(on)))
+        self._ck(self.lib.tda_engine_set_archive_auto_append(self.h, int(on)))
 
     def archive_take(self, rows=None):
         """shared archive: number of pending steps; if `rows` ([steps, chains, dim] array / tensor) is given it is filled"""
         n = np.zeros(1, dtype=np.int64)
-        check(self.lib.tda_engine_archive_take(self.h, _ptr(rows), _ptr(n)))
+        self._ck(self.lib.tda_engine_archive_take(self.h, _ptr(rows), _ptr(n)))
         return int(n[0])
 
     def archive_append(self, rows):
         """rows: [n_rows, dim] numpy array or torch tensor (device ok)"""
         n = rows.shape[0]
-        check(self.lib.tda_engine_archive_append(self.h, _ptr(rows), n))
+        self._ck(self.lib.tda_engine_archive_append(self.h, _ptr(rows), n))
 
     def set_subchains(self, lengths, randomize=False):
         arr = np.ascontiguousarray(np.asarray(lengths, dtype=np.int32))
         assert arr.shape == (self.n_levels - 1,)
         self.subchain_lengths = [int(x) for x in arr]
-        check(self.lib.tda_engine_set_subchains(self.h, _ptr(arr), int(randomize)))
+        self._ck(self.lib.tda_engine_set_subchains(self.h, _ptr(arr), int(randomize)))
 
     def reduce_moments(self, rows, out=None):
         """[count, sum x, sum x x^T] over a device record buffer [..., dim]; `out` torch tensor (device) or None -> numpy"""
@@ -201,34 +206,34 @@ class Engine:
             n *= int(sdim)
         if out is None:
             out = np.empty(1 + self.dim + self.dim * self.dim)
-        check(self.lib.tda_engine_reduce_moments(self.h, _ptr(rows), n, _ptr(out)))
+        self._ck(self.lib.tda_engine_reduce_moments(self.h, _ptr(rows), n, _ptr(out)))
         return out
 
     def set_proposal_covariance(self, Cm):
         Cm = _f64(Cm)
         assert Cm.shape == (self.dim, self.dim)
-        check(self.lib.tda_engine_set_proposal_covariance(self.h, _ptr(Cm)))
+        self._ck(self.lib.tda_engine_set_proposal_covariance(self.h, _ptr(Cm)))
 
     def get_state(self):
         """checkpoint: opaque bytes (numpy uint8) holding chain, proposal and counter state"""
         n = int(self.lib.tda_engine_state_size(self.h))
         if n < 0:
-            check(n)
+            self._ck(n)
         blob = np.empty(n, dtype=np.uint8)
-        check(self.lib.tda_engine_get_state(self.h, _ptr(blob), n))
+        self._ck(self.lib.tda_engine_get_state(self.h, _ptr(blob), n))
         return blob
 
     def set_state(self, blob):
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
-        check(self.lib.tda_engine_set_state(self.h, _ptr(blob), blob.size))
+        self._ck(self.lib.tda_engine_set_state(self.h, _ptr(blob), blob.size))
 
     def set_error_model(self, kind):
         code = {None: 0, "state-independent": 1, "state-dependent": 2, "state-independent-diagonal": 3}[kind]
-        check(self.lib.tda_engine_set_error_model(self.h, code))
+        self._ck(self.lib.tda_engine_set_error_model(self.h, code))
 
     def error_model_state(self, level, m):
         bias, P = np.empty((self.n_chains, m)), np.empty((self.n_chains, m, m))
-        check(self.lib.tda_engine_get_error_model(self.h, level, _ptr(bias), _ptr(P)))
+        self._ck(self.lib.tda_engine_get_error_model(self.h, level, _ptr(bias), _ptr(P)))
         return bias, P
 
     def init(self, theta0=None):
@@ -241,26 +246,26 @@ class Engine:
     def set_replay(self, z, u):
         """z [steps, chains, dim], u [steps, chains]"""
         if z is None:
-            check(self.lib.tda_engine_set_replay(self.h, None, None, 0))
+            self._ck(self.lib.tda_engine_set_replay(self.h, None, None, 0))
             return
         z, u = _f64(z), _f64(u)
         assert z.shape[1:] == (self.n_chains, self.dim) and u.shape == z.shape[:2]
-        check(self.lib.tda_engine_set_replay(self.h, _ptr(z), _ptr(u), z.shape[0]))
+        self._ck(self.lib.tda_engine_set_replay(self.h, _ptr(z), _ptr(u), z.shape[0]))
 
     def set_replay_level(self, level, u):
         """uniforms of level >= 1 as [steps of that level, chains]; level = -1: DA promoted index in [-L, -1]"""
         if u is None:
-            check(self.lib.tda_engine_set_replay_level(self.h, level, None, 0))
+            self._ck(self.lib.tda_engine_set_replay_level(self.h, level, None, 0))
             return
         u = _f64(u)
         assert u.shape[1] == self.n_chains
-        check(self.lib.tda_engine_set_replay_level(self.h, level, _ptr(u), u.shape[0]))
+        self._ck(self.lib.tda_engine_set_replay_level(self.h, level, _ptr(u), u.shape[0]))
 
     def set_export(self, n_steps):
         z = np.zeros((n_steps, self.n_chains, self.dim))
         u = np.zeros((n_steps, self.n_chains))
         self._keep = [z, u]
-        check(self.lib.tda_engine_set_export(self.h, _ptr(z), _ptr(u), n_steps))
+        self._ck(self.lib.tda_engine_set_export(self.h, _ptr(z), _ptr(u), n_steps))
         return z, u
 
     # -- running ------------------------------------------------------------------------
@@ -316,7 +321,7 @@ class Engine:
 
     def level_state(self, level):
         th, st = np.empty((self.n_chains, self.dim)), np.empty((self.n_chains, 3))
-        check(self.lib.tda_engine_get_level_state(self.h, level, _ptr(th), _ptr(st)))
+        self._ck(self.lib.tda_engine_get_level_state(self.h, level, _ptr(th), _ptr(st)))
         return th, st
 
     def run_host(self, n_iterations):
@@ -328,11 +333,11 @@ class Engine:
         return params, stats, acc
 
     def sync(self):
-        check(self.lib.tda_engine_sync(self.h))
+        self._ck(self.lib.tda_engine_sync(self.h))
 
     def current(self):
         th, st = np.empty((self.n_chains, self.dim)), np.empty((self.n_chains, 3))
-        check(self.lib.tda_engine_get_current(self.h, _ptr(th), _ptr(st)))
+        self._ck(self.lib.tda_engine_get_current(self.h, _ptr(th), _ptr(st)))
         return th, st
 
     def proposal_state(self, want_am=False):
@@ -340,35 +345,35 @@ class Engine:
         sc, Cm, cnt = np.empty(N), np.empty((N, d, d)), np.zeros(2, dtype=np.int64)
         mu = np.empty((N, d)) if want_am else None
         sg = np.empty((N, d, d)) if want_am else None
-        check(self.lib.tda_engine_get_proposal_state(self.h, _ptr(sc), _ptr(Cm), _ptr(mu), _ptr(sg), _ptr(cnt)))
+        self._ck(self.lib.tda_engine_get_proposal_state(self.h, _ptr(sc), _ptr(Cm), _ptr(mu), _ptr(sg), _ptr(cnt)))
         return dict(scaling=sc, C=Cm, am_mu=mu, am_sigma=sg, t=int(cnt[0]), k=int(cnt[1]))
 
     def proposal_state_scaling(self):
         sc = np.empty(self.n_chains)
-        check(self.lib.tda_engine_get_proposal_state(self.h, _ptr(sc), None, None, None, None))
+        self._ck(self.lib.tda_engine_get_proposal_state(self.h, _ptr(sc), None, None, None, None))
         return sc
 
     def flags(self):
         f = np.zeros(self.n_chains, dtype=np.int32)
-        check(self.lib.tda_engine_get_flags(self.h, _ptr(f)))
+        self._ck(self.lib.tda_engine_get_flags(self.h, _ptr(f)))
         return f
 
     def evaluate(self, theta, level=0):
         theta = _f64(theta)
         n = theta.shape[0]
         st = np.empty((n, 3))
-        check(self.lib.tda_engine_evaluate(self.h, level, _ptr(theta), n, _ptr(st)))
+        self._ck(self.lib.tda_engine_evaluate(self.h, level, _ptr(theta), n, _ptr(st)))
         return st
 
     def rng_probe(self, step):
         z, u = np.empty((self.n_chains, self.dim)), np.empty(self.n_chains)
-        check(self.lib.tda_engine_rng_probe(self.h, step, _ptr(z), _ptr(u)))
+        self._ck(self.lib.tda_engine_rng_probe(self.h, step, _ptr(z), _ptr(u)))
         return z, u
 
     def set_profiling(self, on):
-        check(self.lib.tda_engine_set_profiling(self.h, int(on)))
+        self._ck(self.lib.tda_engine_set_profiling(self.h, int(on)))
 
     def profile(self):
         p = _lib.tda_profile(C.sizeof(_lib.tda_profile))
-        check(self.lib.tda_engine_get_profile(self.h, C.byref(p)))
+        self._ck(self.lib.tda_engine_get_profile(self.h, C.byref(p)))
         return {k: getattr(p, k) for k, _ in p._fields_ if k != "struct_size"}
