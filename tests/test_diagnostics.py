@@ -1,8 +1,14 @@
-"""ESS / R-hat: ArviZ is not importable here and the reference pins no values ('parity
-unpinned'), so the estimators are pinned on processes with known answers."""
+"""ESS / R-hat.  ArviZ is not importable here and the reference pins no values ('parity unpinned'), so the
+estimators are pinned two ways: (1) the product's NumPy implementation (tinyda_amd.summaries; the HIP one in
+tests/test_gpu_diag.py) against oracle/ess_oracle.py, an independent restatement of Vehtari et al. (2021) that shares no code
+path with it (explicit lagged sums instead of FFTs, its own tie-averaged ranks), on the paper's stress cases -- heavy tails,
+antithetic chains, chains that disagree, a chain stuck on ties; (2) both against processes whose effective sample size is
+known in closed form."""
 import numpy as np
+import pytest
 
 import tinyda_amd as tda
+from oracle import ess_oracle as eo
 
 
 def _ar1(rho, chains, n, seed):
@@ -15,20 +21,56 @@ def _ar1(rho, chains, n, seed):
     return x
 
 
-def test_ess_iid_and_ar1():
-    x = _ar1(0.0, 8, 2000, 1)
-    assert abs(tda.ess_bulk(x) / x.size - 1) < 0.1
-    for rho in (0.5, 0.9):
-        x = _ar1(rho, 16, 4000, 2)
-        expect = x.size * (1 - rho) / (1 + rho)
-        assert abs(tda.ess_bulk(x) / expect - 1) < 0.15, (rho, tda.ess_bulk(x), expect)
-    assert abs(tda.rhat(_ar1(0.3, 8, 2000, 3)) - 1) < 0.01
-    shifted = _ar1(0.3, 4, 1000, 4)
-    shifted[0] += 3.0
-    assert tda.rhat(shifted) > 1.2
+def cases():
+    rng = np.random.default_rng(11)
+    out = {}
+    out["iid"] = _ar1(0.0, 4, 600, 1)
+    out["ar1_0.9"] = _ar1(0.9, 6, 900, 2)
+    out["antithetic_-0.7"] = _ar1(-0.7, 4, 800, 3)  # negative autocorrelation: ESS above the number of draws (paper sec. 3.2)
+    out["cauchy"] = np.tan(np.pi * (rng.random((4, 700)) - 0.5))  # infinite variance: only rank-normalisation makes sense of it (sec. 4.1)
+    heavy = _ar1(0.6, 4, 700, 4)
+    out["heavy_ar1"] = np.sign(heavy) * np.abs(heavy) ** 3
+    shifted = _ar1(0.3, 4, 500, 5)
+    shifted[0] += 2.0
+    out["one_chain_off"] = shifted  # chains disagree in location (sec. 4.2)
+    scaled = _ar1(0.3, 4, 500, 6)
+    scaled[1] *= 4.0
+    out["one_chain_wide"] = scaled  # same location, different scale: the folded R-hat catches it
+    sticky = _ar1(0.5, 3, 401, 7)
+    sticky[:, 100:160] = sticky[:, 99:100]  # a run of rejections: exact ties, odd draw count
+    out["ties_odd"] = sticky
+    out["short"] = _ar1(0.2, 2, 9, 8)
+    return out
+
+
+@pytest.mark.parametrize("name", list(cases()))
+def test_product_numpy_matches_the_oracle(name):
+    x = cases()[name]
+    np.testing.assert_allclose(tda.ess_bulk(x), eo.ess_bulk(x), rtol=1e-9)
+    np.testing.assert_allclose(tda.rhat(x), eo.rhat(x), rtol=1e-10)
+
+
+def test_known_answers():
+    """AR(1): ESS = S (1 - rho) / (1 + rho); iid heavy tails: ESS ~ S after rank normalisation; disagreement shows in R-hat"""
+    for est in (tda.ess_bulk, eo.ess_bulk):
+        x = _ar1(0.0, 8, 2000, 1)
+        assert abs(est(x) / x.size - 1) < 0.1
+        for rho in (0.5, 0.9):
+            x = _ar1(rho, 16, 4000 if est is tda.ess_bulk else 1500, 2)
+            expect = x.size * (1 - rho) / (1 + rho)
+            assert abs(est(x) / expect - 1) < 0.2, (rho, est(x), expect)
+        x = _ar1(-0.5, 8, 1500, 9)
+        assert est(x) > 1.8 * x.size  # antithetic: (1 + 0.5) / (1 - 0.5) = 3 in the limit, capped by S log10 S
+        c = cases()["cauchy"]
+        assert abs(est(c) / c.size - 1) < 0.15
+    for r in (tda.rhat, eo.rhat):
+        assert abs(r(_ar1(0.3, 8, 2000, 3)) - 1) < 0.01
+        assert r(cases()["one_chain_off"]) > 1.2
+        assert r(cases()["one_chain_wide"]) > 1.05
 
 
 def test_ess_summary_layout():
     x = np.stack([_ar1(0.5, 6, 800, s).T for s in range(3)], axis=2)  # [draws, chains, dim]
     s = tda.ess_summary(x, burnin=100)
     assert s["ess"].shape == (3,) and s["ess_min"] <= s["ess_median"]
+    np.testing.assert_allclose(s["ess"][1], eo.ess_bulk(x[100:, :, 1].T), rtol=1e-9)

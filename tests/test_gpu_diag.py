@@ -1,4 +1,5 @@
-"""On-device bulk ESS / R-hat (tda_diag_ess_rhat) against the NumPy implementation in tinyda_amd.summaries."""
+"""On-device bulk ESS / R-hat (tda_diag_ess_rhat) against oracle/ess_oracle.py, the independent restatement of Vehtari et al.
+(2021) that also checks the package's NumPy implementation (tests/test_diagnostics.py)."""
 import numpy as np
 import pytest
 
@@ -20,9 +21,10 @@ def _chains(T, N, d, seed, rho, sticky):
 
 
 @pytest.mark.parametrize("T,N,d,burnin", [(400, 16, 3, 0), (257, 5, 2, 31), (1200, 64, 4, 200)])
-def test_device_ess_rhat_matches_numpy(T, N, d, burnin):
+def test_device_ess_rhat_matches_the_oracle(T, N, d, burnin):
     import torch
 
+    from oracle import ess_oracle as eo
     from tinyda_amd import summaries as sm
 
     x = _chains(T, N, d, seed=T + N, rho=0.9, sticky=0.6)
@@ -30,9 +32,26 @@ def test_device_ess_rhat_matches_numpy(T, N, d, burnin):
     out = sm.ess_rhat_device(dev, burnin=burnin)
     for j in range(d):
         xs = x[burnin:, :, j].T
-        np.testing.assert_allclose(out["ess"][j], sm.ess_bulk(xs), rtol=1e-8)
-        np.testing.assert_allclose(out["rhat"][j], sm.rhat(xs), rtol=1e-10)
+        np.testing.assert_allclose(out["ess"][j], eo.ess_bulk(xs), rtol=1e-8)
+        np.testing.assert_allclose(out["rhat"][j], eo.rhat(xs), rtol=1e-10)
     assert out["rhat"][-1] > out["rhat"][0]
+
+
+def test_device_ess_rhat_on_the_stress_cases():
+    """heavy tails, antithetic chains, disagreeing chains, runs of ties with an odd number of draws (tests/test_diagnostics.py)"""
+    import torch
+
+    from oracle import ess_oracle as eo
+    from tests.test_diagnostics import cases
+    from tinyda_amd import summaries as sm
+
+    for name, x in cases().items():
+        if x.shape[1] < 16:
+            continue
+        dev = torch.tensor(np.ascontiguousarray(x.T[:, :, None]), dtype=torch.float64, device="cuda")  # [draws, chains, 1]
+        out = sm.ess_rhat_device(dev)
+        np.testing.assert_allclose(out["ess"][0], eo.ess_bulk(x), rtol=1e-8, err_msg=name)
+        np.testing.assert_allclose(out["rhat"][0], eo.rhat(x), rtol=1e-10, err_msg=name)
 
 
 def test_device_diag_rejects_host_pointers():
