@@ -2967,7 +2967,8 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
   }
   const int prow = e->prior_kind == PRIOR_DENSE ? e->prior_ncb * 16 : 0;
   const size_t lds = ((size_t)16 * (DP + 2) + 128 + off + prow + (e->aem ? 16 * (e->levels[0].m_pad + 2) + 16 : 0)) * sizeof(double);
-  if (lds > 160 * 1024) return fail(TDA_ERR_UNSUPPORTED, "levels need %zu bytes of LDS staging", lds);
+  if (!e->ext_hier && lds > 160 * 1024)  // (host-sequenced hierarchies stage nothing: their level kernels stream the model outputs)
+    return fail(TDA_ERR_UNSUPPORTED, "levels need %zu bytes of LDS staging", lds);
 
   if (e->profiling) {
     for (auto& t : e->timed) {

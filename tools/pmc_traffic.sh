@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 for pass in 1 2; do
   if [ $pass = 1 ]; then C="FETCH_SIZE"; else C="WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; fi
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc$pass -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-ess > /tmp/pmc$pass.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc$pass -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --pilot 1000 --burnin 2000 --no-cpu-baseline --no-ess > /tmp/pmc$pass.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, json, statistics as st, collections
@@ -28,4 +28,4 @@ for k, c in res.items():
 json.dump(out, open("/tmp/pmc_out.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
-cp /tmp/pmc_out.json $GRAFT_REPO_ROOT/gpurun_out/pmc_g.json
+cp /tmp/pmc_out.json $GRAFT_REPO_ROOT/gpurun_out/r02_pmc_raw.json

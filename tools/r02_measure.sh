@@ -1,0 +1,12 @@
+# round-2 measurement pass on the GPU box: tests, the driver's bench command, rocprofv3 kernel stats of it, PMC traffic, configs
+cd $GRAFT_REPO_ROOT
+python -u -m pytest tests -x -q -m gpu > gpurun_out/r02_gputests.log 2>&1; echo "tests rc=$?" | tee -a gpurun_out/r02_progress.log
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r02_bench.json 2> gpurun_out/r02_bench.err; echo "bench rc=$?" | tee -a gpurun_out/r02_progress.log
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r02 -- python3 $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > /tmp/prof_r02.log 2>&1; find /tmp/prof_r02 -name "*kernel_stats.csv" -exec cp {} $GRAFT_REPO_ROOT/gpurun_out/r02_kernel_stats.csv \; ; tail -1 /tmp/prof_r02.log | cut -c1-300 > $GRAFT_REPO_ROOT/gpurun_out/r02_bench_under_rocprof.json)
+echo "rocprof done" | tee -a gpurun_out/r02_progress.log
+bash tools/pmc_traffic.sh > gpurun_out/r02_pmc.log 2>&1; echo "pmc rc=$?" | tee -a gpurun_out/r02_progress.log
+python -u tools/bench_configs.py > gpurun_out/r02_configs.jsonl 2>&1; echo "configs rc=$?" | tee -a gpurun_out/r02_progress.log
+python -u tools/bench_configs.py c5aem 128 >> gpurun_out/r02_configs.jsonl 2>&1
+python -u tools/bench_configs.py c5aemd 128 >> gpurun_out/r02_configs.jsonl 2>&1
+python -u tools/bench_configs.py c5aemd 1024 10 >> gpurun_out/r02_configs.jsonl 2>&1
+echo "all done" | tee -a gpurun_out/r02_progress.log
