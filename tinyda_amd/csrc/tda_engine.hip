@@ -373,9 +373,22 @@ template <int DPAD>
 int launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st) {
   if (da_lean_eligible(a)) {
     const size_t lds8 = (size_t)da_lds_doubles<DPAD>(a.lds_total) * sizeof(double);
-    if (lds8 > 64 * 1024)
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_da_steps<DPAD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
-    hipLaunchKernelGGL((k_da_steps<DPAD>), dim3((unsigned)tiles), dim3(512), lds8, st, a);
+    const bool pcn = a.prop_kind == TDA_PROP_PCN, dg0 = a.lv[0].noise_kind == 1, one = a.lv[0].ncb <= 8;
+#define TDA_DA_LAUNCH(RBV, PCNV, DGV)                                                                                              \
+  do {                                                                                                                             \
+    if (lds8 > 64 * 1024)                                                                                                          \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_da_steps<DPAD, RBV, PCNV, DGV>),                                \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));                                         \
+    hipLaunchKernelGGL((k_da_steps<DPAD, RBV, PCNV, DGV>), dim3((unsigned)tiles), dim3(512), lds8, st, a);                         \
+  } while (0)
+    if (one) {
+      if (pcn) { if (dg0) TDA_DA_LAUNCH(1, true, true); else TDA_DA_LAUNCH(1, true, false); }
+      else { if (dg0) TDA_DA_LAUNCH(1, false, true); else TDA_DA_LAUNCH(1, false, false); }
+    } else {
+      if (pcn) { if (dg0) TDA_DA_LAUNCH(2, true, true); else TDA_DA_LAUNCH(2, true, false); }
+      else { if (dg0) TDA_DA_LAUNCH(2, false, true); else TDA_DA_LAUNCH(2, false, false); }
+    }
+#undef TDA_DA_LAUNCH
     return TDA_OK;
   }
   switch (a.nlev) {

@@ -550,9 +550,12 @@ __device__ long long g_da_trace[128 * 8 * 8];  // debug builds only: [step][wave
 #define DA_STAMP(i)
 #endif
 
-template <int DPAD>
+// RB = 16-row blocks of the coarse operator per wave (1: m0 <= 128, 2: m0 <= 256); PCN: CrankNicolson proposals; DIAG0: diagonal noise
+// on the coarse level -- template parameters, because as run-time flags they cost a select per model output and step in the
+// vector section that decides when the SIMD's other wave may start its burst
+template <int DPAD, int RB, bool PCN, bool DIAG0>
 __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
-  constexpr int NW = 8, NT = 64 * NW, TPC = 4 * NW, RB = 2;
+  constexpr int NW = 8, NT = 64 * NW, TPC = 4 * NW;
   constexpr int KS = DPAD / 4, K2 = DPAD / 8, LDP = DPAD + 2, RSX = KS + 2;
   constexpr int EPT = DPAD >= TPC ? DPAD / TPC : 1;
   constexpr int QACT = DPAD / EPT;
@@ -588,7 +591,7 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
     s_pinv[i] = a.pr.pinv[i];
   }
   const bool prior_std = a.pr.kind == PRIOR_STANDARD;
-  const bool dg0 = a.lv[0].noise_kind == 1;
+  constexpr bool dg0 = DIAG0;
 
   double cur0[EPT], cur1[EPT], prp[EPT];
   double sxa[EPT], sxb[EPT], sxc[EPT], sxd[EPT];  // increments of steps s .. s + 3 as loaded (a load has a whole step to arrive)
@@ -602,7 +605,7 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
   int anyacc0 = a.anyacc[gcl];
   const int anyacc1 = a.anyacc[a.NP + gcl];  // the finest level has no level above that would read it: carried unchanged
   const double scal_t = a.scaling[gct];
-  const bool is_pcn = a.prop_kind == 1;
+  constexpr bool is_pcn = PCN;
   const double keep_t = is_pcn ? sqrt(1.0 - scal_t * scal_t) : 1.0;
   const double scal_l = a.scaling[gcl];
   const double keep_l = is_pcn ? sqrt(1.0 - scal_l * scal_l) : 1.0;  // the same factor for this lane's chain (model outputs)
@@ -613,7 +616,9 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
   int64_t ringpos = a.ring_pos;
   const int L0 = a.sl[0];
   const int ncb0 = a.lv[0].ncb;
-  const bool has_b[RB] = {wave < ncb0, wave + NW < ncb0};
+  bool has_b[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) has_b[i] = wave + i * NW < ncb0;
 
   // where this thread's elements of an increment go in the fragment-ordered tile: row = fragment lane (dim & 3) * 16 + chain
   int st_dst[EPT];
@@ -758,7 +763,7 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         yv[i][r] = s_stage[a.lds_y[0] + ob[i] + 4 * r];
-        wv[i][r] = s_stage[a.lds_w[0] + ob[i] + 4 * r];  // (isotropic noise: an unused read of valid memory)
+        wv[i][r] = dg0 ? s_stage[a.lds_w[0] + ob[i] + 4 * r] : 1.0;
       }
     double sse = 0.0;
 #pragma unroll
