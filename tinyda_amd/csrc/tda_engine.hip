@@ -564,6 +564,11 @@ int ext_level_dense(tda_engine* /*e*/, Level& lv, int m, const double* cov) {
 int ext_model_outputs(tda_engine* e, const Level& lv) {
   if (lv.model == MODEL_USER) return launch_user_eval(lv.ufn_eval, e->N, e->d, lv.m, lv.cb_prop.p, lv.cb_F.p, e->stream);
   if (lv.model == MODEL_LINEAR) {
+    if (lv.Apk.p) {  // on the matrix cores, every operator fragment serving a 16-chain tile
+      DISPATCH_DPAD(e->DP, hipLaunchKernelGGL((k_linear_outputs<DPAD>), dim3((unsigned)(e->NP / 16)), dim3(256), 0, e->stream, (long long)e->N,
+                                              e->d, lv.m, lv.Apk.p, lv.ncb, lv.b_dev.p, lv.cb_prop.p, lv.cb_F.p));
+      return TDA_OK;
+    }
     hipLaunchKernelGGL(k_ext_linear_eval, dim3((unsigned)((e->N + EXT_WAVES - 1) / EXT_WAVES)), dim3(64 * EXT_WAVES), 0, e->stream,
                        (long long)e->N, e->d, lv.m, lv.A_dev.p, lv.b_dev.p, lv.cb_prop.p, lv.cb_F.p);
     return TDA_OK;

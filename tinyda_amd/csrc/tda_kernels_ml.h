@@ -948,6 +948,67 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Model outputs of a LINEAR level inside a host-sequenced hierarchy (callback / source-defined levels beside it, DREAMZ at the
+// base, the diagonal error model): F[N][m] = prop[N][d] A^T + b for all chains on the matrix cores.  One workgroup of four
+// waves per 16-chain tile; the chains' parameters are gathered once into MFMA B fragments, the observation blocks are dealt
+// over the waves, A comes as the packed fragments the fused kernels use (two register sets, next block in flight), so every
+// fragment read serves 16 chains.  (The first version -- one wave per chain, every wave streaming all of A -- moved
+// N m d 8 bytes through L2 per launch: 256 MB at 4096 chains, m = 128, 2 GB at m = 1024.)
+// ------------------------------------------------------------------------------------------------
+template <int DPAD>
+__global__ void __launch_bounds__(256) k_linear_outputs(long long N, int d, int m, const double* __restrict__ Apk, int ncb,
+                                                        const double* __restrict__ bvec, const double* __restrict__ prop,
+                                                        double* __restrict__ F) {
+  constexpr int KS = DPAD / 4, K2 = DPAD / 8, NWV = 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lc = lane & 15, hi = lane >> 4;
+  const long long c = (long long)blockIdx.x * 16 + lc;
+  double th[KS];
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) th[kk] = (c < N && 4 * kk + hi < d) ? prop[c * d + 4 * kk + hi] : 0.0;
+  const FragSrc src = frag_src(Apk, lane);
+  double2 fa[K2], fb[K2];
+  if (wave < ncb) frag_load_buf<DPAD>(src, wave, fa);
+  for (int cb = wave; cb < ncb; cb += 2 * NWV) {
+    const bool more = cb + NWV < ncb;
+    frag_load_buf<DPAD>(src, more ? cb + NWV : cb, fb);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int k = 0; k < K2; ++k) {
+        acc = mfma_f64(fa[k].x, th[2 * k], acc);
+        acc = mfma_f64(fa[k].y, th[2 * k + 1], acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = cb * 16 + hi + 4 * r;
+        if (c < N && o < m) F[c * m + o] = acc[r] + bvec[o];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!more) break;
+    frag_load_buf<DPAD>(src, cb + 2 * NWV < ncb ? cb + 2 * NWV : cb, fa);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int k = 0; k < K2; ++k) {
+        acc = mfma_f64(fb[k].x, th[2 * k], acc);
+        acc = mfma_f64(fb[k].y, th[2 * k + 1], acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = (cb + NWV) * 16 + hi + 4 * r;
+        if (c < N && o < m) F[c * m + o] = acc[r] + bvec[o];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Adaptive error model (Cui et al. 2019): one step of level q >= 1 for every chain, one wave per chain, followed by
 // the error-model update of level q-1.  Used in the host-sequenced mode (MLArgs::cascade = 0): the tile kernel
 // advances the base level, this kernel performs what DAChain.sample (chain.py:353-402, 446-523) / MLDA.make_mlda_proposal
