@@ -158,3 +158,81 @@ def test_c5_error_model_full_size(eng_mod):
     np.testing.assert_allclose(Sf[-1, idx, 2], lp + ll, rtol=1e-10)
     assert np.allclose(P, np.swapaxes(P, 1, 2), rtol=1e-9, atol=1e-9) and (np.einsum("cii->ci", P) > 0).all()
     assert 0.02 < outs[0][2].mean() < 0.98 and 0.02 < Af_.mean() <= 1.0
+
+
+def test_c5_diagonal_error_model_full_size(eng_mod):
+    """C5 with the diagonal error model at an output dimension the dense model cannot hold: 4096 chains, d = 64, three linear
+    levels of 1024 outputs, AdaptiveMetropolis, subchains [5, 3].  Invariants: finest records carry the finest posterior
+    (oracle re-evaluation), biases finite and of the size of the model discrepancy, every level moves, the skip rule holds."""
+    N, d, m, n_fine = 4096, 64, 1024, 3
+    rng = np.random.default_rng(16)
+    truth = rng.standard_normal(d)
+    Af = rng.standard_normal((m, d)) / 8
+    y = Af @ truth + 0.1 * rng.standard_normal(m)
+    As = [Af + 0.02 * (2 - k) * rng.standard_normal((m, d)) / 8 for k in range(3)]
+    e = eng_mod.Engine(N, d, seed=12, n_levels=3)
+    e.set_prior(np.zeros(d), np.eye(d))
+    for k in range(3):
+        e.set_level(k, As[k], y, 0, 0.01)
+    e.set_proposal(2, 1e-4 * np.eye(d), t0=100, period=100)
+    e.set_subchains([5, 3])
+    e.set_error_model("state-independent-diagonal")
+    th0 = truth + 0.02 * rng.standard_normal((N, d))
+    e.init(th0)
+    outs = e.run_levels_host(n_fine)
+    bias0, _ = e.error_model_state(0, m, covariance=False)
+    bias1, _ = e.error_model_state(1, m, covariance=False)
+    assert not e.flags().any()
+    e.close()
+    Pf, Sf, Af_ = outs[2]
+    assert all(np.isfinite(o[0]).all() and np.isfinite(o[1]).all() for o in outs)
+    lvl = orc.LinearGaussianLevel(As[2], y, "iso", 0.01, orc.MVNPrior(np.zeros(d), np.eye(d)))
+    idx = rng.choice(N, 64, replace=False)
+    lp, ll, _ = lvl.evaluate(Pf[-1, idx])
+    np.testing.assert_allclose(Sf[-1, idx, 2], lp + ll, rtol=1e-10)
+    # the bias of level k estimates F_{k+1}(theta) - F_k(theta) at the states the chains visit (chain.py:1016-1040)
+    for k, bias in ((0, bias0), (1, bias1)):
+        assert np.isfinite(bias).all()
+        gap = (As[k + 1] - As[k]) @ truth
+        assert np.abs(bias.mean(axis=0) - gap).max() < 0.2 * np.abs(gap).max() + 0.05
+    A1 = outs[1][2].reshape(n_fine, 3, N).astype(bool)
+    A0 = outs[0][2].reshape(n_fine, 3, 5, N).astype(bool)
+    assert not (A1 & ~A0.any(axis=2)).any()
+    assert not (Af_.astype(bool) & ~A1.any(axis=1)).any()
+    assert 0.02 < outs[0][2].mean() < 0.98 and 0.02 < Af_.mean() <= 1.0
+
+
+def test_mlda_dreamz_full_size(eng_mod):
+    """DREAM(Z) below a three-level hierarchy (the reference's MLDA notebook, cells 20-23) at 4096 chains: per-chain archives
+    grow by one row per base step, records of every level re-evaluate with the oracle, the skip rule holds."""
+    d, N, sl, n_fine, M0 = 16, 4096, [4, 2], 6, 48
+    rng = np.random.default_rng(26)
+    truth = rng.standard_normal(d) * 0.5
+    lv = []
+    for m in (32, 64, 128):
+        A = rng.standard_normal((m, d)) / 4
+        lv.append((A, A @ truth + 0.1 * rng.standard_normal(m)))
+    base_steps = n_fine * sl[0] * sl[1]
+    e = eng_mod.Engine(N, d, seed=14, n_levels=3)
+    e.set_prior(np.zeros(d), np.eye(d))
+    for k, (A, y) in enumerate(lv):
+        e.set_level(k, A, y, 0, 0.01)
+    e.set_proposal_dreamz(M0, delta=1, nCR=3, adaptive=True, period=8, capacity=M0 + base_steps)
+    e.set_subchains(sl)
+    e.set_archive(rng.standard_normal((N, M0, d)))
+    e.init(np.tile(truth, (N, 1)) + 0.05 * rng.standard_normal((N, d)))
+    th0, _ = e.level_state(2)
+    outs = e.run_levels_host(n_fine)
+    st = e.dreamz_state()
+    e.close()
+    assert st["archive_rows"] == M0 + base_steps
+    np.testing.assert_allclose(st["pCR"].sum(axis=1), 1.0, rtol=1e-12)
+    prior = orc.MVNPrior(np.zeros(d), np.eye(d))
+    levels = [orc.LinearGaussianLevel(A, y, "iso", 0.01, prior) for A, y in lv]
+    for k in range(3):
+        _check_level_records(outs[k][0], outs[k][1], outs[k][2], th0, levels[k], 96, 30 + k)
+    A1 = outs[1][2].reshape(n_fine, sl[1], N).astype(bool)
+    A0 = outs[0][2].reshape(n_fine, sl[1], sl[0], N).astype(bool)
+    assert not (A1 & ~A0.any(axis=2)).any()
+    assert not (outs[2][2].astype(bool) & ~A1.any(axis=1)).any()
+    assert 0.02 < outs[0][2].mean() < 0.98

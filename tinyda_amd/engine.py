@@ -231,8 +231,10 @@ class Engine:
         code = {None: 0, "state-independent": 1, "state-dependent": 2, "state-independent-diagonal": 3}[kind]
         self._ck(self.lib.tda_engine_set_error_model(self.h, code))
 
-    def error_model_state(self, level, m):
-        bias, P = np.empty((self.n_chains, m)), np.empty((self.n_chains, m, m))
+    def error_model_state(self, level, m, covariance=True):
+        """bias [chains, m] and (Sigma_e + Sigma_bias)^-1 [chains, m, m] of one level (covariance=False: bias only, None)"""
+        bias = np.empty((self.n_chains, m))
+        P = np.empty((self.n_chains, m, m)) if covariance else None
         self._ck(self.lib.tda_engine_get_error_model(self.h, level, _ptr(bias), _ptr(P)))
         return bias, P
 
