@@ -124,9 +124,26 @@ def cpu_baseline(A, y, target_seconds=12.0):
     rate = cores * 50 / t_cal
     n_chains = int(max(cores, min(4096, round(rate * target_seconds / T / cores) * cores)))
     dt = run(n_chains, T)
-    return {"value": n_chains * T / dt, "unit": "evals/s", "cores": cores, "kind": "port",
-            "sample": "%d chains x %d MH iterations of the same workload through the CPU build of the C-ABI (libtda_cpu.so, "
-                      "OpenMP over chains, %.1f s)" % (n_chains, T, dt)}
+    out = {"value": n_chains * T / dt, "unit": "evals/s", "cores": cores, "kind": "port",
+           "sample": "%d chains x %d MH iterations of the same workload through the CPU build of the C-ABI (libtda_cpu.so, "
+                     "OpenMP over chains, %.1f s)" % (n_chains, T, dt)}
+    # the reference's cost profile next to it -- one chain at a time in NumPy / SciPy with the SVD-based draw
+    # and scipy's logpdf on every step (oracle/tinyda_oracle.py::reference_shaped_am_chain), one core, ~2 s
+    try:
+        from oracle import tinyda_oracle as orc
+
+        th0 = np.random.default_rng(3).standard_normal(D)
+        n_ref = 400
+        orc.reference_shaped_am_chain(A, y, SIGMA ** 2, th0, 20, 1e-4 * np.eye(D))
+        t0 = time.perf_counter()
+        orc.reference_shaped_am_chain(A, y, SIGMA ** 2, th0, n_ref, 1e-4 * np.eye(D))
+        dt_ref = time.perf_counter() - t0
+        out["reference_shaped"] = {"value": n_ref / dt_ref, "unit": "evals/s", "cores": 1, "kind": "port",
+                                   "sample": "1 chain x %d MH iterations, chain-at-a-time NumPy / SciPy with the reference's per-step "
+                                             "calls (SVD-based multivariate_normal draw, scipy logpdf, three outer products), %.1f s" % (n_ref, dt_ref)}
+    except Exception as ex:  # the port's number above stands on its own
+        out["reference_shaped"] = {"error": repr(ex)}
+    return out
 
 
 def latest_pmc_traffic():

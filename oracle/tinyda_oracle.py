@@ -864,3 +864,41 @@ def run_multilevel_aem(levels, proposal, subchain_lengths, theta0, z, u_levels, 
         out.append(dict(theta=np.swapaxes(np.array(r["theta"]), 0, 1), logprior=lpk, loglike=llk, logpost=lpk + llk,
                         accepted=np.array(r["accepted"]).T.astype(np.uint8)))
     return out, dict(bias=bias_tot, b_mu=b_mu, b_sigma=b_sig, cov_inv=cov_inv)
+
+
+# ----------------------------------------------------------------------------------------
+# the reference's cost profile (bench.py cpu_baseline): ONE chain at a time, every call the reference
+# makes per step -- scipy's frozen multivariate_normal.logpdf (posterior.py:92), the forward model, the isotropic
+# log-likelihood (distributions.py:295-298), np.random.multivariate_normal with its SVD of the proposal covariance on every
+# draw (proposal.py:249-251), the accept test (chain.py:104-119) and the RecursiveSampleMoments update with its three outer
+# products (utils.py:113-122; proposal.py:509-510 for the swap).  Timing aid, not a parity path.
+# ----------------------------------------------------------------------------------------
+def reference_shaped_am_chain(A, y, sigma2, theta0, n_steps, C0, t0=100, period=100, epsilon=1e-6, seed=0):
+    import scipy.stats as stats
+
+    d = A.shape[1]
+    rs = np.random.RandomState(seed)
+    prior = stats.multivariate_normal(np.zeros(d), np.eye(d))
+    sd = min(1.0, 2.4 ** 2 / d)
+    theta = np.array(theta0, dtype=float)
+    r = A @ theta - y
+    logpost = prior.logpdf(theta) + -0.5 * (r @ r) / sigma2
+    C = np.array(C0, dtype=float)
+    mu, sigma, t = theta.copy(), np.zeros((d, d)), 1
+    accepted = 0
+    for k in range(n_steps):
+        prop = theta + rs.multivariate_normal(np.zeros(d), C)
+        r = A @ prop - y
+        lp = prior.logpdf(prop) + -0.5 * (r @ r) / sigma2
+        with np.errstate(over="ignore"):
+            alpha = np.exp(lp - logpost)
+        if rs.random_sample() < alpha:
+            theta, logpost = prop, lp
+            accepted += 1
+        mu_new = (1 / (t + 1)) * (t * mu + theta)
+        sigma = (t - 1) / t * sigma + sd / t * (t * np.outer(mu, mu) - (t + 1) * np.outer(mu_new, mu_new) + np.outer(theta, theta) + epsilon * np.eye(d))
+        mu = mu_new
+        t += 1
+        if (k + 1) >= t0 and (k + 1) % period == 0:
+            C = sigma.copy()
+    return theta, accepted / max(n_steps, 1)

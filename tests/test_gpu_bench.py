@@ -40,6 +40,7 @@ def test_bench_with_the_drivers_arguments():
     assert 0.0 < rf["whole_pipeline_frac"] <= rf["frac"]
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    assert cb["reference_shaped"].get("value", 0) > 0, cb["reference_shaped"]  # the reference's cost profile, one core
     assert "roofline_hbm_step_synchronous" not in out
     assert "ess" in out and "max_rhat" in out["ess"], out.get("ess_error")
     if out["ess"]["valid"]:

@@ -1,5 +1,5 @@
 import time, numpy as np, scipy.stats as st, sys, os
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tinyda_amd as tda
 d, m, N, T = 64, 1024, 4096, 1000
 rng = np.random.default_rng(1)
