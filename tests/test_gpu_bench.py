@@ -145,3 +145,21 @@ def test_short_multilevel_buffers_are_refused():
         e.run_levels(10, [bufs(10), bufs(10)])  # the coarse level needs 30 rows
     e.run_levels(10, [bufs(30), bufs(10)])
     e.close()
+
+
+def test_collectives_on_rccl_with_one_rank():
+    """tools/rccl_smoke.py under torch.distributed.run, backend nccl (= RCCL), world size 1: every collective the N > 1 path
+    issues (archive all_gather blocking and overlapped, pooled-moment all_reduce, timing all_reduce, barrier) runs on the real
+    library and leaves the one-rank results bit-identical"""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TINYDA_BENCH_ONE_GPU"):
+        env.pop(k, None)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "tools", "rccl_smoke.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["ok"] and out["backend"] == "nccl"
+    assert all(v for k, v in out.items() if k.endswith("_identical"))

@@ -23,6 +23,17 @@ def shard_chains(n_total, rank, world):
     return offset, count
 
 
+def _collectives_active():
+    """True when the collectives of this module should actually run: a process group of more than one rank, or of ONE rank
+    with TINYDA_FORCE_COLLECTIVES=1 (tools/rccl_smoke.py: on a one-GPU box that is the only way to put the very RCCL calls
+    of the N > 1 path -- all_gather, all_reduce, stream ordering of async work -- on real hardware)."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("TINYDA_FORCE_COLLECTIVES") == "1"
+
+
 def init_process_group(backend=None):
     import torch
     import torch.distributed as dist
@@ -30,7 +41,8 @@ def init_process_group(backend=None):
     rank, local_rank, world = env_rank_world()
     # the host driver of this pool only supports dmabuf IPC: without it RCCL fails with hipIpcGetMemHandle: invalid argument
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if world > 1 and not dist.is_initialized():
+    forced = os.environ.get("TINYDA_FORCE_COLLECTIVES") == "1" and "WORLD_SIZE" in os.environ
+    if (world > 1 or forced) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -84,7 +96,7 @@ def gather_archive_rows(local_rows):
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collectives_active():
         return local_rows.reshape(-1, local_rows.shape[-1]).contiguous()
     parts = [torch.empty_like(local_rows) for _ in range(dist.get_world_size())]
     dist.all_gather(parts, local_rows.contiguous())
@@ -116,7 +128,7 @@ def run_shared_dream(engine, n_iterations, sync_every, params=None, stats=None, 
     import torch
     import torch.distributed as dist
 
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    multi = _collectives_active()
     world = dist.get_world_size() if multi else 1
     N, d = engine.n_chains, engine.dim
     if not overlap:
@@ -208,7 +220,7 @@ class PooledAdaptiveMetropolis:
 
         part = torch.empty_like(self.sums)
         self.e.reduce_moments(rows, part)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if _collectives_active():
             dist.all_reduce(part)  # RCCL: {n, sum x, sum x x^T}
         self.sums += part
 
