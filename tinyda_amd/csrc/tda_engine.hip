@@ -276,6 +276,7 @@ struct tda_engine {
   bool arch_set = false, arch_given = false, auto_append = true;  // arch_given: the caller supplied the initial archive
   std::vector<double> Z0_h;
   int64_t arch_rows = 0;    // rows currently in the archive(s)
+  int64_t sums_rows = 0;    // shared archive: rows already in zsum / zsq (the column sums are caught up at adaptation boundaries only)
   int64_t arch_cap = 0;
   int64_t pending_steps = 0;  // shared mode: steps whose states are in blk_hist but not yet appended
   DevBuf<double> arch, zsum, zsq, dz_pCR, dz_LCR, dz_Delta, dz_coef, dz_epsm, theta_prev, blk_states, blk_hist;
@@ -1360,6 +1361,7 @@ void enumerate_state(tda_engine* e, std::vector<StateItem>& v) {
   }
   if (e->is_dreamz) {
     host(&e->arch_rows, sizeof e->arch_rows);
+    host(&e->sums_rows, sizeof e->sums_rows);
     host(&e->pending_steps, sizeof e->pending_steps);
     dev(e->arch);
     dev(e->zsum);
@@ -1774,6 +1776,7 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
       }
     }
     e->arch_rows = M0;
+    e->sums_rows = 0;
     const size_t nsum = (size_t)(sh ? 1 : NP) * DP;
     std::vector<double> zero(nsum, 0.0), pcr((size_t)NP * MAX_NCR, 0.0), ones((size_t)NP * MAX_NCR, 1.0), zer2((size_t)NP * MAX_NCR, 0.0);
     for (int64_t c = 0; c < NP; ++c)
@@ -3471,19 +3474,25 @@ static int dreamz_sums_catchup(tda_engine* e, int64_t row0, int64_t nrows, bool 
   aa.nrows = nrows;
   aa.M_total = row0 + nrows;
   if (e->dz.shared) {
-    if (nrows > 0) {  // chunked column sums in parallel, then one wave accumulates the chunks in order
-      const int64_t nb = (nrows + COLSUM_CHUNK - 1) / COLSUM_CHUNK;
+    // The column sums only feed the crossover adaptation (np.var(Z, axis=0), proposal.py:800), so appended rows are summed
+    // when a boundary asks for them -- [sums_rows, row0 + nrows) in one pass -- and not after every exchange interval (two
+    // launches per block, 18 % of the kernel time of C4 at an interval of 16 steps).  Chunked column sums in parallel, then
+    // one workgroup accumulates the chunks in a fixed order: deterministic for a given sequence of appends and boundaries.
+    if (!boundary) return TDA_OK;
+    const int64_t upto = row0 + nrows, from = e->sums_rows;
+    if (upto > from) {
+      const int64_t nb = (upto - from + COLSUM_CHUNK - 1) / COLSUM_CHUNK;
       if (e->dz_partial.n < (size_t)nb * 2 * e->DP) {
         HIP_TRY(hipStreamSynchronize(e->stream));
         int rc = e->dz_partial.alloc((size_t)nb * 2 * e->DP);
         if (rc) return rc;
       }
-      DISPATCH_DPAD(e->DP, launch_colsum<DPAD>(e->arch.p, row0, nrows, e->dz_partial.p, nb, e->stream));
+      DISPATCH_DPAD(e->DP, launch_colsum<DPAD>(e->arch.p, from, upto - from, e->dz_partial.p, nb, e->stream));
       DISPATCH_DPAD(e->DP, launch_colsum_final<DPAD>(e->dz_partial.p, nb, e->zsum.p, e->zsq.p, e->stream));
+      e->sums_rows = upto;
     }
-    if (!boundary) return TDA_OK;
     aa.nrows = 0;  // ... then every chain adapts against the finished sums
-    aa.M_total = row0 + nrows;
+    aa.M_total = upto;
   }
   aa.boundary = boundary;
   aa.do_scale = scale;

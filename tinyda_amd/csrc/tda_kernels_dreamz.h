@@ -91,16 +91,32 @@ __global__ void __launch_bounds__(64) k_dreamz_draw(const DreamDrawArgs a) {
   constexpr int HALF = DPAD / 2;
   const bool philox_normals = a.sub_rep == nullptr;  // wave-uniform
   double zp0 = 0.0, zp1 = 0.0;
+  constexpr int SPP = DPAD / 8;  // steps per pass of the per-chain scalar blocks (8 lanes per step)
+  u32x4 xs_pass{0u, 0u, 0u, 0u};
   for (int s = 0; s < a.S; ++s) {
     const uint32_t step = (uint32_t)(a.step0 + s);
     const int64_t M = a.M_base + (a.grow ? s : 0);
     const size_t row = (size_t)s * a.N + c;  // replay / export row (real chains only)
-    // The per-chain scalars of a step -- delta row pairs, the crossover draw, the accept uniform -- are delta + 2 Philox
-    // blocks; lanes 0 .. delta + 1 of the chain evaluate one each in a single pass (each used to be a pass of its own
-    // in which all but a few lanes idled), the others repeat the crossover block
+    // The per-chain scalars of a step -- delta row pairs, the crossover draw, the accept uniform -- are delta + 2 <= 6 Philox
+    // blocks.  The chain's DPAD lanes evaluate them for DPAD / 8 steps in ONE pass (lane = 8 * step-in-pass + kind; a pass
+    // per step left all but delta + 2 lanes repeating a block: 0.75 of the 2.5 generator calls per lane and step at d = 32)
+    // and every step fetches its values with shuffles.
     const bool acc_lane = lane == a.delta + 1;
-    const u32x4 xs = philox4x32_10(u32x4{acc_lane ? 0u : (uint32_t)(lane < a.delta ? lane : a.delta), step, gc,
-                                         acc_lane ? (uint32_t)STREAM_ACCEPT : (uint32_t)STREAM_DREAM}, k0, k1);
+    if (s % SPP == 0) {
+      const int kind = lane & 7;
+      const bool acc_k = kind == a.delta + 1;
+      xs_pass = philox4x32_10(u32x4{acc_k ? 0u : (uint32_t)(kind < a.delta ? kind : a.delta), step + (uint32_t)(lane >> 3), gc,
+                                    acc_k ? (uint32_t)STREAM_ACCEPT : (uint32_t)STREAM_DREAM}, k0, k1);
+    }
+    const int slot = seg * DPAD + 8 * (s % SPP);
+    u32x4 xs;  // lanes < delta: their row-pair block; lane delta + 1: the accept block (x, y)
+    {
+      const int src = slot + (lane < a.delta ? lane : a.delta + 1);
+      xs.x = (uint32_t)__shfl((int)xs_pass.x, src);
+      xs.y = (uint32_t)__shfl((int)xs_pass.y, src);
+      xs.z = 0u;
+      xs.w = 0u;
+    }
     // ---- archive row pairs (proposal.py:823-826) ----
     int r1 = 0, r2 = 0;
     if (lane < a.delta) {
@@ -127,8 +143,8 @@ __global__ void __launch_bounds__(64) k_dreamz_draw(const DreamDrawArgs a) {
     // ---- crossover index and the index forced when the subspace is empty (proposal.py:829-839) ----
     int forced;
     {
-      const int src = seg * DPAD + a.delta;  // the lane that evaluated the crossover block
-      const u32x4 x = u32x4{(uint32_t)__shfl((int)xs.x, src), (uint32_t)__shfl((int)xs.y, src), (uint32_t)__shfl((int)xs.z, src), 0u};
+      const int src = slot + a.delta;  // the lane that evaluated this step's crossover block
+      const u32x4 x = u32x4{(uint32_t)__shfl((int)xs_pass.x, src), (uint32_t)__shfl((int)xs_pass.y, src), (uint32_t)__shfl((int)xs_pass.z, src), 0u};
       if (a.mcr_rep && real_chain) {
         mcr = a.mcr_rep[row];
         forced = a.forced_rep[row];

@@ -135,8 +135,13 @@ def run_shared_dream(engine, n_iterations, sync_every, params=None, stats=None, 
         if not multi:
             # one process: its rows are all rows; the engine appends each `sync_every`-step block in place (same archive
             # contents and order as the exchange below produces with one rank), no copies, no host synchronisation
+            # ONE call: the engine cuts the run into `sync_every`-step blocks itself (tda_engine_set_proposal_dreamz), and a
+            # call per block from here left the GPU idle a third of the time (C4: 29 us of host work per 117 us block)
             engine.set_archive_auto_append(True)
-            for done in range(0, n_iterations, sync_every):
+            if getattr(engine, "_dz", {}).get("sync_every") == sync_every:
+                engine.run(n_iterations, params, stats, accepted)
+                return
+            for done in range(0, n_iterations, sync_every):  # an interval other than the engine's own: block by block
                 sl = slice(done, min(done + sync_every, n_iterations))
                 engine.run(sl.stop - sl.start, None if params is None else params[sl], None if stats is None else stats[sl],
                            None if accepted is None else accepted[sl])

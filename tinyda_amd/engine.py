@@ -153,7 +153,7 @@ class Engine:
         cap = int(capacity if capacity is not None else M0)
         p = _lib.tda_dreamz_params(C.sizeof(_lib.tda_dreamz_params), M0, delta, nCR, b, b_star, int(adaptive), period, gamma,
                                    int(shared), sync_every, cap)
-        self._dz = dict(M0=M0, delta=delta, nCR=nCR, shared=bool(shared))
+        self._dz = dict(M0=M0, delta=delta, nCR=nCR, shared=bool(shared), sync_every=int(sync_every))
         self._ck(self.lib.tda_engine_set_proposal_dreamz(self.h, C.byref(p)))
 
     def set_archive(self, Z0=None):

@@ -140,7 +140,6 @@ def run_c4(N=8192, d=32, T=400, M0=320, K=16):
     stats = torch.empty((T, N, 3), dtype=torch.float64, device="cuda")
     acc = torch.empty((T, N), dtype=torch.uint8, device="cuda")
     tdist.run_shared_dream(e, 48, K, params, stats, acc)  # warm-up
-    e.set_profiling(True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     tdist.run_shared_dream(e, T, K, params, stats, acc)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
