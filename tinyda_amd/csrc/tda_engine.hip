@@ -406,6 +406,17 @@ void launch_dz_draw(const DreamDrawArgs& a, hipStream_t st) {
 }
 template <int DPAD>
 void launch_dz_steps(const DreamStepArgs& a, size_t lds, hipStream_t st) {
+  // the built-in non-linear model under a diagonal prior: chains as lane groups of a wave, no tile, no barriers
+  // (TINYDA_DZ_WAVE=0: the 16-chain tile kernel, for A/B measurements)
+  static const bool wave_ok = [] {
+    const char* v = getenv("TINYDA_DZ_WAVE");
+    return !(v && v[0] == '0');
+  }();
+  if (wave_ok && a.model == MODEL_ROSENBROCK && a.pr.kind != PRIOR_DENSE) {
+    constexpr int CPW = 64 / (DPAD >= 16 ? 16 : DPAD);
+    hipLaunchKernelGGL(k_dreamz_steps_wave<DPAD>, dim3((unsigned)(a.NP / CPW)), dim3(64), 0, st, a);
+    return;
+  }
   hipLaunchKernelGGL(k_dreamz_steps<DPAD>, dim3((unsigned)(a.NP / 16)), dim3(256), lds, st, a);
 }
 template <int DPAD>

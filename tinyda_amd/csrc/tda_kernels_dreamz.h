@@ -437,6 +437,149 @@ __global__ void __launch_bounds__(256, 2) k_dreamz_steps(const DreamStepArgs a) 
   }
 }
 
+// sum over the LPC lanes of a chain, every lane receives the same bits (rotations / xor butterfly: commutative pairs)
+template <int LPC>
+__device__ __forceinline__ double sum_chain_lanes(double v) {
+  if constexpr (LPC == 16) {
+    v += dpp_move<0x128>(v);  // row_ror:8
+    v += dpp_move<0x124>(v);  // row_ror:4
+    v += dpp_move<0x122>(v);  // row_ror:2
+    v += dpp_move<0x121>(v);  // row_ror:1
+  } else {
+#pragma unroll
+    for (int off = LPC / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  }
+  return v;
+}
+
+// The Rosenbrock example model under a diagonal prior needs neither the matrix cores nor a 16-chain tile: k_dreamz_steps
+// spends its step in two workgroup barriers and an LDS round trip while its four waves repeat the same evaluation
+// (2.4 us per step of 8192 chains, 2 waves per SIMD).  Here a chain is 16 lanes of a wave (8 at DPAD = 8) holding DPAD / 16
+// parameters each; the prior and the model reduce over those lanes with DPP rotations, the next parameter of the Rosenbrock
+// coupling comes from the neighbouring lane, and the only memory traffic of a step is its algorithmic traffic (jump in, record
+// / archive row out), prefetched one step ahead.  Same DreamStepArgs, same records; log-densities equal k_dreamz_steps' to
+// rounding (a different summation order).
+template <int DPAD>
+__global__ void __launch_bounds__(64) k_dreamz_steps_wave(const DreamStepArgs a) {
+  constexpr int LPC = DPAD >= 16 ? 16 : DPAD;
+  constexpr int EPT = DPAD / LPC;
+  constexpr int CPW = 64 / LPC;
+  const int lane = threadIdx.x;
+  const int q = lane % LPC;
+  const int64_t c = (int64_t)blockIdx.x * CPW + lane / LPC;  // NP is a multiple of 16: every c < NP
+  const bool real = c < a.N;
+  const int j0 = q * EPT;
+  double pm[EPT], pinv[EPT], blo[EPT], bhi[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    pm[e] = a.pr.mean[j0 + e];
+    pinv[e] = a.pr.pinv[j0 + e];
+    blo[e] = a.pr.lo ? a.pr.lo[j0 + e] : -INFINITY;
+    bhi[e] = a.pr.lo ? a.pr.hi[j0 + e] : INFINITY;
+  }
+  double cur[EPT], prp[EPT], prev[EPT], jn[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    cur[e] = a.theta[c * DPAD + j0 + e];
+    prev[e] = cur[e];
+    jn[e] = a.jump_ready ? a.coef[(size_t)c * DPAD + j0 + e] : 0.0;
+  }
+  double lp = a.lp[c], ll = a.ll[c];
+  int nacc = 0;
+  double* arch_c = a.shared ? a.arch : a.arch + (size_t)c * a.cap * DPAD;
+  double unext = a.u[c];
+  for (int s = 0; s < a.S; ++s) {
+    const double u = unext;
+    if (s + 1 < a.S) unext = a.u[(size_t)(s + 1) * a.NP + c];
+    // ---- proposal (proposal.py:850-852) ----
+    if (a.jump_ready) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        prp[e] = cur[e] + jn[e];
+        if (s + 1 < a.S) jn[e] = a.coef[((size_t)(s + 1) * a.NP + c) * DPAD + j0 + e];  // flies under this step
+      }
+    } else {
+      double z1[EPT], z2[EPT];
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) z1[e] = z2[e] = 0.0;
+      for (int i = 0; i < a.delta; ++i) {
+        const int r1 = a.ridx[((size_t)s * a.NP + c) * (2 * MAX_DELTA) + 2 * i + 0];
+        const int r2 = a.ridx[((size_t)s * a.NP + c) * (2 * MAX_DELTA) + 2 * i + 1];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          z1[e] += arch_c[(size_t)r1 * DPAD + j0 + e];
+          z2[e] += arch_c[(size_t)r2 * DPAD + j0 + e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const size_t o = ((size_t)s * a.NP + c) * DPAD + j0 + e;
+        prp[e] = cur[e] + (a.coef[o] * (z1[e] - z2[e]) + a.epsm[o]);
+      }
+    }
+    // ---- prior ----
+    double p = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const double dv = prp[e] - pm[e];
+      p += dv * dv * pinv[e];
+      if (prp[e] < blo[e] || prp[e] > bhi[e]) p = INFINITY;  // uniform components: zero density outside their support
+    }
+    const double maha = sum_chain_lanes<LPC>(p);
+    // ---- Rosenbrock chain: f = sum_i (a - x_i)^2 + b (x_{i+1} - x_i^2)^2 ; loglike = -0.5 (f - data)^2 / var ----
+    const double xnb = __shfl_down(prp[0], 1, LPC);  // first parameter of the next lane (unused by the chain's last lane)
+    double f = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const double x0 = prp[e], x1 = e + 1 < EPT ? prp[e + 1 < EPT ? e + 1 : e] : xnb;
+      const double t0 = a.ros_a - x0, t1 = x1 - x0 * x0;
+      if (j0 + e + 1 < a.d) f += t0 * t0 + a.ros_b * (t1 * t1);
+    }
+    f = sum_chain_lanes<LPC>(f);
+    const double r = f - a.ros_data;
+    const double ll_n = -0.5 * (r * r) / a.lv.var;
+    const double lp_n = -0.5 * (a.pr.logconst + maha);
+    const double post_n = lp_n + ll_n;
+    double alpha = exp(post_n - (lp + ll));
+    if (post_n != post_n) alpha = 0.0;
+    const bool acc = u < alpha;
+    if (acc) {
+      lp = lp_n;
+      ll = ll_n;
+    }
+    nacc += acc ? 1 : 0;
+    if (q == 0 && real) {
+      const size_t rr = (size_t)s * a.N + c;
+      if (a.rec_stats) {
+        a.rec_stats[rr * 3 + 0] = lp;
+        a.rec_stats[rr * 3 + 1] = ll;
+        a.rec_stats[rr * 3 + 2] = lp + ll;
+      }
+      if (a.rec_acc) a.rec_acc[rr] = acc ? 1 : 0;
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      if (s == a.S - 1) prev[e] = cur[e];
+      cur[e] = acc ? prp[e] : cur[e];
+      const int j = j0 + e;
+      if (a.rec_params && real && j < a.d) a.rec_params[((size_t)s * a.N + c) * a.d + j] = cur[e];
+      // archive append (proposal.py:794): per-chain archives see it at once, the shared one after the block
+      if (!a.shared) arch_c[(size_t)(a.M_base + s) * DPAD + j] = cur[e];
+      if (a.blk_states) a.blk_states[((size_t)s * a.NP + c) * DPAD + j] = cur[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    a.theta[c * DPAD + j0 + e] = cur[e];
+    a.theta_prev[c * DPAD + j0 + e] = prev[e];
+  }
+  if (q == 0) {
+    a.lp[c] = lp;
+    a.ll[c] = ll;
+    a.acc_count[c] += nacc;
+  }
+}
+
 struct DreamAdaptArgs {
   int64_t N, NP;
   int d, nCR, period;
