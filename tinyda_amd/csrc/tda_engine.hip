@@ -281,6 +281,9 @@ struct tda_engine {
   int64_t pending_steps = 0;  // shared mode: steps whose states are in blk_hist but not yet appended
   DevBuf<double> arch, zsum, zsq, dz_pCR, dz_LCR, dz_Delta, dz_coef, dz_epsm, theta_prev, blk_states, blk_hist;
   DevBuf<int32_t> dz_ridx, dz_mcr_last;
+  DevBuf<double> dz_coef2, dz_epsm2, dz_u2;  // second set of draw outputs (shared DREAM: block b + 1 is drawn under block b's steps)
+  DevBuf<int32_t> dz_ridx2;
+  hipEvent_t ev_dz_adapt = nullptr;
   DevBuf<double> dz_partial;
   DevBuf<int32_t> rp_r, rp_mcr, rp_forced;
   DevBuf<double> rp_sub, rp_e, rp_eps, rp_u;
@@ -740,6 +743,7 @@ void tda_engine_destroy(tda_engine* e) {
       (void)hipEventDestroy(e->ev_cp[i]);
     }
   }
+  if (e->ev_dz_adapt) (void)hipEventDestroy(e->ev_dz_adapt);
   if (e->rng_stream) {
     (void)hipStreamSynchronize(e->rng_stream);
     (void)hipStreamDestroy(e->rng_stream);
@@ -3541,18 +3545,44 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     }
     e->timed.clear();
   }
-  int64_t done = 0;
-  while (done < n_iter) {
-    int64_t S = std::min<int64_t>(n_iter - done, e->SMAX);
-    if (adaptive) S = std::min<int64_t>(S, period - (e->t % period));
+  const bool ext_model0 = lv.model == MODEL_CALLBACK || lv.model == MODEL_USER;
+  // TINYDA_DZ_PIPELINE=1 (off by default -- measured SLOWER): one process, shared archive appended in place: everything
+  // k_dreamz_draw produces except the archive gather depends on the step counter only (and on pCR / scaling, which change at
+  // adaptation boundaries), so block b + 1 can be drawn on a second stream while block b steps, the step kernel gathering the
+  // archive rows itself (the same sums in the same order: results do not depend on this switch, the sharding-invariance tests
+  // pass either way).  On C4 (8192 chains, d = 32, interval 16) the two kernels do run concurrently but each then takes the sum
+  // of their stand-alone times (draw 52 us and steps 28 us alone, 80-97 us each together: the draw saturates the VALU issue of
+  // every SIMD and the steps' dependent chains wait behind it, s_setprio made no difference) and every block pays ~13 us for
+  // the cross-stream events: 1.00e9 evals/s against 1.19e9 for the plain sequence.
+  static const bool pipe_ok = getenv("TINYDA_DZ_PIPELINE") && atoi(getenv("TINYDA_DZ_PIPELINE")) == 1;
+  const bool pipe = pipe_ok && sh && e->auto_append && N == NP && e->pending_steps == 0 && !ext_model0;
+  if (pipe && !e->dz_coef2.p) {
+    int rc;
+    if ((rc = e->dz_coef2.alloc((size_t)e->SMAX * NP * DP)) || (rc = e->dz_epsm2.alloc((size_t)e->SMAX * NP * DP)) ||
+        (rc = e->dz_ridx2.alloc((size_t)e->SMAX * NP * 2 * MAX_DELTA)) || (rc = e->dz_u2.alloc((size_t)e->SMAX * NP)))
+      return rc;
+  }
+  if (pipe && !e->rng_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&e->rng_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      HIP_TRY(hipEventCreateWithFlags(&e->ev_rng[i], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&e->ev_apply[i], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&e->ev_steps[i], hipEventDisableTiming));
+    }
+  }
+  if (pipe && !e->ev_dz_adapt) HIP_TRY(hipEventCreateWithFlags(&e->ev_dz_adapt, hipEventDisableTiming));
+  auto block_len = [&](int64_t t_now, int64_t left) {
+    int64_t S = std::min<int64_t>(left, e->SMAX);
+    if (adaptive) S = std::min<int64_t>(S, period - (t_now % period));
     if (sh) {
       const int64_t K = e->dz.sync_every > 0 ? e->dz.sync_every : e->SMAX;
       S = std::min<int64_t>(S, K);
-      if (!e->auto_append) {
-        if (e->pending_steps + S > e->SMAX) S = e->SMAX - e->pending_steps;
-        if (S <= 0) return fail(TDA_ERR_STATE, "shared archive: call archive_take / archive_append before running further");
-      }
+      if (!e->auto_append && e->pending_steps + S > e->SMAX) S = e->SMAX - e->pending_steps;
     }
+    return S;
+  };
+  // everything DREAMZ.make_proposal draws for S steps from step t0 on, the archive holding M_base rows: into buffer set `set`
+  auto enqueue_draw = [&](int set, int64_t t0, int64_t M_base, int64_t S, int64_t rp_pos, int64_t exp_pos, bool gather, hipStream_t st) {
     DreamDrawArgs da{};
     da.N = N;
     da.NP = NP;
@@ -3561,21 +3591,21 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     da.S = (int)S;
     da.delta = e->dz.delta;
     da.nCR = e->dz.nCR;
-    da.step0 = e->t;
-    da.M_base = e->arch_rows;
+    da.step0 = t0;
+    da.M_base = M_base;
     da.grow = sh ? 0 : 1;
     da.seed = e->cfg.seed;
     da.b = e->dz.b;
     da.b_star = e->dz.b_star;
     da.scaling = e->scaling.p;
     da.pCR = e->dz_pCR.p;
-    da.coef = e->dz_coef.p;
-    da.epsm = e->dz_epsm.p;
-    da.ridx = e->dz_ridx.p;
-    da.u = e->ublk.p;
+    da.coef = set ? e->dz_coef2.p : e->dz_coef.p;
+    da.epsm = set ? e->dz_epsm2.p : e->dz_epsm.p;
+    da.ridx = set ? e->dz_ridx2.p : e->dz_ridx.p;
+    da.u = set ? e->dz_u2.p : e->ublk.p;
     da.mcr_last = e->dz_mcr_last.p;
     if (e->rp_steps) {
-      const size_t o = (size_t)e->rp_pos * N;
+      const size_t o = (size_t)rp_pos * N;
       da.r_rep = e->rp_r.p + o * e->dz.delta * 2;
       da.mcr_rep = e->rp_mcr.p + o;
       da.forced_rep = e->rp_forced.p + o;
@@ -3585,19 +3615,41 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
       da.u_rep = e->rp_u.p + o;
     }
     if (e->exp_steps) {
-      da.eps_export = (e->exp_dev ? e->z_exp : e->z_exp_d.p) + (size_t)e->exp_pos * N * d;
-      da.u_export = (e->exp_dev ? e->u_exp : e->u_exp_d.p) + (size_t)e->exp_pos * N;
+      da.eps_export = (e->exp_dev ? e->z_exp : e->z_exp_d.p) + (size_t)exp_pos * N * d;
+      da.u_export = (e->exp_dev ? e->u_exp : e->u_exp_d.p) + (size_t)exp_pos * N;
     }
-    da.arch_shared = sh ? e->arch.p : nullptr;
-    {
+    da.arch_shared = gather ? e->arch.p : nullptr;
+    DISPATCH_DPAD(DP, launch_dz_draw<DPAD>(da, st));
+  };
+  int64_t done = 0, blk = 0;
+  if (pipe && n_iter > 0) {
+    // everything queued on the main stream so far (init, earlier run() calls, their adaptation) precedes the first draw
+    HIP_TRY(hipEventRecord(e->ev_dz_adapt, e->stream));
+    HIP_TRY(hipStreamWaitEvent(e->rng_stream, e->ev_dz_adapt, 0));
+    enqueue_draw(0, e->t, e->arch_rows, block_len(e->t, n_iter), e->rp_pos, e->exp_pos, false, e->rng_stream);
+    HIP_TRY(hipEventRecord(e->ev_rng[0], e->rng_stream));
+  }
+  while (done < n_iter) {
+    const int64_t S = block_len(e->t, n_iter - done);
+    if (S <= 0) return fail(TDA_ERR_STATE, "shared archive: call archive_take / archive_append before running further");
+    const int set = pipe ? (int)(blk & 1) : 0;
+    if (pipe) {
+      HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_rng[set], 0));
+    } else {
       ScopedTimer tm(e, 0);
-      DISPATCH_DPAD(DP, launch_dz_draw<DPAD>(da, e->stream));
+      enqueue_draw(0, e->t, e->arch_rows, S, e->rp_pos, e->exp_pos, sh, e->stream);
     }
     DreamStepArgs sa{};
     fill_dreamz_step_args(e, sa);
     sa.S = (int)S;
-    sa.jump_ready = sh ? 1 : 0;
-    const bool ext_model = lv.model == MODEL_CALLBACK || lv.model == MODEL_USER;
+    sa.jump_ready = (sh && !pipe) ? 1 : 0;
+    if (set) {
+      sa.coef = e->dz_coef2.p;
+      sa.epsm = e->dz_epsm2.p;
+      sa.ridx = e->dz_ridx2.p;
+      sa.u = e->dz_u2.p;
+    }
+    const bool ext_model = ext_model0;
     sa.rec_params = p_dev ? o_params + (size_t)done * N * d : (o_params ? e->rec_params.p : nullptr);
     sa.rec_stats = s_dev ? o_stats + (size_t)done * N * 3 : (o_stats ? e->rec_stats.p : nullptr);
     sa.rec_acc = a_dev ? o_acc + (size_t)done * N : (o_acc ? e->rec_acc.p : nullptr);
@@ -3693,6 +3745,19 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
       }
     }
     if (boundary) e->k_adapt += 1;
+    if (pipe) {
+      // block b's steps (and its adaptation, if any) are queued: its buffer set is free once they have run.  The draws of
+      // block b + 1 start as soon as the set they overwrite (block b - 1's) is free -- i.e. under block b's steps -- unless
+      // block b ended on an adaptation boundary, whose new pCR / scaling they must see.
+      HIP_TRY(hipEventRecord(e->ev_steps[set], e->stream));
+      if (done + S < n_iter) {
+        const int nset = (int)((blk + 1) & 1);
+        if (blk >= 1) HIP_TRY(hipStreamWaitEvent(e->rng_stream, e->ev_steps[nset], 0));
+        if (boundary) HIP_TRY(hipStreamWaitEvent(e->rng_stream, e->ev_steps[set], 0));
+        enqueue_draw(nset, e->t + S, e->arch_rows, block_len(e->t + S, n_iter - done - S), e->rp_pos + S, e->exp_pos + S, false, e->rng_stream);
+        HIP_TRY(hipEventRecord(e->ev_rng[nset], e->rng_stream));
+      }
+    }
     bool host_copies = false;
     if (o_params && !p_dev) {
       if ((rc = copy_out(e, o_params + (size_t)done * N * d, e->rec_params.p, (size_t)S * N * d * sizeof(double)))) return rc;
@@ -3709,6 +3774,7 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     if (host_copies) HIP_TRY(hipStreamSynchronize(e->stream));
     e->t += S;
     done += S;
+    blk += 1;
     if (e->rp_steps) e->rp_pos += S;
     if (e->exp_steps) e->exp_pos += S;
   }
