@@ -553,8 +553,10 @@ __device__ long long g_da_trace[128 * 8 * 8];  // debug builds only: [step][wave
 // RB = 16-row blocks of the coarse operator per wave (1: m0 <= 128, 2: m0 <= 256); PCN: CrankNicolson proposals; DIAG0: diagonal noise
 // on the coarse level -- template parameters, because as run-time flags they cost a select per model output and step in the
 // vector section that decides when the SIMD's other wave may start its burst
-template <int DPAD, int RB, bool PCN, bool DIAG0>
+template <int DPAD, int RB, bool PCN, bool DIAG0, int NLEV = 2>
 __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
+  static_assert(NLEV == 2 || NLEV == 3, "two-level Delayed Acceptance or three-level MLDA");
+  constexpr int NPAIR = NLEV * (NLEV - 1) / 2;
   constexpr int NW = 8, NT = 64 * NW, TPC = 4 * NW;
   constexpr int KS = DPAD / 4, K2 = DPAD / 8, LDP = DPAD + 2, RSX = KS + 2;
   constexpr int EPT = DPAD >= TPC ? DPAD / TPC : 1;
@@ -581,7 +583,7 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
   const uint32_t gchain = (uint32_t)(a.chain_offset + gcl);
 
 #pragma unroll
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < NLEV; ++k)
     for (int i = tid; i < a.lv[k].m_pad; i += NT) {
       s_stage[a.lds_y[k] + i] = a.lv[k].ytil[i];
       if (a.lv[k].noise_kind == 1) s_stage[a.lds_w[k] + i] = a.lv[k].w[i];
@@ -593,17 +595,34 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
   const bool prior_std = a.pr.kind == PRIOR_STANDARD;
   constexpr bool dg0 = DIAG0;
 
-  double cur0[EPT], cur1[EPT], prp[EPT];
+  // level 0 in scalars of its own (the step loop below), the levels above in arrays indexed by level - 1
+  double cur0[EPT], curU[NLEV - 1][EPT], prp[EPT];
   double sxa[EPT], sxb[EPT], sxc[EPT], sxd[EPT];  // increments of steps s .. s + 3 as loaded (a load has a whole step to arrive)
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
     cur0[e] = active ? a.theta[gct * DPAD + q_ * EPT + e] : 0.0;
-    cur1[e] = active ? a.theta[((size_t)a.NP + gct) * DPAD + q_ * EPT + e] : 0.0;
+#pragma unroll
+    for (int q = 1; q < NLEV; ++q) curU[q - 1][e] = active ? a.theta[((size_t)q * a.NP + gct) * DPAD + q_ * EPT + e] : 0.0;
   }
-  double lp0 = a.lp[gcl], ll0 = a.ll[gcl], lp1 = a.lp[a.NP + gcl], ll1 = a.ll[a.NP + gcl];
-  double Slp = a.Sst[gcl], Sll = a.Sst[a.NP + gcl];  // level 0 at the subchain start (pair (0, 1))
+  double lp0 = a.lp[gcl], ll0 = a.ll[gcl], lpU[NLEV - 1], llU[NLEV - 1];
+  int anyU[NLEV - 1], cntU[NLEV - 1], nrecU[NLEV - 1];
+  int64_t stepU[NLEV - 1];
+#pragma unroll
+  for (int q = 1; q < NLEV; ++q) {
+    lpU[q - 1] = a.lp[(size_t)q * a.NP + gcl];
+    llU[q - 1] = a.ll[(size_t)q * a.NP + gcl];
+    anyU[q - 1] = a.anyacc[(size_t)q * a.NP + gcl];  // (the finest level's is never read: carried unchanged)
+    cntU[q - 1] = a.cnt[q];
+    stepU[q - 1] = a.done[q];
+    nrecU[q - 1] = 0;
+  }
+  double Slp[NPAIR], Sll[NPAIR];  // level j at the start of level q's current step, pair_index(j, q)
+#pragma unroll
+  for (int p = 0; p < NPAIR; ++p) {
+    Slp[p] = a.Sst[((size_t)p * 2 + 0) * a.NP + gcl];
+    Sll[p] = a.Sst[((size_t)p * 2 + 1) * a.NP + gcl];
+  }
   int anyacc0 = a.anyacc[gcl];
-  const int anyacc1 = a.anyacc[a.NP + gcl];  // the finest level has no level above that would read it: carried unchanged
   const double scal_t = a.scaling[gct];
   constexpr bool is_pcn = PCN;
   const double keep_t = is_pcn ? sqrt(1.0 - scal_t * scal_t) : 1.0;
@@ -611,8 +630,8 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
   const double keep_l = is_pcn ? sqrt(1.0 - scal_l * scal_l) : 1.0;  // the same factor for this lane's chain (model outputs)
   const bool has_logu = a.logu0 != nullptr;
   int cnt0 = a.cnt[0];
-  int64_t step0 = a.done[0], step1 = a.done[1];
-  int nrec0 = 0, nrec1 = 0;
+  int64_t step0 = a.done[0];
+  int nrec0 = 0;
   int64_t ringpos = a.ring_pos;
   const int L0 = a.sl[0];
   const int ncb0 = a.lv[0].ncb;
@@ -852,79 +871,109 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
     DA_STAMP(6);
     if (cnt0 != L0) continue;
 
-    // ================= fine level: the subchain is complete (chain.py:354-402) =================
-    // evaluated directly at y = the coarse state; the registers of the coarse operator serve as its fragment pipeline
-    // (the operator is fetched again afterwards: two block loads per subchain).  One prior for all levels: log-prior(y) = lp0.
-    flush_coarse_record();  // the fine level may move the coarse state: its last step is recorded first
-    if (active) {
+    // ================= upper levels whose subchain just completed (chain.py:354-402; MLDA: proposal.py:1441-1530) =========
+    // Level q = k + 1 is evaluated directly at y = the state of the levels below it (after an action of level q - 1 these all
+    // coincide with level 0's, so y is always cur0); the registers of the coarse operator serve as the fragment pipeline
+    // (the operator is fetched again afterwards).  One prior for all levels: log-prior(y) = lp0.
+    flush_coarse_record();  // an upper level may move the coarse state: its last step is recorded first
+    auto LP = [&](int j) -> double& { return j == 0 ? lp0 : lpU[j - 1]; };
+    auto LL = [&](int j) -> double& { return j == 0 ? ll0 : llU[j - 1]; };
+    bool more = true;
 #pragma unroll
-      for (int e = 0; e < EPT; ++e) s_prop[c * LDP + q_ * EPT + e] = cur0[e];
-    }
-    frag_load_buf<DPAD>(frag_src(a.lv[1].Apk, lane), wave < a.lv[1].ncb ? wave : a.lv[1].ncb - 1, fA[0]);
-    __syncthreads();
-    double llq;
-    {
-      double th[KS];
-#pragma unroll
-      for (int kk = 0; kk < KS; ++kk) th[kk] = s_prop[lc * LDP + 4 * kk + hi];
-      const LevelDev& L = a.lv[1];
-      const bool dg = L.noise_kind == 1;
-      double sq = dg ? level_sse_single<DPAD, 1, NW>(L.Apk, L.ncb, s_stage + a.lds_y[1], s_stage + a.lds_w[1], th, wave, lane, fA[0])
-                     : level_sse_single<DPAD, 0, NW>(L.Apk, L.ncb, s_stage + a.lds_y[1], nullptr, th, wave, lane, fA[0]);
-      sq = sum_rows(sq);
-      if (lane < 16) s_red[wave * 16 + lane] = sq;  // (both reduction slabs are free here: the step's was read above)
-      __syncthreads();
-      double t1 = s_red[lc];
-#pragma unroll
-      for (int w = 1; w < NW; ++w) t1 += s_red[w * 16 + lc];
-      llq = dg ? -0.5 * t1 : -0.5 * t1 / L.var;
-    }
-    const double lpq = lp0;
-    load_coarse_operator();
-    double uq;
-    if (a.u_rep[1]) uq = a.u_rep[1][(size_t)(step1 - a.done[1]) * a.N + (gcl < a.N ? gcl : 0)];
-    else uq = accept_uniform(a.seed, gchain, (uint32_t)step1, 1u);
-    const double alq = exp(((lpq + llq) - (lp1 + ll1)) + (Slp + Sll) - (lp0 + ll0));  // chain.py:475-483
-    const bool acc1 = (anyacc0 != 0) && (uq < alq);  // skip rule: nothing accepted below -> a recorded rejection (:357-364)
-    {
-      const int accf = __shfl(acc1 ? 1 : 0, c);
+    for (int k = 0; k < NLEV - 1; ++k) {
+      if (!more) break;
+      const int q = k + 1;
       if (active) {
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-          if (accf) cur1[e] = cur0[e];
-          else cur0[e] = cur1[e];  // the coarse chain restarts from the fine state (:360-362, 394-396)
-          const int j = q_ * EPT + e;
-          if (a.rec_params[1] && gct < a.N && j < a.d) a.rec_params[1][((size_t)nrec1 * a.N + gct) * a.d + j] = cur1[e];
+        for (int e = 0; e < EPT; ++e) s_prop[c * LDP + q_ * EPT + e] = cur0[e];
+      }
+      const LevelDev& L = a.lv[q];
+      frag_load_buf<DPAD>(frag_src(L.Apk, lane), wave < L.ncb ? wave : L.ncb - 1, fA[0]);
+      __syncthreads();
+      double llq;
+      {
+        double th[KS];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) th[kk] = s_prop[lc * LDP + 4 * kk + hi];
+        const bool dg = L.noise_kind == 1;
+        double sq = dg ? level_sse_single<DPAD, 1, NW>(L.Apk, L.ncb, s_stage + a.lds_y[q], s_stage + a.lds_w[q], th, wave, lane, fA[0])
+                       : level_sse_single<DPAD, 0, NW>(L.Apk, L.ncb, s_stage + a.lds_y[q], nullptr, th, wave, lane, fA[0]);
+        sq = sum_rows(sq);
+        if (lane < 16) s_red[wave * 16 + lane] = sq;  // (both reduction slabs are free here: the step's was read above)
+        __syncthreads();
+        double t1 = s_red[lc];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) t1 += s_red[w * 16 + lc];
+        llq = dg ? -0.5 * t1 : -0.5 * t1 / L.var;
+      }
+      const double y_lp = LP(k), y_ll = LL(k);
+      const double lpq = y_lp;
+      double uq;
+      if (a.u_rep[q]) uq = a.u_rep[q][(size_t)(stepU[q - 1] - a.done[q]) * a.N + (gcl < a.N ? gcl : 0)];
+      else uq = accept_uniform(a.seed, gchain, (uint32_t)stepU[q - 1], (uint32_t)q);
+      const int pkq = pair_index(k, q);
+      const double alq = exp(((lpq + llq) - (lpU[q - 1] + llU[q - 1])) + (Slp[pkq] + Sll[pkq]) - (y_lp + y_ll));  // chain.py:475-483
+      const int any_below = k == 0 ? anyacc0 : anyU[k - 1];
+      const bool accq = (any_below != 0) && (uq < alq);  // skip rule: nothing accepted below -> a recorded rejection (:357-364)
+      {
+        const int accf = __shfl(accq ? 1 : 0, c);
+        if (active) {
+#pragma unroll
+          for (int e = 0; e < EPT; ++e) {
+            if (accf) {
+              curU[q - 1][e] = cur0[e];
+            } else {  // every level below q restarts from theta_q (:360-362, 394-396)
+              cur0[e] = curU[q - 1][e];
+#pragma unroll
+              for (int j = 1; j < q; ++j) curU[j - 1][e] = curU[q - 1][e];
+            }
+            const int j = q_ * EPT + e;
+            if (a.rec_params[q] && gct < a.N && j < a.d) a.rec_params[q][((size_t)nrecU[q - 1] * a.N + gct) * a.d + j] = curU[q - 1][e];
+          }
         }
       }
-    }
-    if (acc1) {
-      lp1 = lpq;
-      ll1 = llq;
-    } else {
-      lp0 = Slp;
-      ll0 = Sll;
-    }
-    direct_outputs(cur0, Fc);  // rejected chains are back at the fine state: outputs re-derived (and re-anchored) for the tile
-    Slp = lp0;
-    Sll = ll0;
-    anyacc0 = 0;
-    if (wave == 0 && lane < 16) {
-      if (gcl < a.N) {
-        const size_t r = (size_t)nrec1 * a.N + gcl;
-        if (a.rec_stats[1]) {
-          a.rec_stats[1][r * 3 + 0] = lp1;
-          a.rec_stats[1][r * 3 + 1] = ll1;
-          a.rec_stats[1][r * 3 + 2] = lp1 + ll1;
+      if (accq) {
+        lpU[q - 1] = lpq;
+        llU[q - 1] = llq;
+      } else {
+#pragma unroll
+        for (int j = 0; j < q; ++j) {
+          LP(j) = Slp[pair_index(j, q)];
+          LL(j) = Sll[pair_index(j, q)];
         }
-        if (a.rec_acc[1]) a.rec_acc[1][r] = acc1 ? 1 : 0;
       }
-      a.ring[(size_t)(ringpos % a.ring_P) * a.NP + gcl] = acc1 ? 1 : 0;  // alignment entry of the coarse accept list (:363,389,397)
+#pragma unroll
+      for (int j = 0; j < q; ++j)
+#pragma unroll
+        for (int q2 = j + 1; q2 <= q; ++q2) {
+          Slp[pair_index(j, q2)] = LP(j);
+          Sll[pair_index(j, q2)] = LL(j);
+        }
+      if (k == 0) anyacc0 = 0;
+      else anyU[k - 1] = 0;
+      if (q < NLEV - 1) anyU[q - 1] |= accq ? 1 : 0;
+      if (wave == 0 && lane < 16) {
+        if (gcl < a.N) {
+          const size_t r = (size_t)nrecU[q - 1] * a.N + gcl;
+          if (a.rec_stats[q]) {
+            a.rec_stats[q][r * 3 + 0] = lpU[q - 1];
+            a.rec_stats[q][r * 3 + 1] = llU[q - 1];
+            a.rec_stats[q][r * 3 + 2] = lpU[q - 1] + llU[q - 1];
+          }
+          if (a.rec_acc[q]) a.rec_acc[q][r] = accq ? 1 : 0;
+        }
+        a.ring[(size_t)(ringpos % a.ring_P) * a.NP + gcl] = accq ? 1 : 0;  // alignment entry of the coarse accept list (:363,389,397)
+      }
+      ringpos += 1;
+      nrecU[q - 1] += 1;
+      stepU[q - 1] += 1;
+      if (k == 0) cnt0 = 0;
+      else cntU[k - 1] = 0;
+      cntU[q - 1] += 1;
+      more = q < NLEV - 1 && cntU[q - 1] == a.sl[q];
     }
-    ringpos += 1;
-    nrec1 += 1;
-    step1 += 1;
-    cnt0 = 0;
+    load_coarse_operator();
+    direct_outputs(cur0, Fc);  // rejected chains are back at an upper state: outputs re-derived (and re-anchored) for the tile
   }
   flush_coarse_record();
 
@@ -932,18 +981,25 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       a.theta[gct * DPAD + q_ * EPT + e] = cur0[e];
-      a.theta[((size_t)a.NP + gct) * DPAD + q_ * EPT + e] = cur1[e];
+#pragma unroll
+      for (int q = 1; q < NLEV; ++q) a.theta[((size_t)q * a.NP + gct) * DPAD + q_ * EPT + e] = curU[q - 1][e];
     }
   }
   if (wave == 0 && lane < 16) {
     a.lp[gcl] = lp0;
     a.ll[gcl] = ll0;
-    a.lp[a.NP + gcl] = lp1;
-    a.ll[a.NP + gcl] = ll1;
     a.anyacc[gcl] = anyacc0;
-    a.anyacc[a.NP + gcl] = anyacc1;
-    a.Sst[gcl] = Slp;
-    a.Sst[a.NP + gcl] = Sll;
+#pragma unroll
+    for (int q = 1; q < NLEV; ++q) {
+      a.lp[(size_t)q * a.NP + gcl] = lpU[q - 1];
+      a.ll[(size_t)q * a.NP + gcl] = llU[q - 1];
+      a.anyacc[(size_t)q * a.NP + gcl] = anyU[q - 1];
+    }
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) {
+      a.Sst[((size_t)p * 2 + 0) * a.NP + gcl] = Slp[p];
+      a.Sst[((size_t)p * 2 + 1) * a.NP + gcl] = Sll[p];
+    }
   }
 }
 
