@@ -1,0 +1,52 @@
+"""The kernels an environment switch selects between must agree: every switch in README.md that changes which kernel runs is
+exercised both ways on the same seeded problem (fresh processes: the switches are read once) -- accept flags equal, states and
+log-densities to rounding (the lean kernels sum in a different order), bitwise where the arithmetic is the same."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _probe(what, env_extra, tmp_path, tag):
+    out = str(tmp_path / ("%s_%s.npz" % (what, tag)))
+    env = dict(os.environ)
+    for k in ("TINYDA_DA_LEAN", "TINYDA_DZ_WAVE", "TINYDA_DZ_PIPELINE"):
+        env.pop(k, None)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "switch_probe.py"), what, out], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return dict(np.load(out))
+
+
+@pytest.mark.parametrize("what", ["mlda3", "da2"])
+def test_pipelined_level_kernel_equals_the_generic_one(what, tmp_path):
+    """k_da_steps (two levels, and three with a coarse operator of <= 128 observations) against k_ml_steps (TINYDA_DA_LEAN=0)"""
+    lean, generic = _probe(what, {}, tmp_path, "lean"), _probe(what, {"TINYDA_DA_LEAN": "0"}, tmp_path, "generic")
+    for k in lean:
+        if k.startswith("acc"):
+            assert np.array_equal(lean[k], generic[k]), "%s: %d accept flips" % (k, int((lean[k] != generic[k]).sum()))
+        else:
+            np.testing.assert_allclose(lean[k], generic[k], rtol=1e-10, atol=1e-12, err_msg=k)
+    assert 0.02 < lean["acc0"].mean() < 0.98
+
+
+def test_dream_kernel_choices_agree(tmp_path):
+    """k_dreamz_steps_wave against the 16-chain tile kernel (TINYDA_DZ_WAVE=0), and the draw-ahead pipeline
+    (TINYDA_DZ_PIPELINE=1: same sums in the same order, bitwise)"""
+    wave = _probe("dream", {}, tmp_path, "wave")
+    tile = _probe("dream", {"TINYDA_DZ_WAVE": "0"}, tmp_path, "tile")
+    pipe = _probe("dream", {"TINYDA_DZ_PIPELINE": "1"}, tmp_path, "pipe")
+    assert np.array_equal(wave["acc0"], tile["acc0"])
+    np.testing.assert_allclose(wave["stats0"], tile["stats0"], rtol=1e-10)
+    np.testing.assert_allclose(wave["params0"], tile["params0"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(wave["pCR"], tile["pCR"], rtol=1e-9)
+    for k in ("acc0", "stats0", "params0", "pCR"):
+        assert np.array_equal(wave[k], pipe[k]), "draw-ahead pipeline changed %s" % k
+    assert 0.01 < wave["acc0"].mean() < 0.9

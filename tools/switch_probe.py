@@ -1,0 +1,54 @@
+"""One seeded run of a configuration whose kernel choice an environment switch changes; records to an .npz.  The switches are
+read once per process, so A/B comparisons start this script twice (tests/test_gpu_switches.py).
+    python tools/switch_probe.py {mlda3|da2|dream} out.npz"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from tinyda_amd import _lib, engine
+
+
+def hierarchy(ms, sl, kind, n_fine, N=256, d=64):
+    rng = np.random.default_rng(11)
+    truth = rng.standard_normal(d)
+    e = engine.Engine(N, d, seed=9, n_levels=len(ms))
+    e.set_prior(np.zeros(d), np.eye(d))
+    for k, m in enumerate(ms):
+        A = rng.standard_normal((m, d)) / 8
+        e.set_level(k, A, A @ truth + 0.1 * rng.standard_normal(m), 0, 0.01)
+    if kind == "am":
+        e.set_proposal(2, 1e-4 * np.eye(d), t0=20, period=20)
+    else:
+        e.set_proposal(1, None, scaling=0.02)
+    e.set_subchains(sl)
+    e.init(truth + 0.05 * rng.standard_normal((N, d)))
+    outs = e.run_levels_host(n_fine)
+    e.close()
+    return {"%s%d" % (n, k): o[i] for k, o in enumerate(outs) for i, n in enumerate(("params", "stats", "acc"))}
+
+
+def dream(N=512, d=32, T=70, M0=64, K=16):
+    e = engine.Engine(N, d, seed=8)
+    e.set_prior(np.zeros(d), np.eye(d))
+    e.set_level_rosenbrock(0, 1.0, 10.0, 0.0, 1.0)
+    e.set_proposal_dreamz(M0, delta=2, nCR=3, adaptive=True, period=32, shared=True, sync_every=K, capacity=M0 + T * N)
+    e.set_archive(None)
+    e.init(None)
+    P, S, A = e.run_host(T)
+    st = e.dreamz_state()
+    e.close()
+    return dict(params0=P, stats0=S, acc0=A, pCR=st["pCR"])
+
+
+if __name__ == "__main__":
+    _lib.load()
+    what, out = sys.argv[1], sys.argv[2]
+    if what == "mlda3":
+        res = hierarchy((128, 256, 512), [5, 3], "am", 6)
+    elif what == "da2":
+        res = hierarchy((256, 1024), [10], "pcn", 8)
+    else:
+        res = dream()
+    np.savez(out, **res)
