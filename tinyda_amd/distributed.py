@@ -47,6 +47,8 @@ def init_process_group(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":  # RCCL binds a rank's communicator to the current device: one GPU per local rank, chosen first
+            torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
