@@ -12,6 +12,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # no test may hang a run: with pytest-timeout present every test gets a ceiling (a stuck rendezvous or child process then
+    # fails with a traceback instead of stalling the whole suite); an explicit --timeout on the command line wins
+    if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
+        config.option.timeout = 400
 
 
 @pytest.fixture(scope="session")

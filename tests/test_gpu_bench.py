@@ -155,9 +155,15 @@ def test_collectives_on_rccl_with_one_rank():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TINYDA_BENCH_ONE_GPU"):
         env.pop(k, None)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    import socket
+
+    sock = socket.socket()  # a port nobody holds (a fixed one can be busy on a shared box: the rendezvous then waits minutes)
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "tools", "rccl_smoke.py")]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+           "--master-port", str(port), os.path.join(ROOT, "tools", "rccl_smoke.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
