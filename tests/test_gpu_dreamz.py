@@ -84,10 +84,13 @@ def _philox_dreamz_variates(seed, N, T, d, delta, nCR, M0, pCR_fn, grow=True, ch
     return dict(r=r, u_mcr=u_mcr, forced=forced, sub_u=sub_u, e_u=e_u, u=u)
 
 
-def test_dreamz_philox_forward_rosenbrock32(eng_mod):
+@pytest.mark.parametrize("d,delta", [(32, 1), (5, 2), (12, 1), (40, 3), (64, 1)])
+def test_dreamz_philox_forward_rosenbrock32(eng_mod, d, delta):
     """BASELINE config-4 shape (d = 32 Rosenbrock chain, per-chain archive, non-adaptive so pCR stays uniform):
-    the engine's own stream; integers / uniforms regenerated bit-exactly by the oracle, normals exported."""
-    d, N, T, M0, delta, nCR, seed = 32, 40, 120, 64, 1, 3, 2468
+    the engine's own stream; integers / uniforms regenerated bit-exactly by the oracle, normals exported.  The other
+    dimensions put every lane layout of k_dreamz_draw / k_dreamz_steps_wave (8, 16, 32, 64 padded parameters; 8 or 4 chains
+    per wave; 1 to 4 parameters per lane) and several row-pair counts through the same comparison."""
+    N, T, M0, nCR, seed = 40, 120, 64, 3, 2468
     prior_mean, prior_cov = np.zeros(d), np.eye(d)
     e = eng_mod.Engine(N, d, seed=seed)
     e.set_prior(prior_mean, prior_cov)
