@@ -992,6 +992,35 @@ __global__ void __launch_bounds__(64, 8) k_rng(const RngArgs a) {
   }
 }
 
+// Proposal increments when the proposal factor is the identity (CrankNicolson under a standard-normal prior, a random walk with
+// C = I): INC = Z, written straight in the [S][NP][DPAD] layout the step kernels read -- no fragments, no product.  A wave takes
+// 16 steps of one chain; lane = (step-in-pass, Box-Muller pair): the DPAD / 2 lanes of a step write its DPAD doubles as one
+// contiguous row.  Same counters as k_propose / k_rng (block = pair, step, chain), so the increments are bitwise the ones
+// k_propose computes with L = I (its products with the zeros of L add exact zeros).
+template <int DPAD>
+__global__ void __launch_bounds__(64, 8) k_rng_direct(const RngArgs a, double* __restrict__ inc) {
+  constexpr int HP = DPAD / 2;   // pairs per step
+  constexpr int SPW = 64 / HP;   // steps per pass of the wave
+  const int lane = threadIdx.x, p = lane % HP, so = lane / HP;
+  const int64_t c = blockIdx.x;
+  const int s_hi = (int)blockIdx.y * 16 + 16 < a.S ? (int)blockIdx.y * 16 + 16 : a.S;
+  const bool real_chain = c < a.N;
+  const uint32_t gc = (uint32_t)(a.chain_offset + c);
+  for (int s = (int)blockIdx.y * 16 + so; s < s_hi; s += SPW) {
+    double z0 = 0.0, z1 = 0.0;
+    if (real_chain && 2 * p < a.d) {
+      normal_pair(a.seed, gc, (uint32_t)(a.step0 + s), STREAM_PROPOSAL, (uint32_t)p, z0, z1);
+      if (2 * p + 1 >= a.d) z1 = 0.0;
+      if (a.z_export) {
+        const size_t o = ((size_t)s * a.N + c) * a.d + 2 * p;
+        a.z_export[o] = z0;
+        if (2 * p + 1 < a.d) a.z_export[o + 1] = z1;
+      }
+    }
+    *reinterpret_cast<double2*>(inc + ((size_t)s * a.NP + c) * DPAD + 2 * p) = double2{z0, z1};
+  }
+}
+
 // accept uniforms of a block (chain.py:112) and their logs: one thread per (step, chain)
 __global__ void __launch_bounds__(256, 2) k_rng_uniforms(const RngArgs a) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
