@@ -116,11 +116,14 @@ def test_dreamz_philox_forward_rosenbrock32(eng_mod, d, delta):
     e.close()
 
 
-def test_dream_shared_archive_sharding_invariance(eng_mod):
+@pytest.mark.parametrize("model,N,d", [("linear", 32, 8), ("rosenbrock", 32, 8), ("rosenbrock", 24, 12), ("linear", 40, 8)])
+def test_dream_shared_archive_sharding_invariance(eng_mod, model, N, d):
     """DREAM (one archive for all chains, synchronised every K steps): two engines holding half of the chains each,
     exchanging rows through archive_take / archive_append in canonical (step, global chain) order, reproduce the
-    single-engine run bit for bit.  This is the exchange the RCCL all-gather performs across GPUs."""
-    d, N, T, M0, K, seed = 8, 32, 60, 24, 5, 99
+    single-engine run bit for bit.  This is the exchange the RCCL all-gather performs across GPUs.  Linear model (tile kernel)
+    and the Rosenbrock chain (k_dreamz_steps_wave); chain counts that are not multiples of 16 exercise the padded chains and
+    the strided archive copies."""
+    T, M0, K, seed = 60, 24, 5, 99
     rng = np.random.default_rng(2)
     A = rng.standard_normal((12, d)) / np.sqrt(d)
     y = rng.standard_normal(12)
@@ -130,7 +133,10 @@ def test_dream_shared_archive_sharding_invariance(eng_mod):
     def make(n, off, th):
         e = eng_mod.Engine(n, d, seed=seed, chain_offset=off)
         e.set_prior(np.zeros(d), np.eye(d))
-        e.set_level(0, A, y, 0, 0.25)
+        if model == "linear":
+            e.set_level(0, A, y, 0, 0.25)
+        else:
+            e.set_level_rosenbrock(0, 1.0, 10.0, 0.0, 1.0)
         e.set_proposal_dreamz(M0, delta=2, nCR=3, adaptive=True, period=20, gamma=1.02, shared=True, sync_every=K,
                               capacity=M0 + T * N)
         e.set_archive(Z0)
