@@ -2613,6 +2613,16 @@ static int run_ext_hierarchy_block(tda_engine* e, const MLArgs& ma, int64_t S, b
   int64_t row[MAXLEV] = {0, 0, 0, 0};
   int64_t rp = e->ring_pos;  // position in the base proposal's accepted list: one entry per base step and per level action
   for (int k = 0; k < MAXLEV; ++k) cc[k] = e->cnt[k];
+  // diagonal error model over a hierarchy of linear levels: base subchains in the fused level kernel (TINYDA_AEMD_FUSED=0: one
+  // propose / outputs / accept triple per base step, for A/B measurements); the residual tile of level 0 must fit into LDS
+  static const bool aemd_fused_ok = !(getenv("TINYDA_AEMD_FUSED") && atoi(getenv("TINYDA_AEMD_FUSED")) == 0);
+  bool all_linear = true;
+  for (int k = 0; k < nl; ++k) all_linear = all_linear && e->levels[k].model == MODEL_LINEAR && e->levels[k].Apk.p != nullptr;
+  const size_t aemd_lds = ((size_t)16 * (DP + 2) + 128 + ma.lds_total + (e->prior_kind == PRIOR_DENSE ? e->prior_ncb * 16 : 0) +
+                           16 * (e->levels[0].m_pad + 2) + 16) * sizeof(double);
+  const bool aemd_fused = aemd_fused_ok && e->aem == TDA_AEM_STATE_INDEPENDENT_DIAGONAL && all_linear && !e->randomize && !e->is_dreamz &&
+                          aemd_lds <= 160 * 1024;
+  bool fused_base_ran = false;
   for (int64_t s = 0; s < S;) {
     if (e->randomize && cc[0] == 0) {  // Delayed Acceptance: draw the promoted index of the subchain that starts now
       hipLaunchKernelGGL(k_ext_pick, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, e->stream, (long long)N, e->sl[0],
@@ -2644,6 +2654,37 @@ static int run_ext_hierarchy_block(tda_engine* e, const MLArgs& ma, int64_t S, b
       ua.ring_P = e->ring_P;
       ua.ring_pos = rp;
       if ((urc = launch_user_steps(e->levels[0].ufn, ua, e->stream))) return urc;
+      rp += n;
+      s += n;
+      cc[0] += (int)n;
+    } else if (aemd_fused) {
+      // diagonal error model over linear levels: the rest of the running base subchain (inside this block) is ONE launch of the
+      // fused level kernel with the corrected likelihood (k_ml_steps, aem_on = 2: bias and inverse variances of chain c from
+      // the arrays the level actions maintain) instead of propose / outputs / accept launches per base step
+      const int64_t n = std::min<int64_t>(S - s, (int64_t)e->sl[0] - cc[0]);
+      MLArgs mb = ma;
+      mb.S = (int)n;
+      mb.cascade = 0;
+      mb.randomize = 0;
+      mb.aem_on = 2;
+      mb.aem_mp = e->levels[0].m_pad;
+      mb.aem_ld = e->levels[0].m;
+      mb.aem_bias = e->aemd_bias[0].p;
+      mb.aem_P = e->aemd_w[0].p;
+      mb.inc = e->inc.p + (size_t)s * NP * DP;
+      mb.u0 = e->ublk.p + (size_t)s * NP;
+      mb.logu0 = nullptr;
+      mb.cnt[0] = cc[0];
+      mb.done[0] = e->done[0] + s;
+      mb.ring_pos = rp;
+      mb.rec_params[0] = ma.rec_params[0] ? ma.rec_params[0] + (size_t)s * N * d : nullptr;
+      mb.rec_stats[0] = ma.rec_stats[0] ? ma.rec_stats[0] + (size_t)s * N * 3 : nullptr;
+      mb.rec_acc[0] = ma.rec_acc[0] ? ma.rec_acc[0] + (size_t)s * N : nullptr;
+      int lrc = TDA_OK;
+      DISPATCH_DPAD(DP, lrc = launch_ml<DPAD>(mb, NP / 16, aemd_lds, e->stream));
+      if (lrc) return lrc;
+      HIP_TRY(hipGetLastError());
+      fused_base_ran = true;
       rp += n;
       s += n;
       cc[0] += (int)n;
@@ -2794,6 +2835,21 @@ static int run_ext_hierarchy_block(tda_engine* e, const MLArgs& ma, int64_t S, b
     }
     cc[0] += 1;
     s += 1;
+    }
+    if (fused_base_ran && cc[0] == e->sl[0]) {
+      // the level actions keep the model output of every level's current link; the fused base kernel does not: F_0(theta_0)
+      // for all chains by the same product that evaluates linear levels anywhere else on this path
+      const Level& l0 = e->levels[0];
+      ExtArgs ya{};
+      fill_ext_args(e, l0, ya);
+      ya.mode = 1;
+      ya.theta = e->ml_theta.p;
+      ya.theta_ld = 0;
+      hipLaunchKernelGGL(k_ext_propose, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, ya);
+      const int mrc = ext_model_outputs(e, l0);
+      if (mrc) return mrc;
+      HIP_TRY(hipMemcpyAsync(e->aemd_F[0].p, l0.cb_F.p, (size_t)N * l0.m * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+      fused_base_ran = false;
     }
     for (int k = 0; k < nl - 1 && cc[k] == e->sl[k]; ++k) {
       const int q = k + 1;
@@ -3072,7 +3128,7 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
   while (done_base < total_base) {
     int64_t S = std::min<int64_t>(total_base - done_base, e->SMAX);
     if (periodic) S = std::min<int64_t>(S, period - (e->t % period));
-    if (e->aem) S = std::min<int64_t>(S, e->sl[0] - e->cnt[0]);  // host-sequenced: stop when the base subchain completes
+    if (e->aem && !e->ext_hier) S = std::min<int64_t>(S, e->sl[0] - e->cnt[0]);  // level actions sequenced after the block: stop when the base subchain completes (host-sequenced hierarchies run their actions inside the block)
     // how many local steps each level completes inside this block (uniform schedule)
     int c2[MAXLEV];
     int64_t nblk[MAXLEV] = {S, 0, 0, 0};

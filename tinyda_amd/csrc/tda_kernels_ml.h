@@ -62,11 +62,11 @@ struct MLArgs {
   // adaptive error model (host-sequenced mode): the kernel only advances level 0, whose likelihood is the
   // bias-corrected dense Gaussian of AdaptiveGaussianLogLike (distributions.py:404-425) with per-chain state
   int cascade;             // 1: upper levels act inside the kernel; 0: the host launches k_aem_action between blocks
-  int aem_on;
-  int aem_mp;              // output dimension padded to 16 (<= 128)
-  int aem_ld;              // row stride of the per-chain error-model state: 64 or 128
-  const double* aem_bias;  // [NP][aem_ld]          total bias of level 0
-  const double* aem_P;     // [NP][aem_ld][aem_ld]  (Sigma_e + Sigma_bias)^-1 of level 0
+  int aem_on;              // 1: dense error model, 2: diagonal error model (level 0's likelihood under chain c's bias)
+  int aem_mp;              // output dimension padded to 16 (dense: <= 128)
+  int aem_ld;              // row stride of the per-chain error-model state: dense 64 or 128, diagonal m
+  const double* aem_bias;  // [NP][aem_ld] (diagonal: [N][m])  total bias of level 0
+  const double* aem_P;     // dense [NP][aem_ld][aem_ld] (Sigma_e + Sigma_bias)^-1 of level 0; diagonal [N][m] inverse variances
   int64_t* sid;            // [nlev][NP] identity of the parameter vector each level currently holds
   const double* logu0;     // [S][NP] log of the base-level uniforms (k_propose / k_rng, off the critical path); may be null
 };
@@ -213,6 +213,31 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
       else (void)level_sse_single<DPAD, 2, NW>(L.Apk, L.ncb, s_stage + a.lds_y[k], s_R + lc * RSa, th, wave, lane, g0);
       __syncthreads();
       const int MP = a.aem_mp, LD = a.aem_ld;
+      if (a.aem_on == 2) {
+        // diagonal error model (tda_kernels_aemd.h): -1/2 sum_o w_o (F_o - y_o + b_o)^2 with chain c's bias and inverse
+        // variances, [N][m] each (LD = m); any m the residual tile holds
+        for (int cc = wave; cc < 16; cc += NW) {
+          const int64_t gc = tile * 16 + cc;
+          const double* rrow = s_R + cc * RSa;
+          double sacc = 0.0;
+          if (gc < a.N)
+            for (int o = lane; o < LD; o += 64) {
+              const double r = rrow[o] + a.aem_bias[gc * LD + o];
+              sacc += a.aem_P[gc * LD + o] * (r * r);
+            }
+          for (int off = 32; off >= 1; off >>= 1) sacc += __shfl_xor(sacc, off);
+          if (lane == 0) s_R[16 * RSa + cc] = -0.5 * sacc;
+        }
+        __syncthreads();
+        ll_n = s_R[16 * RSa + lc];
+        if (prior_dense) {
+          maha = s_redp[lc];
+#pragma unroll
+          for (int w = 1; w < NW; ++w) maha += s_redp[w * 16 + lc];
+        }
+        lp_n = -0.5 * (a.pr.logconst + maha);
+        return;
+      }
       for (int cc = wave; cc < 16; cc += NW) {  // lane = observation (and observation + 64 beyond 64 outputs)
         const int64_t gc = tile * 16 + cc;
         double* rrow = s_R + cc * RSa;
