@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _probe(what, env_extra, tmp_path, tag):
     out = str(tmp_path / ("%s_%s.npz" % (what, tag)))
     env = dict(os.environ)
-    for k in ("TINYDA_DA_LEAN", "TINYDA_DZ_WAVE", "TINYDA_DZ_PIPELINE"):
+    for k in ("TINYDA_DA_LEAN", "TINYDA_DZ_WAVE", "TINYDA_DZ_PIPELINE", "TINYDA_AEMD_FUSED"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "switch_probe.py"), what, out], cwd=ROOT, env=env,
@@ -50,3 +50,15 @@ def test_dream_kernel_choices_agree(tmp_path):
     for k in ("acc0", "stats0", "params0", "pCR"):
         assert np.array_equal(wave[k], pipe[k]), "draw-ahead pipeline changed %s" % k
     assert 0.01 < wave["acc0"].mean() < 0.9
+
+
+def test_fused_and_per_step_diagonal_error_model_agree(tmp_path):
+    """diagonal error model over three linear levels: base subchains in the fused level kernel against one propose / outputs /
+    accept triple per base step (TINYDA_AEMD_FUSED=0)"""
+    fused, steps = _probe("aemd", {}, tmp_path, "fused"), _probe("aemd", {"TINYDA_AEMD_FUSED": "0"}, tmp_path, "steps")
+    for k in fused:
+        if k.startswith("acc"):
+            assert np.array_equal(fused[k], steps[k]), "%s: %d accept flips" % (k, int((fused[k] != steps[k]).sum()))
+        else:
+            np.testing.assert_allclose(fused[k], steps[k], rtol=1e-9, atol=1e-11, err_msg=k)
+    assert 0.02 < fused["acc0"].mean() < 0.98 and 0.02 < fused["acc2"].mean() <= 1.0

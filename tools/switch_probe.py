@@ -1,6 +1,6 @@
 """One seeded run of a configuration whose kernel choice an environment switch changes; records to an .npz.  The switches are
 read once per process, so A/B comparisons start this script twice (tests/test_gpu_switches.py).
-    python tools/switch_probe.py {mlda3|da2|dream} out.npz"""
+    python tools/switch_probe.py {mlda3|da2|aemd|dream} out.npz"""
 import os
 import sys
 
@@ -10,19 +10,22 @@ import numpy as np
 from tinyda_amd import _lib, engine
 
 
-def hierarchy(ms, sl, kind, n_fine, N=256, d=64):
+def hierarchy(ms, sl, kind, n_fine, N=256, d=64, error_model=None):
     rng = np.random.default_rng(11)
     truth = rng.standard_normal(d)
     e = engine.Engine(N, d, seed=9, n_levels=len(ms))
     e.set_prior(np.zeros(d), np.eye(d))
+    base = rng.standard_normal((ms[-1], d)) / 8
     for k, m in enumerate(ms):
-        A = rng.standard_normal((m, d)) / 8
+        A = base[:m] + (0.02 * (len(ms) - 1 - k) * rng.standard_normal((m, d)) / 8 if error_model else 0.0) if error_model else rng.standard_normal((m, d)) / 8
         e.set_level(k, A, A @ truth + 0.1 * rng.standard_normal(m), 0, 0.01)
     if kind == "am":
         e.set_proposal(2, 1e-4 * np.eye(d), t0=20, period=20)
     else:
         e.set_proposal(1, None, scaling=0.02)
     e.set_subchains(sl)
+    if error_model:
+        e.set_error_model(error_model)
     e.init(truth + 0.05 * rng.standard_normal((N, d)))
     outs = e.run_levels_host(n_fine)
     e.close()
@@ -49,6 +52,8 @@ if __name__ == "__main__":
         res = hierarchy((128, 256, 512), [5, 3], "am", 6)
     elif what == "da2":
         res = hierarchy((256, 1024), [10], "pcn", 8)
+    elif what == "aemd":
+        res = hierarchy((200, 200, 200), [5, 3], "am", 8, N=96, error_model="state-independent-diagonal")
     else:
         res = dream()
     np.savez(out, **res)
