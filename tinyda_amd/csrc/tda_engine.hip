@@ -591,7 +591,7 @@ int ext_model_outputs(tda_engine* e, const Level& lv) {
   if (lv.model == MODEL_LINEAR) {
     if (lv.Apk.p) {  // on the matrix cores, every operator fragment serving a 16-chain tile
       DISPATCH_DPAD(e->DP, hipLaunchKernelGGL((k_linear_outputs<DPAD>), dim3((unsigned)(e->NP / 16)), dim3(256), 0, e->stream, (long long)e->N,
-                                              e->d, lv.m, lv.Apk.p, lv.ncb, lv.b_dev.p, lv.cb_prop.p, lv.cb_F.p));
+                                              e->d, lv.m, lv.Apk.p, lv.ncb, lv.b_dev.p, lv.cb_prop.p, e->d, lv.cb_F.p));
       return TDA_OK;
     }
     hipLaunchKernelGGL(k_ext_linear_eval, dim3((unsigned)((e->N + EXT_WAVES - 1) / EXT_WAVES)), dim3(64 * EXT_WAVES), 0, e->stream,
@@ -604,6 +604,12 @@ int ext_model_outputs(tda_engine* e, const Level& lv) {
   if (crc != 0) return fail(TDA_ERR_CALLBACK, "the forward-model callback returned %d", crc);
   HIP_TRY(hipMemcpyAsync(lv.cb_F.p, lv.cb_F_h, (size_t)e->N * lv.m * sizeof(double), hipMemcpyHostToDevice, e->stream));
   return TDA_OK;
+}
+
+// outputs of a linear level with a packed operator at the states theta[N][ld] (a level's slab of the state array), into out[N][m]
+void linear_outputs_at(tda_engine* e, const Level& lv, const double* theta, int ld, double* out) {
+  DISPATCH_DPAD(e->DP, hipLaunchKernelGGL((k_linear_outputs<DPAD>), dim3((unsigned)(e->NP / 16)), dim3(256), 0, e->stream, (long long)e->N,
+                                          e->d, lv.m, lv.Apk.p, lv.ncb, lv.b_dev.p, theta, ld, out));
 }
 
 // one step of such a level: proposals -> model outputs -> accept (xa.s, xa.mode set)
@@ -2839,16 +2845,7 @@ static int run_ext_hierarchy_block(tda_engine* e, const MLArgs& ma, int64_t S, b
     if (fused_base_ran && cc[0] == e->sl[0]) {
       // the level actions keep the model output of every level's current link; the fused base kernel does not: F_0(theta_0)
       // for all chains by the same product that evaluates linear levels anywhere else on this path
-      const Level& l0 = e->levels[0];
-      ExtArgs ya{};
-      fill_ext_args(e, l0, ya);
-      ya.mode = 1;
-      ya.theta = e->ml_theta.p;
-      ya.theta_ld = 0;
-      hipLaunchKernelGGL(k_ext_propose, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, ya);
-      const int mrc = ext_model_outputs(e, l0);
-      if (mrc) return mrc;
-      HIP_TRY(hipMemcpyAsync(e->aemd_F[0].p, l0.cb_F.p, (size_t)N * l0.m * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+      linear_outputs_at(e, e->levels[0], e->ml_theta.p, DP, e->aemd_F[0].p);
       fused_base_ran = false;
     }
     for (int k = 0; k < nl - 1 && cc[k] == e->sl[k]; ++k) {
@@ -2892,15 +2889,20 @@ static int run_ext_hierarchy_block(tda_engine* e, const MLArgs& ma, int64_t S, b
         row[q] += 1;
         continue;
       }
-      ExtArgs ya{};
-      fill_ext_args(e, lq, ya);
-      ya.mode = 1;  // "proposals" = the current states of level k (the promoted states of a randomised subchain)
       const bool snap = e->randomize && k == 0;
-      ya.theta = snap ? e->ml_ysnap.p : e->ml_theta.p + (size_t)k * NP * DP;
-      ya.theta_ld = snap ? DP + 2 : 0;
-      hipLaunchKernelGGL(k_ext_propose, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, ya);
-      const int mrc = ext_model_outputs(e, lq);
-      if (mrc) return mrc;
+      if (lq.model == MODEL_LINEAR && lq.Apk.p) {
+        // linear level: its outputs at the states of level k straight from the state array (no copy of the states first)
+        linear_outputs_at(e, lq, snap ? e->ml_ysnap.p : e->ml_theta.p + (size_t)k * NP * DP, snap ? DP + 2 : DP, lq.cb_F.p);
+      } else {
+        ExtArgs ya{};
+        fill_ext_args(e, lq, ya);
+        ya.mode = 1;  // "proposals" = the current states of level k (the promoted states of a randomised subchain)
+        ya.theta = snap ? e->ml_ysnap.p : e->ml_theta.p + (size_t)k * NP * DP;
+        ya.theta_ld = snap ? DP + 2 : 0;
+        hipLaunchKernelGGL(k_ext_propose, dim3(grid), dim3(64 * EXT_WAVES), 0, e->stream, ya);
+        const int mrc = ext_model_outputs(e, lq);
+        if (mrc) return mrc;
+      }
       if (e->aem == TDA_AEM_STATE_INDEPENDENT_DIAGONAL) {  // decision, alignment, tracker, bias, update_link: one launch
         AemdArgs da{};
         fill_aemd_args(e, da);

@@ -1038,8 +1038,8 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
 // ------------------------------------------------------------------------------------------------
 template <int DPAD>
 __global__ void __launch_bounds__(256) k_linear_outputs(long long N, int d, int m, const double* __restrict__ Apk, int ncb,
-                                                        const double* __restrict__ bvec, const double* __restrict__ prop,
-                                                        double* __restrict__ F) {
+                                                        const double* __restrict__ bvec, const double* __restrict__ prop, int ldp,
+                                                        double* __restrict__ F) {  // prop: rows of ldp doubles ([N][d] or a state array)
   constexpr int KS = DPAD / 4, K2 = DPAD / 8, NWV = 4;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1047,7 +1047,7 @@ __global__ void __launch_bounds__(256) k_linear_outputs(long long N, int d, int 
   const long long c = (long long)blockIdx.x * 16 + lc;
   double th[KS];
 #pragma unroll
-  for (int kk = 0; kk < KS; ++kk) th[kk] = (c < N && 4 * kk + hi < d) ? prop[c * d + 4 * kk + hi] : 0.0;
+  for (int kk = 0; kk < KS; ++kk) th[kk] = (c < N && 4 * kk + hi < d) ? prop[c * ldp + 4 * kk + hi] : 0.0;
   const FragSrc src = frag_src(Apk, lane);
   double2 fa[K2], fb[K2];
   if (wave < ncb) frag_load_buf<DPAD>(src, wave, fa);
