@@ -144,7 +144,13 @@ def _diag_levels(rng, d, m, nl, sigma, diag_noise):
 
 
 @pytest.mark.parametrize("nl,sl,d,m,diag_noise,kind", [(2, [3], 5, 8, False, "grw"), (2, [4], 6, 70, True, "pcn"), (3, [3, 2], 5, 24, False, "grw"),
-                                                        (3, [2, 2], 8, 300, False, "am")])
+                                                        (3, [2, 2], 8, 300, False, "am"),
+                                                        # more than 32 parameters and at most 128 outputs: the base subchains run in
+                                                        # k_da_steps with per-chain corrected data and inverse variances
+                                                        # (AdaptiveMetropolis with t0 = 4 in 40 dimensions factors a rank-4 + 1e-6 I covariance:
+                                                        # device and LAPACK Cholesky then differ by 1e-10 in the proposals, so these cases
+                                                        # use the other proposals; AM on this path: tests/test_gpu_switches.py)
+                                                        (3, [5, 3], 40, 128, False, "grw"), (2, [4], 64, 100, True, "pcn"), (3, [3, 2], 33, 50, True, "grw")])
 def test_diagonal_error_model_vs_oracle(eng_mod, nl, sl, d, m, diag_noise, kind):
     """TDA_AEM_STATE_INDEPENDENT_DIAGONAL (extension: diagonal bias covariances, any output dimension -- here up to m = 300,
     beyond the 128 of the dense model): Delayed Acceptance and MLDA on the engine's own Philox stream against the oracle's

@@ -52,10 +52,12 @@ def test_dream_kernel_choices_agree(tmp_path):
     assert 0.01 < wave["acc0"].mean() < 0.9
 
 
-def test_fused_and_per_step_diagonal_error_model_agree(tmp_path):
-    """diagonal error model over three linear levels: base subchains in the fused level kernel against one propose / outputs /
-    accept triple per base step (TINYDA_AEMD_FUSED=0)"""
-    fused, steps = _probe("aemd", {}, tmp_path, "fused"), _probe("aemd", {"TINYDA_AEMD_FUSED": "0"}, tmp_path, "steps")
+@pytest.mark.parametrize("what,other", [("aemd", {"TINYDA_AEMD_FUSED": "0"}), ("aemd_lean", {"TINYDA_AEMD_FUSED": "0"}),
+                                        ("aemd_lean", {"TINYDA_DA_LEAN": "0"})])
+def test_fused_and_per_step_diagonal_error_model_agree(what, other, tmp_path):
+    """diagonal error model over three linear levels: base subchains in the fused level kernels (k_ml_steps; k_da_steps at <= 128
+    outputs) against one propose / outputs / accept triple per base step (TINYDA_AEMD_FUSED=0) and against each other"""
+    fused, steps = _probe(what, {}, tmp_path, "fused"), _probe(what, other, tmp_path, "other")
     for k in fused:
         if k.startswith("acc"):
             assert np.array_equal(fused[k], steps[k]), "%s: %d accept flips" % (k, int((fused[k] != steps[k]).sum()))

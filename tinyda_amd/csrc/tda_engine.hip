@@ -371,9 +371,11 @@ constexpr size_t aem_inverse_lds_bytes(int nb) { return (size_t)(nb * (nb + 1) /
 // (BASELINE config 3) run on the pipelined 8-wave Delayed-Acceptance kernel; everything else (3-4 levels, error model,
 // randomised subchains, dense prior, larger coarse models) on the generic one.
 inline bool da_lean_eligible(const MLArgs& a) {
-  if ((a.nlev != 2 && a.nlev != 3) || a.aem_on || !a.cascade || a.randomize || a.pr.kind == PRIOR_DENSE) return false;
+  // (the diagonal error model, aem_on == 2, runs its base subchains here with the level actions sequenced by the host)
+  if ((a.nlev != 2 && a.nlev != 3) || a.aem_on == 1 || (a.aem_on == 2) == (a.cascade != 0) || a.randomize || a.pr.kind == PRIOR_DENSE) return false;
   // the coarse operator lives in registers: two 16-row blocks per wave (one with a third level's state beside it)
-  if (a.lv[0].ncb > (a.nlev == 2 ? 16 : 8)) return false;
+  if (a.lv[0].ncb > ((a.nlev == 2 && a.aem_on != 2) ? 16 : 8)) return false;
+  if (a.aem_on == 2 && a.d <= 32) return false;  // (its instances exist for the 64-parameter padding only)
   for (int k = 0; k < a.nlev; ++k)
     if (a.lv[k].noise_kind != 0 && a.lv[k].noise_kind != 1) return false;
   static const bool off = getenv("TINYDA_DA_LEAN") && atoi(getenv("TINYDA_DA_LEAN")) == 0;  // A/B switch for measurements
@@ -385,22 +387,27 @@ int launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st) {
   if (da_lean_eligible(a)) {
     const size_t lds8 = (size_t)da_lds_doubles<DPAD>(a.lds_total) * sizeof(double);
     const bool pcn = a.prop_kind == TDA_PROP_PCN, dg0 = a.lv[0].noise_kind == 1, one = a.lv[0].ncb <= 8;
-#define TDA_DA_LAUNCH(RBV, PCNV, DGV, NLV)                                                                                         \
+#define TDA_DA_LAUNCH(RBV, PCNV, NZV, NLV)                                                                                         \
   do {                                                                                                                             \
     if (lds8 > 64 * 1024)                                                                                                          \
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_da_steps<DPAD, RBV, PCNV, DGV, NLV>),                           \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_da_steps<DPAD, RBV, PCNV, NZV, NLV>),                           \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));                                         \
-    hipLaunchKernelGGL((k_da_steps<DPAD, RBV, PCNV, DGV, NLV>), dim3((unsigned)tiles), dim3(512), lds8, st, a);                    \
+    hipLaunchKernelGGL((k_da_steps<DPAD, RBV, PCNV, NZV, NLV>), dim3((unsigned)tiles), dim3(512), lds8, st, a);                    \
   } while (0)
-    if (a.nlev == 3) {  // (one operator block per wave: da_lean_eligible)
-      if (pcn) { if (dg0) TDA_DA_LAUNCH(1, true, true, 3); else TDA_DA_LAUNCH(1, true, false, 3); }
-      else { if (dg0) TDA_DA_LAUNCH(1, false, true, 3); else TDA_DA_LAUNCH(1, false, false, 3); }
+    if (a.aem_on == 2) {  // (instantiated for 33..64 parameters and one operator block per wave: da_lean_eligible)
+      if constexpr (DPAD == 64) {
+        if (a.nlev == 3) { if (pcn) TDA_DA_LAUNCH(1, true, 2, 3); else TDA_DA_LAUNCH(1, false, 2, 3); }
+        else { if (pcn) TDA_DA_LAUNCH(1, true, 2, 2); else TDA_DA_LAUNCH(1, false, 2, 2); }
+      }
+    } else if (a.nlev == 3) {  // (one operator block per wave: da_lean_eligible)
+      if (pcn) { if (dg0) TDA_DA_LAUNCH(1, true, 1, 3); else TDA_DA_LAUNCH(1, true, 0, 3); }
+      else { if (dg0) TDA_DA_LAUNCH(1, false, 1, 3); else TDA_DA_LAUNCH(1, false, 0, 3); }
     } else if (one) {
-      if (pcn) { if (dg0) TDA_DA_LAUNCH(1, true, true, 2); else TDA_DA_LAUNCH(1, true, false, 2); }
-      else { if (dg0) TDA_DA_LAUNCH(1, false, true, 2); else TDA_DA_LAUNCH(1, false, false, 2); }
+      if (pcn) { if (dg0) TDA_DA_LAUNCH(1, true, 1, 2); else TDA_DA_LAUNCH(1, true, 0, 2); }
+      else { if (dg0) TDA_DA_LAUNCH(1, false, 1, 2); else TDA_DA_LAUNCH(1, false, 0, 2); }
     } else {
-      if (pcn) { if (dg0) TDA_DA_LAUNCH(2, true, true, 2); else TDA_DA_LAUNCH(2, true, false, 2); }
-      else { if (dg0) TDA_DA_LAUNCH(2, false, true, 2); else TDA_DA_LAUNCH(2, false, false, 2); }
+      if (pcn) { if (dg0) TDA_DA_LAUNCH(2, true, 1, 2); else TDA_DA_LAUNCH(2, true, 0, 2); }
+      else { if (dg0) TDA_DA_LAUNCH(2, false, 1, 2); else TDA_DA_LAUNCH(2, false, 0, 2); }
     }
 #undef TDA_DA_LAUNCH
     return TDA_OK;

@@ -575,10 +575,12 @@ __device__ long long g_da_trace[128 * 8 * 8];  // debug builds only: [step][wave
 #define DA_STAMP(i)
 #endif
 
-// RB = 16-row blocks of the coarse operator per wave (1: m0 <= 128, 2: m0 <= 256); PCN: CrankNicolson proposals; DIAG0: diagonal noise
+// RB = 16-row blocks of the coarse operator per wave (1: m0 <= 128, 2: m0 <= 256); PCN: CrankNicolson proposals; NZ0: noise of the
+// coarse level: 0 isotropic, 1 diagonal, 2 the diagonal error model (per-chain bias and inverse variances, MLArgs::aem_on == 2: the
+// launch is one base subchain, the host sequences the level actions, MLArgs::cascade == 0)
 // on the coarse level -- template parameters, because as run-time flags they cost a select per model output and step in the
 // vector section that decides when the SIMD's other wave may start its burst
-template <int DPAD, int RB, bool PCN, bool DIAG0, int NLEV = 2>
+template <int DPAD, int RB, bool PCN, int NZ0, int NLEV = 2>
 __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
   static_assert(NLEV == 2 || NLEV == 3, "two-level Delayed Acceptance or three-level MLDA");
   constexpr int NPAIR = NLEV * (NLEV - 1) / 2;
@@ -618,7 +620,8 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
     s_pinv[i] = a.pr.pinv[i];
   }
   const bool prior_std = a.pr.kind == PRIOR_STANDARD;
-  constexpr bool dg0 = DIAG0;
+  constexpr bool dg0 = NZ0 != 0;
+  constexpr bool aemd0 = NZ0 == 2;
 
   // level 0 in scalars of its own (the step loop below), the levels above in arrays indexed by level - 1
   double cur0[EPT], curU[NLEV - 1][EPT], prp[EPT];
@@ -705,6 +708,21 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
     ob[i] = (has_b[i] ? wave + i * NW : 0) * 16 + hi;
+  }
+  double yc[aemd0 ? RB : 1][4], wc[aemd0 ? RB : 1][4];
+  if constexpr (aemd0) {
+    const int m0 = a.aem_ld;  // real output count = row stride of the [N][m] bias / inverse-variance arrays
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = ob[i] + 4 * r;
+        const bool in = has_b[i] && gcl < a.N && o < m0;
+        yc[i][r] = s_stage[a.lds_y[0] + o] - (in ? a.aem_bias[(size_t)gcl * m0 + o] : 0.0);
+        wc[i][r] = in ? a.aem_P[(size_t)gcl * m0 + o] : 0.0;
+      }
+  } else {
+    yc[0][0] = wc[0][0] = 0.0;
   }
 
   // ---- model outputs of the current coarse state, re-derived from theta at every launch and after every fine step ----
@@ -806,8 +824,13 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
     for (int i = 0; i < RB; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        yv[i][r] = s_stage[a.lds_y[0] + ob[i] + 4 * r];
-        wv[i][r] = dg0 ? s_stage[a.lds_w[0] + ob[i] + 4 * r] : 1.0;
+        if constexpr (aemd0) {  // this chain's corrected data y - b and inverse variances: registers for the whole subchain
+          yv[i][r] = yc[i][r];
+          wv[i][r] = wc[i][r];
+        } else {
+          yv[i][r] = s_stage[a.lds_y[0] + ob[i] + 4 * r];
+          wv[i][r] = dg0 ? s_stage[a.lds_w[0] + ob[i] + 4 * r] : 1.0;
+        }
       }
     double sse = 0.0;
 #pragma unroll
@@ -894,7 +917,7 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
     step0 += 1;
     cnt0 += 1;
     DA_STAMP(6);
-    if (cnt0 != L0) continue;
+    if (!a.cascade || cnt0 != L0) continue;  // (host-sequenced level actions: the launch ends with the subchain)
 
     // ================= upper levels whose subchain just completed (chain.py:354-402; MLDA: proposal.py:1441-1530) =========
     // Level q = k + 1 is evaluated directly at y = the state of the levels below it (after an action of level q - 1 these all

@@ -1,6 +1,6 @@
 """One seeded run of a configuration whose kernel choice an environment switch changes; records to an .npz.  The switches are
 read once per process, so A/B comparisons start this script twice (tests/test_gpu_switches.py).
-    python tools/switch_probe.py {mlda3|da2|aemd|dream} out.npz"""
+    python tools/switch_probe.py {mlda3|da2|aemd|aemd_lean|dream} out.npz"""
 import os
 import sys
 
@@ -54,6 +54,8 @@ if __name__ == "__main__":
         res = hierarchy((256, 1024), [10], "pcn", 8)
     elif what == "aemd":
         res = hierarchy((200, 200, 200), [5, 3], "am", 8, N=96, error_model="state-independent-diagonal")
+    elif what == "aemd_lean":  # at most 128 outputs: the base subchains are eligible for k_da_steps
+        res = hierarchy((128, 128, 128), [5, 3], "am", 8, N=96, error_model="state-independent-diagonal")
     else:
         res = dream()
     np.savez(out, **res)
