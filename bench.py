@@ -141,7 +141,7 @@ def cpu_baseline(A, y, target_seconds=12.0):
         except Exception:
             one_thread = contextlib.nullcontext()
         th0 = np.random.default_rng(3).standard_normal(D)
-        n_ref = 400
+        n_ref = 3000
         with one_thread:
             orc.reference_shaped_am_chain(A, y, SIGMA ** 2, th0, 20, 1e-4 * np.eye(D))
             t0 = time.perf_counter()
