@@ -412,12 +412,17 @@ int launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st) {
 #undef TDA_DA_LAUNCH
     return TDA_OK;
   }
+  auto go = [&](auto kern) -> int {
+    if (lds > 64 * 1024)  // beyond the default dynamic-LDS window (the residual tile of an error model at several hundred outputs)
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, st, a);
+    return TDA_OK;
+  };
   switch (a.nlev) {
-    case 2: hipLaunchKernelGGL((k_ml_steps<DPAD, 2>), dim3((unsigned)tiles), dim3(256), lds, st, a); break;
-    case 3: hipLaunchKernelGGL((k_ml_steps<DPAD, 3>), dim3((unsigned)tiles), dim3(256), lds, st, a); break;
-    default: hipLaunchKernelGGL((k_ml_steps<DPAD, 4>), dim3((unsigned)tiles), dim3(256), lds, st, a); break;
+    case 2: return go(&k_ml_steps<DPAD, 2>);
+    case 3: return go(&k_ml_steps<DPAD, 3>);
+    default: return go(&k_ml_steps<DPAD, 4>);
   }
-  return TDA_OK;
 }
 
 template <int DPAD>
@@ -2631,7 +2636,10 @@ static int run_ext_hierarchy_block(tda_engine* e, const MLArgs& ma, int64_t S, b
   static const bool aemd_fused_ok = !(getenv("TINYDA_AEMD_FUSED") && atoi(getenv("TINYDA_AEMD_FUSED")) == 0);
   bool all_linear = true;
   for (int k = 0; k < nl; ++k) all_linear = all_linear && e->levels[k].model == MODEL_LINEAR && e->levels[k].Apk.p != nullptr;
-  const size_t aemd_lds = ((size_t)16 * (DP + 2) + 128 + ma.lds_total + (e->prior_kind == PRIOR_DENSE ? e->prior_ncb * 16 : 0) +
+  // (LDS of k_ml_steps with only the base level staged: proposal tile, reduction slabs, level 0's data [and weights], prior rows,
+  // the residual tile; lds_y[0] = 0, so the base level's slab is the first of the staging region)
+  const int stage0 = e->levels[0].m_pad * (e->levels[0].noise_kind == TDA_NOISE_DIAG ? 2 : 1);
+  const size_t aemd_lds = ((size_t)16 * (DP + 2) + 128 + stage0 + (e->prior_kind == PRIOR_DENSE ? e->prior_ncb * 16 : 0) +
                            16 * (e->levels[0].m_pad + 2) + 16) * sizeof(double);
   const bool aemd_fused = aemd_fused_ok && e->aem == TDA_AEM_STATE_INDEPENDENT_DIAGONAL && all_linear && !e->randomize && !e->is_dreamz &&
                           aemd_lds <= 160 * 1024;
@@ -2684,6 +2692,7 @@ static int run_ext_hierarchy_block(tda_engine* e, const MLArgs& ma, int64_t S, b
       mb.aem_ld = e->levels[0].m;
       mb.aem_bias = e->aemd_bias[0].p;
       mb.aem_P = e->aemd_w[0].p;
+      mb.lds_total = stage0;
       mb.inc = e->inc.p + (size_t)s * NP * DP;
       mb.u0 = e->ublk.p + (size_t)s * NP;
       mb.logu0 = nullptr;

@@ -109,6 +109,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
 
 #pragma unroll
   for (int k = 0; k < NLEV; ++k) {
+    if (k > 0 && !a.cascade) break;  // host-sequenced level actions: only the base level is evaluated here (and staged: the
+                                     // residual tile of the error models needs the room)
     for (int i = tid; i < a.lv[k].m_pad; i += NT) {
       s_stage[a.lds_y[k] + i] = a.lv[k].ytil[i];
       if (a.lv[k].noise_kind == 1) s_stage[a.lds_w[k] + i] = a.lv[k].w[i];
@@ -220,11 +222,29 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
           const int64_t gc = tile * 16 + cc;
           const double* rrow = s_R + cc * RSa;
           double sacc = 0.0;
-          if (gc < a.N)
-            for (int o = lane; o < LD; o += 64) {
-              const double r = rrow[o] + a.aem_bias[gc * LD + o];
-              sacc += a.aem_P[gc * LD + o] * (r * r);
+          if (gc < a.N) {
+            // eight outputs per lane in flight (the loop is bound by the latency of the two loads per output, not by their volume)
+            const double* __restrict__ bc = a.aem_bias + gc * LD;
+            const double* __restrict__ wc = a.aem_P + gc * LD;
+            int o = lane;
+            for (; o + 7 * 64 < LD; o += 8 * 64) {
+              double bv[8], wv[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                bv[u] = bc[o + 64 * u];
+                wv[u] = wc[o + 64 * u];
+              }
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                const double r = rrow[o + 64 * u] + bv[u];
+                sacc += wv[u] * (r * r);
+              }
             }
+            for (; o < LD; o += 64) {
+              const double r = rrow[o] + bc[o];
+              sacc += wc[o] * (r * r);
+            }
+          }
           for (int off = 32; off >= 1; off >>= 1) sacc += __shfl_xor(sacc, off);
           if (lane == 0) s_R[16 * RSa + cc] = -0.5 * sacc;
         }
@@ -610,11 +630,13 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
   const uint32_t gchain = (uint32_t)(a.chain_offset + gcl);
 
 #pragma unroll
-  for (int k = 0; k < NLEV; ++k)
+  for (int k = 0; k < NLEV; ++k) {
+    if (k > 0 && !a.cascade) break;  // (host-sequenced level actions: only the base level is evaluated, and staged)
     for (int i = tid; i < a.lv[k].m_pad; i += NT) {
       s_stage[a.lds_y[k] + i] = a.lv[k].ytil[i];
       if (a.lv[k].noise_kind == 1) s_stage[a.lds_w[k] + i] = a.lv[k].w[i];
     }
+  }
   for (int i = tid; i < DPAD; i += NT) {
     s_pm[i] = a.pr.mean[i];
     s_pinv[i] = a.pr.pinv[i];
