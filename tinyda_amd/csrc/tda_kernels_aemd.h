@@ -238,51 +238,115 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_aemd_action(const AemdArgs a
 
   // ---- model outputs of the aligned links, tracker of the pair (k, q), stacked bias / inverse variances of level k,
   //      update_link of level k's latest link (posterior.py:112-134) ----
+  // Two outputs per lane and pass, every load of a pass before its first store: the arrays may alias as far as the compiler can
+  // tell, so a load written after a store waits for it -- in the one-output-at-a-time form a pass was a chain of ~15 dependent
+  // trips to memory (25 us per action at m = 128, 156 us at m = 1024).
   const double t = (double)a.b_t;
   const double ca = (t - 1.0) / t, cb = 1.0 / t;
   bool small = true;  // every entry of the total bias variance below 1e-9: set_bias keeps the inverse (distributions.py:399-402)
-  for (int o = lane; o < m; o += 64) {
-    const double fnew = a.F[c * m + o];
-    const double fq_cur = acc ? fnew : a.Fcur[q][c * m + o];
-    const double fk_cur = acc ? a.Fcur[k][c * m + o] : FS(k, q)[o];
-    if (acc) {
-      a.Fcur[q][c * m + o] = fnew;
-    } else {
-      for (int j = 0; j < q; ++j) a.Fcur[j][c * m + o] = FS(j, q)[o];
+  for (int o0 = lane; o0 < m; o0 += 128) {
+    double fnew[2], fq_old[2], fj_old[MAXLEV - 1][2], fs[MAXLEV - 1][2], md_old[2], mu_p[MAXLEV][2], var_p[MAXLEV][2];
+    bool in[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int o = o0 + 64 * u;
+      in[u] = o < m;
+      const size_t i = (size_t)c * m + (in[u] ? o : o0);
+      fnew[u] = a.F[i];
+      fq_old[u] = a.Fcur[q][i];
+      md_old[u] = a.md[q][i];
+#pragma unroll
+      for (int j = 0; j < MAXLEV - 1; ++j)  // (constant trip counts + predicates: the per-level values stay in registers)
+        if (j < q) {
+          fj_old[j][u] = a.Fcur[j][i];
+          fs[j][u] = FS(j, q)[in[u] ? o : o0];
+        } else {
+          fj_old[j][u] = fs[j][u] = 0.0;
+        }
+#pragma unroll
+      for (int p = 1; p < MAXLEV; ++p)
+        if (p >= q && p < nl) {
+          mu_p[p][u] = a.mu[p][i];
+          var_p[p][u] = a.var[p][i];
+        } else {
+          mu_p[p][u] = var_p[p][u] = 0.0;
+        }
     }
-    for (int j = 0; j < q; ++j) {
-      const double fj = a.Fcur[j][c * m + o];  // this very lane wrote / owns the entry
-      for (int q2 = j + 1; q2 <= q; ++q2) FS(j, q2)[o] = fj;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (!in[u]) continue;
+      const int o = o0 + 64 * u;
+      const size_t i = (size_t)c * m + o;
+      const double fq_cur = acc ? fnew[u] : fq_old[u];
+      double fk_cur = 0.0;  // acc ? Fcur[k] : FS(k, q): the aligned output of level k, picked up in the loop below
+      if (acc) a.Fcur[q][i] = fnew[u];
+#pragma unroll
+      for (int j = 0; j < MAXLEV - 1; ++j)
+        if (j < q) {
+          const double fj = acc ? fj_old[j][u] : fs[j][u];  // the output of level j's current link after the alignment
+          if (j == k) fk_cur = fj;
+          if (!acc) a.Fcur[j][i] = fj;
+          for (int q2 = j + 1; q2 <= q; ++q2) FS(j, q2)[o] = fj;
+        }
+      // RecursiveSampleMoments.update restricted to the diagonal (utils.py:113-122 with sd = 1, eps = 0)
+      const double diff_new = fq_cur - fk_cur;
+      const double dm = (a.is_da || acc) ? diff_new : md_old[u];  // MLDA refreshes the difference on accept only
+      a.md[q][i] = dm;
+      double mu_o = 0.0, var_o = 0.0;
+#pragma unroll
+      for (int p = 1; p < MAXLEV; ++p)
+        if (p == q) {
+          mu_o = mu_p[p][u];
+          var_o = var_p[p][u];
+        }
+      const double mu_n = (1.0 / (t + 1.0)) * (t * mu_o + dm);
+      const double M = (t * (mu_o * mu_o) - (t + 1.0) * (mu_n * mu_n)) + dm * dm;
+      const double var_n = ca * var_o + cb * M;
+      a.var[q][i] = var_n;
+      a.mu[q][i] = mu_n;
+      double bt = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int p = 1; p < MAXLEV; ++p)  // ascending p, as the reference sums the trackers (proposal.py:1563-1569)
+        if (p >= q && p < nl) {
+          bt += p == q ? mu_n : mu_p[p][u];
+          s2 += p == q ? var_n : var_p[p][u];
+        }
+      a.bias[k][i] = bt;
+      small = small && (s2 < 1e-9);
     }
-    // RecursiveSampleMoments.update restricted to the diagonal (utils.py:113-122 with sd = 1, eps = 0)
-    const double diff_new = fq_cur - fk_cur;
-    const double dm = (a.is_da || acc) ? diff_new : a.md[q][c * m + o];  // MLDA refreshes the difference on accept only
-    a.md[q][c * m + o] = dm;
-    const double mu_o = a.mu[q][c * m + o];
-    const double mu_n = (1.0 / (t + 1.0)) * (t * mu_o + dm);
-    const double M = (t * (mu_o * mu_o) - (t + 1.0) * (mu_n * mu_n)) + dm * dm;
-    a.var[q][c * m + o] = ca * a.var[q][c * m + o] + cb * M;
-    a.mu[q][c * m + o] = mu_n;
-    double bt = 0.0, s2 = 0.0;
-    for (int p = q; p < nl; ++p) {
-      bt += a.mu[p][c * m + o];
-      s2 += a.var[p][c * m + o];
-    }
-    a.bias[k][c * m + o] = bt;
-    small = small && (s2 < 1e-9);
   }
   const bool keep = aemd_wave_all(small);
   double sk = 0.0;
-  for (int o = lane; o < m; o += 64) {
-    double wv = a.w[k][c * m + o];
-    if (!keep) {
-      double s2 = 0.0;
-      for (int p = q; p < nl; ++p) s2 += a.var[p][c * m + o];
-      wv = 1.0 / (a.sig2[k][o] + s2);
-      a.w[k][c * m + o] = wv;
+  for (int o0 = lane; o0 < m; o0 += 128) {
+    double wv[2], s2[2], fk[2], bk[2], dk[2], sg[2];
+    bool in[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int o = o0 + 64 * u;
+      in[u] = o < m;
+      const int oo = in[u] ? o : o0;
+      const size_t i = (size_t)c * m + oo;
+      wv[u] = a.w[k][i];
+      s2[u] = 0.0;
+      if (!keep)
+        for (int p = q; p < nl; ++p) s2[u] += a.var[p][i];  // (loads only: no per-level array needed)
+      sg[u] = a.sig2[k][oo];
+      fk[u] = a.Fcur[k][i];
+      bk[u] = a.bias[k][i];
+      dk[u] = a.data[k][oo];
     }
-    const double r = (a.Fcur[k][c * m + o] + a.bias[k][c * m + o]) - a.data[k][o];
-    sk += wv * (r * r);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (!in[u]) continue;
+      const size_t i = (size_t)c * m + o0 + 64 * u;
+      double w_ = wv[u];
+      if (!keep) {
+        w_ = 1.0 / (sg[u] + s2[u]);
+        a.w[k][i] = w_;
+      }
+      const double r = (fk[u] + bk[u]) - dk[u];
+      sk += w_ * (r * r);
+    }
   }
   const double llk = -0.5 * ext_wave_sum(sk);
   if (lane == 0) {
