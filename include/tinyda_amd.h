@@ -265,6 +265,29 @@ int tda_engine_archive_take(tda_engine* e, double* rows, int64_t* n_steps);
 int tda_engine_archive_append(tda_engine* e, const double* rows, int64_t n_rows);
 int tda_engine_set_archive_auto_append(tda_engine* e, int on);
 
+/* Distributed shared archive (extension; DREAM over several GPUs without replicating the archive).  The reference appends
+ * every chain's state to one archive at every step (ray.py:365-384); replicating it costs every GPU the other ranks' rows over
+ * xGMI at every step (2 MiB per GPU and step at 8192 chains x 32 parameters).  Here every rank keeps only the rows of its own
+ * chains -- segment = [M0 shared initial rows][step][n_chains][dim padded] -- and a proposal reads the 2 delta rows it needs
+ * from the owner's segment in place (peer-mapped memory): a quarter of the traffic, none of it on the critical path of a step.
+ *   tda_engine_archive_ipc_handle   64-byte IPC handle of this engine's segment, to be sent to the other ranks
+ *   tda_engine_archive_pointer      device address of the segment (what engines of ONE process hand to each other)
+ *   tda_engine_set_archive_peers    once, right after init (chain count a multiple of 16, the same on every rank): `handles`
+ *                                   = n_ranks x 64 bytes (entry my_rank ignored) or, for engines of one process, `pointers`
+ *                                   = the segments' device addresses (the other may be NULL)
+ *   tda_engine_run                  then covers at most one exchange interval (sync_every steps, not across an adaptation
+ *                                   boundary) per call; its rows stay invisible until
+ *   tda_engine_archive_publish      called after EVERY rank has finished the block (a barrier / the collective below).
+ *   tda_engine_archive_local_sums   [2][dim] host: column sums / sums of squares of this rank's visible rows not yet in the
+ *                                   archive sums; the ranks add these up (an all-gather of 2 dim doubles, which also is the
+ *                                   barrier) and hand the total to publish, which then runs a pending crossover adaptation.
+ * Results equal the replicated archive's up to the rounding of those sums (they are added per rank, not per row). */
+int tda_engine_archive_ipc_handle(tda_engine* e, void* handle);
+int tda_engine_archive_pointer(tda_engine* e, void** pointer);
+int tda_engine_set_archive_peers(tda_engine* e, int n_ranks, int my_rank, const void* handles, const double* const* pointers);
+int tda_engine_archive_local_sums(tda_engine* e, double* sums);
+int tda_engine_archive_publish(tda_engine* e, const double* sums_total);
+
 /* Pooled AdaptiveMetropolis (extension; tinyDA's AM is strictly per chain, proposal.py:492-500): sums over the rows
  * of a record buffer, out = [n_rows, sum x (dim), sum x x^T (dim*dim)], `rows` a DEVICE pointer to [n_rows][dim],
  * `out` device or host.  One process per GPU all-reduces `out` over RCCL and hands the pooled covariance back with

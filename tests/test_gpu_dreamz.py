@@ -386,3 +386,65 @@ def test_dream_overlapped_exchange_is_sharding_invariant(eng_mod):
     np.testing.assert_array_equal(np.concatenate([e0.dreamz_state()["pCR"], e1.dreamz_state()["pCR"]]), ref_pcr)
     e0.close()
     e1.close()
+
+
+@pytest.mark.parametrize("model,adaptive", [("linear", False), ("rosenbrock", False), ("rosenbrock", True), ("linear", True)])
+def test_dream_distributed_archive_equals_the_replicated_one(eng_mod, model, adaptive):
+    """tda_engine_set_archive_peers: every rank keeps only the rows of its own chains, proposals read the owners' segments in
+    place.  Two engines of this process (half of the chains each, segments exchanged as device pointers) against one engine with
+    the replicated archive: without adaptation bit for bit; with it the crossover sums are added per rank instead of per row, so
+    accept flags must agree and densities / pCR to rounding."""
+    d, N, T, M0, K, seed = 8, 32, 63, 24, 5, 123
+    rng = np.random.default_rng(12)
+    A = rng.standard_normal((12, d)) / np.sqrt(d)
+    y = rng.standard_normal(12)
+    Z0 = rng.standard_normal((M0, d))
+    theta0 = 0.3 * rng.standard_normal((N, d))
+
+    def make(n, off, th):
+        e = eng_mod.Engine(n, d, seed=seed, chain_offset=off)
+        e.set_prior(np.zeros(d), np.eye(d))
+        if model == "linear":
+            e.set_level(0, A, y, 0, 0.25)
+        else:
+            e.set_level_rosenbrock(0, 1.0, 10.0, 0.0, 1.0)
+        e.set_proposal_dreamz(M0, delta=2, nCR=3, adaptive=adaptive, period=20, gamma=1.02, shared=True, sync_every=K, capacity=M0 + T * N)
+        e.set_archive(Z0)
+        e.init(th)
+        return e
+
+    one = make(N, 0, theta0)
+    full = one.run_host(T)
+    ref_pcr = one.dreamz_state()["pCR"]
+    one.close()
+    h = N // 2
+    e0, e1 = make(h, 0, theta0[:h]), make(h, h, theta0[h:])
+    ptrs = [e0.archive_pointer(), e1.archive_pointer()]
+    e0.set_archive_peers(2, 0, pointers=ptrs)
+    e1.set_archive_peers(2, 1, pointers=ptrs)
+    with pytest.raises(Exception):
+        e0.run_host(K + 1)  # more than one exchange interval per call
+    outs0, outs1 = [], []
+    done = 0
+    while done < T:
+        k = min(K, T - done)
+        outs0.append(e0.run_host(k))
+        outs1.append(e1.run_host(k))
+        with pytest.raises(Exception):
+            e0.run_host(1)  # not before the block is published
+        sums = e0.archive_local_sums() + e1.archive_local_sums()
+        e0.archive_publish(sums)
+        e1.archive_publish(sums)
+        done += k
+    assert e0.dreamz_state()["archive_rows"] == M0 + T * N
+    joined = [np.concatenate([np.concatenate([a[k] for a in outs0]), np.concatenate([a[k] for a in outs1])], axis=1) for k in range(3)]
+    pcr = np.concatenate([e0.dreamz_state()["pCR"], e1.dreamz_state()["pCR"]])
+    e0.close()
+    e1.close()
+    assert np.array_equal(joined[2], full[2]), "%d accept flips" % int((joined[2] != full[2]).sum())
+    if adaptive:
+        np.testing.assert_allclose(joined[0], full[0], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(joined[1], full[1], rtol=1e-9)
+        np.testing.assert_allclose(pcr, ref_pcr, rtol=1e-9)
+    else:
+        assert np.array_equal(joined[0], full[0]) and np.array_equal(joined[1], full[1])

@@ -113,6 +113,11 @@ SYMBOLS = {
     "tda_engine_archive_take": (C.c_int, [_P, _P, _P]),
     "tda_engine_archive_append": (C.c_int, [_P, _P, C.c_int64]),
     "tda_engine_set_archive_auto_append": (C.c_int, [_P, C.c_int]),
+    "tda_engine_archive_ipc_handle": (C.c_int, [_P, _P]),
+    "tda_engine_archive_pointer": (C.c_int, [_P, _P]),
+    "tda_engine_set_archive_peers": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
+    "tda_engine_archive_local_sums": (C.c_int, [_P, _P]),
+    "tda_engine_archive_publish": (C.c_int, [_P, _P]),
     "tda_engine_reduce_moments": (C.c_int, [_P, _P, C.c_int64, _P]),
     "tda_engine_set_proposal_covariance": (C.c_int, [_P, _P]),
     "tda_engine_set_prior_joint": (C.c_int, [_P, _P, _P, _P]),

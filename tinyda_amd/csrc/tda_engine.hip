@@ -278,6 +278,16 @@ struct tda_engine {
   std::vector<double> Z0_h;
   int64_t arch_rows = 0;    // rows currently in the archive(s)
   int64_t sums_rows = 0;    // shared archive: rows already in zsum / zsq (the column sums are caught up at adaptation boundaries only)
+  // distributed shared archive (tda_engine_set_archive_peers): this rank's segment is e->arch, the others are peer-mapped
+  int dist_ranks = 0, dist_me = 0;
+  const double* dist_seg[tda::MAX_PEERS] = {};
+  void* dist_opened[tda::MAX_PEERS] = {};   // pointers obtained from hipIpcOpenMemHandle (closed in destroy)
+  int64_t dist_steps = 0;       // global steps whose rows are visible to the proposals (published)
+  int64_t dist_pending = 0;     // steps of the block that ran last, waiting for tda_engine_archive_publish
+  int64_t dist_sum_steps = 0;   // steps whose local rows are already in the column sums
+  bool dist_m0_summed = false;
+  bool dist_adapt_pending = false;
+  double dist_adapt_gamma = 1.0;
   int64_t arch_cap = 0;
   int64_t pending_steps = 0;  // shared mode: steps whose states are in blk_hist but not yet appended
   DevBuf<double> arch, zsum, zsq, dz_pCR, dz_LCR, dz_Delta, dz_coef, dz_epsm, theta_prev, blk_states, blk_hist;
@@ -771,6 +781,8 @@ void tda_engine_destroy(tda_engine* e) {
       (void)hipEventDestroy(e->ev_cp[i]);
     }
   }
+  for (int r = 0; r < tda::MAX_PEERS; ++r)
+    if (e->dist_opened[r]) (void)hipIpcCloseMemHandle(e->dist_opened[r]);
   if (e->ev_dz_adapt) (void)hipEventDestroy(e->ev_dz_adapt);
   if (e->rng_stream) {
     (void)hipStreamSynchronize(e->rng_stream);
@@ -1303,6 +1315,135 @@ int tda_engine_archive_append(tda_engine* e, const double* rows, int64_t n_rows)
   if (rc) return rc;
   e->arch_rows += n_rows;
   if (kind == hipMemcpyHostToDevice) HIP_TRY(hipStreamSynchronize(e->stream));
+  return TDA_OK;
+}
+
+// ---- distributed shared archive: every rank keeps the rows of its own chains, proposals read peers' rows in place ----
+int tda_engine_archive_ipc_handle(tda_engine* e, void* handle) {
+  if (!e || !handle) return fail(TDA_ERR_INVALID, "null argument");
+  if (!e->inited || !e->is_dreamz || !e->dz.shared) return fail(TDA_ERR_STATE, "no shared-archive engine initialised");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "the header promises 64-byte handles");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  hipIpcMemHandle_t h;
+  HIP_TRY(hipIpcGetMemHandle(&h, e->arch.p));
+  memcpy(handle, &h, sizeof h);
+  return TDA_OK;
+}
+
+int tda_engine_archive_pointer(tda_engine* e, void** pointer) {
+  if (!e || !pointer) return fail(TDA_ERR_INVALID, "null argument");
+  if (!e->inited || !e->is_dreamz || !e->dz.shared) return fail(TDA_ERR_STATE, "no shared-archive engine initialised");
+  *pointer = e->arch.p;
+  return TDA_OK;
+}
+
+int tda_engine_set_archive_peers(tda_engine* e, int n_ranks, int my_rank, const void* handles, const double* const* pointers) {
+  if (!e) return fail(TDA_ERR_INVALID, "null engine");
+  if (!e->inited || !e->is_dreamz || !e->dz.shared) return fail(TDA_ERR_STATE, "no shared-archive engine initialised");
+  if (n_ranks < 1 || n_ranks > MAX_PEERS || my_rank < 0 || my_rank >= n_ranks) return fail(TDA_ERR_INVALID, "1 <= n_ranks <= %d, 0 <= my_rank < n_ranks", MAX_PEERS);
+  if (n_ranks > 1 && !handles && !pointers) return fail(TDA_ERR_INVALID, "peer segments need IPC handles or device pointers");
+  if (e->N != e->NP) return fail(TDA_ERR_UNSUPPORTED, "the distributed archive needs a chain count that is a multiple of 16");
+  if (e->arch_rows != e->dz.M0 || e->pending_steps || e->dist_ranks) return fail(TDA_ERR_STATE, "set the peers once, right after init");
+  const Level& lv = e->levels[0];
+  if (lv.model == MODEL_CALLBACK || lv.model == MODEL_USER) return fail(TDA_ERR_UNSUPPORTED, "the distributed archive serves the engine's own models");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  for (int r = 0; r < n_ranks; ++r) {
+    if (r == my_rank) {
+      e->dist_seg[r] = e->arch.p;
+    } else if (pointers) {
+      if (!pointers[r]) return fail(TDA_ERR_INVALID, "null segment pointer of rank %d", r);
+      e->dist_seg[r] = pointers[r];
+    } else {
+      hipIpcMemHandle_t h;
+      memcpy(&h, (const char*)handles + (size_t)r * sizeof h, sizeof h);
+      void* p = nullptr;
+      HIP_TRY(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+      e->dist_opened[r] = p;
+      e->dist_seg[r] = (const double*)p;
+    }
+  }
+  e->dist_ranks = n_ranks;
+  e->dist_me = my_rank;
+  e->dist_steps = e->dist_pending = e->dist_sum_steps = 0;
+  e->dist_m0_summed = false;
+  e->auto_append = false;
+  return TDA_OK;
+}
+
+// column sums and sums of squares [2][d] (host) of this rank's rows that are visible but not yet in the archive sums: the ranks
+// exchange these (2 d doubles) instead of the rows themselves
+int tda_engine_archive_local_sums(tda_engine* e, double* sums) {
+  if (!e || !sums) return fail(TDA_ERR_INVALID, "null argument");
+  if (!e->dist_ranks) return fail(TDA_ERR_STATE, "no distributed archive");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const int d = e->d, DP = e->DP;
+  std::fill(sums, sums + 2 * d, 0.0);
+  const int64_t from = e->dist_sum_steps, upto = e->dist_steps;  // rows before the block that waits for publication
+  if (upto <= from) return TDA_OK;
+  const int64_t nrows = (upto - from) * e->N, row0 = e->dz.M0 + from * e->N;
+  const int64_t nb = (nrows + COLSUM_CHUNK - 1) / COLSUM_CHUNK;
+  int rc;
+  if (e->dz_partial.n < (size_t)nb * 2 * DP) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if ((rc = e->dz_partial.alloc((size_t)nb * 2 * DP))) return rc;
+  }
+  DevBuf<double> tmp;
+  if ((rc = tmp.alloc((size_t)2 * DP))) return rc;
+  HIP_TRY(hipMemsetAsync(tmp.p, 0, 2 * DP * sizeof(double), e->stream));
+  DISPATCH_DPAD(DP, launch_colsum<DPAD>(e->arch.p, row0, nrows, e->dz_partial.p, nb, e->stream));
+  DISPATCH_DPAD(DP, launch_colsum_final<DPAD>(e->dz_partial.p, nb, tmp.p, tmp.p + DP, e->stream));
+  std::vector<double> h((size_t)2 * DP);
+  HIP_TRY(hipMemcpyAsync(h.data(), tmp.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  for (int j = 0; j < d; ++j) {
+    sums[j] = h[j];
+    sums[d + j] = h[DP + j];
+  }
+  return TDA_OK;
+}
+
+// every rank has finished the block: its rows become visible to the proposals; sums_total ([2][d], host; may be NULL when the
+// proposal does not adapt) = the ranks' local sums added up -- the same on every rank --, then the adaptation the block left pending
+int tda_engine_archive_publish(tda_engine* e, const double* sums_total) {
+  if (!e) return fail(TDA_ERR_INVALID, "null engine");
+  if (!e->dist_ranks) return fail(TDA_ERR_STATE, "no distributed archive");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const int d = e->d, DP = e->DP;
+  const int64_t rows_before = e->dz.M0 + e->dist_steps * e->N * e->dist_ranks;  // the archive the pending block proposed from
+  if (sums_total) {
+    std::vector<double> zs(DP), zq(DP);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(zs.data(), e->zsum.p, DP * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(zq.data(), e->zsq.p, DP * sizeof(double), hipMemcpyDeviceToHost));
+    if (!e->dist_m0_summed) {  // the M0 shared initial rows: every rank holds them, nobody exchanges them
+      std::vector<double> z0((size_t)e->dz.M0 * DP);
+      HIP_TRY(hipMemcpy(z0.data(), e->arch.p, z0.size() * sizeof(double), hipMemcpyDeviceToHost));
+      for (int64_t r = 0; r < e->dz.M0; ++r)
+        for (int j = 0; j < d; ++j) {
+          zs[j] += z0[(size_t)r * DP + j];
+          zq[j] += z0[(size_t)r * DP + j] * z0[(size_t)r * DP + j];
+        }
+      e->dist_m0_summed = true;
+    }
+    for (int j = 0; j < d; ++j) {
+      zs[j] += sums_total[j];
+      zq[j] += sums_total[d + j];
+    }
+    HIP_TRY(hipMemcpy(e->zsum.p, zs.data(), DP * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->zsq.p, zq.data(), DP * sizeof(double), hipMemcpyHostToDevice));
+    e->dist_sum_steps = e->dist_steps;
+    e->sums_rows = rows_before;
+  }
+  if (e->dist_adapt_pending) {
+    if (e->dz.adaptive && !sums_total) return fail(TDA_ERR_INVALID, "an adaptation is pending: publish needs the archive sums");
+    int rc = dreamz_sums_catchup(e, rows_before, 0, true, e->dz.adaptive != 0, e->dist_adapt_gamma);
+    if (rc) return rc;
+    e->k_adapt += 1;
+    e->dist_adapt_pending = false;
+  }
+  e->dist_steps += e->dist_pending;
+  e->dist_pending = 0;
+  e->arch_rows = e->dz.M0 + e->dist_steps * e->N * e->dist_ranks;
   return TDA_OK;
 }
 
@@ -3668,7 +3809,7 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
   // every SIMD and the steps' dependent chains wait behind it, s_setprio made no difference) and every block pays ~13 us for
   // the cross-stream events: 1.00e9 evals/s against 1.19e9 for the plain sequence.
   static const bool pipe_ok = getenv("TINYDA_DZ_PIPELINE") && atoi(getenv("TINYDA_DZ_PIPELINE")) == 1;
-  const bool pipe = pipe_ok && sh && e->auto_append && N == NP && e->pending_steps == 0 && !ext_model0;
+  const bool pipe = pipe_ok && sh && e->auto_append && N == NP && e->pending_steps == 0 && !ext_model0 && !e->dist_ranks;
   if (pipe && !e->dz_coef2.p) {
     int rc;
     if ((rc = e->dz_coef2.alloc((size_t)e->SMAX * NP * DP)) || (rc = e->dz_epsm2.alloc((size_t)e->SMAX * NP * DP)) ||
@@ -3690,10 +3831,17 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     if (sh) {
       const int64_t K = e->dz.sync_every > 0 ? e->dz.sync_every : e->SMAX;
       S = std::min<int64_t>(S, K);
-      if (!e->auto_append && e->pending_steps + S > e->SMAX) S = e->SMAX - e->pending_steps;
+      if (!e->dist_ranks && !e->auto_append && e->pending_steps + S > e->SMAX) S = e->SMAX - e->pending_steps;
     }
     return S;
   };
+  if (e->dist_ranks) {  // distributed archive: one exchange interval per call, then tda_engine_archive_publish (after the ranks met)
+    if (e->dist_pending) return fail(TDA_ERR_STATE, "distributed archive: call tda_engine_archive_publish before running further");
+    const int64_t K = e->dz.sync_every > 0 ? e->dz.sync_every : e->SMAX;
+    if (n_iter > K || (adaptive && n_iter > period - (e->t % period)))
+      return fail(TDA_ERR_INVALID, "distributed archive: a run() call covers at most one exchange interval (%lld steps) and does not cross an adaptation boundary", (long long)K);
+    if (e->dz.M0 + (e->dist_steps + n_iter) * N > e->arch_cap) return fail(TDA_ERR_INVALID, "archive segment capacity (%lld rows) exceeded", (long long)e->arch_cap);
+  }
   // everything DREAMZ.make_proposal draws for S steps from step t0 on, the archive holding M_base rows: into buffer set `set`
   auto enqueue_draw = [&](int set, int64_t t0, int64_t M_base, int64_t S, int64_t rp_pos, int64_t exp_pos, bool gather, hipStream_t st) {
     DreamDrawArgs da{};
@@ -3732,6 +3880,14 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
       da.u_export = (e->exp_dev ? e->u_exp : e->u_exp_d.p) + (size_t)exp_pos * N;
     }
     da.arch_shared = gather ? e->arch.p : nullptr;
+    if (e->dist_ranks) {
+      da.dist_ranks = e->dist_ranks;
+      da.dist_me = e->dist_me;
+      da.dist_M0 = e->dz.M0;
+      da.dist_nloc = N;
+      da.dist_ntot = N * e->dist_ranks;
+      for (int r = 0; r < e->dist_ranks; ++r) da.seg[r] = e->dist_seg[r];
+    }
     DISPATCH_DPAD(DP, launch_dz_draw<DPAD>(da, st));
   };
   int64_t done = 0, blk = 0;
@@ -3768,8 +3924,11 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     sa.rec_acc = a_dev ? o_acc + (size_t)done * N : (o_acc ? e->rec_acc.p : nullptr);
     // single process, no padding chains: the block's states ARE the next archive rows in canonical order (step-major,
     // chain minor), the kernel appends them in place (the jumps of this block were gathered before it started)
-    const bool direct = sh && e->auto_append && N == NP && e->pending_steps == 0;
-    sa.blk_states = sh ? (direct ? e->arch.p + (size_t)e->arch_rows * DP : e->blk_states.p) : nullptr;
+    const bool dist = e->dist_ranks != 0;
+    const bool direct = !dist && sh && e->auto_append && N == NP && e->pending_steps == 0;
+    // distributed archive: the block's states are this rank's next rows of its own segment, written in place
+    sa.blk_states = sh ? (dist ? e->arch.p + (size_t)(e->dz.M0 + e->dist_steps * N) * DP : (direct ? e->arch.p + (size_t)e->arch_rows * DP : e->blk_states.p))
+                       : nullptr;
     if (ext_model) {
       // model outside the engine's kernels: per step apply the jump, evaluate (callback: one host call for all chains;
       // source-defined: tda_user_eval on the stream), accept, append
@@ -3827,6 +3986,12 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
       ScopedTimer tm(e, 2);
       if ((rc = dreamz_sums_catchup(e, e->arch_rows, S, boundary, adaptive, std::pow(e->dz.gamma, -(double)e->k_adapt)))) return rc;
       e->arch_rows += S;
+    } else if (dist) {
+      // rows are in place in this rank's segment; they become visible (and an adaptation at this boundary runs) in
+      // tda_engine_archive_publish, once every rank has finished the block
+      e->dist_pending = S;
+      e->dist_adapt_pending = boundary;
+      e->dist_adapt_gamma = std::pow(e->dz.gamma, -(double)e->k_adapt);
     } else {
       // keep this block's states for the exchange, [pending + s][NP][DP]
       if (!direct)
@@ -3857,7 +4022,7 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
         e->arch_rows += new_rows;
       }
     }
-    if (boundary) e->k_adapt += 1;
+    if (boundary && !dist) e->k_adapt += 1;
     if (pipe) {
       // block b's steps (and its adaptation, if any) are queued: its buffer set is free once they have run.  The draws of
       // block b + 1 start as soon as the set they overwrite (block b - 1's) is free -- i.e. under block b's steps -- unless

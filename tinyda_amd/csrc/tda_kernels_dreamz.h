@@ -22,6 +22,7 @@ namespace tda {
 enum : uint32_t { STREAM_DREAM = 4 };
 constexpr int MAX_NCR = 8;
 constexpr int MAX_DELTA = 4;
+constexpr int MAX_PEERS = 16;
 
 struct DreamDrawArgs {
   int64_t N, NP, chain_offset;
@@ -52,6 +53,13 @@ struct DreamDrawArgs {
   // chains AND free of the step kernel's accept/reject chain -- gathers the archive rows and writes the finished jump
   // mask * ((1 + e) * gamma * (sum Z[r1] - sum Z[r2]) + eps) into `coef`; k_dreamz_steps then only adds it (jump_ready)
   const double* arch_shared;  // [cap][DPAD] or null
+  // distributed shared archive (tda_engine_set_archive_peers): the archive is NOT replicated -- rank o keeps the rows of its own
+  // chains, seg[o] = [M0 shared initial rows][step][n_local chains][DPAD], reachable from every rank (peer-mapped).  Global row
+  // r >= M0 is (step s, global chain g) = divmod(r - M0, n_total), owned by rank g / n_local at local row M0 + s n_local + g % n_local.
+  int dist_ranks;              // 0 = off
+  int dist_me;
+  long long dist_M0, dist_nloc, dist_ntot;
+  const double* seg[MAX_PEERS];
 };
 
 // 64 / DPAD chains share a wave (lane = chain-in-wave * DPAD + parameter), so small dimensions do not idle lanes
@@ -134,10 +142,17 @@ __global__ void __launch_bounds__(64) k_dreamz_draw(const DreamDrawArgs a) {
     }
     double zs1 = 0.0, zs2 = 0.0;
     if (a.arch_shared) {  // rows in flight under the draws below
+      auto row_of = [&](int r) -> const double* {
+        if (a.dist_ranks == 0) return a.arch_shared + (size_t)r * DPAD;
+        if (r < a.dist_M0) return a.seg[a.dist_me] + (size_t)r * DPAD;
+        const long long q = r - a.dist_M0, sg = q / a.dist_ntot, g = q - sg * a.dist_ntot;
+        const long long o = g / a.dist_nloc, l = g - o * a.dist_nloc;
+        return a.seg[o] + (size_t)(a.dist_M0 + sg * a.dist_nloc + l) * DPAD;
+      };
       for (int i = 0; i < a.delta; ++i) {
         const int r1i = __shfl(r1, seg * DPAD + i), r2i = __shfl(r2, seg * DPAD + i);
-        zs1 += a.arch_shared[(size_t)r1i * DPAD + lane];
-        zs2 += a.arch_shared[(size_t)r2i * DPAD + lane];
+        zs1 += row_of(r1i)[lane];
+        zs2 += row_of(r2i)[lane];
       }
     }
     // ---- crossover index and the index forced when the subspace is empty (proposal.py:829-839) ----

@@ -182,6 +182,41 @@ class Engine:
     def set_archive_auto_append(self, on):
         self._ck(self.lib.tda_engine_set_archive_auto_append(self.h, int(on)))
 
+    # -- distributed shared archive (every rank keeps its own rows; include/tinyda_amd.h) ------------
+    def archive_ipc_handle(self):
+        h = (C.c_ubyte * 64)()
+        self._ck(self.lib.tda_engine_archive_ipc_handle(self.h, C.byref(h)))
+        return bytes(h)
+
+    def archive_pointer(self):
+        p = C.c_void_p()
+        self._ck(self.lib.tda_engine_archive_pointer(self.h, C.byref(p)))
+        return p.value
+
+    def set_archive_peers(self, n_ranks, my_rank, handles=None, pointers=None):
+        """handles: list of n_ranks 64-byte IPC handles (other processes) or pointers: list of n_ranks device addresses (engines
+        of this process); the entry of my_rank is ignored"""
+        hb = pb = None
+        if handles is not None:
+            assert len(handles) == n_ranks and all(len(x) == 64 for x in handles)
+            hb = (C.c_ubyte * (64 * n_ranks)).from_buffer_copy(b"".join(handles))
+        if pointers is not None:
+            assert len(pointers) == n_ranks
+            pb = (C.c_void_p * n_ranks)(*[C.c_void_p(int(x)) for x in pointers])
+        self._ck(self.lib.tda_engine_set_archive_peers(self.h, n_ranks, my_rank, hb, pb))
+        self._dz["dist_ranks"] = n_ranks
+
+    def archive_local_sums(self):
+        out = np.zeros((2, self.dim))
+        self._ck(self.lib.tda_engine_archive_local_sums(self.h, _ptr(out)))
+        return out
+
+    def archive_publish(self, sums_total=None):
+        if sums_total is not None:
+            sums_total = _f64(sums_total)
+            assert sums_total.shape == (2, self.dim)
+        self._ck(self.lib.tda_engine_archive_publish(self.h, _ptr(sums_total)))
+
     def archive_take(self, rows=None):
         """shared archive: number of pending steps; if `rows` ([steps, chains, dim] array / tensor) is given it is filled"""
         n = np.zeros(1, dtype=np.int64)
