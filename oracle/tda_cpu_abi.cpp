@@ -472,6 +472,11 @@ int tda_engine_set_replay_dreamz(tda_engine*, const int32_t*, const int32_t*, co
 int tda_engine_get_dreamz_state(tda_engine*, double*, int64_t*) { TDA_CPU_UNSUPPORTED("DREAM(Z)"); }
 int tda_engine_archive_take(tda_engine*, double*, int64_t*) { TDA_CPU_UNSUPPORTED("DREAM"); }
 int tda_engine_archive_append(tda_engine*, const double*, int64_t) { TDA_CPU_UNSUPPORTED("DREAM"); }
+int tda_engine_archive_ipc_handle(tda_engine*, void*) { TDA_CPU_UNSUPPORTED("DREAM"); }
+int tda_engine_archive_pointer(tda_engine*, void**) { TDA_CPU_UNSUPPORTED("DREAM"); }
+int tda_engine_set_archive_peers(tda_engine*, int, int, const void*, const double* const*) { TDA_CPU_UNSUPPORTED("DREAM"); }
+int tda_engine_archive_local_sums(tda_engine*, double*) { TDA_CPU_UNSUPPORTED("DREAM"); }
+int tda_engine_archive_publish(tda_engine*, const double*) { TDA_CPU_UNSUPPORTED("DREAM"); }
 int tda_engine_set_archive_auto_append(tda_engine*, int) { TDA_CPU_UNSUPPORTED("DREAM"); }
 int tda_engine_reduce_moments(tda_engine*, const double*, int64_t, double*) { TDA_CPU_UNSUPPORTED("pooled moments"); }
 int tda_engine_set_proposal_covariance(tda_engine*, const double*) { TDA_CPU_UNSUPPORTED("pooled moments"); }

@@ -169,3 +169,25 @@ def test_collectives_on_rccl_with_one_rank():
     out = json.loads(line)
     assert out["ok"] and out["backend"] == "nccl"
     assert all(v for k, v in out.items() if k.endswith("_identical"))
+
+
+def test_distributed_archive_across_processes():
+    """tools/peer_archive_check.py: two processes on this GPU, archive segments exchanged as IPC handles and mapped into each
+    other's address space, block-wise publish protocol driven by distributed.run_peer_dream over gloo; the union of the two
+    ranks' records equals the one-engine run with the replicated archive"""
+    import socket
+
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TINYDA_BENCH_ONE_GPU", "TINYDA_FORCE_COLLECTIVES"):
+        env.pop(k, None)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tools", "peer_archive_check.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["ok"], out

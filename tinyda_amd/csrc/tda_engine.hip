@@ -281,6 +281,7 @@ struct tda_engine {
   // distributed shared archive (tda_engine_set_archive_peers): this rank's segment is e->arch, the others are peer-mapped
   int dist_ranks = 0, dist_me = 0;
   const double* dist_seg[tda::MAX_PEERS] = {};
+  DevBuf<const double*> dist_seg_dev;        // the same table in device memory (k_dreamz_draw<., true>)
   void* dist_opened[tda::MAX_PEERS] = {};   // pointers obtained from hipIpcOpenMemHandle (closed in destroy)
   int64_t dist_steps = 0;       // global steps whose rows are visible to the proposals (published)
   int64_t dist_pending = 0;     // steps of the block that ran last, waiting for tda_engine_archive_publish
@@ -437,7 +438,8 @@ int launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st) {
 
 template <int DPAD>
 void launch_dz_draw(const DreamDrawArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_dreamz_draw<DPAD>, dim3((unsigned)(a.NP / dz_chains_per_wave<DPAD>())), dim3(64), 0, st, a);
+  if (a.dist_ranks) hipLaunchKernelGGL((k_dreamz_draw<DPAD, true>), dim3((unsigned)(a.NP / dz_chains_per_wave<DPAD>())), dim3(64), 0, st, a);
+  else hipLaunchKernelGGL((k_dreamz_draw<DPAD, false>), dim3((unsigned)(a.NP / dz_chains_per_wave<DPAD>())), dim3(64), 0, st, a);
 }
 template <int DPAD>
 void launch_dz_steps(const DreamStepArgs& a, size_t lds, hipStream_t st) {
@@ -1361,6 +1363,11 @@ int tda_engine_set_archive_peers(tda_engine* e, int n_ranks, int my_rank, const 
       e->dist_opened[r] = p;
       e->dist_seg[r] = (const double*)p;
     }
+  }
+  {
+    int rc = e->dist_seg_dev.alloc((size_t)n_ranks);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(e->dist_seg_dev.p, e->dist_seg, (size_t)n_ranks * sizeof(const double*), hipMemcpyHostToDevice));
   }
   e->dist_ranks = n_ranks;
   e->dist_me = my_rank;
@@ -3886,7 +3893,7 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
       da.dist_M0 = e->dz.M0;
       da.dist_nloc = N;
       da.dist_ntot = N * e->dist_ranks;
-      for (int r = 0; r < e->dist_ranks; ++r) da.seg[r] = e->dist_seg[r];
+      da.seg = e->dist_seg_dev.p;
     }
     DISPATCH_DPAD(DP, launch_dz_draw<DPAD>(da, st));
   };

@@ -59,7 +59,8 @@ struct DreamDrawArgs {
   int dist_ranks;              // 0 = off
   int dist_me;
   long long dist_M0, dist_nloc, dist_ntot;
-  const double* seg[MAX_PEERS];
+  const double* const* seg;    // [dist_ranks] device table of the segments' addresses (a table in memory: indexing an array inside
+                               // the kernel arguments per lane would copy the whole argument block to scratch)
 };
 
 // 64 / DPAD chains share a wave (lane = chain-in-wave * DPAD + parameter), so small dimensions do not idle lanes
@@ -68,7 +69,8 @@ constexpr int dz_chains_per_wave() {
   return 64 / DPAD;
 }
 
-template <int DPAD>
+// DIST: the shared archive is distributed over the ranks (a template parameter: the plain kernel stays as it was)
+template <int DPAD, bool DIST = false>
 __global__ void __launch_bounds__(64) k_dreamz_draw(const DreamDrawArgs a) {
   constexpr int CPW = dz_chains_per_wave<DPAD>();
   const int seg = threadIdx.x / DPAD;
@@ -143,8 +145,8 @@ __global__ void __launch_bounds__(64) k_dreamz_draw(const DreamDrawArgs a) {
     double zs1 = 0.0, zs2 = 0.0;
     if (a.arch_shared) {  // rows in flight under the draws below
       auto row_of = [&](int r) -> const double* {
-        if (a.dist_ranks == 0) return a.arch_shared + (size_t)r * DPAD;
-        if (r < a.dist_M0) return a.seg[a.dist_me] + (size_t)r * DPAD;
+        if constexpr (!DIST) return a.arch_shared + (size_t)r * DPAD;
+        if (r < a.dist_M0) return a.arch_shared + (size_t)r * DPAD;  // (this rank's own copy of the shared initial rows)
         const long long q = r - a.dist_M0, sg = q / a.dist_ntot, g = q - sg * a.dist_ntot;
         const long long o = g / a.dist_nloc, l = g - o * a.dist_nloc;
         return a.seg[o] + (size_t)(a.dist_M0 + sg * a.dist_nloc + l) * DPAD;

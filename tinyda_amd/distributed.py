@@ -204,6 +204,63 @@ def run_shared_dream(engine, n_iterations, sync_every, params=None, stats=None, 
         engine.sync()
 
 
+def setup_peer_archive(engine):
+    """Distributed shared archive (include/tinyda_amd.h: tda_engine_set_archive_peers): exchange the IPC handles of the ranks'
+    archive segments once and map them.  One process per GPU of one node (peer access over xGMI); with one rank it is a no-op
+    apart from switching the engine to the block-wise publish protocol."""
+    import torch.distributed as dist
+
+    if not _collectives_active():
+        engine.set_archive_peers(1, 0, pointers=[engine.archive_pointer()])
+        return 1
+    world, rank = dist.get_world_size(), dist.get_rank()
+    handles = [None] * world
+    dist.all_gather_object(handles, engine.archive_ipc_handle())
+    engine.set_archive_peers(world, rank, handles=handles)
+    return world
+
+
+def run_peer_dream(engine, n_iterations, sync_every, params=None, stats=None, accepted=None, period=None):
+    """Drive a DREAM engine whose shared archive is DISTRIBUTED (setup_peer_archive): per exchange interval one run(), then ONE
+    small collective -- the all-gather of the ranks' column sums of the rows that just became visible, 2 d doubles per rank,
+    which is also the barrier after which those rows may be read -- then publish.  No row ever travels unless a proposal reads
+    it.  `period`: the proposal's adaptation period (a run() call must not cross an adaptation boundary); None = no adaptation."""
+    import torch
+    import torch.distributed as dist
+
+    multi = _collectives_active()
+    world = dist.get_world_size() if multi else 1
+    backend_dev = torch.device("cuda", engine.device) if (multi and dist.get_backend() == "nccl") else torch.device("cpu")
+    done, t = 0, getattr(engine, "_peer_t", 0)  # steps this driver has run on the engine before (adaptation boundaries count from 0)
+    while done < n_iterations:
+        k = min(sync_every, n_iterations - done)
+        if period:
+            k = min(k, period - (t % period))
+        sl = slice(done, done + k)
+        engine.run(k, None if params is None else params[sl], None if stats is None else stats[sl],
+                   None if accepted is None else accepted[sl], sync=False)
+        boundary = bool(period) and (t + k) % period == 0
+        if boundary:
+            # the crossover adaptation needs the column sums of the whole archive: the ranks' partial sums (2 d doubles each),
+            # added in rank order -- the same bits on every rank; the collective is the block's barrier as well
+            local = torch.from_numpy(engine.archive_local_sums()).to(backend_dev)  # (the call waits for the engine's stream)
+            if multi:
+                parts = [torch.empty_like(local) for _ in range(world)]
+                dist.all_gather(parts, local)
+                total = torch.stack(parts).sum(dim=0)
+            else:
+                total = local
+            engine.archive_publish(total.cpu().numpy())
+        else:
+            engine.sync()  # this rank's rows are written ...
+            if multi:
+                dist.barrier()  # ... and so are everybody else's
+            engine.archive_publish(None)
+        done += k
+        t += k
+    engine._peer_t = t
+
+
 class PooledAdaptiveMetropolis:
     """Extension (not in tinyDA, whose AdaptiveMetropolis is strictly per chain): one proposal covariance for all
     chains on all GPUs, C = sd (Cov_pooled + eps I), refreshed every `period` steps once t >= t0.  Each refresh costs

@@ -1,0 +1,78 @@
+"""The distributed shared archive across PROCESSES on the one GPU a box has: two ranks under torch.distributed.run (gloo for the
+control collectives), each with an engine for half of the chains on cuda:0, the segments exchanged as IPC handles and mapped with
+hipIpcOpenMemHandle -- everything the 8-GPU deployment does except that the peer mapping crosses xGMI there.  Rank 0 also runs the
+whole problem on one engine with the replicated archive and compares (bit for bit: no adaptation; to rounding with it).
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P tools/peer_archive_check.py
+Prints one JSON line on rank 0."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from tinyda_amd import distributed as tdist
+from tinyda_amd.engine import Engine
+
+D, N, T, M0, K = 8, 64, 47, 24, 5
+
+
+def make(n, off, theta0, Z0, adaptive):
+    e = Engine(n, D, seed=321, chain_offset=off, device=0)
+    e.set_prior(np.zeros(D), np.eye(D))
+    e.set_level_rosenbrock(0, 1.0, 10.0, 0.0, 1.0)
+    e.set_proposal_dreamz(M0, delta=2, nCR=3, adaptive=adaptive, period=20, gamma=1.02, shared=True, sync_every=K, capacity=M0 + T * N)
+    e.set_archive(Z0)
+    e.init(theta0)
+    return e
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    rng = np.random.default_rng(5)
+    Z0 = rng.standard_normal((M0, D))
+    theta0 = 0.3 * rng.standard_normal((N, D))
+    h = N // world
+    out = {"world": world}
+    for adaptive in (False, True):
+        e = make(h, rank * h, theta0[rank * h:(rank + 1) * h], Z0, adaptive)
+        assert tdist.setup_peer_archive(e) == world
+        dev = torch.device("cuda", 0)
+        p = torch.zeros((T, h, D), dtype=torch.float64, device=dev)
+        s = torch.zeros((T, h, 3), dtype=torch.float64, device=dev)
+        a = torch.zeros((T, h), dtype=torch.uint8, device=dev)
+        tdist.run_peer_dream(e, T, K, p, s, a, period=20 if adaptive else None)
+        e.sync()
+        rows = e.dreamz_state()["archive_rows"]
+        mine = [p.cpu(), s.cpu(), a.cpu()]
+        gathered = [[torch.empty_like(x) for _ in range(world)] for x in mine]
+        for g, x in zip(gathered, mine):
+            dist.all_gather(g, x)
+        dist.barrier()  # nobody unmaps a segment a peer may still read
+        e.close()
+        if rank == 0:
+            one = make(N, 0, theta0, Z0, adaptive)
+            P, S, A = one.run_host(T)
+            one.close()
+            jp, js, ja = (torch.cat(g, dim=1).numpy() for g in gathered)
+            tag = "adaptive" if adaptive else "plain"
+            out[tag + "_rows_ok"] = bool(rows == M0 + T * N)
+            out[tag + "_accept_equal"] = bool(np.array_equal(ja, A))
+            out[tag + "_max_rel_logpost"] = float(np.max(np.abs(js[:, :, 2] - S[:, :, 2]) / np.abs(S[:, :, 2])))
+            out[tag + "_params_equal"] = bool(np.array_equal(jp, P))
+    dist.barrier()
+    if rank == 0:
+        out["ok"] = bool(out["plain_accept_equal"] and out["plain_params_equal"] and out["plain_max_rel_logpost"] == 0.0 and
+                         out["adaptive_accept_equal"] and out["adaptive_max_rel_logpost"] < 1e-9 and out["plain_rows_ok"] and out["adaptive_rows_ok"])
+        print(json.dumps(out), flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
