@@ -13,3 +13,5 @@ echo "all done" | tee -a gpurun_out/r02_progress.log
 python -u tools/bench_configs.py c5aemd 2048 6 >> gpurun_out/r02_configs.jsonl 2>&1
 python -u tools/bench_configs.py c4 128 >> gpurun_out/r02_configs.jsonl 2>&1
 echo "extra configs done" | tee -a gpurun_out/r02_progress.log
+python -u tools/bench_configs.py c4peer 16 >> gpurun_out/r02_configs.jsonl 2>&1
+python -u tools/bench_configs.py c4peer 64 >> gpurun_out/r02_configs.jsonl 2>&1
