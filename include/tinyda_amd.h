@@ -277,7 +277,9 @@ int tda_engine_set_archive_auto_append(tda_engine* e, int on);
  *                                   = the segments' device addresses (the other may be NULL)
  *   tda_engine_run                  then covers at most one exchange interval (sync_every steps, not across an adaptation
  *                                   boundary) per call; its rows stay invisible until
- *   tda_engine_archive_publish      called after EVERY rank has finished the block (a barrier / the collective below).
+ *   tda_engine_archive_publish      (publishes the OLDEST unpublished block) called after EVERY rank has finished that block (a
+ *                                   barrier / the collective below).  At most two blocks may be unpublished: a block may run
+ *                                   while its predecessor's collective is in flight (rows of block b visible from b + 2).
  *   tda_engine_archive_local_sums   [2][dim] host: column sums / sums of squares of this rank's visible rows not yet in the
  *                                   archive sums; the ranks add these up (an all-gather of 2 dim doubles, which also is the
  *                                   barrier) and hand the total to publish, which then runs a pending crossover adaptation.

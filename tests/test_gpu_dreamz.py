@@ -430,8 +430,6 @@ def test_dream_distributed_archive_equals_the_replicated_one(eng_mod, model, ada
         k = min(K, T - done)
         outs0.append(e0.run_host(k))
         outs1.append(e1.run_host(k))
-        with pytest.raises(Exception):
-            e0.run_host(1)  # not before the block is published
         sums = e0.archive_local_sums() + e1.archive_local_sums()
         e0.archive_publish(sums)
         e1.archive_publish(sums)
@@ -444,6 +442,88 @@ def test_dream_distributed_archive_equals_the_replicated_one(eng_mod, model, ada
     assert np.array_equal(joined[2], full[2]), "%d accept flips" % int((joined[2] != full[2]).sum())
     if adaptive:
         np.testing.assert_allclose(joined[0], full[0], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(joined[1], full[1], rtol=1e-9)
+        np.testing.assert_allclose(pcr, ref_pcr, rtol=1e-9)
+    else:
+        assert np.array_equal(joined[0], full[0]) and np.array_equal(joined[1], full[1])
+
+
+@pytest.mark.parametrize("model,adaptive", [("rosenbrock", False), ("linear", True)])
+def test_dream_distributed_archive_lagged_publish(eng_mod, model, adaptive):
+    """two unpublished blocks: block b runs while the collective of block b - 1 is in flight, its rows become visible from block
+    b + 2 -- the lag of run_shared_dream(overlap=True).  Two engines with distributed segments against ONE engine with the
+    replicated archive driven by that pipeline."""
+    import torch
+
+    from tinyda_amd import distributed as tdist
+
+    d, N, T, M0, K, seed, period = 8, 32, 63, 24, 5, 77, 20
+    rng = np.random.default_rng(14)
+    A = rng.standard_normal((12, d)) / np.sqrt(d)
+    y = rng.standard_normal(12)
+    Z0 = rng.standard_normal((M0, d))
+    theta0 = 0.3 * rng.standard_normal((N, d))
+
+    def make(n, off, th, stream=None):
+        e = eng_mod.Engine(n, d, seed=seed, chain_offset=off, stream=stream)
+        e.set_prior(np.zeros(d), np.eye(d))
+        if model == "linear":
+            e.set_level(0, A, y, 0, 0.25)
+        else:
+            e.set_level_rosenbrock(0, 1.0, 10.0, 0.0, 1.0)
+        e.set_proposal_dreamz(M0, delta=2, nCR=3, adaptive=adaptive, period=period, gamma=1.02, shared=True, sync_every=K, capacity=M0 + T * N)
+        e.set_archive(Z0)
+        e.init(th)
+        return e
+
+    ts = torch.cuda.Stream()
+    one = make(N, 0, theta0, ts.cuda_stream)
+    dev = torch.device("cuda", 0)
+    p = torch.zeros((T, N, d), dtype=torch.float64, device=dev)
+    s_ = torch.zeros((T, N, 3), dtype=torch.float64, device=dev)
+    a = torch.zeros((T, N), dtype=torch.uint8, device=dev)
+    tdist.run_shared_dream(one, T, K, p, s_, a, overlap=True, stream=ts)
+    ts.synchronize()
+    full = [p.cpu().numpy(), s_.cpu().numpy(), a.cpu().numpy()]
+    ref_pcr = one.dreamz_state()["pCR"]
+    one.close()
+
+    h = N // 2
+    e0, e1 = make(h, 0, theta0[:h]), make(h, h, theta0[h:])
+    ptrs = [e0.archive_pointer(), e1.archive_pointer()]
+    e0.set_archive_peers(2, 0, pointers=ptrs)
+    e1.set_archive_peers(2, 1, pointers=ptrs)
+    outs0, outs1, unpublished, done, t = [], [], 0, 0, 0
+    while done < T:
+        k = min(K, T - done, period - t % period)
+        if unpublished == 2:
+            e0.archive_publish(None)
+            e1.archive_publish(None)
+            unpublished -= 1
+        outs0.append(e0.run_host(k))
+        outs1.append(e1.run_host(k))
+        unpublished += 1
+        if adaptive and (t + k) % period == 0:
+            sums = e0.archive_local_sums() + e1.archive_local_sums()
+            e0.archive_publish(sums)
+            e1.archive_publish(sums)
+            unpublished -= 1
+        if unpublished == 2:
+            with pytest.raises(Exception):
+                e0.run_host(1)  # a third unpublished block
+        done += k
+        t += k
+    while unpublished:
+        e0.archive_publish(None)
+        e1.archive_publish(None)
+        unpublished -= 1
+    assert e0.dreamz_state()["archive_rows"] == M0 + T * N
+    joined = [np.concatenate([np.concatenate([x[k] for x in outs0]), np.concatenate([x[k] for x in outs1])], axis=1) for k in range(3)]
+    pcr = np.concatenate([e0.dreamz_state()["pCR"], e1.dreamz_state()["pCR"]])
+    e0.close()
+    e1.close()
+    assert np.array_equal(joined[2], full[2]), "%d accept flips" % int((joined[2] != full[2]).sum())
+    if adaptive:
         np.testing.assert_allclose(joined[1], full[1], rtol=1e-9)
         np.testing.assert_allclose(pcr, ref_pcr, rtol=1e-9)
     else:

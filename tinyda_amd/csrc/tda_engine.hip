@@ -284,7 +284,11 @@ struct tda_engine {
   DevBuf<const double*> dist_seg_dev;        // the same table in device memory (k_dreamz_draw<., true>)
   void* dist_opened[tda::MAX_PEERS] = {};   // pointers obtained from hipIpcOpenMemHandle (closed in destroy)
   int64_t dist_steps = 0;       // global steps whose rows are visible to the proposals (published)
-  int64_t dist_pending = 0;     // steps of the block that ran last, waiting for tda_engine_archive_publish
+  int64_t dist_pending = 0;     // steps of the unpublished blocks (at most two: a block may run while its predecessor's collective
+                                // is still in flight -- the rows of block b then become visible from block b + 2)
+  int64_t dist_unpub[2] = {0, 0};  // their step counts, oldest first
+  int dist_n_unpub = 0;
+  int64_t dist_adapt_rows = 0;  // archive size the block that left an adaptation pending proposed from
   int64_t dist_sum_steps = 0;   // steps whose local rows are already in the column sums
   bool dist_m0_summed = false;
   bool dist_adapt_pending = false;
@@ -1372,6 +1376,7 @@ int tda_engine_set_archive_peers(tda_engine* e, int n_ranks, int my_rank, const 
   e->dist_ranks = n_ranks;
   e->dist_me = my_rank;
   e->dist_steps = e->dist_pending = e->dist_sum_steps = 0;
+  e->dist_n_unpub = 0;
   e->dist_m0_summed = false;
   e->auto_append = false;
   return TDA_OK;
@@ -1416,7 +1421,8 @@ int tda_engine_archive_publish(tda_engine* e, const double* sums_total) {
   if (!e->dist_ranks) return fail(TDA_ERR_STATE, "no distributed archive");
   HIP_TRY(hipSetDevice(e->cfg.device));
   const int d = e->d, DP = e->DP;
-  const int64_t rows_before = e->dz.M0 + e->dist_steps * e->N * e->dist_ranks;  // the archive the pending block proposed from
+  if (e->dist_n_unpub == 0) return fail(TDA_ERR_STATE, "distributed archive: nothing to publish");
+  const int64_t rows_before = e->dz.M0 + e->dist_steps * e->N * e->dist_ranks;  // the published archive (what the latest block proposed from)
   if (sums_total) {
     std::vector<double> zs(DP), zq(DP);
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1443,13 +1449,18 @@ int tda_engine_archive_publish(tda_engine* e, const double* sums_total) {
   }
   if (e->dist_adapt_pending) {
     if (e->dz.adaptive && !sums_total) return fail(TDA_ERR_INVALID, "an adaptation is pending: publish needs the archive sums");
+    if (e->dist_adapt_rows != rows_before) return fail(TDA_ERR_STATE, "distributed archive: publish the adaptation before anything else");
     int rc = dreamz_sums_catchup(e, rows_before, 0, true, e->dz.adaptive != 0, e->dist_adapt_gamma);
     if (rc) return rc;
     e->k_adapt += 1;
     e->dist_adapt_pending = false;
   }
-  e->dist_steps += e->dist_pending;
-  e->dist_pending = 0;
+  const int64_t k = e->dist_unpub[0];  // the oldest unpublished block
+  e->dist_unpub[0] = e->dist_unpub[1];
+  e->dist_unpub[1] = 0;
+  e->dist_n_unpub -= 1;
+  e->dist_pending -= k;
+  e->dist_steps += k;
   e->arch_rows = e->dz.M0 + e->dist_steps * e->N * e->dist_ranks;
   return TDA_OK;
 }
@@ -3843,11 +3854,12 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     return S;
   };
   if (e->dist_ranks) {  // distributed archive: one exchange interval per call, then tda_engine_archive_publish (after the ranks met)
-    if (e->dist_pending) return fail(TDA_ERR_STATE, "distributed archive: call tda_engine_archive_publish before running further");
+    if (e->dist_n_unpub >= 2) return fail(TDA_ERR_STATE, "distributed archive: two blocks wait for tda_engine_archive_publish");
+    if (e->dist_adapt_pending) return fail(TDA_ERR_STATE, "distributed archive: an adaptation waits for tda_engine_archive_publish");
     const int64_t K = e->dz.sync_every > 0 ? e->dz.sync_every : e->SMAX;
     if (n_iter > K || (adaptive && n_iter > period - (e->t % period)))
       return fail(TDA_ERR_INVALID, "distributed archive: a run() call covers at most one exchange interval (%lld steps) and does not cross an adaptation boundary", (long long)K);
-    if (e->dz.M0 + (e->dist_steps + n_iter) * N > e->arch_cap) return fail(TDA_ERR_INVALID, "archive segment capacity (%lld rows) exceeded", (long long)e->arch_cap);
+    if (e->dz.M0 + (e->dist_steps + e->dist_pending + n_iter) * N > e->arch_cap) return fail(TDA_ERR_INVALID, "archive segment capacity (%lld rows) exceeded", (long long)e->arch_cap);
   }
   // everything DREAMZ.make_proposal draws for S steps from step t0 on, the archive holding M_base rows: into buffer set `set`
   auto enqueue_draw = [&](int set, int64_t t0, int64_t M_base, int64_t S, int64_t rp_pos, int64_t exp_pos, bool gather, hipStream_t st) {
@@ -3934,7 +3946,7 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     const bool dist = e->dist_ranks != 0;
     const bool direct = !dist && sh && e->auto_append && N == NP && e->pending_steps == 0;
     // distributed archive: the block's states are this rank's next rows of its own segment, written in place
-    sa.blk_states = sh ? (dist ? e->arch.p + (size_t)(e->dz.M0 + e->dist_steps * N) * DP : (direct ? e->arch.p + (size_t)e->arch_rows * DP : e->blk_states.p))
+    sa.blk_states = sh ? (dist ? e->arch.p + (size_t)(e->dz.M0 + (e->dist_steps + e->dist_pending) * N) * DP : (direct ? e->arch.p + (size_t)e->arch_rows * DP : e->blk_states.p))
                        : nullptr;
     if (ext_model) {
       // model outside the engine's kernels: per step apply the jump, evaluate (callback: one host call for all chains;
@@ -3996,9 +4008,11 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     } else if (dist) {
       // rows are in place in this rank's segment; they become visible (and an adaptation at this boundary runs) in
       // tda_engine_archive_publish, once every rank has finished the block
-      e->dist_pending = S;
+      e->dist_unpub[e->dist_n_unpub++] = S;
+      e->dist_pending += S;
       e->dist_adapt_pending = boundary;
       e->dist_adapt_gamma = std::pow(e->dz.gamma, -(double)e->k_adapt);
+      e->dist_adapt_rows = e->arch_rows;  // what this block's proposals could see
     } else {
       // keep this block's states for the exchange, [pending + s][NP][DP]
       if (!direct)

@@ -90,6 +90,13 @@ __global__ void __launch_bounds__(64) k_dreamz_draw(const DreamDrawArgs a) {
     }
   }
   const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
+  // distributed archive: the ranks' segment addresses in LDS (a per-lane pick from a table in memory would put a second
+  // dependent trip to memory in front of every gathered row)
+  __shared__ const double* s_seg[MAX_PEERS];
+  if constexpr (DIST) {
+    if (threadIdx.x < (unsigned)a.dist_ranks) s_seg[threadIdx.x] = a.seg[threadIdx.x];
+    __syncthreads();
+  }
   int mcr = 0;
   // Box-Muller pairs: a chain needs DPAD / 2 pairs per step (pair p -> dimensions 2p, 2p + 1, the RNG contract), its
   // DPAD lanes can draw DPAD pairs at once: the lower half draws the pairs of step s, the upper half those of step
@@ -147,9 +154,11 @@ __global__ void __launch_bounds__(64) k_dreamz_draw(const DreamDrawArgs a) {
       auto row_of = [&](int r) -> const double* {
         if constexpr (!DIST) return a.arch_shared + (size_t)r * DPAD;
         if (r < a.dist_M0) return a.arch_shared + (size_t)r * DPAD;  // (this rank's own copy of the shared initial rows)
-        const long long q = r - a.dist_M0, sg = q / a.dist_ntot, g = q - sg * a.dist_ntot;
-        const long long o = g / a.dist_nloc, l = g - o * a.dist_nloc;
-        return a.seg[o] + (size_t)(a.dist_M0 + sg * a.dist_nloc + l) * DPAD;
+        // 32-bit arithmetic: row indices are ints (the row-pair draw), and a 64-bit division costs ~100 instructions per lane
+        const uint32_t nt = (uint32_t)a.dist_ntot, nlc = (uint32_t)a.dist_nloc;
+        const uint32_t q = (uint32_t)r - (uint32_t)a.dist_M0, sg = q / nt, g = q - sg * nt;
+        const uint32_t o = g / nlc, l = g - o * nlc;
+        return s_seg[o] + ((size_t)a.dist_M0 + (size_t)sg * nlc + l) * DPAD;
       };
       for (int i = 0; i < a.delta; ++i) {
         const int r1i = __shfl(r1, seg * DPAD + i), r2i = __shfl(r2, seg * DPAD + i);

@@ -220,44 +220,89 @@ def setup_peer_archive(engine):
     return world
 
 
-def run_peer_dream(engine, n_iterations, sync_every, params=None, stats=None, accepted=None, period=None):
+def run_peer_dream(engine, n_iterations, sync_every, params=None, stats=None, accepted=None, period=None, lag=False, stream=None):
     """Drive a DREAM engine whose shared archive is DISTRIBUTED (setup_peer_archive): per exchange interval one run(), then ONE
-    small collective -- the all-gather of the ranks' column sums of the rows that just became visible, 2 d doubles per rank,
-    which is also the barrier after which those rows may be read -- then publish.  No row ever travels unless a proposal reads
-    it.  `period`: the proposal's adaptation period (a run() call must not cross an adaptation boundary); None = no adaptation."""
+    small collective -- a barrier; at adaptation boundaries the all-gather of the ranks' column sums of the visible rows, 2 d
+    doubles per rank -- then publish.  No row ever travels unless a proposal reads it.  `period`: the proposal's adaptation
+    period (a run() call must not cross an adaptation boundary); None = no adaptation.
+
+    lag=False: block b's rows are visible to block b + 1; every block ends in a host round trip (stream sync, collective, publish).
+
+    lag=True: block b's rows are visible from block b + 2 (the same fixed lag as run_shared_dream(overlap=True), for any number
+    of ranks): the barrier of block b is issued behind the engine's work on a side stream and runs under block b + 1; the engine's
+    stream waits for it (no host wait) before block b + 2 draws.  Only adaptation boundaries synchronise with the host.  `stream`:
+    the torch.cuda.Stream the engine was created on.  With a CPU backend (gloo) the barrier cannot be stream-ordered and is taken
+    right away -- the same results, none of the overlap."""
+    import contextlib
+
     import torch
     import torch.distributed as dist
 
     multi = _collectives_active()
     world = dist.get_world_size() if multi else 1
-    backend_dev = torch.device("cuda", engine.device) if (multi and dist.get_backend() == "nccl") else torch.device("cpu")
+    on_gpu = multi and dist.get_backend() == "nccl"
+    dev = torch.device("cuda", engine.device)
+    backend_dev = dev if on_gpu else torch.device("cpu")
+    ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+    side = torch.cuda.Stream(device=dev) if (lag and on_gpu) else None
+    token = torch.zeros(1, device=dev) if on_gpu else None
+    in_flight = []  # per unpublished block: the async work of its barrier (None = already taken)
+
+    def meet():
+        """every rank has finished everything it has queued so far: returns the async work (GPU backend, lagged) or None"""
+        if not multi:
+            return None
+        if side is not None:
+            side.wait_stream(stream if stream is not None else torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                return dist.all_reduce(token, async_op=True)
+        engine.sync()
+        dist.barrier()
+        return None
+
+    def publish_oldest(total=None):
+        work = in_flight.pop(0)
+        if work is not None:
+            work.wait()  # orders the current (= the engine's) stream behind the collective, no host wait
+        engine.archive_publish(total)
+
     done, t = 0, getattr(engine, "_peer_t", 0)  # steps this driver has run on the engine before (adaptation boundaries count from 0)
-    while done < n_iterations:
-        k = min(sync_every, n_iterations - done)
-        if period:
-            k = min(k, period - (t % period))
-        sl = slice(done, done + k)
-        engine.run(k, None if params is None else params[sl], None if stats is None else stats[sl],
-                   None if accepted is None else accepted[sl], sync=False)
-        boundary = bool(period) and (t + k) % period == 0
-        if boundary:
-            # the crossover adaptation needs the column sums of the whole archive: the ranks' partial sums (2 d doubles each),
-            # added in rank order -- the same bits on every rank; the collective is the block's barrier as well
-            local = torch.from_numpy(engine.archive_local_sums()).to(backend_dev)  # (the call waits for the engine's stream)
-            if multi:
-                parts = [torch.empty_like(local) for _ in range(world)]
-                dist.all_gather(parts, local)
-                total = torch.stack(parts).sum(dim=0)
+    with ctx:
+        while done < n_iterations:
+            k = min(sync_every, n_iterations - done)
+            if period:
+                k = min(k, period - (t % period))
+            sl = slice(done, done + k)
+            if len(in_flight) == (2 if lag else 1):
+                publish_oldest()
+            engine.run(k, None if params is None else params[sl], None if stats is None else stats[sl],
+                       None if accepted is None else accepted[sl], sync=False)
+            boundary = bool(period) and (t + k) % period == 0
+            if boundary:
+                # the crossover adaptation needs the column sums of the archive the block proposed from: the ranks' partial sums
+                # (2 d doubles each), added in rank order -- the same bits on every rank; the collective is a barrier as well
+                local = torch.from_numpy(engine.archive_local_sums()).to(backend_dev)  # (waits for the engine's stream)
+                if multi:
+                    parts = [torch.empty_like(local) for _ in range(world)]
+                    dist.all_gather(parts, local)
+                    total = torch.stack(parts).sum(dim=0)
+                else:
+                    total = local
+                in_flight.append(None)  # this block is complete on every rank
+                for i in range(len(in_flight)):  # ... and so is everything before it
+                    in_flight[i] = None
+                publish_oldest(total.cpu().numpy())  # adds the sums, adapts, publishes the oldest unpublished block
             else:
-                total = local
-            engine.archive_publish(total.cpu().numpy())
-        else:
-            engine.sync()  # this rank's rows are written ...
-            if multi:
-                dist.barrier()  # ... and so are everybody else's
-            engine.archive_publish(None)
-        done += k
-        t += k
+                in_flight.append(meet() if lag else None)
+                if not lag:
+                    engine.sync()
+                    if multi:
+                        dist.barrier()
+            done += k
+            t += k
+        while in_flight:  # the archive ends complete
+            publish_oldest()
+    engine.sync()
     engine._peer_t = t
 
 

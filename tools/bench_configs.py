@@ -126,7 +126,7 @@ def run_c2b(N=4096, d=64, m=1024, T=300):
     e.close()
 
 
-def run_c4(N=8192, d=32, T=400, M0=320, K=16, peer=False):
+def run_c4(N=8192, d=32, T=400, M0=320, K=16, peer=False, lag=False):
     """C4 on one GPU: d=32 Rosenbrock chain, DREAM (shared archive of M0 prior rows + every chain's states, synchronised
     every K steps), 8192 chains/GPU."""
     from tinyda_amd import distributed as tdist
@@ -141,11 +141,11 @@ def run_c4(N=8192, d=32, T=400, M0=320, K=16, peer=False):
     acc = torch.empty((T, N), dtype=torch.uint8, device="cuda")
     if peer:  # the distributed archive's block-wise publish protocol with the one rank a box has (what it costs on the host side)
         tdist.setup_peer_archive(e)
-        tdist.run_peer_dream(e, 48, K, params, stats, acc, period=100)
+        tdist.run_peer_dream(e, 48, K, params, stats, acc, period=100, lag=lag)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        tdist.run_peer_dream(e, T, K, params, stats, acc, period=100)
+        tdist.run_peer_dream(e, T, K, params, stats, acc, period=100, lag=lag)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print(json.dumps(dict(config="C4 with the distributed archive protocol (one rank), sync every %d" % K, chains=N, steps=T, seconds=dt,
+        print(json.dumps(dict(config="C4 with the distributed archive protocol (one rank%s), sync every %d" % (", lagged publish" if lag else "", K), chains=N, steps=T, seconds=dt,
                               evals_per_s=N * T / dt, archive_rows=e.dreamz_state()["archive_rows"])))
         e.close()
         return
@@ -166,8 +166,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "c3":
         run("C3: DA pCN(0.02) 256/2048 obs, subsampling_rate=10", (256, 2048), [10], dict(kind=1, scaling=0.02), 200)
         sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] in ("c4", "c4peer"):
-        run_c4(K=int(sys.argv[2]) if len(sys.argv) > 2 else 16, peer=sys.argv[1] == "c4peer")
+    if len(sys.argv) > 1 and sys.argv[1] in ("c4", "c4peer", "c4peerlag"):
+        run_c4(K=int(sys.argv[2]) if len(sys.argv) > 2 else 16, peer=sys.argv[1] != "c4", lag=sys.argv[1] == "c4peerlag")
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "mala":
         run_mala()

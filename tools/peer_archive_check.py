@@ -31,6 +31,24 @@ def make(n, off, theta0, Z0, adaptive):
     return e
 
 
+def _lagged_reference(e, P, S, A):
+    """one engine, replicated archive, rows of block b appended before block b + 2 (by hand: no process group involved)"""
+    e.set_archive_auto_append(False)
+    pend, done = [], 0
+    while done < T:
+        k = min(K, T - done)
+        if len(pend) == 2:
+            e.archive_append(pend.pop(0))
+        e.run(k, P[done:done + k], S[done:done + k], A[done:done + k])
+        buf = torch.empty((k, N, D), dtype=torch.float64, device=P.device)
+        e.archive_take(buf)
+        pend.append(buf.reshape(-1, D))
+        done += k
+    for rows in pend:
+        e.archive_append(rows)
+    e.sync()
+
+
 def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -40,14 +58,14 @@ def main():
     theta0 = 0.3 * rng.standard_normal((N, D))
     h = N // world
     out = {"world": world}
-    for adaptive in (False, True):
+    for adaptive, lag in ((False, False), (True, False), (False, True)):
         e = make(h, rank * h, theta0[rank * h:(rank + 1) * h], Z0, adaptive)
         assert tdist.setup_peer_archive(e) == world
         dev = torch.device("cuda", 0)
         p = torch.zeros((T, h, D), dtype=torch.float64, device=dev)
         s = torch.zeros((T, h, 3), dtype=torch.float64, device=dev)
         a = torch.zeros((T, h), dtype=torch.uint8, device=dev)
-        tdist.run_peer_dream(e, T, K, p, s, a, period=20 if adaptive else None)
+        tdist.run_peer_dream(e, T, K, p, s, a, period=20 if adaptive else None, lag=lag)
         e.sync()
         rows = e.dreamz_state()["archive_rows"]
         mine = [p.cpu(), s.cpu(), a.cpu()]
@@ -58,10 +76,17 @@ def main():
         e.close()
         if rank == 0:
             one = make(N, 0, theta0, Z0, adaptive)
-            P, S, A = one.run_host(T)
+            if lag:  # the replicated archive with the same one-block lag
+                P_ = torch.zeros((T, N, D), dtype=torch.float64, device=dev)
+                S_ = torch.zeros((T, N, 3), dtype=torch.float64, device=dev)
+                A_ = torch.zeros((T, N), dtype=torch.uint8, device=dev)
+                _lagged_reference(one, P_, S_, A_)
+                P, S, A = P_.cpu().numpy(), S_.cpu().numpy(), A_.cpu().numpy()
+            else:
+                P, S, A = one.run_host(T)
             one.close()
             jp, js, ja = (torch.cat(g, dim=1).numpy() for g in gathered)
-            tag = "adaptive" if adaptive else "plain"
+            tag = "lagged" if lag else ("adaptive" if adaptive else "plain")
             out[tag + "_rows_ok"] = bool(rows == M0 + T * N)
             out[tag + "_accept_equal"] = bool(np.array_equal(ja, A))
             out[tag + "_max_rel_logpost"] = float(np.max(np.abs(js[:, :, 2] - S[:, :, 2]) / np.abs(S[:, :, 2])))
@@ -69,7 +94,8 @@ def main():
     dist.barrier()
     if rank == 0:
         out["ok"] = bool(out["plain_accept_equal"] and out["plain_params_equal"] and out["plain_max_rel_logpost"] == 0.0 and
-                         out["adaptive_accept_equal"] and out["adaptive_max_rel_logpost"] < 1e-9 and out["plain_rows_ok"] and out["adaptive_rows_ok"])
+                         out["adaptive_accept_equal"] and out["adaptive_max_rel_logpost"] < 1e-9 and out["plain_rows_ok"] and out["adaptive_rows_ok"] and
+                         out["lagged_accept_equal"] and out["lagged_params_equal"] and out["lagged_max_rel_logpost"] == 0.0 and out["lagged_rows_ok"])
         print(json.dumps(out), flush=True)
     dist.destroy_process_group()
 

@@ -50,6 +50,21 @@ def run_dream(overlap):
     return p.cpu().numpy(), a.cpu().numpy(), rows
 
 
+def run_peer(lag):
+    """the distributed-archive protocol (one rank: its own segment only): barrier per block, lagged = stream-ordered async"""
+    ts = torch.cuda.Stream()
+    e, T, K = dream_engine(ts.cuda_stream)
+    dev = torch.device("cuda", 0)
+    p = torch.zeros((T, e.n_chains, e.dim), dtype=torch.float64, device=dev)
+    a = torch.zeros((T, e.n_chains), dtype=torch.uint8, device=dev)
+    tdist.setup_peer_archive(e)
+    tdist.run_peer_dream(e, T, K, p, None, a, period=20, lag=lag, stream=ts)
+    ts.synchronize()
+    rows = e.dreamz_state()["archive_rows"]
+    e.close()
+    return p.cpu().numpy(), a.cpu().numpy(), rows
+
+
 def run_pooled():
     d, m, N, T = 8, 24, 128, 200
     rng = np.random.default_rng(8)
@@ -73,7 +88,7 @@ def main():
     out = {}
     # 1. without a process group: the collectives short-cut (reference results)
     assert not tdist._collectives_active()
-    ref = {"dream": run_dream(False), "dream_overlap": run_dream(True), "pooled": run_pooled()}
+    ref = {"dream": run_dream(False), "dream_overlap": run_dream(True), "pooled": run_pooled(), "peer": run_peer(False), "peer_lag": run_peer(True)}
     # 2. RCCL, one rank
     rank, local_rank, world = tdist.init_process_group()
     assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1, (dist.is_initialized(), world)
@@ -82,7 +97,11 @@ def main():
     tdist.barrier()
     out["reduce_scalar_max"] = tdist.reduce_scalar(1.25, "max")
     assert out["reduce_scalar_max"] == 1.25
-    got = {"dream": run_dream(False), "dream_overlap": run_dream(True), "pooled": run_pooled()}
+    got = {"dream": run_dream(False), "dream_overlap": run_dream(True), "pooled": run_pooled(), "peer": run_peer(False), "peer_lag": run_peer(True)}
+    # the distributed archive with one rank is the replicated one: same visibility of the rows, block-synchronous or lagged
+    for a_, b_ in (("peer", "dream"), ("peer_lag", "dream_overlap")):
+        same = all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in ((got[a_][0], got[b_][0]), (got[a_][1], got[b_][1])))
+        out["%s_equals_%s" % (a_, b_)] = bool(same)
     for k in ref:
         for i, (r, g) in enumerate(zip(ref[k], got[k])):
             same = np.array_equal(np.asarray(r), np.asarray(g))
