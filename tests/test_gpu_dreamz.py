@@ -528,3 +528,29 @@ def test_dream_distributed_archive_lagged_publish(eng_mod, model, adaptive):
         np.testing.assert_allclose(pcr, ref_pcr, rtol=1e-9)
     else:
         assert np.array_equal(joined[0], full[0]) and np.array_equal(joined[1], full[1])
+
+
+def test_sample_api_with_the_distributed_archive():
+    """tda.sample(..., DREAM(...), shared_archive='distributed'): one process is one rank -- the protocol of the N > 1 run with
+    its own segment only; seeded runs repeat, the chains move, the lagged variant runs on its stream"""
+    import scipy.stats as stats
+
+    import tinyda_amd as tda
+
+    d = 6
+    prior = stats.multivariate_normal(np.zeros(d), np.eye(d))
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((10, d)) / 2
+    post = tda.Posterior(prior, tda.GaussianLogLike(A @ (0.3 * rng.standard_normal(d)), 0.04 * np.eye(10)), tda.LinearModel(A))
+    runs = []
+    for overlap in (False, False, True):
+        res = tda.sample(post, tda.DREAM(M0=30, delta=1, adaptive=True, period=32), iterations=70, n_chains=32, seed=5, backend="hip",
+                         shared_archive="distributed", overlap_archive_exchange=overlap)
+        x = tda.get_samples(res)
+        runs.append(np.stack([x["chain_%d" % c] for c in range(32)]))
+        assert res["backend"] == "hip" and np.isfinite(runs[-1]).all()
+    assert np.array_equal(runs[0], runs[1])
+    assert (np.abs(np.diff(runs[0], axis=1)).sum(axis=(1, 2)) > 0).all()  # every chain moved
+    assert runs[2].shape == runs[0].shape
+    with pytest.raises(ValueError):
+        tda.sample(post, tda.DREAM(M0=30), iterations=2, n_chains=16, seed=5, shared_archive="scattered")

@@ -175,7 +175,7 @@ def _wrap_opaque_models(posteriors):
 def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None, subchain_length=1,
            randomize_subchain_length=False, adaptive_error_model=None, store_coarse_chain=True,
            force_sequential=False, force_progress_bar=False, subsampling_rate=None, *, seed=None,
-           backend="auto", device=0, chain_offset=0, distributed=False, overlap_archive_exchange=False,
+           backend="auto", device=0, chain_offset=0, distributed=False, overlap_archive_exchange=False, shared_archive="replicated",
            error_model_covariance="dense"):
     """Extra keyword-only arguments (not in tinyDA): seed, backend ('auto' | 'hip' | 'host'), device, chain_offset, and
     distributed=True: under torch.distributed (one process per GPU) `n_chains` is the GLOBAL chain count, this rank
@@ -185,7 +185,12 @@ def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None
     use only the diagonal of their covariance -- O(m) instead of O(m^2) memory and O(m^3) work per chain and level step, any
     output dimension (include/tinyda_amd.h, TDA_AEM_STATE_INDEPENDENT_DIAGONAL); 'dense' is the reference's model.
     overlap_archive_exchange=True (DREAM's shared archive): the all-gather of a block's new archive rows runs under the next
-    block's steps and the rows become visible one block later (tinyda_amd.distributed.run_shared_dream)."""
+    block's steps and the rows become visible one block later (tinyda_amd.distributed.run_shared_dream).
+    shared_archive='distributed' (DREAM under distributed=True, one process per GPU of a node): no rank holds the whole archive;
+    every rank keeps the rows of its own chains and proposals read the owners' rows in place (tinyda_amd.distributed.
+    setup_peer_archive / run_peer_dream; with overlap_archive_exchange=True the lagged protocol)."""
+    if shared_archive not in ("replicated", "distributed"):
+        raise ValueError("shared_archive must be 'replicated' or 'distributed'")
     if distributed:
         from . import distributed as tdist
 
@@ -270,7 +275,8 @@ def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None
     if plan is not None:
         if n_levels == 1:
             return _sample_device(plan, posteriors[0], iterations, n_chains, initial_parameters, seed, device,
-                                  chain_offset, distributed, total if distributed else None, overlap_archive_exchange)
+                                  chain_offset, distributed, total if distributed else None, overlap_archive_exchange,
+                                  shared_archive == "distributed")
         return _sample_device_multilevel(plan, posteriors, iterations, n_chains, initial_parameters, subchain_length,
                                          subchain_lengths, randomize_subchain_length, store_coarse_chain, seed, device,
                                          chain_offset, "state-independent-diagonal" if diag_aem else adaptive_error_model)
@@ -334,7 +340,7 @@ def _sample_host_multilevel(posteriors, proposal, iterations, n_chains, initial_
 
 
 def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, seed, device, chain_offset,
-                   distributed=False, total_chains=None, overlap_exchange=False):
+                   distributed=False, total_chains=None, overlap_exchange=False, peer_archive=False):
     from .engine import Engine  # raises EngineError when libtinyda_hip.so is missing: no CPU fallback
 
     lows, prop = plan
@@ -367,7 +373,9 @@ def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, se
             eng.set_level(0, low["A"], low["data"], low["noise_kind"], low["noise"], b=low["b"])
         if prop["kind"] == _lib.PROP_DREAMZ:
             dz = {k: v for k, v in prop.items() if k not in ("kind", "Z_method")}
-            rows = dz["M0"] + iterations * ((total_chains or n_chains) if dz["shared"] else 1)
+            # rows per archive: per-chain archives grow by one row per step; the replicated shared archive by every chain of
+            # every rank; a distributed shared archive only by this rank's chains
+            rows = dz["M0"] + iterations * ((n_chains if peer_archive else (total_chains or n_chains)) if dz["shared"] else 1)
             eng.set_proposal_dreamz(capacity=rows, **dz)
             eng.set_archive(_initial_archive(prop, low, n_chains, chain_offset, seed))
         else:
@@ -382,7 +390,7 @@ def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, se
         acc = pinned_empty((T + 1, N), dtype=np.uint8)
         acc[0] = 1
         params[0], stat[0] = eng.current()
-        if T > 0 and prop["kind"] == _lib.PROP_DREAMZ and prop.get("shared") and (distributed or tstream is not None):
+        if T > 0 and prop["kind"] == _lib.PROP_DREAMZ and prop.get("shared") and (distributed or tstream is not None or peer_archive):
             import torch
 
             from . import distributed as tdist
@@ -391,8 +399,14 @@ def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, se
             dp = torch.empty((T, N, d), dtype=torch.float64, device=tdev)
             ds = torch.empty((T, N, 3), dtype=torch.float64, device=tdev)
             da = torch.empty((T, N), dtype=torch.uint8, device=tdev)
-            # one all_gather of the new archive rows per 16 steps
-            tdist.run_shared_dream(eng, T, 16, dp, ds, da, overlap=tstream is not None, stream=tstream)
+            if peer_archive:
+                # every rank keeps its own rows; one small collective per 16 steps, the rows are read in place
+                tdist.setup_peer_archive(eng)
+                tdist.run_peer_dream(eng, T, 16, dp, ds, da, period=prop.get("period") if prop.get("adaptive") else None,
+                                     lag=tstream is not None, stream=tstream)
+            else:
+                # one all_gather of the new archive rows per 16 steps
+                tdist.run_shared_dream(eng, T, 16, dp, ds, da, overlap=tstream is not None, stream=tstream)
             if tstream is not None:
                 tstream.synchronize()
             params[1:], stat[1:], acc[1:] = dp.cpu().numpy(), ds.cpu().numpy(), da.cpu().numpy()
