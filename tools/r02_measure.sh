@@ -15,3 +15,4 @@ python -u tools/bench_configs.py c4 128 >> gpurun_out/r02_configs.jsonl 2>&1
 echo "extra configs done" | tee -a gpurun_out/r02_progress.log
 python -u tools/bench_configs.py c4peer 16 >> gpurun_out/r02_configs.jsonl 2>&1
 python -u tools/bench_configs.py c4peer 64 >> gpurun_out/r02_configs.jsonl 2>&1
+python -u tools/bench_configs.py c4peerlag 16 >> gpurun_out/r02_configs.jsonl 2>&1
