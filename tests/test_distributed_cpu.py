@@ -50,9 +50,40 @@ torch.device = lambda *a, **k: _dev("cpu")  # the staging buffers of the pipelin
 fe = FakeEngine()
 tdist.run_shared_dream(fe, 7, 3, overlap=True)
 torch.device = _dev
+# the distributed-archive protocol (setup_peer_archive / run_peer_dream) with a stand-in engine: handles exchanged once, per block
+# run -> collective -> publish (block-synchronous) or at most two unpublished blocks (lagged); sums only at adaptation boundaries
+import numpy as np
+class PeerEngine:
+    n_chains, dim, device = cnt, 2, 0
+    def __init__(self):
+        self.log, self.unpub, self.steps = [], 0, 0
+    def archive_ipc_handle(self):
+        return bytes([rank]) * 64
+    def set_archive_peers(self, n, me, handles=None, pointers=None):
+        self.log.append(("peers", n, me, [h[0] for h in handles]))
+    def run(self, k, params=None, stats=None, accepted=None, sync=True):
+        assert self.unpub < 2
+        self.unpub += 1
+        self.steps += k
+        self.log.append(("run", k, self.unpub))
+    def archive_local_sums(self):
+        return np.full((2, 2), float(rank + 1) * self.steps)
+    def archive_publish(self, total=None):
+        assert self.unpub >= 1
+        self.unpub -= 1
+        self.log.append(("publish", None if total is None else float(total[0, 0])))
+    def sync(self):
+        pass
+logs = {}
+for lag in (False, True):
+    pe = PeerEngine()
+    assert tdist.setup_peer_archive(pe) == world
+    tdist.run_peer_dream(pe, 11, 3, period=6, lag=lag)
+    assert pe.unpub == 0
+    logs["lag" if lag else "sync"] = pe.log
 with open(os.path.join(%(out)r, "rank%%d.json" %% rank), "w") as fh:
     json.dump(dict(rank=rank, off=off, cnt=cnt, mx=mx, sm=sm, n=n, mu=mu.tolist(), M2=M2.tolist(), rows=rows[:, 0].tolist(),
-                   pipeline=fe.log), fh)
+                   pipeline=fe.log, peer=logs), fh)
 """
 
 
@@ -90,3 +121,15 @@ def test_world_size_2_gloo(tmp_path):
     x = torch.randn(10, 3, generator=torch.Generator().manual_seed(5), dtype=torch.float64).numpy()
     np.testing.assert_allclose(res[0]["mu"], x.mean(0), rtol=1e-12)
     np.testing.assert_allclose(res[1]["M2"], (x - x.mean(0)).T @ (x - x.mean(0)), rtol=1e-10)
+    # distributed archive: handles of both ranks everywhere; steps 11 = blocks 3, 3 (adaptation boundary at 6), 3, 2.
+    # block-synchronous: every block is published before the next runs; the boundary block's publish carries the total of the ranks'
+    # sums (rank r reports (r + 1) * steps done: 6 + 12 = 18)
+    for r_ in range(2):
+        sync_log, lag_log = res[r_]["peer"]["sync"], res[r_]["peer"]["lag"]
+        assert sync_log[0] == ["peers", 2, r_, [0, 1]]
+        assert sync_log[1:] == [["run", 3, 1], ["publish", None], ["run", 3, 1], ["publish", 18.0], ["run", 3, 1], ["publish", None],
+                                ["run", 2, 1], ["publish", None]]
+        # lagged: a second block runs before the first is published; the boundary block publishes the OLDEST unpublished block with
+        # the sums; everything is published at the end
+        assert lag_log[1:] == [["run", 3, 1], ["run", 3, 2], ["publish", 18.0], ["run", 3, 2], ["publish", None], ["run", 2, 2],
+                               ["publish", None], ["publish", None]]
