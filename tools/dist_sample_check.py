@@ -11,3 +11,7 @@ res = tda.sample(post, tda.AdaptiveMetropolis(0.05 * np.eye(6), t0=10, period=10
 print("DIST_OK", res["n_chains"], res["chain_offset"], len(res["chain_%d" % (res["n_chains"] - 1)]))
 res = tda.sample(post, tda.DREAM(24, adaptive=True, period=20), 40, n_chains=32, seed=5, distributed=True, overlap_archive_exchange=True)
 print("DIST_OVERLAP_OK", res["n_chains"], res["chain_offset"], len(res["chain_0"]), res["proposal_state"]["archive_rows"])
+for overlap in (False, True):
+    res = tda.sample(post, tda.DREAM(24, adaptive=True, period=20), 40, n_chains=32, seed=5, distributed=True, shared_archive="distributed",
+                     overlap_archive_exchange=overlap)
+    print("DIST_PEER_OK", overlap, res["n_chains"], res["chain_offset"], len(res["chain_0"]), res["proposal_state"]["archive_rows"])
