@@ -18,11 +18,14 @@ import torch.distributed as dist
 from tinyda_amd import distributed as tdist
 from tinyda_amd.engine import Engine
 
-D, N, T, M0, K = 8, 64, 47, 24, 5
+D, N, T, M0, K = 8, 128, 47, 24, 5  # (128 chains: 16 per rank with eight ranks)
+
+
+DEV = 0  # set in main(): the rank's own GPU on a multi-GPU node, cuda:0 for every rank on a one-GPU box
 
 
 def make(n, off, theta0, Z0, adaptive):
-    e = Engine(n, D, seed=321, chain_offset=off, device=0)
+    e = Engine(n, D, seed=321, chain_offset=off, device=DEV)
     e.set_prior(np.zeros(D), np.eye(D))
     e.set_level_rosenbrock(0, 1.0, 10.0, 0.0, 1.0)
     e.set_proposal_dreamz(M0, delta=2, nCR=3, adaptive=adaptive, period=20, gamma=1.02, shared=True, sync_every=K, capacity=M0 + T * N)
@@ -51,8 +54,11 @@ def _lagged_reference(e, P, S, A):
 
 def main():
     dist.init_process_group("gloo")
+    global DEV
     rank, world = dist.get_rank(), dist.get_world_size()
-    torch.cuda.set_device(0)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    DEV = local_rank if torch.cuda.device_count() > local_rank else 0
+    torch.cuda.set_device(DEV)
     rng = np.random.default_rng(5)
     Z0 = rng.standard_normal((M0, D))
     theta0 = 0.3 * rng.standard_normal((N, D))
@@ -61,7 +67,7 @@ def main():
     for adaptive, lag in ((False, False), (True, False), (False, True)):
         e = make(h, rank * h, theta0[rank * h:(rank + 1) * h], Z0, adaptive)
         assert tdist.setup_peer_archive(e) == world
-        dev = torch.device("cuda", 0)
+        dev = torch.device("cuda", DEV)
         p = torch.zeros((T, h, D), dtype=torch.float64, device=dev)
         s = torch.zeros((T, h, 3), dtype=torch.float64, device=dev)
         a = torch.zeros((T, h), dtype=torch.uint8, device=dev)
