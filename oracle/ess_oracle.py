@@ -64,8 +64,8 @@ def rhat(x):
     return max(_rhat_plain(normal_scores(s)), _rhat_plain(normal_scores(folded)))
 
 
-def ess_bulk(x):
-    z = normal_scores(split_chains(x))
+def _ess_of(z):
+    """ESS of already split (and, for the bulk estimate, rank-normalised) chains z [M][N] (eq. 10-13)"""
     m, n = z.shape
     if n < 4:
         return float("nan")
@@ -96,3 +96,39 @@ def ess_bulk(x):
         tau += max(rho[2 * k], 0.0)
     tau = max(tau, 1.0 / np.log10(m * n))
     return float(m * n / tau)
+
+
+def ess_bulk(x):
+    return _ess_of(normal_scores(split_chains(x)))
+
+
+def ess_tail(x):
+    """tail ESS (paper sec. 4.3): the smaller of the ESS of the indicators I(x <= q) at the 5 % and 95 % quantiles of all
+    draws, computed on the split chains without rank-normalisation"""
+    x = np.asarray(x, dtype=np.float64)
+    out = []
+    for prob in (0.05, 0.95):
+        q = np.quantile(x, prob)
+        out.append(_ess_of(split_chains((x <= q).astype(np.float64))))
+    return float(min(out))
+
+
+def ess_mean(x):
+    """ESS of the mean: split chains, no rank-normalisation (what the Monte Carlo standard error of the mean uses)"""
+    return _ess_of(split_chains(x))
+
+
+def mcse_mean(x):
+    """Monte Carlo standard error of the posterior mean: sd / sqrt(ESS of the mean)"""
+    x = np.asarray(x, dtype=np.float64)
+    return float(np.std(x, ddof=1) / np.sqrt(ess_mean(x)))
+
+
+def hdi(x, prob=0.94):
+    """highest density interval: the narrowest interval containing `prob` of the pooled draws (unimodal convention)"""
+    v = np.sort(np.asarray(x, dtype=np.float64).ravel())
+    n = v.size
+    k = int(np.floor(prob * n))
+    widths = [v[i + k] - v[i] for i in range(n - k)]
+    i = int(np.argmin(widths))
+    return float(v[i]), float(v[i + k])

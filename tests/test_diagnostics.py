@@ -50,6 +50,31 @@ def test_product_numpy_matches_the_oracle(name):
     np.testing.assert_allclose(tda.rhat(x), eo.rhat(x), rtol=1e-10)
 
 
+@pytest.mark.parametrize("name", list(cases()))
+def test_tail_ess_mcse_hdi_match_the_oracle(name):
+    """the other az.summary columns: tail ESS (indicator chains at the 5 % / 95 % quantiles), Monte Carlo standard error of the
+    mean, 94 % highest density interval"""
+    x = cases()[name]
+    if x.shape[1] < 8:
+        return
+    np.testing.assert_allclose(tda.ess_tail(x), eo.ess_tail(x), rtol=1e-9)
+    np.testing.assert_allclose(tda.mcse_mean(x), eo.mcse_mean(x), rtol=1e-9)
+    np.testing.assert_allclose(tda.hdi(x), eo.hdi(x), rtol=0, atol=0)
+
+
+def test_tail_ess_and_mcse_known_answers():
+    """iid draws: tail ESS ~ S and mcse ~ sd / sqrt(S); AR(1): mcse^2 S / var ~ (1 + rho) / (1 - rho); HDI of a standard normal"""
+    x = _ar1(0.0, 8, 2000, 21)
+    assert abs(tda.ess_tail(x) / x.size - 1) < 0.15
+    assert abs(tda.mcse_mean(x) * np.sqrt(x.size) / x.std(ddof=1) - 1) < 0.1
+    lo, hi = tda.hdi(x)
+    assert abs(lo + 1.88) < 0.12 and abs(hi - 1.88) < 0.12  # 94 % of N(0, 1)
+    y = _ar1(0.8, 16, 4000, 22)
+    infl = (tda.mcse_mean(y) ** 2) * y.size / y.var(ddof=1)
+    assert abs(infl / 9.0 - 1) < 0.25
+    assert tda.ess_tail(y) < 0.5 * y.size
+
+
 def test_known_answers():
     """AR(1): ESS = S (1 - rho) / (1 + rho); iid heavy tails: ESS ~ S after rank normalisation; disagreement shows in R-hat"""
     for est in (tda.ess_bulk, eo.ess_bulk):
@@ -71,6 +96,8 @@ def test_known_answers():
 
 def test_ess_summary_layout():
     x = np.stack([_ar1(0.5, 6, 800, s).T for s in range(3)], axis=2)  # [draws, chains, dim]
+    from tinyda_amd.summaries import InferenceDataLite  # the az.summary columns of the shim
+
     s = tda.ess_summary(x, burnin=100)
     assert s["ess"].shape == (3,) and s["ess_min"] <= s["ess_median"]
     np.testing.assert_allclose(s["ess"][1], eo.ess_bulk(x[100:, :, 1].T), rtol=1e-9)

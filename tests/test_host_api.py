@@ -158,6 +158,9 @@ def test_config1_basic_sampler_host_path():
     if hasattr(idata, "summary"):
         row = idata.summary()["slope"]
         assert abs(row["mean"] - mean[1]) < 0.2 and row["ess_bulk"] > 20 and 0.9 < row["r_hat"] < 1.5
+        # the columns of az.summary (examples/Basic Sampler.ipynb cell 17)
+        assert set(row) == {"mean", "sd", "hdi_3%", "hdi_97%", "mcse_mean", "ess_bulk", "ess_tail", "r_hat"}
+        assert row["hdi_3%"] < row["mean"] < row["hdi_97%"] and row["ess_tail"] > 10 and 0 < row["mcse_mean"] < row["sd"]
 
 
 def test_lowering_pass():

@@ -7,7 +7,7 @@ __version__ = "0.1.0"
 
 from ._lib import EngineError  # noqa: F401
 from .hostloop import Chain  # noqa: F401
-from .summaries import ess_bulk, ess_summary, get_samples, rhat, to_inference_data  # noqa: F401
+from .summaries import ess_bulk, ess_summary, ess_tail, get_samples, hdi, mcse_mean, rhat, to_inference_data  # noqa: F401
 from .likelihoods import (  # noqa: F401
     JointPrior,
     AdaptiveGaussianLogLike,

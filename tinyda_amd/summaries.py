@@ -91,8 +91,12 @@ class InferenceDataLite:
         for name in ds:
             x = np.asarray(ds[name], dtype=np.float64)
             split_ok = x.shape[1] >= 4
+            lo, hi = hdi(x) if x.size > 1 else (float("nan"), float("nan"))
             rows[name] = {"mean": float(x.mean()), "sd": float(x.std(ddof=1)) if x.size > 1 else float("nan"),
+                          "hdi_3%": lo, "hdi_97%": hi,
+                          "mcse_mean": mcse_mean(x) if split_ok else float("nan"),
                           "ess_bulk": float(ess_bulk(x)) if split_ok else float("nan"),
+                          "ess_tail": ess_tail(x) if split_ok else float("nan"),
                           "r_hat": float(rhat(x)) if split_ok else float("nan")}
         return rows
 
@@ -192,6 +196,29 @@ def ess_bulk(x):
     """Bulk ESS of one scalar quantity: x [chains, draws] -> float."""
     x = np.asarray(x, dtype=np.float64)
     return _ess_raw(_rank_normalise(_split(x)))
+
+
+def ess_tail(x):
+    """Tail ESS (Vehtari et al. 2021, sec. 4.3; the `ess_tail` column of az.summary): the smaller ESS of the indicators
+    I(x <= q05), I(x <= q95) on the split chains."""
+    x = np.asarray(x, dtype=np.float64)
+    return float(min(_ess_raw(_split((x <= np.quantile(x, prob)).astype(np.float64))) for prob in (0.05, 0.95)))
+
+
+def mcse_mean(x):
+    """Monte Carlo standard error of the mean: sd / sqrt(ESS of the mean) (`mcse_mean` of az.summary)."""
+    x = np.asarray(x, dtype=np.float64)
+    return float(x.std(ddof=1) / np.sqrt(_ess_raw(_split(x))))
+
+
+def hdi(x, prob=0.94):
+    """Highest density interval of the pooled draws (az.summary's hdi_3% / hdi_97% at the default 0.94): the narrowest interval
+    holding `prob` of them."""
+    v = np.sort(np.asarray(x, dtype=np.float64).ravel())
+    k = int(np.floor(prob * v.size))
+    w = v[k:] - v[:v.size - k]
+    i = int(np.argmin(w))
+    return float(v[i]), float(v[i + k])
 
 
 def rhat(x):
