@@ -96,8 +96,6 @@ def test_known_answers():
 
 def test_ess_summary_layout():
     x = np.stack([_ar1(0.5, 6, 800, s).T for s in range(3)], axis=2)  # [draws, chains, dim]
-    from tinyda_amd.summaries import InferenceDataLite  # the az.summary columns of the shim
-
     s = tda.ess_summary(x, burnin=100)
     assert s["ess"].shape == (3,) and s["ess_min"] <= s["ess_median"]
     np.testing.assert_allclose(s["ess"][1], eo.ess_bulk(x[100:, :, 1].T), rtol=1e-9)
