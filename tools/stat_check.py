@@ -83,3 +83,21 @@ for blk in range(10):
 mean = (sums / n).cpu().numpy(); cov = (outer / n).cpu().numpy() - np.outer(mean, mean)
 r = np.diag(cov) / np.diag(cov_post)
 print(json.dumps(dict(check="control: GaussianRandomWalk with the fixed covariance 2.4^2/d * posterior covariance, started in stationarity, 4096 chains x 20000 recorded iterations", acc=float(a.float().mean()), ess_min=float(ess.min()), var_ratio_min=float(r.min()), var_ratio_max=float(r.max()), var_ratio_mean=float(r.mean()))))
+
+# ---- the pooled-moments extension from the same pilot states: one covariance from all chains, refreshed every 100 steps ----
+from tinyda_amd.distributed import PooledAdaptiveMetropolis
+
+e = engine(0)
+e.init(start)
+pam = PooledAdaptiveMetropolis(e, 1e-4 * np.eye(D), t0=100, period=100)
+for blk in range(10):
+    pam.run(T, p, None, a)
+sums.zero_(); outer.zero_(); n = 0
+for blk in range(10):
+    pam.run(T, p, None, a)
+    f = p.reshape(-1, D); sums += f.sum(0); outer += f.T @ f; n += f.shape[0]
+e.close()
+mean = (sums / n).cpu().numpy(); cov = (outer / n).cpu().numpy() - np.outer(mean, mean)
+r = np.diag(cov) / np.diag(cov_post)
+print(json.dumps(dict(check="PooledAdaptiveMetropolis (extension) from the pilot states, 4096 chains x 20000 recorded iterations after 20000", acc=float(a.float().mean()),
+                      var_ratio_min=float(r.min()), var_ratio_max=float(r.max()), var_ratio_mean=float(r.mean()))))
