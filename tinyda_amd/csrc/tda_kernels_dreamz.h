@@ -71,7 +71,7 @@ constexpr int dz_chains_per_wave() {
 
 // DIST: the shared archive is distributed over the ranks (a template parameter: the plain kernel stays as it was)
 template <int DPAD, bool DIST = false>
-__global__ void __launch_bounds__(64) k_dreamz_draw(const DreamDrawArgs a) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_dreamz_draw(const DreamDrawArgs a) {
   constexpr int CPW = dz_chains_per_wave<DPAD>();
   const int seg = threadIdx.x / DPAD;
   const int lane = threadIdx.x % DPAD;  // parameter index within the chain
