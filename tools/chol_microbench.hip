@@ -1,6 +1,8 @@
 // Stand-alone timing / equality harness for the per-chain Cholesky kernel (debug tool, not part of the library).
 // Measured on MI355X (4096 chains, d = 64): library k_chol 105 us; LDS-broadcast variant 114 us (bitwise equal); forcing 3 waves/SIMD
-// 157 us (spills); reciprocal-sqrt pivots 126-135 us; two lanes per row 1.2 ms.  None replaced the library kernel.
+// 157 us (spills); reciprocal-sqrt pivots 126-135 us; two lanes per row 1.2 ms; round 2: k_chol_loop (a real column loop, shifting
+// registers) 134 us, 115 without any HBM access.  None replaced the library kernel (tools/experimental/README.md has the table).
+// Usage: /tmp/cmb [d [chains]]
 // Build on the GPU box: hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -w -Itinyda_amd/csrc -Iinclude -Itools -o /tmp/cmb tools/chol_microbench.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -19,8 +21,8 @@ using namespace tda;
 
 int main(int argc, char** argv) {
   constexpr int D = 64;
-  const int64_t N = 4096;
   const int d = argc > 1 ? atoi(argv[1]) : 64;
+  const int64_t N = argc > 2 ? atoll(argv[2]) : 4096;
   constexpr int NTL = am_tiles<D>();
   std::mt19937_64 g(3);
   std::normal_distribution<double> nd;
@@ -54,9 +56,9 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   const char* names[] = {"k_chol (library: readlane)", "k_chol_x<rs=0,wpe=2> (LDS broadcast)", "k_chol_x<rs=0,wpe=3>", "k_chol_x<rs=1,wpe=2>", "k_chol_x<rs=1,wpe=3>",
-                         "k_chol_2t<rs=0>", "k_chol_2t<rs=1>"};
+                         "k_chol_2t<rs=0>", "k_chol_2t<rs=1>", "k_chol_loop", "k_chol_loop, no loads", "k_chol_loop, no stores", "k_chol_loop, neither"};
   std::vector<double> h1((size_t)N * D * D), h2((size_t)N * D * D);
-  for (int which = 0; which < 7; ++which) {
+  for (int which = 0; which < 11; ++which) {
     a.Lk = which ? L2 : L1;
     float best = 1e9f;
     for (int rep = 0; rep < 6; ++rep) {
@@ -69,7 +71,11 @@ int main(int argc, char** argv) {
         case 3: hipLaunchKernelGGL((k_chol_x<D, 1, 2>), g4, dim3(256), 0, 0, a); break;
         case 4: hipLaunchKernelGGL((k_chol_x<D, 1, 3>), g4, dim3(256), 0, 0, a); break;
         case 5: hipLaunchKernelGGL((k_chol_2t<D, 0>), g2, dim3(256), 0, 0, a); break;
-        default: hipLaunchKernelGGL((k_chol_2t<D, 1>), g2, dim3(256), 0, 0, a); break;
+        case 6: hipLaunchKernelGGL((k_chol_2t<D, 1>), g2, dim3(256), 0, 0, a); break;
+        case 7: hipLaunchKernelGGL((k_chol_loop<D, 0>), dim3((unsigned)N), dim3(64), 0, 0, a); break;
+        case 8: hipLaunchKernelGGL((k_chol_loop<D, 1>), dim3((unsigned)N), dim3(64), 0, 0, a); break;
+        case 9: hipLaunchKernelGGL((k_chol_loop<D, 2>), dim3((unsigned)N), dim3(64), 0, 0, a); break;
+        default: hipLaunchKernelGGL((k_chol_loop<D, 3>), dim3((unsigned)N), dim3(64), 0, 0, a); break;
       }
       CK(hipEventRecord(e1));
       CK(hipEventSynchronize(e1));
