@@ -88,7 +88,7 @@ struct StepArgs {
   double* rec_params;
   double* rec_stats;
   uint8_t* rec_acc;
-  long long* trace;  // debug builds (-DTDA_STEP_TRACE, tools/steps_microbench.hip): [S][waves][8] cycle stamps of tile 0
+  long long* trace;  // debug builds (-DTDA_STEP_TRACE, tools/steps_microbench.hip): [S][waves][8] cycle stamps of tile 0, then 4 clock stamps
 };
 
 struct ProposeArgs {
@@ -574,6 +574,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
   const bool tracing = a.trace != nullptr && blockIdx.x == 0 && lane == 0;
 #define TDA_STAMP(i) \
   if (tracing) a.trace[((size_t)s * NW + wave) * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime()
+  // the clock the chip holds under this kernel: shader cycles (s_memtime) per 100 MHz tick (s_memrealtime) over the step loop
+  if (tracing && wave == 0) {
+    a.trace[(size_t)a.S * NW * 8 + 0] = (long long)__builtin_amdgcn_s_memtime();
+    a.trace[(size_t)a.S * NW * 8 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+  }
 #else
 #define TDA_STAMP(i)
 #endif
@@ -800,6 +805,12 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
     TDA_STAMP(7);
   }
 #undef TDA_STAMP
+#ifdef TDA_STEP_TRACE
+  if (tracing && wave == 0) {
+    a.trace[(size_t)a.S * NW * 8 + 2] = (long long)__builtin_amdgcn_s_memtime();
+    a.trace[(size_t)a.S * NW * 8 + 3] = (long long)__builtin_amdgcn_s_memrealtime();
+  }
+#endif
 
   if (active) {
 #pragma unroll
@@ -1154,7 +1165,11 @@ __device__ __forceinline__ double bcast_lane64(double v, int src) {
 // order (column operands: one ds_read_b64 per tile column) and permuted so that a lane's four row indices are
 // contiguous (row operands: two ds_read_b128 per tile row); mu mu^T is carried over from the previous step's
 // (t + 1) mu' mu'^T.  24 LDS reads + 320 fp64 operations per state; the circulant fold used earlier needed 99 + 330 and ran
-// at the speed of the 36 + 400 tile version: the bound is the VALU.
+// at the speed of the 36 + 400 tile version: the bound is the VALU.  Round 2 confirmed it from the other side: staging the
+// operands of step s + 1 under step s (no store -> load round trip in front of a step) and reading the row operands one tile
+// row ahead changed nothing (347 -> 349-359 us per 100 states of 4096 chains); the 382 vector instructions of a state take
+// 2 100 cycles of a SIMD with its two resident waves, 5.5 per instruction, where tools/valu_rate_probe.hip gets 4.1 for the
+// same 5 mul : 3 add mix on 16 registers -- the rest is the operand traffic of 230 live registers, not latency.
 template <int DPAD>
 __global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
   constexpr int T = am_tile_rows<DPAD>();

@@ -80,12 +80,19 @@ int main(int argc, char** argv) {
 #ifdef TDA_STEP_TRACE
   {  // one more launch with cycle stamps of tile 0: median interval between consecutive stamps, per wave
     long long* tr = nullptr;
-    CK(hipMalloc((void**)&tr, (size_t)S * 64 * 8));
-    CK(hipMemset(tr, 0, (size_t)S * 64 * 8));
+    CK(hipMalloc((void**)&tr, ((size_t)S * 64 + 8) * 8));
+    CK(hipMemset(tr, 0, ((size_t)S * 64 + 8) * 8));
     a.trace = tr;
+    // the clock the chip holds under this kernel (MI355X_MICROARCH.md, DVFS give-back (6)): stamped after >= 2 s of
+    // back-to-back launches; shader cycles per 100 MHz tick over the step loop of tile 0
+    if (which == 0) {
+      const int warm = (int)(2000.0 / (ms / R)) + 1;
+      for (int i = 0; i < warm; ++i) launch();
+      CK(hipDeviceSynchronize());
+    }
     launch();
     CK(hipDeviceSynchronize());
-    std::vector<long long> h((size_t)S * 64);
+    std::vector<long long> h((size_t)S * 64 + 8);
     CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
     const int ord_frag[8] = {0, 2, 3, 1, 4, 5, 6, 7}, ord_tm[8] = {0, 1, 2, 3, 4, 5, 6, 7}, ord_lin[8] = {0, 2, 3, 1, 4, 5, 6, 7};
     const int* ord = which == 3 ? ord_lin : (which >= 1 ? ord_frag : ord_tm);
@@ -105,6 +112,11 @@ int main(int argc, char** argv) {
       printf("  %d -> %d        ", ord[i], ord[i + 1]);
       for (int w = 0; w < nwk; ++w) printf(" %6lld", med(w, ord[i], ord[i + 1], 0));
       printf("\n");
+    }
+    if (which == 0) {
+      const long long* cs = h.data() + (size_t)S * 8 * 8;
+      const double cyc = (double)(cs[2] - cs[0]), ticks = (double)(cs[3] - cs[1]);
+      printf("  in-kernel clock: %.0f shader cycles in %.0f ticks of 100 MHz = %.3f GHz (%.0f cycles per step)\n", cyc, ticks, cyc / ticks * 0.1, cyc / S);
     }
     printf("  7 -> next 0   ");
     for (int w = 0; w < nwk; ++w) printf(" %6lld", med(w, 7, 0, 1));
