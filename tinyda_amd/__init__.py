@@ -26,3 +26,5 @@ from .proposals import (  # noqa: F401
 from .records import DeviceChain  # noqa: F401
 from .api import sample  # noqa: F401
 from .moments import RecursiveSampleMoments, ZeroMeanRecursiveSampleMoments  # noqa: F401
+from .compat import (  # noqa: F401
+    BlackBoxLinkFactory, CompositePrior, DAChain, LinkFactory, MLDAChain, SingleDreamZ, get_MAP, get_ML, grad_log_l, grad_log_p, to_xarray)
