@@ -18,7 +18,7 @@ import torch.distributed as dist
 from tinyda_amd import distributed as tdist
 from tinyda_amd.engine import Engine
 
-D, N, T, M0, K = 8, 128, 47, 24, 5  # (128 chains: 16 per rank with eight ranks)
+D, N, T, M0, K = 8, 128, 47, 24, 5  # (128 chains: 16 per rank with eight ranks; adjusted in main() when the world does not divide it)
 
 
 DEV = 0  # set in main(): the rank's own GPU on a multi-GPU node, cuda:0 for every rank on a one-GPU box
@@ -54,8 +54,10 @@ def _lagged_reference(e, P, S, A):
 
 def main():
     dist.init_process_group("gloo")
-    global DEV
+    global DEV, N
     rank, world = dist.get_rank(), dist.get_world_size()
+    if N % (16 * world):  # a rank's share is a multiple of the 16-chain tile (3, 5, 6 ... ranks)
+        N = 16 * world * max(1, N // (16 * world))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     DEV = local_rank if torch.cuda.device_count() > local_rank else 0
     torch.cuda.set_device(DEV)
