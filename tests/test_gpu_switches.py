@@ -25,7 +25,7 @@ def _probe(what, env_extra, tmp_path, tag):
     return dict(np.load(out))
 
 
-@pytest.mark.parametrize("what", ["mlda3", "da2"])
+@pytest.mark.parametrize("what", ["mlda3", "da2", "mlda3_ragged", "da2_ragged"])
 def test_pipelined_level_kernel_equals_the_generic_one(what, tmp_path):
     """k_da_steps (two levels, and three with a coarse operator of <= 128 observations) against k_ml_steps (TINYDA_DA_LEAN=0)"""
     lean, generic = _probe(what, {}, tmp_path, "lean"), _probe(what, {"TINYDA_DA_LEAN": "0"}, tmp_path, "generic")
@@ -37,12 +37,13 @@ def test_pipelined_level_kernel_equals_the_generic_one(what, tmp_path):
     assert 0.02 < lean["acc0"].mean() < 0.98
 
 
-def test_dream_kernel_choices_agree(tmp_path):
+@pytest.mark.parametrize("what", ["dream", "dream_ragged"])
+def test_dream_kernel_choices_agree(what, tmp_path):
     """k_dreamz_steps_wave against the 16-chain tile kernel (TINYDA_DZ_WAVE=0), and the draw-ahead pipeline
     (TINYDA_DZ_PIPELINE=1: same sums in the same order, bitwise)"""
-    wave = _probe("dream", {}, tmp_path, "wave")
-    tile = _probe("dream", {"TINYDA_DZ_WAVE": "0"}, tmp_path, "tile")
-    pipe = _probe("dream", {"TINYDA_DZ_PIPELINE": "1"}, tmp_path, "pipe")
+    wave = _probe(what, {}, tmp_path, "wave")
+    tile = _probe(what, {"TINYDA_DZ_WAVE": "0"}, tmp_path, "tile")
+    pipe = _probe(what, {"TINYDA_DZ_PIPELINE": "1"}, tmp_path, "pipe")
     assert np.array_equal(wave["acc0"], tile["acc0"])
     np.testing.assert_allclose(wave["stats0"], tile["stats0"], rtol=1e-10)
     np.testing.assert_allclose(wave["params0"], tile["params0"], rtol=1e-12, atol=1e-14)
@@ -53,7 +54,8 @@ def test_dream_kernel_choices_agree(tmp_path):
 
 
 @pytest.mark.parametrize("what,other", [("aemd", {"TINYDA_AEMD_FUSED": "0"}), ("aemd_lean", {"TINYDA_AEMD_FUSED": "0"}),
-                                        ("aemd_lean", {"TINYDA_DA_LEAN": "0"})])
+                                        ("aemd_lean", {"TINYDA_DA_LEAN": "0"}), ("aemd_ragged", {"TINYDA_AEMD_FUSED": "0"}),
+                                        ("aemd_lean_ragged", {"TINYDA_AEMD_FUSED": "0"})])
 def test_fused_and_per_step_diagonal_error_model_agree(what, other, tmp_path):
     """diagonal error model over three linear levels: base subchains in the fused level kernels (k_ml_steps; k_da_steps at <= 128
     outputs) against one propose / outputs / accept triple per base step (TINYDA_AEMD_FUSED=0) and against each other"""

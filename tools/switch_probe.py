@@ -1,6 +1,6 @@
 """One seeded run of a configuration whose kernel choice an environment switch changes; records to an .npz.  The switches are
 read once per process, so A/B comparisons start this script twice (tests/test_gpu_switches.py).
-    python tools/switch_probe.py {mlda3|da2|aemd|aemd_lean|dream} out.npz"""
+    python tools/switch_probe.py {mlda3|da2|aemd|aemd_lean|dream}[_ragged] out.npz     (_ragged: a chain count that is not a multiple of the 16-chain tile)"""
 import os
 import sys
 
@@ -48,14 +48,17 @@ def dream(N=512, d=32, T=70, M0=64, K=16):
 if __name__ == "__main__":
     _lib.load()
     what, out = sys.argv[1], sys.argv[2]
+    ragged = what.endswith("_ragged")
+    what = what[:-7] if ragged else what
+    cut = 7 if ragged else 0  # the last tile holds 9 chains
     if what == "mlda3":
-        res = hierarchy((128, 256, 512), [5, 3], "am", 6)
+        res = hierarchy((128, 256, 512), [5, 3], "am", 6, N=256 - cut)
     elif what == "da2":
-        res = hierarchy((256, 1024), [10], "pcn", 8)
+        res = hierarchy((256, 1024), [10], "pcn", 8, N=256 - cut)
     elif what == "aemd":
-        res = hierarchy((200, 200, 200), [5, 3], "am", 8, N=96, error_model="state-independent-diagonal")
+        res = hierarchy((200, 200, 200), [5, 3], "am", 8, N=96 - cut, error_model="state-independent-diagonal")
     elif what == "aemd_lean":  # at most 128 outputs: the base subchains are eligible for k_da_steps
-        res = hierarchy((128, 128, 128), [5, 3], "am", 8, N=96, error_model="state-independent-diagonal")
+        res = hierarchy((128, 128, 128), [5, 3], "am", 8, N=96 - cut, error_model="state-independent-diagonal")
     else:
-        res = dream()
+        res = dream(N=512 - cut)
     np.savez(out, **res)
