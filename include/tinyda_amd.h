@@ -300,7 +300,8 @@ int tda_engine_set_proposal_covariance(tda_engine* e, const double* C);
 /* Checkpoint / resume (the reference has none: sample() cannot continue a previous run).  The blob holds every chain's
  * state at every level, the proposal state (scaling, factors, running moments, archives, error-model trackers) and the
  * step / RNG counters; restoring it into an engine that was configured and init()-ed identically continues the run
- * bit for bit.  HOST pointers. */
+ * bit for bit.  With a distributed archive (tda_engine_set_archive_peers) the blob holds this rank's segment and the position
+ * of the publish protocol; the restoring process sets the peers up again before tda_engine_set_state.  HOST pointers. */
 int64_t tda_engine_state_size(tda_engine* e);
 int tda_engine_get_state(tda_engine* e, void* blob, int64_t bytes);
 int tda_engine_set_state(tda_engine* e, const void* blob, int64_t bytes);

@@ -448,6 +448,65 @@ def test_dream_distributed_archive_equals_the_replicated_one(eng_mod, model, ada
         assert np.array_equal(joined[0], full[0]) and np.array_equal(joined[1], full[1])
 
 
+def test_dream_distributed_archive_checkpoint_resume(eng_mod):
+    """get_state / set_state with the distributed archive: the blob carries the rank's segment and the position of the publish
+    protocol, the peer mappings are set up again by the restoring process; resumed ranks continue bit for bit (adaptive run:
+    the deferred column sums and the pending-adaptation bookkeeping are part of the state)."""
+    d, N, M0, K, seed = 8, 32, 24, 5, 77
+    rng = np.random.default_rng(4)
+    Z0 = rng.standard_normal((M0, d))
+    theta0 = 0.3 * rng.standard_normal((N, d))
+    h = N // 2
+
+    def make(off):
+        e = eng_mod.Engine(h, d, seed=seed, chain_offset=off)
+        e.set_prior(np.zeros(d), np.eye(d))
+        e.set_level_rosenbrock(0, 1.0, 10.0, 0.0, 1.0)
+        e.set_proposal_dreamz(M0, delta=2, nCR=3, adaptive=True, period=20, gamma=1.02, shared=True, sync_every=K, capacity=M0 + 60 * N)
+        e.set_archive(Z0)
+        e.init(theta0[off:off + h])
+        return e
+
+    def pair():
+        es = [make(0), make(h)]
+        ptrs = [e.archive_pointer() for e in es]
+        for r, e in enumerate(es):
+            e.set_archive_peers(2, r, pointers=ptrs)
+        return es
+
+    def advance(es, steps):
+        outs, done = [[], []], 0
+        while done < steps:
+            k = min(K, steps - done)
+            for r, e in enumerate(es):
+                outs[r].append(e.run_host(k))
+            sums = es[0].archive_local_sums() + es[1].archive_local_sums()
+            for e in es:
+                e.archive_publish(sums)
+            done += k
+        return [np.concatenate([np.concatenate([o[i] for o in outs[r]]) for r in range(2)], axis=1) for i in range(3)]
+
+    first = pair()
+    advance(first, 35)  # past one adaptation boundary, not on a multiple of the period
+    blobs = [e.get_state() for e in first]
+    ref = advance(first, 25)
+    ref_rows = first[0].dreamz_state()["archive_rows"]
+    ref_pcr = [e.dreamz_state()["pCR"] for e in first]
+    for e in first:
+        e.close()
+    second = pair()
+    for e, b in zip(second, blobs):
+        e.set_state(b)
+        assert e._peer_t == 35
+    got = advance(second, 25)
+    for x, y in zip(got, ref):
+        assert np.array_equal(x, y)
+    assert second[0].dreamz_state()["archive_rows"] == ref_rows == M0 + 60 * N
+    for e, pc in zip(second, ref_pcr):
+        np.testing.assert_array_equal(e.dreamz_state()["pCR"], pc)
+        e.close()
+
+
 @pytest.mark.parametrize("model,adaptive", [("rosenbrock", False), ("linear", True)])
 def test_dream_distributed_archive_lagged_publish(eng_mod, model, adaptive):
     """two unpublished blocks: block b runs while the collective of block b - 1 is in flight, its rows become visible from block

@@ -1566,6 +1566,17 @@ void enumerate_state(tda_engine* e, std::vector<StateItem>& v) {
     host(&e->arch_rows, sizeof e->arch_rows);
     host(&e->sums_rows, sizeof e->sums_rows);
     host(&e->pending_steps, sizeof e->pending_steps);
+    if (e->dist_ranks) {  // distributed archive: the publish protocol's position (the peer mappings belong to the process, not the state)
+      host(&e->dist_steps, sizeof e->dist_steps);
+      host(&e->dist_pending, sizeof e->dist_pending);
+      host(e->dist_unpub, sizeof e->dist_unpub);
+      host(&e->dist_n_unpub, sizeof e->dist_n_unpub);
+      host(&e->dist_adapt_rows, sizeof e->dist_adapt_rows);
+      host(&e->dist_sum_steps, sizeof e->dist_sum_steps);
+      host(&e->dist_m0_summed, sizeof e->dist_m0_summed);
+      host(&e->dist_adapt_pending, sizeof e->dist_adapt_pending);
+      host(&e->dist_adapt_gamma, sizeof e->dist_adapt_gamma);
+    }
     dev(e->arch);
     dev(e->zsum);
     dev(e->zsq);

@@ -261,6 +261,9 @@ class Engine:
     def set_state(self, blob):
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         self._ck(self.lib.tda_engine_set_state(self.h, _ptr(blob), blob.size))
+        # distributed.run_peer_dream counts the engine's steps to find the adaptation boundaries: the first item of a blob is the
+        # engine's iteration counter (16-byte header, 8-byte item size, then the int64; tda_engine.hip enumerate_state)
+        self._peer_t = int(blob[24:32].view(np.int64)[0])
 
     def set_error_model(self, kind):
         code = {None: 0, "state-independent": 1, "state-dependent": 2, "state-independent-diagonal": 3}[kind]
