@@ -424,6 +424,10 @@ def test_dream_distributed_archive_equals_the_replicated_one(eng_mod, model, ada
     e1.set_archive_peers(2, 1, pointers=ptrs)
     with pytest.raises(Exception):
         e0.run_host(K + 1)  # more than one exchange interval per call
+    with pytest.raises(Exception, match="distributed"):
+        e0.archive_append(np.zeros((N, d)))  # the replicated-archive exchange does not apply
+    with pytest.raises(Exception, match="distributed"):
+        e0.archive_take(np.empty((1, h, d)))
     outs0, outs1 = [], []
     done = 0
     while done < T:

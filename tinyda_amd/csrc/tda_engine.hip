@@ -1291,6 +1291,7 @@ static int dreamz_sums_catchup(tda_engine* e, int64_t row0, int64_t nrows, bool 
 
 int tda_engine_archive_take(tda_engine* e, double* rows, int64_t* n_steps) {
   if (!e || !e->inited || !e->is_dreamz || !e->dz.shared) return fail(TDA_ERR_STATE, "no shared-archive engine initialised");
+  if (e->dist_ranks) return fail(TDA_ERR_STATE, "the archive is distributed: its rows stay where they are written (tda_engine_archive_publish)");
   HIP_TRY(hipSetDevice(e->cfg.device));
   if (n_steps) *n_steps = e->pending_steps;
   if (rows && e->pending_steps) {  // [steps][N][d] without padding
@@ -1311,6 +1312,7 @@ int tda_engine_archive_take(tda_engine* e, double* rows, int64_t* n_steps) {
 
 int tda_engine_archive_append(tda_engine* e, const double* rows, int64_t n_rows) {
   if (!e || !e->inited || !e->is_dreamz || !e->dz.shared) return fail(TDA_ERR_STATE, "no shared-archive engine initialised");
+  if (e->dist_ranks) return fail(TDA_ERR_STATE, "the archive is distributed: its rows stay where they are written (tda_engine_archive_publish)");
   if (n_rows <= 0) return TDA_OK;
   if (e->arch_rows + n_rows > e->arch_cap) return fail(TDA_ERR_INVALID, "shared archive capacity (%lld rows) exceeded", (long long)e->arch_cap);
   HIP_TRY(hipSetDevice(e->cfg.device));
