@@ -1354,6 +1354,7 @@ int tda_engine_set_archive_peers(tda_engine* e, int n_ranks, int my_rank, const 
   if (e->arch_rows != e->dz.M0 || e->pending_steps || e->dist_ranks) return fail(TDA_ERR_STATE, "set the peers once, right after init");
   const Level& lv = e->levels[0];
   if (lv.model == MODEL_CALLBACK || lv.model == MODEL_USER) return fail(TDA_ERR_UNSUPPORTED, "the distributed archive serves the engine's own models");
+  if (e->nlev > 1) return fail(TDA_ERR_UNSUPPORTED, "the distributed archive serves single-level DREAM runs (below a hierarchy the archive is replicated)");
   HIP_TRY(hipSetDevice(e->cfg.device));
   for (int r = 0; r < n_ranks; ++r) {
     if (r == my_rank) {
