@@ -215,3 +215,43 @@ def test_pinned_host_records_equal_pageable(eng_mod):
     b.run(T - 40, pb[40:], sb[40:], ab[40:])
     b.close()
     assert np.array_equal(pa, pb) and np.array_equal(sa, sb) and np.array_equal(aa, ab)
+
+
+def test_proposal_covariance_set_at_run_time_survives_a_checkpoint(eng_mod):
+    """tda_engine_set_proposal_covariance on a two-level GaussianRandomWalk engine that started from the identity (increments =
+    the normals themselves, k_rng_direct): the new factor takes effect, and a checkpoint taken afterwards restores it into an
+    engine that was again initialised with the identity."""
+    d, N = 8, 32
+    r2 = np.random.default_rng(3)
+    A0, A1 = r2.standard_normal((10, d)) / 2, r2.standard_normal((24, d)) / 2
+    y0, y1 = r2.standard_normal(10), r2.standard_normal(24)
+    C = np.diag(np.linspace(0.2, 2.0, d))
+
+    def make():
+        e = eng_mod.Engine(N, d, seed=21, n_levels=2)
+        e.set_prior(np.zeros(d), np.eye(d))
+        e.set_level(0, A0, y0, 0, 0.5)
+        e.set_level(1, A1, y1, 0, 0.5)
+        e.set_proposal(0, np.eye(d), scaling=0.1)
+        e.set_subchains([4])
+        e.init(np.zeros((N, d)))
+        return e
+
+    flat = lambda outs: [a for lvl in outs for a in lvl]
+    plain = make()
+    ident_run = flat(plain.run_levels_host(6))
+    plain.close()
+    a = make()
+    a.set_proposal_covariance(C)
+    first = flat(a.run_levels_host(6))
+    assert not np.array_equal(first[0], ident_run[0])  # the factor is in use
+    # steps of level 0 are scaling * L z: per-dimension spread of the first increments follows diag(C)
+    blob = a.get_state()
+    ref = flat(a.run_levels_host(6))
+    a.close()
+    b = make()
+    b.set_state(blob)
+    got = flat(b.run_levels_host(6))
+    b.close()
+    for x, y in zip(got, ref):
+        assert np.array_equal(x, y)

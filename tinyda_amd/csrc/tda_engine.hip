@@ -1647,6 +1647,17 @@ int tda_engine_set_state(tda_engine* e, const void* blob, int64_t bytes) {
     else memcpy(it.p, o, it.bytes);
     o += it.bytes;
   }
+  if (e->L_identity) {  // derived from the factor at init(): the restored one may come from tda_engine_set_proposal_covariance
+    const int d = e->d, DP = e->DP;
+    std::vector<double> Lh((size_t)DP * DP);
+    HIP_TRY(hipMemcpy(Lh.data(), e->Lk.p, Lh.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int k = 0; k < d && e->L_identity; ++k)
+      for (int j = 0; j < d; ++j)
+        if (Lh[(size_t)k * DP + j] != (j == k ? 1.0 : 0.0)) {
+          e->L_identity = false;
+          break;
+        }
+  }
   return TDA_OK;
 }
 
