@@ -140,7 +140,8 @@ def test_nan_posterior_is_rejected_and_overflow_accepts(eng_mod):
     e.close()
 
 
-@pytest.mark.parametrize("kind", ["am", "mlda", "dreamz"])
+@pytest.mark.parametrize("kind", ["am", "mlda", "dreamz", "mlda_aem", "mlda_aemd", "mlda_aemd_wide", "da_aem_sd", "da_random",
+                                  "dream_shared", "mlda_dreamz"])
 def test_checkpoint_resume_is_bitwise(eng_mod, kind):
     """get_state / set_state: a run interrupted at an awkward point (mid period, mid subchain) and resumed in a fresh,
     identically configured engine continues bit for bit."""
@@ -149,6 +150,60 @@ def test_checkpoint_resume_is_bitwise(eng_mod, kind):
     prior = (np.zeros(d), np.eye(d))
 
     def make():
+        if kind in ("mlda_aem", "mlda_aemd", "mlda_aemd_wide", "mlda_dreamz"):
+            # error models over three levels with a common output count (dense; diagonal; diagonal with d > 32, where the base
+            # subchains run in the fused level kernel) and DREAM(Z) as the base proposal of a hierarchy (host-sequenced path)
+            dd = 40 if kind == "mlda_aemd_wide" else d
+            e = eng_mod.Engine(N, dd, seed=9, n_levels=3, block_steps=7)
+            e.set_prior(np.zeros(dd), np.eye(dd))
+            r2 = np.random.default_rng(1)
+            base = r2.standard_normal((16, dd)) / 2
+            yy = r2.standard_normal(16)
+            for k in range(3):
+                Ak = base + 0.03 * (2 - k) * r2.standard_normal((16, dd))
+                if kind == "mlda_aem" and k < 2:
+                    e.set_level(k, Ak, yy, 3, 0.5 * np.eye(16))  # AdaptiveGaussianLogLike below the finest level
+                else:
+                    e.set_level(k, Ak, yy, 0, 0.5)
+            if kind == "mlda_dreamz":
+                e.set_proposal_dreamz(12, delta=2, adaptive=True, period=10, capacity=12 + 400)
+                e.set_archive(np.random.default_rng(2).standard_normal((N, 12, dd)))
+            elif kind == "mlda_aemd_wide":
+                e.set_proposal(0, 0.01 * np.eye(dd), scaling=1.0)
+            else:
+                e.set_proposal(2, 0.05 * np.eye(dd), t0=10, period=10, adaptive=True)
+            e.set_subchains([3, 2])
+            if kind != "mlda_dreamz":
+                e.set_error_model("state-independent" if kind == "mlda_aem" else "state-independent-diagonal")
+            e.init(np.full((N, dd), 0.1))
+            return e
+        if kind in ("da_aem_sd", "da_random"):
+            e = eng_mod.Engine(N, d, seed=9, n_levels=2, block_steps=7)
+            e.set_prior(*prior)
+            r2 = np.random.default_rng(1)
+            base = r2.standard_normal((12, d)) / 2
+            yy = r2.standard_normal(12)
+            if kind == "da_aem_sd":
+                e.set_level(0, base + 0.05 * r2.standard_normal((12, d)), yy, 3, 0.5 * np.eye(12))
+            else:
+                e.set_level(0, base + 0.05 * r2.standard_normal((12, d)), yy, 0, 0.5)
+            e.set_level(1, base, yy, 0, 0.5)
+            e.set_proposal(2, 0.05 * np.eye(d), t0=10, period=10, adaptive=True)
+            if kind == "da_random":
+                e.set_subchains([4], randomize=True)
+            else:
+                e.set_subchains([3])
+                e.set_error_model("state-dependent")
+            e.init(np.full((N, d), 0.1))
+            return e
+        if kind == "dream_shared":
+            e = eng_mod.Engine(N, d, seed=9, block_steps=7)
+            e.set_prior(*prior)
+            e.set_level_rosenbrock(0, 1.0, 10.0, 0.0, 1.0)
+            e.set_proposal_dreamz(12, delta=2, adaptive=True, period=10, shared=True, sync_every=4, capacity=12 + 80 * N)
+            e.set_archive(np.random.default_rng(2).standard_normal((12, d)))
+            e.init(np.full((N, d), 0.1))
+            return e
         if kind == "mlda":
             e = eng_mod.Engine(N, d, seed=9, n_levels=3, block_steps=7)
             e.set_prior(*prior)
@@ -173,8 +228,9 @@ def test_checkpoint_resume_is_bitwise(eng_mod, kind):
         e.init(np.full((N, d), 0.1))
         return e
 
-    run = (lambda e, n: e.run_levels_host(n)) if kind == "mlda" else (lambda e, n: e.run_host(n))
-    flat = (lambda o: [a for lvl in o for a in lvl]) if kind == "mlda" else (lambda o: list(o))
+    levels = kind.startswith("mlda") or kind.startswith("da_")
+    run = (lambda e, n: e.run_levels_host(n)) if levels else (lambda e, n: e.run_host(n))
+    flat = (lambda o: [a for lvl in o for a in lvl]) if levels else (lambda o: list(o))
     a = make()
     run(a, 33)
     blob = a.get_state()
