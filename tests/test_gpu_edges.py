@@ -311,3 +311,58 @@ def test_proposal_covariance_set_at_run_time_survives_a_checkpoint(eng_mod):
     b.close()
     for x, y in zip(got, ref):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("kind", ["mlda", "dreamz", "da_aem"])
+def test_pageable_host_records_equal_pinned_in_the_other_drivers(eng_mod, kind):
+    """run() / run_levels() into ordinary (pageable) NumPy arrays against page-locked ones for the multilevel, DREAM(Z) and
+    error-model drivers (every *_host helper of the wrapper uses page-locked buffers, so the pageable branch needs its own
+    case), with the run split at an awkward point."""
+    d, N, T = 7, 24, 23
+
+    def make():
+        r2 = np.random.default_rng(1)
+        if kind == "dreamz":
+            e = eng_mod.Engine(N, d, seed=4, block_steps=8)
+            e.set_prior(np.zeros(d), np.eye(d))
+            e.set_level(0, r2.standard_normal((10, d)) / 2, r2.standard_normal(10), 0, 0.5)
+            e.set_proposal_dreamz(12, delta=2, adaptive=True, period=10, capacity=12 + 2 * T)
+            e.set_archive(np.random.default_rng(2).standard_normal((N, 12, d)))
+        else:
+            nl = 3 if kind == "mlda" else 2
+            e = eng_mod.Engine(N, d, seed=4, n_levels=nl, block_steps=8)
+            e.set_prior(np.zeros(d), np.eye(d))
+            base, yy = r2.standard_normal((12, d)) / 2, r2.standard_normal(12)
+            for k in range(nl):
+                Ak = base + 0.04 * (nl - 1 - k) * r2.standard_normal((12, d))
+                if kind == "da_aem" and k == 0:
+                    e.set_level(k, Ak, yy, 3, 0.5 * np.eye(12))
+                else:
+                    e.set_level(k, Ak, yy, 0, 0.5)
+            e.set_proposal(2, 0.05 * np.eye(d), t0=10, period=10, adaptive=True)
+            e.set_subchains([3, 2] if nl == 3 else [3])
+            if kind == "da_aem":
+                e.set_error_model("state-independent")
+        e.init(np.full((N, d), 0.1))
+        return e
+
+    def bufs(e, n, pinned):
+        mk = eng_mod.pinned_empty if pinned else (lambda shape, dtype=np.float64: np.empty(shape, dtype=dtype))
+        rows = e.rows_per_level(n) if kind != "dreamz" else [n]
+        return [(mk((r, N, d)), mk((r, N, 3)), mk((r, N), dtype=np.uint8)) for r in rows]
+
+    got = {}
+    for pinned in (True, False):
+        e = make()
+        parts = []
+        for n in (9, T - 9):
+            o = bufs(e, n, pinned)
+            if kind == "dreamz":
+                e.run(n, *o[0])
+            else:
+                e.run_levels(n, o)
+            parts.append(o)
+        e.close()
+        got[pinned] = [np.concatenate([part[lv][i] for part in parts]) for lv in range(len(parts[0])) for i in range(3)]
+    for x, y in zip(got[True], got[False]):
+        assert np.array_equal(x, y)
