@@ -1169,10 +1169,13 @@ __device__ __forceinline__ double bcast_lane64(double v, int src) {
 // operands of step s + 1 under step s (no store -> load round trip in front of a step) and reading the row operands one tile
 // row ahead changed nothing (347 -> 349-359 us per 100 states of 4096 chains); the 382 vector instructions of a state take
 // 2 100 cycles of a SIMD with its two resident waves, 5.5 per instruction, where tools/valu_rate_probe.hip gets 4.1 for the
-// same 5 mul : 3 add mix on 16 registers -- the rest is the operand traffic of 230 live registers, not latency.  (At DPAD <= 32 the
-// picture differs: 125 instructions per state are less than the latency of the one record load a wave has in flight, k_adapt<32>
-// takes 150 us per 100 states of 4096 chains = 3 600 cycles per state; a deeper prefetch would help there.  No benchmark
-// configuration adapts in fewer than 64 dimensions.)
+// same 5 mul : 3 add mix on 16 registers -- the rest is the operand traffic of 230 live registers, not latency.  Also tried late in round 2,
+// same-box A/B on the headline run: pinning this state's record before the next one's load is issued (the compiler waits with
+// vmcnt(0) at the first use, which otherwise covers the load just issued) -- 8.85 against 8.89 ms per 20 periods, no change:
+// the partner wave's arithmetic already covers that latency; the wave-scope fence instead of __syncthreads() -- no change.
+// At DPAD <= 16 the two together took 82 -> 66-71 us per 100 states of 4096 chains (the fixed ~50 instructions per state
+// dominate there), at DPAD = 32 nothing (150 us: four resident waves x 125 instructions, the vector unit 56 % busy); not
+// adopted, no benchmark configuration adapts in fewer than 64 dimensions.
 template <int DPAD>
 __global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
   constexpr int T = am_tile_rows<DPAD>();
