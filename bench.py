@@ -123,12 +123,14 @@ def cpu_baseline(A, y, target_seconds=12.0):
     t_cal = run(cores, 50)
     rate = cores * 50 / t_cal
     n_chains = int(max(cores, min(4096, round(rate * target_seconds / T / cores) * cores)))
+    if n_chains == 4096:  # a many-core host finishes 4096 x 250 in a second or two: lengthen the chains up to the target time
+        T = int(min(5000, max(T, rate * target_seconds / n_chains))) // 50 * 50
     dt = run(n_chains, T)
     out = {"value": n_chains * T / dt, "unit": "evals/s", "cores": cores, "kind": "port",
            "sample": "%d chains x %d MH iterations of the same workload through the CPU build of the C-ABI (libtda_cpu.so, "
                      "OpenMP over chains, %.1f s)" % (n_chains, T, dt)}
     # the reference's cost profile next to it -- one chain at a time in NumPy / SciPy with the SVD-based draw
-    # and scipy's logpdf on every step (oracle/tinyda_oracle.py::reference_shaped_am_chain), one core, ~2 s
+    # and scipy's logpdf on every step (oracle/tinyda_oracle.py::reference_shaped_am_chain), one core, ~6 s
     try:
         from oracle import tinyda_oracle as orc
 
@@ -141,7 +143,7 @@ def cpu_baseline(A, y, target_seconds=12.0):
         except Exception:
             one_thread = contextlib.nullcontext()
         th0 = np.random.default_rng(3).standard_normal(D)
-        n_ref = 3000
+        n_ref = 20000  # ~6 s on one core
         with one_thread:
             orc.reference_shaped_am_chain(A, y, SIGMA ** 2, th0, 20, 1e-4 * np.eye(D))
             t0 = time.perf_counter()
