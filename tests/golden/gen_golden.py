@@ -899,6 +899,59 @@ def g12_independence():
          q_mean=q_mean, q_cov=q_cov, theta0=theta0, **res)
 
 
+def g16_get_samples():
+    """Layout pin for diagnostics.get_samples (diagnostics.py:114-209): the REFERENCE's sample() result dicts (MH, Delayed
+    Acceptance, 3-level MLDA; a model returning (output, qoi)) flattened to arrays, and what the reference's get_samples makes
+    of them for every attribute / level / burn-in the notebooks use.  Stored: the per-link traces of every chain key of the
+    result dict (`<case>__res__<key>__<field>`) and every get_samples output (`<case>__gs<j>__<key>`), scalars as 0-d arrays."""
+    import contextlib
+    import io
+
+    sigma, d = 0.2, 4
+    As, ys, theta_true, pm, pc = _ml_problem(1601, d, (6, 9, 12), sigma)
+    prior = stats.multivariate_normal(pm, pc)
+    w = np.linspace(0.5, 1.5, d)
+
+    def model_of(A):
+        return lambda th: (A @ th, np.array([float(w @ th), float(th[0] * th[1])]))  # (output, qoi): posterior.py:97-101
+
+    posts = [tda.Posterior(prior, tda.GaussianLogLike(y, sigma ** 2 * np.eye(len(y))), model_of(A)) for A, y in zip(As, ys)]
+    rng = np.random.default_rng(1602)
+    theta0 = [theta_true + 0.2 * rng.standard_normal(d) for _ in range(3)]
+    cases = {
+        "mh": dict(posteriors=posts[2], proposal=tda.GaussianRandomWalk(0.02 * np.eye(d)), iterations=24, n_chains=3),
+        "da": dict(posteriors=posts[1:], proposal=tda.GaussianRandomWalk(0.02 * np.eye(d)), iterations=12, n_chains=3, subchain_length=3),
+        "mlda": dict(posteriors=posts, proposal=tda.GaussianRandomWalk(0.02 * np.eye(d)), iterations=8, n_chains=3, subchain_length=[3, 2]),
+    }
+    queries = {
+        "mh": [dict(), dict(burnin=5), dict(attribute="stats", burnin=3), dict(attribute="model_output"), dict(attribute="qoi", burnin=2),
+               dict(attribute="likelihood", burnin=4)],
+        "da": [dict(), dict(level="coarse", burnin=4), dict(attribute="stats", level="coarse"), dict(attribute="model_output", level="fine", burnin=2),
+               dict(attribute="qoi", level="coarse", burnin=1), dict(attribute="posterior", level="fine")],
+        "mlda": [dict(level=2), dict(level=1, burnin=3), dict(level=0, burnin=7), dict(attribute="stats", level=1), dict(attribute="model_output", level=0, burnin=2),
+                 dict(attribute="qoi", level=2, burnin=1)],
+    }
+    arrays = {}
+    for name, kw in cases.items():
+        with Tap(1610 + len(name)), contextlib.redirect_stdout(io.StringIO()):
+            res = tda.sample(initial_parameters=[t.copy() for t in theta0], force_sequential=True, **kw)
+        for key, val in res.items():
+            if key.startswith("chain_"):
+                arrays["%s__res__%s__parameters" % (name, key)] = np.array([l.parameters for l in val])
+                arrays["%s__res__%s__prior" % (name, key)] = np.array([l.prior for l in val])
+                arrays["%s__res__%s__likelihood" % (name, key)] = np.array([l.likelihood for l in val])
+                arrays["%s__res__%s__model_output" % (name, key)] = np.array([l.model_output for l in val])
+                arrays["%s__res__%s__qoi" % (name, key)] = np.array([l.qoi for l in val])
+            else:
+                arrays["%s__res__%s" % (name, key)] = np.array(val)
+        for j, q in enumerate(queries[name]):
+            gs = tda.get_samples(res, **q)
+            arrays["%s__gs%d__query" % (name, j)] = np.array(repr(sorted(q.items())))
+            for key, val in gs.items():
+                arrays["%s__gs%d__%s" % (name, j, key)] = np.array(val)
+    save("g16_get_samples", **arrays)
+
+
 FIXTURES = {
     "g1_basic_sampler": g1_basic_sampler,
     "g2_am_small": lambda: g2_am("g2_am_small", d=8, m=16, n_chains=8, iters=128, t0=16, period=16, seed=201),
@@ -940,6 +993,7 @@ FIXTURES = {
     "g15_da_dreamz": lambda: g15_hier_dreamz("g15_da_dreamz", ms=(10, 24), sl=(3,), seed=1501),
     "g15_mlda_dreamz": lambda: g15_hier_dreamz("g15_mlda_dreamz", ms=(8, 14, 24), sl=(3, 2), iters=20, seed=1502),
     "g7_moments": g7_moments,
+    "g16_get_samples": g16_get_samples,
     "g9_mvn_logpdf": g9_mvn_logpdf,
     "g10_jointprior": g10_jointprior,
     "g12_independence": g12_independence,

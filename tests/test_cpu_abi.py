@@ -20,7 +20,9 @@ def cpu():
     g.build()
     from tinyda_amd import _lib
 
-    return _lib.load_from(g.CPU_ABI_SO), g.CPU_ABI_SO
+    # tests/test_cpu_twin_sanitized.py re-runs this module in a child process against an ASan + UBSan build of the same source
+    path = os.environ.get("TINYDA_CPU_ABI_SO", g.CPU_ABI_SO)
+    return _lib.load_from(path), path
 
 
 def test_cpu_twin_exports_the_whole_abi(cpu):
