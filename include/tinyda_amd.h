@@ -165,7 +165,15 @@ typedef struct tda_profile {
 } tda_profile;
 
 const char* tda_last_error(void);
+/* "tinyda_amd <abi>.<minor> (...)".  ABI history: 0.1 round 1; 0.2 tda_outputs.reserved became `rows` (a caller built against 0.1
+ * that passes 0 with non-NULL buffers is refused with TDA_ERR_INVALID); 0.3 tda_release_cached_memory, tda_engine_set_record_thinning,
+ * tda_engine_set_progress / get_progress, tda_engine_detach_proposal_state + tda_proposal_snapshot_*. */
 const char* tda_version(void);
+
+/* Released engines park their large device buffers in a per-process pool (TINYDA_POOL_GB, default 8 GiB) so that the next
+ * engine does not pay hipMalloc / hipFree again (tda.sample() creates one engine per call).  Returns the bytes handed back
+ * to the driver. */
+int64_t tda_release_cached_memory(void);
 
 int tda_engine_create(const tda_config* cfg, tda_engine** out);
 void tda_engine_destroy(tda_engine* e);
@@ -249,12 +257,35 @@ int tda_engine_set_export(tda_engine* e, double* z, double* u, int64_t n_steps);
 int tda_engine_run(tda_engine* e, int64_t n_iterations, const tda_outputs* out);
 int tda_engine_sync(tda_engine* e);
 
+/* Record thinning (single-level GRW / pCN / AM / MALA runs): of the iterations a run() advances, only those with
+ * (t + 1) % thin == 0 -- t = iterations the engine had taken before that one, so the phase carries over split runs and
+ * checkpoints -- reach the caller's buffers, packed: a run of n iterations from t produces (t + n) / thin - t / thin records
+ * (integer divisions), and tda_outputs.rows is checked against that.  Adaptation still sees every iteration.  thin = 1: off.
+ * (The reference keeps every Link in a Python list; SURVEY section 5 asks for a thinned mode for long histories.) */
+int tda_engine_set_record_thinning(tda_engine* e, int32_t thin);
+
+/* Progress without host synchronisation (the reference's tqdm bar, chain.py:96-99 / :343-351): when enabled, the end of every
+ * block of a run() leaves the number of iterations completed so far (finest-level iterations for DA / MLDA) and the mean accept
+ * flag of that block (-1 when the driver does not have it) in page-locked memory; get_progress only reads that memory -- it may
+ * be called from another host thread while run() or sync() is blocking. */
+int tda_engine_set_progress(tda_engine* e, int enable);
+int tda_engine_get_progress(tda_engine* e, int64_t* iterations_done, int64_t* iterations_queued, double* accept_rate);
+
 /* Proposal state, HOST pointers, any may be NULL: scaling[n_chains], C[n_chains*d*d] (covariance in use),
  * am_mu[n_chains*d], am_sigma[n_chains*d*d] (RecursiveSampleMoments), counters[2] = {t, k}. */
 int tda_engine_get_proposal_state(tda_engine* e, double* scaling, double* C, double* am_mu,
                                   double* am_sigma, int64_t* counters);
 
 /* DREAMZ state, HOST pointers, any may be NULL: pCR [n_chains][nCR], archive_rows[1]. */
+/* The proposal state of an engine that has finished its work, taken over WITHOUT a copy (tda.sample() returns it lazily: the
+ * 4096 per-chain covariances of BASELINE config 2 are 134 MB that most callers never look at).  detach moves the engine's
+ * proposal buffers into the snapshot; the engine can only be destroyed afterwards.  snapshot_read takes the same host output
+ * pointers (any of them NULL) as tda_engine_get_proposal_state. */
+typedef struct tda_proposal_snapshot tda_proposal_snapshot;
+int tda_engine_detach_proposal_state(tda_engine* e, tda_proposal_snapshot** out);
+int tda_proposal_snapshot_read(tda_proposal_snapshot* s, double* scaling, double* C, double* am_mu, double* am_sigma, int64_t* counters);
+void tda_proposal_snapshot_destroy(tda_proposal_snapshot* s);
+
 int tda_engine_get_dreamz_state(tda_engine* e, double* pCR, int64_t* archive_rows);
 
 /* Shared-archive exchange for one process per GPU (DREAM over RCCL): after run() with auto-append off, take the

@@ -121,7 +121,8 @@ struct tda_engine {
 extern "C" {
 
 const char* tda_last_error(void) { return g_err.c_str(); }
-const char* tda_version(void) { return "tinyda_amd 0.1 (cpu twin of the C-ABI: test / baseline infrastructure)"; }
+const char* tda_version(void) { return "tinyda_amd 0.3 (cpu twin of the C-ABI: test / baseline infrastructure)"; }
+int64_t tda_release_cached_memory(void) { return 0; }
 
 int tda_engine_create(const tda_config* cfg, tda_engine** out) {
   if (!cfg || !out) return fail(TDA_ERR_INVALID, "null argument");
@@ -457,6 +458,12 @@ int tda_engine_get_profile(tda_engine* e, tda_profile* p) {
 
 // ---- the rest of the header: declared, exported, not available on the CPU twin ----
 #define TDA_CPU_UNSUPPORTED(what) return fail(TDA_ERR_UNSUPPORTED, what " is not part of the CPU twin of the ABI")
+int tda_engine_set_record_thinning(tda_engine*, int32_t thin) { if (thin == 1) return TDA_OK; TDA_CPU_UNSUPPORTED("record thinning"); }
+int tda_engine_set_progress(tda_engine*, int) { TDA_CPU_UNSUPPORTED("progress reporting"); }
+int tda_engine_detach_proposal_state(tda_engine*, tda_proposal_snapshot**) { TDA_CPU_UNSUPPORTED("proposal snapshots"); }
+int tda_proposal_snapshot_read(tda_proposal_snapshot*, double*, double*, double*, double*, int64_t*) { TDA_CPU_UNSUPPORTED("proposal snapshots"); }
+void tda_proposal_snapshot_destroy(tda_proposal_snapshot*) {}
+int tda_engine_get_progress(tda_engine*, int64_t*, int64_t*, double*) { TDA_CPU_UNSUPPORTED("progress reporting"); }
 int tda_engine_set_proposal_dreamz(tda_engine*, const tda_dreamz_params*) { TDA_CPU_UNSUPPORTED("DREAM(Z)"); }
 int tda_engine_set_proposal_operators(tda_engine*, const double*, const double*) { TDA_CPU_UNSUPPORTED("OperatorWeightedCrankNicolson"); }
 int tda_engine_set_archive(tda_engine*, const double*) { TDA_CPU_UNSUPPORTED("DREAM(Z)"); }

@@ -54,9 +54,12 @@ torch.device = _dev
 # run -> collective -> publish (block-synchronous) or at most two unpublished blocks (lagged); sums only at adaptation boundaries
 import numpy as np
 class PeerEngine:
-    n_chains, dim, device = cnt, 2, 0
+    n_chains, dim, device = 16, 2, 0
+    _dz = dict(M0=4, capacity=100)
     def __init__(self):
         self.log, self.unpub, self.steps = [], 0, 0
+    def counters(self):
+        return self.steps, 0
     def archive_ipc_handle(self):
         return bytes([rank]) * 64
     def set_archive_peers(self, n, me, handles=None, pointers=None):
@@ -81,6 +84,18 @@ for lag in (False, True):
     tdist.run_peer_dream(pe, 11, 3, period=6, lag=lag)
     assert pe.unpub == 0
     logs["lag" if lag else "sync"] = pe.log
+# ranks that disagree in their chain count (or hold a count that is not a multiple of the tile) must ALL raise before any of them
+# maps a segment or waits in a barrier (the advisor's hang: one rank fails a local check, its peers wait for it forever)
+mismatch = []
+for n_bad in (16 + 16 * rank, 24):
+    bad = PeerEngine()
+    bad.n_chains = n_bad
+    try:
+        tdist.setup_peer_archive(bad)
+        mismatch.append("no error")
+    except ValueError as exc:
+        mismatch.append("ValueError" if not bad.log else "mapped before raising")
+logs["mismatch"] = mismatch
 with open(os.path.join(%(out)r, "rank%%d.json" %% rank), "w") as fh:
     json.dump(dict(rank=rank, off=off, cnt=cnt, mx=mx, sm=sm, n=n, mu=mu.tolist(), M2=M2.tolist(), rows=rows[:, 0].tolist(),
                    pipeline=fe.log, peer=logs), fh)
@@ -139,3 +154,5 @@ def test_world_size_2_gloo(tmp_path):
         # the sums; everything is published at the end
         assert lag_log[1:] == [["run", 3, 1], ["run", 3, 2], ["publish", 18.0], ["run", 3, 2], ["publish", None], ["run", 2, 2],
                                ["publish", None], ["publish", None]]
+        # unequal chain counts (16 / 32) and a count that is not a multiple of the tile (24 on both): ValueError on EVERY rank
+        assert res[r_]["peer"]["mismatch"] == ["ValueError", "ValueError"]

@@ -99,6 +99,7 @@ FORWARD_BATCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POI
 SYMBOLS = {
     "tda_last_error": (C.c_char_p, []),
     "tda_version": (C.c_char_p, []),
+    "tda_release_cached_memory": (C.c_int64, []),
     "tda_engine_create": (C.c_int, [C.POINTER(tda_config), C.POINTER(_P)]),
     "tda_engine_destroy": (None, [_P]),
     "tda_engine_set_prior": (C.c_int, [_P, _P, _P]),
@@ -138,7 +139,13 @@ SYMBOLS = {
     "tda_engine_set_export": (C.c_int, [_P, _P, _P, C.c_int64]),
     "tda_engine_run": (C.c_int, [_P, C.c_int64, C.POINTER(tda_outputs)]),
     "tda_engine_sync": (C.c_int, [_P]),
+    "tda_engine_set_record_thinning": (C.c_int, [_P, C.c_int32]),
+    "tda_engine_set_progress": (C.c_int, [_P, C.c_int]),
+    "tda_engine_get_progress": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "tda_engine_get_proposal_state": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "tda_engine_detach_proposal_state": (C.c_int, [_P, C.POINTER(_P)]),
+    "tda_proposal_snapshot_read": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "tda_proposal_snapshot_destroy": (None, [_P]),
     "tda_engine_get_flags": (C.c_int, [_P, _P]),
     "tda_engine_evaluate": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P]),
     "tda_engine_rng_probe": (C.c_int, [_P, C.c_int64, _P, _P]),
@@ -151,10 +158,15 @@ _lib = None
 
 
 def _bind_single_hip_runtime():
-    """One HIP runtime per process.  The PyTorch-ROCm wheel bundles its own libamdhip64 (SONAME
-    libamdhip64.so.7, the same as /opt/rocm's).  If this library pulled in /opt/rocm's copy first and torch
-    loaded its own afterwards, the second runtime would find no GPU.  So when torch is installed, its copy is
-    mapped first and libtinyda_hip.so binds to it by SONAME; torch later re-uses the same mapping."""
+    """One HIP runtime per process, and torch's libraries mapped BEFORE that runtime is initialised.
+
+    The PyTorch-ROCm wheel bundles its own libamdhip64 (SONAME libamdhip64.so.7, the same as /opt/rocm's).  If this library
+    pulled in /opt/rocm's copy first and torch loaded its own afterwards, the second runtime would find no GPU.  And when torch is
+    imported AFTER the first HIP call of the process, mapping its libraries takes ~10 s instead of ~0.7 s (measured on MI355X,
+    profiles/r03_api.json: the runtime then loads every code object of libtorch_hip eagerly instead of on first use) -- which is
+    what made the first tda.sample() of a script that had not imported torch itself take 11 s.  So when torch is installed it is
+    imported here, before libtinyda_hip.so is mapped and before any HIP call; without torch the library binds to the system
+    runtime named in its RUNPATH."""
     import sys
 
     if "torch" in sys.modules:
@@ -162,13 +174,9 @@ def _bind_single_hip_runtime():
     try:
         import importlib.util
 
-        spec = importlib.util.find_spec("torch")
-        if spec is None or not spec.submodule_search_locations:
-            return
-        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-        if os.path.exists(cand):
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
-    except Exception:  # fall back to the system runtime named in the library's RUNPATH
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401  (device memory, streams and torch.distributed are this package's plumbing anyway)
+    except Exception:  # a broken torch install: fall back to the system runtime
         pass
 
 

@@ -6,6 +6,7 @@ Extra keyword-only arguments (not in the reference): seed, backend, device, chai
 import copy
 import os
 import warnings
+from collections.abc import Mapping
 
 import numpy as np
 import scipy.stats as stats
@@ -14,7 +15,7 @@ from . import _lib
 from .hostloop import Chain, HierarchyChain
 from .proposals import (DREAM, DREAMZ, MALA, AdaptiveMetropolis, CrankNicolson, GaussianRandomWalk, IndependenceSampler,
                         OperatorWeightedCrankNicolson)
-from .records import DeviceChain
+from .records import DeviceChain, DeviceRecords
 
 _DEVICE_PROPOSALS = (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis, DREAMZ, DREAM, IndependenceSampler,
                      OperatorWeightedCrankNicolson, MALA)
@@ -176,7 +177,7 @@ def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None
            randomize_subchain_length=False, adaptive_error_model=None, store_coarse_chain=True,
            force_sequential=False, force_progress_bar=False, subsampling_rate=None, *, seed=None,
            backend="auto", device=0, chain_offset=0, distributed=False, overlap_archive_exchange=False, shared_archive="replicated",
-           error_model_covariance="dense"):
+           error_model_covariance="dense", thin=1):
     """Extra keyword-only arguments (not in tinyDA): seed, backend ('auto' | 'hip' | 'host'), device, chain_offset, and
     distributed=True: under torch.distributed (one process per GPU) `n_chains` is the GLOBAL chain count, this rank
     samples its contiguous shard (tinyda_amd.distributed.shard_chains) on GPU LOCAL_RANK and returns it with
@@ -186,17 +187,30 @@ def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None
     output dimension (include/tinyda_amd.h, TDA_AEM_STATE_INDEPENDENT_DIAGONAL); 'dense' is the reference's model.
     overlap_archive_exchange=True (DREAM's shared archive): the all-gather of a block's new archive rows runs under the next
     block's steps and the rows become visible one block later (tinyda_amd.distributed.run_shared_dream).
+    thin=k (single-level device runs): every k-th iteration is recorded (include/tinyda_amd.h, tda_engine_set_record_thinning); the
+    result then holds 1 + iterations // k links per chain (the initial one first) and 'thin': k.  Adaptation sees every iteration.
+    force_progress_bar=True (sampler.py:33): a progress line on the device path too (the engine's polled progress counters; one line
+    for all chains, with the mean acceptance rate of the last block), which is otherwise silent.
+    The device path returns with the records still in HBM: `chain_i` are lazy views (records.DeviceChain), get_samples copies what it
+    is asked for, and result['proposal_state'] reads the engine's final proposal state when it is first indexed.
     shared_archive='distributed' (DREAM under distributed=True, one process per GPU of a node): no rank holds the whole archive;
     every rank keeps the rows of its own chains and proposals read the owners' rows in place (tinyda_amd.distributed.
     setup_peer_archive / run_peer_dream; with overlap_archive_exchange=True the lagged protocol)."""
     if shared_archive not in ("replicated", "distributed"):
         raise ValueError("shared_archive must be 'replicated' or 'distributed'")
+    if int(thin) != thin or thin < 1:
+        raise ValueError("thin must be a positive integer")
+    thin = int(thin)
     if distributed:
         from . import distributed as tdist
 
         one_gpu = os.environ.get("TINYDA_BENCH_ONE_GPU") == "1"  # rehearsal of the N > 1 path on a one-GPU box: every rank on cuda:0, gloo
         rank, local_rank, world = tdist.init_process_group("gloo" if one_gpu else None)
         total = n_chains
+        if shared_archive == "distributed" and total % (16 * world):
+            # the owner of an archive row is found by dividing by ONE per-rank chain count (a multiple of the 16-chain tile):
+            # refused here, on every rank alike, before any engine exists or any rank waits for another
+            raise ValueError("shared_archive='distributed' needs n_chains to be a multiple of 16 * world size (%d)" % (16 * world))
         chain_offset, n_chains = tdist.shard_chains(total, rank, world)
         device = 0 if one_gpu else local_rank
         if isinstance(initial_parameters, list):
@@ -272,14 +286,17 @@ def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None
                 posteriors = wrapped
     if backend == "hip" and plan is None:
         raise _lib.EngineError("this posterior / proposal combination cannot be lowered to the HIP engine")
+    if thin > 1 and (plan is None or n_levels > 1 or isinstance(proposal, DREAMZ)):
+        raise NotImplementedError("thin > 1 is a single-level device option (GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis / MALA ...)")
     if plan is not None:
         if n_levels == 1:
             return _sample_device(plan, posteriors[0], iterations, n_chains, initial_parameters, seed, device,
                                   chain_offset, distributed, total if distributed else None, overlap_archive_exchange,
-                                  shared_archive == "distributed")
+                                  shared_archive == "distributed", thin, force_progress_bar)
         return _sample_device_multilevel(plan, posteriors, iterations, n_chains, initial_parameters, subchain_length,
                                          subchain_lengths, randomize_subchain_length, store_coarse_chain, seed, device,
-                                         chain_offset, "state-independent-diagonal" if diag_aem else adaptive_error_model)
+                                         chain_offset, "state-independent-diagonal" if diag_aem else adaptive_error_model,
+                                         force_progress_bar)
     if n_levels > 1:
         return _sample_host_multilevel(posteriors, proposal, iterations, n_chains, initial_parameters, subchain_length,
                                        subchain_lengths, randomize_subchain_length, adaptive_error_model, store_coarse_chain,
@@ -339,20 +356,68 @@ def _sample_host_multilevel(posteriors, proposal, iterations, n_chains, initial_
     return result
 
 
+class LazyProposalState(Mapping):
+    """result['proposal_state'] of a device run: the final state of the proposal (scaling, covariance C, AdaptiveMetropolis
+    moments, counters) -- read from the device when first indexed.  The engine hands its proposal buffers over without a copy
+    (tda_engine_detach_proposal_state) and is gone by the time sample() returns; unpacking 4096 covariance matrices took three
+    times as long as the 2000 iterations that produced them, and hardly any caller looks at them."""
+
+    def __init__(self, snapshot, n_chains, dim, want_am):
+        self._snap, self._shape, self._want_am, self._data = snapshot, (n_chains, dim), want_am, None
+
+    def _load(self):
+        if self._data is None:
+            self._data = self._snap.read(self._shape[0], self._shape[1], self._want_am)
+            self._snap.close()
+            self._snap = None
+        return self._data
+
+    def __getitem__(self, key):
+        return self._load()[key]
+
+    def __iter__(self):
+        return iter(("scaling", "C", "am_mu", "am_sigma", "t", "k"))
+
+    def __len__(self):
+        return 6
+
+
+def _run_with_progress(eng, run, total, what):
+    """run() queued without waiting, then the engine's progress counters polled (no host synchronisation inside the run): one
+    line for all chains in place of the reference's per-chain tqdm bars (chain.py:96-99)."""
+    import sys
+    import time
+
+    eng.set_progress(True)
+    run()
+    last = -1
+    while True:
+        done, _, rate = eng.progress()
+        if done != last:
+            sys.stderr.write("\r%s: %d/%d iterations%s" % (what, done, total, "" if rate < 0 else ", acceptance %.2f" % rate))
+            sys.stderr.flush()
+            last = done
+        if done >= total:
+            break
+        time.sleep(0.02)
+    sys.stderr.write("\n")
+    eng.sync()
+
+
 def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, seed, device, chain_offset,
-                   distributed=False, total_chains=None, overlap_exchange=False, peer_archive=False):
+                   distributed=False, total_chains=None, overlap_exchange=False, peer_archive=False, thin=1, progress=False):
     from .engine import Engine  # raises EngineError when libtinyda_hip.so is missing: no CPU fallback
+    import torch
 
     lows, prop = plan
     low = lows[0]
     d = low["prior_mean"].shape[0]
     if seed is None:
         seed = int(np.random.randint(0, 2 ** 31 - 1))
+    tdev = torch.device("cuda", device)
     tstream = None
     if overlap_exchange and prop["kind"] == _lib.PROP_DREAMZ and prop.get("shared"):
-        import torch
-
-        tstream = torch.cuda.Stream(device=torch.device("cuda", device))  # the collective is ordered behind the engine's work on it
+        tstream = torch.cuda.Stream(device=tdev)  # the collective is ordered behind the engine's work on it
     eng = Engine(n_chains, d, seed=seed, device=device, chain_offset=chain_offset,
                  stream=None if tstream is None else tstream.cuda_stream)
     try:
@@ -383,58 +448,64 @@ def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, se
         theta0 = None if initial_parameters is None else np.stack([np.asarray(p, float) for p in initial_parameters])
         eng.init(theta0)
         T, N = iterations, n_chains
-        from .engine import pinned_empty
-
-        params = pinned_empty((T + 1, N, d))
-        stat = pinned_empty((T + 1, N, 3))
-        acc = pinned_empty((T + 1, N), dtype=np.uint8)
-        acc[0] = 1
-        params[0], stat[0] = eng.current()
-        if T > 0 and prop["kind"] == _lib.PROP_DREAMZ and prop.get("shared") and (distributed or tstream is not None or peer_archive):
-            import torch
-
+        if thin > 1:
+            eng.set_record_thinning(thin)
+        R = T // thin  # records the run produces (the engine starts at t = 0)
+        # the history stays in HBM (BASELINE config 2, T = 2000: 4.4 GB of 288): nothing crosses PCIe unless somebody asks
+        with torch.cuda.device(tdev):
+            params = torch.empty((R + 1, N, d), dtype=torch.float64, device=tdev)
+            stat = torch.empty((R + 1, N, 3), dtype=torch.float64, device=tdev)
+            acc = torch.empty((R + 1, N), dtype=torch.uint8, device=tdev)
+            acc[0] = 1
+        eng.current_into(params[0], stat[0])
+        shared_dz = prop["kind"] == _lib.PROP_DREAMZ and prop.get("shared")
+        if T > 0 and shared_dz and (distributed or tstream is not None or peer_archive):
             from . import distributed as tdist
 
-            tdev = torch.device("cuda", device)
-            dp = torch.empty((T, N, d), dtype=torch.float64, device=tdev)
-            ds = torch.empty((T, N, 3), dtype=torch.float64, device=tdev)
-            da = torch.empty((T, N), dtype=torch.uint8, device=tdev)
             if peer_archive:
                 # every rank keeps its own rows; one small collective per 16 steps, the rows are read in place
                 tdist.setup_peer_archive(eng)
-                tdist.run_peer_dream(eng, T, 16, dp, ds, da, period=prop.get("period") if prop.get("adaptive") else None,
+                tdist.run_peer_dream(eng, T, 16, params[1:], stat[1:], acc[1:], period=prop.get("period") if prop.get("adaptive") else None,
                                      lag=tstream is not None, stream=tstream)
             else:
                 # one all_gather of the new archive rows per 16 steps
-                tdist.run_shared_dream(eng, T, 16, dp, ds, da, overlap=tstream is not None, stream=tstream)
+                tdist.run_shared_dream(eng, T, 16, params[1:], stat[1:], acc[1:], overlap=tstream is not None, stream=tstream)
             if tstream is not None:
                 tstream.synchronize()
-            params[1:], stat[1:], acc[1:] = dp.cpu().numpy(), ds.cpu().numpy(), da.cpu().numpy()
+        elif T > 0 and progress and "batched" not in low:
+            _run_with_progress(eng, lambda: eng.run(T, params[1:], stat[1:], acc[1:], sync=False), T, "Sampling %d chains" % N)
         elif T > 0:
             eng.run(T, params[1:], stat[1:], acc[1:])
         if prop["kind"] == _lib.PROP_DREAMZ:
             state = dict(eng.dreamz_state(), scaling=eng.proposal_state_scaling())
         else:
-            state = eng.proposal_state(want_am=prop["kind"] == _lib.PROP_AM)
+            state = LazyProposalState(eng.detach_proposal_state(), N, d, prop["kind"] == _lib.PROP_AM)
     finally:
         eng.close()
-    result = {"sampler": "MH", "n_chains": n_chains, "iterations": iterations + 1, "backend": "hip",
+    result = {"sampler": "MH", "n_chains": n_chains, "iterations": R + 1, "backend": "hip",
               "seed": seed, "proposal_state": state, "chain_offset": chain_offset}
+    if thin > 1:
+        result["thin"] = thin
+    recs = DeviceRecords(params, stat, acc)
+    model = posterior.model
     for i in range(n_chains):
-        result["chain_{}".format(i)] = DeviceChain(params[:, i], stat[:, i], acc[:, i], posterior.model)
+        result["chain_%d" % i] = DeviceChain(recs, i, model)
     return result
 
 
 def _sample_device_multilevel(plan, posteriors, iterations, n_chains, initial_parameters, subchain_length,
-                              subchain_lengths, randomize, store_coarse_chain, seed, device, chain_offset, aem=None):
-    """Delayed Acceptance (2 levels, result of sampler.py:406-439) and MLDA (>= 3 levels, :510-547) on the device."""
+                              subchain_lengths, randomize, store_coarse_chain, seed, device, chain_offset, aem=None, progress=False):
+    """Delayed Acceptance (2 levels, result of sampler.py:406-439) and MLDA (>= 3 levels, :510-547) on the device; the records of
+    every stored level stay in HBM (lazy DeviceChain views, as for single-level runs)."""
     from .engine import Engine
+    import torch
 
     lows, prop = plan
     nl = len(lows)
     d = lows[0]["prior_mean"].shape[0]
     if seed is None:
         seed = int(np.random.randint(0, 2 ** 31 - 1))
+    tdev = torch.device("cuda", device)
     eng = Engine(n_chains, d, seed=seed, device=device, chain_offset=chain_offset, n_levels=nl)
     try:
         if "prior_joint" in lows[0]:
@@ -461,30 +532,31 @@ def _sample_device_multilevel(plan, posteriors, iterations, n_chains, initial_pa
         eng.init(theta0)
         T, N = iterations, n_chains
         rows = eng.rows_per_level(T)
-        from .engine import pinned_empty
-
         outs = []
-        for k in range(nl):
-            if k < nl - 1 and not store_coarse_chain:
-                outs.append(None)
-                continue
-            extra = 1 if k == nl - 1 else 0  # only the finest chain carries the initial link
-            acc_k = pinned_empty((rows[k] + extra, N), dtype=np.uint8)
-            acc_k[:extra] = 1
-            outs.append((pinned_empty((rows[k] + extra, N, d)), pinned_empty((rows[k] + extra, N, 3)), acc_k))
+        with torch.cuda.device(tdev):
+            for k in range(nl):
+                if k < nl - 1 and not store_coarse_chain:
+                    outs.append(None)
+                    continue
+                extra = 1 if k == nl - 1 else 0  # only the finest chain carries the initial link
+                acc_k = torch.empty((rows[k] + extra, N), dtype=torch.uint8, device=tdev)
+                acc_k[:extra] = 1
+                outs.append((torch.empty((rows[k] + extra, N, d), dtype=torch.float64, device=tdev),
+                             torch.empty((rows[k] + extra, N, 3), dtype=torch.float64, device=tdev), acc_k))
         pf, sf, af = outs[nl - 1]
-        pf[0], sf[0] = eng.level_state(nl - 1)
+        eng.level_state_into(nl - 1, pf[0], sf[0])
         run_outs = [o if (o is None or k < nl - 1) else (o[0][1:], o[1][1:], o[2][1:]) for k, o in enumerate(outs)]
-        if T > 0:
+        host_models = any("batched" in low for low in lows)
+        if T > 0 and progress and not host_models:
+            _run_with_progress(eng, lambda: eng.run_levels(T, run_outs, sync=False), T, "Sampling %d chains" % N)
+        elif T > 0:
             eng.run_levels(T, run_outs)
     finally:
         eng.close()
+    recs = [None if o is None else DeviceRecords(*o) for o in outs]
 
     def chain_of(k, i):
-        if outs[k] is None:
-            return None
-        p, s_, a = outs[k]
-        return DeviceChain(p[:, i], s_[:, i], a[:, i], posteriors[k].model)
+        return None if recs[k] is None else DeviceChain(recs[k], i, posteriors[k].model)
 
     if nl == 2:
         result = {"sampler": "DA", "n_chains": n_chains, "iterations": iterations + 1, "subchain_length": subchain_length,

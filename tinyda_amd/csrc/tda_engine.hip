@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -107,16 +109,84 @@ void pack_fragments(const double* A, int rows, int cols, int dpad, std::vector<d
         }
 }
 
+// Device-memory pool: an engine holds ~1.2 GB of block buffers at BASELINE config 2, and tda.sample() creates and destroys
+// one engine per call.  hipMalloc / hipFree of that set cost 10-20 ms per call (hipFree synchronises the device), which is
+// as long as 1000 iterations of 4096 chains take.  Released buffers are therefore kept per (device, byte count) and handed
+// out again -- zeroed, as fresh allocations are -- up to TINYDA_POOL_GB (default 8) GiB; tda_release_cached_memory() returns
+// them to the driver, as does an allocation failure before it is reported.
+struct DevPool {
+  std::mutex mu;
+  std::multimap<std::pair<int, size_t>, void*> idle;
+  size_t held = 0, cap = 0;
+  bool cap_read = false;
+  size_t capacity() {
+    if (!cap_read) {
+      const char* v = getenv("TINYDA_POOL_GB");
+      cap = (size_t)((v ? atof(v) : 8.0) * 1073741824.0);
+      cap_read = true;
+    }
+    return cap;
+  }
+  void* take(int dev, size_t bytes) {
+    std::lock_guard<std::mutex> g(mu);
+    auto it = idle.find({dev, bytes});
+    if (it == idle.end()) return nullptr;
+    void* p = it->second;
+    idle.erase(it);
+    held -= bytes;
+    return p;
+  }
+  bool give(int dev, size_t bytes, void* p) {
+    std::lock_guard<std::mutex> g(mu);
+    if (bytes < (64u << 10) || held + bytes > capacity()) return false;  // small buffers: the runtime's own sub-allocator is fast
+    idle.insert({{dev, bytes}, p});
+    held += bytes;
+    return true;
+  }
+  size_t trim() {
+    std::lock_guard<std::mutex> g(mu);
+    const size_t was = held;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto& kv : idle) {
+      (void)hipSetDevice(kv.first.first);
+      (void)hipFree(kv.second);
+    }
+    (void)hipSetDevice(cur);
+    idle.clear();
+    held = 0;
+    return was;
+  }
+};
+DevPool g_pool;
+thread_local bool g_pool_accepting = false;
+
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  int dev = 0;
   int alloc(size_t count) {
     release();
     n = count;
     if (count == 0) return TDA_OK;
-    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
-    if (e != hipSuccess) return fail(TDA_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    const size_t bytes = count * sizeof(T);
+    (void)hipGetDevice(&dev);
+    if (void* q = g_pool.take(dev, bytes)) {
+      p = (T*)q;
+      hipError_t e = hipMemset(p, 0, bytes);  // what a fresh allocation holds
+      if (e != hipSuccess) return fail(TDA_ERR_HIP, "hipMemset(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+      return TDA_OK;
+    }
+    hipError_t e = hipMalloc((void**)&p, bytes);
+    if (e != hipSuccess && g_pool.trim() > 0) {
+      (void)hipGetLastError();
+      e = hipMalloc((void**)&p, bytes);
+    }
+    if (e != hipSuccess) {
+      p = nullptr;
+      return fail(TDA_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    }
     return TDA_OK;
   }
   int upload(const std::vector<T>& h) {
@@ -126,7 +196,9 @@ struct DevBuf {
     return TDA_OK;
   }
   void release() {
-    if (p) (void)hipFree(p);
+    // only buffers of an engine being destroyed go back to the pool: its streams have been synchronised by then, whereas a
+    // buffer replaced in the middle of a run may still be read by queued kernels (hipFree waits for them, the pool would not)
+    if (p && !(g_pool_accepting && g_pool.give(dev, n * sizeof(T), p))) (void)hipFree(p);
     p = nullptr;
     n = 0;
   }
@@ -308,6 +380,13 @@ struct tda_engine {
   // profiling
   bool profiling = false;
   std::vector<TimedLaunch> timed;
+
+  // records: only every `thin`-th iteration (those with (t + 1) % thin == 0, t = iterations before it) reaches the caller
+  int thin = 1;
+  // progress (tda_engine_set_progress): at the end of every block a one-workgroup kernel writes the iterations completed so far
+  // and the block's mean accept flag into page-locked host memory; tda_engine_get_progress reads it -- polled, never a sync
+  double* prog_h = nullptr;  // [0] iterations completed, [1] mean accept flag of the last block (-1: not recorded)
+  int64_t prog_queued = 0;   // iterations queued by run() so far (host side)
 };
 
 namespace {
@@ -726,10 +805,73 @@ static void host_chain_ranges(int64_t n, F f) {
   for (auto& th : pool) th.join();
 }
 
+namespace {
+// progress mark at the end of a block: mean of its accept flags and the iteration count, into device-visible host memory
+__global__ void k_progress_mark(const uint8_t* __restrict__ acc, int64_t count, double iters_total, double* __restrict__ out_h) {
+  __shared__ unsigned int part[256];
+  unsigned int sum = 0;
+  if (acc)
+    for (int64_t i = threadIdx.x; i < count; i += 256) sum += acc[i];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out_h[1] = acc ? (double)part[0] / (double)count : -1.0;
+    __threadfence_system();
+    out_h[0] = iters_total;
+  }
+}
+
+// rows src[(s0 + j * thin)][row_bytes] -> dst[j][row_bytes], j < nkeep (row_bytes a multiple of 8 or, for flags, any size)
+__global__ void k_thin_rows(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, int64_t row_bytes, int64_t s0, int thin, int64_t nkeep) {
+  const int64_t j = blockIdx.y;
+  if (j >= nkeep) return;
+  const uint8_t* sp = src + (size_t)(s0 + j * thin) * row_bytes;
+  uint8_t* dp = dst + (size_t)j * row_bytes;
+  if (((row_bytes | (int64_t)(uintptr_t)sp | (int64_t)(uintptr_t)dp) & 7) == 0) {
+    const int64_t n8 = row_bytes >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x)
+      reinterpret_cast<uint64_t*>(dp)[i] = reinterpret_cast<const uint64_t*>(sp)[i];
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_bytes; i += (int64_t)gridDim.x * blockDim.x) dp[i] = sp[i];
+  }
+}
+
+// records of this run() that reach the caller under thinning: iterations g in [t, t + n) with (g + 1) % thin == 0
+inline int64_t kept_records(int64_t t, int64_t n, int thin) { return thin <= 1 ? n : (t + n) / thin - t / thin; }
+
+// kept rows of one block buffer -> the caller's buffer (device: one gather launch; host: one copy per kept row on `cs`)
+int thin_out(tda_engine* e, void* dst, bool dst_dev, const void* blk, size_t row_bytes, int64_t s0, int64_t nkeep, hipStream_t cs) {
+  if (!dst || nkeep <= 0) return TDA_OK;
+  if (dst_dev) {
+    const unsigned gx = (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, (int64_t)(row_bytes / 8 + 255) / 256));
+    hipLaunchKernelGGL(k_thin_rows, dim3(gx, (unsigned)nkeep), dim3(256), 0, cs, (uint8_t*)dst, (const uint8_t*)blk, (int64_t)row_bytes, s0, e->thin, nkeep);
+    HIP_TRY(hipGetLastError());
+    return TDA_OK;
+  }
+  for (int64_t j = 0; j < nkeep; ++j)
+    HIP_TRY(hipMemcpyAsync((uint8_t*)dst + (size_t)j * row_bytes, (const uint8_t*)blk + (size_t)(s0 + j * e->thin) * row_bytes, row_bytes,
+                           hipMemcpyDeviceToHost, cs));
+  return TDA_OK;
+}
+
+// end of a block of S iterations: progress mark (when enabled)
+int progress_mark(tda_engine* e, int64_t S, const uint8_t* blk_acc, int64_t n_flags) {
+  e->prog_queued += S;
+  if (!e->prog_h) return TDA_OK;
+  hipLaunchKernelGGL(k_progress_mark, dim3(1), dim3(256), 0, e->stream, blk_acc, n_flags, (double)e->prog_queued, e->prog_h);
+  HIP_TRY(hipGetLastError());
+  return TDA_OK;
+}
+}  // namespace
+
 extern "C" {
 
 const char* tda_last_error(void) { return g_err.c_str(); }
-const char* tda_version(void) { return "tinyda_amd 0.1 (gfx950)"; }
+const char* tda_version(void) { return "tinyda_amd 0.3 (gfx950)"; }
 
 int tda_engine_create(const tda_config* cfg, tda_engine** out) {
   if (!cfg || !out) return fail(TDA_ERR_INVALID, "null argument");
@@ -800,8 +942,14 @@ void tda_engine_destroy(tda_engine* e) {
     }
   }
   if (e->own_stream) (void)hipStreamDestroy(e->stream);
+  if (e->prog_h) (void)hipHostFree(e->prog_h);
+  if (e->dist_ranks) e->arch.release();  // exported to the peers as an IPC handle: not a candidate for reuse
+  g_pool_accepting = true;  // every stream of the engine is idle: its buffers may serve the next engine
   delete e;
+  g_pool_accepting = false;
 }
+
+int64_t tda_release_cached_memory(void) { return (int64_t)g_pool.trim(); }
 
 int tda_engine_set_prior(tda_engine* e, const double* mean, const double* cov) {
   if (!e || !mean || !cov) return fail(TDA_ERR_INVALID, "null argument");
@@ -2137,12 +2285,13 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
   if (e->pp.kind == TDA_PROP_AM) {
     e->L_shared = false;
     if ((rc = e->Lk.alloc((size_t)NP * DP * DP))) return rc;
-    std::vector<double> rep((size_t)std::min<int64_t>(NP, 256) * DP * DP);
-    for (size_t i = 0; i < rep.size(); ++i) rep[i] = Lk[i % ((size_t)DP * DP)];
-    for (int64_t c0 = 0; c0 < NP; c0 += 256) {
-      const int64_t n = std::min<int64_t>(256, NP - c0);
-      HIP_TRY(hipMemcpy(e->Lk.p + (size_t)c0 * DP * DP, rep.data(), (size_t)n * DP * DP * sizeof(double), hipMemcpyHostToDevice));
-    }
+    // one factor over PCIe, replicated to every chain by doubling device copies (the 128 MiB of 4096 copies took 10 ms from
+    // pageable host memory)
+    HIP_TRY(hipMemcpyAsync(e->Lk.p, Lk.data(), (size_t)DP * DP * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    for (int64_t have = 1; have < NP; have *= 2)
+      HIP_TRY(hipMemcpyAsync(e->Lk.p + (size_t)have * DP * DP, e->Lk.p, (size_t)std::min<int64_t>(have, NP - have) * DP * DP * sizeof(double),
+                             hipMemcpyDeviceToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));  // (Lk is a local: the first copy must have left the host before it goes)
     // RecursiveSampleMoments(mu0 = theta0, sigma0 = 0) (proposal.py:495-500)
     if ((rc = e->am_mu.alloc((size_t)NP * DP))) return rc;
     const size_t nsig = (size_t)NP * am_tiles_rt(DP) * 256;  // lower 16x16 tiles in MFMA C/D layout (k_adapt)
@@ -2469,10 +2618,12 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     return fail(TDA_ERR_INVALID, "replay buffer holds %lld steps, %lld requested", (long long)(e->rep_steps - e->rep_pos), (long long)n_iter);
   if (e->exp_steps && e->exp_pos + n_iter > e->exp_steps)
     return fail(TDA_ERR_INVALID, "export buffer too small");
-  if (int crc = check_out_capacity(out, 0, n_iter, e->N, e->d)) return crc;
+  const int thin = e->thin;
+  if (int crc = check_out_capacity(out, 0, kept_records(e->t, n_iter, thin), e->N, e->d)) return crc;
 
   const int d = e->d;
   const int64_t N = e->N, NP = e->NP;
+  int64_t out_row = 0;  // thinning: next row of the caller's buffers
   double* o_params = out ? out->params : nullptr;
   double* o_stats = out ? out->stats : nullptr;
   uint8_t* o_acc = out ? out->accepted : nullptr;
@@ -2657,9 +2808,9 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     double* const blk_stats = (async_host && (blk & 1)) ? e->rec_stats2.p : e->rec_stats.p;
     uint8_t* const blk_acc = (async_host && (blk & 1)) ? e->rec_acc2.p : e->rec_acc.p;
     if (async_host && blk >= 2) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_cp[blk & 1], 0));  // buffer set free again
-    sa.rec_params = p_dev ? o_params + (size_t)done * N * d : ((o_params || is_am) ? blk_params : nullptr);
-    sa.rec_stats = s_dev ? o_stats + (size_t)done * N * 3 : (o_stats ? blk_stats : nullptr);
-    sa.rec_acc = a_dev ? o_acc + (size_t)done * N : (o_acc ? blk_acc : nullptr);
+    sa.rec_params = (p_dev && thin == 1) ? o_params + (size_t)done * N * d : ((o_params || is_am) ? blk_params : nullptr);
+    sa.rec_stats = (s_dev && thin == 1) ? o_stats + (size_t)done * N * 3 : (o_stats ? blk_stats : nullptr);
+    sa.rec_acc = (a_dev && thin == 1) ? o_acc + (size_t)done * N : ((o_acc || (e->prog_h && thin > 1)) ? blk_acc : nullptr);
     const bool user_stepwise = lv.model == MODEL_USER && (lv.noise_kind == TDA_NOISE_DENSE || e->pp.kind == TDA_PROP_INDEPENDENCE || e->pp.kind == TDA_PROP_OWCN);
     if (lv.model == MODEL_CALLBACK || user_stepwise) {  // (the fused source-model kernel knows GRW / pCN steps and iso / diag noise)
       ExtArgs xa{};
@@ -2753,9 +2904,27 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     HIP_TRY(hipGetLastError());
     if (boundary && adaptive) e->k_adapt += 1;
 
-    // ---- host-side records ----
+    // ---- progress mark; thinned / host-side records ----
     int rc;
-    if (async_host) {
+    if ((rc = progress_mark(e, S, sa.rec_acc, S * N))) return rc;
+    if (thin > 1) {
+      // kept iterations of this block: s with (t + s + 1) % thin == 0
+      const int64_t s0 = (thin - 1 - (e->t % thin)) % thin, nkeep = s0 < S ? (S - s0 + thin - 1) / thin : 0;
+      hipStream_t cs = e->stream;
+      if (async_host) {
+        HIP_TRY(hipEventRecord(e->ev_rec[blk & 1], e->stream));
+        HIP_TRY(hipStreamWaitEvent(e->copy_stream, e->ev_rec[blk & 1], 0));
+        cs = e->copy_stream;
+      }
+      // (device destinations are gathered on the main stream, host ones copied row by row on the copy stream when page-locked)
+      if ((rc = thin_out(e, o_params ? o_params + (size_t)out_row * N * d : nullptr, p_dev, blk_params, (size_t)N * d * sizeof(double), s0, nkeep, p_dev ? e->stream : cs)) ||
+          (rc = thin_out(e, o_stats ? o_stats + (size_t)out_row * N * 3 : nullptr, s_dev, blk_stats, (size_t)N * 3 * sizeof(double), s0, nkeep, s_dev ? e->stream : cs)) ||
+          (rc = thin_out(e, o_acc ? o_acc + (size_t)out_row * N : nullptr, a_dev, blk_acc, (size_t)N, s0, nkeep, a_dev ? e->stream : cs)))
+        return rc;
+      if (async_host) HIP_TRY(hipEventRecord(e->ev_cp[blk & 1], e->copy_stream));
+      else if (any_host) HIP_TRY(hipStreamSynchronize(e->stream));  // block buffers are reused next iteration
+      out_row += nkeep;
+    } else if (async_host) {
       const int i = (int)(blk & 1);
       HIP_TRY(hipEventRecord(e->ev_rec[i], e->stream));
       HIP_TRY(hipStreamWaitEvent(e->copy_stream, e->ev_rec[i], 0));
@@ -3688,6 +3857,7 @@ static int run_multilevel(tda_engine* e, int64_t n_fine, const tda_outputs* outs
       if (host_copies) HIP_TRY(hipStreamSynchronize(e->stream));
     }
     blk_ix += 1;
+    if (int prc = progress_mark(e, nblk[nl - 1], nullptr, 0)) return prc;  // progress counts finest-level iterations (chain.py:343-351)
 
     int64_t appended = 0;
     for (int k = 0; k < nl; ++k) {
@@ -4096,6 +4266,7 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
       host_copies = true;
     }
     if (host_copies) HIP_TRY(hipStreamSynchronize(e->stream));
+    if ((rc = progress_mark(e, S, nullptr, 0))) return rc;
     e->t += S;
     done += S;
     blk += 1;
@@ -4117,22 +4288,64 @@ int tda_engine_sync(tda_engine* e) {
   return TDA_OK;
 }
 
-int tda_engine_get_proposal_state(tda_engine* e, double* scaling, double* C, double* am_mu, double* am_sigma,
-                                  int64_t* counters) {
-  if (!e || !e->inited) return fail(TDA_ERR_STATE, "engine not initialised");
+int tda_engine_set_record_thinning(tda_engine* e, int32_t thin) {
+  if (!e) return fail(TDA_ERR_INVALID, "null engine");
+  if (thin < 1) return fail(TDA_ERR_INVALID, "thin must be >= 1");
+  if (thin > 1 && (e->nlev > 1 || e->is_dreamz)) return fail(TDA_ERR_UNSUPPORTED, "record thinning is implemented for single-level GRW / pCN / AM / MALA runs");
+  e->thin = thin;
+  return TDA_OK;
+}
+
+int tda_engine_set_progress(tda_engine* e, int enable) {
+  if (!e) return fail(TDA_ERR_INVALID, "null engine");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  const int d = e->d, DP = e->DP;
-  const int64_t N = e->N, NP = e->NP;
+  if (enable && !e->prog_h) {
+    HIP_TRY(hipHostMalloc((void**)&e->prog_h, 2 * sizeof(double), hipHostMallocDefault));
+    e->prog_h[0] = 0.0;
+    e->prog_h[1] = -1.0;
+    e->prog_queued = 0;
+  } else if (!enable && e->prog_h) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipHostFree(e->prog_h));
+    e->prog_h = nullptr;
+  }
+  return TDA_OK;
+}
+
+int tda_engine_get_progress(tda_engine* e, int64_t* iterations_done, int64_t* iterations_queued, double* accept_rate) {
+  if (!e) return fail(TDA_ERR_INVALID, "null engine");
+  if (!e->prog_h) return fail(TDA_ERR_STATE, "progress reporting is off (tda_engine_set_progress)");
+  const volatile double* h = e->prog_h;  // written by the GPU at block ends; no HIP call, no synchronisation
+  const double done = h[0];
+  if (iterations_done) *iterations_done = (int64_t)done;
+  if (accept_rate) *accept_rate = h[1];
+  if (iterations_queued) *iterations_queued = e->prog_queued;
+  return TDA_OK;
+}
+
+}  // extern "C"
+
+namespace {
+// what tda_engine_get_proposal_state reads: the engine's own buffers, or the ones a snapshot took over from it
+struct PropView {
+  int device = 0, d = 0, DP = 0, kind = 0;
+  int64_t N = 0, NP = 0, t = 0, k = 0;
+  bool L_shared = true;
+  const double *Lk = nullptr, *am_mu = nullptr, *am_sigma = nullptr, *scaling = nullptr;
+};
+
+int read_proposal_view(const PropView& v, double* scaling, double* C, double* am_mu, double* am_sigma, int64_t* counters) {
+  const int d = v.d, DP = v.DP;
+  const int64_t N = v.N, NP = v.NP;
   if (scaling) {
     std::vector<double> h(NP);
-    HIP_TRY(hipMemcpy(h.data(), e->scaling.p, NP * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h.data(), v.scaling, NP * sizeof(double), hipMemcpyDeviceToHost));
     std::copy(h.begin(), h.begin() + N, scaling);
   }
   if (C) {  // C = L L^T from the factor in use
-    const int64_t nL = e->L_shared ? 1 : NP;
+    const int64_t nL = v.L_shared ? 1 : NP;
     std::vector<double> h((size_t)nL * DP * DP);
-    HIP_TRY(hipMemcpy(h.data(), e->Lk.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h.data(), v.Lk, h.size() * sizeof(double), hipMemcpyDeviceToHost));
     // C = L L^T as d rank-1 updates per chain (the innermost loop runs over contiguous memory and vectorises; every
     // element still accumulates its products in ascending k); a factor shared by all chains is multiplied out once
     auto unpack = [&](int64_t c0, int64_t c1) {
@@ -4153,7 +4366,7 @@ int tda_engine_get_proposal_state(tda_engine* e, double* scaling, double* C, dou
           for (int j = 0; j <= i; ++j) Cc[(size_t)i * d + j] = Cc[(size_t)j * d + i] = acc[(size_t)i * d + j];
       }
     };
-    if (e->L_shared) {
+    if (v.L_shared) {
       unpack(0, 1);
       for (int64_t c = 1; c < N; ++c) std::copy(C, C + (size_t)d * d, C + (size_t)c * d * d);
     } else {
@@ -4161,17 +4374,17 @@ int tda_engine_get_proposal_state(tda_engine* e, double* scaling, double* C, dou
     }
   }
   if (am_mu || am_sigma) {
-    if (e->pp.kind != TDA_PROP_AM) return fail(TDA_ERR_STATE, "proposal has no running moments");
+    if (v.kind != TDA_PROP_AM) return fail(TDA_ERR_STATE, "proposal has no running moments");
     if (am_mu) {
       std::vector<double> h((size_t)NP * DP);
-      HIP_TRY(hipMemcpy(h.data(), e->am_mu.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(h.data(), v.am_mu, h.size() * sizeof(double), hipMemcpyDeviceToHost));
       for (int64_t c = 0; c < N; ++c)
         for (int j = 0; j < d; ++j) am_mu[(size_t)c * d + j] = h[(size_t)c * DP + j];
     }
     if (am_sigma) {  // dense symmetric matrices from the lower-tile storage
       const size_t per = (size_t)am_tiles_rt(DP) * 256;
       std::vector<double> h((size_t)N * per);
-      HIP_TRY(hipMemcpy(h.data(), e->am_sigma.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(h.data(), v.am_sigma, h.size() * sizeof(double), hipMemcpyDeviceToHost));
       host_chain_ranges(N, [&](int64_t c0, int64_t c1) {
         for (int64_t c = c0; c < c1; ++c) {
           const double* f = h.data() + (size_t)c * per;
@@ -4183,10 +4396,84 @@ int tda_engine_get_proposal_state(tda_engine* e, double* scaling, double* C, dou
     }
   }
   if (counters) {
-    counters[0] = e->t;
-    counters[1] = e->k_adapt;
+    counters[0] = v.t;
+    counters[1] = v.k;
   }
   return TDA_OK;
+}
+
+PropView view_of(const tda_engine* e) {
+  PropView v;
+  v.device = e->cfg.device;
+  v.d = e->d;
+  v.DP = e->DP;
+  v.kind = e->is_dreamz ? TDA_PROP_DREAMZ : e->pp.kind;
+  v.N = e->N;
+  v.NP = e->NP;
+  v.t = e->t;
+  v.k = e->k_adapt;
+  v.L_shared = e->L_shared;
+  v.Lk = e->Lk.p;
+  v.am_mu = e->am_mu.p;
+  v.am_sigma = e->am_sigma.p;
+  v.scaling = e->scaling.p;
+  return v;
+}
+}  // namespace
+
+// the proposal state of an engine that is about to be destroyed: the buffers themselves, taken over without a copy
+struct tda_proposal_snapshot {
+  PropView v;
+  DevBuf<double> Lk, am_mu, am_sigma, scaling;
+};
+
+extern "C" {
+
+int tda_engine_get_proposal_state(tda_engine* e, double* scaling, double* C, double* am_mu, double* am_sigma,
+                                  int64_t* counters) {
+  if (!e || !e->inited) return fail(TDA_ERR_STATE, "engine not initialised");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (C && !e->Lk.p) return fail(TDA_ERR_STATE, "this proposal has no covariance factor");
+  return read_proposal_view(view_of(e), scaling, C, am_mu, am_sigma, counters);
+}
+
+int tda_engine_detach_proposal_state(tda_engine* e, tda_proposal_snapshot** out) {
+  if (!e || !e->inited || !out) return fail(TDA_ERR_STATE, "engine not initialised");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (e->rng_stream) HIP_TRY(hipStreamSynchronize(e->rng_stream));
+  tda_proposal_snapshot* s = new tda_proposal_snapshot();
+  s->v = view_of(e);
+  auto take = [](DevBuf<double>& dst, DevBuf<double>& src) {
+    dst.p = src.p;
+    dst.n = src.n;
+    dst.dev = src.dev;
+    src.p = nullptr;
+    src.n = 0;
+  };
+  take(s->Lk, e->Lk);
+  take(s->am_mu, e->am_mu);
+  take(s->am_sigma, e->am_sigma);
+  take(s->scaling, e->scaling);
+  e->inited = false;  // the engine has given its proposal away: only tda_engine_destroy is left for it
+  *out = s;
+  return TDA_OK;
+}
+
+int tda_proposal_snapshot_read(tda_proposal_snapshot* s, double* scaling, double* C, double* am_mu, double* am_sigma, int64_t* counters) {
+  if (!s) return fail(TDA_ERR_INVALID, "null snapshot");
+  HIP_TRY(hipSetDevice(s->v.device));
+  if (C && !s->v.Lk) return fail(TDA_ERR_STATE, "this proposal has no covariance factor");
+  return read_proposal_view(s->v, scaling, C, am_mu, am_sigma, counters);
+}
+
+void tda_proposal_snapshot_destroy(tda_proposal_snapshot* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->v.device);
+  g_pool_accepting = true;  // nothing is queued on these buffers (detach synchronised the engine's streams)
+  delete s;
+  g_pool_accepting = false;
 }
 
 int tda_engine_get_flags(tda_engine* e, int32_t* flags) {

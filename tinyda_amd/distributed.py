@@ -140,7 +140,12 @@ def run_shared_dream(engine, n_iterations, sync_every, params=None, stats=None, 
             # ONE call: the engine cuts the run into `sync_every`-step blocks itself (tda_engine_set_proposal_dreamz), and a
             # call per block from here left the GPU idle a third of the time (C4: 29 us of host work per 117 us block)
             engine.set_archive_auto_append(True)
-            if getattr(engine, "_dz", {}).get("sync_every") == sync_every:
+            dz = getattr(engine, "_dz", {})
+            # the engine restarts full `sync_every` blocks after an adaptation boundary; the exchange below (and the N-rank
+            # path) keeps its exchange points at call-relative multiples of `sync_every`.  The two coincide -- and the result
+            # stays independent of the sharding -- when nothing adapts or the period is a multiple of the interval
+            aligned = not dz.get("adaptive") or dz.get("period", 0) % sync_every == 0
+            if dz.get("sync_every") == sync_every and aligned:
                 engine.run(n_iterations, params, stats, accepted)
                 return
             for done in range(0, n_iterations, sync_every):  # an interval other than the engine's own: block by block
@@ -150,15 +155,20 @@ def run_shared_dream(engine, n_iterations, sync_every, params=None, stats=None, 
             return
         engine.set_archive_auto_append(False)
         done = 0
-        while done < n_iterations:
-            k = min(sync_every, n_iterations - done)
-            sl = slice(done, done + k)
-            engine.run(k, None if params is None else params[sl], None if stats is None else stats[sl],
-                       None if accepted is None else accepted[sl])
-            buf = torch.empty((k, N, d), dtype=torch.float64, device=torch.device("cuda", engine.device))
-            engine.archive_take(buf)
-            engine.archive_append(gather_archive_rows(buf))
-            done += k
+        # archive_take queues its copy on the engine's stream: the collective must be ordered behind it, so it is issued with
+        # that stream current (an engine on the default stream: legacy null-stream ordering does the same)
+        with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+            while done < n_iterations:
+                k = min(sync_every, n_iterations - done)
+                sl = slice(done, done + k)
+                engine.run(k, None if params is None else params[sl], None if stats is None else stats[sl],
+                           None if accepted is None else accepted[sl])
+                buf = torch.empty((k, N, d), dtype=torch.float64, device=torch.device("cuda", engine.device))
+                engine.archive_take(buf)
+                if stream is None:
+                    engine.sync()  # no torch stream to order the collective behind: wait for the copy on the host
+                engine.archive_append(gather_archive_rows(buf))
+                done += k
         return
 
     # ---- overlapped exchange, fixed lag of one block ----
@@ -214,9 +224,19 @@ def setup_peer_archive(engine):
         engine.set_archive_peers(1, 0, pointers=[engine.archive_pointer()])
         return 1
     world, rank = dist.get_world_size(), dist.get_rank()
-    handles = [None] * world
-    dist.all_gather_object(handles, engine.archive_ipc_handle())
-    engine.set_archive_peers(world, rank, handles=handles)
+    # k_dreamz_draw<., true> maps a global archive row to (owner, local row) by dividing by ONE chain count, and reads the owner's
+    # segment up to ONE capacity: every rank must hold the same number of chains (a multiple of the 16-chain tile), dimension,
+    # M0 and segment capacity.  Checked on every rank from the same gathered list, BEFORE any rank maps a segment or enters a
+    # barrier, so a mismatch raises everywhere instead of hanging the ranks that happened to pass a local check.
+    dz = getattr(engine, "_dz", {})
+    mine = (engine.n_chains, engine.dim, dz.get("M0"), dz.get("capacity"))
+    entries = [None] * world
+    dist.all_gather_object(entries, (mine, engine.archive_ipc_handle()))
+    shapes = [e[0] for e in entries]
+    if any(sh != shapes[0] for sh in shapes) or shapes[0][0] % 16 != 0:
+        raise ValueError("distributed DREAM archive: every rank needs the same (n_chains, dim, M0, capacity) and n_chains a multiple of 16; "
+                         "got %s" % (shapes,))
+    engine.set_archive_peers(world, rank, handles=[e[1] for e in entries])
     return world
 
 
@@ -266,7 +286,7 @@ def run_peer_dream(engine, n_iterations, sync_every, params=None, stats=None, ac
             work.wait()  # orders the current (= the engine's) stream behind the collective, no host wait
         engine.archive_publish(total)
 
-    done, t = 0, getattr(engine, "_peer_t", 0)  # steps this driver has run on the engine before (adaptation boundaries count from 0)
+    done, t = 0, engine.counters()[0]  # steps the engine has taken so far, whoever drove them (adaptation boundaries count from 0)
     with ctx:
         while done < n_iterations:
             k = min(sync_every, n_iterations - done)
@@ -303,7 +323,6 @@ def run_peer_dream(engine, n_iterations, sync_every, params=None, stats=None, ac
         while in_flight:  # the archive ends complete
             publish_oldest()
     engine.sync()
-    engine._peer_t = t
 
 
 class PooledAdaptiveMetropolis:

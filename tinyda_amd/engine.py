@@ -38,6 +38,32 @@ def pinned_empty(shape, dtype=np.float64):
     return np.empty(shape, dtype=dtype)
 
 
+class ProposalSnapshot:
+    """Proposal state taken over from a finished engine (tda_engine_detach_proposal_state): device buffers, read on demand."""
+
+    def __init__(self, lib, handle):
+        self.lib, self.h = lib, handle
+
+    def read(self, n_chains, dim, want_am=False):
+        N, d = n_chains, dim
+        sc, Cm, cnt = np.empty(N), np.empty((N, d, d)), np.zeros(2, dtype=np.int64)
+        mu = np.empty((N, d)) if want_am else None
+        sg = np.empty((N, d, d)) if want_am else None
+        _check(self.lib.tda_proposal_snapshot_read(self.h, _ptr(sc), _ptr(Cm), _ptr(mu), _ptr(sg), _ptr(cnt)), self.lib)
+        return dict(scaling=sc, C=Cm, am_mu=mu, am_sigma=sg, t=int(cnt[0]), k=int(cnt[1]))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tda_proposal_snapshot_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Engine:
     """One many-chain MH engine on one GPU (one per process under torch.distributed)."""
 
@@ -153,7 +179,8 @@ class Engine:
         cap = int(capacity if capacity is not None else M0)
         p = _lib.tda_dreamz_params(C.sizeof(_lib.tda_dreamz_params), M0, delta, nCR, b, b_star, int(adaptive), period, gamma,
                                    int(shared), sync_every, cap)
-        self._dz = dict(M0=M0, delta=delta, nCR=nCR, shared=bool(shared), sync_every=int(sync_every))
+        self._dz = dict(M0=M0, delta=delta, nCR=nCR, shared=bool(shared), sync_every=int(sync_every), adaptive=bool(adaptive),
+                        period=int(period), capacity=cap)
         self._ck(self.lib.tda_engine_set_proposal_dreamz(self.h, C.byref(p)))
 
     def set_archive(self, Z0=None):
@@ -261,9 +288,12 @@ class Engine:
     def set_state(self, blob):
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         self._ck(self.lib.tda_engine_set_state(self.h, _ptr(blob), blob.size))
-        # distributed.run_peer_dream counts the engine's steps to find the adaptation boundaries: the first item of a blob is the
-        # engine's iteration counter (16-byte header, 8-byte item size, then the int64; tda_engine.hip enumerate_state)
-        self._peer_t = int(blob[24:32].view(np.int64)[0])
+
+    def counters(self):
+        """(t, k): adapt() calls so far = steps taken (proposal.py:228, :509) and the diminishing-adaptation counter, from the engine"""
+        cnt = np.zeros(2, dtype=np.int64)
+        self._ck(self.lib.tda_engine_get_proposal_state(self.h, None, None, None, None, _ptr(cnt)))
+        return int(cnt[0]), int(cnt[1])
 
     def set_error_model(self, kind):
         code = {None: 0, "state-independent": 1, "state-dependent": 2, "state-independent-diagonal": 3}[kind]
@@ -374,6 +404,33 @@ class Engine:
 
     def sync(self):
         self._ck(self.lib.tda_engine_sync(self.h))
+
+    def set_record_thinning(self, thin):
+        """only iterations with (t + 1) % thin == 0 reach the record buffers (a run of n from t = 0 gives n // thin records)"""
+        self._ck(self.lib.tda_engine_set_record_thinning(self.h, int(thin)))
+
+    def set_progress(self, on=True):
+        self._ck(self.lib.tda_engine_set_progress(self.h, int(on)))
+
+    def progress(self):
+        """(iterations completed on the device, iterations queued, mean accept flag of the last completed block or -1): a read of
+        page-locked memory, no synchronisation -- callable while run(sync=False) work is in flight"""
+        done, queued, rate = C.c_int64(0), C.c_int64(0), C.c_double(-1.0)
+        self._ck(self.lib.tda_engine_get_progress(self.h, C.byref(done), C.byref(queued), C.byref(rate)))
+        return done.value, queued.value, rate.value
+
+    def current_into(self, theta, stats):
+        """current states into caller arrays / DEVICE tensors ([chains, dim], [chains, 3])"""
+        self._ck(self.lib.tda_engine_get_current(self.h, _ptr(theta), _ptr(stats)))
+
+    def level_state_into(self, level, theta, stats):
+        self._ck(self.lib.tda_engine_get_level_state(self.h, level, _ptr(theta), _ptr(stats)))
+
+    def detach_proposal_state(self):
+        """hand the proposal buffers to a ProposalSnapshot (no copy); the engine can only be closed afterwards"""
+        h = C.c_void_p()
+        self._ck(self.lib.tda_engine_detach_proposal_state(self.h, C.byref(h)))
+        return ProposalSnapshot(self.lib, h)
 
     def current(self):
         th, st = np.empty((self.n_chains, self.dim)), np.empty((self.n_chains, 3))

@@ -22,8 +22,24 @@ def _attribute_rows(chain, attribute, burnin):
     return np.array([getattr(l, attribute) for l in chain[burnin:]])
 
 
+def _bulk_rows(chains, attribute, burnin):
+    """All chains of a device result at once: when every value is an untouched DeviceChain over the SAME device records, chain i
+    being column i, the history crosses PCIe in one chunked pass (DeviceRecords.all_chains_host) instead of one strided gather
+    per chain.  Returns [n_chains, rows, width] or None (anything else: chain by chain)."""
+    first = chains[0]
+    if attribute not in ("parameters", "stats") or not isinstance(first, DeviceChain) or first._records is None or burnin < 0:
+        return None
+    recs = first._records
+    if recs.n_chains != len(chains):
+        return None
+    for i, c in enumerate(chains):
+        if not isinstance(c, DeviceChain) or c._records is not recs or c._chain != i or c._rows != slice(None) or c._cache:
+            return None
+    return recs.all_chains_host(attribute, start=burnin)
+
+
 def get_samples(chain, attribute="parameters", level="fine", burnin=0):
-    """Result dict of sample() -> per-chain (iterations - burnin, dim) arrays keyed chain_i."""
+    """Result dict of sample() -> per-chain (iterations - burnin, dim) arrays keyed chain_i (diagnostics.py:114-209)."""
     out = {"sampler": chain["sampler"], "n_chains": chain["n_chains"], "attribute": attribute}
     if chain["sampler"] == "MH":
         key = "chain_{}"
@@ -37,8 +53,10 @@ def get_samples(chain, attribute="parameters", level="fine", burnin=0):
         key = "chain_l" + str(level) + "_{}"
     else:
         raise ValueError("unknown sampler %r" % chain["sampler"])
+    chains = [chain[key.format(i)] for i in range(chain["n_chains"])]
+    bulk = _bulk_rows(chains, attribute, burnin)
     for i in range(chain["n_chains"]):
-        rows = _attribute_rows(chain[key.format(i)], attribute, burnin)
+        rows = bulk[i] if bulk is not None else _attribute_rows(chains[i], attribute, burnin)
         out["chain_{}".format(i)] = rows[..., np.newaxis] if rows.ndim == 1 else rows
     out["iterations"] = out["chain_0"].shape[0]
     out["dimension"] = out["chain_0"].shape[1]
