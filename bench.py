@@ -53,6 +53,9 @@ def parse_args():
     ap.add_argument("--ess-iterations", type=int, default=20000,
                     help="length of the separate stationary window ESS/s is measured on (0 = only the timed window)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help="internal: run only the CPU legs and print their JSON")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="allow --gpus N with fewer than N devices: every rank on cuda:0 over gloo (same as TINYDA_BENCH_ONE_GPU=1)")
     ap.add_argument("--no-ess", action="store_true")
     ap.add_argument("--extras", action="store_true", help="side measurements (other proposals / extensions), never the headline")
     return ap.parse_args()
@@ -157,23 +160,62 @@ def cpu_baseline(A, y, target_seconds=12.0):
     return out
 
 
+CPU_BASELINE_CAP_S = 75.0  # wall-clock cap of the CPU legs (child process; they take ~12 + ~6 s when healthy)
+
+
+def cpu_baseline_capped():
+    """The CPU legs in a CHILD process killed at CPU_BASELINE_CAP_S: a hung OpenMP run or a host with an odd thread count must
+    cost the bench line its `cpu_baseline`, not the GPU result that is already measured.  The child never
+    touches the GPU (it loads oracle/_build/libtda_cpu.so only)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child"]
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=float(os.environ.get("TINYDA_CPU_BASELINE_CAP_S", CPU_BASELINE_CAP_S)),
+                           env=env, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        return None, "timeout: the CPU baseline child exceeded its wall-clock cap and was killed"
+    for ln in reversed(r.stdout.splitlines()):
+        if ln.startswith("{"):
+            return json.loads(ln), None
+    return None, "child failed (rc %d): %s" % (r.returncode, r.stderr[-500:])
+
+
+def kernel_source_blob():
+    """git blob hash of the file that defines the dominant kernel (tda_kernels_mh.h: k_mh_steps), computed without git"""
+    import hashlib
+
+    data = open(os.path.join(ROOT, "tinyda_amd", "csrc", "tda_kernels_mh.h"), "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
 def latest_pmc_traffic():
-    """HBM bytes per k_mh_steps launch from the newest committed PMC pass (tools/pmc_traffic.sh), or None"""
+    """(file, HBM bytes per k_mh_steps launch, stale) from the newest committed PMC pass (tools/pmc_traffic.sh).  The PMC passes
+    are separate profiler runs, so `traffic` is a committed measurement, not a live one: the file records the git blob of the
+    kernel source it was taken on, and `stale` says whether the source has changed since (True also when the file predates the
+    stamp)."""
     pdir = os.path.join(ROOT, "profiles")
     best = None
     try:
         for f in sorted(os.listdir(pdir)):
             if f.endswith("pmc_traffic.json"):
-                v = json.load(open(os.path.join(pdir, f))).get("k_mh_steps_hbm_bytes_per_launch")
+                j = json.load(open(os.path.join(pdir, f)))
+                v = j.get("k_mh_steps_hbm_bytes_per_launch")
                 if v:
-                    best = (f, v)
+                    best = (f, v, j.get("kernel_source_blob") != kernel_source_blob())
     except Exception:
-        return None, None
-    return best if best else (None, None)
+        return None, None, None
+    return best if best else (None, None, None)
 
 
 def main():
     args = parse_args()
+    if args.cpu_baseline_child:  # the CPU legs alone (cpu_baseline_capped): no torch, no GPU
+        A, _, y = c2_problem()
+        print(json.dumps(cpu_baseline(A, y)), flush=True)
+        return
+    if args.rehearse_on_one_gpu:
+        os.environ["TINYDA_BENCH_ONE_GPU"] = "1"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
 
@@ -186,6 +228,11 @@ def main():
 
     # TINYDA_BENCH_ONE_GPU=1 (rehearsing the N > 1 code path on a one-GPU box): every rank on cuda:0, gloo instead of RCCL
     one_gpu = os.environ.get("TINYDA_BENCH_ONE_GPU") == "1"
+    if args.gpus > torch.cuda.device_count() and not one_gpu:
+        # N ranks on fewer than N devices would time oversubscribed GPUs and print it as an N-GPU number: refused unless the
+        # rehearsal switch says that is the point (device_count() does not initialise the GPU)
+        raise SystemExit("--gpus %d but only %d device(s) visible: refusing to report a multi-GPU figure (rehearse the N > 1 code "
+                         "path with --rehearse-on-one-gpu / TINYDA_BENCH_ONE_GPU=1)" % (args.gpus, torch.cuda.device_count()))
     rank, local_rank, world = tdist.init_process_group("gloo" if one_gpu else None)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
@@ -285,13 +332,14 @@ def main():
             ms_st, n_st = kern["k_mh_steps"]
             avg_launch_s = ms_st * 1e-3 / max(n_st, 1)
             evals_per_launch = ev_rank / max(n_st, 1)
-            pmc_file, traffic = latest_pmc_traffic()
+            pmc_file, traffic, stale = latest_pmc_traffic()
             if traffic is not None and abs(evals_per_launch - PERIOD * CHAINS_PER_GPU) > 0.5:
                 traffic = traffic * evals_per_launch / (PERIOD * CHAINS_PER_GPU)  # PMC passes are collected on 100-step launches of 4096 chains
             achieved = FLOPS_PER_EVAL * evals_per_launch / avg_launch_s
             rate_gpu = ev_rank / dt
             out["roofline"] = {"kernel": "k_mh_steps", "bound": "mfma", "achieved": achieved / 1e12, "peak": FP64_MFMA_PEAK / 1e12,
                                "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK, "traffic": traffic, "traffic_source": pmc_file,
+                               "traffic_stale": stale,
                                "flops_per_eval": FLOPS_PER_EVAL, "evals_per_launch": evals_per_launch,
                                "algorithmic_hbm_bytes_per_launch": BYTES_PER_EVAL_STEPS * evals_per_launch,
                                "avg_launch_ms": avg_launch_s * 1e3,
@@ -315,10 +363,15 @@ def main():
             out["extras_error"] = repr(exc)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(A, y)
-            except Exception as exc:
-                out["cpu_baseline_error"] = repr(exc)
+            # the GPU result is complete: keep it on stderr in case anything below goes wrong (stdout carries ONE line, at the end)
+            sys.stderr.write("[bench] GPU part done: %.4g %s, ms_per_step %.4f; CPU baseline legs follow (capped at %.0f s)\n"
+                             % (out["value"], out["unit"], out["ms_per_step"], CPU_BASELINE_CAP_S))
+            sys.stderr.flush()
+            cb, err = cpu_baseline_capped()
+            if cb is not None:
+                out["cpu_baseline"] = cb
+            else:
+                out["cpu_baseline_error"] = err
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:
@@ -358,6 +411,8 @@ def ess_section(args, eng, diagnostics, params, stats, acc, rows, N, T_timed, dt
         e_min, e_med, rh = float(np.nanmin(dd["ess"])), float(np.nanmedian(dd["ess"])), float(np.nanmax(dd["rhat"]))
         valid = bool(rh < 1.05)
         res["ess_per_sec"] = e_min * world / dl if valid else None
+        res["ess_parity"] = ("unpinned (ArviZ unavailable): the estimator restates Vehtari et al. 2021 as ArviZ's summary does, checked "
+                             "against oracle/ess_oracle.py and closed forms only; the reference pins no ESS value")
         res["ess"] = {"valid": valid, "max_rhat": rh, "min_bulk_ess_node": e_min * world, "median_bulk_ess_node": e_med * world,
                       "window_mh_iterations": L, "window_seconds": dl, "evals_per_sec_in_window": N * L * world / dl,
                       "draws_per_chain_used": L - L // 2, "chains_used": N,

@@ -90,7 +90,7 @@ def test_sample_keeps_records_on_the_device_and_returns_the_engine_s_records(eng
     ref = post.create_link(link.parameters)
     np.testing.assert_allclose([link.prior, link.likelihood], [ref.prior, ref.likelihood], rtol=1e-10)
     assert np.array_equal(link.parameters, P[-1, 7]) and link.model_output.shape == y.shape
-    # all chains in one pass (chains 5..7 have been touched: the bulk path is refused, chain by chain gives the same)
+    # all chains in one pass
     for burnin in (0, 31, T + 1, T + 5):
         s = tda.get_samples(res, burnin=burnin)
         assert s["iterations"] == max(T + 1 - burnin, 0) and s["dimension"] == d
@@ -98,7 +98,7 @@ def test_sample_keeps_records_on_the_device_and_returns_the_engine_s_records(eng
             want = np.concatenate([th0[i][None], P[:, i]])[burnin:]
             assert np.array_equal(s["chain_%d" % i], want)
     res2 = tda.sample(post, tda.AdaptiveMetropolis(1e-3 * np.eye(d), t0=50, period=50), T, n_chains=N, seed=11)
-    big = tda.get_samples(res2, "stats", burnin=17)  # untouched result: the bulk path (pooled engine buffers: same records again)
+    big = tda.get_samples(res2, "stats", burnin=17)  # (a second engine out of pooled buffers: the same records again)
     for i in range(N):
         assert np.array_equal(big["chain_%d" % i], np.concatenate([st0[i][None], S[:, i]])[17:])
     assert big["chain_0"].base is not None and big["dimension"] == 3

@@ -2090,16 +2090,19 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
   std::vector<double> th0;
   if (!theta0) {  // theta0 ~ prior (sampler.py:209) from RNG stream 2
     th0.resize((size_t)N * d);
-    std::vector<double> z(d + 1);
-    for (int64_t c = 0; c < N; ++c) {
-      for (int b = 0; b < (d + 1) / 2; ++b)
-        normal_pair(e->cfg.seed, (uint32_t)(e->cfg.chain_offset + c), 0u, STREAM_INIT, (uint32_t)b, z[2 * b], z[2 * b + 1]);
-      for (int i = 0; i < d; ++i) {
-        double s = 0.0;
-        for (int k = 0; k <= i; ++k) s = std::fma(e->prior_L_h[(size_t)i * d + k], z[k], s);
-        th0[(size_t)c * d + i] = e->prior_mean_h[i] + s;
+    // (a few host threads: 4096 chains x 32 Philox / Box-Muller pairs were 17 of the 20 ms an init took)
+    host_chain_ranges(N, [&](int64_t c0, int64_t c1) {
+      std::vector<double> z(d + 1);
+      for (int64_t c = c0; c < c1; ++c) {
+        for (int b = 0; b < (d + 1) / 2; ++b)
+          normal_pair(e->cfg.seed, (uint32_t)(e->cfg.chain_offset + c), 0u, STREAM_INIT, (uint32_t)b, z[2 * b], z[2 * b + 1]);
+        for (int i = 0; i < d; ++i) {
+          double s = 0.0;
+          for (int k = 0; k <= i; ++k) s = std::fma(e->prior_L_h[(size_t)i * d + k], z[k], s);
+          th0[(size_t)c * d + i] = e->prior_mean_h[i] + s;
+        }
       }
-    }
+    });
     theta0 = th0.data();
   }
   if ((rc = upload_states(e, theta0, N, e->theta.p))) return rc;

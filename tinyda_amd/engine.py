@@ -359,7 +359,12 @@ class Engine:
         return _lib.tda_outputs(C.sizeof(_lib.tda_outputs), min(rows or 0, 0xFFFFFFFF), _ptr(params), _ptr(stats), _ptr(accepted))
 
     def run(self, n_iterations, params=None, stats=None, accepted=None, sync=True):
-        out = self._outputs(0, int(n_iterations), params, stats, accepted)
+        need = int(n_iterations)
+        thin = getattr(self, "_thin", 1)
+        if thin > 1 and not (params is None and stats is None and accepted is None):
+            t = self.counters()[0]
+            need = (t + need) // thin - t // thin  # records that reach the caller (include/tinyda_amd.h, record thinning)
+        out = self._outputs(0, need, params, stats, accepted)
         self._check_run(self.lib.tda_engine_run(self.h, n_iterations, C.byref(out)))
         if sync:
             self.sync()
@@ -408,6 +413,7 @@ class Engine:
     def set_record_thinning(self, thin):
         """only iterations with (t + 1) % thin == 0 reach the record buffers (a run of n from t = 0 gives n // thin records)"""
         self._ck(self.lib.tda_engine_set_record_thinning(self.h, int(thin)))
+        self._thin = int(thin)
 
     def set_progress(self, on=True):
         self._ck(self.lib.tda_engine_set_progress(self.h, int(on)))

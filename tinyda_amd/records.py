@@ -30,6 +30,30 @@ class Link:
 _STAGE_BYTES = 64 << 20  # per page-locked staging buffer (two per process and device)
 _stage = {}
 _stage_lock = threading.Lock()
+_COPY_THREADS = 8
+_copy_pool = None
+
+
+def _parallel_copy(dst, src):
+    """dst[...] = src for large host arrays, split over a few threads along the first axis: NumPy releases the GIL while it
+    copies, and the destination is freshly allocated pageable memory whose first touch (one page fault per 4 KiB) is what a
+    single thread spends most of its time on (measured: 2 GB/s with one thread)."""
+    global _copy_pool
+    n = dst.shape[0]
+    if dst.nbytes < (8 << 20) or n < 2:
+        dst[...] = src
+        return
+    if _copy_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _copy_pool = ThreadPoolExecutor(max_workers=_COPY_THREADS, thread_name_prefix="tda-copy")
+    k = min(_COPY_THREADS, n)
+    bounds = [n * i // k for i in range(k + 1)]
+
+    def part(i):
+        dst[bounds[i]:bounds[i + 1]] = src[bounds[i]:bounds[i + 1]]
+
+    list(_copy_pool.map(part, range(k)))
 
 
 def _staging(device):
@@ -110,11 +134,11 @@ class DeviceRecords:
                 if pending is not None:
                     ps, p0, p1, pview = pending
                     events[ps].synchronize()
-                    out[p0:p1] = pview.numpy()
+                    _parallel_copy(out[p0:p1], pview.numpy())
                 pending = (slot, c0, c1, view)
             ps, p0, p1, pview = pending
             events[ps].synchronize()
-            out[p0:p1] = pview.numpy()
+            _parallel_copy(out[p0:p1], pview.numpy())
         return out
 
 

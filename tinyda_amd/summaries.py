@@ -23,9 +23,9 @@ def _attribute_rows(chain, attribute, burnin):
 
 
 def _bulk_rows(chains, attribute, burnin):
-    """All chains of a device result at once: when every value is an untouched DeviceChain over the SAME device records, chain i
-    being column i, the history crosses PCIe in one chunked pass (DeviceRecords.all_chains_host) instead of one strided gather
-    per chain.  Returns [n_chains, rows, width] or None (anything else: chain by chain)."""
+    """All chains of a device result at once: when every value is a DeviceChain over the SAME device records, chain i being column
+    i, the history crosses PCIe in one chunked pass (DeviceRecords.all_chains_host) instead of one strided gather per chain.
+    Returns [n_chains, rows, width] or None (anything else: chain by chain)."""
     first = chains[0]
     if attribute not in ("parameters", "stats") or not isinstance(first, DeviceChain) or first._records is None or burnin < 0:
         return None
@@ -33,7 +33,7 @@ def _bulk_rows(chains, attribute, burnin):
     if recs.n_chains != len(chains):
         return None
     for i, c in enumerate(chains):
-        if not isinstance(c, DeviceChain) or c._records is not recs or c._chain != i or c._rows != slice(None) or c._cache:
+        if not isinstance(c, DeviceChain) or c._records is not recs or c._chain != i or c._rows != slice(None):
             return None
     return recs.all_chains_host(attribute, start=burnin)
 

@@ -28,4 +28,20 @@ for k, c in res.items():
 json.dump(out, open("/tmp/pmc_out.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
-cp /tmp/pmc_out.json $GRAFT_REPO_ROOT/gpurun_out/r02_pmc_raw.json
+python3 - <<'PY'
+# the file bench.py reads (profiles/rNN_pmc_traffic.json after review): per-launch figure of the dominant kernel + the git blob of
+# the kernel source it was measured on (bench.py prints traffic_stale when the source has changed since)
+import hashlib, json, os
+root = os.environ["GRAFT_REPO_ROOT"]
+raw = json.load(open("/tmp/pmc_out.json"))
+data = open(os.path.join(root, "tinyda_amd", "csrc", "tda_kernels_mh.h"), "rb").read()
+key = [k for k in raw if "k_mh_steps<64, 8" in k][0]
+out = {"note": "rocprofv3 --pmc, two separate passes (FETCH_SIZE | WRITE_SIZE TCC_HIT_sum TCC_MISS_sum) of `bench.py --steps 10 --warmup 2 "
+               "--pilot 1000 --burnin 2000 --no-cpu-baseline --no-ess` (tools/pmc_traffic.sh); median over the 100-iteration launches "
+               "(409600 evals each). FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for wide coalesced streaming reads on gfx950; "
+               "units KiB -> bytes.",
+       "evals_per_launch": 409600, "k_mh_steps_hbm_bytes_per_launch": raw[key]["hbm_bytes_corrected"],
+       "k_mh_steps_algorithmic_bytes_per_launch": 1057 * 409600,
+       "kernel_source_blob": hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest(), "kernels": raw}
+json.dump(out, open(os.path.join(root, "gpurun_out", os.environ.get("PMC_OUT", "r03_pmc_traffic.json")), "w"), indent=1)
+PY
