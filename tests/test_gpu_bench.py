@@ -100,6 +100,26 @@ def test_bench_launches_its_own_ranks():
     assert 0.4 * one["value"] < two["value"] < 2.2 * one["value"]
 
 
+def test_scale_script_rehearsal_on_one_gpu(tmp_path):
+    """tools/r03_scale.sh -- the one command for an 8-GPU node (bench at 1/2/4/8 ranks, config 4 in the four archive modes, the peer
+    archive check) -- rehearsed with two ranks on this one GPU over gloo: every stage runs, every line carries its rank count."""
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "r03_scale.sh"), str(tmp_path)], cwd=ROOT, env=dict(os.environ, REHEARSE="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-4000:]
+    rep = json.load(open(tmp_path / "summary.json"))
+    assert [b["n_gpus"] for b in rep["bench"]] == [1, 2] and all(b["value"] > 0 and b["efficiency"] > 0 for b in rep["bench"])
+    assert rep["bench"][1]["rccl_ranks"] == "gloo rehearsal on one GPU"
+    modes = [(c["mode"], c["n_gpus"]) for c in rep["c4"]]
+    assert modes == [(m, n) for n in (1, 2) for m in ("replicated-blocking", "replicated-overlapped", "distributed-sync", "distributed-lagged")]
+    for c in rep["c4"]:
+        assert c["evals_per_s"] > 0 and len(c["per_rank_evals_per_s"]) == c["n_gpus"] and c["efficiency"] > 0
+        assert c["ran_as"].startswith(c["mode"].split("-")[0]) and c["note"] is None  # IPC mapping works between processes on one GPU
+        assert c["archive_rows_rank0"] == 320 + (64 + 48) * 512 * (1 if c["mode"].startswith("distributed") else c["n_gpus"])
+    assert rep["peer_archive_check"] and rep["peer_archive_check"][0]["world"] == 2
+
+
 def _small_engine(eng_mod, N=32, d=8, m=16, n_levels=1):
     rng = np.random.default_rng(3)
     e = eng_mod.Engine(N, d, seed=5, n_levels=n_levels)

@@ -464,7 +464,15 @@ def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, se
 
             if peer_archive:
                 # every rank keeps its own rows; one small collective per 16 steps, the rows are read in place
-                tdist.setup_peer_archive(eng)
+                try:
+                    tdist.setup_peer_archive(eng)
+                except tdist.PeerArchiveUnavailable as exc:  # raised on every rank alike: all fall back together, loudly
+                    warnings.warn("shared_archive='distributed' is not available here (%s): FALLING BACK to the replicated archive "
+                                  "(one all_gather of the new rows per 16 steps)" % exc)
+                    eng.close()
+                    del params, stat, acc
+                    return _sample_device(plan, posterior, iterations, n_chains, initial_parameters, seed, device, chain_offset,
+                                          distributed, total_chains, overlap_exchange, False, thin, progress)
                 tdist.run_peer_dream(eng, T, 16, params[1:], stat[1:], acc[1:], period=prop.get("period") if prop.get("adaptive") else None,
                                      lag=tstream is not None, stream=tstream)
             else:

@@ -15,11 +15,33 @@ namespace tda {
 //                   gathered from the chain's archive in HBM, evaluation (linear model on MFMA, or the
 //                   Rosenbrock chain on VALU), accept, record, archive append (proposal.py:794)
 //   k_dreamz_adapt  wave per chain: archive column sums catch-up, global scaling, pCR update (proposal.py:797-809)
-// RNG stream 4 (block = what, step, chain):  block i < delta : r1 = (x0*M)>>32, r2 = (x1*(M-1))>>32, r2 += r2>=r1
-//   block delta : mCR by inverse cdf of u53(x0,x1) over pCR, forced index = (x2*d)>>32
-//   block delta+1+j : subspace uniform u53(x0,x1) and e-uniform u53(x2,x3) of parameter j;  eps_j from stream 0.
+// RNG contract of DREAM(Z) (round 3; counter = (block, step field, global chain id, stream tag)):
+//   stream 4, step field = step, per chain and step:
+//     block i < delta : archive rows r1 = (x0*M)>>32, r2 = (x1*(M-1))>>32, r2 += r2>=r1
+//     block delta     : mCR by inverse cdf of u53(x0,x1) over pCR, forced index = (x2*d)>>32
+//   per parameter j, one block serves FOUR consecutive steps (step field = step >> 2, word = step & 3, block = delta + 1 + j):
+//     stream 5 : crossover uniform of step 4Q + w :  (x_w + 0.5) 2^-32  (a `u < CR` test against k / nCR does not need 53 bits)
+//     stream 6 : e-uniform of step 4Q + w, the same map
+//     stream 7 : eps normals by Box-Muller in single precision: (x0, x1) -> steps 4Q, 4Q + 1; (x2, x3) -> steps 4Q + 2, 4Q + 3, with
+//                u1 = ((x >> 8) + 0.5) 2^-24, r = sqrt(-2 ln u1), angle = 2 pi ((x' >> 8) + 0.5) 2^-24  (eps = b* z, b* = 1e-6: a
+//                jitter; the normals actually used are exported to the oracle like every normal of the engine)
+//   Three generator calls per parameter and FOUR steps where rounds 1-2 spent 1.5 calls and one double-precision Box-Muller pair
+//   per parameter and step: k_dreamz_draw was generator-bound at twice the cost of the step kernel it feeds.
 // ------------------------------------------------------------------------------------------------
-enum : uint32_t { STREAM_DREAM = 4 };
+enum : uint32_t { STREAM_DREAM = 4, STREAM_DREAM_MASK = 5, STREAM_DREAM_E = 6, STREAM_DREAM_EPS = 7 };
+
+__device__ __forceinline__ double u32_uniform(uint32_t x) { return ((double)x + 0.5) * (1.0 / 4294967296.0); }
+
+// two standard normals from two 32-bit words, single precision (the DREAM(Z) eps jitter only)
+__device__ __forceinline__ void normal_pair_f32(uint32_t xa, uint32_t xb, float& z0, float& z1) {
+  const float u1 = ((float)(xa >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u2 = ((float)(xb >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float r = __builtin_sqrtf(-2.0f * __logf(u1));
+  float sn, cs;
+  __sincosf(6.283185307179586f * u2, &sn, &cs);
+  z0 = r * cs;
+  z1 = r * sn;
+}
 constexpr int MAX_NCR = 8;
 constexpr int MAX_DELTA = 4;
 constexpr int MAX_PEERS = 16;
@@ -98,16 +120,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
     __syncthreads();
   }
   int mcr = 0;
-  // Box-Muller pairs: a chain needs DPAD / 2 pairs per step (pair p -> dimensions 2p, 2p + 1, the RNG contract), its
-  // DPAD lanes can draw DPAD pairs at once: the lower half draws the pairs of step s, the upper half those of step
-  // s + 1, and two shuffles per step hand every dimension its normal -- one normal_pair per lane and TWO steps instead
-  // of one per step (the normals are ~2/3 of this kernel's instructions).
   // jump scale for every possible subspace size (proposal.py:842-844), lane k - 1 of the chain holds the one for k
   // dimensions: a shuffle per step instead of a square root and a division
   const double gam_tab = scaling * 2.38 / sqrt((double)(2 * a.delta * (lane + 1)));
-  constexpr int HALF = DPAD / 2;
   const bool philox_normals = a.sub_rep == nullptr;  // wave-uniform
-  double zp0 = 0.0, zp1 = 0.0;
+  // per-parameter variates: one block each for the crossover uniforms, the e-uniforms and the eps normals of FOUR steps
+  u32x4 q_mask{0u, 0u, 0u, 0u}, q_e{0u, 0u, 0u, 0u};
+  float q_z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   constexpr int SPP = DPAD / 8;  // steps per pass of the per-chain scalar blocks (8 lanes per step)
   u32x4 xs_pass{0u, 0u, 0u, 0u};
   for (int s = 0; s < a.S; ++s) {
@@ -184,12 +203,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
     }
     const double CR = (double)(mcr + 1) / (double)a.nCR;
     // ---- per-parameter draws ----
-    double en_philox = 0.0;
-    if (philox_normals) {
-      if ((s & 1) == 0) normal_pair(a.seed, gc, step + (lane >= HALF ? 1u : 0u), STREAM_PROPOSAL, (uint32_t)(lane % HALF), zp0, zp1);
-      const int src = seg * DPAD + ((s & 1) ? HALF : 0) + (lane >> 1);
-      const double g0 = __shfl(zp0, src), g1 = __shfl(zp1, src);
-      en_philox = (lane & 1) ? g1 : g0;
+    if (philox_normals && (s == 0 || (step & 3u) == 0u)) {
+      const uint32_t blk = (uint32_t)(a.delta + 1 + lane), quad = step >> 2;
+      q_mask = philox4x32_10(u32x4{blk, quad, gc, STREAM_DREAM_MASK}, k0, k1);
+      q_e = philox4x32_10(u32x4{blk, quad, gc, STREAM_DREAM_E}, k0, k1);
+      const u32x4 zz = philox4x32_10(u32x4{blk, quad, gc, STREAM_DREAM_EPS}, k0, k1);
+      normal_pair_f32(zz.x, zz.y, q_z[0], q_z[1]);
+      normal_pair_f32(zz.z, zz.w, q_z[2], q_z[3]);
     }
     double su = 2.0, eu = 0.5, en = 0.0;
     if (lj) {
@@ -200,10 +220,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
           en = a.eps_rep[row * a.d + lane];
         }
       } else {
-        const u32x4 x = philox4x32_10(u32x4{(uint32_t)(a.delta + 1 + lane), step, gc, STREAM_DREAM}, k0, k1);
-        su = u53(x.x, x.y);
-        eu = u53(x.z, x.w);
-        en = en_philox;
+        const uint32_t w = step & 3u;  // wave-uniform
+        su = u32_uniform(w == 0 ? q_mask.x : w == 1 ? q_mask.y : w == 2 ? q_mask.z : q_mask.w);
+        eu = u32_uniform(w == 0 ? q_e.x : w == 1 ? q_e.y : w == 2 ? q_e.z : q_e.w);
+        en = (double)(w == 0 ? q_z[0] : w == 1 ? q_z[1] : w == 2 ? q_z[2] : q_z[3]);
       }
       if (a.eps_export && real_chain) a.eps_export[row * a.d + lane] = en;
     }

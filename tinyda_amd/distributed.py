@@ -214,10 +214,17 @@ def run_shared_dream(engine, n_iterations, sync_every, params=None, stats=None, 
         engine.sync()
 
 
+class PeerArchiveUnavailable(RuntimeError):
+    """raised on EVERY rank when any rank could not map its peers' archive segments (hipIpcOpenMemHandle across devices refused:
+    no peer access, an IPC mode the driver does not support, processes on different nodes)"""
+
+
 def setup_peer_archive(engine):
     """Distributed shared archive (include/tinyda_amd.h: tda_engine_set_archive_peers): exchange the IPC handles of the ranks'
     archive segments once and map them.  One process per GPU of one node (peer access over xGMI); with one rank it is a no-op
-    apart from switching the engine to the block-wise publish protocol."""
+    apart from switching the engine to the block-wise publish protocol.  If any rank fails to map a segment, every rank raises
+    PeerArchiveUnavailable (agreed through one more small collective, so nobody is left waiting in a barrier); callers fall back
+    to the replicated archive."""
     import torch.distributed as dist
 
     if not _collectives_active():
@@ -236,7 +243,15 @@ def setup_peer_archive(engine):
     if any(sh != shapes[0] for sh in shapes) or shapes[0][0] % 16 != 0:
         raise ValueError("distributed DREAM archive: every rank needs the same (n_chains, dim, M0, capacity) and n_chains a multiple of 16; "
                          "got %s" % (shapes,))
-    engine.set_archive_peers(world, rank, handles=[e[1] for e in entries])
+    err = None
+    try:
+        engine.set_archive_peers(world, rank, handles=[e[1] for e in entries])
+    except Exception as exc:  # EngineError: hipIpcOpenMemHandle / peer access refused
+        err = "rank %d: %s" % (rank, exc)
+    errs = [None] * world
+    dist.all_gather_object(errs, err)
+    if any(errs):
+        raise PeerArchiveUnavailable("; ".join(x for x in errs if x))
     return world
 
 
