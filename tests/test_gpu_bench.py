@@ -116,7 +116,7 @@ def test_scale_script_rehearsal_on_one_gpu(tmp_path):
     for c in rep["c4"]:
         assert c["evals_per_s"] > 0 and len(c["per_rank_evals_per_s"]) == c["n_gpus"] and c["efficiency"] > 0
         assert c["ran_as"].startswith(c["mode"].split("-")[0]) and c["note"] is None  # IPC mapping works between processes on one GPU
-        assert c["archive_rows_rank0"] == 320 + (64 + 48) * 512 * (1 if c["mode"].startswith("distributed") else c["n_gpus"])
+        assert c["archive_rows_rank0"] == 320 + (64 + 48) * 512 * c["n_gpus"]  # every chain's state of every step, whoever stores it
     assert rep["peer_archive_check"] and rep["peer_archive_check"][0]["world"] == 2
 
 

@@ -4041,12 +4041,19 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     }
   }
   if (pipe && !e->ev_dz_adapt) HIP_TRY(hipEventCreateWithFlags(&e->ev_dz_adapt, hipEventDisableTiming));
-  auto block_len = [&](int64_t t_now, int64_t left) {
+  // Shared archive, one process appending its own rows: the exchange points are the CALL-RELATIVE multiples of sync_every -- where
+  // the multi-rank driver (distributed.run_shared_dream: one run() per interval, then the all-gather) has them.  A block that an
+  // adaptation boundary cuts in two is not an exchange point: the rows of its first half become visible together with the second
+  // half's (`since` = steps since the last exchange point), so one process and N ranks see the same archive at every step whatever
+  // the period (the engine used to restart full intervals after a boundary).
+  int64_t since = 0;
+  const bool pending_at_entry = e->pending_steps != 0;  // (rows taken over from an earlier call sit in blk_hist, not in place)
+  auto block_len = [&](int64_t t_now, int64_t left, int64_t since_now) {
     int64_t S = std::min<int64_t>(left, e->SMAX);
     if (adaptive) S = std::min<int64_t>(S, period - (t_now % period));
     if (sh) {
       const int64_t K = e->dz.sync_every > 0 ? e->dz.sync_every : e->SMAX;
-      S = std::min<int64_t>(S, K);
+      S = std::min<int64_t>(S, K - (e->auto_append && !e->dist_ranks ? since_now % K : 0));
       if (!e->dist_ranks && !e->auto_append && e->pending_steps + S > e->SMAX) S = e->SMAX - e->pending_steps;
     }
     return S;
@@ -4112,11 +4119,11 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     // everything queued on the main stream so far (init, earlier run() calls, their adaptation) precedes the first draw
     HIP_TRY(hipEventRecord(e->ev_dz_adapt, e->stream));
     HIP_TRY(hipStreamWaitEvent(e->rng_stream, e->ev_dz_adapt, 0));
-    enqueue_draw(0, e->t, e->arch_rows, block_len(e->t, n_iter), e->rp_pos, e->exp_pos, false, e->rng_stream);
+    enqueue_draw(0, e->t, e->arch_rows, block_len(e->t, n_iter, 0), e->rp_pos, e->exp_pos, false, e->rng_stream);
     HIP_TRY(hipEventRecord(e->ev_rng[0], e->rng_stream));
   }
   while (done < n_iter) {
-    const int64_t S = block_len(e->t, n_iter - done);
+    const int64_t S = block_len(e->t, n_iter - done, since);
     if (S <= 0) return fail(TDA_ERR_STATE, "shared archive: call archive_take / archive_append before running further");
     const int set = pipe ? (int)(blk & 1) : 0;
     if (pipe) {
@@ -4142,9 +4149,11 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     // single process, no padding chains: the block's states ARE the next archive rows in canonical order (step-major,
     // chain minor), the kernel appends them in place (the jumps of this block were gathered before it started)
     const bool dist = e->dist_ranks != 0;
-    const bool direct = !dist && sh && e->auto_append && N == NP && e->pending_steps == 0;
+    const bool direct = !dist && sh && e->auto_append && N == NP && !pending_at_entry;
     // distributed archive: the block's states are this rank's next rows of its own segment, written in place
-    sa.blk_states = sh ? (dist ? e->arch.p + (size_t)(e->dz.M0 + (e->dist_steps + e->dist_pending) * N) * DP : (direct ? e->arch.p + (size_t)e->arch_rows * DP : e->blk_states.p))
+    // (in place = behind the visible rows and behind the rows of an interval's earlier blocks that are not visible yet)
+    sa.blk_states = sh ? (dist ? e->arch.p + (size_t)(e->dz.M0 + (e->dist_steps + e->dist_pending) * N) * DP
+                               : (direct ? e->arch.p + (size_t)(e->arch_rows + e->pending_steps * N) * DP : e->blk_states.p))
                        : nullptr;
     if (ext_model) {
       // model outside the engine's kernels: per step apply the jump, evaluate (callback: one host call for all chains;
@@ -4223,7 +4232,9 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
         ScopedTimer tm(e, 2);
         if (boundary && (rc = dreamz_sums_catchup(e, e->arch_rows, 0, true, adaptive, std::pow(e->dz.gamma, -(double)e->k_adapt)))) return rc;
       }
-      if (e->auto_append) {  // single process: the local rows are all rows; canonical order = step-major, chain minor
+      since += S;
+      const int64_t Ksync = e->dz.sync_every > 0 ? e->dz.sync_every : e->SMAX;
+      if (e->auto_append && (since % Ksync == 0 || done + S >= n_iter)) {  // single process: the local rows are all rows; canonical order = step-major, chain minor
         if (direct) {
           // already in place
         } else if (N == NP) {
@@ -4251,7 +4262,7 @@ static int run_dreamz(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
         const int nset = (int)((blk + 1) & 1);
         if (blk >= 1) HIP_TRY(hipStreamWaitEvent(e->rng_stream, e->ev_steps[nset], 0));
         if (boundary) HIP_TRY(hipStreamWaitEvent(e->rng_stream, e->ev_steps[set], 0));
-        enqueue_draw(nset, e->t + S, e->arch_rows, block_len(e->t + S, n_iter - done - S), e->rp_pos + S, e->exp_pos + S, false, e->rng_stream);
+        enqueue_draw(nset, e->t + S, e->arch_rows, block_len(e->t + S, n_iter - done - S, since), e->rp_pos + S, e->exp_pos + S, false, e->rng_stream);
         HIP_TRY(hipEventRecord(e->ev_rng[nset], e->rng_stream));
       }
     }

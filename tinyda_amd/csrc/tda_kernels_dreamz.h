@@ -102,15 +102,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
   const uint32_t gc = (uint32_t)(a.chain_offset + c);
   const bool lj = lane < a.d;
   const double scaling = a.scaling[c];
-  double cdf[MAX_NCR];
-  {
+  // cumulative crossover probabilities of the wave's chains: in LDS, not in 16 registers per lane (the kernel is held to 128)
+  __shared__ double s_cdf[CPW][MAX_NCR];
+  __shared__ double s_CR[MAX_NCR];  // crossover probability of index k: (k + 1) / nCR (a table lookup per step instead of a division)
+  __shared__ int s_rows[CPW][DPAD][2 * MAX_DELTA];  // archive row pairs of the chunk's steps (written by the step's owner lane)
+  __shared__ int s_mf[CPW][DPAD];                    // crossover index | forced index << 8
+  if (lane == 0) {
     double run = 0.0;
-#pragma unroll
     for (int k = 0; k < MAX_NCR; ++k) {
       run += k < a.nCR ? a.pCR[c * MAX_NCR + k] : 0.0;
-      cdf[k] = run;
+      s_cdf[seg][k] = run;
     }
   }
+  if (threadIdx.x < MAX_NCR) s_CR[threadIdx.x] = (double)(threadIdx.x + 1) / (double)a.nCR;
+  __syncthreads();
   const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
   // distributed archive: the ranks' segment addresses in LDS (a per-lane pick from a table in memory would put a second
   // dependent trip to memory in front of every gathered row)
@@ -119,7 +124,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
     if (threadIdx.x < (unsigned)a.dist_ranks) s_seg[threadIdx.x] = a.seg[threadIdx.x];
     __syncthreads();
   }
-  int mcr = 0;
   // jump scale for every possible subspace size (proposal.py:842-844), lane k - 1 of the chain holds the one for k
   // dimensions: a shuffle per step instead of a square root and a division
   const double gam_tab = scaling * 2.38 / sqrt((double)(2 * a.delta * (lane + 1)));
@@ -127,137 +131,179 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
   // per-parameter variates: one block each for the crossover uniforms, the e-uniforms and the eps normals of FOUR steps
   u32x4 q_mask{0u, 0u, 0u, 0u}, q_e{0u, 0u, 0u, 0u};
   float q_z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  constexpr int SPP = DPAD / 8;  // steps per pass of the per-chain scalar blocks (8 lanes per step)
-  u32x4 xs_pass{0u, 0u, 0u, 0u};
-  for (int s = 0; s < a.S; ++s) {
-    const uint32_t step = (uint32_t)(a.step0 + s);
-    const int64_t M = a.M_base + (a.grow ? s : 0);
-    const size_t row = (size_t)s * a.N + c;  // replay / export row (real chains only)
-    // The per-chain scalars of a step -- delta row pairs, the crossover draw, the accept uniform -- are delta + 2 <= 6 Philox
-    // blocks.  The chain's DPAD lanes evaluate them for DPAD / 8 steps in ONE pass (lane = 8 * step-in-pass + kind; a pass
-    // per step left all but delta + 2 lanes repeating a block: 0.75 of the 2.5 generator calls per lane and step at d = 32)
-    // and every step fetches its values with shuffles.
-    const bool acc_lane = lane == a.delta + 1;
-    if (s % SPP == 0) {
-      const int kind = lane & 7;
-      const bool acc_k = kind == a.delta + 1;
-      xs_pass = philox4x32_10(u32x4{acc_k ? 0u : (uint32_t)(kind < a.delta ? kind : a.delta), step + (uint32_t)(lane >> 3), gc,
-                                    acc_k ? (uint32_t)STREAM_ACCEPT : (uint32_t)STREAM_DREAM}, k0, k1);
-    }
-    const int slot = seg * DPAD + 8 * (s % SPP);
-    u32x4 xs;  // lanes < delta: their row-pair block; lane delta + 1: the accept block (x, y)
+  constexpr int GS = DPAD < 4 ? DPAD : 4;  // steps per group: their archive rows are requested together, one group ahead
+  // The per-chain scalars of a step -- delta row pairs, the crossover draw, the accept uniform: delta + 2 <= 6 Philox blocks and
+  // their post-processing (53-bit uniforms, the inverse cdf, two 64-bit products per row pair) -- are worked out ONCE per chain
+  // and step: lane l of the chain owns step c0 + l of a chunk of DPAD steps, and the per-step loop fetches what it needs with
+  // a shuffle.  (Rounds 1-2 had every lane of the chain repeat that post-processing in every step: 250 vector instructions per
+  // lane and step, of which the generator was the smaller part -- profiles/r03_c4_pmc_sq.json.)
+  // With a shared archive this kernel also gathers the rows of the jump; the rows of group g + 1 are requested before the
+  // per-parameter work of group g, so a gather has a whole group of arithmetic to arrive under (round 2 requested them inside
+  // the step that used them: a full memory latency per step).
+  struct Group {
+    double zd[GS];  // sum Z[r1] - sum Z[r2] of this lane's parameter (shared archive)
+    int mf[GS];     // crossover index | forced index << 8
+  };
+  auto row_of = [&](int r) -> const double* {
+    if constexpr (!DIST) return a.arch_shared + (size_t)r * DPAD;
+    if (r < a.dist_M0) return a.arch_shared + (size_t)r * DPAD;  // (this rank's own copy of the shared initial rows)
+    // 32-bit arithmetic: row indices are ints (the row-pair draw), and a 64-bit division costs ~100 instructions per lane
+    const uint32_t nt = (uint32_t)a.dist_ntot, nlc = (uint32_t)a.dist_nloc;
+    const uint32_t q = (uint32_t)r - (uint32_t)a.dist_M0, sg = q / nt, g = q - sg * nt;
+    const uint32_t o = g / nlc, l = g - o * nlc;
+    return s_seg[o] + ((size_t)a.dist_M0 + (size_t)sg * nlc + l) * DPAD;
+  };
+  for (int c0 = 0; c0 < a.S; c0 += DPAD) {
+    // ---- chain-level draws of steps c0 .. c0 + DPAD - 1: this lane's step is c0 + lane ----
+    __syncthreads();  // (one wave per workgroup: orders this chunk's table writes behind the previous chunk's reads)
     {
-      const int src = slot + (lane < a.delta ? lane : a.delta + 1);
-      xs.x = (uint32_t)__shfl((int)xs_pass.x, src);
-      xs.y = (uint32_t)__shfl((int)xs_pass.y, src);
-      xs.z = 0u;
-      xs.w = 0u;
-    }
-    // ---- archive row pairs (proposal.py:823-826) ----
-    int r1 = 0, r2 = 0;
-    if (lane < a.delta) {
-      if (a.r_rep && real_chain) {
-        r1 = a.r_rep[(row * a.delta + lane) * 2 + 0];
-        r2 = a.r_rep[(row * a.delta + lane) * 2 + 1];
-      } else {
-        const u32x4 x = xs;
-        r1 = (int)(((uint64_t)x.x * (uint64_t)M) >> 32);
-        r2 = (int)(((uint64_t)x.y * (uint64_t)(M - 1)) >> 32);
-        r2 += r2 >= r1 ? 1 : 0;
-      }
-      a.ridx[((size_t)s * a.NP + c) * (2 * MAX_DELTA) + 2 * lane + 0] = r1;
-      a.ridx[((size_t)s * a.NP + c) * (2 * MAX_DELTA) + 2 * lane + 1] = r2;
-    }
-    double zs1 = 0.0, zs2 = 0.0;
-    if (a.arch_shared) {  // rows in flight under the draws below
-      auto row_of = [&](int r) -> const double* {
-        if constexpr (!DIST) return a.arch_shared + (size_t)r * DPAD;
-        if (r < a.dist_M0) return a.arch_shared + (size_t)r * DPAD;  // (this rank's own copy of the shared initial rows)
-        // 32-bit arithmetic: row indices are ints (the row-pair draw), and a 64-bit division costs ~100 instructions per lane
-        const uint32_t nt = (uint32_t)a.dist_ntot, nlc = (uint32_t)a.dist_nloc;
-        const uint32_t q = (uint32_t)r - (uint32_t)a.dist_M0, sg = q / nt, g = q - sg * nt;
-        const uint32_t o = g / nlc, l = g - o * nlc;
-        return s_seg[o] + ((size_t)a.dist_M0 + (size_t)sg * nlc + l) * DPAD;
-      };
-      for (int i = 0; i < a.delta; ++i) {
-        const int r1i = __shfl(r1, seg * DPAD + i), r2i = __shfl(r2, seg * DPAD + i);
-        zs1 += row_of(r1i)[lane];
-        zs2 += row_of(r2i)[lane];
-      }
-    }
-    // ---- crossover index and the index forced when the subspace is empty (proposal.py:829-839) ----
-    int forced;
-    {
-      const int src = slot + a.delta;  // the lane that evaluated this step's crossover block
-      const u32x4 x = u32x4{(uint32_t)__shfl((int)xs_pass.x, src), (uint32_t)__shfl((int)xs_pass.y, src), (uint32_t)__shfl((int)xs_pass.z, src), 0u};
-      if (a.mcr_rep && real_chain) {
-        mcr = a.mcr_rep[row];
-        forced = a.forced_rep[row];
-      } else {
-        const double uu = u53(x.x, x.y);
-        mcr = a.nCR - 1;
-        for (int k = a.nCR - 1; k >= 0; --k)
-          if (cdf[k] > uu) mcr = k;
-        forced = (int)(((uint64_t)x.z * (uint64_t)a.d) >> 32);
-      }
-    }
-    const double CR = (double)(mcr + 1) / (double)a.nCR;
-    // ---- per-parameter draws ----
-    if (philox_normals && (s == 0 || (step & 3u) == 0u)) {
-      const uint32_t blk = (uint32_t)(a.delta + 1 + lane), quad = step >> 2;
-      q_mask = philox4x32_10(u32x4{blk, quad, gc, STREAM_DREAM_MASK}, k0, k1);
-      q_e = philox4x32_10(u32x4{blk, quad, gc, STREAM_DREAM_E}, k0, k1);
-      const u32x4 zz = philox4x32_10(u32x4{blk, quad, gc, STREAM_DREAM_EPS}, k0, k1);
-      normal_pair_f32(zz.x, zz.y, q_z[0], q_z[1]);
-      normal_pair_f32(zz.z, zz.w, q_z[2], q_z[3]);
-    }
-    double su = 2.0, eu = 0.5, en = 0.0;
-    if (lj) {
-      if (!philox_normals) {
-        if (real_chain) {
-          su = a.sub_rep[row * a.d + lane];
-          eu = a.e_rep[row * a.d + lane];
-          en = a.eps_rep[row * a.d + lane];
+      const int s = c0 + lane;
+      if (s < a.S) {
+        const uint32_t step = (uint32_t)(a.step0 + s);
+        const int64_t M = a.M_base + (a.grow ? s : 0);
+        const size_t row = (size_t)s * a.N + c;  // replay / export row (real chains only)
+        // archive row pairs (proposal.py:823-826)
+        for (int i = 0; i < a.delta; ++i) {
+          int r1, r2;
+          if (a.r_rep && real_chain) {
+            r1 = a.r_rep[(row * a.delta + i) * 2 + 0];
+            r2 = a.r_rep[(row * a.delta + i) * 2 + 1];
+          } else {
+            const u32x4 x = philox4x32_10(u32x4{(uint32_t)i, step, gc, STREAM_DREAM}, k0, k1);
+            r1 = (int)(((uint64_t)x.x * (uint64_t)M) >> 32);
+            r2 = (int)(((uint64_t)x.y * (uint64_t)(M - 1)) >> 32);
+            r2 += r2 >= r1 ? 1 : 0;
+          }
+          a.ridx[((size_t)s * a.NP + c) * (2 * MAX_DELTA) + 2 * i + 0] = r1;
+          a.ridx[((size_t)s * a.NP + c) * (2 * MAX_DELTA) + 2 * i + 1] = r2;
+          s_rows[seg][lane][2 * i + 0] = r1;
+          s_rows[seg][lane][2 * i + 1] = r2;
         }
-      } else {
-        const uint32_t w = step & 3u;  // wave-uniform
-        su = u32_uniform(w == 0 ? q_mask.x : w == 1 ? q_mask.y : w == 2 ? q_mask.z : q_mask.w);
-        eu = u32_uniform(w == 0 ? q_e.x : w == 1 ? q_e.y : w == 2 ? q_e.z : q_e.w);
-        en = (double)(w == 0 ? q_z[0] : w == 1 ? q_z[1] : w == 2 ? q_z[2] : q_z[3]);
+        // crossover index and the index forced when the subspace is empty (proposal.py:829-839)
+        int mcr, forced;
+        if (a.mcr_rep && real_chain) {
+          mcr = a.mcr_rep[row];
+          forced = a.forced_rep[row];
+        } else {
+          const u32x4 x = philox4x32_10(u32x4{(uint32_t)a.delta, step, gc, STREAM_DREAM}, k0, k1);
+          const double uu = u53(x.x, x.y);
+          mcr = a.nCR - 1;
+          for (int k = a.nCR - 1; k >= 0; --k)
+            if (s_cdf[seg][k] > uu) mcr = k;
+          forced = (int)(((uint64_t)x.z * (uint64_t)a.d) >> 32);
+        }
+        s_mf[seg][lane] = mcr | (forced << 8);
+        if (s == a.S - 1) a.mcr_last[c] = mcr;  // crossover index of the block's last step (proposal.py:801)
+        // accept_uniform(seed, chain, step, level 0): u53 of the first two words of that block
+        double u = 0.5;
+        if (real_chain) {
+          if (a.u_rep) {
+            u = a.u_rep[row];
+          } else {
+            const u32x4 x = philox4x32_10(u32x4{0u, step, gc, STREAM_ACCEPT}, k0, k1);
+            u = u53(x.x, x.y);
+          }
+          if (a.u_export) a.u_export[row] = u;
+        }
+        a.u[(size_t)s * a.NP + c] = u;
       }
-      if (a.eps_export && real_chain) a.eps_export[row * a.d + lane] = en;
     }
-    bool ind = lj && (su < CR);
-    unsigned long long bal = __ballot(ind);
-    if (CPW > 1) bal = (bal >> (seg * DPAD)) & ((1ull << (DPAD & 63)) - 1ull);  // this chain's lanes
-    int dsub = __popcll(bal);
-    if (dsub == 0) {  // proposal.py:838-839
-      ind = lane == forced;
-      dsub = 1;
-    }
-    const double gam = __shfl(gam_tab, seg * DPAD + dsub - 1);  // scaling * 2.38 / sqrt(2 delta d'), proposal.py:842-844
-    const double e = -a.b + (a.b - (-a.b)) * eu;
-    const double eps = 0.0 + a.b_star * en;
-    if (lane < DPAD) {
-      const double cf = ind ? (1.0 + e) * gam : 0.0, em = ind ? eps : 0.0;
-      const size_t o = ((size_t)s * a.NP + c) * DPAD + lane;
-      if (a.arch_shared) {
-        a.coef[o] = cf * (zs1 - zs2) + em;  // the jump itself (proposal.py:850-852)
-      } else {
-        a.coef[o] = cf;
-        a.epsm[o] = em;
+    __syncthreads();
+    const int c1 = a.S - c0 < DPAD ? a.S : c0 + DPAD;  // end of this chunk
+    // what the per-step loop needs of steps s0 .. s0 + GS - 1 (from their owner lanes), and the requests for their archive rows
+    auto draw_group = [&](int s0, Group& g) {
+      int sl[GS];  // the steps' slots in the chunk's tables
+#pragma unroll
+      for (int q = 0; q < GS; ++q) {
+        sl[q] = (s0 + q - c0) & (DPAD - 1);  // (past the chunk's end: some slot, never used)
+        g.mf[q] = s_mf[seg][sl[q]];
+        g.zd[q] = 0.0;
       }
-    }
-    if (acc_lane) {  // accept_uniform(seed, chain, step, level 0): u53 of the first two words of that block
-      double u = 0.5;
-      if (real_chain) {
-        u = a.u_rep ? a.u_rep[row] : u53(xs.x, xs.y);
-        if (a.u_export) a.u_export[row] = u;
+      if (a.arch_shared) {  // the row requests of the group back to back (nothing between them that they could alias with)
+        double zs1[GS], zs2[GS];  // (the order of the sums the step kernel's own gather uses: ascending pair index, r1 and r2 apart)
+#pragma unroll
+        for (int q = 0; q < GS; ++q) zs1[q] = zs2[q] = 0.0;
+        for (int i = 0; i < a.delta; ++i) {
+          double z1[GS], z2[GS];
+#pragma unroll
+          for (int q = 0; q < GS; ++q) {
+            const int vq = s0 + q < c1 ? sl[q] : 0;  // (a step past the chunk's end gathers a valid row: harmless, never used)
+            z1[q] = row_of(s_rows[seg][vq][2 * i + 0])[lane];
+            z2[q] = row_of(s_rows[seg][vq][2 * i + 1])[lane];
+          }
+#pragma unroll
+          for (int q = 0; q < GS; ++q) {
+            zs1[q] += z1[q];
+            zs2[q] += z2[q];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < GS; ++q) g.zd[q] = zs1[q] - zs2[q];
       }
-      a.u[(size_t)s * a.NP + c] = u;
+    };
+    Group cur, nxt;
+    draw_group(c0, cur);
+    for (int s0 = c0; s0 < c1; s0 += GS) {
+      if (s0 + GS < c1) draw_group(s0 + GS, nxt);  // its rows arrive under this group's per-parameter arithmetic
+#pragma unroll
+      for (int q = 0; q < GS; ++q) {
+        const int s = s0 + q;
+        if (s < c1) {  // (no `break`: the loop must unroll completely, or the group arrays are indexed dynamically and live in scratch)
+          const uint32_t step = (uint32_t)(a.step0 + s);
+          const size_t row = (size_t)s * a.N + c;
+          const int mcr = cur.mf[q] & 255, forced = cur.mf[q] >> 8;
+          const double CR = s_CR[mcr];  // (mcr + 1) / nCR
+          // ---- per-parameter draws ----
+          if (philox_normals && (s == 0 || (step & 3u) == 0u)) {
+            const uint32_t blk = (uint32_t)(a.delta + 1 + lane), quad = step >> 2;
+            q_mask = philox4x32_10(u32x4{blk, quad, gc, STREAM_DREAM_MASK}, k0, k1);
+            q_e = philox4x32_10(u32x4{blk, quad, gc, STREAM_DREAM_E}, k0, k1);
+            const u32x4 zz = philox4x32_10(u32x4{blk, quad, gc, STREAM_DREAM_EPS}, k0, k1);
+            normal_pair_f32(zz.x, zz.y, q_z[0], q_z[1]);
+            normal_pair_f32(zz.z, zz.w, q_z[2], q_z[3]);
+          }
+          double su = 2.0, eu = 0.5, en = 0.0;
+          if (lj) {
+            if (!philox_normals) {
+              if (real_chain) {
+                su = a.sub_rep[row * a.d + lane];
+                eu = a.e_rep[row * a.d + lane];
+                en = a.eps_rep[row * a.d + lane];
+              }
+            } else {
+              const uint32_t w = step & 3u;  // wave-uniform
+              su = u32_uniform(w == 0 ? q_mask.x : w == 1 ? q_mask.y : w == 2 ? q_mask.z : q_mask.w);
+              eu = u32_uniform(w == 0 ? q_e.x : w == 1 ? q_e.y : w == 2 ? q_e.z : q_e.w);
+              en = (double)(w == 0 ? q_z[0] : w == 1 ? q_z[1] : w == 2 ? q_z[2] : q_z[3]);
+            }
+            if (a.eps_export && real_chain) a.eps_export[row * a.d + lane] = en;
+          }
+          bool ind = lj && (su < CR);
+          unsigned long long bal = __ballot(ind);
+          if (CPW > 1) bal = (bal >> (seg * DPAD)) & ((1ull << (DPAD & 63)) - 1ull);  // this chain's lanes
+          int dsub = __popcll(bal);
+          if (dsub == 0) {  // proposal.py:838-839
+            ind = lane == forced;
+            dsub = 1;
+          }
+          const double gam = __shfl(gam_tab, seg * DPAD + dsub - 1);  // scaling * 2.38 / sqrt(2 delta d'), proposal.py:842-844
+          const double e = -a.b + (a.b - (-a.b)) * eu;
+          const double eps = 0.0 + a.b_star * en;
+          if (lane < DPAD) {
+            const double cf = ind ? (1.0 + e) * gam : 0.0, em = ind ? eps : 0.0;
+            const size_t o = ((size_t)s * a.NP + c) * DPAD + lane;
+            if (a.arch_shared) {
+              a.coef[o] = cf * cur.zd[q] + em;  // the jump itself (proposal.py:850-852)
+            } else {
+              a.coef[o] = cf;
+              a.epsm[o] = em;
+            }
+          }
+        }
+      }
+      cur = nxt;
     }
   }
-  if (lane == 0) a.mcr_last[c] = mcr;
 }
 
 enum : int { MODEL_LINEAR = 0, MODEL_ROSENBROCK = 1 };

@@ -140,12 +140,9 @@ def run_shared_dream(engine, n_iterations, sync_every, params=None, stats=None, 
             # ONE call: the engine cuts the run into `sync_every`-step blocks itself (tda_engine_set_proposal_dreamz), and a
             # call per block from here left the GPU idle a third of the time (C4: 29 us of host work per 117 us block)
             engine.set_archive_auto_append(True)
-            dz = getattr(engine, "_dz", {})
-            # the engine restarts full `sync_every` blocks after an adaptation boundary; the exchange below (and the N-rank
-            # path) keeps its exchange points at call-relative multiples of `sync_every`.  The two coincide -- and the result
-            # stays independent of the sharding -- when nothing adapts or the period is a multiple of the interval
-            aligned = not dz.get("adaptive") or dz.get("period", 0) % sync_every == 0
-            if dz.get("sync_every") == sync_every and aligned:
+            # (the engine's exchange points are the call-relative multiples of its interval, a block cut by an adaptation boundary
+            # is exchanged whole -- exactly what the loop further down does with several ranks -- so one call is the same run)
+            if getattr(engine, "_dz", {}).get("sync_every") == sync_every:
                 engine.run(n_iterations, params, stats, accepted)
                 return
             for done in range(0, n_iterations, sync_every):  # an interval other than the engine's own: block by block
