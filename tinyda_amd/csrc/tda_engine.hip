@@ -457,6 +457,10 @@ template <int DPAD>
 void launch_chol(const CholArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_chol<DPAD>, dim3((unsigned)a.N), dim3(64), 0, st, a);
 }
+template <int DPAD>
+void launch_chol_apply(const CholArgs& a, const ApplyArgs& ap, hipStream_t st) {
+  hipLaunchKernelGGL(k_chol_apply<DPAD>, dim3((unsigned)ap.NP), dim3(64), 0, st, a, ap);
+}
 
 // dynamic LDS of k_aem_inverse: the 16 x 16 blocks on or below the diagonal, row stride 17
 constexpr size_t aem_inverse_lds_bytes(int nb) { return (size_t)(nb * (nb + 1) / 2) * AEM_BS * sizeof(double); }
@@ -2715,6 +2719,7 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
   };
 
   int64_t done = 0, blk = 0;
+  bool inc_ready = false;  // the block about to start already has its increments (k_chol_apply of the block before it)
   if (split && n_iter > 0) {
     // everything queued on the main stream so far (init, earlier run() calls) precedes the first draw
     HIP_TRY(hipEventRecord(e->ev_steps[0], e->stream));
@@ -2731,18 +2736,19 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
     // ---- proposal increments + uniforms ----
     if (split) {
       const int b = (int)(blk & 1);
-      HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_rng[b], 0));
-      ApplyArgs ap{};
-      ap.NP = NP;
-      ap.S = (int)S;
-      ap.Lk = e->Lk.p;
-      ap.L_stride = e->L_shared ? 0 : (int64_t)e->DP * e->DP;
-      ap.zf = e->zfrag[b].p;
-      ap.inc = e->inc.p;
-      {
+      if (!inc_ready) {  // (after a covariance swap the previous block's k_chol_apply has produced this block's increments already)
+        HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_rng[b], 0));
+        ApplyArgs ap{};
+        ap.NP = NP;
+        ap.S = (int)S;
+        ap.Lk = e->Lk.p;
+        ap.L_stride = e->L_shared ? 0 : (int64_t)e->DP * e->DP;
+        ap.zf = e->zfrag[b].p;
+        ap.inc = e->inc.p;
         ScopedTimer tm(e, 0);
         DISPATCH_DPAD(e->DP, launch_apply<DPAD>(ap, e->stream));
       }
+      inc_ready = false;
       HIP_TRY(hipEventRecord(e->ev_apply[b], e->stream));
       u_blk = e->ublk2[b].p;
       lu_blk = e->lublk2[b].p;
@@ -2899,7 +2905,24 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
         ca.am_sigma = e->am_sigma.p;
         ca.Lk = e->Lk.p;
         ca.flags = e->flags.p;
-        DISPATCH_DPAD(e->DP, launch_chol<DPAD>(ca, e->stream));
+        static const bool fuse_ok = !(getenv("TINYDA_FUSE_CHOL_APPLY") && atoi(getenv("TINYDA_FUSE_CHOL_APPLY")) == 0);  // A/B switch
+        if (split && fuse_ok && done + S < n_iter) {
+          // ... and the next block's increments from the new factor in the same launch (k_chol_apply); that block's normals were
+          // drawn under this block's steps
+          const int nb = (int)((blk + 1) & 1);
+          HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_rng[nb], 0));
+          ApplyArgs ap{};
+          ap.NP = NP;
+          ap.S = (int)block_len(e->t + S, n_iter - done - S);
+          ap.Lk = e->Lk.p;
+          ap.L_stride = (int64_t)e->DP * e->DP;
+          ap.zf = e->zfrag[nb].p;
+          ap.inc = e->inc.p;
+          DISPATCH_DPAD(e->DP, launch_chol_apply<DPAD>(ca, ap, e->stream));
+          inc_ready = true;
+        } else {
+          DISPATCH_DPAD(e->DP, launch_chol<DPAD>(ca, e->stream));
+        }
       }
     } else if (boundary) {
       HIP_TRY(hipMemsetAsync(e->acc_count.p, 0, NP * sizeof(int32_t), e->stream));

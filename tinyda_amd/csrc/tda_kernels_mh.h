@@ -1056,11 +1056,10 @@ struct ApplyArgs {
 };
 
 template <int DPAD>
-__global__ void __launch_bounds__(64, 2) k_apply(const ApplyArgs a) {
+__device__ __forceinline__ void apply_chain(const ApplyArgs& a, const int64_t c) {
   constexpr int KK = DPAD / 4;
   constexpr int TJ = DPAD >= 16 ? DPAD / 16 : 1;
   const int lane = threadIdx.x, lc = lane & 15, hi = lane >> 4;
-  const int64_t c = blockIdx.x;
   double Lf[TJ][KK];  // B fragments, see k_propose
 #pragma unroll
   for (int tj = 0; tj < TJ; ++tj)
@@ -1098,6 +1097,11 @@ __global__ void __launch_bounds__(64, 2) k_apply(const ApplyArgs a) {
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) zf[kk] = zn[kk];
   }
+}
+
+template <int DPAD>
+__global__ void __launch_bounds__(64, 2) k_apply(const ApplyArgs a) {
+  apply_chain<DPAD>(a, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1396,11 +1400,9 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {  // wave-unifo
 // barriers.  Element (i, j) receives the subtractions fma(-L[i][k], L[j][k], .) for k = 0..j-1 in ascending order,
 // the same sequence as a left-looking dot product.
 template <int DPAD>
-__global__ void __launch_bounds__(64) k_chol(const CholArgs a) {
+__device__ __forceinline__ void chol_chain(const CholArgs& a, const int64_t c) {
   constexpr int NTL = am_tiles<DPAD>();
   const int lane = threadIdx.x;
-  const int64_t c = blockIdx.x;
-  if (c >= a.N) return;
   const bool lj = lane < a.d;
   const int li = lane < DPAD ? lane : DPAD - 1;
   double A[DPAD];
@@ -1436,6 +1438,33 @@ __global__ void __launch_bounds__(64) k_chol(const CholArgs a) {
   } else if (lane == 0) {
     atomicOr(&a.flags[c], 1);
   }
+}
+
+template <int DPAD>
+__global__ void __launch_bounds__(64) k_chol(const CholArgs a) {
+  if ((int64_t)blockIdx.x >= a.N) return;
+  chol_chain<DPAD>(a, blockIdx.x);
+}
+
+// C <- Sigma at a swap boundary AND the next block's increments INC = Z L^T in one launch, one wave per chain: the factor a
+// wave has just stored is read back as MFMA B fragments by the same wave (an L2 hit: nothing else touches that chain's factor;
+// the stores are complete and the wave's L1 view invalidated before the first load).  Against k_chol followed by k_apply this
+// saves a kernel boundary and the 134 MB the second kernel read from HBM, and it lets the two phases overlap ACROSS waves: the
+// Cholesky is bound by its chain of pivots (v_readlane -> sqrt -> divide, two waves per SIMD), the product by HBM (the
+// normals in, the increments out), and a wave in one phase no longer waits for every other wave to finish the other.
+template <int DPAD>
+__global__ void __launch_bounds__(64, 2) k_chol_apply(const CholArgs ca, const ApplyArgs ap) {
+  const int64_t c = blockIdx.x;
+  if (c < ca.N) {
+    chol_chain<DPAD>(ca, c);
+    // The wave reads back what it has just written itself: the stores only have to be complete (the vector L1 is write-through,
+    // and nothing on this CU has read these lines since the launch invalidated it).  Workgroup scope does exactly that; an
+    // AGENT-scope release / acquire pair writes back and invalidates the XCD's whole L2 per wave (the L2s of the eight XCDs are not
+    // coherent with each other) and made the launch 75 % slower than the two kernels it replaces.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  apply_chain<DPAD>(ap, c);  // (padding chains c >= N: their factor is whatever init left there, as for k_apply)
 }
 
 }  // namespace tda

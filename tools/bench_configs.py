@@ -169,6 +169,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] in ("c4", "c4peer", "c4peerlag"):
         run_c4(K=int(sys.argv[2]) if len(sys.argv) > 2 else 16, peer=sys.argv[1] != "c4", lag=sys.argv[1] == "c4peerlag")
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "c5":
+        run("C5-literal: MLDA AM 128/512/2048 obs, subchains [5,3], no AEM", (128, 512, 2048), [5, 3],
+            dict(kind=2, C_=1e-4 * np.eye(64), t0=100, period=100), 60)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "mala":
         run_mala()
         sys.exit(0)
