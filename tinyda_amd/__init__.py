@@ -3,7 +3,7 @@
 Drop-in for the hot path tda.sample() -> Chain.sample -> Proposal / Posterior / GaussianLogLike
 (tinyDA/sampler.py, chain.py, proposal.py, posterior.py, distributions.py); see DESIGN.md for the scope.
 """
-__version__ = "0.1.0"
+__version__ = "0.3.0"
 
 from ._lib import EngineError  # noqa: F401
 from .hostloop import Chain  # noqa: F401
@@ -26,5 +26,3 @@ from .proposals import (  # noqa: F401
 from .records import DeviceChain  # noqa: F401
 from .api import sample  # noqa: F401
 from .moments import RecursiveSampleMoments, ZeroMeanRecursiveSampleMoments  # noqa: F401
-from .compat import (  # noqa: F401
-    BlackBoxLinkFactory, CompositePrior, DAChain, LinkFactory, MLDAChain, SingleDreamZ, get_MAP, get_ML, grad_log_l, grad_log_p, to_xarray)
