@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _probe(what, env_extra, tmp_path, tag):
     out = str(tmp_path / ("%s_%s.npz" % (what, tag)))
     env = dict(os.environ)
-    for k in ("TINYDA_DA_LEAN", "TINYDA_DZ_WAVE", "TINYDA_DZ_PIPELINE", "TINYDA_AEMD_FUSED"):
+    for k in ("TINYDA_DA_LEAN", "TINYDA_DZ_WAVE", "TINYDA_DZ_PIPELINE", "TINYDA_AEMD_FUSED", "TINYDA_FUSE_CHOL_APPLY"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "switch_probe.py"), what, out], cwd=ROOT, env=env,
@@ -35,6 +35,16 @@ def test_pipelined_level_kernel_equals_the_generic_one(what, tmp_path):
         else:
             np.testing.assert_allclose(lean[k], generic[k], rtol=1e-10, atol=1e-12, err_msg=k)
     assert 0.02 < lean["acc0"].mean() < 0.98
+
+
+@pytest.mark.parametrize("what", ["am", "am_ragged"])
+def test_fused_swap_and_increments_equal_the_two_launches(what, tmp_path):
+    """k_chol_apply (covariance swap + the next block's increments in one launch, the factor read back from L2 by the wave that
+    wrote it) against k_chol followed by k_apply (TINYDA_FUSE_CHOL_APPLY=0): the same arithmetic, bit for bit, over five swaps"""
+    fused, split = _probe(what, {}, tmp_path, "fused"), _probe(what, {"TINYDA_FUSE_CHOL_APPLY": "0"}, tmp_path, "split")
+    for k in fused:
+        assert np.array_equal(fused[k], split[k]), k
+    assert 0.02 < fused["acc0"].mean() < 0.98 and np.abs(fused["C"]).max() > 0
 
 
 @pytest.mark.parametrize("what", ["dream", "dream_ragged"])

@@ -390,14 +390,16 @@ def _run_with_progress(eng, run, total, what):
 
     eng.set_progress(True)
     run()
-    last = -1
+    last, t_last = -1, time.time()
     while True:
         done, _, rate = eng.progress()
         if done != last:
             sys.stderr.write("\r%s: %d/%d iterations%s" % (what, done, total, "" if rate < 0 else ", acceptance %.2f" % rate))
             sys.stderr.flush()
-            last = done
+            last, t_last = done, time.time()
         if done >= total:
+            break
+        if time.time() - t_last > 600.0:  # nothing for ten minutes: let the synchronisation below report what the device says
             break
         time.sleep(0.02)
     sys.stderr.write("\n")

@@ -1,6 +1,6 @@
 """One seeded run of a configuration whose kernel choice an environment switch changes; records to an .npz.  The switches are
 read once per process, so A/B comparisons start this script twice (tests/test_gpu_switches.py).
-    python tools/switch_probe.py {mlda3|da2|aemd|aemd_lean|dream}[_ragged] out.npz     (_ragged: a chain count that is not a multiple of the 16-chain tile)"""
+    python tools/switch_probe.py {mlda3|da2|aemd|aemd_lean|dream|am}[_ragged] out.npz     (_ragged: a chain count that is not a multiple of the 16-chain tile)"""
 import os
 import sys
 
@@ -45,6 +45,22 @@ def dream(N=512, d=32, T=70, M0=64, K=16):
     return dict(params0=P, stats0=S, acc0=A, pCR=st["pCR"])
 
 
+def single_am(N=96, d=64, m=200, T=330):
+    """single-level AdaptiveMetropolis over several covariance swaps (k_chol_apply against k_chol + k_apply)"""
+    rng = np.random.default_rng(12)
+    A = rng.standard_normal((m, d)) / 8
+    truth = rng.standard_normal(d)
+    e = engine.Engine(N, d, seed=10)
+    e.set_prior(np.zeros(d), np.eye(d))
+    e.set_level(0, A, A @ truth + 0.1 * rng.standard_normal(m), 0, 0.01)
+    e.set_proposal(2, 1e-4 * np.eye(d), t0=60, period=60, adaptive=True)
+    e.init(truth + 0.05 * rng.standard_normal((N, d)))
+    P, S, Acc = e.run_host(T)
+    st = e.proposal_state(want_am=True)
+    e.close()
+    return dict(params0=P, stats0=S, acc0=Acc, C=st["C"], sigma=st["am_sigma"], scaling=st["scaling"])
+
+
 if __name__ == "__main__":
     _lib.load()
     what, out = sys.argv[1], sys.argv[2]
@@ -59,6 +75,8 @@ if __name__ == "__main__":
         res = hierarchy((200, 200, 200), [5, 3], "am", 8, N=96 - cut, error_model="state-independent-diagonal")
     elif what == "aemd_lean":  # at most 128 outputs: the base subchains are eligible for k_da_steps
         res = hierarchy((128, 128, 128), [5, 3], "am", 8, N=96 - cut, error_model="state-independent-diagonal")
+    elif what == "am":
+        res = single_am(N=96 - cut)
     else:
         res = dream(N=512 - cut)
     np.savez(out, **res)
