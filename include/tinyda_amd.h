@@ -173,7 +173,8 @@ typedef struct tda_profile {
 const char* tda_last_error(void);
 /* "tinyda_amd <abi>.<minor> (...)".  ABI history: 0.1 round 1; 0.2 tda_outputs.reserved became `rows` (a caller built against 0.1
  * that passes 0 with non-NULL buffers is refused with TDA_ERR_INVALID); 0.3 tda_release_cached_memory, tda_engine_set_record_thinning,
- * tda_engine_set_progress / get_progress, tda_engine_detach_proposal_state + tda_proposal_snapshot_*. */
+ * tda_engine_set_progress / get_progress, tda_engine_detach_proposal_state + tda_proposal_snapshot_*,
+ * tda_engine_set_proposal_spectrum. */
 const char* tda_version(void);
 
 /* Released engines park their large device buffers in a per-process pool (TINYDA_POOL_GB, default 8 GiB) so that the next
@@ -204,6 +205,12 @@ int tda_engine_set_proposal_dreamz(tda_engine* e, const tda_dreamz_params* p);
  * [dim][dim] row-major, what the reference computes in setup_proposal (:576-580: real(sqrtm(I - scaling B)), real(sqrtm(scaling B))).
  * Single-level chains with a linear forward model.  Call after set_proposal, before init. */
 int tda_engine_set_proposal_operators(tda_engine* e, const double* state_operator, const double* noise_operator);
+/* OperatorWeightedCrankNicolson with PER-CHAIN operators -- what adaptive=True needs (proposal.py:582-590: the operators are
+ * recomputed from the chain's own scaling every period).  For a symmetric B = V diag(lambda) V^T they are functions of the
+ * spectrum: sqrtm(I - s B) = V diag(sqrt(1 - s lambda)) V^T, sqrtm(s B) = V diag(sqrt(s lambda)) V^T (real parts).  V [dim][dim]
+ * row-major with the eigenvectors in its columns, lambda [dim]; HOST pointers; after set_proposal(kind = TDA_PROP_OWCN, scaling,
+ * adaptive, gamma, period), instead of set_proposal_operators.  Single level, linear forward model. */
+int tda_engine_set_proposal_spectrum(tda_engine* e, const double* V, const double* lambda);
 
 /* Initial archive Z (DREAMZ.setup_proposal, proposal.py:744-788): [n_chains][M0][dim] (per chain) or [M0][dim]
  * (shared).  NULL = draw the rows from the prior with RNG stream 2. Call after set_proposal_dreamz, before init. */

@@ -460,6 +460,7 @@ int tda_engine_get_profile(tda_engine* e, tda_profile* p) {
 #define TDA_CPU_UNSUPPORTED(what) return fail(TDA_ERR_UNSUPPORTED, what " is not part of the CPU twin of the ABI")
 int tda_engine_set_record_thinning(tda_engine*, int32_t thin) { if (thin == 1) return TDA_OK; TDA_CPU_UNSUPPORTED("record thinning"); }
 int tda_engine_set_progress(tda_engine*, int) { TDA_CPU_UNSUPPORTED("progress reporting"); }
+int tda_engine_set_proposal_spectrum(tda_engine*, const double*, const double*) { TDA_CPU_UNSUPPORTED("operator-weighted pCN"); }
 int tda_engine_detach_proposal_state(tda_engine*, tda_proposal_snapshot**) { TDA_CPU_UNSUPPORTED("proposal snapshots"); }
 int tda_proposal_snapshot_read(tda_proposal_snapshot*, double*, double*, double*, double*, int64_t*) { TDA_CPU_UNSUPPORTED("proposal snapshots"); }
 void tda_proposal_snapshot_destroy(tda_proposal_snapshot*) {}

@@ -107,6 +107,7 @@ SYMBOLS = {
     "tda_engine_set_proposal": (C.c_int, [_P, C.POINTER(tda_proposal_params)]),
     "tda_engine_set_proposal_dreamz": (C.c_int, [_P, C.POINTER(tda_dreamz_params)]),
     "tda_engine_set_proposal_operators": (C.c_int, [_P, _P, _P]),
+    "tda_engine_set_proposal_spectrum": (C.c_int, [_P, _P, _P]),
     "tda_engine_set_archive": (C.c_int, [_P, _P]),
     "tda_engine_set_level_rosenbrock": (C.c_int, [_P, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]),
     "tda_engine_set_replay_dreamz": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int64]),

@@ -78,9 +78,11 @@ def _device_plan(posteriors, proposal, diagonal_error_model=False):
     if isinstance(proposal, MALA):  # exact gradient of a linear-Gaussian posterior: single level, linear model, Gaussian prior
         if len(posteriors) != 1 or "source" in lows[0] or "batched" in lows[0] or "rosenbrock" in lows[0] or "prior_joint" in lows[0]:
             return None
-    if isinstance(proposal, OperatorWeightedCrankNicolson):  # fixed operators, single level; linear, callback or source-defined model
+    if isinstance(proposal, OperatorWeightedCrankNicolson):  # single level; fixed operators: linear, callback or source-defined model
         if len(posteriors) != 1 or proposal._lowering() is None or "rosenbrock" in lows[0] or "prior_joint" in lows[0]:
             return None
+        if proposal.adaptive and ("source" in lows[0] or "batched" in lows[0]):
+            return None  # per-chain operators (the spectrum of B) are lowered for linear models
     if isinstance(proposal, IndependenceSampler):  # Gaussian q, single level; linear, callback or source-defined model
         if len(posteriors) != 1 or proposal._lowering() is None or "rosenbrock" in lows[0]:
             return None

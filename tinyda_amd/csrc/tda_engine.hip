@@ -274,6 +274,11 @@ struct tda_engine {
   std::vector<double> prop_C_h, q_mean_h;  // q_mean_h: independence sampler
   std::vector<double> ow_state_h, ow_noise_h;  // OperatorWeightedCrankNicolson operators [d][d]
   DevBuf<double> ow_SopT;                      // state operator, transposed and padded: [DP][DP], SopT[j][i] = S[i][j]
+  // OperatorWeightedCrankNicolson with per-chain operators (tda_engine_set_proposal_spectrum): B = V diag(lambda) V^T
+  bool ow_spectral = false;
+  double ow_scaling0 = 1.0;
+  std::vector<double> ow_V_h, ow_lam_h;        // V [d][d] row-major (columns = eigenvectors), lambda [d]
+  DevBuf<double> ow_VVt, ow_lam;               // [2][DP][DP]: V, then V^T; [DP]
   DevBuf<double> mala_H, mala_c, mala_grad;    // MALA: H [DP][DP] (symmetric), c [DP], grad log post of the current states [NP][DP]
   DevBuf<double> q_mean_d, lq, qzblk, qzblk2[2];
   double am_sd = 1.0;
@@ -409,9 +414,11 @@ void launch_steps(const StepArgs& a, int64_t tiles, size_t lds, hipStream_t st) 
   // dense noise keeps a 128 KiB residual tile and long MFMA chains per wave: 4 waves (512 registers) there
   const bool eight = g_steps_waves == 8 && a.lv.noise_kind != TDA_NOISE_DENSE;
   const bool ind = a.prop_kind == TDA_PROP_INDEPENDENCE;
-  const bool ow = a.prop_kind == TDA_PROP_OWCN && a.mode == MODE_STEP;  // + current-state tile and the state operator in LDS
+  const bool os = a.prop_kind == TDA_PROP_OWCN && a.mode == MODE_STEP && a.cvec != nullptr;  // per-chain operators from the spectrum of B
+  const bool ow = a.prop_kind == TDA_PROP_OWCN && a.mode == MODE_STEP && !os;  // + current-state tile and the state operator in LDS
   const bool ma = a.prop_kind == TDA_PROP_MALA && a.mode == MODE_STEP;  // + the gradient operator and 32 transition-density slots
   if (ow || ma) lds += ((size_t)16 * (DPAD + 2) + (size_t)DPAD * DPAD) * sizeof(double);
+  if (os) lds += ((size_t)16 * (DPAD + 2) + (size_t)2 * DPAD * DPAD) * sizeof(double);
   auto go = [&](auto kern, unsigned threads, size_t bytes) {
     if (bytes > 64 * 1024)  // beyond the default dynamic-LDS window (gfx950 has 160 KiB per CU)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -421,11 +428,13 @@ void launch_steps(const StepArgs& a, int64_t tiles, size_t lds, hipStream_t st) 
     const size_t l8 = lds + 2 * 64 * sizeof(double);  // two more [4][16] reduction slabs
     if (ind) go(&k_mh_steps<DPAD, 8, true>, 512, l8);
     else if (ow) go(&k_mh_steps<DPAD, 8, false, 1>, 512, l8);
+    else if (os) go(&k_mh_steps<DPAD, 8, false, 3>, 512, l8);
     else if (ma) go(&k_mh_steps<DPAD, 8, false, 2>, 512, l8);
     else go(&k_mh_steps<DPAD, 8, false>, 512, l8);
   } else {
     if (ind) go(&k_mh_steps<DPAD, 4, true>, 256, lds);
     else if (ow) go(&k_mh_steps<DPAD, 4, false, 1>, 256, lds);
+    else if (os) go(&k_mh_steps<DPAD, 4, false, 3>, 256, lds);
     else if (ma) go(&k_mh_steps<DPAD, 4, false, 2>, 256, lds);
     else go(&k_mh_steps<DPAD, 4, false>, 256, lds);
   }

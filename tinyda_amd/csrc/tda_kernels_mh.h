@@ -465,9 +465,15 @@ __host__ __device__ constexpr int steps_lds_doubles(int m_pad, bool diag, int pr
 // d x d product from LDS (the operator sits where S^T does) instead of a second pass over the observations; the
 // gradient at the current state is chain state.  The two transition densities reach the lane-mapped accept test
 // through 32 LDS slots.
+// PX = 3: OperatorWeightedCrankNicolson with PER-CHAIN operators (adaptive scaling, proposal.py:582-590).  For a symmetric
+// B = V diag(lambda) V^T the operators of a chain with scaling s are functions of the spectrum,
+//   sqrtm(I - s B) = V diag(sqrt(1 - s lambda)) V^T,   sqrtm(s B) = V diag(sqrt(s lambda)) V^T   (real parts: negative arguments -> 0),
+// so the chain state is also carried in eigen-coordinates e = V^T theta: e' = a . e + b . w with w = V^T chol(C_prior) z (the
+// increment block, shared factor) and theta' = V e' -- ONE d x d product per step from LDS, like PX = 1, and no matrix square
+// root per chain and period.  SopT = [V row-major | V^T row-major], cvec = lambda.
 template <int DPAD, int NW, bool IND = false, int PX = 0>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) {
-  constexpr bool OW = PX == 1, MA = PX == 2;
+  constexpr bool OW = PX == 1, MA = PX == 2, OS = PX == 3;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int KS = DPAD / 4;
   constexpr int LDP = DPAD + 2;  // row stride: conflict-free ds_read_b64 fragment gather
@@ -489,7 +495,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
   double* s_py = s_w + (diag ? a.lv.m_pad : 0);
   double* s_R = s_py + (prior_dense ? a.pr.ncb * 16 : 0);
   double* s_cur = s_R + (dense ? 16 * RS : 0);  // OW: current states [16][LDP]; MALA: [0..32) the transition densities
-  double* s_S = s_cur + 16 * LDP;               // OW: S^T [DPAD][DPAD]; MALA: H
+  double* s_S = s_cur + 16 * LDP;               // OW: S^T [DPAD][DPAD]; MALA: H; OS: V [DPAD][DPAD], then V^T [DPAD][DPAD]
 
   // the step kernel is the critical path: kernels that share its SIMDs (k_rng on the second stream) only get the
   // issue slots it leaves empty
@@ -527,7 +533,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
   const double keep_t = a.prop_kind == 1 ? sqrt(1.0 - scal_t * scal_t) : 1.0;  // proposal.py:351-352
   int nacc = 0;
   const bool is_eval = a.mode == MODE_EVAL;
-  const bool is_pcn = a.prop_kind == 1 || OW;  // OperatorWeightedCrankNicolson inherits pCN's likelihood-ratio acceptance
+  const bool is_pcn = a.prop_kind == 1 || OW || OS;  // OperatorWeightedCrankNicolson inherits pCN's likelihood-ratio acceptance
   constexpr bool is_ind = IND;  // IndependenceSampler (proposal.py:65-129)
   double qm[EPT];
 #pragma unroll
@@ -558,14 +564,33 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
   }
   const double sig_t = scal_t, half_s2 = 0.5 * sig_t * sig_t;  // thread-mapped chain: 0.5 * scaling**2 (proposal.py:953)
   const double sig_l = MA ? a.scaling[gcl] : 1.0;              // lane-mapped chain
-  if constexpr (OW || MA) {
-    for (int i = tid; i < DPAD * DPAD; i += NT) s_S[i] = a.SopT[i];
-    if (OW && active) {
+  if constexpr (OW || MA || OS) {
+    for (int i = tid; i < (OS ? 2 : 1) * DPAD * DPAD; i += NT) s_S[i] = a.SopT[i];
+    if ((OW || OS) && active) {
 #pragma unroll
       for (int e = 0; e < EPT; ++e) s_cur[c * LDP + q * EPT + e] = cur[e];
     }
   }
   __syncthreads();
+  double ecur[EPT], eprp[EPT], oa[EPT], ob[EPT];  // OS: state / proposal in eigen-coordinates, this chain's jump coefficients
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) ecur[e] = eprp[e] = oa[e] = ob[e] = 0.0;
+  if constexpr (OS) {
+    if (active) {
+      for (int j = 0; j < DPAD; ++j) {  // e = V^T theta: e[i] = sum_j V[j][i] theta[j] (consecutive threads, consecutive i)
+        const double tj = s_cur[c * LDP + j];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) ecur[e] = fma(s_S[j * DPAD + q * EPT + e], tj, ecur[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const double sl = scal_t * a.cvec[q * EPT + e];
+        oa[e] = sqrt(fmax(0.0, 1.0 - sl));
+        ob[e] = sqrt(fmax(0.0, sl));
+      }
+    }
+    __syncthreads();  // s_cur is the exchange tile of the step loop from here on
+  }
 
   if constexpr (!PAIRS) frag_load_buf<DPAD>(frag_src(a.lv.Apk, lane), wave < a.lv.ncb ? wave : a.lv.ncb - 1, f0);  // later steps: prefetched by the previous step
   // cycle stamps for tools/steps_microbench.hip: compiled in only on request, because even a never-taken s_memtime
@@ -604,6 +629,30 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
           prp[e] = st[e] + xin[e];
+          s_prop[c * LDP + q * EPT + e] = prp[e];
+        }
+      }
+    } else if constexpr (OS) {
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          eprp[e] = oa[e] * ecur[e] + ob[e] * xin[e];
+          s_cur[c * LDP + q * EPT + e] = eprp[e];
+        }
+      }
+      __syncthreads();
+      if (active) {
+        double st[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) st[e] = 0.0;
+        for (int i = 0; i < DPAD; ++i) {  // theta'[k] = sum_i V[k][i] e'[i], read from V^T: consecutive threads, consecutive k
+          const double ei = s_cur[c * LDP + i];
+#pragma unroll
+          for (int e = 0; e < EPT; ++e) st[e] = fma(s_S[DPAD * DPAD + i * DPAD + q * EPT + e], ei, st[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          prp[e] = st[e];
           s_prop[c * LDP + q * EPT + e] = prp[e];
         }
       }
@@ -795,6 +844,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
 #pragma unroll
       for (int e = 0; e < EPT; ++e) {
         cur[e] = accf ? prp[e] : cur[e];
+        if constexpr (OS) ecur[e] = accf ? eprp[e] : ecur[e];
         if constexpr (OW) s_cur[c * LDP + q * EPT + e] = cur[e];
         if constexpr (MA) gcur[e] = accf ? gprp[e] : gcur[e];
         const int j = q * EPT + e;

@@ -109,7 +109,7 @@ class Engine:
         self._ck(self.lib.tda_engine_set_level(self.h, level, m, _ptr(A), _ptr(b), _ptr(data), noise_kind, _ptr(noise)))
 
     def set_proposal(self, kind, C_=None, scaling=1.0, adaptive=False, gamma=1.01, period=100, sd=None,
-                     epsilon=1e-6, t0=0, block_moments=False, q_mean=None, state_operator=None, noise_operator=None):
+                     epsilon=1e-6, t0=0, block_moments=False, q_mean=None, state_operator=None, noise_operator=None, spectrum=None):
         Cm = None if C_ is None else _f64(C_)
         p = _lib.tda_proposal_params(C.sizeof(_lib.tda_proposal_params), kind, scaling, int(adaptive), period, gamma,
                                      _ptr(Cm), -1.0 if sd is None else sd, epsilon, t0, int(block_moments),
@@ -119,6 +119,10 @@ class Engine:
             So, No = _f64(state_operator), _f64(noise_operator)
             assert So.shape == (self.dim, self.dim) and No.shape == (self.dim, self.dim)
             self._ck(self.lib.tda_engine_set_proposal_operators(self.h, _ptr(So), _ptr(No)))
+        if spectrum is not None:  # OperatorWeightedCrankNicolson with per-chain operators: B = V diag(lam) V^T, V's columns the eigenvectors
+            V, lam = _f64(spectrum[0]), _f64(spectrum[1])
+            assert V.shape == (self.dim, self.dim) and lam.shape == (self.dim,)
+            self._ck(self.lib.tda_engine_set_proposal_spectrum(self.h, _ptr(V), _ptr(lam)))
 
     def set_prior_joint(self, kinds, loc, scale):
         """JointPrior of scalar components: kinds[j] 0 = norm(loc, scale), 1 = uniform(loc, scale)"""

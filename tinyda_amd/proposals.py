@@ -154,7 +154,8 @@ class CrankNicolson(GaussianRandomWalk):
 class OperatorWeightedCrankNicolson(CrankNicolson):
     """Operator-weighted pCN (Law 2014): theta' = sqrtm(I - scaling B) theta + sqrtm(scaling B) N(0, C_prior), acceptance on
     the likelihood ratio (proposal.py:515-605).  The operators are recomputed when the adaptive scaling changes.  On the
-    device path the (non-adaptive) operators are handed to the engine: single-level chains, linear forward model."""
+    device path the fixed operators are handed to the engine; with adaptive=True and a symmetric B the engine gets B's spectrum and
+    works the per-chain operators out from each chain's own scaling (single-level chains, linear forward model)."""
 
     def __init__(self, B, scaling=1.0, adaptive=False, gamma=1.01, period=100):
         self.B = B
@@ -186,7 +187,14 @@ class OperatorWeightedCrankNicolson(CrankNicolson):
 
     def _lowering(self):
         if self.adaptive:
-            return None  # per-chain operators would need a matrix square root per chain and period: host protocol
+            # per-chain operators (every chain adapts its own scaling): for a symmetric B they are functions of its spectrum,
+            # which is what the engine takes (tda_engine_set_proposal_spectrum); any other B: host protocol
+            B = np.atleast_2d(np.asarray(self.B, dtype=np.float64))
+            if B.shape[0] != B.shape[1] or not np.allclose(B, B.T, rtol=1e-12, atol=1e-14):
+                return None
+            lam, V = np.linalg.eigh(0.5 * (B + B.T))
+            return dict(kind=_lib.PROP_OWCN, C_=None, scaling=float(self.scaling), adaptive=True, gamma=float(self.gamma),
+                        period=int(self.period), spectrum=(np.ascontiguousarray(V), np.ascontiguousarray(lam)))
         self._operators()
         return dict(kind=_lib.PROP_OWCN, C_=None, scaling=1.0, adaptive=False, gamma=float(self.gamma), period=int(self.period),
                     state_operator=np.ascontiguousarray(self.state_operator, dtype=np.float64),
