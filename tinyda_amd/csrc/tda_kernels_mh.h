@@ -577,6 +577,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
   for (int e = 0; e < EPT; ++e) ecur[e] = eprp[e] = oa[e] = ob[e] = 0.0;
   if constexpr (OS) {
     if (active) {
+#pragma unroll 4
       for (int j = 0; j < DPAD; ++j) {  // e = V^T theta: e[i] = sum_j V[j][i] theta[j] (consecutive threads, consecutive i)
         const double tj = s_cur[c * LDP + j];
 #pragma unroll
@@ -645,6 +646,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_mh_steps(const StepArgs a) 
         double st[EPT];
 #pragma unroll
         for (int e = 0; e < EPT; ++e) st[e] = 0.0;
+#pragma unroll 4
         for (int i = 0; i < DPAD; ++i) {  // theta'[k] = sum_i V[k][i] e'[i], read from V^T: consecutive threads, consecutive k
           const double ei = s_cur[c * LDP + i];
 #pragma unroll
