@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 python -u -m pytest tests -x -q -m gpu > gpurun_out/r03_gputests.log 2>&1; echo "tests rc=$?" | tee -a gpurun_out/r03_progress.log
 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r03_bench.json 2> gpurun_out/r03_bench.err; echo "bench rc=$?" | tee -a gpurun_out/r03_progress.log
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r03 -- python3 $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > /tmp/prof_r03.log 2>&1; find /tmp/prof_r03 -name "*kernel_stats.csv" -exec cp {} $GRAFT_REPO_ROOT/gpurun_out/r03_kernel_stats.csv \; ; tail -1 /tmp/prof_r03.log | cut -c1-300 > $GRAFT_REPO_ROOT/gpurun_out/r03_bench_under_rocprof.json)
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r03 -- python3 $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > /tmp/prof_r03.log 2>&1; find /tmp/prof_r03 -name "*kernel_stats.csv" -exec cp {} $GRAFT_REPO_ROOT/gpurun_out/r03_kernel_stats.csv \; ; grep '^{"metric"' /tmp/prof_r03.log | cut -c1-400 > $GRAFT_REPO_ROOT/gpurun_out/r03_bench_under_rocprof.json)
 echo "rocprof done" | tee -a gpurun_out/r03_progress.log
 PMC_OUT=r03_pmc_traffic.json bash tools/pmc_traffic.sh > gpurun_out/r03_pmc.log 2>&1; echo "pmc rc=$?" | tee -a gpurun_out/r03_progress.log
 python -u tools/api_rate.py 2000 6 > gpurun_out/r03_api.json 2> gpurun_out/r03_api.err; echo "api rc=$?" | tee -a gpurun_out/r03_progress.log
