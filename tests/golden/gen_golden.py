@@ -619,17 +619,29 @@ def g6_dreamz(name, problem, d, M0, delta, nCR, adaptive, period, iters, n_chain
 
 
 
-def g15_hier_dreamz(name, ms, sl, d=5, M0=24, delta=1, nCR=3, adaptive=True, period=6, iters=30, n_chains=3, seed=1501):
+def g15_hier_dreamz(name, ms, sl, d=5, M0=24, delta=1, nCR=3, adaptive=True, period=6, iters=30, n_chains=3, seed=1501, randomize=False,
+                    aem=None):
     """DREAMZ as the base proposal of Delayed Acceptance (2 levels, DAChain) / MLDA (3 levels, MLDAChain): the configuration of
     the reference's own MLDA notebook (examples/Multilevel Delayed Acceptance.ipynb cells 20-23)."""
     sigma = 0.2
-    As, ys, theta_true, pm, pc = _ml_problem(seed, d, ms, sigma)
-    prior = stats.multivariate_normal(pm, pc)
-    posts = [tda.Posterior(prior, tda.GaussianLogLike(y, sigma ** 2 * np.eye(len(y))), make_model(A)) for A, y in zip(As, ys)]
+    nl = len(ms)
+    bs = None
+    if aem is None:
+        As, ys, theta_true, pm, pc = _ml_problem(seed, d, ms, sigma)
+        prior = stats.multivariate_normal(pm, pc)
+        posts = [tda.Posterior(prior, tda.GaussianLogLike(y, sigma ** 2 * np.eye(len(y))), make_model(A)) for A, y in zip(As, ys)]
+    else:  # adaptive error model: the levels share the observation vector, the coarse likelihoods are adaptive (chain.py:268-305)
+        assert len(set(ms)) == 1
+        As, bs, y, theta_true = _aem_problem(seed, d, ms[0], nl, sigma)
+        ys = [y] * nl
+        pm, pc = np.zeros(d), np.eye(d)
+        prior = stats.multivariate_normal(pm, pc)
+        cov = sigma ** 2 * np.eye(ms[0])
+        posts = [tda.Posterior(prior, tda.AdaptiveGaussianLogLike(y, cov) if k < nl - 1 else tda.GaussianLogLike(y, cov),
+                               make_model(As[k], bs[k])) for k in range(nl)]
     rng = np.random.default_rng(seed + 1)
     theta0 = theta_true[None] + 0.2 * rng.standard_normal((n_chains, d))
-    nl = len(ms)
-    out = {k: [] for k in ("Z0", "r", "mcr", "sub_u", "forced", "e_u", "eps_n", "u0", "pCR", "scaling")}
+    out = {k: [] for k in ("Z0", "r", "mcr", "sub_u", "forced", "e_u", "eps_n", "u0", "pCR", "scaling", "ridx")}
     for k in range(nl):
         for key in ("th", "lp", "ll", "acc"):
             out["%s%d" % (key, k)] = []
@@ -640,9 +652,11 @@ def g15_hier_dreamz(name, ms, sl, d=5, M0=24, delta=1, nCR=3, adaptive=True, per
         prop = tda.DREAMZ(M0, delta=delta, Z_method="random", nCR=nCR, adaptive=adaptive, gamma=1.02, period=period)
         with Tap(seed + 50 * c) as tap:
             if nl == 2:
-                ch = tda.DAChain(copy.deepcopy(posts[0]), copy.deepcopy(posts[1]), prop, sl[0], initial_parameters=theta0[c].copy())
+                ch = tda.DAChain(copy.deepcopy(posts[0]), copy.deepcopy(posts[1]), prop, sl[0], randomize_subchain_length=randomize,
+                                 initial_parameters=theta0[c].copy(), adaptive_error_model=aem)
             else:
-                ch = tda.MLDAChain([copy.deepcopy(p) for p in posts], prop, list(sl), initial_parameters=theta0[c].copy())
+                ch = tda.MLDAChain([copy.deepcopy(p) for p in posts], prop, list(sl), initial_parameters=theta0[c].copy(),
+                                   adaptive_error_model=aem)
             base = ch.proposal if nl == 2 else None
             ch.sample(iters, progressbar=False)
         if nl == 2:
@@ -677,7 +691,7 @@ def g15_hier_dreamz(name, ms, sl, d=5, M0=24, delta=1, nCR=3, adaptive=True, per
         it = iter(tap.log)
         R, MC, SU, FO, EU, EN, U = [], [], [], [], [], [], []
         for kind, v in it:
-            if kind == "u":
+            if kind in ("u", "randint"):  # an upper level's uniform / the promoted index of a randomised subchain (chain.py:525-527)
                 continue
             assert kind == "choice" and np.size(v) == 2
             rr = [np.array(v)]
@@ -718,15 +732,22 @@ def g15_hier_dreamz(name, ms, sl, d=5, M0=24, delta=1, nCR=3, adaptive=True, per
             nsteps = len(traces[k][3]) - (1 if k == nl - 1 else 0)
             evaluated = below.reshape(nsteps, sl[k - 1]).sum(axis=1) > 0
             out["u%d" % k].append(_place(us[k], evaluated))
+            if k == 1:
+                rr_ = tap.take("randint")
+                out["ridx"].append(_place([int(x) for x in rr_], evaluated) if randomize else np.full(nsteps, -1.0))
         out["pCR"].append(np.array(base_prop.pCR))
         out["scaling"].append(float(base_prop.scaling))
     lv = {}
     for k in range(nl):
         lv["A%d" % k] = As[k]
         lv["y%d" % k] = ys[k]
+        if bs is not None:
+            lv["b%d" % k] = bs[k]
+    if aem is not None:
+        lv["aem"] = np.array(aem)
     save(name, noise_var=np.array(sigma ** 2), prior_mean=pm, prior_cov=pc, theta0=theta0, subchain_lengths=np.array(sl),
          n_levels=np.array(nl), M0=np.array(M0), delta=np.array(delta), nCR=np.array(nCR), adaptive=np.array(adaptive),
-         period=np.array(period), gamma=np.array(1.02), b=np.array(5e-2), b_star=np.array(1e-6), **lv,
+         period=np.array(period), gamma=np.array(1.02), b=np.array(5e-2), b_star=np.array(1e-6), randomize=np.array(randomize), **lv,
          **{k: np.array(v) for k, v in out.items()})
 
 
@@ -992,6 +1013,10 @@ FIXTURES = {
     "g5_mlda_4level": lambda: g5_mlda("g5_mlda_4level", "am", ms=(6, 10, 16, 24), sl=(3, 2, 2), iters=20, period=10, seed=503),
     "g15_da_dreamz": lambda: g15_hier_dreamz("g15_da_dreamz", ms=(10, 24), sl=(3,), seed=1501),
     "g15_mlda_dreamz": lambda: g15_hier_dreamz("g15_mlda_dreamz", ms=(8, 14, 24), sl=(3, 2), iters=20, seed=1502),
+    "g15_da_dreamz_random": lambda: g15_hier_dreamz("g15_da_dreamz_random", ms=(10, 24), sl=(4,), seed=1503, randomize=True),
+    "g15_da_dreamz_aem": lambda: g15_hier_dreamz("g15_da_dreamz_aem", ms=(8, 8), sl=(3,), seed=1504, aem="state-independent"),
+    "g15_da_dreamz_aem_dep": lambda: g15_hier_dreamz("g15_da_dreamz_aem_dep", ms=(8, 8), sl=(2,), seed=1505, aem="state-dependent"),
+    "g15_mlda_dreamz_aem": lambda: g15_hier_dreamz("g15_mlda_dreamz_aem", ms=(8, 8, 8), sl=(3, 2), iters=20, seed=1506, aem="state-independent"),
     "g7_moments": g7_moments,
     "g16_get_samples": g16_get_samples,
     "g9_mvn_logpdf": g9_mvn_logpdf,

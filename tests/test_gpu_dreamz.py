@@ -254,7 +254,10 @@ def test_sample_api_dreamz_with_uniform_prior_components():
     assert np.mean([np.mean(res["chain_%d" % i].accepted[1:]) for i in range(12)]) > 0.01
 
 
-@pytest.mark.parametrize("name,block", [("g15_da_dreamz", 0), ("g15_da_dreamz", 5), ("g15_mlda_dreamz", 0), ("g15_mlda_dreamz", 7)])
+@pytest.mark.parametrize("name,block", [("g15_da_dreamz", 0), ("g15_da_dreamz", 5), ("g15_mlda_dreamz", 0), ("g15_mlda_dreamz", 7),
+                                        ("g15_da_dreamz_random", 0), ("g15_da_dreamz_random", 6),
+                                        ("g15_da_dreamz_aem", 0), ("g15_da_dreamz_aem", 5), ("g15_da_dreamz_aem_dep", 0), ("g15_mlda_dreamz_aem", 0),
+                                        ("g15_mlda_dreamz_aem", 7)])
 def test_dreamz_below_a_hierarchy_replay(eng_mod, golden, name, block):
     """DREAMZ as the base proposal of Delayed Acceptance / MLDA (the reference's MLDA notebook configuration,
     examples/Multilevel Delayed Acceptance.ipynb cells 20-23; proposal.py:1583-1613, chain.py:404-444) on the device: traces
@@ -268,17 +271,26 @@ def test_dreamz_below_a_hierarchy_replay(eng_mod, golden, name, block):
     T0 = g["u0"].shape[1]
     e = eng_mod.Engine(N, d, seed=11, n_levels=nl, block_steps=block)
     e.set_prior(g["prior_mean"], g["prior_cov"])
+    aem = str(g["aem"]) if "aem" in g.files else None  # round 3: DREAMZ below DA / MLDA with the (dense) adaptive error model
     for k in range(nl):
-        e.set_level(k, g["A%d" % k], g["y%d" % k], 0, float(g["noise_var"]))
+        if aem is not None and k < nl - 1:  # AdaptiveGaussianLogLike on the coarse levels (chain.py:268-305)
+            e.set_level(k, g["A%d" % k], g["y%d" % k], 3, float(g["noise_var"]) * np.eye(len(g["y%d" % k])), b=g["b%d" % k])
+        else:
+            e.set_level(k, g["A%d" % k], g["y%d" % k], 0, float(g["noise_var"]), b=g["b%d" % k] if aem is not None else None)
     e.set_proposal_dreamz(int(g["M0"]), delta=int(g["delta"]), b=float(g["b"]), b_star=float(g["b_star"]), nCR=int(g["nCR"]),
                           adaptive=bool(g["adaptive"]), gamma=float(g["gamma"]), period=int(g["period"]), capacity=int(g["M0"]) + T0)
-    e.set_subchains(sl)
+    randomize = bool(g["randomize"])  # round 3: DREAMZ below Delayed Acceptance with randomize_subchain_length (chain.py:525-527)
+    e.set_subchains(sl, randomize)
+    if aem is not None:
+        e.set_error_model(aem)
     e.set_archive(g["Z0"])
     e.init(g["theta0"])
     sw = lambda a: np.ascontiguousarray(np.swapaxes(a, 0, 1))
     e.set_replay_dreamz(sw(g["r"]), sw(g["mcr"]), sw(g["sub_u"]), sw(g["forced"]), sw(g["e_u"]), sw(g["eps_n"]), sw(g["u0"]))
     for k in range(1, nl):
         e.set_replay_level(k, sw(g["u%d" % k]))
+    if randomize:
+        e.set_replay_level(-1, sw(g["ridx"]))
     outs = e.run_levels_host(n_fine)
     for k in range(nl):
         p, s_, a = outs[k]
@@ -292,6 +304,34 @@ def test_dreamz_below_a_hierarchy_replay(eng_mod, golden, name, block):
     np.testing.assert_allclose(st["pCR"], g["pCR"], rtol=1e-8)
     assert st["archive_rows"] == int(g["M0"]) + T0
     e.close()
+
+
+def test_sample_dreamz_below_da_with_error_model_and_randomised_subchains():
+    """sample([adaptive coarse, fine], DREAMZ(...), adaptive_error_model=..., randomize_subchain_length=...) stays on the device
+    (round 3; the replays above pin the arithmetic on tinyDA's traces)"""
+    import scipy.stats as stats
+
+    import tinyda_amd as tda
+
+    rng = np.random.default_rng(4)
+    d, m = 5, 12
+    Af = rng.standard_normal((m, d)) / np.sqrt(d)
+    truth = rng.standard_normal(d)
+    y = Af @ truth + 0.2 * rng.standard_normal(m)
+    prior = stats.multivariate_normal(np.zeros(d), np.eye(d))
+    cov = 0.04 * np.eye(m)
+    coarse = tda.Posterior(prior, tda.AdaptiveGaussianLogLike(y, cov), tda.LinearModel(Af + 0.1 * rng.standard_normal((m, d)), 0.05 * rng.standard_normal(m)))
+    fine = tda.Posterior(prior, tda.GaussianLogLike(y, cov), tda.LinearModel(Af))
+    res = tda.sample([coarse, fine], tda.DREAMZ(30, adaptive=True, period=20), 60, n_chains=16, subchain_length=4, seed=3,
+                     adaptive_error_model="state-independent", backend="hip")
+    assert res["sampler"] == "DA" and res["backend"] == "hip" and len(res["chain_fine_0"]) == 61 and len(res["chain_coarse_15"]) == 240
+    link = res["chain_fine_3"][-1]
+    np.testing.assert_allclose(link.likelihood, fine.create_link(link.parameters).likelihood, rtol=1e-10)
+    plain = tda.Posterior(prior, tda.GaussianLogLike(y, cov), coarse.model)
+    res = tda.sample([plain, fine], tda.DREAMZ(30), 40, n_chains=16, subchain_length=5, randomize_subchain_length=True, seed=3, backend="hip")
+    assert res["backend"] == "hip" and len(res["chain_fine_0"]) == 41
+    acc = np.mean([res["chain_fine_%d" % i].accepted[1:].mean() for i in range(16)])
+    assert 0.02 < acc < 0.98
 
 
 def test_sample_dreamz_below_mlda_on_device():

@@ -274,8 +274,8 @@ def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None
     if diag_aem and adaptive_error_model != "state-independent":
         raise ValueError("the diagonal error model is state-independent")
     plan = None if backend == "host" else _device_plan(posteriors, proposal, diag_aem)
-    if plan is not None and isinstance(proposal, DREAMZ) and n_levels > 1 and (adaptive_error_model is not None or randomize_subchain_length):
-        plan = None  # not lowered: host protocol under 'auto'
+    if plan is not None and isinstance(proposal, DREAMZ) and n_levels > 1 and diag_aem:
+        plan = None  # (DREAMZ below a hierarchy runs with the reference's dense error model; the diagonal extension: host protocol)
     if plan is None and backend != "host" and n_levels > 1:
         # Delayed Acceptance / MLDA over opaque Python models (plain callables theta -> ndarray, the reference's everyday
         # case): the engine needs the outputs of all chains per level step, so a plain callable is evaluated chain by chain
