@@ -187,13 +187,17 @@ class _DreamzTap:
         return loc + scale * self.eps.pop(0)
 
 
-@pytest.mark.parametrize("name", ["g15_da_dreamz", "g15_mlda_dreamz"])
+@pytest.mark.parametrize("name", ["g15_da_dreamz", "g15_mlda_dreamz", "g15_da_dreamz_random", "g15_da_dreamz_aem", "g15_da_dreamz_aem_dep",
+                                  "g15_mlda_dreamz_aem"])
 def test_dreamz_below_a_hierarchy_replay(golden, name):
-    """DREAMZ as the base proposal of Delayed Acceptance / MLDA (the reference's MLDA notebook configuration) on the host driver"""
+    """DREAMZ as the base proposal of Delayed Acceptance / MLDA (the reference's MLDA notebook configuration) on the host driver;
+    round 3: also with randomised subchains and with the state-independent / state-dependent error model"""
     g = golden(name)
     nl = int(g["n_levels"])
     prior = stats.multivariate_normal(g["prior_mean"], g["prior_cov"])
     var = float(g["noise_var"])
+    aem = str(g["aem"]) if "aem" in g.files else None
+    randomize = bool(g["randomize"])
     for c in range(g["theta0"].shape[0]):
         Z0 = g["Z0"][c]
 
@@ -202,16 +206,18 @@ def test_dreamz_below_a_hierarchy_replay(golden, name):
                 super().setup_proposal(**kw)
                 self.Z = Z0.copy()
 
-        posts = [tda.Posterior(prior, tda.GaussianLogLike(g["y%d" % k], var * np.eye(len(g["y%d" % k]))), _model(g["A%d" % k])) for k in range(nl)]
+        posts = _aem_posts(g, nl)() if aem else [tda.Posterior(prior, tda.GaussianLogLike(g["y%d" % k], var * np.eye(len(g["y%d" % k]))),
+                                                               _model(g["A%d" % k])) for k in range(nl)]
         prop = Seeded(int(g["M0"]), delta=int(g["delta"]), nCR=int(g["nCR"]), adaptive=bool(g["adaptive"]), gamma=float(g["gamma"]),
                       period=int(g["period"]))
         ch = _Fed.__new__(_Fed)
-        ch.feed(np.zeros((0, 1)), [g["u0"][c]] + [g["u%d" % k][c] for k in range(1, nl)])
+        ch.feed(np.zeros((0, 1)), [g["u0"][c]] + [g["u%d" % k][c] for k in range(1, nl)], g["ridx"][c] if randomize else None)
         with _DreamzTap(g, c, int(g["delta"])) as tap:
-            HierarchyChain.__init__(ch, posts, prop, [int(v) for v in g["subchain_lengths"]], initial_parameters=g["theta0"][c].copy())
+            HierarchyChain.__init__(ch, posts, prop, [int(v) for v in g["subchain_lengths"]], initial_parameters=g["theta0"][c].copy(),
+                                    adaptive_error_model=aem, randomize_subchain_length=randomize)
             ch.sample(g["th%d" % (nl - 1)].shape[1] - 1)
         assert not tap.r and not tap.mcr and not tap.eps and all(len(q) == 0 for q in ch._u)
-        _check(ch, g, c, nl)
+        _check(ch, g, c, nl, with_like=aem is None)
         np.testing.assert_allclose(ch.proposal.scaling, g["scaling"][c], rtol=1e-12)
         np.testing.assert_allclose(ch.proposal.pCR, g["pCR"][c], rtol=1e-10)
 
