@@ -468,6 +468,13 @@ void launch_chol(const CholArgs& a, hipStream_t st) {
 }
 template <int DPAD>
 void launch_chol_apply(const CholArgs& a, const ApplyArgs& ap, hipStream_t st) {
+  if constexpr (DPAD == 64) {  // four 16-column panels: the blocked kernel (TINYDA_CHOL_BLOCKED=0: the row-per-lane one, for A/B measurements)
+    static const bool blocked_ok = !(getenv("TINYDA_CHOL_BLOCKED") && atoi(getenv("TINYDA_CHOL_BLOCKED")) == 0);
+    if (blocked_ok) {
+      hipLaunchKernelGGL(k_chol_apply_blk<DPAD>, dim3((unsigned)ap.NP), dim3(64), 0, st, a, ap);
+      return;
+    }
+  }
   hipLaunchKernelGGL(k_chol_apply<DPAD>, dim3((unsigned)ap.NP), dim3(64), 0, st, a, ap);
 }
 

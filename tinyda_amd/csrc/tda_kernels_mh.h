@@ -1519,4 +1519,162 @@ __global__ void __launch_bounds__(64, 2) k_chol_apply(const CholArgs ca, const A
   apply_chain<DPAD>(ap, c);  // (padding chains c >= N: their factor is whatever init left there, as for k_apply)
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Blocked covariance swap + increments for 64 parameters (round 3).  The unblocked kernel above spends its time on operand
+// delivery: 2016 column updates per chain, each one fma fed by TWO v_readlane (9 000 vector instructions per chain, bound by the
+// pivot chain at two waves per SIMD).  Here the matrix stays in the layout k_adapt keeps it in -- 16 x 16 tiles in the MFMA C/D
+// register layout, as the UPPER factor (tile (p, i), p <= i, holds rows 16 p + hi + 4 r, column 16 i + lc of U = L^T):
+//   * a block row of 16 pivots is eliminated across all its tiles at once: the pivot row reaches the other lanes of its column
+//     with one ds_bpermute per tile, the four multipliers of a lane's own rows with four more -- no per-element readlane;
+//   * the trailing update of the block rows below runs on the matrix cores: tile(q, i) -= U_pq^T U_pi is
+//     mfma(-tile(p, q)[r], tile(p, i)[r], .) over the four registers r, both operands ARE the C/D registers of the block row
+//     (the accumulator layout of the fp64 MFMA is its operand layout for X^T Y products);
+//   * and the finished tiles ARE the B fragments of INC = Z L^T (row 16 p + 4 r + hi <-> k = 4 kk + hi with kk = 4 p + r), so the
+//     increments of the next block are multiplied out of the registers that hold the factor: no read-back at all, and the
+//     16 - 10 = 6 all-zero tiles below the block diagonal are skipped (40 instead of 64 MFMAs per group of 16 steps).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ constexpr int up_tile(int p, int i) { return p * 4 - p * (p - 1) / 2 + (i - p); }  // p <= i < 4
+
+__device__ __forceinline__ double lane_pick(double v, int src) { return __shfl(v, src); }
+
+template <int DPAD>
+__global__ void __launch_bounds__(64, 2) k_chol_apply_blk(const CholArgs ca, const ApplyArgs ap) {
+  static_assert(DPAD == 64, "the blocked swap is written for four 16-column panels");
+  constexpr int NTL = am_tiles<DPAD>();
+  const int lane = threadIdx.x, lc = lane & 15, hi = lane >> 4;
+  const int64_t c = blockIdx.x;
+  double G[10][4];  // upper tiles of Sigma, then of U
+  bool have = false;
+  if (c < ca.N) {
+    const double* __restrict__ sig = ca.am_sigma + (size_t)c * NTL * 256;
+    const int d = ca.d;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int i = p; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * p + hi + 4 * r, col = 16 * i + lc;
+          // stored: the tiles on or below the diagonal, [tile(ti, tj)][r][lane] = Sigma[16 ti + hi + 4 r][16 tj + lc]; an upper
+          // tile is the transpose of its mirror image (Sigma is symmetric: bitwise, k_adapt computes x_i x_j = x_j x_i)
+          const int off = (p == i) ? ((p * (p + 1) / 2 + p) * 4 + r) * 64 + lane : am_sigma_offset(col, row);
+          double v = sig[off];
+          if (row >= d || col >= d) v = (row == col) ? 1.0 : 0.0;  // padded rows / columns: identity
+          G[up_tile(p, i)][r] = v;
+        }
+    bool ok = true;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+#pragma unroll
+      for (int kl = 0; kl < 16; ++kl) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int kh = kl & 3, kr = kl >> 2;
+        const double dkk = bcast_lane64(G[up_tile(p, p)][kr], kh * 16 + kl);
+        ok = ok && (dkk > 0.0);
+        // 1 / sqrt(pivot): the hardware estimate (2^-26) and one third-order correction y (1 + e / 2 + 3 e^2 / 8), e = 1 - d y^2 --
+        // eight instructions where sqrt followed by a division takes thirty, per pivot and on every lane; the result is within
+        // a few units in the last place, which is what a factor of a sample covariance needs (the swap is compared at 1e-9)
+        const double y0 = __builtin_amdgcn_rsq(dkk);
+        const double e0 = fma(-dkk * y0, y0, 1.0);
+        const double inv = fma(y0 * e0, fma(0.375, e0, 0.5), y0);
+        const double fac = (hi == kh) ? inv : 1.0;  // the pivot row lives in the lanes with hi == kh
+#pragma unroll
+        for (int i = p; i < 4; ++i) G[up_tile(p, i)][kr] *= fac;
+        // multipliers of this lane's rows 16 p + hi + 4 r' > k: U[k][16 p + hi + 4 r'], from the lane that holds that column
+        double ucol[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) ucol[rr] = rr >= kr ? lane_pick(G[up_tile(p, p)][kr], kh * 16 + hi + 4 * rr) : 0.0;
+#pragma unroll
+        for (int i = p; i < 4; ++i) {
+          const double urow = lane_pick(G[up_tile(p, i)][kr], kh * 16 + lc);  // U[k][16 i + lc] for every row group of this column
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            if (rr < kr) continue;  // rows 16 p + hi + 4 rr <= k: finished
+            const double upd = fma(-ucol[rr], urow, G[up_tile(p, i)][rr]);
+            G[up_tile(p, i)][rr] = (rr > kr || hi > kh) ? upd : G[up_tile(p, i)][rr];
+          }
+        }
+      }
+      // block rows below: tile(q, i) -= U_pq^T U_pi on the matrix cores
+#pragma unroll
+      for (int q = p + 1; q < 4; ++q)
+#pragma unroll
+        for (int i = q; i < 4; ++i) {
+          double4_t acc = {G[up_tile(q, i)][0], G[up_tile(q, i)][1], G[up_tile(q, i)][2], G[up_tile(q, i)][3]};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc = mfma_f64(-G[up_tile(p, q)][r], G[up_tile(p, i)][r], acc);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) G[up_tile(q, i)][r] = acc[r];
+        }
+    }
+    if (ok) {
+      have = true;
+      // U as the factor in use: zero below the diagonal and in the padding, stored k-major (Lk[k][j] = L[j][k] = U[k][j])
+      double* __restrict__ Lk = ca.Lk + (size_t)c * DPAD * DPAD;
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * p + hi + 4 * r, col = 16 * i + lc;
+            double v = 0.0;
+            if (i >= p) {
+              v = (col >= row && row < d && col < d) ? G[up_tile(p, i < p ? p : i)][r] : 0.0;
+              G[up_tile(p, i < p ? p : i)][r] = v;
+            }
+            Lk[(size_t)row * DPAD + col] = v;
+          }
+    } else if (lane == 0) {
+      atomicOr(&ca.flags[c], 1);
+    }
+  }
+  // ---- increments of the next block: INC[S][64] = Z[S][64] L^T, 16 steps per group ----
+  constexpr int KK = DPAD / 4;
+  if (!have) {  // not positive definite (flagged) or a padding chain: the factor in memory, tile by tile in the same register layout
+    const double* __restrict__ Lk = ap.Lk + (size_t)c * ap.L_stride;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int i = p; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) G[up_tile(p, i)][r] = Lk[(size_t)(16 * p + hi + 4 * r) * DPAD + 16 * i + lc];
+  }
+  const int ng = (ap.S + 15) / 16;
+  double zf[KK], zn[KK];
+  {
+    const double* __restrict__ src = ap.zf + (size_t)c * KK * 64 + lane;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) zf[kk] = src[kk * 64];
+  }
+  for (int g = 0; g < ng; ++g) {
+    {  // next group's fragments fly during this group's MFMAs (clamped: the last group re-reads itself)
+      const int gn = g + 1 < ng ? g + 1 : g;
+      const double* __restrict__ src = ap.zf + ((size_t)gn * ap.NP + c) * KK * 64 + lane;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) zn[kk] = src[kk * 64];
+    }
+    double4_t acc[4];
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) acc[tj] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int tj = p; tj < 4; ++tj) acc[tj] = mfma_f64(zf[4 * p + r], G[up_tile(p, tj)][r], acc[tj]);  // (tiles below the block diagonal are zero)
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int so = g * 16 + hi + 4 * r;
+        if (so < ap.S) ap.inc[((size_t)so * ap.NP + c) * DPAD + 16 * tj + lc] = acc[tj][r];
+      }
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) zf[kk] = zn[kk];
+  }
+}
+
 }  // namespace tda
