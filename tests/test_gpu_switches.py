@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _probe(what, env_extra, tmp_path, tag):
     out = str(tmp_path / ("%s_%s.npz" % (what, tag)))
     env = dict(os.environ)
-    for k in ("TINYDA_DA_LEAN", "TINYDA_DZ_WAVE", "TINYDA_DZ_PIPELINE", "TINYDA_AEMD_FUSED", "TINYDA_FUSE_CHOL_APPLY"):
+    for k in ("TINYDA_DA_LEAN", "TINYDA_DZ_WAVE", "TINYDA_DZ_PIPELINE", "TINYDA_AEMD_FUSED", "TINYDA_FUSE_CHOL_APPLY", "TINYDA_CHOL_BLOCKED"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "switch_probe.py"), what, out], cwd=ROOT, env=env,
@@ -41,10 +41,22 @@ def test_pipelined_level_kernel_equals_the_generic_one(what, tmp_path):
 def test_fused_swap_and_increments_equal_the_two_launches(what, tmp_path):
     """k_chol_apply (covariance swap + the next block's increments in one launch, the factor read back from L2 by the wave that
     wrote it) against k_chol followed by k_apply (TINYDA_FUSE_CHOL_APPLY=0): the same arithmetic, bit for bit, over five swaps"""
-    fused, split = _probe(what, {}, tmp_path, "fused"), _probe(what, {"TINYDA_FUSE_CHOL_APPLY": "0"}, tmp_path, "split")
+    off = {"TINYDA_CHOL_BLOCKED": "0"}  # the row-per-lane factorisation in both: the same arithmetic, so the same bits
+    fused, split = _probe(what, off, tmp_path, "fused"), _probe(what, dict(off, TINYDA_FUSE_CHOL_APPLY="0"), tmp_path, "split")
     for k in fused:
         assert np.array_equal(fused[k], split[k]), k
     assert 0.02 < fused["acc0"].mean() < 0.98 and np.abs(fused["C"]).max() > 0
+    # the blocked factorisation (default at 64 parameters) sums in a different order and takes its pivots' reciprocal square roots
+    # from the hardware estimate + one correction: the same factor to rounding, the same decisions
+    blk = _probe(what, {}, tmp_path, "blocked")
+    assert np.array_equal(blk["acc0"], fused["acc0"])
+    # (the probe swaps after 60 steps in 64 dimensions: its first covariances are rank-deficient up to the eps I term, so their
+    # factors -- and the states proposed from them -- move by the rounding error times a large condition number)
+    for k, tol in (("params0", 1e-8), ("stats0", 1e-6), ("C", 1e-8), ("sigma", 1e-8), ("scaling", 1e-12)):
+        np.testing.assert_allclose(blk[k], fused[k], rtol=tol, atol=tol * np.abs(fused[k]).max(), err_msg=k)
+    blk2 = _probe(what, {"TINYDA_FUSE_CHOL_APPLY": "0"}, tmp_path, "blocked_split")  # k_chol_apply_blk<., false> + k_apply
+    assert np.array_equal(blk2["acc0"], blk["acc0"])
+    np.testing.assert_allclose(blk2["stats0"], blk["stats0"], rtol=1e-6)
 
 
 @pytest.mark.parametrize("what", ["dream", "dream_ragged"])

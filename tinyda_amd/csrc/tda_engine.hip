@@ -464,6 +464,13 @@ void launch_adapt(const AdaptArgs& a, hipStream_t st) {
 }
 template <int DPAD>
 void launch_chol(const CholArgs& a, hipStream_t st) {
+  if constexpr (DPAD == 64) {  // the blocked factorisation (k_chol_apply_blk without its second half)
+    static const bool blocked_ok = !(getenv("TINYDA_CHOL_BLOCKED") && atoi(getenv("TINYDA_CHOL_BLOCKED")) == 0);
+    if (blocked_ok) {
+      hipLaunchKernelGGL((k_chol_apply_blk<DPAD, false>), dim3((unsigned)a.N), dim3(64), 0, st, a, ApplyArgs{});
+      return;
+    }
+  }
   hipLaunchKernelGGL(k_chol<DPAD>, dim3((unsigned)a.N), dim3(64), 0, st, a);
 }
 template <int DPAD>

@@ -1538,7 +1538,8 @@ __device__ __forceinline__ constexpr int up_tile(int p, int i) { return p * 4 - 
 
 __device__ __forceinline__ double lane_pick(double v, int src) { return __shfl(v, src); }
 
-template <int DPAD>
+// APPLY = false: the swap alone (multilevel drivers, whose increments come from the fused k_propose)
+template <int DPAD, bool APPLY = true>
 __global__ void __launch_bounds__(64, 2) k_chol_apply_blk(const CholArgs ca, const ApplyArgs ap) {
   static_assert(DPAD == 64, "the blocked swap is written for four 16-column panels");
   constexpr int NTL = am_tiles<DPAD>();
@@ -1631,6 +1632,7 @@ __global__ void __launch_bounds__(64, 2) k_chol_apply_blk(const CholArgs ca, con
       atomicOr(&ca.flags[c], 1);
     }
   }
+  if constexpr (!APPLY) return;
   // ---- increments of the next block: INC[S][64] = Z[S][64] L^T, 16 steps per group ----
   constexpr int KK = DPAD / 4;
   if (!have) {  // not positive definite (flagged) or a padding chain: the factor in memory, tile by tile in the same register layout
