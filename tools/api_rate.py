@@ -48,8 +48,6 @@ t0 = time.perf_counter()
 ps = res["proposal_state"]["C"]
 out["lazy_proposal_state_seconds"] = round(time.perf_counter() - t0, 4)
 out["proposal_state_C_shape"] = list(ps.shape)
-import torch  # noqa: E402
-
 out["device_memory_GB_held_by_result"] = round(sum(getattr(res["chain_0"]._records, f).numel() * getattr(res["chain_0"]._records, f).element_size()
                                                    for f in ("parameters", "stats", "accepted")) / 1e9, 3)
 out["torch_pinned_or_host_record_bytes"] = 0
