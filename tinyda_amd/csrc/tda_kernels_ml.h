@@ -165,7 +165,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
     stepno[k] = a.done[k];
     nrec[k] = 0;
   }
-  int64_t ringpos = a.ring_pos;
+  // slot of the next entry in the accept-flag ring, kept incrementally: the 64-bit remainder is ~150 instructions, and wave 0
+  // alone would pay them in every step while seven waves wait at the barrier
+  int ringidx = (int)(a.ring_pos % a.ring_P);
   const FragSrc fbase = frag_src(a.lv[0].Apk, lane);
   constexpr bool PAIRS = NW == 4;
   double2 f0[KS / 2], f1[PAIRS ? KS / 2 : 1];
@@ -428,9 +430,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
         }
         if (a.rec_acc[0]) a.rec_acc[0][r] = acc0 ? 1 : 0;
       }
-      a.ring[(size_t)(ringpos % a.ring_P) * a.NP + gcl] = acc0 ? 1 : 0;
+      a.ring[(size_t)ringidx * a.NP + gcl] = acc0 ? 1 : 0;
     }
-    ringpos += 1;
+    ringidx = ringidx + 1 == a.ring_P ? 0 : ringidx + 1;
     nrec[0] += 1;
     stepno[0] += 1;
     cnt[0] += 1;
@@ -523,9 +525,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
           }
           if (a.rec_acc[q]) a.rec_acc[q][r] = accq ? 1 : 0;
         }
-        a.ring[(size_t)(ringpos % a.ring_P) * a.NP + gcl] = accq ? 1 : 0;
+        a.ring[(size_t)ringidx * a.NP + gcl] = accq ? 1 : 0;
       }
-      ringpos += 1;
+      ringidx = ringidx + 1 == a.ring_P ? 0 : ringidx + 1;
       nrec[q] += 1;
       stepno[q] += 1;
       cnt[k] = 0;
@@ -682,7 +684,9 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
   int cnt0 = a.cnt[0];
   int64_t step0 = a.done[0];
   int nrec0 = 0;
-  int64_t ringpos = a.ring_pos;
+  // slot of the next entry in the accept-flag ring, kept incrementally: the 64-bit remainder is ~150 instructions, and wave 0
+  // alone would pay them in every step while seven waves wait at the barrier
+  int ringidx = (int)(a.ring_pos % a.ring_P);
   const int L0 = a.sl[0];
   const int ncb0 = a.lv[0].ncb;
   bool has_b[RB];
@@ -795,7 +799,7 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
   // record of the last decided coarse step (state after the decision, its densities, the flag, the accept-flag window) and the
   // loads of later steps: off the chain decision -> next proposal, issued while the matrix pipe works
   bool rec_pending = false, rec_acc0 = false;
-  int64_t rec_ring = 0;
+  int rec_ring = 0;
   auto flush_coarse_record = [&]() {
     if (!rec_pending) return;
     rec_pending = false;
@@ -817,7 +821,7 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
         }
         if (a.rec_acc[0]) a.rec_acc[0][r] = rec_acc0 ? 1 : 0;
       }
-      a.ring[(size_t)(rec_ring % a.ring_P) * a.NP + gcl] = rec_acc0 ? 1 : 0;
+      a.ring[(size_t)rec_ring * a.NP + gcl] = rec_acc0 ? 1 : 0;
     }
   };
 
@@ -925,7 +929,7 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
     }
     unext = u_nx;
     lunext = lu_nx;
-    rec_ring = ringpos;
+    rec_ring = ringidx;
     rec_pending = true;  // the record of this step is written behind the next step's products (or before the fine level acts)
     rec_acc0 = acc0;
 #pragma unroll
@@ -934,7 +938,7 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
       sxb[e] = sxc[e];
       sxc[e] = sxd[e];
     }
-    ringpos += 1;
+    ringidx = ringidx + 1 == a.ring_P ? 0 : ringidx + 1;
     nrec0 += 1;
     step0 += 1;
     cnt0 += 1;
@@ -1032,9 +1036,9 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
           }
           if (a.rec_acc[q]) a.rec_acc[q][r] = accq ? 1 : 0;
         }
-        a.ring[(size_t)(ringpos % a.ring_P) * a.NP + gcl] = accq ? 1 : 0;  // alignment entry of the coarse accept list (:363,389,397)
+        a.ring[(size_t)ringidx * a.NP + gcl] = accq ? 1 : 0;  // alignment entry of the coarse accept list (:363,389,397)
       }
-      ringpos += 1;
+      ringidx = ringidx + 1 == a.ring_P ? 0 : ringidx + 1;
       nrecU[q - 1] += 1;
       stepU[q - 1] += 1;
       if (k == 0) cnt0 = 0;
