@@ -312,6 +312,55 @@ __device__ __forceinline__ double block_sse(const double2 (&f)[DPAD / 8], const 
   return sse;
 }
 
+// The same with BOTH fragment buffers supplied by the caller (k_da_steps lends the registers of its coarse operator), and --
+// FRESH -- with the chains' parameters (the B operand) read from LDS for every block instead of 32 registers held across the
+// sum: the level actions of the multi-level kernels run at the kernel's register peak.  The parameters are staged in
+// fragment order, th_frag = tile + lane * (DPAD / 4 + 2): one 16-byte read serves two MFMAs (k-slices 2 k, 2 k + 1).
+template <int DPAD, int MODE, bool FRESH>
+__device__ __forceinline__ double block_sse_frag(const double2 (&f)[DPAD / 8], const double2* th_frag, const double* __restrict__ s_y,
+                                                 double* __restrict__ s_w, int cb, int hi) {
+  double4_t a0 = {0.0, 0.0, 0.0, 0.0};
+  if (FRESH) asm volatile("" : "+v"(th_frag));  // (a new read per block: hoisted out of the block loop these are the 32 registers again)
+#pragma unroll
+  for (int k = 0; k < DPAD / 8; ++k) {
+    const double2 b = th_frag[k];
+    a0 = mfma_f64(f[k].x, b.x, a0);
+    a0 = mfma_f64(f[k].y, b.y, a0);
+  }
+  double sse = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = cb * 16 + hi + 4 * r;
+    const double res = a0[r] - s_y[o];
+    double sq = res * res;
+    if (MODE == 1) sq *= s_w[o];
+    sse += sq;
+  }
+  return sse;
+}
+template <int DPAD, int MODE, int NW, bool FRESH>
+__device__ __forceinline__ double level_sse_frag(const double* __restrict__ Apk, int ncb, const double* __restrict__ s_y,
+                                                 double* __restrict__ s_w, const double2* th_frag, int wave, int lane,
+                                                 double2 (&fa)[DPAD / 8], double2 (&fb)[DPAD / 8]) {
+  const int hi = lane >> 4;
+  const FragSrc src = frag_src(Apk, lane);
+  const int first = wave < ncb ? wave : ncb - 1;
+  double sse = 0.0;
+  for (int cb = wave; cb < ncb; cb += 2 * NW) {  // fa holds block cb
+    frag_load_buf<DPAD>(src, cb + NW < ncb ? cb + NW : first, fb);
+    __builtin_amdgcn_sched_barrier(0);
+    sse += block_sse_frag<DPAD, MODE, FRESH>(fa, th_frag, s_y, s_w, cb, hi);
+    __builtin_amdgcn_sched_barrier(0);
+    if (cb + NW < ncb) {
+      frag_load_buf<DPAD>(src, cb + 2 * NW < ncb ? cb + 2 * NW : first, fa);
+      __builtin_amdgcn_sched_barrier(0);
+      sse += block_sse_frag<DPAD, MODE, FRESH>(fb, th_frag, s_y, s_w, cb + NW, hi);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  return sse;  // (the buffers hold nothing the caller may rely on)
+}
+
 template <int DPAD, int MODE, int NW>
 __device__ __forceinline__ double level_sse_single(const double* __restrict__ Apk, int ncb,
                                                    const double* __restrict__ s_y, double* __restrict__ s_w,

@@ -586,7 +586,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
 // ------------------------------------------------------------------------------------------------
 template <int DPAD>
 __host__ __device__ constexpr int da_lds_doubles(int stage_total) {
-  return 16 * (DPAD + 2) + 2 * 64 * (DPAD / 4 + 2) + 2 * 16 * 8 + 2 * 16 + 2 * DPAD + stage_total;
+  return 16 * (DPAD + 2) + 2 * 64 * (DPAD / 4 + 2) + 2 * 16 * 8 + 2 * 16 + 2 * DPAD + 6 * 16 + 64 * (DPAD / 4 + 2) + stage_total;
 }
 
 #ifdef TDA_DA_TRACE
@@ -617,7 +617,9 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
   double* s_pri = s_red + 2 * 16 * NW;      // [2][16] prior quadratic form of theta'
   double* s_pm = s_pri + 2 * 16;
   double* s_pinv = s_pm + DPAD;
-  double* s_stage = s_pinv + DPAD;
+  double* s_S = s_pinv + DPAD;              // [2 NPAIR][16] densities of level j at the start of level q's step, between level actions
+  double* s_thf = s_S + 6 * 16;             // [64][RSX] the states a level action evaluates, in fragment order
+  double* s_stage = s_thf + 64 * RSX;
 
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x;
@@ -668,11 +670,14 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
     stepU[q - 1] = a.done[q];
     nrecU[q - 1] = 0;
   }
-  double Slp[NPAIR], Sll[NPAIR];  // level j at the start of level q's current step, pair_index(j, q)
+  // level j at the start of level q's current step, pair_index(j, q): only the level actions touch these, so they wait in LDS
+  // (lane-mapped, every wave would hold the same copy: 4 NPAIR registers in the step loop for nothing)
+  if (wave == 0 && lane < 16) {
 #pragma unroll
-  for (int p = 0; p < NPAIR; ++p) {
-    Slp[p] = a.Sst[((size_t)p * 2 + 0) * a.NP + gcl];
-    Sll[p] = a.Sst[((size_t)p * 2 + 1) * a.NP + gcl];
+    for (int p = 0; p < NPAIR; ++p) {
+      s_S[(2 * p) * 16 + lc] = a.Sst[((size_t)p * 2 + 0) * a.NP + gcl];
+      s_S[(2 * p + 1) * 16 + lc] = a.Sst[((size_t)p * 2 + 1) * a.NP + gcl];
+    }
   }
   int anyacc0 = a.anyacc[gcl];
   const double scal_t = a.scaling[gct];
@@ -952,6 +957,12 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
     flush_coarse_record();  // an upper level may move the coarse state: its last step is recorded first
     auto LP = [&](int j) -> double& { return j == 0 ? lp0 : lpU[j - 1]; };
     auto LL = [&](int j) -> double& { return j == 0 ? ll0 : llU[j - 1]; };
+    double Slp[NPAIR], Sll[NPAIR];
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) {  // (written before the previous action's last barrier, or the kernel's first)
+      Slp[p] = s_S[(2 * p) * 16 + lc];
+      Sll[p] = s_S[(2 * p + 1) * 16 + lc];
+    }
     bool more = true;
 #pragma unroll
     for (int k = 0; k < NLEV - 1; ++k) {
@@ -959,19 +970,27 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
       const int q = k + 1;
       if (active) {
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) s_prop[c * LDP + q_ * EPT + e] = cur0[e];
+        for (int e = 0; e < EPT; ++e) s_thf[st_dst[e]] = cur0[e];
       }
       const LevelDev& L = a.lv[q];
       frag_load_buf<DPAD>(frag_src(L.Apk, lane), wave < L.ncb ? wave : L.ncb - 1, fA[0]);
       __syncthreads();
       double llq;
       {
-        double th[KS];
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) th[kk] = s_prop[lc * LDP + 4 * kk + hi];
+        // (this section is the register peak of the kernel: the second fragment buffer is the coarse operator's second block where
+        // there is one; with one block per wave the chains' parameters come from LDS block by block instead of 32 registers)
+        const double2* th_frag = reinterpret_cast<const double2*>(s_thf + lane * RSX);
         const bool dg = L.noise_kind == 1;
-        double sq = dg ? level_sse_single<DPAD, 1, NW>(L.Apk, L.ncb, s_stage + a.lds_y[q], s_stage + a.lds_w[q], th, wave, lane, fA[0])
-                       : level_sse_single<DPAD, 0, NW>(L.Apk, L.ncb, s_stage + a.lds_y[q], nullptr, th, wave, lane, fA[0]);
+        double sq;
+        if constexpr (RB >= 2) {
+          sq = dg ? level_sse_frag<DPAD, 1, NW, false>(L.Apk, L.ncb, s_stage + a.lds_y[q], s_stage + a.lds_w[q], th_frag, wave, lane, fA[0], fA[1])
+                  : level_sse_frag<DPAD, 0, NW, false>(L.Apk, L.ncb, s_stage + a.lds_y[q], nullptr, th_frag, wave, lane, fA[0], fA[1]);
+        } else {
+          double2 fb[K2];
+          constexpr bool fresh = NLEV >= 3;  // (two levels leave the 32 registers: 2 us less per action at 2048 observations)
+          sq = dg ? level_sse_frag<DPAD, 1, NW, fresh>(L.Apk, L.ncb, s_stage + a.lds_y[q], s_stage + a.lds_w[q], th_frag, wave, lane, fA[0], fb)
+                  : level_sse_frag<DPAD, 0, NW, fresh>(L.Apk, L.ncb, s_stage + a.lds_y[q], nullptr, th_frag, wave, lane, fA[0], fb);
+        }
         sq = sum_rows(sq);
         if (lane < 16) s_red[wave * 16 + lane] = sq;  // (both reduction slabs are free here: the step's was read above)
         __syncthreads();
@@ -984,7 +1003,11 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
       const double lpq = y_lp;
       double uq;
       if (a.u_rep[q]) uq = a.u_rep[q][(size_t)(stepU[q - 1] - a.done[q]) * a.N + (gcl < a.N ? gcl : 0)];
-      else uq = accept_uniform(a.seed, gchain, (uint32_t)stepU[q - 1], (uint32_t)q);
+      else {
+        uint32_t gc = gchain;
+        asm volatile("" : "+v"(gc));  // (the generator's chain-dependent words are formed here, not kept across the step loop)
+        uq = accept_uniform(a.seed, gc, (uint32_t)stepU[q - 1], (uint32_t)q);
+      }
       const int pkq = pair_index(k, q);
       const double alq = exp(((lpq + llq) - (lpU[q - 1] + llU[q - 1])) + (Slp[pkq] + Sll[pkq]) - (y_lp + y_ll));  // chain.py:475-483
       const int any_below = k == 0 ? anyacc0 : anyU[k - 1];
@@ -1046,17 +1069,27 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
       cntU[q - 1] += 1;
       more = q < NLEV - 1 && cntU[q - 1] == a.sl[q];
     }
+    if (wave == 0 && lane < 16) {
+#pragma unroll
+      for (int p = 0; p < NPAIR; ++p) {
+        s_S[(2 * p) * 16 + lc] = Slp[p];
+        s_S[(2 * p + 1) * 16 + lc] = Sll[p];
+      }
+    }
     load_coarse_operator();
     direct_outputs(cur0, Fc);  // rejected chains are back at an upper state: outputs re-derived (and re-anchored) for the tile
   }
   flush_coarse_record();
 
   if (active) {
+    int64_t gce = gct;
+    asm volatile("" : "+v"(gce));  // (addresses rebuilt here: as common subexpressions of the loads at the top they would occupy
+                                   // registers -- or scratch -- across the whole step loop)
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-      a.theta[gct * DPAD + q_ * EPT + e] = cur0[e];
+      a.theta[gce * DPAD + q_ * EPT + e] = cur0[e];
 #pragma unroll
-      for (int q = 1; q < NLEV; ++q) a.theta[((size_t)q * a.NP + gct) * DPAD + q_ * EPT + e] = curU[q - 1][e];
+      for (int q = 1; q < NLEV; ++q) a.theta[((size_t)q * a.NP + gce) * DPAD + q_ * EPT + e] = curU[q - 1][e];
     }
   }
   if (wave == 0 && lane < 16) {
@@ -1070,9 +1103,9 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
       a.anyacc[(size_t)q * a.NP + gcl] = anyU[q - 1];
     }
 #pragma unroll
-    for (int p = 0; p < NPAIR; ++p) {
-      a.Sst[((size_t)p * 2 + 0) * a.NP + gcl] = Slp[p];
-      a.Sst[((size_t)p * 2 + 1) * a.NP + gcl] = Sll[p];
+    for (int p = 0; p < NPAIR; ++p) {  // (this wave wrote the slots)
+      a.Sst[((size_t)p * 2 + 0) * a.NP + gcl] = s_S[(2 * p) * 16 + lc];
+      a.Sst[((size_t)p * 2 + 1) * a.NP + gcl] = s_S[(2 * p + 1) * 16 + lc];
     }
   }
 }
