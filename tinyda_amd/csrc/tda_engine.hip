@@ -505,8 +505,9 @@ inline bool da_lean_eligible(const MLArgs& a) {
 
 template <int DPAD>
 int launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st) {
-  if (da_lean_eligible(a)) {
-    const size_t lds8 = (size_t)da_lds_doubles<DPAD>(a.lds_total) * sizeof(double);
+  // (the lean kernel keeps 64 KB of model outputs per tile in LDS: with very long data vectors staged beside them it does not fit)
+  const size_t lds8 = (size_t)da_lds_doubles<DPAD>(a.lds_total) * sizeof(double);
+  if (da_lean_eligible(a) && lds8 <= 160 * 1024) {
     const bool pcn = a.prop_kind == TDA_PROP_PCN, dg0 = a.lv[0].noise_kind == 1, one = a.lv[0].ncb <= 8;
 #define TDA_DA_LAUNCH(RBV, PCNV, NZV, NLV)                                                                                         \
   do {                                                                                                                             \

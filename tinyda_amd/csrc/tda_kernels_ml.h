@@ -577,8 +577,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
 //   * the coarse operator itself is register resident (2 blocks x 32 registers per wave; nothing is streamed per step);
 //   * increments are staged two steps ahead into LDS in fragment order by the threads that also keep the chain state;
 //     the prior of theta' is a thread-mapped partial sum reduced in the shadow of the MFMAs;
-//   * F is re-derived from theta by a direct product at every launch and after every fine step (where rejected chains
-//     return to the fine state anyway), so rounding cannot accumulate beyond one subchain;
+//   * F is re-derived from theta by a direct product at every launch, so rounding cannot accumulate beyond one block; the
+//     outputs at the states the upper levels hold wait in LDS and return with the state when a level step is rejected
+//     (re-deriving them after every level action was 7 000 cycles of barriers, LDS round trips and a cold MFMA chain);
 //   * the fine level is evaluated directly (streamed fragments, two waves per SIMD) every sl[0] coarse steps: skip rule,
 //     two-stage acceptance with the densities kept from the subchain start, alignment, records, accept-flag window.
 // Same MLArgs, records and RNG contract as k_ml_steps<DPAD, 2>; log-densities agree with it to rounding (the linear update
@@ -586,7 +587,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
 // ------------------------------------------------------------------------------------------------
 template <int DPAD>
 __host__ __device__ constexpr int da_lds_doubles(int stage_total) {
-  return 16 * (DPAD + 2) + 2 * 64 * (DPAD / 4 + 2) + 2 * 16 * 8 + 2 * 16 + 2 * DPAD + 6 * 16 + 64 * (DPAD / 4 + 2) + stage_total;
+  return 16 * (DPAD + 2) + 2 * 64 * (DPAD / 4 + 2) + 2 * 16 * 8 + 2 * 16 + 2 * DPAD + 6 * 16 + 64 * (DPAD / 4 + 2) + 16 * 512 + stage_total;
 }
 
 #ifdef TDA_DA_TRACE
@@ -619,7 +620,10 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
   double* s_pinv = s_pm + DPAD;
   double* s_S = s_pinv + DPAD;              // [2 NPAIR][16] densities of level j at the start of level q's step, between level actions
   double* s_thf = s_S + 6 * 16;             // [64][RSX] the states a level action evaluates, in fragment order
-  double* s_stage = s_thf + 64 * RSX;
+  double* s_Fs = s_thf + 64 * RSX;          // [NLEV RB 4][512] coarse model outputs at the states the upper levels hold, per thread;
+  double* s_stage = s_Fs + 16 * 512;        // the last RB 4 pieces: those of the coarse state itself while a level acts
+  static_assert(NLEV * RB * 4 <= 16, "s_Fs holds sixteen doubles per thread");
+  constexpr int FS_CUR = (NLEV - 1) * RB * 4;
 
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x;
@@ -776,6 +780,19 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
     __syncthreads();
   };
   direct_outputs(cur0, Fc);
+  double* __restrict__ const fs_slot = s_Fs + tid;  // this thread's piece (q - 1) RB 4 + 4 i + r of level q at stride 512
+  if (a.cascade) {
+#pragma unroll
+    for (int q = 1; q < NLEV; ++q) {
+      double Fq[RB][4];
+      direct_outputs(curU[q - 1], Fq);
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fs_slot[((q - 1) * RB * 4 + 4 * i + r) * 512] = Fq[i][r];
+    }
+  }
+  const double llscale0 = dg0 ? -0.5 : -0.5 / a.lv[0].var;
 
   // ---- pipeline prologue: increments of steps 0 and 1 staged, A (s inc_0) issued ----
 #pragma unroll
@@ -907,7 +924,7 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
     double tot = part[0];
 #pragma unroll
     for (int w = 1; w < NW; ++w) tot += part[w];
-    const double ll_n = dg0 ? -0.5 * tot : -0.5 * tot / a.lv[0].var;
+    const double ll_n = llscale0 * tot;
     const double lp_n = -0.5 * (a.pr.logconst + maha);
     const double post_n = lp_n + ll_n;
     const double delta = is_pcn ? ll_n - ll0 : post_n - (lp0 + ll0);
@@ -957,6 +974,11 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
     flush_coarse_record();  // an upper level may move the coarse state: its last step is recorded first
     auto LP = [&](int j) -> double& { return j == 0 ? lp0 : lpU[j - 1]; };
     auto LL = [&](int j) -> double& { return j == 0 ? ll0 : llU[j - 1]; };
+    // (the coarse state's model outputs wait in LDS while the level streams its fragments: this section is the register peak)
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) fs_slot[(FS_CUR + 4 * i + r) * 512] = Fc[i][r];
     double Slp[NPAIR], Sll[NPAIR];
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p) {  // (written before the previous action's last barrier, or the kernel's first)
@@ -974,6 +996,14 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
       }
       const LevelDev& L = a.lv[q];
       frag_load_buf<DPAD>(frag_src(L.Apk, lane), wave < L.ncb ? wave : L.ncb - 1, fA[0]);
+      double uq;  // (independent of the residuals: formed while the first fragments travel)
+      if (a.u_rep[q]) uq = a.u_rep[q][(size_t)(stepU[q - 1] - a.done[q]) * a.N + (gcl < a.N ? gcl : 0)];
+      else {
+        uint32_t gc = gchain;
+        asm volatile("" : "+v"(gc));  // (the generator's chain-dependent words are formed here, not kept across the step loop)
+        uq = accept_uniform(a.seed, gc, (uint32_t)stepU[q - 1], (uint32_t)q);
+      }
+      const bool more_after = q < NLEV - 1 && cntU[q - 1] + 1 == a.sl[q];  // the level above acts right after this one
       __syncthreads();
       double llq;
       {
@@ -991,6 +1021,7 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
           sq = dg ? level_sse_frag<DPAD, 1, NW, fresh>(L.Apk, L.ncb, s_stage + a.lds_y[q], s_stage + a.lds_w[q], th_frag, wave, lane, fA[0], fb)
                   : level_sse_frag<DPAD, 0, NW, fresh>(L.Apk, L.ncb, s_stage + a.lds_y[q], nullptr, th_frag, wave, lane, fA[0], fb);
         }
+        if (!more_after) load_coarse_operator();  // (the fragment registers are free: the operator returns under the decision)
         sq = sum_rows(sq);
         if (lane < 16) s_red[wave * 16 + lane] = sq;  // (both reduction slabs are free here: the step's was read above)
         __syncthreads();
@@ -1001,13 +1032,6 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
       }
       const double y_lp = LP(k), y_ll = LL(k);
       const double lpq = y_lp;
-      double uq;
-      if (a.u_rep[q]) uq = a.u_rep[q][(size_t)(stepU[q - 1] - a.done[q]) * a.N + (gcl < a.N ? gcl : 0)];
-      else {
-        uint32_t gc = gchain;
-        asm volatile("" : "+v"(gc));  // (the generator's chain-dependent words are formed here, not kept across the step loop)
-        uq = accept_uniform(a.seed, gc, (uint32_t)stepU[q - 1], (uint32_t)q);
-      }
       const int pkq = pair_index(k, q);
       const double alq = exp(((lpq + llq) - (lpU[q - 1] + llU[q - 1])) + (Slp[pkq] + Sll[pkq]) - (y_lp + y_ll));  // chain.py:475-483
       const int any_below = k == 0 ? anyacc0 : anyU[k - 1];
@@ -1032,12 +1056,26 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
       if (accq) {
         lpU[q - 1] = lpq;
         llU[q - 1] = llq;
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)  // the outputs follow the state
+            fs_slot[((q - 1) * RB * 4 + 4 * i + r) * 512] = fs_slot[(FS_CUR + 4 * i + r) * 512];
       } else {
 #pragma unroll
         for (int j = 0; j < q; ++j) {
           LP(j) = Slp[pair_index(j, q)];
           LL(j) = Sll[pair_index(j, q)];
         }
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double v = fs_slot[((q - 1) * RB * 4 + 4 * i + r) * 512];
+            fs_slot[(FS_CUR + 4 * i + r) * 512] = v;
+#pragma unroll
+            for (int j = 1; j < q; ++j) fs_slot[((j - 1) * RB * 4 + 4 * i + r) * 512] = v;
+          }
       }
 #pragma unroll
       for (int j = 0; j < q; ++j)
@@ -1067,7 +1105,7 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
       if (k == 0) cnt0 = 0;
       else cntU[k - 1] = 0;
       cntU[q - 1] += 1;
-      more = q < NLEV - 1 && cntU[q - 1] == a.sl[q];
+      more = more_after;
     }
     if (wave == 0 && lane < 16) {
 #pragma unroll
@@ -1076,8 +1114,11 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
         s_S[(2 * p + 1) * 16 + lc] = Sll[p];
       }
     }
-    load_coarse_operator();
-    direct_outputs(cur0, Fc);  // rejected chains are back at an upper state: outputs re-derived (and re-anchored) for the tile
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Fc[i][r] = fs_slot[(FS_CUR + 4 * i + r) * 512];
+    __syncthreads();  // (the reduction slab and the state tile are the next step's / action's again)
   }
   flush_coarse_record();
 
