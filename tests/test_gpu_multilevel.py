@@ -105,12 +105,16 @@ def _oracle_uniforms(seed, N, rows, sl, randomize_L=None):
     return us, ridx
 
 
-@pytest.mark.parametrize("case", ["da_c3", "da_random", "mlda3"])
+@pytest.mark.parametrize("case", ["da_c3", "da_random", "mlda3", "da_long_data"])
 def test_multilevel_philox_forward_vs_oracle(eng_mod, case):
     """Engine on its own Philox stream (normals exported, uniforms / promoted index regenerated bit-exactly by the
-    oracle's Philox); BASELINE config-3 / config-5 shapes at reduced chain counts."""
+    oracle's Philox); BASELINE config-3 / config-5 shapes at reduced chain counts.  da_long_data: a fine level of 9 000
+    observations -- its data vector beside the lean kernel's LDS rows exceeds 160 KB, the launcher takes the generic kernel."""
     rng = np.random.default_rng(77)
-    if case == "mlda3":
+    if case == "da_long_data":
+        d, ms, sl, n_fine, N = 64, (256, 9000), [10], 6, 32
+        prop = dict(kind="pcn", scaling=0.02, adaptive=True, gamma=1.01, period=40)
+    elif case == "mlda3":
         d, ms, sl, n_fine, N = 64, (128, 512, 2048), [5, 3], 12, 32
         prop = dict(kind="am", C0=1e-4 * np.eye(d), t0=50, period=50)
     else:
