@@ -569,17 +569,24 @@ __global__ void __launch_bounds__(64) k_dreamz_steps_wave(const DreamStepArgs a)
     blo[e] = a.pr.lo ? a.pr.lo[j0 + e] : -INFINITY;
     bhi[e] = a.pr.lo ? a.pr.hi[j0 + e] : INFINITY;
   }
-  double cur[EPT], prp[EPT], prev[EPT], jn[EPT];
+  double cur[EPT], prp[EPT], prev[EPT];
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
     cur[e] = a.theta[c * DPAD + j0 + e];
     prev[e] = cur[e];
-    jn[e] = a.jump_ready ? a.coef[(size_t)c * DPAD + j0 + e] : 0.0;
   }
   double lp = a.lp[c], ll = a.ll[c];
   int nacc = 0;
   double* arch_c = a.shared ? a.arch : a.arch + (size_t)c * a.cap * DPAD;
-  double unext = a.u[c];
+  // Finished jumps (k_dreamz_draw): the jumps and uniforms of DZ_SB steps come into LDS in ONE round of loads, and the step loop
+  // itself issues no load.  With a load per step, its wait was a wait for the record stores of the step before as well -- loads
+  // and stores count on one counter (vmcnt) on gfx9 and the stores sit in branches the compiler cannot count, so it waits for
+  // zero: 1.7 us per step of 8192 chains, a store acknowledgement each, for 150 instructions of arithmetic.
+  constexpr int DZ_SB = 16;
+  __shared__ double s_jump[DZ_SB * CPW * DPAD];
+  __shared__ double s_unif[DZ_SB * CPW];
+  const int cw = lane / LPC;
+  double unext = a.jump_ready ? 0.0 : a.u[c];
   // shared (frozen) archive gathered here: the rows of step s + 1 and the row indices of step s + 2 are requested while step s
   // computes -- two dependent trips to HBM per step otherwise (5 us per step of 8192 chains instead of 1.8)
   const bool ahead = !a.jump_ready && a.shared;
@@ -610,15 +617,33 @@ __global__ void __launch_bounds__(64) k_dreamz_steps_wave(const DreamStepArgs a)
     if (a.S > 1) request_indices(1);
   }
   for (int s = 0; s < a.S; ++s) {
-    const double u = unext;
-    if (s + 1 < a.S) unext = a.u[(size_t)(s + 1) * a.NP + c];
+    double u = unext;
+    if (a.jump_ready) {
+      const int k = s % DZ_SB;
+      if (k == 0) {  // (wave-uniform) the next DZ_SB steps: every lane its own elements, lane 0 of a chain its uniforms
+        const int n = a.S - s < DZ_SB ? a.S - s : DZ_SB;
+        double jl[DZ_SB][EPT], ul[DZ_SB];
+#pragma unroll
+        for (int i = 0; i < DZ_SB; ++i) {
+#pragma unroll
+          for (int e = 0; e < EPT; ++e) jl[i][e] = i < n ? a.coef[((size_t)(s + i) * a.NP + c) * DPAD + j0 + e] : 0.0;
+          ul[i] = (i < n && q == 0) ? a.u[(size_t)(s + i) * a.NP + c] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < DZ_SB; ++i) {
+#pragma unroll
+          for (int e = 0; e < EPT; ++e) s_jump[(i * CPW + cw) * DPAD + j0 + e] = jl[i][e];
+          if (q == 0) s_unif[i * CPW + cw] = ul[i];
+        }
+      }
+      u = s_unif[k * CPW + cw];
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) prp[e] = cur[e] + s_jump[(k * CPW + cw) * DPAD + j0 + e];
+    } else if (s + 1 < a.S) {
+      unext = a.u[(size_t)(s + 1) * a.NP + c];
+    }
     // ---- proposal (proposal.py:850-852) ----
     if (a.jump_ready) {
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) {
-        prp[e] = cur[e] + jn[e];
-        if (s + 1 < a.S) jn[e] = a.coef[((size_t)(s + 1) * a.NP + c) * DPAD + j0 + e];  // flies under this step
-      }
     } else if (ahead) {
 #pragma unroll
       for (int e = 0; e < EPT; ++e) {
