@@ -760,7 +760,7 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
     yc[0][0] = wc[0][0] = 0.0;
   }
 
-  // ---- model outputs of the current coarse state, re-derived from theta at every launch and after every fine step ----
+  // ---- model outputs of a state by a direct product: the anchors of every launch (coarse state, and the states the upper levels hold) ----
   double Fc[RB][4], G[RB][4];
   auto direct_outputs = [&](const double (&state)[EPT], double (&F)[RB][4]) {
     if (active) {
