@@ -540,6 +540,11 @@ int launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, st, a);
     return TDA_OK;
   };
+  // host-sequenced level actions (the dense error model): the kernel advances the base level only and would carry the states
+  // and densities of the levels above through the step loop untouched -- in the three- and four-level instances that is 33 / 91
+  // spilled registers whose reloads drain the prefetch of the per-chain precision matrices; the one-level instance leaves them
+  // in memory
+  if (!a.cascade && !a.randomize) return go(&k_ml_steps<DPAD, 1>);
   switch (a.nlev) {
     case 2: return go(&k_ml_steps<DPAD, 2>);
     case 3: return go(&k_ml_steps<DPAD, 3>);

@@ -364,10 +364,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
     if (a.randomize && cnt[0] == 0) {  // DA: draw the promoted index of the subchain that starts now
       const int L0 = a.sl[0];
       if (a.ridx_rep) {
-        const double r = a.ridx_rep[(size_t)(stepno[1] - a.done[1]) * a.N + (gcl < a.N ? gcl : 0)];
+        const double r = a.ridx_rep[(size_t)(stepno[NLEV > 1 ? 1 : 0] - a.done[1]) * a.N + (gcl < a.N ? gcl : 0)];  // (NLEV = 1 is never launched with randomised subchains)
         pick = (r != r) ? L0 - 1 : (int)r + L0;  // reference index in [-L, -1] (chain.py:525-527)
       } else {
-        const u32x4 r = philox4x32_10(u32x4{0u, (uint32_t)stepno[1], gchain, STREAM_INDEX}, (uint32_t)a.seed,
+        const u32x4 r = philox4x32_10(u32x4{0u, (uint32_t)stepno[NLEV > 1 ? 1 : 0], gchain, STREAM_INDEX}, (uint32_t)a.seed,
                                       (uint32_t)(a.seed >> 32));
         pick = (int)(((uint64_t)r.x * (uint64_t)L0) >> 32);
       }
