@@ -1,0 +1,72 @@
+"""The shipped gfx950 code object, read without a GPU: the kernels of the BASELINE configurations must not spill registers.
+
+A spilled register in a step loop is not two instructions: on gfx9 a scratch reload counts on the same in-order counter as
+global loads and stores, so its use is `s_waitcnt vmcnt(0)` -- every prefetch in flight is waited for (DESIGN.md 5, round 3:
+three reloads per coarse step cost `k_da_steps` 2 ms of 15).  The AMDGPU metadata note of the code object states spilled
+registers and scratch bytes per kernel; `profiles/r03_scratch_counts.txt` is the same table for every instance."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tinyda_amd", "lib", "libtinyda_hip.so")
+
+# kernel instance (mangled prefix) -> what launches it
+HOT = {
+    "_ZN3tda10k_mh_stepsILi64ELi8ELb0ELi0EEE": "C2a step kernel",
+    "_ZN3tda7k_adaptILi64EEE": "C2a moment recursion",
+    "_ZN3tda16k_chol_apply_blkILi64ELb1EEE": "C2a covariance swap + increments",
+    "_ZN3tda7k_applyILi64EEE": "C2a increments",
+    "_ZN3tda10k_da_stepsILi64ELi2ELb1ELi0ELi2EEE": "C3 Delayed Acceptance",
+    "_ZN3tda10k_da_stepsILi64ELi1ELb0ELi0ELi3EEE": "C5-literal MLDA",
+    "_ZN3tda12k_rng_directILi64EEE": "C3 proposal normals",
+    "_ZN3tda9k_proposeILi64EEE": "C5 proposal increments",
+    "_ZN3tda19k_dreamz_steps_waveILi32EEE": "C4 DREAM steps",
+    "_ZN3tda10k_ml_stepsILi64ELi1ELi4EEE": "C5 + dense error model base steps",
+}
+
+
+@pytest.fixture(scope="module")
+def kernel_metadata():
+    tools = [os.path.join(LLVM_BIN, t) for t in ("llvm-objdump", "llvm-readelf")]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip("ROCm LLVM tools not installed")
+    if not os.path.exists(LIB):
+        pytest.skip("libtinyda_hip.so not built (python -c 'import __graft_entry__ as g; g.build()')")
+    tmp = tempfile.mkdtemp(prefix="tda_co_")
+    try:
+        so = os.path.join(tmp, "lib.so")
+        shutil.copy(LIB, so)
+        subprocess.run([tools[0], "--offloading", so], cwd=tmp, check=True, capture_output=True)  # writes lib.so.0.hipv4-...gfx950
+        co = [f for f in os.listdir(tmp) if "gfx950" in f]
+        assert co, "no gfx950 code object in the library"
+        notes = subprocess.run([tools[1], "--notes", os.path.join(tmp, co[0])], check=True, capture_output=True, text=True).stdout
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    meta = {}
+    for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", notes):
+        meta[m.group(1)] = dict(scratch_bytes=int(m.group(2)), vgprs=int(m.group(3)), spilled=int(m.group(4)))
+    assert len(meta) > 100, "kernel metadata not parsed"
+    return meta
+
+
+@pytest.mark.parametrize("prefix", sorted(HOT))
+def test_hot_kernels_do_not_spill(kernel_metadata, prefix):
+    hits = {k: v for k, v in kernel_metadata.items() if k.startswith(prefix)}
+    assert len(hits) == 1, "%s (%s): %d instances in the code object" % (prefix, HOT[prefix], len(hits))
+    (name, md), = hits.items()
+    assert md["spilled"] == 0, "%s (%s) spills %d registers" % (name, HOT[prefix], md["spilled"])
+    # (a frame of the out-of-line accept_exact is allowed: 32 bytes, no spill)
+    assert md["scratch_bytes"] <= 32, "%s (%s) uses %d bytes of scratch" % (name, HOT[prefix], md["scratch_bytes"])
+
+
+def test_rng_kernel_fits_beside_the_step_kernel(kernel_metadata):
+    """k_rng runs on the second stream UNDER k_mh_steps: two step waves and one generator wave share a SIMD's 512 registers"""
+    step = [v for k, v in kernel_metadata.items() if k.startswith("_ZN3tda10k_mh_stepsILi64ELi8ELb0ELi0EEE")][0]
+    rng = [v for k, v in kernel_metadata.items() if k.startswith("_ZN3tda5k_rngILi64EEE")][0]
+    gran = lambda n: (n + 7) // 8 * 8  # allocation granule
+    assert 2 * gran(step["vgprs"]) + gran(rng["vgprs"]) <= 512, (step, rng)
