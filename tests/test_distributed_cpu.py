@@ -115,14 +115,17 @@ def test_world_size_2_gloo(tmp_path):
     script.write_text(_WORKER % {"root": ROOT, "out": str(tmp_path)})
     import socket
 
-    sock = socket.socket()  # a port nobody holds
-    sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
-    sock.close()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-                        "127.0.0.1", "--master-port", str(port), str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                       text=True, env=env, timeout=300)
+    for attempt in range(2):  # (the port is free when picked, not necessarily a moment later: one retry with another)
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                            "127.0.0.1", "--master-port", str(port), str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           text=True, env=env, timeout=300)
+        if r.returncode == 0 or "address already in use" not in r.stdout.lower():
+            break
     assert r.returncode == 0, r.stdout[-3000:]
     import json
 
