@@ -58,6 +58,9 @@ def parse_args():
                     help="allow --gpus N with fewer than N devices: every rank on cuda:0 over gloo (same as TINYDA_BENCH_ONE_GPU=1)")
     ap.add_argument("--no-ess", action="store_true")
     ap.add_argument("--extras", action="store_true", help="side measurements (other proposals / extensions), never the headline")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` block (the other BASELINE configurations at full chain counts, each with its own "
+                         "roofline: tools/bench_configs.py; rank 0 at N = 1 only, after the headline is measured, ~10 s)")
     return ap.parse_args()
 
 
@@ -365,6 +368,22 @@ def main():
             out["extras"] = extras(Engine, diagnostics, A, y, N, K, W, params, stats, acc, rows, local_rank, rank)
         except Exception as exc:
             out["extras_error"] = repr(exc)
+    if rank == 0 and world == 1 and not args.no_configs:
+        # the other BASELINE configurations (C2b, C3, C4 at exchange intervals 16 / 128, C5-literal, C5 + dense error model),
+        # full per-GPU chain counts, each with its own roofline entry; side runs after the headline, never `value`
+        try:
+            del params, stats, acc
+            torch.cuda.empty_cache()
+            import importlib.util
+
+            spec = importlib.util.spec_from_file_location("tda_bench_configs", os.path.join(ROOT, "tools", "bench_configs.py"))
+            bc = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(bc)
+            t_c = time.perf_counter()
+            out["configs"] = bc.config_block(log=lambda m: (sys.stderr.write(m + "\n"), sys.stderr.flush()))
+            out["configs_seconds"] = time.perf_counter() - t_c
+        except Exception as exc:
+            out["configs_error"] = repr(exc)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             # the GPU result is complete: keep it on stderr in case anything below goes wrong (stdout carries ONE line, at the end)

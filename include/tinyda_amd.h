@@ -168,13 +168,18 @@ typedef struct tda_profile {
   uint32_t n_launch_propose, n_launch_steps, n_launch_adapt;
   double ms_propose, ms_steps, ms_adapt; /* summed kernel durations */
   double ms_total;                        /* first launch -> last completion */
+  /* ABI 0.4 (a caller passing the 48-byte 0.3 struct gets the fields above only): the error-model refresh of host-sequenced
+   * hierarchies (level decision + tracker update + re-inversion + update_link), which 0.3 counted under `adapt` */
+  uint32_t n_launch_aem, reserved0;
+  double ms_aem;
 } tda_profile;
 
 const char* tda_last_error(void);
 /* "tinyda_amd <abi>.<minor> (...)".  ABI history: 0.1 round 1; 0.2 tda_outputs.reserved became `rows` (a caller built against 0.1
  * that passes 0 with non-NULL buffers is refused with TDA_ERR_INVALID); 0.3 tda_release_cached_memory, tda_engine_set_record_thinning,
  * tda_engine_set_progress / get_progress, tda_engine_detach_proposal_state + tda_proposal_snapshot_*,
- * tda_engine_set_proposal_spectrum. */
+ * tda_engine_set_proposal_spectrum; 0.4 tda_profile grew n_launch_aem / ms_aem (struct_size 48 is still accepted), checkpoint blobs
+ * carry the ABI / RNG-contract version and older blobs are refused. */
 const char* tda_version(void);
 
 /* Released engines park their large device buffers in a per-process pool (TINYDA_POOL_GB, default 8 GiB) so that the next

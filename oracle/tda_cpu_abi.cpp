@@ -121,7 +121,7 @@ struct tda_engine {
 extern "C" {
 
 const char* tda_last_error(void) { return g_err.c_str(); }
-const char* tda_version(void) { return "tinyda_amd 0.3 (cpu twin of the C-ABI: test / baseline infrastructure)"; }
+const char* tda_version(void) { return "tinyda_amd 0.4 (cpu twin of the C-ABI: test / baseline infrastructure)"; }
 int64_t tda_release_cached_memory(void) { return 0; }
 
 int tda_engine_create(const tda_config* cfg, tda_engine** out) {
@@ -451,7 +451,8 @@ int tda_engine_set_profiling(tda_engine*, int) { return TDA_OK; }
 int tda_engine_get_profile(tda_engine* e, tda_profile* p) {
   if (!e || !p) return fail(TDA_ERR_INVALID, "null argument");
   const uint32_t sz = p->struct_size;
-  std::memset(p, 0, sizeof *p);
+  if (sz != sizeof(tda_profile) && sz != 48) return fail(TDA_ERR_INVALID, "tda_profile.struct_size mismatch");
+  std::memset(p, 0, sz);  // (a 0.3 caller's struct is 48 bytes)
   p->struct_size = sz;
   return TDA_OK;
 }

@@ -43,7 +43,7 @@ def test_struct_sizes_match_header(lib):
     assert C.sizeof(lib.tda_config) == 56
     assert C.sizeof(lib.tda_proposal_params) == 72  # + q_mean (independence sampler)
     assert C.sizeof(lib.tda_outputs) == 32
-    assert C.sizeof(lib.tda_profile) == 48
+    assert C.sizeof(lib.tda_profile) == 64
 
 
 def test_product_fails_loudly_without_gpu(lib):

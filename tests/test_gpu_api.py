@@ -109,7 +109,21 @@ def test_sample_keeps_records_on_the_device_and_returns_the_engine_s_records(eng
     assert np.array_equal(ps["am_mu"], state["am_mu"]) and ps._snap is None
     # a random walk has no moments
     g = tda.sample(post, tda.GaussianRandomWalk(1e-3 * np.eye(d), adaptive=True, period=40), 100, n_chains=16, seed=2)
+    # the result dict pickles and deep-copies like the reference's plain-Python one (the lazy proposal state wraps a ctypes
+    # handle); a copy holds the materialised state and the original keeps working
+    import copy
+    import pickle
+
+    assert g["proposal_state"]._data is None
+    g2 = pickle.loads(pickle.dumps(g))
+    g3 = copy.deepcopy(g)
+    for other in (g2, g3):
+        assert other["proposal_state"]["k"] == 2 and np.array_equal(other["proposal_state"]["scaling"], g["proposal_state"]["scaling"])
+        assert np.array_equal(other["chain_3"].parameters, g["chain_3"].parameters)
     assert g["proposal_state"]["am_mu"] is None and g["proposal_state"]["scaling"].shape == (16,) and g["proposal_state"]["k"] == 2
+    # to_host(): the records leave HBM, the lazy views keep working
+    recs_g = g["chain_0"]._records.to_host()
+    assert not recs_g.on_device and not recs_g.parameters.is_cuda and np.array_equal(g["chain_9"].parameters, g2["chain_9"].parameters)
 
 
 @pytest.mark.parametrize("where", ["host", "pinned", "device"])
@@ -196,7 +210,7 @@ def test_engine_buffers_are_pooled_and_come_back_zeroed(eng_mod):
     from tinyda_amd import _lib
 
     lib = _lib.load()
-    assert b"0.3" in lib.tda_version()
+    assert b"0.4" in lib.tda_version()
     A, y = _problem(d=33, m=70)  # padded to 64 parameters: pad lanes of recycled buffers must read as zero
     d = A.shape[1]
     post = tda.Posterior(st.multivariate_normal(np.zeros(d), np.eye(d)), tda.GaussianLogLike(y, 0.01 * np.eye(len(y))), tda.LinearModel(A))

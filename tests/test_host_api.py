@@ -179,6 +179,36 @@ def test_lowering_pass():
     assert _device_plan([tda.Posterior(prior, like, tda.LinearModel(A))], Custom(np.eye(4))) is None
 
 
+def test_host_fallback_is_announced_with_the_rule_that_refused_the_problem():
+    """backend='auto' past a device limit: the reference's protocol runs, and ONE HostFallbackWarning names why;
+    backend='host' is silent, backend='hip' raises with the same reason"""
+    import warnings
+
+    from tinyda_amd import api
+
+    d = 65  # one parameter past the engine's limit
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((8, d))
+    post = tda.Posterior(stats.multivariate_normal(np.zeros(d), np.eye(d)), tda.GaussianLogLike(np.zeros(8), 0.1 * np.eye(8)), tda.LinearModel(A))
+    with pytest.warns(tda.HostFallbackWarning, match="more than 64 parameters") as rec:
+        res = tda.sample(post, tda.GaussianRandomWalk(np.eye(d), scaling=0.05), 5, n_chains=1)
+    assert res["backend"] == "host" and len([w for w in rec if issubclass(w.category, tda.HostFallbackWarning)]) == 1
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", tda.HostFallbackWarning)
+        tda.sample(post, tda.GaussianRandomWalk(np.eye(d), scaling=0.05), 5, n_chains=1, backend="host")
+    with pytest.raises(tda.EngineError, match="more than 64 parameters"):
+        tda.sample(post, tda.GaussianRandomWalk(np.eye(d), scaling=0.05), 5, n_chains=1, backend="hip")
+    # every refusal of the lowering pass leaves its reason
+    prior4 = stats.multivariate_normal(np.zeros(4), np.eye(4))
+    like = tda.GaussianLogLike(np.zeros(10), 0.1 * np.eye(10))
+    assert api._device_plan([tda.Posterior(prior4, like, lambda th: th)], tda.AdaptiveMetropolis(np.eye(4))) is None
+    assert "opaque Python model" in api._refusal[0]
+    posts = [tda.Posterior(prior4, tda.AdaptiveGaussianLogLike(np.zeros(200), 0.1 * np.eye(200)), tda.LinearModel(rng.standard_normal((200, 4)))),
+             tda.Posterior(prior4, tda.GaussianLogLike(np.zeros(200), 0.1 * np.eye(200)), tda.LinearModel(rng.standard_normal((200, 4))))]
+    if api.MAX_AEM_OUTPUTS < 200:
+        assert api._device_plan(posts, tda.CrankNicolson()) is None and "AdaptiveGaussianLogLike" in api._refusal[0]
+
+
 def test_multilevel_lowering_and_argument_checks():
     from tinyda_amd.api import _device_plan
 

@@ -3,7 +3,7 @@
 Drop-in for the hot path tda.sample() -> Chain.sample -> Proposal / Posterior / GaussianLogLike
 (tinyDA/sampler.py, chain.py, proposal.py, posterior.py, distributions.py); see DESIGN.md for the scope.
 """
-__version__ = "0.3.0"
+__version__ = "0.4.0"
 
 from ._lib import EngineError  # noqa: F401
 from .hostloop import Chain  # noqa: F401
@@ -24,5 +24,5 @@ from .proposals import (  # noqa: F401
     DREAM, DREAMZ, MALA, AdaptiveMetropolis, CrankNicolson, GaussianRandomWalk, IndependenceSampler,
     OperatorWeightedCrankNicolson, Proposal)
 from .records import DeviceChain  # noqa: F401
-from .api import sample  # noqa: F401
+from .api import HostFallbackWarning, sample  # noqa: F401
 from .moments import RecursiveSampleMoments, ZeroMeanRecursiveSampleMoments  # noqa: F401

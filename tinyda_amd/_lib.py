@@ -89,6 +89,9 @@ class tda_profile(C.Structure):
         ("ms_steps", C.c_double),
         ("ms_adapt", C.c_double),
         ("ms_total", C.c_double),
+        ("n_launch_aem", C.c_uint32),
+        ("reserved0", C.c_uint32),
+        ("ms_aem", C.c_double),
     ]
 
 

@@ -904,7 +904,7 @@ int progress_mark(tda_engine* e, int64_t S, const uint8_t* blk_acc, int64_t n_fl
 extern "C" {
 
 const char* tda_last_error(void) { return g_err.c_str(); }
-const char* tda_version(void) { return "tinyda_amd 0.3 (gfx950)"; }
+const char* tda_version(void) { return "tinyda_amd 0.4 (gfx950)"; }
 
 int tda_engine_create(const tda_config* cfg, tda_engine** out) {
   if (!cfg || !out) return fail(TDA_ERR_INVALID, "null argument");

@@ -1,0 +1,327 @@
+// Error-model refresh (round 4): (Sigma_e + Sigma_bias)^-1 of one level for every chain, as the triangular factor
+// V = L^-1 (Sigma = L L^T, so r^T Sigma^-1 r = |V r|^2), ONE WAVE PER CHAIN with the whole matrix in registers.
+//
+// What it replaces (k_aem_inverse, round 1-3): one workgroup of eight waves per chain around an LDS copy of the matrix, three
+// barriers per block column, one wave factoring the diagonal block while seven wait, then W = L^-1 and P = W^T W as two more
+// passes -- 0.73 ms per launch at 4096 chains x 128 outputs, 0.10-0.15 of the fp64 matrix peak.
+//
+// Here (reference: distributions.py:385-425 set_bias / loglike; chain.py:740-765; proposal.py:1548-1578):
+//   * the matrix is held as 16 x 16 tiles in the fp64 MFMA C/D register layout (lane (lc, hi), register r = element
+//     [hi + 4 r][lc]), upper factor U = L^T, exactly the layout k_chol_apply_blk uses for the proposal covariance: the
+//     accumulator layout of v_mfma_f64_16x16x4 is its operand layout for X^T Y products, so EVERY matrix-core operand below
+//     comes straight out of the registers that hold the tiles -- no LDS copy of the matrix, no barrier, no other wave;
+//   * the inverse comes out of the same elimination: [Sigma | I] -> [U | V] (block Gauss-Jordan on the augmented matrix).
+//     Block row p: the diagonal tile is factored and inverted in registers (16 pivots, pivot rows by ds_bpermute), the rest
+//     of the row is multiplied by that inverse on the matrix cores, the rows below are updated on the matrix cores.  A block
+//     row of U is dead once its trailing update is done and a block row of V is final at the same moment, so the live set
+//     peaks at 44 of the 72 tiles (352 registers of the wave's 512 at one wave per SIMD);
+//   * P = V^T V is never formed: every consumer evaluates |V r|^2 from the lower tiles (aem_quad_tiles below): a third
+//     fewer flops here and 72 KB instead of 128 KB per chain written;
+//   * update_link of the level under the refreshed model (posterior.py:112-134) is the last step of the same wave, from the V
+//     tiles while they are still in registers: the second launch of k_aem_action and its 72 KB read per chain are gone.
+// Padding rows / columns (m not a multiple of 16, or fewer tiles than the instance) are identity.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tda_kernels_mh.h"
+
+namespace tda {
+
+constexpr int AEMR_MAXSUM = 3;  // trackers summed into Sigma_bias (levels above the refreshed one: MAXLEV - 1)
+
+__host__ __device__ constexpr int aemr_ut(int T, int p, int i) { return p * T - p * (p - 1) / 2 + (i - p); }  // upper tile (p, i), p <= i
+__host__ __device__ constexpr int aemr_lt(int q, int i) { return q * (q + 1) / 2 + i; }                        // lower tile (q, i), i <= q
+__host__ __device__ constexpr int aemr_tiles(int T) { return T * (T + 1) / 2; }
+// doubles per chain of the V array for row stride MP (64 or 128)
+__host__ __device__ constexpr size_t aemr_v_doubles(int MP) { return (size_t)aemr_tiles(MP / 16) * 256; }
+// offset (doubles, inside one chain's V array) of V[i][j], i >= j
+__host__ __device__ inline size_t aemr_v_offset(int i, int j) {
+  const int ti = i >> 4, tj = j >> 4, ri = i & 15, cj = j & 15;
+  return ((size_t)(aemr_lt(ti, tj) * 4 + (ri >> 2)) * 64) + (ri & 3) * 16 + cj;
+}
+
+struct AemRefreshArgs {
+  int64_t N, NP;
+  int m, MP;                        // outputs, row stride of the row-major per-chain matrices (64 / 128)
+  int nsum;                         // tracker covariances summed into Sigma_bias
+  const double* cov;                // [MP][MP] Sigma_e, row-major, IDENTITY in the padding rows / columns (>= m)
+  const double* sig[AEMR_MAXSUM];   // [NP][MP][MP] row-major, zero in the padding (bitwise symmetric: k_aem_action writes x_i x_j and x_j x_i)
+  double* V;                        // [NP][tiles][4][64]: lower tiles of L^-1 in C/D layout
+  // update_link of the refreshed level (null rvec: not wanted)
+  const double* rvec;               // [NP][MP]  F_k(theta_k) - y_k + bias_k (k_aem_action phase 0 leaves it), 0 beyond m
+  double* ll;                       // [nlev][NP]
+  double* Sst;                      // [npairs][2][NP]
+  const int64_t* sid;               // [nlev][NP]
+  int nlev, k;                      // the refreshed level; its log-likelihood also goes to S[k][q2] of every level q2 > k holding the same parameters
+};
+
+__device__ __forceinline__ double aemr_pick(double v, int src) { return __shfl(v, src); }
+
+// Buffer addressing (descriptor in SGPRs + ONE 32-bit lane offset + a compile-time scalar offset per access): with 64-bit
+// per-lane pointers the compiler kept an address pair per access alive -- hundreds of registers in a fully unrolled kernel.
+typedef unsigned int aemr_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t aemr_rsrc(const double* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ double aemr_ld(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+  const aemr_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+  return __hiloint2double((int)v.y, (int)v.x);
+}
+__device__ __forceinline__ void aemr_st(double x, __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+  const aemr_u32x2 v = {(unsigned)__double2loint(x), (unsigned)__double2hiint(x)};
+  __builtin_amdgcn_raw_buffer_store_b64(v, rs, voff, soff, 0);
+}
+
+// sum over the 16 lanes of a DPP row (every lane of the row ends up with the total)
+__device__ __forceinline__ double aemr_row_sum(double v) {
+  v += dpp_move<0x128>(v);  // row_ror:8
+  v += dpp_move<0x124>(v);  // row_ror:4
+  v += dpp_move<0x122>(v);  // row_ror:2
+  v += dpp_move<0x121>(v);  // row_ror:1
+  return v;
+}
+
+// One wave: C (symmetric positive definite 16 x 16 tile, C/D layout; destroyed) -> Vd = inverse of its lower Cholesky factor in
+// C/D layout, Vt = the transpose of that (the A operand of "V_pp times a tile").  Gauss elimination of [C | I] with the upper
+// factor: pivot row k lives in the lanes hi == k & 3, register k >> 2; it reaches the lanes of its column with one ds_bpermute
+// per tile, the multipliers of a lane's own rows with up to four more.  1 / sqrt(pivot) = v_rsq_f64 + one third-order correction
+// (error ~ e^3, e = 2^-26: full precision), no division.
+__device__ __forceinline__ void aemr_diag(double (&C)[4], double (&Vd)[4], double (&Vt)[4], int lc, int hi) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) Vd[r] = (hi + 4 * r == lc) ? 1.0 : 0.0;
+#pragma unroll
+  for (int kl = 0; kl < 16; ++kl) {
+    const int kh = kl & 3, kr = kl >> 2;
+    const double dkk = bcast_lane64(C[kr], kh * 16 + kl);
+    const double y0 = __builtin_amdgcn_rsq(dkk);
+    const double e0 = fma(-dkk * y0, y0, 1.0);
+    const double inv = fma(y0 * e0, fma(0.375, e0, 0.5), y0);
+    const double fac = (hi == kh) ? inv : 1.0;
+    C[kr] *= fac;
+    Vd[kr] *= fac;
+    double ucol[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) ucol[rr] = rr >= kr ? aemr_pick(C[kr], kh * 16 + hi + 4 * rr) : 0.0;
+    const double urc = aemr_pick(C[kr], kh * 16 + lc);
+    const double urv = kl > 0 ? aemr_pick(Vd[kr], kh * 16 + lc) : ((lc == 0) ? inv : 0.0);  // (row 0 of V is e_0 / l_00: no exchange needed)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      if (rr < kr) continue;
+      const bool live = rr > kr || hi > kh;
+      const double uc = fma(-ucol[rr], urc, C[rr]);
+      const double uv = fma(-ucol[rr], urv, Vd[rr]);
+      C[rr] = live ? uc : C[rr];
+      Vd[rr] = live ? uv : Vd[rr];
+    }
+  }
+  // Vt[hi + 4 r][lc] = Vd[lc][hi + 4 r]: that element sits in lane ((lc & 3), hi + 4 r) -> index (lc & 3) * 16 + hi + 4 r, register lc >> 2
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int src = (lc & 3) * 16 + hi + 4 * r;
+    const double t0 = aemr_pick(Vd[0], src), t1 = aemr_pick(Vd[1], src), t2 = aemr_pick(Vd[2], src), t3 = aemr_pick(Vd[3], src);
+    const int sr = lc >> 2;
+    Vt[r] = sr == 0 ? t0 : (sr == 1 ? t1 : (sr == 2 ? t2 : t3));
+  }
+}
+
+// -1/2 |V r|^2 for one chain by ONE wave: Vc = that chain's lower tiles, s_r = r in LDS (zero beyond m, 16 T entries).
+// Block row p: z[hi + 4 r] += V(p, i)[r] * r[16 i + lc] over its tiles, one 16-lane reduction per register, squares summed.
+// Every lane returns the value.  TW / tw: block rows are dealt round-robin to TW cooperating waves (the caller adds the parts).
+template <int T, int TW = 1>
+__device__ __forceinline__ double aem_quad_tiles_part(const double* __restrict__ Vc, const double* __restrict__ s_r, int lane, int tw = 0) {
+  const int lc = lane & 15;
+  double sq = 0.0;
+#pragma unroll
+  for (int p = 0; p < T; ++p) {
+    if (TW > 1 && (p % TW) != tw) continue;
+    double v[T][4];
+#pragma unroll
+    for (int i = 0; i <= p; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[i][r] = Vc[(size_t)(aemr_lt(p, i) * 4 + r) * 64 + lane];
+    double z[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i <= p; ++i) {
+      const double rv = s_r[16 * i + lc];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) z[r] = fma(v[i][r], rv, z[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double zz = aemr_row_sum(z[r]);
+      sq = fma(zz, zz, sq);
+    }
+  }
+  return sq;  // per 16-lane row: the squares of its four output rows per block row; finish with sum_rows() and -0.5
+}
+template <int T>
+__device__ __forceinline__ double aem_quad_tiles(const double* __restrict__ Vc, const double* __restrict__ s_r, int lane) {
+  return -0.5 * sum_rows(aem_quad_tiles_part<T, 1>(Vc, s_r, lane, 0));
+}
+
+// NSUM = trackers summed into Sigma_bias (a template parameter: every `nsum > 1 ? load : 0` of a runtime count became a branch
+// of its own -- a thousand basic blocks -- and the register allocator spilled 700 registers across them)
+template <int T, int NSUM>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) k_aem_refresh(const AemRefreshArgs a) {
+  constexpr int NT = aemr_tiles(T);
+  __shared__ double s_r[16 * T];
+  const int lane = threadIdx.x, lc = lane & 15, hi = lane >> 4;
+  const int64_t c = blockIdx.x;
+  if (c >= a.N) return;
+  constexpr int MP = 16 * T;
+  const bool want_ll = a.rvec != nullptr;
+  {
+    const double* __restrict__ rsrc = want_ll ? a.rvec + c * MP : a.cov;  // (no r wanted: any readable address, the result is dropped)
+#pragma unroll
+    for (int i = lane; i < 16 * T; i += 64) s_r[i] = rsrc[i];
+  }
+  double* __restrict__ Vc = a.V + (size_t)c * NT * 256;
+  const __amdgpu_buffer_rsrc_t Vrs = aemr_rsrc(Vc);
+
+  // ---- Sigma_e + Sigma_bias into the upper tiles, and the 1e-9 rule (distributions.py:399-402) ----
+  // Two tiles per round, the next round's loads issued before this round's sums (the scheduler is fenced per round: left alone
+  // it hoists all 36 x 4 x (nsum + 1) loads to the top and spills)
+  double U[NT][4];
+  bool big = false;
+  {
+    constexpr int MPc = 16 * T;  // the row stride IS the instance's width (64 / 128): compile-time offsets
+    const size_t cbase = (size_t)c * MPc * MPc;
+    const __amdgpu_buffer_rsrc_t sg0 = aemr_rsrc(a.sig[0] + cbase);
+    const __amdgpu_buffer_rsrc_t sg1 = aemr_rsrc(NSUM > 1 ? a.sig[1] + cbase : a.sig[0] + cbase);
+    const __amdgpu_buffer_rsrc_t sg2 = aemr_rsrc(NSUM > 2 ? a.sig[2] + cbase : a.sig[0] + cbase);
+    const __amdgpu_buffer_rsrc_t sge = aemr_rsrc(a.cov);
+    const int lane_rm = (hi * MPc + lc) * 8;  // byte offset of element [hi][lc] of a row-major tile
+    constexpr int CH = 2;  // tiles per round
+    constexpr int NR = (NT + CH - 1) / CH;
+    double raw[2][CH][4][4];  // [buffer][tile][source: 3 trackers + Sigma_e][r]
+    auto tile_pi = [](int t, int& p, int& i) {  // upper tile index -> (p, i)
+      p = 0;
+      int rem = t;
+      while (rem >= T - p) { rem -= T - p; ++p; }
+      i = p + rem;
+    };
+    auto issue = [&](int rd, int buf) {
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int t = rd * CH + u;
+        if (t >= NT) continue;
+        int p, i;
+        tile_pi(t, p, i);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // (no bounds: the padding of the trackers is zero and that of Sigma_e the identity -- tda_engine_set_level)
+          const int so = ((16 * p + 4 * r) * MPc + 16 * i) * 8;
+          raw[buf][u][0][r] = aemr_ld(sg0, lane_rm, so);
+          if constexpr (NSUM > 1) raw[buf][u][1][r] = aemr_ld(sg1, lane_rm, so);
+          if constexpr (NSUM > 2) raw[buf][u][2][r] = aemr_ld(sg2, lane_rm, so);
+          raw[buf][u][3][r] = aemr_ld(sge, lane_rm, so);
+        }
+      }
+    };
+    issue(0, 0);
+#pragma unroll
+    for (int rd = 0; rd < NR; ++rd) {
+      if (rd + 1 < NR) issue(rd + 1, (rd + 1) & 1);
+      asm volatile("" ::: "memory");  // IR-level fence (loads stay in their round), then the machine scheduler's
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int t = rd * CH + u;
+        if (t >= NT) continue;
+        int p, i;
+        tile_pi(t, p, i);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double sb = 0.0 + raw[rd & 1][u][0][r];  // the reference's sum over the trackers starts from zero (proposal.py:1563-1569)
+          if constexpr (NSUM > 1) sb += raw[rd & 1][u][1][r];
+          if constexpr (NSUM > 2) sb += raw[rd & 1][u][2][r];
+          big = big || !(sb < 1e-9);
+          U[t][r] = raw[rd & 1][u][3][r] + sb;
+        }
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();  // s_r
+  double sq = 0.0;
+  if (__builtin_amdgcn_ballot_w64(big) == 0) {
+    // every entry of Sigma_bias below 1e-9: set_bias keeps the previous inverse; update_link still runs under the new bias
+    sq = aem_quad_tiles_part<T, 1>(Vc, s_r, lane, 0);
+  } else {
+    double Vl[NT][4];
+#pragma unroll
+    for (int p = 0; p < T; ++p) {
+      double Vd[4], Vt[4];
+      aemr_diag(U[aemr_ut(T, p, p)], Vd, Vt, lc, hi);
+      // the rest of block row p times V_pp (lower-triangular inverse of the diagonal tile's factor)
+#pragma unroll
+      for (int i = p + 1; i < T; ++i) {
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) acc = mfma_f64(Vt[kc], U[aemr_ut(T, p, i)][kc], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) U[aemr_ut(T, p, i)][r] = acc[r];
+      }
+#pragma unroll
+      for (int i = 0; i < p; ++i) {
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) acc = mfma_f64(Vt[kc], Vl[aemr_lt(p, i)][kc], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Vl[aemr_lt(p, i)][r] = acc[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Vl[aemr_lt(p, p)][r] = Vd[r];
+      // block row p of V is final: out it goes, and its share of |V r|^2
+      double z[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int i = 0; i <= p; ++i) {
+        const double rv = s_r[16 * i + lc];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          aemr_st(Vl[aemr_lt(p, i)][r], Vrs, lane * 8, (aemr_lt(p, i) * 4 + r) * 512);
+          z[r] = fma(Vl[aemr_lt(p, i)][r], rv, z[r]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double zz = aemr_row_sum(z[r]);
+        sq = fma(zz, zz, sq);
+      }
+      // block rows below: tile(q, i) -= U_pq^T X_pi for the U part (i >= q) and the V part (i <= p)
+#pragma unroll
+      for (int q = p + 1; q < T; ++q) {
+#pragma unroll
+        for (int i = q; i < T; ++i) {
+          double4_t acc = {U[aemr_ut(T, q, i)][0], U[aemr_ut(T, q, i)][1], U[aemr_ut(T, q, i)][2], U[aemr_ut(T, q, i)][3]};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc = mfma_f64(-U[aemr_ut(T, p, q)][r], U[aemr_ut(T, p, i)][r], acc);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) U[aemr_ut(T, q, i)][r] = acc[r];
+        }
+#pragma unroll
+        for (int i = 0; i <= p; ++i) {
+          double4_t acc = {0.0, 0.0, 0.0, 0.0};
+          if (i < p) acc = double4_t{Vl[aemr_lt(q, i)][0], Vl[aemr_lt(q, i)][1], Vl[aemr_lt(q, i)][2], Vl[aemr_lt(q, i)][3]};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc = mfma_f64(-U[aemr_ut(T, p, q)][r], Vl[aemr_lt(p, i)][r], acc);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Vl[aemr_lt(q, i)][r] = acc[r];
+        }
+      }
+    }
+  }
+  if (want_ll) {
+    const double llk = -0.5 * sum_rows(sq);
+    if (lane == 0) {
+      a.ll[(size_t)a.k * a.NP + c] = llk;
+      const int64_t idk = a.sid[(size_t)a.k * a.NP + c];
+      for (int q2 = a.k + 1; q2 < a.nlev; ++q2)
+        if (a.sid[(size_t)q2 * a.NP + c] == idk) a.Sst[((size_t)(q2 * (q2 - 1) / 2 + a.k) * 2 + 1) * a.NP + c] = llk;
+    }
+  }
+}
+
+}  // namespace tda

@@ -116,19 +116,20 @@ class JointPrior:
         self.dim = len(distributions)
 
     def logpdf(self, x):
-        return sum([self.distributions[i].logpdf(x[i]) for i in range(self.dim)])
+        # independent components: the joint log-density is the sum of the marginals, accumulated in parameter order
+        total = 0.0
+        for dist, xi in zip(self.distributions, np.asarray(x).reshape(-1)):
+            total = total + dist.logpdf(xi)
+        return total
 
     def rvs(self, n_samples=1):
-        x = np.zeros((n_samples, self.dim))
-        for i in range(self.dim):
-            x[:, i] = self.distributions[i].rvs(size=n_samples)
-        return x.flatten() if n_samples == 1 else x
+        # one column per component, drawn in parameter order (the order fixes which variates of the global stream go where)
+        draws = np.column_stack([dist.rvs(size=n_samples) for dist in self.distributions])
+        return draws[0] if n_samples == 1 else draws
 
     def ppf(self, x):
-        y = np.zeros(x.shape)
-        for i in range(self.dim):
-            y[:, i] = self.distributions[i].ppf(x[:, i])
-        return y
+        # quantile transform of a [n, dim] array of uniforms (Latin hypercube archives), column by column
+        return np.column_stack([dist.ppf(col) for dist, col in zip(self.distributions, np.asarray(x).T)])
 
     def _lowering(self):
         """(kinds, loc, scale) when every component is a frozen scipy norm or uniform, else None."""

@@ -30,6 +30,7 @@ class Link:
 _STAGE_BYTES = 64 << 20  # per page-locked staging buffer (two per process and device)
 _stage = {}
 _stage_lock = threading.Lock()
+_transfer_locks = {}  # device -> lock held for a whole all_chains_host pass (the two staging slots are per process and device)
 _COPY_THREADS = 8
 _copy_pool = None
 
@@ -66,6 +67,11 @@ def _staging(device):
         return _stage[device]
 
 
+def _transfer_lock(device):
+    with _stage_lock:
+        return _transfer_locks.setdefault(device, threading.Lock())
+
+
 def _is_torch(a):
     return hasattr(a, "data_ptr") and hasattr(a, "device")
 
@@ -88,6 +94,15 @@ class DeviceRecords:
     @property
     def n_chains(self):
         return int(self.parameters.shape[1])
+
+    def to_host(self):
+        """move the record arrays to host memory and let go of the HBM (a C2-size result holds 4.4 GB there, the coarse levels of
+        a long MLDA run far more; the lazy views keep working, from host arrays).  Returns self."""
+        if self.on_device:
+            for f in self.FIELDS:
+                setattr(self, f, getattr(self, f).cpu())
+            self.on_device = False
+        return self
 
     def chain_host(self, field, chain, rows=slice(None)):
         """rows of ONE chain as a NumPy array ([R', d], [R', 3] or [R']); one strided device gather + one copy"""
@@ -122,7 +137,8 @@ class DeviceRecords:
             return out
         stage = _staging(a.device.index or 0)
         events = [torch.cuda.Event(), torch.cuda.Event()]
-        with torch.cuda.device(a.device):
+        # two threads reading results at once would interleave their copies in the same two slots: one pass at a time per device
+        with _transfer_lock(a.device.index or 0), torch.cuda.device(a.device):
             pending = None
             for g, c0 in enumerate(range(0, N, group)):
                 c1 = min(N, c0 + group)

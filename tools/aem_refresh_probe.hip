@@ -1,0 +1,143 @@
+// k_aem_refresh (tda_kernels_aemr.h) on its own: correctness against a host Cholesky / triangular inverse, and launch time at
+// 4096 chains.  Debug tool, not part of the library.
+// Build: hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -w -Itinyda_amd/csrc -Iinclude -o /tmp/arp tools/aem_refresh_probe.hip
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+#include "tinyda_amd.h"
+#include "tda_kernels_aemr.h"
+using namespace tda;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+template <int T>
+static void launch(const AemRefreshArgs& a) {
+  if (a.nsum == 1) hipLaunchKernelGGL((k_aem_refresh<T, 1>), dim3((unsigned)a.N), dim3(64), 0, 0, a);
+  else if (a.nsum == 2) hipLaunchKernelGGL((k_aem_refresh<T, 2>), dim3((unsigned)a.N), dim3(64), 0, 0, a);
+  else hipLaunchKernelGGL((k_aem_refresh<T, 3>), dim3((unsigned)a.N), dim3(64), 0, 0, a);
+}
+
+static int run_case(int m, int64_t N, int nsum, int reps) {
+  const int MP = m <= 64 ? 64 : 128, T = MP / 16;
+  const int nlev = 3, k = 0;
+  std::mt19937_64 g(5 + m + nsum);
+  std::normal_distribution<double> nd;
+  const int NV = 4;  // distinct matrices, dealt round-robin
+  std::vector<double> cov((size_t)MP * MP, 0.0);
+  for (int i = 0; i < MP; ++i) cov[(size_t)i * MP + i] = i < m ? 0.01 : 1.0;
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < i; ++j) cov[(size_t)i * MP + j] = cov[(size_t)j * MP + i] = 1e-4 * nd(g) / m;
+  std::vector<std::vector<double>> sig(nsum * NV, std::vector<double>((size_t)MP * MP, 0.0));
+  std::vector<double> x(m);
+  for (auto& sgm : sig)
+    for (int s = 0; s < 20; ++s) {
+      for (auto& v : x) v = 0.05 * nd(g);
+      for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m; ++j) sgm[(size_t)i * MP + j] += x[i] * x[j] / 20;
+    }
+  std::vector<double> rv((size_t)NV * MP, 0.0);
+  for (int v = 0; v < NV; ++v)
+    for (int i = 0; i < m; ++i) rv[(size_t)v * MP + i] = 0.1 * nd(g);
+  double *dcov, *dsig[3] = {nullptr, nullptr, nullptr}, *dV, *drv, *dll, *dS;
+  int64_t* dsid;
+  const size_t MM = (size_t)MP * MP, VD = aemr_v_doubles(MP);
+  CK(hipMalloc(&dcov, MM * 8));
+  CK(hipMemcpy(dcov, cov.data(), MM * 8, hipMemcpyHostToDevice));
+  for (int s = 0; s < nsum; ++s) {
+    CK(hipMalloc(&dsig[s], (size_t)N * MM * 8));
+    for (int64_t c = 0; c < N; ++c) CK(hipMemcpy(dsig[s] + (size_t)c * MM, sig[s * NV + c % NV].data(), MM * 8, hipMemcpyHostToDevice));
+  }
+  CK(hipMalloc(&dV, (size_t)N * VD * 8));
+  CK(hipMemset(dV, 0, (size_t)N * VD * 8));
+  CK(hipMalloc(&drv, (size_t)N * MP * 8));
+  for (int64_t c = 0; c < N; ++c) CK(hipMemcpy(drv + (size_t)c * MP, rv.data() + (size_t)(c % NV) * MP, MP * 8, hipMemcpyHostToDevice));
+  CK(hipMalloc(&dll, (size_t)nlev * N * 8));
+  CK(hipMalloc(&dS, (size_t)3 * 2 * N * 8));
+  CK(hipMalloc(&dsid, (size_t)nlev * N * 8));
+  CK(hipMemset(dsid, 0, (size_t)nlev * N * 8));
+  AemRefreshArgs a{};
+  a.N = N; a.NP = N; a.m = m; a.MP = MP; a.nsum = nsum; a.cov = dcov;
+  for (int s = 0; s < nsum; ++s) a.sig[s] = dsig[s];
+  a.V = dV; a.rvec = drv; a.ll = dll; a.Sst = dS; a.sid = dsid; a.nlev = nlev; a.k = k;
+  auto go = [&]() { if (T == 4) launch<4>(a); else launch<8>(a); };
+  go();
+  CK(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipEventRecord(e0, 0);
+  for (int r = 0; r < reps; ++r) go();
+  hipEventRecord(e1, 0);
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  // check chains 0 .. NV-1 and the last one
+  double worstV = 0, worstL = 0;
+  std::vector<double> V(VD), ll(N);
+  CK(hipMemcpy(ll.data(), dll, N * 8, hipMemcpyDeviceToHost));
+  for (int64_t c : {(int64_t)0, (int64_t)1, (int64_t)2, (int64_t)3, N - 1}) {
+    if (c >= N) continue;
+    CK(hipMemcpy(V.data(), dV + (size_t)c * VD, VD * 8, hipMemcpyDeviceToHost));
+    std::vector<long double> S((size_t)m * m), L((size_t)m * m, 0.0L), W((size_t)m * m, 0.0L);
+    for (int i = 0; i < m; ++i)
+      for (int j = 0; j < m; ++j) {
+        double sb = 0.0;
+        for (int s = 0; s < nsum; ++s) sb += sig[s * NV + c % NV][(size_t)i * MP + j];
+        S[(size_t)i * m + j] = cov[(size_t)i * MP + j] + sb;
+      }
+    for (int j = 0; j < m; ++j) {
+      long double d = S[(size_t)j * m + j];
+      for (int k2 = 0; k2 < j; ++k2) d -= L[(size_t)j * m + k2] * L[(size_t)j * m + k2];
+      L[(size_t)j * m + j] = sqrtl(d);
+      for (int i = j + 1; i < m; ++i) {
+        long double s = S[(size_t)i * m + j];
+        for (int k2 = 0; k2 < j; ++k2) s -= L[(size_t)i * m + k2] * L[(size_t)j * m + k2];
+        L[(size_t)i * m + j] = s / L[(size_t)j * m + j];
+      }
+    }
+    for (int j = 0; j < m; ++j) {  // column j of W = L^-1
+      W[(size_t)j * m + j] = 1.0L / L[(size_t)j * m + j];
+      for (int i = j + 1; i < m; ++i) {
+        long double s = 0;
+        for (int k2 = j; k2 < i; ++k2) s += L[(size_t)i * m + k2] * W[(size_t)k2 * m + j];
+        W[(size_t)i * m + j] = -s / L[(size_t)i * m + i];
+      }
+    }
+    long double q = 0;
+    for (int i = 0; i < m; ++i) {
+      long double z = 0;
+      for (int j = 0; j <= i; ++j) {
+        z += W[(size_t)i * m + j] * rv[(size_t)(c % NV) * MP + j];
+        const double got = V[aemr_v_offset(i, j)];
+        const double ref = (double)W[(size_t)i * m + j];
+        worstV = fmax(worstV, fabs(got - ref) / (fabs(ref) + 1.0));
+      }
+      q += z * z;
+    }
+    const double llref = (double)(-0.5L * q);
+    worstL = fmax(worstL, fabs(ll[c] - llref) / fabs(llref));
+  }
+  const double us = ms * 1000.0 / reps;
+  const double flops = (double)N * (2.0 / 3.0) * pow((double)MP, 3);
+  printf("m=%3d MP=%3d nsum=%d N=%lld: %8.1f us / launch  (%.1f TFLOP/s at 2/3 m^3)   max rel err V %.2e, ll %.2e\n", m, MP, nsum, (long long)N, us,
+         flops / (us * 1e-6) / 1e12, worstV, worstL);
+  hipFree(dcov); for (int s = 0; s < nsum; ++s) hipFree(dsig[s]);
+  hipFree(dV); hipFree(drv); hipFree(dll); hipFree(dS); hipFree(dsid);
+  return (worstV < 1e-10 && worstL < 1e-10) ? 0 : 2;
+}
+
+int main(int argc, char** argv) {
+  const int64_t N = argc > 1 ? atoll(argv[1]) : 4096;
+  int rc = 0;
+  rc |= run_case(128, N, 2, 10);
+  rc |= run_case(128, N, 1, 10);
+  rc |= run_case(100, N, 3, 5);
+  rc |= run_case(64, N, 2, 10);
+  rc |= run_case(40, N, 1, 5);
+  rc |= run_case(8, N, 1, 5);
+  printf(rc ? "FAILED\n" : "all ok\n");
+  return rc;
+}

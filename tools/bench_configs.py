@@ -1,10 +1,45 @@
-"""Throughput of the other BASELINE configurations (parity-test cases, not the bench line): C3 (2-level DA, pCN,
-256/2048 obs, subsampling 10) and C5-literal (3-level MLDA 128/512/2048 obs, AM, no error model), 4096 chains."""
-import json, os, sys, time
+"""The BASELINE configurations other than the headline (C2a is bench.py itself), each at its full per-GPU chain count, each with
+its own roofline entry.  bench.py imports `config_block()` and puts the list into its one JSON line as `"configs"`; run as a
+script it prints one JSON line per configuration.
+
+    python tools/bench_configs.py                 every configuration
+    python tools/bench_configs.py c3|c4 [K]|c5|c5aem M [n_fine]|c5aemd M|c2b|mala|c4peer|c4peerlag
+
+Accounting; `frac` is the DOMINANT kernel bucket's algorithmic work over its HIP-event time against the peak of
+the unit that bounds it, `pipeline_frac` the same work over the wall time of the run (every kernel and gap included):
+
+  C2b  dense Sigma, AM            flops / eval = 2 m d + 2 m^2 + 3 m                         (2 232 320)       fp64 MFMA 78.6 TF
+  C3   DA pCN 256 / 2048, 10      flops / coarse eval = 2*256*64 + 2*2048*64 / 10            (58 982)          fp64 pipe
+  C4   DREAM, 32-dim Rosenbrock   bytes / eval = theta r/w 512 + record 281 + append 256 + 2 row gathers 512  (1 561)  HBM 8 TB/s
+  C5   MLDA 128/512/2048 [5,3]    flops / coarse eval = 2*64*(128 + 512/5 + 2048/15)         (46 967)          fp64 pipe
+  C5e  C5 + dense error model, common m: per coarse eval the three forward models 2*64*m*(1 + 1/5 + 1/15), the dense
+       quadratic form 2 m^2 of every level-0 evaluation and of the two adaptive upper-level evaluations per 15, and the FOUR
+       m x m inversions per finest iteration priced at m^3 each (Cholesky + triangular inverse + product; numpy's inv is 2 m^3)
+"""
+import json
+import os
+import sys
+import time
+
 import numpy as np
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-from tinyda_amd.engine import Engine
+
+HBM_PEAK = 8.0e12
+FP64_MFMA_PEAK = 78.6e12
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def _engine():
+    from tinyda_amd.engine import Engine
+
+    return Engine
+
 
 def levels(ms, d=64, seed=2, sigma=0.1):
     rng = np.random.default_rng(seed)
@@ -15,9 +50,38 @@ def levels(ms, d=64, seed=2, sigma=0.1):
         out.append((A, A @ truth + sigma * rng.standard_normal(m)))
     return out
 
-def run(name, ms, sl, prop, n_fine, N=4096, d=64):
+
+def _roof(res, bound, per_eval, evals, bucket_ms, seconds, kernel):
+    """roofline fields of one configuration: `per_eval` flops (bound 'mfma') or bytes (bound 'hbm') per coarsest-level evaluation"""
+    peak = FP64_MFMA_PEAK if bound == "mfma" else HBM_PEAK
+    work = per_eval * evals
+    res.update(dominant_kernel=kernel, bound=bound, flops_or_bytes_per_eval=per_eval,
+               unit="TFLOP/s" if bound == "mfma" else "GB/s", peak=peak / (1e12 if bound == "mfma" else 1e9),
+               achieved=(work / (bucket_ms * 1e-3) if bucket_ms > 0 else 0.0) / (1e12 if bound == "mfma" else 1e9),
+               frac=(work / (bucket_ms * 1e-3) / peak) if bucket_ms > 0 else None,
+               pipeline_frac=work / seconds / peak, dominant_kernel_ms=bucket_ms)
+    return res
+
+
+def _timed(fn):
+    torch = _torch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fn()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def _level_buffers(rows, N, d):
+    torch = _torch()
+    return [(torch.empty((r, N, d), dtype=torch.float64, device="cuda"), torch.empty((r, N, 3), dtype=torch.float64, device="cuda"),
+             torch.empty((r, N), dtype=torch.uint8, device="cuda")) for r in rows]
+
+
+def run_hierarchy(name, ms, sl, prop, n_fine, per_eval, kernel, N=4096, d=64):
+    torch = _torch()
     lv = levels(ms)
-    e = Engine(N, d, seed=9, n_levels=len(ms))
+    e = _engine()(N, d, seed=9, n_levels=len(ms))
     e.set_prior(np.zeros(d), np.eye(d))
     for k, (A, y) in enumerate(lv):
         e.set_level(k, A, y, 0, 0.01)
@@ -25,27 +89,38 @@ def run(name, ms, sl, prop, n_fine, N=4096, d=64):
     e.set_subchains(sl)
     e.init(None)
     rows = e.rows_per_level(n_fine)
-    outs = [(torch.empty((r, N, d), dtype=torch.float64, device="cuda"), torch.empty((r, N, 3), dtype=torch.float64, device="cuda"),
-             torch.empty((r, N), dtype=torch.uint8, device="cuda")) for r in rows]
+    outs = _level_buffers(rows, N, d)
     e.run_levels(max(1, n_fine // 10), outs)  # warm-up
+    dt = _timed(lambda: e.run_levels(n_fine, outs))  # wall clock without the profiling events (two per launch)
     e.set_profiling(True)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    e.run_levels(n_fine, outs)
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    _timed(lambda: e.run_levels(n_fine, outs))
     p = e.profile()
-    res = dict(config=name, chains=N, fine_iterations=n_fine, seconds=dt, coarse_evals_per_s=N * rows[0] / dt,
-               finest_iterations_per_s=N * n_fine / dt, acceptance=[float(o[2].float().mean().item()) for o in outs], kernel_ms=p)
-    print(json.dumps(res))
+    res = dict(name=name, chains=N, fine_iterations=n_fine, seconds=dt, evals_per_s=N * rows[0] / dt,
+               finest_it_per_s=N * n_fine / dt, acceptance=[float(o[2].float().mean().item()) for o in outs], kernel_ms=p)
     e.close()
+    return _roof(res, "mfma", per_eval, N * rows[0], p["ms_steps"], dt, kernel)
 
-def run_c5_aem(N=4096, d=64, m=64, n_fine=20, diagonal=False):
+
+def run_c3(n_fine=200):
+    return run_hierarchy("C3: 2-level DA, pCN(0.02), 256/2048 obs, subsampling_rate=10", (256, 2048), [10], dict(kind=1, scaling=0.02), n_fine,
+                         2 * 256 * 64 + 2 * 2048 * 64 / 10, "k_da_steps<64,2,true,0,2>")
+
+
+def run_c5(n_fine=60):
+    return run_hierarchy("C5-literal: 3-level MLDA, AM, 128/512/2048 obs, subchains [5,3], no error model", (128, 512, 2048), [5, 3],
+                         dict(kind=2, C_=1e-4 * np.eye(64), t0=100, period=100), n_fine,
+                         2 * 64 * (128 + 512 / 5 + 2048 / 15), "k_da_steps<64,1,false,0,3>")
+
+
+def run_c5_aem(N=4096, d=64, m=128, n_fine=20, diagonal=False):
     """C5 with the state-independent adaptive error model: levels share the output dimension (m = 128 is SURVEY
-    §8(d)'s C5, the device error-model limit); levels 0/1 AdaptiveGaussianLogLike, level 2 isotropic; AM; subchains [5, 3]."""
+    §8(d)'s C5); levels 0/1 AdaptiveGaussianLogLike, level 2 isotropic; AM; subchains [5, 3]."""
+    torch = _torch()
     rng = np.random.default_rng(6)
     truth = rng.standard_normal(d)
     Af = rng.standard_normal((m, d)) / 8
     y = Af @ truth + 0.1 * rng.standard_normal(m)
-    e = Engine(N, d, seed=10, n_levels=3)
+    e = _engine()(N, d, seed=10, n_levels=3)
     e.set_prior(np.zeros(d), np.eye(d))
     for k in range(3):
         A = Af + 0.02 * (2 - k) * rng.standard_normal((m, d)) / 8
@@ -58,79 +133,98 @@ def run_c5_aem(N=4096, d=64, m=64, n_fine=20, diagonal=False):
     e.set_error_model("state-independent-diagonal" if diagonal else "state-independent")
     e.init(None)
     rows = e.rows_per_level(n_fine)
-    outs = [(torch.empty((r, N, d), dtype=torch.float64, device="cuda"), torch.empty((r, N, 3), dtype=torch.float64, device="cuda"),
-             torch.empty((r, N), dtype=torch.uint8, device="cuda")) for r in rows]
+    outs = _level_buffers(rows, N, d)
     e.run_levels(2, outs)
+    dt = _timed(lambda: e.run_levels(n_fine, outs))
     e.set_profiling(True)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    e.run_levels(n_fine, outs)
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(json.dumps(dict(config="C5 + state-independent AEM (%s), common m=%d, AM, subchains [5,3]" % ("diagonal extension" if diagonal else "dense, reference", m), chains=N, kernel_ms=e.profile(), fine_iterations=n_fine, seconds=dt,
-                          coarse_evals_per_s=N * rows[0] / dt, finest_iterations_per_s=N * n_fine / dt,
-                          acceptance=[float(o[2].float().mean().item()) for o in outs])))
+    _timed(lambda: e.run_levels(n_fine, outs))
+    p = e.profile()
+    res = dict(name="C5 + state-independent error model (%s), common m=%d, AM, subchains [5,3]" % ("diagonal extension" if diagonal else "dense, as the reference", m),
+               chains=N, fine_iterations=n_fine, seconds=dt, evals_per_s=N * rows[0] / dt, finest_it_per_s=N * n_fine / dt,
+               acceptance=[float(o[2].float().mean().item()) for o in outs], kernel_ms=p)
     e.close()
+    if diagonal:
+        per_eval = 2 * 64 * m * (1 + 1 / 5 + 1 / 15) + 3 * m * (1 + 1 / 5)
+        return _roof(res, "mfma", per_eval, N * rows[0], p["ms_steps"] + p["ms_propose"] + p["ms_adapt"], dt, "k_ml_steps + k_aemd_*")
+    per_eval = 2 * 64 * m * (1 + 1 / 5 + 1 / 15) + 2 * m * m * (1 + 2 / 15 + 4 / 15) + 4 * m ** 3 / 15
+    bucket = p.get("ms_aem") or p["ms_adapt"]
+    return _roof(res, "mfma", per_eval, N * rows[0], bucket, dt, "error-model refresh (k_aem_action + k_aem_inverse)")
 
 
 def run_mala(N=4096, d=64, m=1024, T=2000):
     """C2a target (d = 64, m = 1024, iso noise, prior N(0, I), theta0 ~ prior) sampled with MALA, adaptive scaling: evals/s and
     bulk ESS/s of the second half computed on the device, next to AdaptiveMetropolis on the same target."""
     from tinyda_amd import summaries
+
+    torch = _torch()
     rng = np.random.default_rng(1)
     A = rng.standard_normal((m, d)) / 8
     y = A @ rng.standard_normal(d) + 0.1 * rng.standard_normal(m)
+    out = []
     for name, prop in (("MALA(scaling=0.02, adaptive, period=50)", dict(kind=6, scaling=0.02, adaptive=True, gamma=1.01, period=50)),
                        ("AdaptiveMetropolis(C0=1e-4 I, t0=100, period=100)", dict(kind=2, C_=1e-4 * np.eye(d), t0=100, period=100))):
-        e = Engine(N, d, seed=1)
-        e.set_prior(np.zeros(d), np.eye(d)); e.set_level(0, A, y, 0, 0.01)
+        e = _engine()(N, d, seed=1)
+        e.set_prior(np.zeros(d), np.eye(d))
+        e.set_level(0, A, y, 0, 0.01)
         e.set_proposal(**prop)
         e.init(None)
-        p = torch.empty((T, N, d), dtype=torch.float64, device="cuda"); s = torch.empty((T, N, 3), dtype=torch.float64, device="cuda")
+        p = torch.empty((T, N, d), dtype=torch.float64, device="cuda")
+        s = torch.empty((T, N, 3), dtype=torch.float64, device="cuda")
         a = torch.empty((T, N), dtype=torch.uint8, device="cuda")
         e.run(200, p[:200], s[:200], a[:200])
         e.set_profiling(True)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         e.run(T, p, s, a)
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
         pr = e.profile()
         di = summaries.ess_rhat_device(p, burnin=T // 2)
         ess, rhat = di["ess"], di["rhat"]
-        print(json.dumps(dict(config="C2a target, " + name, chains=N, steps=T, evals_per_s=N * T / dt,
-                              steps_kernel_ns_per_eval=pr["ms_steps"] * 1e6 / (N * T), acceptance_second_half=float(a[T // 2:].float().mean().item()),
-                              min_bulk_ess=float(np.min(ess)), ess_per_s=float(np.min(ess)) / dt, max_rhat=float(np.max(rhat)),
-                              scaling_mean=float(np.mean(e.proposal_state()["scaling"])))))
+        out.append(dict(name="C2a target, " + name, chains=N, steps=T, evals_per_s=N * T / dt,
+                        steps_kernel_ns_per_eval=pr["ms_steps"] * 1e6 / (N * T), acceptance_second_half=float(a[T // 2:].float().mean().item()),
+                        min_bulk_ess=float(np.min(ess)), ess_per_s=float(np.min(ess)) / dt, max_rhat=float(np.max(rhat)),
+                        scaling_mean=float(np.mean(e.proposal_state()["scaling"]))))
         e.close()
+    return out
 
 
 def run_c2b(N=4096, d=64, m=1024, T=300):
     """C2b: dense data covariance (DefaultGaussianLogLike), AM, 4096 chains."""
+    torch = _torch()
     rng = np.random.default_rng(1)
     A = rng.standard_normal((m, d)) / 8
     y = A @ rng.standard_normal(d) + 0.1 * rng.standard_normal(m)
     Lc = 0.1 * np.eye(m) + 0.01 * np.tril(rng.standard_normal((m, m)))
-    e = Engine(N, d, seed=1)
-    e.set_prior(np.zeros(d), np.eye(d)); e.set_level(0, A, y, 2, Lc @ Lc.T)
+    e = _engine()(N, d, seed=1)
+    e.set_prior(np.zeros(d), np.eye(d))
+    e.set_level(0, A, y, 2, Lc @ Lc.T)
     e.set_proposal(2, 1e-4 * np.eye(d), t0=100, period=100)
     e.init(None)
-    p = torch.empty((T, N, d), dtype=torch.float64, device="cuda"); s = torch.empty((T, N, 3), dtype=torch.float64, device="cuda")
+    p = torch.empty((T, N, d), dtype=torch.float64, device="cuda")
+    s = torch.empty((T, N, 3), dtype=torch.float64, device="cuda")
     a = torch.empty((T, N), dtype=torch.uint8, device="cuda")
     e.run(100, p[:100], s[:100], a[:100])
+    dt = _timed(lambda: e.run(T, p, s, a))
     e.set_profiling(True)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    e.run(T, p, s, a)
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    _timed(lambda: e.run(T, p, s, a))
     pr = e.profile()
-    flops = 2 * m * d + 2 * m * m + 3 * m
-    print(json.dumps(dict(config="C2b: dense Sigma (m=1024), AM", chains=N, steps=T, evals_per_s=N * T / dt,
-                          steps_kernel_ns_per_eval=pr["ms_steps"] * 1e6 / (N * T),
-                          mfma_tflops_survey_accounting=flops * N * T / (pr["ms_steps"] * 1e-3) / 1e12, mfma_peak_tflops=78.6)))
     e.close()
+    res = dict(name="C2b: dense Sigma (m=1024), AM, 4096 chains", chains=N, steps=T, seconds=dt, evals_per_s=N * T / dt,
+               finest_it_per_s=N * T / dt, kernel_ms=pr)
+    return _roof(res, "mfma", 2 * m * d + 2 * m * m + 3 * m, N * T, pr["ms_steps"], dt, "k_mh_steps<64,4> (dense quadratic form on MFMA)")
+
+
+C4_BYTES_PER_EVAL = 512 + 281 + 256 + 512  # SURVEY §8(d): theta r/w, record, archive append, 2 delta row gathers
 
 
 def run_c4(N=8192, d=32, T=400, M0=320, K=16, peer=False, lag=False):
     """C4 on one GPU: d=32 Rosenbrock chain, DREAM (shared archive of M0 prior rows + every chain's states, synchronised
     every K steps), 8192 chains/GPU."""
     from tinyda_amd import distributed as tdist
-    e = Engine(N, d, seed=4)
+
+    torch = _torch()
+    e = _engine()(N, d, seed=4)
     e.set_prior(np.zeros(d), np.eye(d))
     e.set_level_rosenbrock(0, 1.0, 10.0, 0.0, 1.0)
     e.set_proposal_dreamz(M0, delta=1, nCR=3, adaptive=True, period=100, shared=True, sync_every=K, capacity=M0 + (T + 50) * N)
@@ -142,43 +236,78 @@ def run_c4(N=8192, d=32, T=400, M0=320, K=16, peer=False, lag=False):
     if peer:  # the distributed archive's block-wise publish protocol with the one rank a box has (what it costs on the host side)
         tdist.setup_peer_archive(e)
         tdist.run_peer_dream(e, 48, K, params, stats, acc, period=100, lag=lag)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         tdist.run_peer_dream(e, T, K, params, stats, acc, period=100, lag=lag)
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print(json.dumps(dict(config="C4 with the distributed archive protocol (one rank%s), sync every %d" % (", lagged publish" if lag else "", K), chains=N, steps=T, seconds=dt,
-                              evals_per_s=N * T / dt, archive_rows=e.dreamz_state()["archive_rows"])))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res = dict(name="C4 with the distributed archive protocol (one rank%s), sync every %d" % (", lagged publish" if lag else "", K), chains=N, steps=T, seconds=dt,
+                   evals_per_s=N * T / dt, archive_rows=e.dreamz_state()["archive_rows"])
         e.close()
-        return
+        return res
     tdist.run_shared_dream(e, 48, K, params, stats, acc)  # warm-up
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    tdist.run_shared_dream(e, T, K, params, stats, acc)
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(json.dumps(dict(config="C4: DREAM (shared archive, sync every %d) on 32-dim Rosenbrock" % K, chains=N, steps=T, seconds=dt,
-                          evals_per_s=N * T / dt, acceptance=float(acc.float().mean().item()), archive_rows=e.dreamz_state()["archive_rows"],
-                          alg_bytes_per_eval=1500, hbm_equiv_GBps=N * T / dt * 1500 / 1e9)))
+    dt = _timed(lambda: tdist.run_shared_dream(e, T, K, params, stats, acc))
+    rows_timed = e.dreamz_state()["archive_rows"]
+    acc_timed = float(acc.float().mean().item())
+    res = dict(name="C4: DREAM (shared archive, exchange every %d) on 32-dim Rosenbrock, 8192 chains" % K, chains=N, steps=T, seconds=dt,
+               evals_per_s=N * T / dt, finest_it_per_s=N * T / dt, acceptance=acc_timed, archive_rows=rows_timed)
     e.close()
+    # kernel buckets from a second engine of the same set-up with profiling on (two events per launch cost these 26-37 us
+    # kernels a quarter of the wall clock: never the timed run)
+    e = _engine()(N, d, seed=4)
+    e.set_prior(np.zeros(d), np.eye(d))
+    e.set_level_rosenbrock(0, 1.0, 10.0, 0.0, 1.0)
+    e.set_proposal_dreamz(M0, delta=1, nCR=3, adaptive=True, period=100, shared=True, sync_every=K, capacity=M0 + (T + 50) * N)
+    e.set_archive(None)
+    e.init(None)
+    tdist.run_shared_dream(e, 48, K, params, stats, acc)
+    e.set_profiling(True)
+    _timed(lambda: tdist.run_shared_dream(e, T, K, params, stats, acc))
+    pr = e.profile()
+    res["kernel_ms"] = pr
+    e.close()
+    # the step kernel moves the records and the states; the draw kernel the archive gathers: price the whole period on the
+    # slower of the two buckets, `pipeline_frac` on the wall time
+    dom = "k_dreamz_draw<32>" if pr["ms_propose"] >= pr["ms_steps"] else "k_dreamz_steps_wave<32>"
+    return _roof(res, "hbm", C4_BYTES_PER_EVAL, N * T, max(pr["ms_propose"], pr["ms_steps"]), dt, dom)
+
+
+def config_block(log=None):
+    """Every BASELINE configuration besides the headline, full chain counts, one dict each (errors are reported in place: the
+    headline line must survive a failing side run)."""
+    runs = (("C2b", run_c2b), ("C3", run_c3), ("C4/16", lambda: run_c4(K=16)), ("C4/128", lambda: run_c4(K=128)),
+            ("C5-literal", run_c5), ("C5+AEM128", lambda: run_c5_aem(m=128)))
+    out = []
+    for tag, fn in runs:
+        t0 = time.perf_counter()
+        try:
+            r = fn()
+        except Exception as exc:  # noqa: BLE001
+            r = {"name": tag, "error": repr(exc)}
+        r["tag"] = tag
+        r["setup_and_run_s"] = time.perf_counter() - t0
+        out.append(r)
+        if log:
+            log("[configs] %s: %s (%.1f s)" % (tag, ("%.4g evals/s, frac %s" % (r.get("evals_per_s", 0), r.get("frac"))) if "error" not in r else r["error"],
+                                                 r["setup_and_run_s"]))
+    return out
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] in ("c5aem", "c5aemd"):  # python tools/bench_configs.py c5aem 128 [n_fine]
-        run_c5_aem(m=int(sys.argv[2]), n_fine=int(sys.argv[3]) if len(sys.argv) > 3 else 20, diagonal=sys.argv[1] == "c5aemd")
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "c3":
-        run("C3: DA pCN(0.02) 256/2048 obs, subsampling_rate=10", (256, 2048), [10], dict(kind=1, scaling=0.02), 200)
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] in ("c4", "c4peer", "c4peerlag"):
-        run_c4(K=int(sys.argv[2]) if len(sys.argv) > 2 else 16, peer=sys.argv[1] != "c4", lag=sys.argv[1] == "c4peerlag")
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "c5":
-        run("C5-literal: MLDA AM 128/512/2048 obs, subchains [5,3], no AEM", (128, 512, 2048), [5, 3],
-            dict(kind=2, C_=1e-4 * np.eye(64), t0=100, period=100), 60)
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "mala":
-        run_mala()
-        sys.exit(0)
-    run_c2b()
-    run_c5_aem()
-    run_c4()
-    run("C3: DA pCN(0.02) 256/2048 obs, subsampling_rate=10", (256, 2048), [10], dict(kind=1, scaling=0.02), 200)
-    run("C5-literal: MLDA AM 128/512/2048 obs, subchains [5,3], no AEM", (128, 512, 2048), [5, 3],
-        dict(kind=2, C_=1e-4 * np.eye(64), t0=100, period=100), 60)
+    av = sys.argv
+    if len(av) > 2 and av[1] in ("c5aem", "c5aemd"):  # python tools/bench_configs.py c5aem 128 [n_fine]
+        print(json.dumps(run_c5_aem(m=int(av[2]), n_fine=int(av[3]) if len(av) > 3 else 20, diagonal=av[1] == "c5aemd")))
+    elif len(av) > 1 and av[1] == "c3":
+        print(json.dumps(run_c3()))
+    elif len(av) > 1 and av[1] in ("c4", "c4peer", "c4peerlag"):
+        print(json.dumps(run_c4(K=int(av[2]) if len(av) > 2 else 16, peer=av[1] != "c4", lag=av[1] == "c4peerlag")))
+    elif len(av) > 1 and av[1] == "c5":
+        print(json.dumps(run_c5()))
+    elif len(av) > 1 and av[1] == "c2b":
+        print(json.dumps(run_c2b()))
+    elif len(av) > 1 and av[1] == "mala":
+        for r in run_mala():
+            print(json.dumps(r))
+    else:
+        for r in config_block():
+            print(json.dumps(r))
