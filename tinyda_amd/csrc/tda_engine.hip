@@ -333,6 +333,7 @@ struct tda_engine {
   bool ext_hier = false;  // hierarchy with callback / source-defined levels: sequenced by the host (run_multilevel)
   DevBuf<double> ext_Fcur[tda::MAXLEV], ext_Fst;  // error model there: outputs of the current links [NP][MP], of level j at theta_q [npairs][NP][MP]
   DevBuf<double> aem_bias[tda::MAXLEV], aem_covinv[tda::MAXLEV], aem_bmu[tda::MAXLEV], aem_bsig[tda::MAXLEV], aem_mdiff[tda::MAXLEV];
+  DevBuf<double> aem_rvec;  // [NP][aem_ld] bias-corrected residual the action kernels leave for k_aem_refresh's update_link
   int64_t aem_bt[tda::MAXLEV] = {1, 1, 1, 1};
   DevBuf<int64_t> ml_sid;
   DevBuf<double> prior_W_rm;
@@ -485,8 +486,19 @@ void launch_chol_apply(const CholArgs& a, const ApplyArgs& ap, hipStream_t st) {
   hipLaunchKernelGGL(k_chol_apply<DPAD>, dim3((unsigned)ap.NP), dim3(64), 0, st, a, ap);
 }
 
-// dynamic LDS of k_aem_inverse: the 16 x 16 blocks on or below the diagonal, row stride 17
-constexpr size_t aem_inverse_lds_bytes(int nb) { return (size_t)(nb * (nb + 1) / 2) * AEM_BS * sizeof(double); }
+// k_aem_refresh<T, NSUM> for the engine's row stride (64 / 128 -> 4 / 8 tile rows) and the number of trackers summed
+static int launch_aem_refresh(const tda::AemRefreshArgs& ra, hipStream_t st) {
+  using namespace tda;
+  const dim3 g((unsigned)ra.N), b(64);
+#define TDA_AEMR(TT, NS) hipLaunchKernelGGL((k_aem_refresh<TT, NS>), g, b, 0, st, ra)
+  if (ra.MP == 64) {
+    if (ra.nsum == 1) TDA_AEMR(4, 1); else if (ra.nsum == 2) TDA_AEMR(4, 2); else TDA_AEMR(4, 3);
+  } else {
+    if (ra.nsum == 1) TDA_AEMR(8, 1); else if (ra.nsum == 2) TDA_AEMR(8, 2); else TDA_AEMR(8, 3);
+  }
+#undef TDA_AEMR
+  return TDA_OK;
+}
 
 // Two levels with a small coarse model (m0 <= 256), a fixed subchain length, iso / diag noise and a diagonal prior
 // (BASELINE config 3) run on the pipelined 8-wave Delayed-Acceptance kernel; everything else (3-4 levels, error model,
@@ -700,6 +712,7 @@ int ext_level_adaptive(tda_engine* /*e*/, Level& lv, int m, const double* data, 
   std::vector<double> c64((size_t)MP * MP, 0.0);
   for (int i = 0; i < m; ++i)
     for (int j = 0; j < m; ++j) c64[(size_t)i * MP + j] = cov[(size_t)i * m + j];
+  for (int i = m; i < MP; ++i) c64[(size_t)i * MP + i] = 1.0;  // identity in the padding: k_aem_refresh factors all MP rows
   int rc;
   if ((rc = lv.cov64.upload(c64))) return rc;
   if ((rc = lv.data64.upload(lv.data_h))) return rc;

@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+
 #include "tda_kernels_mh.h"
 
 namespace tda {
@@ -57,6 +59,18 @@ struct AemRefreshArgs {
 };
 
 __device__ __forceinline__ double aemr_pick(double v, int src) { return __shfl(v, src); }
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): the block-row loop with its index a compile-time constant
+// whatever the unroller thinks of the body's size (left to `#pragma unroll` the eight-row instance kept its tile arrays in
+// scratch memory, 4.6 KB per lane, indexed at run time)
+template <class F, int... Qs>
+__device__ __forceinline__ void aemr_static_for_impl(F&& f, std::integer_sequence<int, Qs...>) {
+  (f(std::integral_constant<int, Qs>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void aemr_static_for(F&& f) {
+  aemr_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 // Buffer addressing (descriptor in SGPRs + ONE 32-bit lane offset + a compile-time scalar offset per access): with 64-bit
 // per-lane pointers the compiler kept an address pair per access alive -- hundreds of registers in a fully unrolled kernel.
@@ -125,6 +139,14 @@ __device__ __forceinline__ void aemr_diag(double (&C)[4], double (&Vd)[4], doubl
   }
 }
 
+// (Measured and not kept, tools/aem_diag_probe.hip: a second form of this step without any LDS exchange -- the multipliers of a
+// lane's own rows by a DPP row broadcast (the trailing block of the tile is bitwise symmetric, so C[k][row] is the same 16-lane
+// row's lane k), the pivot row to the other 16-lane rows by v_permlane16_swap / v_permlane32_swap, rows exchanged unscaled so that
+// nothing but the last fma waits for the reciprocal square root, the next pivot formed ahead of the update.  Same results to
+// 1.6e-16; 6 250 cycles per tile against 5 420 for the form above at four waves per CU: the step is bound by the number of vector
+// instructions on its dependent chain (~40 per pivot at ~8 cycles), and the swaps and DPP moves are more instructions than the
+// ds_bpermute they replace.)
+
 // -1/2 |V r|^2 for one chain by ONE wave: Vc = that chain's lower tiles, s_r = r in LDS (zero beyond m, 16 T entries).
 // Block row p: z[hi + 4 r] += V(p, i)[r] * r[16 i + lc] over its tiles, one 16-lane reduction per register, squares summed.
 // Every lane returns the value.  TW / tw: block rows are dealt round-robin to TW cooperating waves (the caller adds the parts).
@@ -155,21 +177,57 @@ __device__ __forceinline__ double aem_quad_tiles_part(const double* __restrict__
   }
   return sq;  // per 16-lane row: the squares of its four output rows per block row; finish with sum_rows() and -0.5
 }
+// The same with the number of block rows known at run time (nbr <= T): r is read below 16 nbr only -- for callers whose residual
+// vector is not padded to the instance's width.
+template <int T>
+__device__ __forceinline__ double aem_quad_tiles_rows(const double* __restrict__ Vc, const double* __restrict__ s_r, int lane, int nbr) {
+  const int lc = lane & 15;
+  double sq = 0.0;
+  for (int p = 0; p < nbr; ++p) {
+    double v[T][4];
+    const double* __restrict__ Vp = Vc + (size_t)aemr_lt(p, 0) * 256 + lane;
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[i][r] = i <= p ? Vp[(size_t)(i * 4 + r) * 64] : 0.0;
+    double z[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+      const double rv = i <= p ? s_r[16 * i + lc] : 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) z[r] = fma(v[i][r], rv, z[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double zz = aemr_row_sum(z[r]);
+      sq = fma(zz, zz, sq);
+    }
+  }
+  return -0.5 * sum_rows(sq);
+}
 template <int T>
 __device__ __forceinline__ double aem_quad_tiles(const double* __restrict__ Vc, const double* __restrict__ s_r, int lane) {
   return -0.5 * sum_rows(aem_quad_tiles_part<T, 1>(Vc, s_r, lane, 0));
 }
 
 // NSUM = trackers summed into Sigma_bias (a template parameter: every `nsum > 1 ? load : 0` of a runtime count became a branch
-// of its own -- a thousand basic blocks -- and the register allocator spilled 700 registers across them)
+// of its own -- a thousand basic blocks -- and the register allocator spilled 700 registers across them).
+//
+// Schedule: LEFT-looking for U (block row q of Sigma is loaded when step q needs it -- its loads fly under step q - 1 -- and
+// receives all its updates from the finished rows at once), RIGHT-looking for V (a finished row of V updates the partial
+// sums of the rows below and leaves).  Live tiles at step q: finished U(p, i), p <= q < i and the V partial sums of the rows
+// below, (q + 1)(T - 1 - q) each: 36 of 72 at most, and nothing is resident before it is needed.  (First version: all 36
+// tiles of Sigma loaded up front, right-looking for both -- 44 live tiles, and the allocator, asked for ~150 registers more than
+// the tiles themselves, spilled the early-loaded late-used tiles to scratch: 180 / 360 / 540 spilled registers and 417 / 624 /
+// 917 us per launch at NSUM = 1 / 2 / 3, still under the 730 us of the kernel it replaces.)
 template <int T, int NSUM>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) k_aem_refresh(const AemRefreshArgs a) {
   constexpr int NT = aemr_tiles(T);
+  constexpr int MP = 16 * T;  // the row stride IS the instance's width (64 / 128): compile-time offsets
   __shared__ double s_r[16 * T];
   const int lane = threadIdx.x, lc = lane & 15, hi = lane >> 4;
   const int64_t c = blockIdx.x;
   if (c >= a.N) return;
-  constexpr int MP = 16 * T;
   const bool want_ll = a.rvec != nullptr;
   {
     const double* __restrict__ rsrc = want_ll ? a.rvec + c * MP : a.cov;  // (no r wanted: any readable address, the result is dropped)
@@ -178,111 +236,122 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   }
   double* __restrict__ Vc = a.V + (size_t)c * NT * 256;
   const __amdgpu_buffer_rsrc_t Vrs = aemr_rsrc(Vc);
+  const size_t cbase = (size_t)c * MP * MP;
+  const __amdgpu_buffer_rsrc_t sg0 = aemr_rsrc(a.sig[0] + cbase);
+  const __amdgpu_buffer_rsrc_t sg1 = aemr_rsrc(NSUM > 1 ? a.sig[1] + cbase : a.sig[0] + cbase);
+  const __amdgpu_buffer_rsrc_t sg2 = aemr_rsrc(NSUM > 2 ? a.sig[2] + cbase : a.sig[0] + cbase);
+  const __amdgpu_buffer_rsrc_t sge = aemr_rsrc(a.cov);
 
-  // ---- Sigma_e + Sigma_bias into the upper tiles, and the 1e-9 rule (distributions.py:399-402) ----
-  // Two tiles per round, the next round's loads issued before this round's sums (the scheduler is fenced per round: left alone
-  // it hoists all 36 x 4 x (nsum + 1) loads to the top and spills)
-  double U[NT][4];
+  // ---- the 1e-9 rule (distributions.py:399-402: no re-inversion while every entry of Sigma_bias is below 1e-9) ----
+  // The rows are loaded lazily, so the decision cannot wait for them: the diagonal decides almost always (a covariance with an
+  // entry >= 1e-9 has a diagonal entry >= 1e-9 up to rounding); when the diagonal says "small" the exact test over every entry
+  // follows -- that is the regime in which the inversion is skipped anyway.
   bool big = false;
-  {
-    constexpr int MPc = 16 * T;  // the row stride IS the instance's width (64 / 128): compile-time offsets
-    const size_t cbase = (size_t)c * MPc * MPc;
-    const __amdgpu_buffer_rsrc_t sg0 = aemr_rsrc(a.sig[0] + cbase);
-    const __amdgpu_buffer_rsrc_t sg1 = aemr_rsrc(NSUM > 1 ? a.sig[1] + cbase : a.sig[0] + cbase);
-    const __amdgpu_buffer_rsrc_t sg2 = aemr_rsrc(NSUM > 2 ? a.sig[2] + cbase : a.sig[0] + cbase);
-    const __amdgpu_buffer_rsrc_t sge = aemr_rsrc(a.cov);
-    const int lane_rm = (hi * MPc + lc) * 8;  // byte offset of element [hi][lc] of a row-major tile
-    constexpr int CH = 2;  // tiles per round
-    constexpr int NR = (NT + CH - 1) / CH;
-    double raw[2][CH][4][4];  // [buffer][tile][source: 3 trackers + Sigma_e][r]
-    auto tile_pi = [](int t, int& p, int& i) {  // upper tile index -> (p, i)
-      p = 0;
-      int rem = t;
-      while (rem >= T - p) { rem -= T - p; ++p; }
-      i = p + rem;
-    };
-    auto issue = [&](int rd, int buf) {
 #pragma unroll
-      for (int u = 0; u < CH; ++u) {
-        const int t = rd * CH + u;
-        if (t >= NT) continue;
-        int p, i;
-        tile_pi(t, p, i);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          // (no bounds: the padding of the trackers is zero and that of Sigma_e the identity -- tda_engine_set_level)
-          const int so = ((16 * p + 4 * r) * MPc + 16 * i) * 8;
-          raw[buf][u][0][r] = aemr_ld(sg0, lane_rm, so);
-          if constexpr (NSUM > 1) raw[buf][u][1][r] = aemr_ld(sg1, lane_rm, so);
-          if constexpr (NSUM > 2) raw[buf][u][2][r] = aemr_ld(sg2, lane_rm, so);
-          raw[buf][u][3][r] = aemr_ld(sge, lane_rm, so);
-        }
-      }
-    };
-    issue(0, 0);
-#pragma unroll
-    for (int rd = 0; rd < NR; ++rd) {
-      if (rd + 1 < NR) issue(rd + 1, (rd + 1) & 1);
-      asm volatile("" ::: "memory");  // IR-level fence (loads stay in their round), then the machine scheduler's
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < CH; ++u) {
-        const int t = rd * CH + u;
-        if (t >= NT) continue;
-        int p, i;
-        tile_pi(t, p, i);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          double sb = 0.0 + raw[rd & 1][u][0][r];  // the reference's sum over the trackers starts from zero (proposal.py:1563-1569)
-          if constexpr (NSUM > 1) sb += raw[rd & 1][u][1][r];
-          if constexpr (NSUM > 2) sb += raw[rd & 1][u][2][r];
-          big = big || !(sb < 1e-9);
-          U[t][r] = raw[rd & 1][u][3][r] + sb;
-        }
-      }
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
+  for (int h = 0; h < (16 * T + 63) / 64; ++h) {
+    const int o = (lane + 64 * h) * (MP + 1) * 8;
+    double sb = 0.0 + aemr_ld(sg0, o, 0);
+    if constexpr (NSUM > 1) sb += aemr_ld(sg1, o, 0);
+    if constexpr (NSUM > 2) sb += aemr_ld(sg2, o, 0);
+    big = big || !(sb < 1e-9);
+  }
+  if (__builtin_amdgcn_ballot_w64(big) == 0) {
+    for (int e = lane; e < MP * MP; e += 64) {  // (padding entries are zero)
+      double sb = 0.0 + aemr_ld(sg0, e * 8, 0);
+      if constexpr (NSUM > 1) sb += aemr_ld(sg1, e * 8, 0);
+      if constexpr (NSUM > 2) sb += aemr_ld(sg2, e * 8, 0);
+      big = big || !(sb < 1e-9);
     }
   }
   __syncthreads();  // s_r
   double sq = 0.0;
   if (__builtin_amdgcn_ballot_w64(big) == 0) {
-    // every entry of Sigma_bias below 1e-9: set_bias keeps the previous inverse; update_link still runs under the new bias
+    // set_bias keeps the previous inverse; update_link still runs under the new bias
     sq = aem_quad_tiles_part<T, 1>(Vc, s_r, lane, 0);
   } else {
-    double Vl[NT][4];
+    const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+    int lane_rm = (hi * MP + lc) * 8;  // byte offset of element [hi][lc] of a row-major tile
+    double4_t Uf[NT];  // finished rows of U (upper tiles), whole 8-register tuples from birth to their last matrix instruction
+    double4_t Vl[NT];  // V: partial sums of the rows below, final rows on their way out
+    double raw[2][T][4][4];  // [buffer][tile i of the row][source: 3 trackers + Sigma_e][r]
+    auto issue_row = [&](int q, int buf) {  // (no bounds: the padding of the trackers is zero and that of Sigma_e the identity)
 #pragma unroll
-    for (int p = 0; p < T; ++p) {
-      double Vd[4], Vt[4];
-      aemr_diag(U[aemr_ut(T, p, p)], Vd, Vt, lc, hi);
-      // the rest of block row p times V_pp (lower-triangular inverse of the diagonal tile's factor)
+      for (int i = q; i < T; ++i)
 #pragma unroll
-      for (int i = p + 1; i < T; ++i) {
-        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+        for (int r = 0; r < 4; ++r) {
+          const int so = ((16 * q + 4 * r) * MP + 16 * i) * 8;
+          raw[buf][i][0][r] = aemr_ld(sg0, lane_rm, so);
+          if constexpr (NSUM > 1) raw[buf][i][1][r] = aemr_ld(sg1, lane_rm, so);
+          if constexpr (NSUM > 2) raw[buf][i][2][r] = aemr_ld(sg2, lane_rm, so);
+          raw[buf][i][3][r] = aemr_ld(sge, lane_rm, so);
+        }
+    };
+    issue_row(0, 0);
+    aemr_static_for<T>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      __builtin_amdgcn_sched_barrier(0);
+      // block row q of Sigma_e + Sigma_bias (the reference's sum over the trackers starts from zero, proposal.py:1563-1569)
+      double4_t Cq[T];
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) acc = mfma_f64(Vt[kc], U[aemr_ut(T, p, i)][kc], acc);
+      for (int i = q; i < T; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) U[aemr_ut(T, p, i)][r] = acc[r];
+        for (int r = 0; r < 4; ++r) {
+          double sb = 0.0 + raw[q & 1][i][0][r];
+          if constexpr (NSUM > 1) sb += raw[q & 1][i][1][r];
+          if constexpr (NSUM > 2) sb += raw[q & 1][i][2][r];
+          Cq[i][r] = raw[q & 1][i][3][r] + sb;
+        }
+      // the lane offset of the loads two rows on is "produced" here, next to a value of this row: neither the optimiser nor the
+      // scheduler can then issue those loads before this row's sums exist (memory clobbers and sched_barrier alone did not hold
+      // them: every load went to the top of the kernel and half of them straight to scratch)
+      asm volatile("" : "+v"(lane_rm) : "v"(Cq[q][0]));
+      __builtin_amdgcn_sched_barrier(0);
+      // left-looking: C(q, i) -= sum_{p < q} U_pq^T U_pi
+#pragma unroll
+      for (int p = 0; p < q; ++p) {
+        const double4_t nA = -Uf[aemr_ut(T, p, q)];
+#pragma unroll
+        for (int i = q; i < T; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Cq[i] = mfma_f64(nA[r], Uf[aemr_ut(T, p, i)][r], Cq[i]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // the next row's loads fly under this row's diagonal tile (16 dependent pivots, ~1.5 us) and V updates: issued here, not at
+      // the top of the step, their 8 (NSUM + 1) registers per tile do not sit beside the accumulators of the update above
+      if constexpr (q + 1 < T) issue_row(q + 1, (q + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      double Cd[4], Vd[4], Vt[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cd[r] = Cq[q][r];
+      aemr_diag(Cd, Vd, Vt, lc, hi);
+      __builtin_amdgcn_sched_barrier(0);
+      // the rest of block row q times V_qq (lower-triangular inverse of the diagonal tile's factor)
+#pragma unroll
+      for (int i = q + 1; i < T; ++i) {
+        double4_t acc = zero4;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) acc = mfma_f64(Vt[kc], Cq[i][kc], acc);
+        Uf[aemr_ut(T, q, i)] = acc;
       }
 #pragma unroll
-      for (int i = 0; i < p; ++i) {
-        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+      for (int i = 0; i < q; ++i) {
+        double4_t acc = zero4;
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) acc = mfma_f64(Vt[kc], Vl[aemr_lt(p, i)][kc], acc);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Vl[aemr_lt(p, i)][r] = acc[r];
+        for (int kc = 0; kc < 4; ++kc) acc = mfma_f64(Vt[kc], Vl[aemr_lt(q, i)][kc], acc);
+        Vl[aemr_lt(q, i)] = acc;
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Vl[aemr_lt(p, p)][r] = Vd[r];
-      // block row p of V is final: out it goes, and its share of |V r|^2
+      for (int r = 0; r < 4; ++r) Vl[aemr_lt(q, q)][r] = Vd[r];
+      __builtin_amdgcn_sched_barrier(0);
+      // block row q of V is final: out it goes, and its share of |V r|^2
       double z[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int i = 0; i <= p; ++i) {
+      for (int i = 0; i <= q; ++i) {
         const double rv = s_r[16 * i + lc];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          aemr_st(Vl[aemr_lt(p, i)][r], Vrs, lane * 8, (aemr_lt(p, i) * 4 + r) * 512);
-          z[r] = fma(Vl[aemr_lt(p, i)][r], rv, z[r]);
+          aemr_st(Vl[aemr_lt(q, i)][r], Vrs, lane * 8, (aemr_lt(q, i) * 4 + r) * 512);
+          z[r] = fma(Vl[aemr_lt(q, i)][r], rv, z[r]);
         }
       }
 #pragma unroll
@@ -290,28 +359,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         const double zz = aemr_row_sum(z[r]);
         sq = fma(zz, zz, sq);
       }
-      // block rows below: tile(q, i) -= U_pq^T X_pi for the U part (i >= q) and the V part (i <= p)
+      // right-looking for V: the rows below take  -U_qq'^T V_qi  into their partial sums (tile (q', q) is born here)
 #pragma unroll
-      for (int q = p + 1; q < T; ++q) {
+      for (int q2 = q + 1; q2 < T; ++q2) {
+        __builtin_amdgcn_sched_barrier(0);  // one block row at a time: the negated copy of U_qq' lives for this row only
+        const double4_t nA = -Uf[aemr_ut(T, q, q2)];
 #pragma unroll
-        for (int i = q; i < T; ++i) {
-          double4_t acc = {U[aemr_ut(T, q, i)][0], U[aemr_ut(T, q, i)][1], U[aemr_ut(T, q, i)][2], U[aemr_ut(T, q, i)][3]};
+        for (int i = 0; i <= q; ++i) {
+          double4_t acc = i < q ? Vl[aemr_lt(q2, i)] : zero4;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc = mfma_f64(-U[aemr_ut(T, p, q)][r], U[aemr_ut(T, p, i)][r], acc);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) U[aemr_ut(T, q, i)][r] = acc[r];
-        }
-#pragma unroll
-        for (int i = 0; i <= p; ++i) {
-          double4_t acc = {0.0, 0.0, 0.0, 0.0};
-          if (i < p) acc = double4_t{Vl[aemr_lt(q, i)][0], Vl[aemr_lt(q, i)][1], Vl[aemr_lt(q, i)][2], Vl[aemr_lt(q, i)][3]};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc = mfma_f64(-U[aemr_ut(T, p, q)][r], Vl[aemr_lt(p, i)][r], acc);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) Vl[aemr_lt(q, i)][r] = acc[r];
+          for (int r = 0; r < 4; ++r) acc = mfma_f64(nA[r], Vl[aemr_lt(q, i)][r], acc);
+          Vl[aemr_lt(q2, i)] = acc;
         }
       }
-    }
+    });
   }
   if (want_ll) {
     const double llk = -0.5 * sum_rows(sq);

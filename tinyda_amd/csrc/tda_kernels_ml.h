@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "tda_kernels_mh.h"
+#include "tda_kernels_aemr.h"
 
 namespace tda {
 
@@ -66,7 +67,7 @@ struct MLArgs {
   int aem_mp;              // output dimension padded to 16 (dense: <= 128)
   int aem_ld;              // row stride of the per-chain error-model state: dense 64 or 128, diagonal m
   const double* aem_bias;  // [NP][aem_ld] (diagonal: [N][m])  total bias of level 0
-  const double* aem_P;     // dense [NP][aem_ld][aem_ld] (Sigma_e + Sigma_bias)^-1 of level 0; diagonal [N][m] inverse variances
+  const double* aem_P;     // dense: [NP][tiles][4][64] lower tiles of V = L^-1, (Sigma_e + Sigma_bias) = L L^T, of level 0 (tda_kernels_aemr.h); diagonal: [N][m] inverse variances
   int64_t* sid;            // [nlev][NP] identity of the parameter vector each level currently holds
   const double* logu0;     // [S][NP] log of the base-level uniforms (k_propose / k_rng, off the critical path); may be null
 };
@@ -271,53 +272,12 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
         if (l0) rrow[lane] = rb0;
         if (l1) rrow[lane + 64] = rb1;
         __builtin_amdgcn_wave_barrier();
-        double sacc = 0.0;
-        const double* Pc = a.aem_P + (size_t)gc * LD * LD + lane;
-        // Beyond 64 outputs: P is symmetric, only the 16 x 16 blocks on or below the block diagonal are read (36 of 64 at
-        // m = 128; this loop runs at the HBM roofline).  Per group of 16 rows every lane has ONE weight: 1 in the diagonal block, 2 below it
-        // (the mirrored block above counts with it), 0 beyond -- no per-element predicates:
-        //   r^T P r = sum_j r_j sum_groups w_gj sum_{o in group} P_oj r_o
-        if (MP <= 64) {  // up to 64 outputs the plain loop over full rows is faster (measured): eight rows in flight per lane
-          if (l0) {
-            for (int o = 0; o < MP; o += 8) {
-              double pv[8];
-#pragma unroll
-              for (int u = 0; u < 8; ++u) pv[u] = Pc[(size_t)(o + u) * LD];
-#pragma unroll
-              for (int u = 0; u < 8; ++u) sacc = fma(pv[u], rrow[o + u], sacc);
-            }
-            sacc *= rb0;
-          }
-        } else {
-          double a0 = 0.0, a1 = 0.0;
-          for (int g = 0; g < MP / 16; ++g) {
-            const int bound = 16 * (g + 1);  // columns of this row group that are read
-            const bool c0 = l0 && lane < bound, c1 = l1 && lane + 64 < bound;
-            const double w0 = (lane >> 4) == g ? 1.0 : 2.0, w1 = ((lane + 64) >> 4) == g ? 1.0 : 2.0;
-            double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              double pv[8], pw[8];
-#pragma unroll
-              for (int u = 0; u < 8; ++u) {
-                const int o = 16 * g + 8 * h + u;
-                pv[u] = c0 ? Pc[(size_t)o * LD] : 0.0;
-                pw[u] = c1 ? Pc[(size_t)o * LD + 64] : 0.0;
-              }
-#pragma unroll
-              for (int u = 0; u < 8; ++u) {
-                const double ro = rrow[16 * g + 8 * h + u];
-                s0 = fma(pv[u], ro, s0);
-                s1 = fma(pw[u], ro, s1);
-              }
-            }
-            a0 = fma(w0, s0, a0);
-            a1 = fma(w1, s1, a1);
-          }
-          sacc = a0 * rb0 + a1 * rb1;
-        }
-        for (int off = 32; off >= 1; off >>= 1) sacc += __shfl_xor(sacc, off);
-        if (lane == 0) s_R[16 * RSa + cc] = -0.5 * sacc;
+        // -1/2 |V r|^2 from the chain's lower tiles of V = L^-1 (72 KB per chain at 128 outputs, 512-byte rows; the rows of
+        // blocks beyond the outputs are identity and r is not defined there: only the block rows of the outputs are read)
+        double qv;
+        if (LD <= 64) qv = aem_quad_tiles_rows<4>(a.aem_P + (size_t)gc * aemr_v_doubles(64), rrow, lane, MP >> 4);
+        else qv = aem_quad_tiles_rows<8>(a.aem_P + (size_t)gc * aemr_v_doubles(128), rrow, lane, MP >> 4);
+        if (lane == 0) s_R[16 * RSa + cc] = qv;
       }
       if (prior_dense && lane < 16) {}  // (s_redp already written above)
       __syncthreads();
@@ -1241,12 +1201,12 @@ struct AemArgs {
   int32_t* anyacc; // [nlev][NP]
   int64_t* sid;    // [nlev][NP]
   double* bias_tot[MAXLEV];  // [NP][MP]     adaptive levels
-  double* cov_inv[MAXLEV];   // [NP][MP][MP]
+  double* cov_inv[MAXLEV];   // [NP][tiles][4][64] lower tiles of V = L^-1 (tda_kernels_aemr.h)
   double* b_mu[MAXLEV];      // trackers of levels >= 1: [NP][MP]
   double* b_sig[MAXLEV];     // [NP][MP][MP]
   double* mdiff[MAXLEV];     // [NP][MP]
   int64_t b_t;               // recursion counter of level q's tracker before this update
-  int phase;                 // 0: decision + error-model update (then k_aem_inverse); 1: update_link of level q-1
+  double* rvec;              // [NP][MP] out: bias-corrected residual of level q-1's latest link (k_aem_refresh ends with its update_link)
   const double* scaling;     // [NP] (pCN beta for the state-dependent q terms)
   const double* u_rep;       // [N] replay uniform of this step (NaN = none drawn) or null
   uint8_t* ring;
@@ -1289,58 +1249,27 @@ __global__ void __launch_bounds__(MPT) k_aem_action(const AemArgs a) {
     }
     return f;
   };
-  // -1/2 r^T P r with chain c's inverse of adaptive level lev; r given per lane (already bias corrected)
+  // -1/2 r^T (Sigma_e + Sigma_bias)^-1 r = -1/2 |V r|^2 with chain c's triangular factor V = L^-1 of adaptive level lev
+  // (tda_kernels_aemr.h: lower 16 x 16 tiles in the MFMA C/D layout); r given per lane (already bias corrected).  The block rows
+  // of V are dealt to the workgroup's waves.
   auto quad = [&](int lev, double r) {
     __syncthreads();
     s_v[MPT + lane] = lo ? r : 0.0;
     __syncthreads();
-    double s = 0.0;
-    if constexpr (MPT > 64) {
-      // P is symmetric: only the 16 x 16 blocks on or below the block diagonal are read; per group of 16 rows a thread's
-      // column weighs 1 (diagonal block), 2 (below: the mirrored block counts with it) or is not read at all
-      const double* __restrict__ Pc = a.cov_inv[lev] + (size_t)c * MP * MP + lane;
-      double acc = 0.0;
-      for (int g = (lane & ~63) >> 4; 16 * g < a.m; ++g) {  // wave-uniform start: the second wave needs the row groups >= 4 only
-        if (lo && lane < 16 * (g + 1)) {
-          double pv[16];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) pv[u] = 16 * g + u < a.m ? Pc[(size_t)(16 * g + u) * MP] : 0.0;
-          double sg = 0.0;
-#pragma unroll
-          for (int u = 0; u < 16; ++u) sg = fma(pv[u], s_v[MPT + 16 * g + u], sg);
-          acc = fma((lane >> 4) == g ? 1.0 : 2.0, sg, acc);
-        }
-      }
-      s = acc * r;
-    } else if (lo) {
-      const double* __restrict__ Pc = a.cov_inv[lev] + (size_t)c * MP * MP + lane;
-#pragma unroll 8
-      for (int o = 0; o < a.m; ++o) s = fma(Pc[(size_t)o * MP], s_v[MPT + o], s);
-      s *= r;
+    const double* __restrict__ Vc = a.cov_inv[lev] + (size_t)c * aemr_v_doubles(MPT);
+    double s = sum_rows(aem_quad_tiles_part<MPT / 16, NW>(Vc, s_v + MPT, lane & 63, lane >> 6));
+    if constexpr (NW > 1) {
+      __syncthreads();
+      if ((lane & 63) == 0) s_x[lane >> 6] = s;
+      __syncthreads();
+      s = s_x[0] + s_x[1];
     }
-    return -0.5 * bsum(s);
+    return -0.5 * s;
   };
   auto loglike_of = [&](int lev, double r0) {  // r0 = F - ytil without bias
     if (lev == nl - 1) return -0.5 * bsum(lo ? r0 * r0 : 0.0) / a.var_finest;
     return quad(lev, lo ? r0 + a.bias_tot[lev][c * MP + lane] : 0.0);
   };
-
-  if (a.phase == 1) {
-    // update_link of level k's latest link (posterior.py:112-134) under the bias / inverse k_aem_inverse has refreshed
-    __syncthreads();
-    s_v[lane] = lj ? TH(k)[lane] : 0.0;
-    __syncthreads();
-    const double rk = resid(k);
-    const double bt = lo ? a.bias_tot[k][c * MP + lane] : 0.0;
-    const double llk = quad(k, lo ? rk + bt : 0.0);
-    if (lane == 0) {
-      a.ll[(size_t)k * a.NP + c] = llk;
-      const int64_t idk = a.sid[(size_t)k * a.NP + c];
-      for (int q2 = q; q2 < nl; ++q2)
-        if (a.sid[(size_t)q2 * a.NP + c] == idk) a.Sst[((size_t)pair_index(k, q2) * 2 + 1) * a.NP + c] = llk;
-    }
-    return;
-  }
 
   // ---------------- the level-q decision ----------------
   const double yj = lj ? TH(k)[lane] : 0.0, xj = lj ? TH(q)[lane] : 0.0;
@@ -1501,6 +1430,9 @@ __global__ void __launch_bounds__(MPT) k_aem_action(const AemArgs a) {
       for (int p = q; p < nl; ++p) bt += a.b_mu[p][c * MP + lane];
     a.bias_tot[k][c * MP + lane] = bt;
   }
+  // update_link of level k's latest link (posterior.py:112-134) happens at the end of k_aem_refresh, under the factor it has just
+  // computed: this kernel leaves the bias-corrected residual F_k(theta_k) - y_k + bias_k (zero in the padding)
+  a.rvec[c * MP + lane] = lo ? rk + bt : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1508,12 +1440,12 @@ __global__ void __launch_bounds__(MPT) k_aem_action(const AemArgs a) {
 // callbacks, source-defined models, linear levels beside them).  Same algorithm as k_aem_action, but a model output is
 // never recomputed from a matrix: every level keeps the output of its current link (Fcur), every pair (j, q) the output
 // of level j at theta_q (Fst, the companion of the densities in Sst), and the host hands in level q's fresh evaluation
-// at theta_{q-1} (Fnew).  Phase 0: decision, alignment, tracker update, total bias, output bookkeeping; k_aem_inverse;
-// phase 1: update_link of level q - 1.  k_ext_aem_accept is the base-level step under the bias-corrected likelihood.
+// at theta_{q-1} (Fnew): decision, alignment, tracker update, total bias, output bookkeeping; then k_aem_refresh (the new factor
+// and update_link of level q - 1).  k_ext_aem_accept is the base-level step under the bias-corrected likelihood.
 // ------------------------------------------------------------------------------------------------
 struct ExtAemArgs {
   int64_t N, NP, chain_offset;
-  int d, DP, m, MP, nlev, q, is_da, phase;
+  int d, DP, m, MP, nlev, q, is_da;
   int dependent, prop_kind;    // state-dependent error model (DA only, chain.py:446-473, :501-523); pCN needs the q terms
   const double* pr_W;          // [d][d] whitening matrix of the prior, row-major
   double pr_logdet;
@@ -1532,11 +1464,12 @@ struct ExtAemArgs {
   int32_t* anyacc;
   int64_t* sid;
   double* bias_tot[MAXLEV];
-  double* cov_inv[MAXLEV];
+  double* cov_inv[MAXLEV];     // [NP][tiles][4][64] lower tiles of V = L^-1 (tda_kernels_aemr.h)
   double* b_mu[MAXLEV];
   double* b_sig[MAXLEV];
   double* mdiff[MAXLEV];
   int64_t b_t;
+  double* rvec;                // [NP][MP] out: bias-corrected residual of level q-1's latest link
   const double* u_rep;
   uint8_t* ring;
   int ring_P;
@@ -1568,53 +1501,24 @@ __global__ void __launch_bounds__(MPT) k_ext_aem_action(const ExtAemArgs a) {
     }
     return v;
   };
-  auto quad = [&](int lev, double r) {  // -1/2 r^T P r with chain c's inverse of adaptive level lev
+  auto quad = [&](int lev, double r) {  // -1/2 |V r|^2 with chain c's factor V = L^-1 of adaptive level lev (as in k_aem_action)
     __syncthreads();
     s_v[MPT + lane] = lo ? r : 0.0;
     __syncthreads();
-    double s = 0.0;
-    if constexpr (MPT > 64) {
-      // P is symmetric: only the 16 x 16 blocks on or below the block diagonal are read; per group of 16 rows a thread's
-      // column weighs 1 (diagonal block), 2 (below: the mirrored block counts with it) or is not read at all
-      const double* __restrict__ Pc = a.cov_inv[lev] + (size_t)c * MP * MP + lane;
-      double acc = 0.0;
-      for (int g = (lane & ~63) >> 4; 16 * g < a.m; ++g) {  // wave-uniform start: the second wave needs the row groups >= 4 only
-        if (lo && lane < 16 * (g + 1)) {
-          double pv[16];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) pv[u] = 16 * g + u < a.m ? Pc[(size_t)(16 * g + u) * MP] : 0.0;
-          double sg = 0.0;
-#pragma unroll
-          for (int u = 0; u < 16; ++u) sg = fma(pv[u], s_v[MPT + 16 * g + u], sg);
-          acc = fma((lane >> 4) == g ? 1.0 : 2.0, sg, acc);
-        }
-      }
-      s = acc * r;
-    } else if (lo) {
-      const double* __restrict__ Pc = a.cov_inv[lev] + (size_t)c * MP * MP + lane;
-#pragma unroll 8
-      for (int o = 0; o < a.m; ++o) s = fma(Pc[(size_t)o * MP], s_v[MPT + o], s);
-      s *= r;
+    const double* __restrict__ Vc = a.cov_inv[lev] + (size_t)c * aemr_v_doubles(MPT);
+    double s = sum_rows(aem_quad_tiles_part<MPT / 16, NW>(Vc, s_v + MPT, lane & 63, lane >> 6));
+    if constexpr (NW > 1) {
+      __syncthreads();
+      if ((lane & 63) == 0) s_x[lane >> 6] = s;
+      __syncthreads();
+      s = s_x[0] + s_x[1];
     }
-    return -0.5 * bsum(s);
+    return -0.5 * s;
   };
   auto loglike_of = [&](int lev, double r0) {  // r0 = F - data without bias
     if (lev == nl - 1) return -0.5 * bsum(lo ? r0 * r0 : 0.0) / a.var_finest;
     return quad(lev, lo ? r0 + a.bias_tot[lev][c * MP + lane] : 0.0);
   };
-
-  if (a.phase == 1) {  // update_link of level k's latest link (posterior.py:112-134)
-    const double rk = lo ? a.Fcur[k][c * MP + lane] - a.data[k][lane] : 0.0;
-    const double bt = lo ? a.bias_tot[k][c * MP + lane] : 0.0;
-    const double llk = quad(k, lo ? rk + bt : 0.0);
-    if (lane == 0) {
-      a.ll[(size_t)k * a.NP + c] = llk;
-      const int64_t idk = a.sid[(size_t)k * a.NP + c];
-      for (int q2 = q; q2 < nl; ++q2)
-        if (a.sid[(size_t)q2 * a.NP + c] == idk) a.Sst[((size_t)pair_index(k, q2) * 2 + 1) * a.NP + c] = llk;
-    }
-    return;
-  }
 
   // ---------------- the level-q decision (chain.py:475-483, proposal.py:1615-1624) ----------------
   const double yj = lj ? TH(k)[lane] : 0.0, xj = lj ? TH(q)[lane] : 0.0;
@@ -1739,6 +1643,7 @@ __global__ void __launch_bounds__(MPT) k_ext_aem_action(const ExtAemArgs a) {
       }
       a.bias_tot[k][c * MP + lane] = diff_new;  // the bias of the coarse level is the last difference
     }
+    a.rvec[c * MP + lane] = lo ? (fk_cur - a.data[k][lane]) + diff_new : 0.0;  // for the update_link at the end of k_aem_refresh
     return;
   }
   const double dm = (a.is_da || acc) ? diff_new : (lo ? md[lane] : 0.0);  // MLDA refreshes the difference on accept only
@@ -1769,11 +1674,12 @@ __global__ void __launch_bounds__(MPT) k_ext_aem_action(const ExtAemArgs a) {
   }
   __threadfence_block();
   __syncthreads();
+  double bt = 0.0;
   if (lo) {  // total bias of level k: sum over the trackers of the levels above
-    double bt = 0.0;
     for (int p = q; p < nl; ++p) bt += a.b_mu[p][c * MP + lane];
     a.bias_tot[k][c * MP + lane] = bt;
   }
+  a.rvec[c * MP + lane] = lo ? (fk_cur - a.data[k][lane]) + bt : 0.0;  // for the update_link at the end of k_aem_refresh
 }
 
 // base-level step of such a hierarchy: like k_ext_accept, with the bias-corrected dense likelihood of
@@ -1789,7 +1695,7 @@ struct ExtAemAcceptArgs {
   const double* F;     // [N][m]
   const double* data;  // [MP]
   const double* bias;  // [NP][MP]
-  const double* P;     // [NP][MP][MP]
+  const double* P;     // [NP][tiles][4][64] lower tiles of V = L^-1 (tda_kernels_aemr.h)
   double* Fcur;        // [NP][MP]
   const double* pr_mean;
   const double* pr_pinv;
@@ -1831,14 +1737,18 @@ __global__ void __launch_bounds__(MPT) k_ext_aem_accept(const ExtAemAcceptArgs a
   const double r = lo ? (f + a.bias[c * MP + lane]) - a.data[lane] : 0.0;
   s_r[lane] = r;
   __syncthreads();
-  double sq = 0.0;
-  if (lo) {
-    const double* __restrict__ Pc = a.P + (size_t)c * MP * MP + lane;
-#pragma unroll 8
-    for (int o = 0; o < a.m; ++o) sq = fma(Pc[(size_t)o * MP], s_r[o], sq);
-    sq *= r;
+  double ll_n;
+  {
+    const double* __restrict__ Vc = a.P + (size_t)c * aemr_v_doubles(MPT);
+    double sq = sum_rows(aem_quad_tiles_part<MPT / 16, NW>(Vc, s_r, lane & 63, lane >> 6));
+    if constexpr (NW > 1) {
+      __syncthreads();
+      if ((lane & 63) == 0) s_x[lane >> 6] = sq;
+      __syncthreads();
+      sq = s_x[0] + s_x[1];
+    }
+    ll_n = -0.5 * sq;
   }
-  const double ll_n = -0.5 * bsum(sq);
   const double prp = lj ? a.prop[c * a.d + lane] : 0.0;
   double pj = 0.0;
   if (lj) {
@@ -1879,241 +1789,6 @@ __global__ void __launch_bounds__(MPT) k_ext_aem_accept(const ExtAemAcceptArgs a
     if (a.rec_acc) a.rec_acc[rr] = acc ? 1 : 0;
   }
   if (a.rec_params && lj) a.rec_params[rr * a.d + lane] = cur;
-}
-
-// ------------------------------------------------------------------------------------------------
-// (Sigma_e + Sigma_bias)^-1 for every chain (distributions.py:399-402: set_bias re-inverts unless every entry of
-// Sigma_bias is < 1e-9), one workgroup of four waves per chain, on the matrix cores.  The matrix lives in LDS as the
-// 16 x 16 blocks on or below the diagonal (row stride 17):
-//   1. blocked Cholesky, left-looking by block column: trailing products on v_mfma_f64_16x16x4_f64, the 16 x 16 diagonal
-//      block factored and inverted by one wave with its rows in registers (v_readlane broadcasts, fully unrolled),
-//      the panel below multiplied by that inverse;
-//   2. W = L^-1 in place, block column by block column from the right (W[i][j] = -(sum_k W[i][k] L[k][j]) W[j][j]);
-//   3. P = W^T W written straight to HBM from the accumulators (both triangles).
-// Padding rows / columns (m not a multiple of 16) are identity and never stored.
-// ------------------------------------------------------------------------------------------------
-struct AemInvArgs {
-  int64_t N;
-  int m, MP, nb;              // outputs, row stride of the per-chain matrices (64 / 128), block rows = ceil(m / 16)
-  int nsum;                   // tracker covariances summed into Sigma_bias
-  const double* cov;          // [MP][MP] Sigma_e
-  const double* sig[MAXLEV];  // [NP][MP][MP]
-  double* P;                  // [NP][MP][MP]
-};
-
-constexpr int AEM_BS = 16 * 17;  // doubles per LDS block
-
-__device__ __forceinline__ double aem_bcast(double v, int src) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-  return __hiloint2double(hi, lo);
-}
-
-// one wave: block <- inverse of the Cholesky factor of the symmetric positive definite 16 x 16 block (lower triangle read).
-// The pivots go through 1 / sqrt (one v_rsq_f64 + refinement per step, no division anywhere); the inverse is built
-// column by column with sixteen independent accumulators instead of one dot product per element.
-__device__ __forceinline__ void aem_diag_block(double* __restrict__ blkp, int lane) {
-  const int li = lane & 15;  // lanes 16.. replicate lanes 0..15
-  double A[16], w[16], rinv[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) A[j] = blkp[li * 17 + j];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const double dkk = aem_bcast(A[k], k);
-    const double r = rsqrt(dkk);
-    rinv[k] = r;
-    const double lik = (li == k) ? dkk * r : A[k] * r;
-    A[k] = lik;
-#pragma unroll
-    for (int j = k + 1; j < 16; ++j) A[j] = fma(-lik, aem_bcast(lik, j), A[j]);
-  }
-  // column li of W = L^-1:  w[i] = -(sum_{p < i} L[i][p] w[p]) / L[i][i]  for i > li, 1 / L[li][li] at i = li, 0 above;
-  // as soon as w[p] is final every later row receives its term (L[i][p] is lane i's A[p])
-#pragma unroll
-  for (int i = 0; i < 16; ++i) w[i] = 0.0;
-#pragma unroll
-  for (int p = 0; p < 16; ++p) {
-    w[p] = p < li ? 0.0 : (p == li ? rinv[p] : -w[p] * rinv[p]);
-#pragma unroll
-    for (int i = p + 1; i < 16; ++i) w[i] = fma(aem_bcast(A[p], i), w[p], w[i]);
-  }
-  __builtin_amdgcn_wave_barrier();
-  if (lane < 16) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) blkp[i * 17 + li] = w[i];
-  }
-}
-
-// SKIP (tools/aem_inverse_probe.hip only; the library instantiates 0): 1 = no diagonal-block factorisation, 2 = return
-// after the matrix is staged, 4 = no P = W^T W, 8 = no triangular inverse, 16 = P computed but not stored -- wrong
-// results, stage timings.
-// NWV = waves per chain (4 or 8): the matrix stages have up to eight independent block rows per step.
-template <int SKIP = 0, int NWV = 8>
-__global__ void __launch_bounds__(64 * NWV) k_aem_inverse(const AemInvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) double aem_blocks[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lc = lane & 15, hi = lane >> 4;
-  const int64_t c = blockIdx.x;
-  if (c >= a.N) return;
-  const int nb = a.nb, m = a.m, MP = a.MP;
-  auto blk = [&](int bi, int bj) { return aem_blocks + (size_t)(bi * (bi + 1) / 2 + bj) * AEM_BS; };
-  const int rowp = lc * 17 + hi;  // + 4 kc: element [lc][4 kc + hi]   (A operand of X, B operand of X^T)
-  const int colp = hi * 17 + lc;  // + 68 kc: element [4 kc + hi][lc]  (B operand of X, A operand of X^T)
-  const int cdp = hi * 17 + lc;   // + 68 r: C/D element [hi + 4 r][lc]
-
-  // ---- Sigma_e + Sigma_bias into the blocks, and the 1e-9 rule ----
-  // thread (r, cc) = element [r][cc] of every (NWV / 4)-th block; twelve blocks in flight (the stage is bound by the latency of
-  // the global loads at two workgroups per CU, not by their volume)
-  bool big = false;
-  const size_t cbase = (size_t)c * MP * MP;
-  const double* __restrict__ sg0 = a.sig[0] + cbase;
-  const double* __restrict__ sg1 = a.nsum > 1 ? a.sig[1] + cbase : sg0;
-  const double* __restrict__ sg2 = a.nsum > 2 ? a.sig[2] + cbase : sg0;
-  const int nblk = nb * (nb + 1) / 2;
-  constexpr int BPP = NWV / 4;  // blocks covered by one pass of the workgroup
-  const int er = (tid & 255) >> 4, ec = tid & 15, bsel = tid >> 8;
-  for (int b0 = 0; b0 < nblk; b0 += 12 * BPP) {
-    double v0[12], v1[12], v2[12], ce[12];
-#pragma unroll
-    for (int u = 0; u < 12; ++u) {
-      const int bq = b0 + BPP * u + bsel;
-      const int b = bq < nblk ? bq : nblk - 1;
-      int bi = 0;
-      while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
-      const int bj = b - bi * (bi + 1) / 2;
-      const int i = 16 * bi + er, j = 16 * bj + ec;
-      const bool in = i < m && j < m;
-      const size_t o = in ? (size_t)i * MP + j : 0;
-      v0[u] = sg0[o];
-      v1[u] = a.nsum > 1 ? sg1[o] : 0.0;
-      v2[u] = a.nsum > 2 ? sg2[o] : 0.0;
-      ce[u] = a.cov[o];
-    }
-#pragma unroll
-    for (int u = 0; u < 12; ++u) {
-      if (b0 + BPP * u + bsel < nblk) {
-        const int b = b0 + BPP * u + bsel;
-        int bi = 0;
-        while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
-        const int bj = b - bi * (bi + 1) / 2;
-        const int i = 16 * bi + er, j = 16 * bj + ec;
-        double v;
-        if (i < m && j < m) {
-          double sb = 0.0 + v0[u];  // the reference's sum over the trackers starts from zero (proposal.py:1563-1569)
-          if (a.nsum > 1) sb += v1[u];
-          if (a.nsum > 2) sb += v2[u];
-          big = big || !(sb < 1e-9);
-          v = ce[u] + sb;
-        } else {
-          v = (i == j) ? 1.0 : 0.0;
-        }
-        aem_blocks[(size_t)b * AEM_BS + er * 17 + ec] = v;
-      }
-    }
-  }
-  if (!__syncthreads_or(big ? 1 : 0)) return;
-  if constexpr ((SKIP & 2) != 0) return;
-
-  // ---- 1. blocked Cholesky; the diagonal blocks end up holding the inverses of their factors ----
-  for (int j = 0; j < nb; ++j) {
-    for (int i = j + wave; i < nb; i += NWV) {
-      double* Cij = blk(i, j);
-      double4_t acc;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = Cij[cdp + 68 * r];
-      for (int k = 0; k < j; ++k) {
-        const double* Lik = blk(i, k);
-        const double* Ljk = blk(j, k);
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) acc = mfma_f64(-Lik[rowp + 4 * kc], Ljk[rowp + 4 * kc], acc);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Cij[cdp + 68 * r] = acc[r];
-    }
-    __syncthreads();
-    if ((SKIP & 1) == 0 && wave == ((j + (int)c) & (NWV - 1))) aem_diag_block(blk(j, j), lane);  // rotated over the SIMDs
-    __syncthreads();
-    const double* Wjj = blk(j, j);
-    for (int i = j + 1 + wave; i < nb; i += NWV) {  // L[i][j] = A[i][j] W[j][j]^T
-      double* Cij = blk(i, j);
-      double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int kc = 0; kc < 4; ++kc) acc = mfma_f64(Cij[rowp + 4 * kc], Wjj[rowp + 4 * kc], acc);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Cij[cdp + 68 * r] = acc[r];
-    }
-    __syncthreads();
-  }
-
-  // ---- 2. W = L^-1 in place ----
-  for (int j = (SKIP & 8) ? -1 : nb - 2; j >= 0; --j) {
-    constexpr int TS = NWV >= 8 ? 1 : 2;  // block rows per wave (at most seven rows below the diagonal)
-    double4_t t[TS];
-#pragma unroll
-    for (int s = 0; s < TS; ++s) {
-      const int i = j + 1 + wave + NWV * s;
-      t[s] = double4_t{0.0, 0.0, 0.0, 0.0};
-      if (i < nb)
-        for (int k = j + 1; k <= i; ++k) {
-          const double* Wik = blk(i, k);
-          const double* Lkj = blk(k, j);
-#pragma unroll
-          for (int kc = 0; kc < 4; ++kc) t[s] = mfma_f64(Wik[rowp + 4 * kc], Lkj[colp + 68 * kc], t[s]);
-        }
-    }
-    __syncthreads();  // every L[k][j] of this block column has been read
-#pragma unroll
-    for (int s = 0; s < TS; ++s) {
-      const int i = j + 1 + wave + NWV * s;
-      if (i < nb) {
-        double* Tij = blk(i, j);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Tij[cdp + 68 * r] = t[s][r];
-      }
-    }
-    __syncthreads();
-    const double* Wjj = blk(j, j);
-#pragma unroll
-    for (int s = 0; s < TS; ++s) {
-      const int i = j + 1 + wave + NWV * s;
-      if (i < nb) {
-        double* Tij = blk(i, j);
-        double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) acc = mfma_f64(-Tij[rowp + 4 * kc], Wjj[colp + 68 * kc], acc);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Tij[cdp + 68 * r] = acc[r];
-      }
-    }
-    __syncthreads();
-  }
-
-  // ---- 3. P = W^T W ----
-  if constexpr ((SKIP & 4) != 0) return;
-  double* Pc = a.P + cbase;
-  int idx = 0;
-  for (int i = 0; i < nb; ++i)
-    for (int jj = 0; jj <= i; ++jj, ++idx) {
-      if ((idx & (NWV - 1)) != wave) continue;
-      double4_t acc = {0.0, 0.0, 0.0, 0.0};
-      for (int k = i; k < nb; ++k) {
-        const double* Wki = blk(k, i);
-        const double* Wkj = blk(k, jj);
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) acc = mfma_f64(Wki[colp + 68 * kc], Wkj[colp + 68 * kc], acc);
-      }
-      // the block in 128-byte row segments, its mirror image element by element (the stores are asynchronous and the
-      // stage is bound by the matrix cores: a second product for the mirror block cost more than the scattered stores)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * i + hi + 4 * r, col = 16 * jj + lc;
-        const bool st = ((SKIP & 16) == 0 || acc[r] == 1.2345) && row < m && col < m;
-        if (st) Pc[(size_t)row * MP + col] = acc[r];
-        if (st && i != jj) Pc[(size_t)col * MP + row] = acc[r];
-      }
-    }
 }
 
 }  // namespace tda
