@@ -234,7 +234,7 @@ struct Level {
   // adaptive error model: plain row-major copies for the wave-per-chain kernel
   std::vector<double> A_h, ytil_h, data_h, cov_h;
   std::vector<double> w_h, Pinv_h;  // diagonal weights 1 / sigma_i^2, dense Sigma_e^-1 [m][m] (MALA's gradient operator)
-  DevBuf<double> A_rm, ytil64, data64, cov64;  // error-model copies, row stride em_ld
+  DevBuf<double> A_rm, ytil64, data64, cov64;  // error-model copies, row stride em_ld (cov64: Sigma_e as upper tiles, tda_kernels_aemr.h)
   DevBuf<double> Pd;                           // callback / source-defined level with dense noise: Sigma^-1 [m][m]
   DevBuf<double> A_dev, b_dev;                 // hierarchies: row-major [m][d] and offset [m] for k_ext_linear_eval (host-sequenced mode)
   int em_ld = 0;                               // 64 (m <= 64) or 128 (m <= 128); 0: level too large for an error model
@@ -334,6 +334,7 @@ struct tda_engine {
   DevBuf<double> ext_Fcur[tda::MAXLEV], ext_Fst;  // error model there: outputs of the current links [NP][MP], of level j at theta_q [npairs][NP][MP]
   DevBuf<double> aem_bias[tda::MAXLEV], aem_covinv[tda::MAXLEV], aem_bmu[tda::MAXLEV], aem_bsig[tda::MAXLEV], aem_mdiff[tda::MAXLEV];
   DevBuf<double> aem_rvec;  // [NP][aem_ld] bias-corrected residual the action kernels leave for k_aem_refresh's update_link
+  DevBuf<double> aem_upd;   // [NP][3][aem_ld] vectors of the tracker covariance update they leave for it
   int64_t aem_bt[tda::MAXLEV] = {1, 1, 1, 1};
   DevBuf<int64_t> ml_sid;
   DevBuf<double> prior_W_rm;
@@ -709,10 +710,10 @@ int ext_level_adaptive(tda_engine* /*e*/, Level& lv, int m, const double* data, 
   lv.ytil_h.assign(MP, 0.0);
   lv.data_h.assign(MP, 0.0);
   for (int i = 0; i < m; ++i) lv.ytil_h[i] = lv.data_h[i] = data[i];
-  std::vector<double> c64((size_t)MP * MP, 0.0);
-  for (int i = 0; i < m; ++i)
-    for (int j = 0; j < m; ++j) c64[(size_t)i * MP + j] = cov[(size_t)i * m + j];
-  for (int i = m; i < MP; ++i) c64[(size_t)i * MP + i] = 1.0;  // identity in the padding: k_aem_refresh factors all MP rows
+  // Sigma_e as the UPPER 16 x 16 tiles k_aem_refresh factors (tda_kernels_aemr.h), identity in the padding rows / columns
+  std::vector<double> c64(tda::aemr_v_doubles(MP), 0.0);
+  for (int i = 0; i < MP; ++i)
+    for (int j = i; j < MP; ++j) c64[tda::aemr_u_offset(MP, i, j)] = (i < m && j < m) ? cov[(size_t)i * m + j] : (i == j ? 1.0 : 0.0);
   int rc;
   if ((rc = lv.cov64.upload(c64))) return rc;
   if ((rc = lv.data64.upload(lv.data_h))) return rc;

@@ -37,6 +37,11 @@ __host__ __device__ constexpr int aemr_lt(int q, int i) { return q * (q + 1) / 2
 __host__ __device__ constexpr int aemr_tiles(int T) { return T * (T + 1) / 2; }
 // doubles per chain of the V array for row stride MP (64 or 128)
 __host__ __device__ constexpr size_t aemr_v_doubles(int MP) { return (size_t)aemr_tiles(MP / 16) * 256; }
+// offset (doubles, inside one chain's tile array of width MP) of element [i][j], i <= j, of a symmetric matrix kept as UPPER tiles
+__host__ __device__ inline size_t aemr_u_offset(int MP, int i, int j) {
+  const int ti = i >> 4, tj = j >> 4, ri = i & 15, cj = j & 15;
+  return ((size_t)(aemr_ut(MP / 16, ti, tj) * 4 + (ri >> 2)) * 64) + (ri & 3) * 16 + cj;
+}
 // offset (doubles, inside one chain's V array) of V[i][j], i >= j
 __host__ __device__ inline size_t aemr_v_offset(int i, int j) {
   const int ti = i >> 4, tj = j >> 4, ri = i & 15, cj = j & 15;
@@ -47,9 +52,13 @@ struct AemRefreshArgs {
   int64_t N, NP;
   int m, MP;                        // outputs, row stride of the row-major per-chain matrices (64 / 128)
   int nsum;                         // tracker covariances summed into Sigma_bias
-  const double* cov;                // [MP][MP] Sigma_e, row-major, IDENTITY in the padding rows / columns (>= m)
-  const double* sig[AEMR_MAXSUM];   // [NP][MP][MP] row-major, zero in the padding (bitwise symmetric: k_aem_action writes x_i x_j and x_j x_i)
+  const double* cov;                // [tiles][4][64] Sigma_e as UPPER tiles (aemr_ut) in C/D layout, IDENTITY in the padding rows / columns (>= m)
+  double* sig[AEMR_MAXSUM];         // [NP][tiles][4][64] tracker covariances, upper tiles, zero in the padding (symmetric: only this half exists)
   double* V;                        // [NP][tiles][4][64]: lower tiles of L^-1 in C/D layout
+  // the covariance update of tracker sig[0] (utils.py:117-122 with sd = 1, eps = 0; state-dependent: utils.py:199), applied to every
+  // tile on its way in and stored back; null upd: sig[0] is used as it is
+  const double* upd;                // [NP][3][MP]: dm, mu, mu' as k_aem_action left them (state-dependent model: x, 0, 0)
+  int64_t b_t;                      // the tracker's recursion counter before this update
   // update_link of the refreshed level (null rvec: not wanted)
   const double* rvec;               // [NP][MP]  F_k(theta_k) - y_k + bias_k (k_aem_action phase 0 leaves it), 0 beyond m
   double* ll;                       // [nlev][NP]
@@ -225,6 +234,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   constexpr int NT = aemr_tiles(T);
   constexpr int MP = 16 * T;  // the row stride IS the instance's width (64 / 128): compile-time offsets
   __shared__ double s_r[16 * T];
+  __shared__ double s_u[3 * 16 * T];  // vectors of the tracker update: x (dm), mu, mu'
   const int lane = threadIdx.x, lc = lane & 15, hi = lane >> 4;
   const int64_t c = blockIdx.x;
   if (c >= a.N) return;
@@ -236,11 +246,30 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   }
   double* __restrict__ Vc = a.V + (size_t)c * NT * 256;
   const __amdgpu_buffer_rsrc_t Vrs = aemr_rsrc(Vc);
-  const size_t cbase = (size_t)c * MP * MP;
+  const size_t cbase = (size_t)c * NT * 256;
   const __amdgpu_buffer_rsrc_t sg0 = aemr_rsrc(a.sig[0] + cbase);
   const __amdgpu_buffer_rsrc_t sg1 = aemr_rsrc(NSUM > 1 ? a.sig[1] + cbase : a.sig[0] + cbase);
   const __amdgpu_buffer_rsrc_t sg2 = aemr_rsrc(NSUM > 2 ? a.sig[2] + cbase : a.sig[0] + cbase);
   const __amdgpu_buffer_rsrc_t sge = aemr_rsrc(a.cov);
+
+  // ---- the tracker's covariance update (k_aem_action left its vectors): every element of sig[0] on its way in ----
+  //   state-independent (utils.py:117-122, sd = 1, eps = 0):  S <- (t-1)/t S + 1/t (t mu mu^T - (t+1) mu' mu'^T + x x^T)
+  //   state-dependent   (utils.py:199):                       S <- (t-1)/t S + 1/t x x^T
+  // in the reference's order of operations; products commute, so the upper half kept here is the whole matrix bit for bit.
+  const bool upd = a.upd != nullptr;
+  const double tt = (double)a.b_t, t1 = tt + 1.0, ca = (tt - 1.0) / tt, cb = 1.0 / tt;
+  {
+    const double* __restrict__ usrc = upd ? a.upd + (size_t)c * 3 * MP : a.cov;
+#pragma unroll
+    for (int i = lane; i < 3 * 16 * T; i += 64) s_u[i] = upd ? usrc[i] : 0.0;
+  }
+  __syncthreads();  // s_u, s_r
+  // (the state-dependent model leaves mu = mu' = 0: (t 0 - (t+1) 0) + x x^T is x x^T exactly -- one formula, no branch per element)
+  auto updated = [&](double old, double xr, double mr, double pr, double xc, double mc, double pc) {
+    const double M = (tt * (mr * mc) - t1 * (pr * pc)) + xr * xc;
+    const double nv = ca * old + cb * M;
+    return upd ? nv : old;
+  };
 
   // ---- the 1e-9 rule (distributions.py:399-402: no re-inversion while every entry of Sigma_bias is below 1e-9) ----
   // The rows are loaded lazily, so the decision cannot wait for them: the diagonal decides almost always (a covariance with an
@@ -249,28 +278,48 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   bool big = false;
 #pragma unroll
   for (int h = 0; h < (16 * T + 63) / 64; ++h) {
-    const int o = (lane + 64 * h) * (MP + 1) * 8;
-    double sb = 0.0 + aemr_ld(sg0, o, 0);
+    const int i = lane + 64 * h;
+    const int o = (int)aemr_u_offset(MP, i, i) * 8;
+    const double x = s_u[i], mo = s_u[MP + i], mn = s_u[2 * MP + i];
+    double sb = 0.0 + updated(aemr_ld(sg0, o, 0), x, mo, mn, x, mo, mn);
     if constexpr (NSUM > 1) sb += aemr_ld(sg1, o, 0);
     if constexpr (NSUM > 2) sb += aemr_ld(sg2, o, 0);
     big = big || !(sb < 1e-9);
   }
   if (__builtin_amdgcn_ballot_w64(big) == 0) {
-    for (int e = lane; e < MP * MP; e += 64) {  // (padding entries are zero)
-      double sb = 0.0 + aemr_ld(sg0, e * 8, 0);
-      if constexpr (NSUM > 1) sb += aemr_ld(sg1, e * 8, 0);
-      if constexpr (NSUM > 2) sb += aemr_ld(sg2, e * 8, 0);
-      big = big || !(sb < 1e-9);
+    for (int t = 0; t < NT; ++t) {  // (padding entries are zero)
+      int p = 0, rem = t;
+      while (rem >= T - p) { rem -= T - p; ++p; }
+      const int i = p + rem;
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * p + hi + 4 * r, col = 16 * i + lc, o = ((t * 4 + r) * 64 + lane) * 8;
+        double sb = 0.0 + updated(aemr_ld(sg0, o, 0), s_u[row], s_u[MP + row], s_u[2 * MP + row], s_u[col], s_u[MP + col], s_u[2 * MP + col]);
+        if constexpr (NSUM > 1) sb += aemr_ld(sg1, o, 0);
+        if constexpr (NSUM > 2) sb += aemr_ld(sg2, o, 0);
+        big = big || !(sb < 1e-9);
+      }
     }
   }
-  __syncthreads();  // s_r
   double sq = 0.0;
   if (__builtin_amdgcn_ballot_w64(big) == 0) {
-    // set_bias keeps the previous inverse; update_link still runs under the new bias
+    // set_bias keeps the previous inverse; update_link still runs under the new bias.  The tracker itself is still updated.
+    if (upd) {
+      double* __restrict__ S0 = a.sig[0] + cbase;
+      for (int t = 0; t < NT; ++t) {
+        int p = 0, rem = t;
+        while (rem >= T - p) { rem -= T - p; ++p; }
+        const int i = p + rem;
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * p + hi + 4 * r, col = 16 * i + lc;
+          const size_t o = (size_t)(t * 4 + r) * 64 + lane;
+          S0[o] = updated(S0[o], s_u[row], s_u[MP + row], s_u[2 * MP + row], s_u[col], s_u[MP + col], s_u[2 * MP + col]);
+        }
+      }
+    }
     sq = aem_quad_tiles_part<T, 1>(Vc, s_r, lane, 0);
   } else {
     const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
-    int lane_rm = (hi * MP + lc) * 8;  // byte offset of element [hi][lc] of a row-major tile
+    int lane_rm = lane * 8;  // byte offset of this lane's element inside a 512-byte tile row
     double4_t Uf[NT];  // finished rows of U (upper tiles), whole 8-register tuples from birth to their last matrix instruction
     double4_t Vl[NT];  // V: partial sums of the rows below, final rows on their way out
     double raw[2][T][4][4];  // [buffer][tile i of the row][source: 3 trackers + Sigma_e][r]
@@ -279,7 +328,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       for (int i = q; i < T; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int so = ((16 * q + 4 * r) * MP + 16 * i) * 8;
+          const int so = (aemr_ut(T, q, i) * 4 + r) * 512;
           raw[buf][i][0][r] = aemr_ld(sg0, lane_rm, so);
           if constexpr (NSUM > 1) raw[buf][i][1][r] = aemr_ld(sg1, lane_rm, so);
           if constexpr (NSUM > 2) raw[buf][i][2][r] = aemr_ld(sg2, lane_rm, so);
@@ -292,15 +341,28 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       __builtin_amdgcn_sched_barrier(0);
       // block row q of Sigma_e + Sigma_bias (the reference's sum over the trackers starts from zero, proposal.py:1563-1569)
       double4_t Cq[T];
-#pragma unroll
-      for (int i = q; i < T; ++i)
+      {
+        double xr[4], mr[4], pr[4];  // the update vectors at this lane's four rows of the block row
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          double sb = 0.0 + raw[q & 1][i][0][r];
-          if constexpr (NSUM > 1) sb += raw[q & 1][i][1][r];
-          if constexpr (NSUM > 2) sb += raw[q & 1][i][2][r];
-          Cq[i][r] = raw[q & 1][i][3][r] + sb;
+          xr[r] = s_u[16 * q + hi + 4 * r];
+          mr[r] = s_u[MP + 16 * q + hi + 4 * r];
+          pr[r] = s_u[2 * MP + 16 * q + hi + 4 * r];
         }
+#pragma unroll
+        for (int i = q; i < T; ++i) {
+          const double xc = s_u[16 * i + lc], mc = s_u[MP + 16 * i + lc], pc = s_u[2 * MP + 16 * i + lc];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double s0 = updated(raw[q & 1][i][0][r], xr[r], mr[r], pr[r], xc, mc, pc);
+            aemr_st(s0, sg0, lane * 8, (aemr_ut(T, q, i) * 4 + r) * 512);  // (no update wanted: the old value goes back)
+            double sb = 0.0 + s0;
+            if constexpr (NSUM > 1) sb += raw[q & 1][i][1][r];
+            if constexpr (NSUM > 2) sb += raw[q & 1][i][2][r];
+            Cq[i][r] = raw[q & 1][i][3][r] + sb;
+          }
+        }
+      }
       // the lane offset of the loads two rows on is "produced" here, next to a value of this row: neither the optimiser nor the
       // scheduler can then issue those loads before this row's sums exist (memory clobbers and sched_barrier alone did not hold
       // them: every load went to the top of the kernel and half of them straight to scratch)

@@ -1189,7 +1189,6 @@ struct AemArgs {
   const double* A[MAXLEV];     // row-major [m][d]
   const double* ytil[MAXLEV];  // y - b, [MP]   (residual r = A theta - ytil = F - y)
   const double* data[MAXLEV];  // y, [MP]       (model output F = r + y)
-  const double* cov[MAXLEV];   // adaptive levels: Sigma_e [MP][MP]
   double var_finest;
   const double* pr_mean;   // [DP]
   const double* pr_W;      // [d][d] whitening (L^-1 of the prior covariance), row-major
@@ -1203,10 +1202,10 @@ struct AemArgs {
   double* bias_tot[MAXLEV];  // [NP][MP]     adaptive levels
   double* cov_inv[MAXLEV];   // [NP][tiles][4][64] lower tiles of V = L^-1 (tda_kernels_aemr.h)
   double* b_mu[MAXLEV];      // trackers of levels >= 1: [NP][MP]
-  double* b_sig[MAXLEV];     // [NP][MP][MP]
   double* mdiff[MAXLEV];     // [NP][MP]
   int64_t b_t;               // recursion counter of level q's tracker before this update
   double* rvec;              // [NP][MP] out: bias-corrected residual of level q-1's latest link (k_aem_refresh ends with its update_link)
+  double* upd;               // [NP][3][MP] out: vectors of the tracker's covariance update (dm, mu, mu'; state-dependent: x), applied by k_aem_refresh
   const double* scaling;     // [NP] (pCN beta for the state-dependent q terms)
   const double* u_rep;       // [N] replay uniform of this step (NaN = none drawn) or null
   uint8_t* ring;
@@ -1371,54 +1370,27 @@ __global__ void __launch_bounds__(MPT) k_aem_action(const AemArgs a) {
   const double rq = resid(q), rk = resid(k);
   const double diff_new = lo ? (rq + a.data[q][lane]) - (rk + a.data[k][lane]) : 0.0;
   double* md = a.mdiff[q] + c * MP;
-  double* Sg = a.b_sig[q] + (size_t)c * MP * MP;
   const double t = (double)a.b_t;
-  double xupd;  // the sample fed to the running moments
+  // The covariance of the tracker (utils.py:117-122 / :199) is updated by k_aem_refresh, which reads every tile of it anyway
+  // (round 4: the read-modify-write of the full m x m matrix here was 1 GB per launch at 4096 chains x 128 outputs, and the
+  // refresh kernel read the result straight back): this kernel leaves the vectors of the update, a.upd[c][3][MP].
+  double* up = a.upd + (size_t)c * 3 * MP;
   if (a.dependent) {
-    xupd = lo ? (rq + a.data[q][lane]) - ((rk + a.data[k][lane]) + md[lane]) : 0.0;  // chain.py:505-507
+    const double xupd = lo ? (rq + a.data[q][lane]) - ((rk + a.data[k][lane]) + md[lane]) : 0.0;  // chain.py:505-507
     if (lo) md[lane] = diff_new;
-    __syncthreads();
-    s_v[MPT + lane] = xupd;
-    __syncthreads();
-    if (lo)
-      for (int i0 = 0; i0 < a.m; i0 += 8) {  // utils.py:199  Sigma <- (t-1)/t Sigma + 1/t x x^T; 8 rows in flight
-        double old[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) old[u] = i0 + u < a.m ? Sg[(size_t)(i0 + u) * MP + lane] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (i0 + u < a.m) {
-            const double xi = s_v[MPT + i0 + u];
-            Sg[(size_t)(i0 + u) * MP + lane] = (t - 1.0) / t * old[u] + 1.0 / t * (xi * xupd);
-          }
-      }
+    up[lane] = xupd;  // Sigma <- (t-1)/t Sigma + 1/t x x^T: the general update with mu = mu' = 0
+    up[MP + lane] = 0.0;
+    up[2 * MP + lane] = 0.0;
   } else {
     const double dm = (a.is_da || acc) ? diff_new : (lo ? md[lane] : 0.0);  // MLDA refreshes the difference on accept only
     if (lo) md[lane] = dm;
     double* mu = a.b_mu[q] + c * MP;
     const double mu_o = lo ? mu[lane] : 0.0;
     const double mu_n = (1.0 / (t + 1.0)) * (t * mu_o + dm);  // utils.py:113-122 with sd = 1, eps = 0
-    __syncthreads();
-    s_v[MPT + lane] = dm;
-    s_v[2 * MPT + lane] = mu_o;
-    s_v[3 * MPT + lane] = mu_n;
-    __syncthreads();
-    if (lo) {
-      const double ca = (t - 1.0) / t, cb = 1.0 / t;
-      for (int i0 = 0; i0 < a.m; i0 += 8) {  // 8 rows in flight
-        double old[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) old[u] = i0 + u < a.m ? Sg[(size_t)(i0 + u) * MP + lane] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (i0 + u < a.m) {
-            const int i = i0 + u;
-            const double M = (t * (s_v[2 * MPT + i] * mu_o) - (t + 1.0) * (s_v[3 * MPT + i] * mu_n)) + s_v[MPT + i] * dm;
-            Sg[(size_t)i * MP + lane] = ca * old[u] + cb * M;
-          }
-      }
-      mu[lane] = mu_n;
-    }
+    up[lane] = lo ? dm : 0.0;
+    up[MP + lane] = mu_o;
+    up[2 * MP + lane] = lo ? mu_n : 0.0;
+    if (lo) mu[lane] = mu_n;
   }
   __threadfence_block();
   __syncthreads();
@@ -1466,10 +1438,10 @@ struct ExtAemArgs {
   double* bias_tot[MAXLEV];
   double* cov_inv[MAXLEV];     // [NP][tiles][4][64] lower tiles of V = L^-1 (tda_kernels_aemr.h)
   double* b_mu[MAXLEV];
-  double* b_sig[MAXLEV];
   double* mdiff[MAXLEV];
   int64_t b_t;
   double* rvec;                // [NP][MP] out: bias-corrected residual of level q-1's latest link
+  double* upd;                 // [NP][3][MP] out: vectors of the tracker's covariance update (k_aem_action)
   const double* u_rep;
   uint8_t* ring;
   int ring_P;
@@ -1621,28 +1593,15 @@ __global__ void __launch_bounds__(MPT) k_ext_aem_action(const ExtAemArgs a) {
   // ---------------- error model update (chain.py:485-499, :739-753; proposal.py:1547-1578; utils.py:113-122) ----------------
   const double diff_new = fq_cur - fk_cur;
   double* md = a.mdiff[q] + c * MP;
-  double* Sg = a.b_sig[q] + (size_t)c * MP * MP;
   const double t = (double)a.b_t;
+  double* up = a.upd + (size_t)c * 3 * MP;  // vectors of the tracker's covariance update, applied by k_aem_refresh (see k_aem_action)
   if (a.dependent) {  // chain.py:501-523; utils.py:199: zero-mean moments of the change of the difference
     const double xupd = lo ? fq_cur - (fk_cur + md[lane]) : 0.0;
     if (lo) md[lane] = diff_new;
-    __syncthreads();
-    s_v[MPT + lane] = xupd;
-    __syncthreads();
-    if (lo) {
-      for (int i0 = 0; i0 < a.m; i0 += 8) {
-        double old[8];
-#pragma unroll
-        for (int uu = 0; uu < 8; ++uu) old[uu] = i0 + uu < a.m ? Sg[(size_t)(i0 + uu) * MP + lane] : 0.0;
-#pragma unroll
-        for (int uu = 0; uu < 8; ++uu)
-          if (i0 + uu < a.m) {
-            const double xi = s_v[MPT + i0 + uu];
-            Sg[(size_t)(i0 + uu) * MP + lane] = (t - 1.0) / t * old[uu] + 1.0 / t * (xi * xupd);
-          }
-      }
-      a.bias_tot[k][c * MP + lane] = diff_new;  // the bias of the coarse level is the last difference
-    }
+    up[lane] = xupd;
+    up[MP + lane] = 0.0;
+    up[2 * MP + lane] = 0.0;
+    if (lo) a.bias_tot[k][c * MP + lane] = diff_new;  // the bias of the coarse level is the last difference
     a.rvec[c * MP + lane] = lo ? (fk_cur - a.data[k][lane]) + diff_new : 0.0;  // for the update_link at the end of k_aem_refresh
     return;
   }
@@ -1651,27 +1610,10 @@ __global__ void __launch_bounds__(MPT) k_ext_aem_action(const ExtAemArgs a) {
   double* mu = a.b_mu[q] + c * MP;
   const double mu_o = lo ? mu[lane] : 0.0;
   const double mu_n = (1.0 / (t + 1.0)) * (t * mu_o + dm);
-  __syncthreads();
-  s_v[MPT + lane] = dm;
-  s_v[2 * MPT + lane] = mu_o;
-  s_v[3 * MPT + lane] = mu_n;
-  __syncthreads();
-  if (lo) {
-    const double ca = (t - 1.0) / t, cb = 1.0 / t;
-    for (int i0 = 0; i0 < a.m; i0 += 8) {
-      double old[8];
-#pragma unroll
-      for (int uu = 0; uu < 8; ++uu) old[uu] = i0 + uu < a.m ? Sg[(size_t)(i0 + uu) * MP + lane] : 0.0;
-#pragma unroll
-      for (int uu = 0; uu < 8; ++uu)
-        if (i0 + uu < a.m) {
-          const int i = i0 + uu;
-          const double M = (t * (s_v[2 * MPT + i] * mu_o) - (t + 1.0) * (s_v[3 * MPT + i] * mu_n)) + s_v[MPT + i] * dm;
-          Sg[(size_t)i * MP + lane] = ca * old[uu] + cb * M;
-        }
-    }
-    mu[lane] = mu_n;
-  }
+  up[lane] = lo ? dm : 0.0;
+  up[MP + lane] = mu_o;
+  up[2 * MP + lane] = lo ? mu_n : 0.0;
+  if (lo) mu[lane] = mu_n;
   __threadfence_block();
   __syncthreads();
   double bt = 0.0;

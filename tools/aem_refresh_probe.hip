@@ -27,13 +27,13 @@ static int run_case(int m, int64_t N, int nsum, int reps) {
   std::normal_distribution<double> nd;
   const int NV = 4;  // distinct matrices, dealt round-robin
   std::vector<double> cov((size_t)MP * MP, 0.0);
-  for (int i = 0; i < MP; ++i) cov[(size_t)i * MP + i] = i < m ? 0.01 : 1.0;
+  for (int i = 0; i < m; ++i) cov[(size_t)i * MP + i] = 0.01;
   for (int i = 0; i < m; ++i)
     for (int j = 0; j < i; ++j) cov[(size_t)i * MP + j] = cov[(size_t)j * MP + i] = 1e-4 * nd(g) / m;
   std::vector<std::vector<double>> sig(nsum * NV, std::vector<double>((size_t)MP * MP, 0.0));
   std::vector<double> x(m);
   for (auto& sgm : sig)
-    for (int s = 0; s < 20; ++s) {
+    for (int s = 0; s < 20; ++s) {  // (x x^T accumulated in one order: bitwise symmetric)
       for (auto& v : x) v = 0.05 * nd(g);
       for (int i = 0; i < m; ++i)
         for (int j = 0; j < m; ++j) sgm[(size_t)i * MP + j] += x[i] * x[j] / 20;
@@ -41,15 +41,42 @@ static int run_case(int m, int64_t N, int nsum, int reps) {
   std::vector<double> rv((size_t)NV * MP, 0.0);
   for (int v = 0; v < NV; ++v)
     for (int i = 0; i < m; ++i) rv[(size_t)v * MP + i] = 0.1 * nd(g);
-  double *dcov, *dsig[3] = {nullptr, nullptr, nullptr}, *dV, *drv, *dll, *dS;
+  // the update of tracker 0 (state-independent form), t = 7
+  const double tt = 7.0;
+  std::vector<double> upd((size_t)NV * 3 * MP, 0.0);
+  for (int v = 0; v < NV; ++v)
+    for (int i = 0; i < m; ++i) {
+      upd[((size_t)v * 3 + 0) * MP + i] = 0.05 * nd(g);
+      upd[((size_t)v * 3 + 1) * MP + i] = 0.02 * nd(g);
+      upd[((size_t)v * 3 + 2) * MP + i] = (1.0 / (tt + 1.0)) * (tt * upd[((size_t)v * 3 + 1) * MP + i] + upd[((size_t)v * 3 + 0) * MP + i]);
+    }
+  std::vector<std::vector<double>> sig0new(NV, std::vector<double>((size_t)MP * MP, 0.0));  // what the kernel must leave in tracker 0
+  for (int v = 0; v < NV; ++v)
+    for (int i = 0; i < m; ++i)
+      for (int j = 0; j < m; ++j) {
+        const double* u = &upd[(size_t)v * 3 * MP];
+        const double M = (tt * (u[MP + i] * u[MP + j]) - (tt + 1.0) * (u[2 * MP + i] * u[2 * MP + j])) + u[i] * u[j];
+        sig0new[v][(size_t)i * MP + j] = (tt - 1.0) / tt * sig[0 * NV + v][(size_t)i * MP + j] + 1.0 / tt * M;
+      }
+  double *dcov, *dsig[3] = {nullptr, nullptr, nullptr}, *dV, *drv, *dll, *dS, *dupd;
   int64_t* dsid;
-  const size_t MM = (size_t)MP * MP, VD = aemr_v_doubles(MP);
-  CK(hipMalloc(&dcov, MM * 8));
-  CK(hipMemcpy(dcov, cov.data(), MM * 8, hipMemcpyHostToDevice));
-  for (int s = 0; s < nsum; ++s) {
-    CK(hipMalloc(&dsig[s], (size_t)N * MM * 8));
-    for (int64_t c = 0; c < N; ++c) CK(hipMemcpy(dsig[s] + (size_t)c * MM, sig[s * NV + c % NV].data(), MM * 8, hipMemcpyHostToDevice));
-  }
+  const size_t VD = aemr_v_doubles(MP);
+  auto tiles_of = [&](const std::vector<double>& full, bool ident) {  // symmetric row-major -> upper tiles
+    std::vector<double> t(VD, 0.0);
+    for (int i = 0; i < MP; ++i)
+      for (int j = i; j < MP; ++j) t[aemr_u_offset(MP, i, j)] = (i < m && j < m) ? full[(size_t)i * MP + j] : ((ident && i == j) ? 1.0 : 0.0);
+    return t;
+  };
+  CK(hipMalloc(&dcov, VD * 8));
+  CK(hipMemcpy(dcov, tiles_of(cov, true).data(), VD * 8, hipMemcpyHostToDevice));
+  for (int s = 0; s < nsum; ++s) CK(hipMalloc(&dsig[s], (size_t)N * VD * 8));
+  auto reset_trackers = [&]() {
+    for (int s = 0; s < nsum; ++s)
+      for (int64_t c = 0; c < N; ++c) hipMemcpy(dsig[s] + (size_t)c * VD, tiles_of(sig[s * NV + c % NV], false).data(), VD * 8, hipMemcpyHostToDevice);
+  };
+  reset_trackers();
+  CK(hipMalloc(&dupd, (size_t)N * 3 * MP * 8));
+  for (int64_t c = 0; c < N; ++c) CK(hipMemcpy(dupd + (size_t)c * 3 * MP, upd.data() + (size_t)(c % NV) * 3 * MP, 3 * MP * 8, hipMemcpyHostToDevice));
   CK(hipMalloc(&dV, (size_t)N * VD * 8));
   CK(hipMemset(dV, 0, (size_t)N * VD * 8));
   CK(hipMalloc(&drv, (size_t)N * MP * 8));
@@ -62,7 +89,9 @@ static int run_case(int m, int64_t N, int nsum, int reps) {
   a.N = N; a.NP = N; a.m = m; a.MP = MP; a.nsum = nsum; a.cov = dcov;
   for (int s = 0; s < nsum; ++s) a.sig[s] = dsig[s];
   a.V = dV; a.rvec = drv; a.ll = dll; a.Sst = dS; a.sid = dsid; a.nlev = nlev; a.k = k;
+  a.upd = nullptr; a.b_t = (int64_t)tt;
   auto go = [&]() { if (T == 4) launch<4>(a); else launch<8>(a); };
+  // timing: no update (the trackers stay what they are over the repetitions; the arithmetic of the update runs all the same)
   go();
   CK(hipDeviceSynchronize());
   hipEvent_t e0, e1;
@@ -74,6 +103,10 @@ static int run_case(int m, int64_t N, int nsum, int reps) {
   CK(hipEventSynchronize(e1));
   float ms = 0;
   hipEventElapsedTime(&ms, e0, e1);
+  // the checked launch: with the update of tracker 0
+  a.upd = dupd;
+  go();
+  CK(hipDeviceSynchronize());
   // check chains 0 .. NV-1 and the last one
   double worstV = 0, worstL = 0;
   std::vector<double> V(VD), ll(N);
@@ -84,8 +117,8 @@ static int run_case(int m, int64_t N, int nsum, int reps) {
     std::vector<long double> S((size_t)m * m), L((size_t)m * m, 0.0L), W((size_t)m * m, 0.0L);
     for (int i = 0; i < m; ++i)
       for (int j = 0; j < m; ++j) {
-        double sb = 0.0;
-        for (int s = 0; s < nsum; ++s) sb += sig[s * NV + c % NV][(size_t)i * MP + j];
+        double sb = sig0new[c % NV][(size_t)i * MP + j];
+        for (int s = 1; s < nsum; ++s) sb += sig[s * NV + c % NV][(size_t)i * MP + j];
         S[(size_t)i * m + j] = cov[(size_t)i * MP + j] + sb;
       }
     for (int j = 0; j < m; ++j) {
@@ -119,13 +152,19 @@ static int run_case(int m, int64_t N, int nsum, int reps) {
     }
     const double llref = (double)(-0.5L * q);
     worstL = fmax(worstL, fabs(ll[c] - llref) / fabs(llref));
+    // tracker 0 after the launch: the reference's arithmetic, bit for bit
+    std::vector<double> T0(VD);
+    CK(hipMemcpy(T0.data(), dsig[0] + (size_t)c * VD, VD * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < m; ++i)
+      for (int j = i; j < m; ++j)
+        if (T0[aemr_u_offset(MP, i, j)] != sig0new[c % NV][(size_t)i * MP + j]) worstV = 1.0;
   }
   const double us = ms * 1000.0 / reps;
   const double flops = (double)N * (2.0 / 3.0) * pow((double)MP, 3);
   printf("m=%3d MP=%3d nsum=%d N=%lld: %8.1f us / launch  (%.1f TFLOP/s at 2/3 m^3)   max rel err V %.2e, ll %.2e\n", m, MP, nsum, (long long)N, us,
          flops / (us * 1e-6) / 1e12, worstV, worstL);
   hipFree(dcov); for (int s = 0; s < nsum; ++s) hipFree(dsig[s]);
-  hipFree(dV); hipFree(drv); hipFree(dll); hipFree(dS); hipFree(dsid);
+  hipFree(dV); hipFree(drv); hipFree(dll); hipFree(dS); hipFree(dsid); hipFree(dupd);
   return (worstV < 1e-10 && worstL < 1e-10) ? 0 : 2;
 }
 
