@@ -219,6 +219,11 @@ __device__ __forceinline__ double aem_quad_tiles(const double* __restrict__ Vc, 
   return -0.5 * sum_rows(aem_quad_tiles_part<T, 1>(Vc, s_r, lane, 0));
 }
 
+// Measured and not kept (tools/aem_refresh_probe.hip -DAEMR_TRACE): the right-looking V update of row q - 1 dealt over the sixteen
+// pivots of row q's diagonal tile (independent work under a dependent chain) -- the two phases took 109 000 cycles together instead
+// of 51 000 + 33 000 one after the other: the fp64 matrix instruction holds the fp64 vector lanes, so it delays the chain it was
+// meant to hide under, as DESIGN.md notes for the step kernels.
+//
 // NSUM = trackers summed into Sigma_bias (a template parameter: every `nsum > 1 ? load : 0` of a runtime count became a branch
 // of its own -- a thousand basic blocks -- and the register allocator spilled 700 registers across them).
 //
@@ -229,9 +234,17 @@ __device__ __forceinline__ double aem_quad_tiles(const double* __restrict__ Vc, 
 // tiles of Sigma loaded up front, right-looking for both -- 44 live tiles, and the allocator, asked for ~150 registers more than
 // the tiles themselves, spilled the early-loaded late-used tiles to scratch: 180 / 360 / 540 spilled registers and 417 / 624 /
 // 917 us per launch at NSUM = 1 / 2 / 3, still under the 730 us of the kernel it replaces.)
+#ifdef AEMR_TRACE  // tools/aem_refresh_probe.hip -DAEMR_TRACE: cycle stamps of chain 0's wave at the phase boundaries
+__device__ long long g_aemr_trace[64];
+#define AEMR_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_aemr_trace[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define AEMR_STAMP(i) do { } while (0)
+#endif
+
 template <int T, int NSUM>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) k_aem_refresh(const AemRefreshArgs a) {
   constexpr int NT = aemr_tiles(T);
+  AEMR_STAMP(0);
   constexpr int MP = 16 * T;  // the row stride IS the instance's width (64 / 128): compile-time offsets
   __shared__ double s_r[16 * T];
   __shared__ double s_u[3 * 16 * T];  // vectors of the tracker update: x (dm), mu, mu'
@@ -239,11 +252,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   const int64_t c = blockIdx.x;
   if (c >= a.N) return;
   const bool want_ll = a.rvec != nullptr;
-  {
-    const double* __restrict__ rsrc = want_ll ? a.rvec + c * MP : a.cov;  // (no r wanted: any readable address, the result is dropped)
-#pragma unroll
-    for (int i = lane; i < 16 * T; i += 64) s_r[i] = rsrc[i];
-  }
   double* __restrict__ Vc = a.V + (size_t)c * NT * 256;
   const __amdgpu_buffer_rsrc_t Vrs = aemr_rsrc(Vc);
   const size_t cbase = (size_t)c * NT * 256;
@@ -258,12 +266,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   // in the reference's order of operations; products commute, so the upper half kept here is the whole matrix bit for bit.
   const bool upd = a.upd != nullptr;
   const double tt = (double)a.b_t, t1 = tt + 1.0, ca = (tt - 1.0) / tt, cb = 1.0 / tt;
-  {
-    const double* __restrict__ usrc = upd ? a.upd + (size_t)c * 3 * MP : a.cov;
-#pragma unroll
-    for (int i = lane; i < 3 * 16 * T; i += 64) s_u[i] = upd ? usrc[i] : 0.0;
-  }
-  __syncthreads();  // s_u, s_r
   // (the state-dependent model leaves mu = mu' = 0: (t 0 - (t+1) 0) + x x^T is x x^T exactly -- one formula, no branch per element)
   auto updated = [&](double old, double xr, double mr, double pr, double xc, double mc, double pc) {
     const double M = (tt * (mr * mc) - t1 * (pr * pc)) + xr * xc;
@@ -271,21 +273,61 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     return upd ? nv : old;
   };
 
+  // ---- everything the first step needs is requested at once: r, the update vectors, the diagonals of the trackers (the 1e-9 rule
+  // below), block row 0 of every source -- ONE memory round trip in front of the first matrix instruction instead of three
+  // dependent ones (vectors to LDS, then the diagonals, then row 0)
+  int lane_rm = lane * 8;  // byte offset of this lane's element inside a 512-byte tile row
+  double raw[2][T][4][4];  // [buffer][tile i of the row][source: 3 trackers + Sigma_e][r]
+  auto issue_row = [&](int q, int buf) {  // (no bounds: the padding of the trackers is zero and that of Sigma_e the identity)
+#pragma unroll
+    for (int i = q; i < T; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int so = (aemr_ut(T, q, i) * 4 + r) * 512;
+        raw[buf][i][0][r] = aemr_ld(sg0, lane_rm, so);
+        if constexpr (NSUM > 1) raw[buf][i][1][r] = aemr_ld(sg1, lane_rm, so);
+        if constexpr (NSUM > 2) raw[buf][i][2][r] = aemr_ld(sg2, lane_rm, so);
+        raw[buf][i][3][r] = aemr_ld(sge, lane_rm, so);
+      }
+  };
+  constexpr int NH = (16 * T + 63) / 64;  // vector elements per lane
+  double rv[NH], ux[NH], um[NH], up[NH], d0[NH], d1[NH], d2[NH];
+  {
+    const double* __restrict__ rsrc = want_ll ? a.rvec + c * MP : a.cov;  // (no r wanted: any readable address, the result is dropped)
+    const double* __restrict__ usrc = upd ? a.upd + (size_t)c * 3 * MP : a.cov;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const int i = lane + 64 * h;
+      const int o = (int)aemr_u_offset(MP, i, i) * 8;
+      rv[h] = rsrc[i];
+      ux[h] = usrc[i];
+      um[h] = usrc[MP + i];
+      up[h] = usrc[2 * MP + i];
+      d0[h] = aemr_ld(sg0, o, 0);
+      d1[h] = NSUM > 1 ? aemr_ld(sg1, o, 0) : 0.0;
+      d2[h] = NSUM > 2 ? aemr_ld(sg2, o, 0) : 0.0;
+    }
+  }
+  issue_row(0, 0);
   // ---- the 1e-9 rule (distributions.py:399-402: no re-inversion while every entry of Sigma_bias is below 1e-9) ----
   // The rows are loaded lazily, so the decision cannot wait for them: the diagonal decides almost always (a covariance with an
   // entry >= 1e-9 has a diagonal entry >= 1e-9 up to rounding); when the diagonal says "small" the exact test over every entry
   // follows -- that is the regime in which the inversion is skipped anyway.
   bool big = false;
 #pragma unroll
-  for (int h = 0; h < (16 * T + 63) / 64; ++h) {
+  for (int h = 0; h < NH; ++h) {
     const int i = lane + 64 * h;
-    const int o = (int)aemr_u_offset(MP, i, i) * 8;
-    const double x = s_u[i], mo = s_u[MP + i], mn = s_u[2 * MP + i];
-    double sb = 0.0 + updated(aemr_ld(sg0, o, 0), x, mo, mn, x, mo, mn);
-    if constexpr (NSUM > 1) sb += aemr_ld(sg1, o, 0);
-    if constexpr (NSUM > 2) sb += aemr_ld(sg2, o, 0);
+    const double x = upd ? ux[h] : 0.0, mo = upd ? um[h] : 0.0, mn = upd ? up[h] : 0.0;
+    s_r[i] = rv[h];
+    s_u[i] = x;
+    s_u[MP + i] = mo;
+    s_u[2 * MP + i] = mn;
+    double sb = 0.0 + updated(d0[h], x, mo, mn, x, mo, mn);
+    if constexpr (NSUM > 1) sb += d1[h];
+    if constexpr (NSUM > 2) sb += d2[h];
     big = big || !(sb < 1e-9);
   }
+  __syncthreads();  // s_u, s_r
   if (__builtin_amdgcn_ballot_w64(big) == 0) {
     for (int t = 0; t < NT; ++t) {  // (padding entries are zero)
       int p = 0, rem = t;
@@ -300,6 +342,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       }
     }
   }
+  AEMR_STAMP(1);
   double sq = 0.0;
   if (__builtin_amdgcn_ballot_w64(big) == 0) {
     // set_bias keeps the previous inverse; update_link still runs under the new bias.  The tracker itself is still updated.
@@ -319,23 +362,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     sq = aem_quad_tiles_part<T, 1>(Vc, s_r, lane, 0);
   } else {
     const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
-    int lane_rm = lane * 8;  // byte offset of this lane's element inside a 512-byte tile row
     double4_t Uf[NT];  // finished rows of U (upper tiles), whole 8-register tuples from birth to their last matrix instruction
     double4_t Vl[NT];  // V: partial sums of the rows below, final rows on their way out
-    double raw[2][T][4][4];  // [buffer][tile i of the row][source: 3 trackers + Sigma_e][r]
-    auto issue_row = [&](int q, int buf) {  // (no bounds: the padding of the trackers is zero and that of Sigma_e the identity)
-#pragma unroll
-      for (int i = q; i < T; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int so = (aemr_ut(T, q, i) * 4 + r) * 512;
-          raw[buf][i][0][r] = aemr_ld(sg0, lane_rm, so);
-          if constexpr (NSUM > 1) raw[buf][i][1][r] = aemr_ld(sg1, lane_rm, so);
-          if constexpr (NSUM > 2) raw[buf][i][2][r] = aemr_ld(sg2, lane_rm, so);
-          raw[buf][i][3][r] = aemr_ld(sge, lane_rm, so);
-        }
-    };
-    issue_row(0, 0);
     aemr_static_for<T>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
       __builtin_amdgcn_sched_barrier(0);
@@ -368,10 +396,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       // them: every load went to the top of the kernel and half of them straight to scratch)
       asm volatile("" : "+v"(lane_rm) : "v"(Cq[q][0]));
       __builtin_amdgcn_sched_barrier(0);
+      AEMR_STAMP(2 + 6 * q);
       // left-looking: C(q, i) -= sum_{p < q} U_pq^T U_pi
 #pragma unroll
       for (int p = 0; p < q; ++p) {
         const double4_t nA = -Uf[aemr_ut(T, p, q)];
+        // (measured: with the k-slice outermost -- consecutive matrix instructions on different accumulators -- here and in the two
+        // loops below the allocator spills 84 instead of 34 registers and the launch takes 447 instead of 390 us)
 #pragma unroll
         for (int i = q; i < T; ++i)
 #pragma unroll
@@ -380,6 +411,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       __builtin_amdgcn_sched_barrier(0);
       // the next row's loads fly under this row's diagonal tile (16 dependent pivots, ~1.5 us) and V updates: issued here, not at
       // the top of the step, their 8 (NSUM + 1) registers per tile do not sit beside the accumulators of the update above
+      AEMR_STAMP(3 + 6 * q);
       if constexpr (q + 1 < T) issue_row(q + 1, (q + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
       double Cd[4], Vd[4], Vt[4];
@@ -387,6 +419,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       for (int r = 0; r < 4; ++r) Cd[r] = Cq[q][r];
       aemr_diag(Cd, Vd, Vt, lc, hi);
       __builtin_amdgcn_sched_barrier(0);
+      AEMR_STAMP(4 + 6 * q);
       // the rest of block row q times V_qq (lower-triangular inverse of the diagonal tile's factor)
 #pragma unroll
       for (int i = q + 1; i < T; ++i) {
@@ -405,6 +438,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #pragma unroll
       for (int r = 0; r < 4; ++r) Vl[aemr_lt(q, q)][r] = Vd[r];
       __builtin_amdgcn_sched_barrier(0);
+      AEMR_STAMP(5 + 6 * q);
       // block row q of V is final: out it goes, and its share of |V r|^2
       double z[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -421,6 +455,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         const double zz = aemr_row_sum(z[r]);
         sq = fma(zz, zz, sq);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      AEMR_STAMP(6 + 6 * q);
       // right-looking for V: the rows below take  -U_qq'^T V_qi  into their partial sums (tile (q', q) is born here)
 #pragma unroll
       for (int q2 = q + 1; q2 < T; ++q2) {
@@ -434,8 +470,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
           Vl[aemr_lt(q2, i)] = acc;
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      AEMR_STAMP(7 + 6 * q);
     });
   }
+  AEMR_STAMP(2 + 6 * T);
   if (want_ll) {
     const double llk = -0.5 * sum_rows(sq);
     if (lane == 0) {

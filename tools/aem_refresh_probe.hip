@@ -107,6 +107,21 @@ static int run_case(int m, int64_t N, int nsum, int reps) {
   a.upd = dupd;
   go();
   CK(hipDeviceSynchronize());
+#ifdef AEMR_TRACE
+  {
+    long long st[64];
+    CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_aemr_trace), sizeof st));
+    printf("  trace of chain 0 (cycles): load+precheck %lld;", st[1] - st[0]);
+    long long tot[6] = {0, 0, 0, 0, 0, 0};
+    for (int q = 0; q < T; ++q) {
+      const long long* b = st + 2 + 6 * q;
+      const long long prev = q == 0 ? st[1] : st[2 + 6 * (q - 1) + 5];
+      tot[0] += b[0] - prev; tot[1] += b[1] - b[0]; tot[2] += b[2] - b[1]; tot[3] += b[3] - b[2]; tot[4] += b[4] - b[3]; tot[5] += b[5] - b[4];
+    }
+    printf(" row sums+update %lld, left-looking U %lld, diagonal tiles %lld, row scaling %lld, V out + z %lld, right-looking V %lld; total %lld\n",
+           tot[0], tot[1], tot[2], tot[3], tot[4], tot[5], st[2 + 6 * T] - st[0]);
+  }
+#endif
   // check chains 0 .. NV-1 and the last one
   double worstV = 0, worstL = 0;
   std::vector<double> V(VD), ll(N);
