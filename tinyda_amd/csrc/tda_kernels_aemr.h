@@ -486,4 +486,220 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The base level of a host-sequenced hierarchy under the dense error model: one subchain of S Metropolis-Hastings steps per
+// launch (chain.py:96-129 inside MLDAChain / DAChain; AdaptiveGaussianLogLike.loglike, distributions.py:404-425), ONE WAVE PER
+// CHAIN.  k_ml_steps evaluates -1/2 |V r'|^2 per step and chain from that chain's 72 KB factor: S passes over V per launch,
+// 360 KB per chain at S = 5 -- the launch ran at the HBM roofline and was a third of the configuration's wall clock.  The model is
+// linear and the increments of the block are known before its first step, so with F = A theta (no offsets)
+//     V r' = keep V F + V A (s inc_k) + V (bias - ytil)            (keep = sqrt(1 - beta^2) for pCN, 1 otherwise)
+// and ONE pass over V multiplies all S + 2 vectors [F | bias - ytil | A s inc_1 ... A s inc_S]; a step is then an m-vector update
+// and two reductions.  The products are re-derived from theta at every launch (rounding does not accumulate beyond one
+// subchain); log-densities agree with the step-by-step evaluation to rounding, decisions are the same.
+// Diagonal prior (bounded support included), fixed subchain lengths; anything else stays with k_ml_steps.
+// ------------------------------------------------------------------------------------------------
+struct AemBaseArgs {
+  int64_t N, NP;
+  int d, DP, m, MP, S, pcn;
+  const double* A_cm;   // [d][MP] level-0 operator, column-major (lane = observation reads consecutive addresses)
+  const double* ytil;   // [MP] y - b
+  const double* bias;   // [NP][MP] total bias of level 0
+  const double* V;      // [NP][tiles][4][64]
+  const double* pr_mean;
+  const double* pr_pinv;
+  const double* pr_lo;  // support bounds of uniform prior components, or null
+  const double* pr_hi;
+  double logconst;
+  double* theta;        // level 0: [NP][DP]
+  double* lp;           // level 0: [NP]
+  double* ll;
+  int32_t* anyacc;      // level 0: [NP]
+  int64_t* sid;         // level 0: [NP] (may be null)
+  int64_t step0;        // base-level steps completed before this launch (identity of the vectors it creates)
+  const double* scaling;  // [NP]
+  const double* inc;      // [S][NP][DP]
+  const double* u0;       // [S][NP]
+  uint8_t* ring;
+  int ring_P;
+  int64_t ring_pos;
+  double* rec_params;   // [S][N][d] or null
+  double* rec_stats;
+  uint8_t* rec_acc;
+};
+
+template <int T>
+__global__ void __launch_bounds__(64) k_aem_base_steps(const AemBaseArgs a) {
+  constexpr int MP = 16 * T, NH = MP / 64 > 0 ? MP / 64 : 1;  // observations per lane
+  constexpr int CMAX = 8;                                      // vectors per pass over V
+  extern __shared__ __attribute__((aligned(16))) double aemb_smem[];
+  double* s_X = aemb_smem;         // [S + 2][MP]: F, bias - ytil, A s inc_k; overwritten by V times them; then CMAX staged parameter vectors [64]
+  const int lane = threadIdx.x, lc = lane & 15, hi = lane >> 4;
+  const int64_t c = blockIdx.x;
+  if (c >= a.N) return;
+  const int d = a.d, S = a.S, NC = S + 2;
+  const bool lj = lane < d;
+  double th = lj ? a.theta[c * a.DP + lane] : 0.0;
+  const double scal = a.scaling[c];
+  const double keep = a.pcn ? sqrt(1.0 - scal * scal) : 1.0;
+  double lp = a.lp[c], ll = a.ll[c];
+  const double* __restrict__ Vc = a.V + (size_t)c * aemr_tiles(T) * 256;
+
+  // ---- the S + 1 products with the level's operator, the offsets ----
+  for (int k0 = 0; k0 <= S; k0 += CMAX) {  // vectors theta (k = 0) and s inc_k (k >= 1), CMAX at a time
+    const int nk = S + 1 - k0 < CMAX ? S + 1 - k0 : CMAX;
+    __syncthreads();
+    for (int k = 0; k < nk; ++k) {  // the chunk's parameter vectors: rows of a [CMAX][64] block (s_th grows into a block here)
+      const int kk = k0 + k;
+      const double v = kk == 0 ? th : (lj ? scal * a.inc[((size_t)(kk - 1) * a.NP + c) * a.DP + lane] : 0.0);
+      s_X[(size_t)NC * MP + k * 64 + lane] = v;  // (staging rows beyond the S + 2 result vectors)
+    }
+    __syncthreads();
+    double acc[NH][CMAX];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int k = 0; k < CMAX; ++k) acc[h][k] = 0.0;
+    const double* __restrict__ xs = s_X + (size_t)NC * MP;
+    for (int j = 0; j < d; ++j) {
+      double av[NH];
+#pragma unroll
+      for (int h = 0; h < NH; ++h) av[h] = a.A_cm[(size_t)j * MP + lane + 64 * h];
+#pragma unroll
+      for (int k = 0; k < CMAX; ++k) {
+        const double xv = k < nk ? xs[k * 64 + j] : 0.0;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) acc[h][k] = fma(av[h], xv, acc[h][k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < CMAX; ++k)
+      if (k < nk) {
+        const int col = k0 + k == 0 ? 0 : k0 + k + 1;  // F first, then (after the offsets) the increments
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+          if (lane + 64 * h < MP) s_X[(size_t)col * MP + lane + 64 * h] = acc[h][k];
+      }
+  }
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    const int o = lane + 64 * h;
+    if (o < MP) s_X[(size_t)MP + o] = o < a.m ? a.bias[c * MP + o] - a.ytil[o] : 0.0;
+  }
+  __syncthreads();
+
+  // ---- Z = V X: one pass over the chain's factor for CMAX vectors; block rows from the last to the first, so that the
+  // results can take the place of the operands (row p of Z needs the blocks 0..p of X only) ----
+  for (int k0 = 0; k0 < NC; k0 += CMAX) {
+    const int nk = NC - k0 < CMAX ? NC - k0 : CMAX;
+    for (int p = T - 1; p >= 0; --p) {
+      double v[T][4];
+      const double* __restrict__ Vp = Vc + (size_t)aemr_lt(p, 0) * 256 + lane;
+#pragma unroll
+      for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[i][r] = i <= p ? Vp[(size_t)(i * 4 + r) * 64] : 0.0;
+      double z[CMAX][4];
+#pragma unroll
+      for (int k = 0; k < CMAX; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[k][r] = 0.0;
+#pragma unroll
+      for (int i = 0; i < T; ++i) {
+        if (i > p) continue;
+#pragma unroll
+        for (int k = 0; k < CMAX; ++k) {
+          const double xv = k < nk ? s_X[(size_t)(k0 + k) * MP + 16 * i + lc] : 0.0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) z[k][r] = fma(v[i][r], xv, z[k][r]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < CMAX; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[k][r] = aemr_row_sum(z[k][r]);
+      __syncthreads();  // every read of block p of X is done
+      if (lc == 0) {
+#pragma unroll
+        for (int k = 0; k < CMAX; ++k)
+          if (k < nk) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_X[(size_t)(k0 + k) * MP + 16 * p + hi + 4 * r] = z[k][r];
+          }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- the S steps ----
+  double zF[NH], zb[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    const int o = lane + 64 * h;
+    zF[h] = o < MP ? s_X[o] : 0.0;
+    zb[h] = o < MP ? s_X[(size_t)MP + o] : 0.0;
+  }
+  const double pm = lj ? a.pr_mean[lane] : 0.0, pinv = lj ? a.pr_pinv[lane] : 0.0;
+  const double plo = (lj && a.pr_lo) ? a.pr_lo[lane] : -__builtin_inf(), phi = (lj && a.pr_lo) ? a.pr_hi[lane] : __builtin_inf();
+  int any = a.anyacc[c];
+  int ringidx = (int)(a.ring_pos % a.ring_P);
+  auto wsum = [&](double v) {
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+  };
+  for (int s = 0; s < S; ++s) {
+    const double incv = lj ? a.inc[((size_t)s * a.NP + c) * a.DP + lane] : 0.0;
+    const double prp = lj ? keep * th + scal * incv : 0.0;
+    double pj = 0.0;
+    if (lj) {
+      const double dv = prp - pm;
+      pj = dv * dv * pinv;
+      if (prp < plo || prp > phi) pj = __builtin_inf();  // uniform components: zero density outside their support
+    }
+    double ssq = 0.0, zn[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const int o = lane + 64 * h;
+      zn[h] = o < MP ? (keep * zF[h] + s_X[(size_t)(s + 2) * MP + o]) : 0.0;  // V (keep F + A s inc): the new V F if accepted
+      const double zz = zn[h] + zb[h];
+      ssq = fma(zz, zz, ssq);
+    }
+    const double maha = wsum(pj);
+    const double ll_n = -0.5 * wsum(ssq);
+    const double lp_n = -0.5 * (a.logconst + maha);
+    const double post_n = lp_n + ll_n;
+    double alpha = a.pcn ? exp(ll_n - ll) : exp(post_n - (lp + ll));
+    if (post_n != post_n) alpha = 0.0;
+    const bool acc = a.u0[(size_t)s * a.NP + c] < alpha;
+    if (acc) {
+      lp = lp_n;
+      ll = ll_n;
+      th = prp;
+#pragma unroll
+      for (int h = 0; h < NH; ++h) zF[h] = zn[h];
+      any = 1;
+    }
+    const size_t rr = (size_t)s * a.N + c;
+    if (a.rec_params && lj) a.rec_params[rr * d + lane] = th;
+    if (lane == 0) {
+      if (acc && a.sid) a.sid[c] = a.step0 + s + 1;  // a new parameter vector was created
+      if (a.rec_stats) {
+        a.rec_stats[rr * 3 + 0] = lp;
+        a.rec_stats[rr * 3 + 1] = ll;
+        a.rec_stats[rr * 3 + 2] = lp + ll;
+      }
+      if (a.rec_acc) a.rec_acc[rr] = acc ? 1 : 0;
+      a.ring[(size_t)ringidx * a.NP + c] = acc ? 1 : 0;
+    }
+    ringidx = ringidx + 1 == a.ring_P ? 0 : ringidx + 1;
+  }
+  if (lane < a.DP) a.theta[c * a.DP + lane] = th;
+  if (lane == 0) {
+    a.lp[c] = lp;
+    a.ll[c] = ll;
+    a.anyacc[c] = any;
+  }
+}
+// dynamic LDS of k_aem_base_steps: (S + 2 result vectors) MP + CMAX staged parameter vectors of 64
+__host__ __device__ constexpr size_t aem_base_lds_bytes(int S, int MP) { return (size_t)((S + 2) * MP + 8 * 64) * sizeof(double); }
+
 }  // namespace tda
