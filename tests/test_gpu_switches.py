@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _probe(what, env_extra, tmp_path, tag):
     out = str(tmp_path / ("%s_%s.npz" % (what, tag)))
     env = dict(os.environ)
-    for k in ("TINYDA_DA_LEAN", "TINYDA_DZ_WAVE", "TINYDA_DZ_PIPELINE", "TINYDA_AEMD_FUSED", "TINYDA_FUSE_CHOL_APPLY", "TINYDA_CHOL_BLOCKED"):
+    for k in ("TINYDA_DA_LEAN", "TINYDA_DZ_WAVE", "TINYDA_DZ_PIPELINE", "TINYDA_AEMD_FUSED", "TINYDA_FUSE_CHOL_APPLY", "TINYDA_CHOL_BLOCKED",
+              "TINYDA_FUSE_ADAPT_CHOL", "TINYDA_AEM_BASE"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "switch_probe.py"), what, out], cwd=ROOT, env=env,
@@ -57,6 +58,26 @@ def test_fused_swap_and_increments_equal_the_two_launches(what, tmp_path):
     blk2 = _probe(what, {"TINYDA_FUSE_CHOL_APPLY": "0"}, tmp_path, "blocked_split")  # k_chol_apply_blk<., false> + k_apply
     assert np.array_equal(blk2["acc0"], blk["acc0"])
     np.testing.assert_allclose(blk2["stats0"], blk["stats0"], rtol=1e-6)
+    # round 4: the moment recursion, the swap and the increments in ONE launch (k_adapt_chol_apply, the default at 64 parameters;
+    # Sigma goes from the recursion's registers into the factorisation through a register transpose) against k_adapt followed by
+    # k_chol_apply_blk (TINYDA_FUSE_ADAPT_CHOL=0): the same arithmetic on the same values -- every record and the final state bitwise
+    two = _probe(what, {"TINYDA_FUSE_ADAPT_CHOL": "0"}, tmp_path, "two_launches")
+    for k in blk:
+        assert np.array_equal(blk[k], two[k]), "one-launch boundary changed %s" % k
+
+
+@pytest.mark.parametrize("what", ["aem_dense", "aem_dense_ragged", "aem_dense_da_pcn"])
+def test_error_model_base_subchain_kernels_agree(what, tmp_path):
+    """dense error model over linear levels: the base subchain on k_aem_base_steps (one pass over each chain's factor V per launch,
+    linear update of V r) against k_ml_steps (TINYDA_AEM_BASE=0: -1/2 |V r'|^2 evaluated per step): same decisions, log-densities
+    to rounding"""
+    one, per_step = _probe(what, {}, tmp_path, "one_pass"), _probe(what, {"TINYDA_AEM_BASE": "0"}, tmp_path, "per_step")
+    for k in one:
+        if k.startswith("acc"):
+            assert np.array_equal(one[k], per_step[k]), "%s: %d accept flips" % (k, int((one[k] != per_step[k]).sum()))
+        else:
+            np.testing.assert_allclose(one[k], per_step[k], rtol=1e-10, atol=1e-12, err_msg=k)
+    assert 0.02 < one["acc0"].mean() < 0.98
 
 
 @pytest.mark.parametrize("what", ["dream", "dream_ragged"])

@@ -487,6 +487,20 @@ void launch_chol_apply(const CholArgs& a, const ApplyArgs& ap, hipStream_t st) {
   hipLaunchKernelGGL(k_chol_apply<DPAD>, dim3((unsigned)ap.NP), dim3(64), 0, st, a, ap);
 }
 
+// the period boundary of the single-level AdaptiveMetropolis pipeline in one launch (k_adapt_chol_apply, DPAD = 64 only)
+template <int DPAD>
+bool launch_adapt_chol_apply(const AdaptArgs& aa, const CholArgs& ca, const ApplyArgs& ap, hipStream_t st) {
+  if constexpr (DPAD == 64) {
+    static const bool ok = !(getenv("TINYDA_FUSE_ADAPT_CHOL") && atoi(getenv("TINYDA_FUSE_ADAPT_CHOL")) == 0) &&  // A/B switches
+                           !(getenv("TINYDA_CHOL_BLOCKED") && atoi(getenv("TINYDA_CHOL_BLOCKED")) == 0);
+    if (ok && aa.do_am && !aa.block_moments) {
+      hipLaunchKernelGGL(k_adapt_chol_apply<DPAD>, dim3((unsigned)ap.NP), dim3(64), 0, st, aa, ca, ap);
+      return true;
+    }
+  }
+  return false;
+}
+
 // k_aem_refresh<T, NSUM> for the engine's row stride (64 / 128 -> 4 / 8 tile rows) and the number of trackers summed
 static int launch_aem_refresh(const tda::AemRefreshArgs& ra, hipStream_t st) {
   using namespace tda;

@@ -1281,23 +1281,20 @@ __device__ __forceinline__ double bcast_lane64(double v, int src) {
 // At DPAD <= 16 the two together took 82 -> 66-71 us per 100 states of 4096 chains (the fixed ~50 instructions per state
 // dominate there), at DPAD = 32 nothing (150 us: four resident waves x 125 instructions, the vector unit 56 % busy); not
 // adopted, no benchmark configuration adapts in fewer than 64 dimensions.
+// the moment recursion of one chain by its wave; Sigma is left in Sg (and stored): k_adapt, and the first half of k_adapt_chol_apply
 template <int DPAD>
-__global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
+__device__ __forceinline__ void adapt_am_chain(const AdaptArgs& a, const int64_t c, const int lane, double (&Sg)[am_tiles<DPAD>()][4]) {
   constexpr int T = am_tile_rows<DPAD>();
   constexpr int NTL = am_tiles<DPAD>();
   constexpr int W = 16 * T;
   __shared__ __attribute__((aligned(16))) double s_nat[2 * W];  // x, mu' by dimension
   __shared__ __attribute__((aligned(16))) double s_prm[2 * W];  // the same, dimension 16 ti + h + 4 r at 16 ti + 4 h + r
-  const int lane = threadIdx.x;
-  const int64_t c = blockIdx.x;
-  if (c >= a.N) return;
   const bool lj = lane < a.d;
   const bool lp = lane < DPAD;
   const int lc = lane & 15, hi = lane >> 4;
-
-  if (a.do_am) {
+  {
     double* __restrict__ sig = a.am_sigma + (size_t)c * NTL * 256;
-    double Sg[NTL][4], TM[NTL][4];  // Sigma and t mu mu^T of the current mean, element (16 ti + hi + 4 r, 16 tj + lc)
+    double TM[NTL][4];  // t mu mu^T of the current mean, element (16 ti + hi + 4 r, 16 tj + lc), like Sigma in Sg
 #pragma unroll
     for (int idx = 0; idx < NTL; ++idx)
 #pragma unroll
@@ -1391,6 +1388,17 @@ __global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
     for (int idx = 0; idx < NTL; ++idx)
 #pragma unroll
       for (int r = 0; r < 4; ++r) sig[(idx * 4 + r) * 64 + lane] = Sg[idx][r];
+  }
+}
+
+template <int DPAD>
+__global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
+  const int lane = threadIdx.x;
+  const int64_t c = blockIdx.x;
+  if (c >= a.N) return;
+  if (a.do_am) {
+    double Sg[am_tiles<DPAD>()][4];
+    adapt_am_chain<DPAD>(a, c, lane, Sg);
   }
   adapt_scaling(a, c, lane);
 }
@@ -1587,32 +1595,15 @@ __device__ __forceinline__ constexpr int up_tile(int p, int i) { return p * 4 - 
 
 __device__ __forceinline__ double lane_pick(double v, int src) { return __shfl(v, src); }
 
-// APPLY = false: the swap alone (multilevel drivers, whose increments come from the fused k_propose)
-template <int DPAD, bool APPLY = true>
-__global__ void __launch_bounds__(64, 2) k_chol_apply_blk(const CholArgs ca, const ApplyArgs ap) {
-  static_assert(DPAD == 64, "the blocked swap is written for four 16-column panels");
-  constexpr int NTL = am_tiles<DPAD>();
+// The factorisation and the increments from the tiles in G (upper tiles of Sigma for chains c < ca.N; padding chains and chains
+// whose Sigma is not positive definite take the factor in memory).  APPLY = false: the swap alone (multilevel drivers, whose
+// increments come from the fused k_propose).
+template <int DPAD, bool APPLY>
+__device__ __forceinline__ void chol_apply_tiles(const CholArgs& ca, const ApplyArgs& ap, const int64_t c, double (&G)[10][4]) {
   const int lane = threadIdx.x, lc = lane & 15, hi = lane >> 4;
-  const int64_t c = blockIdx.x;
-  double G[10][4];  // upper tiles of Sigma, then of U
   bool have = false;
   if (c < ca.N) {
-    const double* __restrict__ sig = ca.am_sigma + (size_t)c * NTL * 256;
     const int d = ca.d;
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-      for (int i = p; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * p + hi + 4 * r, col = 16 * i + lc;
-          // stored: the tiles on or below the diagonal, [tile(ti, tj)][r][lane] = Sigma[16 ti + hi + 4 r][16 tj + lc]; an upper
-          // tile is the transpose of its mirror image (Sigma is symmetric: bitwise, k_adapt computes x_i x_j = x_j x_i)
-          const int off = (p == i) ? ((p * (p + 1) / 2 + p) * 4 + r) * 64 + lane : am_sigma_offset(col, row);
-          double v = sig[off];
-          if (row >= d || col >= d) v = (row == col) ? 1.0 : 0.0;  // padded rows / columns: identity
-          G[up_tile(p, i)][r] = v;
-        }
     bool ok = true;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -1726,6 +1717,81 @@ __global__ void __launch_bounds__(64, 2) k_chol_apply_blk(const CholArgs ca, con
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) zf[kk] = zn[kk];
   }
+}
+
+template <int DPAD, bool APPLY = true>
+__global__ void __launch_bounds__(64, 2) k_chol_apply_blk(const CholArgs ca, const ApplyArgs ap) {
+  static_assert(DPAD == 64, "the blocked swap is written for four 16-column panels");
+  constexpr int NTL = am_tiles<DPAD>();
+  const int lane = threadIdx.x, lc = lane & 15, hi = lane >> 4;
+  const int64_t c = blockIdx.x;
+  double G[10][4];  // upper tiles of Sigma, then of U
+  if (c < ca.N) {
+    const double* __restrict__ sig = ca.am_sigma + (size_t)c * NTL * 256;
+    const int d = ca.d;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int i = p; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * p + hi + 4 * r, col = 16 * i + lc;
+          // stored: the tiles on or below the diagonal, [tile(ti, tj)][r][lane] = Sigma[16 ti + hi + 4 r][16 tj + lc]; an upper
+          // tile is the transpose of its mirror image (Sigma is symmetric: bitwise, k_adapt computes x_i x_j = x_j x_i)
+          const int off = (p == i) ? ((p * (p + 1) / 2 + p) * 4 + r) * 64 + lane : am_sigma_offset(col, row);
+          double v = sig[off];
+          if (row >= d || col >= d) v = (row == col) ? 1.0 : 0.0;  // padded rows / columns: identity
+          G[up_tile(p, i)][r] = v;
+        }
+  }
+  chol_apply_tiles<DPAD, APPLY>(ca, ap, c, G);
+}
+
+// Period boundary of the single-level AdaptiveMetropolis pipeline in ONE launch (round 4): the moment recursion over the block's
+// states, then C <- Sigma and the next block's increments from the tiles the recursion has just left in registers.  As two launches
+// (k_adapt, k_chol_apply_blk) Sigma went out to HBM (80 MiB at 4096 chains) and straight back in through a transposing gather (the
+// factorisation wants the upper tiles, k_adapt keeps the lower ones), with a kernel boundary in between.  Here the upper tiles are
+// formed by a 16 x 16 register transpose of their mirror images (ds_bpermute; Sigma is bitwise symmetric), and Sigma is stored
+// once, for the next period's recursion.  Same arithmetic, same results bit for bit (tests/test_gpu_switches.py).
+template <int DPAD>
+__global__ void __launch_bounds__(64, 2) k_adapt_chol_apply(const AdaptArgs a, const CholArgs ca, const ApplyArgs ap) {
+  static_assert(DPAD == 64, "the blocked swap is written for four 16-column panels");
+  const int lane = threadIdx.x, lc = lane & 15, hi = lane >> 4;
+  const int64_t c = blockIdx.x;
+  double G[10][4];
+  if (c < a.N) {
+    double Sg[am_tiles<DPAD>()][4];
+    adapt_am_chain<DPAD>(a, c, lane, Sg);
+    adapt_scaling(a, c, lane);
+    const int d = ca.d;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int i = p; i < 4; ++i) {
+        double t[4];
+        if (p == i) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t[r] = Sg[p * (p + 1) / 2 + p][r];
+        } else {
+          // upper tile (p, i) = transpose of the lower tile (i, p): element [hi + 4 r][lc] of the result is element [lc][hi + 4 r]
+          // of the source, which sits in lane ((lc & 3), hi + 4 r), register lc >> 2
+          const int idx = i * (i + 1) / 2 + p;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int src = (lc & 3) * 16 + hi + 4 * r;
+            const double t0 = __shfl(Sg[idx][0], src), t1 = __shfl(Sg[idx][1], src), t2 = __shfl(Sg[idx][2], src), t3 = __shfl(Sg[idx][3], src);
+            const int sr = lc >> 2;
+            t[r] = sr == 0 ? t0 : (sr == 1 ? t1 : (sr == 2 ? t2 : t3));
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * p + hi + 4 * r, col = 16 * i + lc;
+          G[up_tile(p, i)][r] = (row >= d || col >= d) ? ((row == col) ? 1.0 : 0.0) : t[r];  // padded rows / columns: identity
+        }
+      }
+  }
+  chol_apply_tiles<DPAD, true>(ca, ap, c, G);
 }
 
 }  // namespace tda

@@ -1,6 +1,6 @@
 """One seeded run of a configuration whose kernel choice an environment switch changes; records to an .npz.  The switches are
 read once per process, so A/B comparisons start this script twice (tests/test_gpu_switches.py).
-    python tools/switch_probe.py {mlda3|da2|aemd|aemd_lean|dream|am}[_ragged] out.npz     (_ragged: a chain count that is not a multiple of the 16-chain tile)"""
+    python tools/switch_probe.py {mlda3|da2|aemd|aemd_lean|aem_dense|aem_dense_da_pcn|dream|am}[_ragged] out.npz     (_ragged: a chain count that is not a multiple of the 16-chain tile)"""
 import os
 import sys
 
@@ -18,7 +18,10 @@ def hierarchy(ms, sl, kind, n_fine, N=256, d=64, error_model=None):
     base = rng.standard_normal((ms[-1], d)) / 8
     for k, m in enumerate(ms):
         A = base[:m] + (0.02 * (len(ms) - 1 - k) * rng.standard_normal((m, d)) / 8 if error_model else 0.0) if error_model else rng.standard_normal((m, d)) / 8
-        e.set_level(k, A, A @ truth + 0.1 * rng.standard_normal(m), 0, 0.01)
+        if error_model in ("state-independent", "state-dependent") and k < len(ms) - 1:  # dense error model: AdaptiveGaussianLogLike below the finest level
+            e.set_level(k, A, A @ truth + 0.1 * rng.standard_normal(m), 3, 0.01 * np.eye(m))
+        else:
+            e.set_level(k, A, A @ truth + 0.1 * rng.standard_normal(m), 0, 0.01)
     if kind == "am":
         e.set_proposal(2, 1e-4 * np.eye(d), t0=20, period=20)
     else:
@@ -75,6 +78,10 @@ if __name__ == "__main__":
         res = hierarchy((200, 200, 200), [5, 3], "am", 8, N=96 - cut, error_model="state-independent-diagonal")
     elif what == "aemd_lean":  # at most 128 outputs: the base subchains are eligible for k_da_steps
         res = hierarchy((128, 128, 128), [5, 3], "am", 8, N=96 - cut, error_model="state-independent-diagonal")
+    elif what == "aem_dense":  # dense error model, three levels: base subchains on k_aem_base_steps / k_ml_steps
+        res = hierarchy((100, 100, 100), [5, 3], "am", 8, N=96 - cut, error_model="state-independent")
+    elif what == "aem_dense_da_pcn":  # two levels, pCN (keep < 1 in the linear update), state-dependent model
+        res = hierarchy((40, 40), [4], "pcn", 12, N=64, error_model="state-dependent")
     elif what == "am":
         res = single_am(N=96 - cut)
     else:
