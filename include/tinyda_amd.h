@@ -31,12 +31,14 @@
  *   stream 1, block = level    : u = u53(x0,x1)                                       (accept uniform)
  *   stream 2, block b          : as stream 0, step = 0                                (theta0 ~ prior)
  *   stream 3, block 0, step = fine iteration : promoted index = (x0 * L) >> 32        (DA randomize_subchain_length)
- *   DREAM(Z) (proposal.py:811-852; round 3 layout, restated in tests/test_gpu_dreamz.py::_philox_dreamz_variates):
+ *   DREAM(Z) (proposal.py:811-852; round 4 layout, restated in tests/test_gpu_dreamz.py::_philox_dreamz_variates):
  *   stream 4, step field = step : block i < delta : archive rows r1 = (x0 M) >> 32, r2 = (x1 (M - 1)) >> 32, r2 += (r2 >= r1);
  *        block delta : crossover index by inverse cdf of u53(x0,x1) over pCR, forced index = (x2 dim) >> 32
- *   streams 5 / 6 / 7, block = delta + 1 + j, step field = step >> 2 : word w = step & 3 of ONE block serves four steps of parameter j:
- *        5: crossover uniform (x_w + 0.5) 2^-32;  6: e-uniform, the same map;  7: eps normals by single-precision Box-Muller,
- *        (x0, x1) -> steps 4Q, 4Q + 1 and (x2, x3) -> steps 4Q + 2, 4Q + 3 with u = ((x >> 8) + 0.5) 2^-24
+ *   stream 5, block = delta + 1 + j, step field = step : crossover uniform of parameter j = u53(x0,x1), e-uniform = u53(x2,x3)
+ *   stream 7, block = delta + 1 + j, step field = step >> 1 : eps normals of parameter j by the Box-Muller map of stream 0 in
+ *        double precision; z0 serves the even step 2Q, z1 the odd step 2Q + 1
+ *        (the reference draws both in double precision, proposal.py:846-847; round 3 used 32-bit uniforms and single-precision
+ *        normals for a < 5 % gain of one kernel and is gone: checkpoint blobs of that release are refused)
  *   For levels >= 1 the accept uniform of that level's step n is stream 1, block = level, step = n.
  *   "step" is the count of base-level proposals made so far on the chain (proposal.t in
  *   tinyDA/proposal.py:223,229).

@@ -58,7 +58,7 @@ def test_dreamz_replay(eng_mod, golden, name, block):
 
 def _philox_dreamz_variates(seed, N, T, d, delta, nCR, M0, pCR_fn, grow=True, chain_offset=0):
     """The oracle's restatement of the DREAM(Z) RNG contract (tda_kernels_dreamz.h, k_dreamz_draw): streams 4 (per chain and step:
-    row pairs, crossover index), 5 / 6 (per parameter, one block for four steps: crossover and e uniforms from single 32-bit words)."""
+    row pairs, crossover index), 5 (per parameter and step: crossover and e uniforms, 53 bits each)."""
     ps = orc.PhiloxStream(seed)
     chains = (np.arange(N) + chain_offset).astype(np.uint32)
     r = np.empty((N, T, delta, 2))
@@ -79,9 +79,8 @@ def _philox_dreamz_variates(seed, N, T, d, delta, nCR, M0, pCR_fn, grow=True, ch
         u_mcr[:, t] = orc.u53(x0, x1)
         forced[:, t] = (x2.astype(np.uint64) * np.uint64(d)) >> np.uint64(32)
         for j in range(d):
-            wm = ps.words(chains, np.uint32(t >> 2), np.uint32(5), np.uint32(delta + 1 + j))[t & 3]
-            we = ps.words(chains, np.uint32(t >> 2), np.uint32(6), np.uint32(delta + 1 + j))[t & 3]
-            sub_u[:, t, j], e_u[:, t, j] = (wm.astype(np.float64) + 0.5) / 4294967296.0, (we.astype(np.float64) + 0.5) / 4294967296.0
+            x0, x1, x2, x3 = ps.words(chains, np.uint32(t), np.uint32(5), np.uint32(delta + 1 + j))
+            sub_u[:, t, j], e_u[:, t, j] = orc.u53(x0, x1), orc.u53(x2, x3)
         u[:, t] = ps.uniform(chains, t)
     return dict(r=r, u_mcr=u_mcr, forced=forced, sub_u=sub_u, e_u=e_u, u=u)
 

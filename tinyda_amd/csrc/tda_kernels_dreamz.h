@@ -19,28 +19,21 @@ namespace tda {
 //   stream 4, step field = step, per chain and step:
 //     block i < delta : archive rows r1 = (x0*M)>>32, r2 = (x1*(M-1))>>32, r2 += r2>=r1
 //     block delta     : mCR by inverse cdf of u53(x0,x1) over pCR, forced index = (x2*d)>>32
-//   per parameter j, one block serves FOUR consecutive steps (step field = step >> 2, word = step & 3, block = delta + 1 + j):
-//     stream 5 : crossover uniform of step 4Q + w :  (x_w + 0.5) 2^-32  (a `u < CR` test against k / nCR does not need 53 bits)
-//     stream 6 : e-uniform of step 4Q + w, the same map
-//     stream 7 : eps normals by Box-Muller in single precision: (x0, x1) -> steps 4Q, 4Q + 1; (x2, x3) -> steps 4Q + 2, 4Q + 3, with
-//                u1 = ((x >> 8) + 0.5) 2^-24, r = sqrt(-2 ln u1), angle = 2 pi ((x' >> 8) + 0.5) 2^-24  (eps = b* z, b* = 1e-6: a
-//                jitter; the normals actually used are exported to the oracle like every normal of the engine)
-//   Three generator calls per parameter and FOUR steps where rounds 1-2 spent 1.5 calls and one double-precision Box-Muller pair
-//   per parameter and step: k_dreamz_draw was generator-bound at twice the cost of the step kernel it feeds.
+//   per parameter j (block = delta + 1 + j), in double precision as the reference draws them (proposal.py:846-847):
+//     stream 5, step field = step      : crossover uniform u53(x0, x1), e-uniform u53(x2, x3)
+//     stream 7, step field = step >> 1 : eps normals, the Box-Muller map of the proposal normals (tda_philox.h normal_pair); z0 for
+//                the even step, z1 for the odd one (the normals actually used are exported to the oracle like every normal of the engine)
+//   1.5 generator calls per parameter and step.  Round 3 cut this to 0.75 with 32-bit uniforms and single-precision normals and
+//   gained < 5 % (the kernel is bound by the per-chain post-processing, not by the generator): not worth narrower variates than
+//   the reference's.
 // ------------------------------------------------------------------------------------------------
 enum : uint32_t { STREAM_DREAM = 4, STREAM_DREAM_MASK = 5, STREAM_DREAM_E = 6, STREAM_DREAM_EPS = 7 };
 
-__device__ __forceinline__ double u32_uniform(uint32_t x) { return ((double)x + 0.5) * (1.0 / 4294967296.0); }
-
-// two standard normals from two 32-bit words, single precision (the DREAM(Z) eps jitter only)
-__device__ __forceinline__ void normal_pair_f32(uint32_t xa, uint32_t xb, float& z0, float& z1) {
-  const float u1 = ((float)(xa >> 8) + 0.5f) * (1.0f / 16777216.0f);
-  const float u2 = ((float)(xb >> 8) + 0.5f) * (1.0f / 16777216.0f);
-  const float r = __builtin_sqrtf(-2.0f * __logf(u1));
-  float sn, cs;
-  __sincosf(6.283185307179586f * u2, &sn, &cs);
-  z0 = r * cs;
-  z1 = r * sn;
+// out of line: the polynomial constants of log / sincospi inlined into the unrolled group loop push k_dreamz_draw past its 128 registers
+__device__ __attribute__((noinline)) double2 dz_normal_pair_call(uint64_t seed, uint32_t chain, uint32_t step2, uint32_t block) {
+  double z0, z1;
+  normal_pair(seed, chain, step2, STREAM_DREAM_EPS, block, z0, z1);
+  return double2{z0, z1};
 }
 constexpr int MAX_NCR = 8;
 constexpr int MAX_DELTA = 4;
@@ -129,8 +122,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
   const double gam_tab = scaling * 2.38 / sqrt((double)(2 * a.delta * (lane + 1)));
   const bool philox_normals = a.sub_rep == nullptr;  // wave-uniform
   // per-parameter variates: one block each for the crossover uniforms, the e-uniforms and the eps normals of FOUR steps
-  u32x4 q_mask{0u, 0u, 0u, 0u}, q_e{0u, 0u, 0u, 0u};
-  float q_z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  double2 q_z{0.0, 0.0};  // eps normals of the step pair in progress
   constexpr int GS = DPAD < 4 ? DPAD : 4;  // steps per group: their archive rows are requested together, one group ahead
   // The per-chain scalars of a step -- delta row pairs, the crossover draw, the accept uniform: delta + 2 <= 6 Philox blocks and
   // their post-processing (53-bit uniforms, the inverse cdf, two 64-bit products per row pair) -- are worked out ONCE per chain
@@ -254,13 +246,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
           const int mcr = cur.mf[q] & 255, forced = cur.mf[q] >> 8;
           const double CR = s_CR[mcr];  // (mcr + 1) / nCR
           // ---- per-parameter draws ----
-          if (philox_normals && (s == 0 || (step & 3u) == 0u)) {
-            const uint32_t blk = (uint32_t)(a.delta + 1 + lane), quad = step >> 2;
-            q_mask = philox4x32_10(u32x4{blk, quad, gc, STREAM_DREAM_MASK}, k0, k1);
-            q_e = philox4x32_10(u32x4{blk, quad, gc, STREAM_DREAM_E}, k0, k1);
-            const u32x4 zz = philox4x32_10(u32x4{blk, quad, gc, STREAM_DREAM_EPS}, k0, k1);
-            normal_pair_f32(zz.x, zz.y, q_z[0], q_z[1]);
-            normal_pair_f32(zz.z, zz.w, q_z[2], q_z[3]);
+          u32x4 q_u{0u, 0u, 0u, 0u};
+          if (philox_normals) {
+            const uint32_t blk = (uint32_t)(a.delta + 1 + lane);
+            q_u = philox4x32_10(u32x4{blk, step, gc, STREAM_DREAM_MASK}, k0, k1);
+            if (s == 0 || (step & 1u) == 0u) q_z = dz_normal_pair_call(a.seed, gc, step >> 1, blk);
           }
           double su = 2.0, eu = 0.5, en = 0.0;
           if (lj) {
@@ -271,10 +261,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
                 en = a.eps_rep[row * a.d + lane];
               }
             } else {
-              const uint32_t w = step & 3u;  // wave-uniform
-              su = u32_uniform(w == 0 ? q_mask.x : w == 1 ? q_mask.y : w == 2 ? q_mask.z : q_mask.w);
-              eu = u32_uniform(w == 0 ? q_e.x : w == 1 ? q_e.y : w == 2 ? q_e.z : q_e.w);
-              en = (double)(w == 0 ? q_z[0] : w == 1 ? q_z[1] : w == 2 ? q_z[2] : q_z[3]);
+              su = u53(q_u.x, q_u.y);
+              eu = u53(q_u.z, q_u.w);
+              en = (step & 1u) ? q_z.y : q_z.x;
             }
             if (a.eps_export && real_chain) a.eps_export[row * a.d + lane] = en;
           }
