@@ -112,11 +112,11 @@ def test_bench_launches_its_own_ranks():
 
 
 def test_scale_script_rehearsal_on_one_gpu(tmp_path):
-    """tools/r03_scale.sh -- the one command for an 8-GPU node (bench at 1/2/4/8 ranks, config 4 in the four archive modes, the peer
+    """tools/r04_scale.sh -- the one command for an 8-GPU node (bench at 1/2/4/8 ranks, config 4 in the four archive modes, the peer
     archive check) -- rehearsed with two ranks on this one GPU over gloo: every stage runs, every line carries its rank count."""
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         os.environ.pop(k, None)
-    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "r03_scale.sh"), str(tmp_path)], cwd=ROOT, env=dict(os.environ, REHEARSE="1"),
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "r04_scale.sh"), str(tmp_path)], cwd=ROOT, env=dict(os.environ, REHEARSE="1"),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-4000:]
     rep = json.load(open(tmp_path / "summary.json"))
@@ -129,6 +129,9 @@ def test_scale_script_rehearsal_on_one_gpu(tmp_path):
         assert c["ran_as"].startswith(c["mode"].split("-")[0]) and c["note"] is None  # IPC mapping works between processes on one GPU
         assert c["archive_rows_rank0"] == 320 + (64 + 48) * 512 * c["n_gpus"]  # every chain's state of every step, whoever stores it
     assert rep["peer_archive_check"] and rep["peer_archive_check"][0]["world"] == 2
+    # round 4: the other configurations per rank count (tools/configs_scale.py; rehearsal sizes)
+    assert [(c["tag"], c["n_gpus"]) for c in rep["configs"]] == [("C3", 1), ("C5+AEM", 1), ("C3", 2), ("C5+AEM", 2)]
+    assert all(c["evals_per_s"] > 0 and len(c["per_rank_evals_per_s"]) == c["n_gpus"] and c["efficiency"] > 0 for c in rep["configs"])
 
 
 def _small_engine(eng_mod, N=32, d=8, m=16, n_levels=1):

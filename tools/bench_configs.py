@@ -35,10 +35,16 @@ def _torch():
     return torch
 
 
+PLACE = {"device": 0, "rank": 0}  # tools/configs_scale.py: one process per GPU, chains keyed by global id (rank * chains + local)
+
+
 def _engine():
     from tinyda_amd.engine import Engine
 
-    return Engine
+    def make(n_chains, dim, **kw):
+        return Engine(n_chains, dim, device=PLACE["device"], chain_offset=PLACE["rank"] * n_chains, **kw)
+
+    return make
 
 
 def levels(ms, d=64, seed=2, sigma=0.1):
@@ -74,8 +80,8 @@ def _timed(fn):
 
 def _level_buffers(rows, N, d):
     torch = _torch()
-    return [(torch.empty((r, N, d), dtype=torch.float64, device="cuda"), torch.empty((r, N, 3), dtype=torch.float64, device="cuda"),
-             torch.empty((r, N), dtype=torch.uint8, device="cuda")) for r in rows]
+    return [(torch.empty((r, N, d), dtype=torch.float64, device="cuda:%d" % PLACE["device"]), torch.empty((r, N, 3), dtype=torch.float64, device="cuda:%d" % PLACE["device"]),
+             torch.empty((r, N), dtype=torch.uint8, device="cuda:%d" % PLACE["device"])) for r in rows]
 
 
 def run_hierarchy(name, ms, sl, prop, n_fine, per_eval, kernel, N=4096, d=64):
@@ -168,9 +174,9 @@ def run_mala(N=4096, d=64, m=1024, T=2000):
         e.set_level(0, A, y, 0, 0.01)
         e.set_proposal(**prop)
         e.init(None)
-        p = torch.empty((T, N, d), dtype=torch.float64, device="cuda")
-        s = torch.empty((T, N, 3), dtype=torch.float64, device="cuda")
-        a = torch.empty((T, N), dtype=torch.uint8, device="cuda")
+        p = torch.empty((T, N, d), dtype=torch.float64, device="cuda:%d" % PLACE["device"])
+        s = torch.empty((T, N, 3), dtype=torch.float64, device="cuda:%d" % PLACE["device"])
+        a = torch.empty((T, N), dtype=torch.uint8, device="cuda:%d" % PLACE["device"])
         e.run(200, p[:200], s[:200], a[:200])
         e.set_profiling(True)
         torch.cuda.synchronize()
@@ -201,9 +207,9 @@ def run_c2b(N=4096, d=64, m=1024, T=300):
     e.set_level(0, A, y, 2, Lc @ Lc.T)
     e.set_proposal(2, 1e-4 * np.eye(d), t0=100, period=100)
     e.init(None)
-    p = torch.empty((T, N, d), dtype=torch.float64, device="cuda")
-    s = torch.empty((T, N, 3), dtype=torch.float64, device="cuda")
-    a = torch.empty((T, N), dtype=torch.uint8, device="cuda")
+    p = torch.empty((T, N, d), dtype=torch.float64, device="cuda:%d" % PLACE["device"])
+    s = torch.empty((T, N, 3), dtype=torch.float64, device="cuda:%d" % PLACE["device"])
+    a = torch.empty((T, N), dtype=torch.uint8, device="cuda:%d" % PLACE["device"])
     e.run(100, p[:100], s[:100], a[:100])
     dt = _timed(lambda: e.run(T, p, s, a))
     e.set_profiling(True)
@@ -230,9 +236,9 @@ def run_c4(N=8192, d=32, T=400, M0=320, K=16, peer=False, lag=False):
     e.set_proposal_dreamz(M0, delta=1, nCR=3, adaptive=True, period=100, shared=True, sync_every=K, capacity=M0 + (T + 50) * N)
     e.set_archive(None)
     e.init(None)
-    params = torch.empty((T, N, d), dtype=torch.float64, device="cuda")
-    stats = torch.empty((T, N, 3), dtype=torch.float64, device="cuda")
-    acc = torch.empty((T, N), dtype=torch.uint8, device="cuda")
+    params = torch.empty((T, N, d), dtype=torch.float64, device="cuda:%d" % PLACE["device"])
+    stats = torch.empty((T, N, 3), dtype=torch.float64, device="cuda:%d" % PLACE["device"])
+    acc = torch.empty((T, N), dtype=torch.uint8, device="cuda:%d" % PLACE["device"])
     if peer:  # the distributed archive's block-wise publish protocol with the one rank a box has (what it costs on the host side)
         tdist.setup_peer_archive(e)
         tdist.run_peer_dream(e, 48, K, params, stats, acc, period=100, lag=lag)
