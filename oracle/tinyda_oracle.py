@@ -170,6 +170,13 @@ def classify_covariance(cov):
     return "dense"
 
 
+def noise_of(cov):
+    """(kind, noise) arguments of make_loglike for a covariance matrix, as the factory classifies it (distributions.py:237-243)"""
+    cov = np.asarray(cov, dtype=float)
+    kind = classify_covariance(cov)
+    return kind, (float(cov[0, 0]) if kind == "iso" else (np.diag(cov).copy() if kind == "diag" else cov))
+
+
 class AdaptiveLogLike:
     """AdaptiveGaussianLogLike (distributions.py:332-449), one instance per chain batch entry."""
 

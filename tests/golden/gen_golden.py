@@ -437,12 +437,28 @@ def _place(consumed, evaluated):
     return arr
 
 
+def _level_covs(seed, ms, sigma, noise):
+    """observation covariance per level: noise[k] in 'iso' | 'diag' | 'dense' (the dense ones as g2_am builds them)"""
+    rng = np.random.default_rng(seed + 31)
+    covs = []
+    for m, kind in zip(ms, noise):
+        if kind == "iso":
+            covs.append(sigma ** 2 * np.eye(m))
+        elif kind == "diag":
+            covs.append(np.diag(sigma ** 2 * (0.5 + rng.random(m))))
+        else:
+            Lc = sigma * np.eye(m) + 0.02 * np.tril(rng.standard_normal((m, m)))
+            covs.append(Lc @ Lc.T)
+    return covs
+
+
 def g4_da(name, proposal_kind, d=6, ms=(10, 24), L=4, iters=60, n_chains=4, seed=401, randomize=False,
-          adaptive=False, period=7, prior_kind="identity"):
+          adaptive=False, period=7, prior_kind="identity", noise=None):
     sigma = 0.2
     As, ys, theta_true, pm, pc = _ml_problem(seed, d, ms, sigma, prior_kind)
     prior = stats.multivariate_normal(pm, pc)
-    posts = [tda.Posterior(prior, tda.GaussianLogLike(y, sigma ** 2 * np.eye(len(y))), make_model(A)) for A, y in zip(As, ys)]
+    covs = _level_covs(seed, ms, sigma, noise or ["iso"] * len(ms))
+    posts = [tda.Posterior(prior, tda.GaussianLogLike(y, cv), make_model(A)) for A, y, cv in zip(As, ys, covs)]
     rng = np.random.default_rng(seed + 1)
     theta0 = theta_true[None] + 0.2 * rng.standard_normal((n_chains, d))
     if proposal_kind == "pcn":
@@ -480,16 +496,18 @@ def g4_da(name, proposal_kind, d=6, ms=(10, 24), L=4, iters=60, n_chains=4, seed
     flat = {}
     for k, v in pcfg.items():
         flat["prop_" + k] = np.array(v)
+    extra = {"cov%d" % k: cv for k, cv in enumerate(covs)} if noise else {}
     save(name, A0=As[0], A1=As[1], y0=ys[0], y1=ys[1], noise_var=np.array(sigma ** 2), prior_mean=pm, prior_cov=pc,
-         theta0=theta0, subchain_length=np.array(L), randomize=np.array(randomize), **flat, **arrays)
+         theta0=theta0, subchain_length=np.array(L), randomize=np.array(randomize), **extra, **flat, **arrays)
 
 
 def g5_mlda(name, proposal_kind, d=6, ms=(8, 14, 24), sl=(3, 2), iters=40, n_chains=4, seed=501, adaptive=False,
-            period=7):
+            period=7, noise=None):
     sigma = 0.2
     As, ys, theta_true, pm, pc = _ml_problem(seed, d, ms, sigma)
     prior = stats.multivariate_normal(pm, pc)
-    posts = [tda.Posterior(prior, tda.GaussianLogLike(y, sigma ** 2 * np.eye(len(y))), make_model(A)) for A, y in zip(As, ys)]
+    covs = _level_covs(seed, ms, sigma, noise or ["iso"] * len(ms))
+    posts = [tda.Posterior(prior, tda.GaussianLogLike(y, cv), make_model(A)) for A, y, cv in zip(As, ys, covs)]
     rng = np.random.default_rng(seed + 1)
     theta0 = theta_true[None] + 0.2 * rng.standard_normal((n_chains, d))
     if proposal_kind == "grw":
@@ -541,6 +559,8 @@ def g5_mlda(name, proposal_kind, d=6, ms=(8, 14, 24), sl=(3, 2), iters=40, n_cha
     for k in range(nl):
         lv["A%d" % k] = As[k]
         lv["y%d" % k] = ys[k]
+        if noise:
+            lv["cov%d" % k] = covs[k]
     save(name, noise_var=np.array(sigma ** 2), prior_mean=pm, prior_cov=pc, theta0=theta0,
          subchain_lengths=np.array(sl), n_levels=np.array(nl), **lv, **flat, **arrays)
 
@@ -991,6 +1011,11 @@ FIXTURES = {
     "g4_da_am_random": lambda: g4_da("g4_da_am_random", "am", randomize=True, period=10, seed=403, prior_kind="general"),
     "g4_da_pcn_adaptive_c3shape": lambda: g4_da("g4_da_pcn_adaptive_c3shape", "pcn", d=16, ms=(32, 96), L=10, iters=30,
                                                 adaptive=True, period=25, seed=404),
+    # dense observation covariances inside a hierarchy (DefaultGaussianLogLike at the fine level / at every level; round 4)
+    "g4_da_pcn_dense_fine": lambda: g4_da("g4_da_pcn_dense_fine", "pcn", seed=405, noise=["iso", "dense"]),
+    "g4_da_am_dense_both": lambda: g4_da("g4_da_am_dense_both", "am", d=9, ms=(20, 40), L=3, iters=40, period=10, seed=406,
+                                         prior_kind="general", noise=["dense", "dense"]),
+    "g5_mlda_am_dense": lambda: g5_mlda("g5_mlda_am_dense", "am", period=10, seed=504, noise=["diag", "dense", "dense"]),
     "g6_dreamz_linear": lambda: g6_dreamz("g6_dreamz_linear", "linear", d=6, M0=20, delta=1, nCR=3, adaptive=False, period=25,
                                           iters=150, n_chains=4, seed=601),
     "g6_dreamz_rosen_adaptive": lambda: g6_dreamz("g6_dreamz_rosen_adaptive", "rosenbrock", d=4, M0=30, delta=2, nCR=3,

@@ -235,3 +235,31 @@ def test_sample_end_to_end_rate_at_config2_size():
     assert out["first_call_overhead_seconds"] < 2.0, out
     assert out["evals_per_s_end_to_end"] >= 1.5e8, out
     assert out["proposal_state_C_shape"] == [4096, 64, 64]
+
+
+def test_sample_hierarchy_with_dense_observation_covariance(eng_mod):
+    """tda.sample over a Delayed-Acceptance hierarchy whose fine level has a DENSE observation covariance (DefaultGaussianLogLike,
+    distributions.py:246-301): lowered to the device since 0.4 (round 3 ran the host protocol, silently)"""
+    import warnings
+
+    import tinyda_amd as tda
+
+    rng = np.random.default_rng(5)
+    d, m0, m1 = 6, 12, 30
+    A0, A1 = rng.standard_normal((m0, d)) / 3, rng.standard_normal((m1, d)) / 3
+    truth = rng.standard_normal(d)
+    Lc = 0.2 * np.eye(m1) + 0.02 * np.tril(rng.standard_normal((m1, m1)))
+    prior = st.multivariate_normal(np.zeros(d), np.eye(d))
+    posts = [tda.Posterior(prior, tda.GaussianLogLike(A0 @ truth, 0.04 * np.eye(m0)), tda.LinearModel(A0)),
+             tda.Posterior(prior, tda.GaussianLogLike(A1 @ truth, Lc @ Lc.T), tda.LinearModel(A1))]
+    assert type(posts[1].likelihood).__name__ == "DefaultGaussianLogLike"
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", tda.HostFallbackWarning)
+        res = tda.sample(posts, tda.CrankNicolson(scaling=0.2), 40, n_chains=24, subchain_length=3, seed=3)
+    assert res["sampler"] == "DA" and res["backend"] == "hip"
+    for i in (0, 11, 23):
+        link = res["chain_fine_%d" % i][-1]
+        ref = posts[1].create_link(link.parameters)
+        np.testing.assert_allclose([link.prior, link.likelihood], [ref.prior, ref.likelihood], rtol=1e-10)
+    acc = np.mean([np.mean(res["chain_fine_%d" % i].accepted[1:]) for i in range(24)])
+    assert 0.02 < acc < 0.98

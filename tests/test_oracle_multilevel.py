@@ -19,6 +19,8 @@ def _prop(g):
 
 def _levels(g, n):
     prior = orc.MVNPrior(g["prior_mean"], g["prior_cov"])
+    if "cov0" in g.files:  # per-level covariances (dense / diagonal / isotropic): what GaussianLogLike's factory makes of each
+        return [orc.LinearGaussianLevel(g["A%d" % k], g["y%d" % k], *orc.noise_of(g["cov%d" % k]), prior) for k in range(n)]
     return [orc.LinearGaussianLevel(g["A%d" % k], g["y%d" % k], "iso", float(g["noise_var"]), prior) for k in range(n)]
 
 
@@ -29,7 +31,8 @@ def _check_level(res, g, k, finest):
     np.testing.assert_allclose(res["theta"], g["th%d" % k], rtol=1e-9, atol=1e-11)
 
 
-@pytest.mark.parametrize("name", ["g4_da_pcn", "g4_da_grw_adaptive", "g4_da_am_random", "g4_da_pcn_adaptive_c3shape"])
+@pytest.mark.parametrize("name", ["g4_da_pcn", "g4_da_grw_adaptive", "g4_da_am_random", "g4_da_pcn_adaptive_c3shape",
+                                  "g4_da_pcn_dense_fine", "g4_da_am_dense_both"])
 def test_delayed_acceptance(golden, name):
     g = golden(name)
     L = int(g["subchain_length"])
@@ -41,7 +44,7 @@ def test_delayed_acceptance(golden, name):
     np.testing.assert_allclose(prop.scaling, g["scaling"], rtol=1e-12)
 
 
-@pytest.mark.parametrize("name", ["g5_mlda_am", "g5_mlda_grw_adaptive", "g5_mlda_4level"])
+@pytest.mark.parametrize("name", ["g5_mlda_am", "g5_mlda_grw_adaptive", "g5_mlda_4level", "g5_mlda_am_dense"])
 def test_mlda(golden, name):
     g = golden(name)
     nl = int(g["n_levels"])

@@ -290,6 +290,30 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
       lp_n = -0.5 * (a.pr.logconst + maha);
       return;
     }
+    if (L.noise_kind == 2) {
+      // dense observation covariance (DefaultGaussianLogLike, distributions.py:246-301) at any level of the hierarchy (round 4):
+      // residual tile to LDS, then r^T Sigma^-1 r for the tile's 16 chains on the matrix cores, as the single-level kernel does
+      const int RSd = L.m_pad + 2;
+      if constexpr (PAIRS) (void)level_sse_partial<DPAD, 2>(L.Apk, L.ncb, s_stage + a.lds_y[k], s_R + lc * RSd, th, wave, lane, g0, g1);
+      else (void)level_sse_single<DPAD, 2, NW>(L.Apk, L.ncb, s_stage + a.lds_y[k], s_R + lc * RSd, th, wave, lane, g0);
+      __syncthreads();
+      double qs = dense_quadform<NW>(L.Ppk, L.ncb, L.m_pad, s_R, RSd, wave, lane);
+      qs = sum_rows(qs);
+      if (lane < 16) s_red[wave * 16 + lane] = qs;
+      __syncthreads();
+      double tot = s_red[lc];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) tot += s_red[w * 16 + lc];
+      if (prior_dense) {
+        maha = s_redp[lc];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) maha += s_redp[w * 16 + lc];
+      }
+      ll_n = -0.5 * tot;
+      lp_n = -0.5 * (a.pr.logconst + maha);
+      __syncthreads();  // s_red / the residual tile are free again
+      return;
+    }
     double sse;
     if constexpr (PAIRS) {
       sse = dg ? level_sse_partial<DPAD, 1>(L.Apk, L.ncb, s_stage + a.lds_y[k], s_stage + a.lds_w[k], th, wave, lane, g0, g1)
