@@ -37,18 +37,20 @@ def _mk_engine(eng_mod, g, n_chains, d, kind, **kw):
     return e
 
 
-def _compare_with_golden(params, stats, acc, th0_stats, g):
+def _compare_with_golden(params, stats, acc, th0_stats, g, tight=True):
     # engine records are [T, N, .]; golden traces are [N, T+1, .] with the initial link first
     acc_ref = np.swapaxes(g["accepted"][:, 1:], 0, 1)
     assert np.array_equal(acc, acc_ref), "accept masks differ: %d flips" % int((acc != acc_ref).sum())
     np.testing.assert_allclose(th0_stats[:, 2], g["logpost"][:, 0], rtol=RTOL)
     np.testing.assert_allclose(stats[:, :, 2], np.swapaxes(g["logpost"][:, 1:], 0, 1), rtol=RTOL)
-    # the stated bar is on the log-posterior; its two summands are checked a decade looser because the
-    # small AM fixtures swap in a nearly singular C (16 samples in 8 dims) whose factorisation amplifies
-    # last-bit differences between LAPACK and the in-LDS Cholesky.
-    np.testing.assert_allclose(stats[:, :, 1], np.swapaxes(g["loglike"][:, 1:], 0, 1), rtol=1e-9)
-    np.testing.assert_allclose(stats[:, :, 0], np.swapaxes(g["logprior"][:, 1:], 0, 1), rtol=1e-9, atol=1e-12)
-    np.testing.assert_allclose(params, np.swapaxes(g["theta"][:, 1:], 0, 1), rtol=1e-9, atol=1e-11)
+    # the stated bar is on the log-posterior; its two summands and the states are held to the same 1e-10 wherever the proposal
+    # covariance is well conditioned (`tight`: g1, g2_am_c2, g2b -- VERDICT r3 item 9) and a decade looser only for the small AM
+    # fixtures, which swap in a nearly singular C (16 samples in 8 dims) whose factorisation amplifies last-bit differences
+    # between LAPACK and the device's Cholesky.
+    tol = 1e-10 if tight else 1e-9
+    np.testing.assert_allclose(stats[:, :, 1], np.swapaxes(g["loglike"][:, 1:], 0, 1), rtol=tol)
+    np.testing.assert_allclose(stats[:, :, 0], np.swapaxes(g["logprior"][:, 1:], 0, 1), rtol=tol, atol=1e-12)
+    np.testing.assert_allclose(params, np.swapaxes(g["theta"][:, 1:], 0, 1), rtol=tol, atol=1e-11)  # (parameters near zero: an absolute floor)
 
 
 def test_device_rng_matches_contract(eng_mod):
@@ -143,7 +145,7 @@ def test_golden_g2_am_replay(eng_mod, golden, name, block):
     e.set_replay(np.swapaxes(g["z"], 0, 1), np.swapaxes(g["u"], 0, 1))
     _, st0 = e.current()
     params, stats, acc = e.run_host(T1 - 1)
-    _compare_with_golden(params, stats, acc, st0, g)
+    _compare_with_golden(params, stats, acc, st0, g, tight=(name == "g2_am_c2"))
     ps = e.proposal_state(want_am=True)
     assert not e.flags().any()
     np.testing.assert_allclose(ps["am_mu"], g["mu_hist"][:, -1], rtol=1e-9)
