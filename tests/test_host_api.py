@@ -297,3 +297,39 @@ def test_host_hierarchy_fallback_runs_the_references_mlda_notebook_shape():
     res2 = tda.sample(two, tda.CrankNicolson(scaling=0.2), 10, n_chains=1, subchain_length=3, adaptive_error_model="state-dependent",
                       store_coarse_chain=False, backend="host")
     assert res2["sampler"] == "DA" and res2["chain_coarse_0"] is None and len(res2["chain_fine_0"]) == 11
+
+
+def test_record_buffers_fall_back_when_the_device_is_full(monkeypatch):
+    """device records that do not fit: the library's buffer pool is handed back, torch's cache emptied, then page-locked host memory
+     -- driven here with a stand-in allocator, no GPU"""
+    import types
+    import warnings
+
+    from tinyda_amd import api
+
+    calls, released = [], []
+
+    class OOM(RuntimeError):
+        pass
+
+    def empty(shape, dtype=None, device=None, pin_memory=False):
+        calls.append((tuple(shape), device, pin_memory))
+        if device != "cpu" and len([c for c in calls if c[1] != "cpu"]) <= fail_first:
+            raise OOM("out of memory")
+        return ("buf", tuple(shape), device, pin_memory)
+
+    fake = types.SimpleNamespace(empty=empty, cuda=types.SimpleNamespace(OutOfMemoryError=OOM, empty_cache=lambda: released.append("cache")))
+    monkeypatch.setattr(api, "release_cached_memory", lambda: released.append("pool") or 0)
+    shapes = [((5, 4, 3), "f64"), ((5, 4), "u8")]
+    fail_first = 0
+    assert [b[2] for b in api._record_buffers(fake, "cuda:0", shapes)] == ["cuda:0", "cuda:0"] and not released
+    calls.clear()
+    fail_first = 1  # the first device allocation fails, the retry after the release succeeds
+    assert [b[2] for b in api._record_buffers(fake, "cuda:0", shapes)] == ["cuda:0", "cuda:0"] and released == ["pool", "cache"]
+    calls.clear()
+    del released[:]
+    fail_first = 10 ** 6
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        bufs = api._record_buffers(fake, "cuda:0", shapes)
+    assert [(b[2], b[3]) for b in bufs] == [("cpu", True), ("cpu", True)] and any(issubclass(x.category, ResourceWarning) for x in w)

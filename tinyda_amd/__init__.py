@@ -24,5 +24,5 @@ from .proposals import (  # noqa: F401
     DREAM, DREAMZ, MALA, AdaptiveMetropolis, CrankNicolson, GaussianRandomWalk, IndependenceSampler,
     OperatorWeightedCrankNicolson, Proposal)
 from .records import DeviceChain  # noqa: F401
-from .api import HostFallbackWarning, sample  # noqa: F401
+from .api import HostFallbackWarning, release_cached_memory, sample  # noqa: F401
 from .moments import RecursiveSampleMoments, ZeroMeanRecursiveSampleMoments  # noqa: F401

@@ -385,6 +385,34 @@ def _sample_host_multilevel(posteriors, proposal, iterations, n_chains, initial_
     return result
 
 
+def release_cached_memory():
+    """Hand the engine library's parked device buffers back to the driver (include/tinyda_amd.h: tda_release_cached_memory; the pool
+    lives outside torch's caching allocator, up to TINYDA_POOL_GB).  Returns the bytes released."""
+    return int(_lib.load().tda_release_cached_memory())
+
+
+def _record_buffers(torch, tdev, shapes):
+    """Record arrays for a device run, in HBM when they fit: [(shape, dtype)] -> tensors.  When the allocation fails, first the engine
+    library's own buffer pool is handed back (it sits outside torch's allocator), then torch's cache is emptied, and as the last
+    resort the records go to page-locked host memory -- the engine writes there just as well (copies on a second stream), and the
+    lazy views of the result work on either (a long MLDA run with coarse chains stored used to fail where the host-record
+    path of earlier releases worked)."""
+    def alloc(dev, pin=False):
+        return [torch.empty(tuple(int(v) for v in shp), dtype=dt, device=dev, pin_memory=pin) for shp, dt in shapes]
+
+    try:
+        return alloc(tdev)
+    except torch.cuda.OutOfMemoryError:
+        release_cached_memory()
+        torch.cuda.empty_cache()
+    try:
+        return alloc(tdev)
+    except torch.cuda.OutOfMemoryError:
+        warnings.warn("tinyda_amd.sample: the sample records do not fit into device memory next to what is resident; keeping them in "
+                      "page-locked host memory (slower: every record crosses PCIe)", ResourceWarning, stacklevel=3)
+        return alloc("cpu", pin=True)
+
+
 class LazyProposalState(Mapping):
     """result['proposal_state'] of a device run: the final state of the proposal (scaling, covariance C, AdaptiveMetropolis
     moments, counters) -- read from the device when first indexed.  The engine hands its proposal buffers over without a copy
@@ -501,9 +529,8 @@ def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, se
         R = T // thin  # records the run produces (the engine starts at t = 0)
         # the history stays in HBM (BASELINE config 2, T = 2000: 4.4 GB of 288): nothing crosses PCIe unless somebody asks
         with torch.cuda.device(tdev):
-            params = torch.empty((R + 1, N, d), dtype=torch.float64, device=tdev)
-            stat = torch.empty((R + 1, N, 3), dtype=torch.float64, device=tdev)
-            acc = torch.empty((R + 1, N), dtype=torch.uint8, device=tdev)
+            params, stat, acc = _record_buffers(torch, tdev, [((R + 1, N, d), torch.float64), ((R + 1, N, 3), torch.float64),
+                                                                ((R + 1, N), torch.uint8)])
             acc[0] = 1
         eng.current_into(params[0], stat[0])
         shared_dz = prop["kind"] == _lib.PROP_DREAMZ and prop.get("shared")
@@ -595,10 +622,10 @@ def _sample_device_multilevel(plan, posteriors, iterations, n_chains, initial_pa
                     outs.append(None)
                     continue
                 extra = 1 if k == nl - 1 else 0  # only the finest chain carries the initial link
-                acc_k = torch.empty((rows[k] + extra, N), dtype=torch.uint8, device=tdev)
+                p_k, s_k, acc_k = _record_buffers(torch, tdev, [((rows[k] + extra, N, d), torch.float64), ((rows[k] + extra, N, 3), torch.float64),
+                                                                  ((rows[k] + extra, N), torch.uint8)])
                 acc_k[:extra] = 1
-                outs.append((torch.empty((rows[k] + extra, N, d), dtype=torch.float64, device=tdev),
-                             torch.empty((rows[k] + extra, N, 3), dtype=torch.float64, device=tdev), acc_k))
+                outs.append((p_k, s_k, acc_k))
         pf, sf, af = outs[nl - 1]
         eng.level_state_into(nl - 1, pf[0], sf[0])
         run_outs = [o if (o is None or k < nl - 1) else (o[0][1:], o[1][1:], o[2][1:]) for k, o in enumerate(outs)]

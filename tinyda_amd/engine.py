@@ -292,6 +292,7 @@ class Engine:
     def set_state(self, blob):
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         self._ck(self.lib.tda_engine_set_state(self.h, _ptr(blob), blob.size))
+        self._t_py = None  # the step counter came out of the blob: ask the engine once
 
     def counters(self):
         """(t, k): adapt() calls so far = steps taken (proposal.py:228, :509) and the diminishing-adaptation counter, from the engine"""
@@ -315,6 +316,7 @@ class Engine:
             theta0 = _f64(theta0)
             assert theta0.shape == (self.n_chains, self.dim)
         self._check_run(self.lib.tda_engine_init(self.h, _ptr(theta0)))
+        self._t_py = 0  # single-level step counter kept on this side: run(sync=False) must not ask the engine (that synchronises)
 
     # -- variates -----------------------------------------------------------------------
     def set_replay(self, z, u):
@@ -366,10 +368,14 @@ class Engine:
         need = int(n_iterations)
         thin = getattr(self, "_thin", 1)
         if thin > 1 and not (params is None and stats is None and accepted is None):
-            t = self.counters()[0]
+            if getattr(self, "_t_py", None) is None:
+                self._t_py = self.counters()[0]
+            t = self._t_py
             need = (t + need) // thin - t // thin  # records that reach the caller (include/tinyda_amd.h, record thinning)
         out = self._outputs(0, need, params, stats, accepted)
         self._check_run(self.lib.tda_engine_run(self.h, n_iterations, C.byref(out)))
+        if getattr(self, "_t_py", None) is not None:
+            self._t_py += int(n_iterations)
         if sync:
             self.sync()
 
