@@ -2,7 +2,7 @@
 # (rocprofv3 reports the sum over the 8 XCDs; reads high on dispatches much shorter than 0.3 ms).  Counter collection serialises
 # the two streams, so k_rng does not run next to k_mh_steps here.
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmcclk -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --pilot 1000 --burnin 2000 --no-cpu-baseline --no-ess > /tmp/pmcclk.log 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmcclk -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --pilot 1000 --burnin 2000 --no-cpu-baseline --no-ess --no-configs > /tmp/pmcclk.log 2>&1
 python3 - <<'PY'
 import csv, glob, json, statistics as st, collections
 f = glob.glob("/tmp/pmcclk/**/*counter_collection.csv", recursive=True)[0]

@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 for pass in 1 2; do
   if [ $pass = 1 ]; then C="FETCH_SIZE"; else C="WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; fi
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc$pass -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --pilot 1000 --burnin 2000 --no-cpu-baseline --no-ess > /tmp/pmc$pass.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc$pass -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --pilot 1000 --burnin 2000 --no-cpu-baseline --no-ess --no-configs > /tmp/pmc$pass.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, json, statistics as st, collections
@@ -37,7 +37,7 @@ raw = json.load(open("/tmp/pmc_out.json"))
 data = open(os.path.join(root, "tinyda_amd", "csrc", "tda_kernels_mh.h"), "rb").read()
 key = [k for k in raw if "k_mh_steps<64, 8" in k][0]
 out = {"note": "rocprofv3 --pmc, two separate passes (FETCH_SIZE | WRITE_SIZE TCC_HIT_sum TCC_MISS_sum) of `bench.py --steps 10 --warmup 2 "
-               "--pilot 1000 --burnin 2000 --no-cpu-baseline --no-ess` (tools/pmc_traffic.sh); median over the 100-iteration launches "
+               "--pilot 1000 --burnin 2000 --no-cpu-baseline --no-ess --no-configs` (tools/pmc_traffic.sh); median over the 100-iteration launches "
                "(409600 evals each). FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for wide coalesced streaming reads on gfx950; "
                "units KiB -> bytes.",
        "evals_per_launch": 409600, "k_mh_steps_hbm_bytes_per_launch": raw[key]["hbm_bytes_corrected"],
