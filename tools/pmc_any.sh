@@ -28,8 +28,6 @@ for k, c in res.items():
     if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
         c["hbm_bytes_corrected"] = int((2 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024)
         c["L2_hit_rate"] = c.get("TCC_HIT_sum", 0.0) / max(c.get("TCC_HIT_sum", 0.0) + c.get("TCC_MISS_sum", 0.0), 1.0)
-    if c.get("SQ_BUSY_CYCLES") and c.get("SQ_ACTIVE_INST_VALU"):
-        c["valu_busy_frac_of_busy_cycles"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_BUSY_CYCLES"] / 4.0  # (four SIMDs per CU issue in parallel)
 json.dump(res, open(sys.argv[2], "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
