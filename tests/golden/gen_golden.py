@@ -571,16 +571,19 @@ def rosenbrock_model(a=1.0, b=10.0):
     return lambda th: np.array([np.sum((a - th[:-1]) ** 2 + b * (th[1:] - th[:-1] ** 2) ** 2)])
 
 
-def g6_dreamz(name, problem, d, M0, delta, nCR, adaptive, period, iters, n_chains, seed, b=5e-2, b_star=1e-6, m=12):
+def g6_dreamz(name, problem, d, M0, delta, nCR, adaptive, period, iters, n_chains, seed, b=5e-2, b_star=1e-6, m=12, noise="iso"):
     rng = np.random.default_rng(seed)
     pm, pc = np.zeros(d), np.eye(d)
     prior = stats.multivariate_normal(pm, pc)
     extra = {}
     if problem == "linear":
         A, theta_true, y = linear_problem(seed, d, m, sigma=0.3)
-        like = tda.GaussianLogLike(y, 0.09 * np.eye(m))
+        cov = _level_covs(seed, [m], 0.3, [noise])[0]
+        like = tda.GaussianLogLike(y, cov)
         post = tda.Posterior(prior, like, make_model(A))
         extra = dict(A=A, data=y, noise_var=np.array(0.09))
+        if noise != "iso":
+            extra["noise_cov"] = cov
     else:
         like = tda.GaussianLogLike(np.zeros(1), np.eye(1))
         post = tda.Posterior(prior, like, rosenbrock_model(1.0, 10.0))
@@ -1022,6 +1025,8 @@ FIXTURES = {
                                                   adaptive=True, period=25, iters=200, n_chains=4, seed=602),
     "g6_dreamz_empty_subspace": lambda: g6_dreamz("g6_dreamz_empty_subspace", "linear", d=3, M0=12, delta=1, nCR=3,
                                                   adaptive=True, period=20, iters=120, n_chains=3, seed=603, m=7),
+    "g6_dreamz_linear_dense": lambda: g6_dreamz("g6_dreamz_linear_dense", "linear", d=6, M0=20, delta=2, nCR=3, adaptive=True, period=25,
+                                                iters=120, n_chains=4, seed=604, m=20, noise="dense"),
     "g8_da_aem_indep": lambda: g8_da_aem("g8_da_aem_indep", "state-independent"),
     "g8_da_aem_dep": lambda: g8_da_aem("g8_da_aem_dep", "state-dependent", seed=802),
     "g8_da_aem_dep_pcn": lambda: g8_da_aem("g8_da_aem_dep_pcn", "state-dependent", proposal_kind="pcn", L=1, seed=803),

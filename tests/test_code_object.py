@@ -26,7 +26,7 @@ HOT = {
     "_ZN3tda12k_rng_directILi64EEE": "C3 proposal normals",
     "_ZN3tda9k_proposeILi64EEE": "C5 proposal increments",
     "_ZN3tda19k_dreamz_steps_waveILi32EEE": "C4 DREAM steps",
-    "_ZN3tda10k_ml_stepsILi64ELi1ELi4EEE": "dense error model base steps, step-by-step path (TINYDA_AEM_BASE=0, dense priors)",
+    "_ZN3tda10k_ml_stepsILi64ELi1ELi4ELb0EEE": "dense error model base steps, step-by-step path (TINYDA_AEM_BASE=0, dense priors)",
     "_ZN3tda16k_aem_base_stepsILi8EEE": "C5 + dense error model base subchain (one pass over V per launch)",
     "_ZN3tda12k_aem_actionILi128EEE": "C5 + dense error model level decision",
     "_ZN3tda18k_adapt_chol_applyILi64EEE": "C2a period boundary in one launch",
@@ -37,14 +37,17 @@ HOT = {
 # they are known to have (a cap per instance, so that neither a new spiller nor a worse one goes unnoticed).
 #   k_aem_refresh<8, *>  one wave per SIMD with 512 registers by design (the 128 x 128 matrix lives in registers); what is spilled
 #                        is reloaded once, outside any loop (straight-line code)
-#   k_dreamz_steps<64>   the 16-chain tile kernel of DREAM(Z) at 64 parameters under a LINEAR model (C4 runs k_dreamz_steps_wave)
-#   k_ml_steps<64,3|4,4> the generic level kernel with three / four levels in one launch (C5 runs k_da_steps)
+#   k_dreamz_steps<64,*> the 16-chain tile kernel of DREAM(Z) at 64 parameters under a LINEAR model (C4 runs k_dreamz_steps_wave);
+#                        <32,true>: its instance for a dense observation covariance
+#   k_ml_steps<64,3|4,4,false> the generic level kernel with three / four levels in one launch (C5 runs k_da_steps);
+#   k_ml_steps<64,*,4,true>    its instances for hierarchies with a dense observation covariance on some level (round 4)
 #   k_da_steps<64,1,*,1|2,3> three-level lean kernel with diagonal noise / the diagonal error model on the coarse level
 #   k_rng<*>             2-3 registers, the generator is held to 64 registers so that it fits beside two step waves
 KNOWN_SPILLERS = {
     "_ZN3tda13k_aem_refreshILi8ELi1EEE": 40, "_ZN3tda13k_aem_refreshILi8ELi2EEE": 48, "_ZN3tda13k_aem_refreshILi8ELi3EEE": 96,
-    "_ZN3tda14k_dreamz_stepsILi64EEE": 160,
-    "_ZN3tda10k_ml_stepsILi64ELi3ELi4EEE": 56, "_ZN3tda10k_ml_stepsILi64ELi4ELi4EEE": 128,
+    "_ZN3tda14k_dreamz_stepsILi64ELb0EEE": 160, "_ZN3tda14k_dreamz_stepsILi64ELb1EEE": 176, "_ZN3tda14k_dreamz_stepsILi32ELb1EEE": 8,
+    "_ZN3tda10k_ml_stepsILi64ELi3ELi4ELb0EEE": 56, "_ZN3tda10k_ml_stepsILi64ELi4ELi4ELb0EEE": 128,
+    "_ZN3tda10k_ml_stepsILi64ELi2ELi4ELb1EEE": 48, "_ZN3tda10k_ml_stepsILi64ELi3ELi4ELb1EEE": 136, "_ZN3tda10k_ml_stepsILi64ELi4ELi4ELb1EEE": 232,
     "_ZN3tda10k_da_stepsILi64ELi1ELb1ELi2ELi3EEE": 24, "_ZN3tda10k_da_stepsILi64ELi1ELb0ELi2ELi3EEE": 16,
     "_ZN3tda10k_da_stepsILi64ELi1ELb1ELi1ELi3EEE": 4, "_ZN3tda10k_da_stepsILi64ELi1ELb1ELi0ELi3EEE": 4,
     "_ZN3tda5k_rngILi16EEE": 3, "_ZN3tda5k_rngILi32EEE": 3, "_ZN3tda5k_rngILi64EEE": 3,

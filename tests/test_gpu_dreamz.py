@@ -22,7 +22,10 @@ def _setup(eng_mod, g, cfg, T, block=0, seed=3):
     e = eng_mod.Engine(N, d, seed=seed, block_steps=block)
     e.set_prior(g["prior_mean"], g["prior_cov"])
     if str(g["problem"]) == "linear":
-        e.set_level(0, g["A"], g["data"], 0, float(g["noise_var"]))
+        if "noise_cov" in g.files:  # dense observation covariance under DREAM(Z) (round 4)
+            e.set_level(0, g["A"], g["data"], 2, g["noise_cov"])
+        else:
+            e.set_level(0, g["A"], g["data"], 0, float(g["noise_var"]))
     else:
         e.set_level_rosenbrock(0, float(g["rosen_a"]), float(g["rosen_b"]), 0.0, 1.0)
     e.set_proposal_dreamz(cfg["M0"], delta=cfg["delta"], b=cfg["b"], b_star=cfg["b_star"], nCR=cfg["nCR"],
@@ -31,7 +34,7 @@ def _setup(eng_mod, g, cfg, T, block=0, seed=3):
 
 
 @pytest.mark.parametrize("name,block", [("g6_dreamz_linear", 0), ("g6_dreamz_linear", 7), ("g6_dreamz_rosen_adaptive", 0),
-                                        ("g6_dreamz_empty_subspace", 0)])
+                                        ("g6_dreamz_empty_subspace", 0), ("g6_dreamz_linear_dense", 0), ("g6_dreamz_linear_dense", 5)])
 def test_dreamz_replay(eng_mod, golden, name, block):
     g = golden(name)
     _, cfg, var = dreamz_inputs(g)

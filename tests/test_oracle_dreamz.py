@@ -8,7 +8,8 @@ from oracle import tinyda_oracle as orc
 def dreamz_inputs(g):
     prior = orc.MVNPrior(g["prior_mean"], g["prior_cov"])
     if str(g["problem"]) == "linear":
-        level = orc.LinearGaussianLevel(g["A"], g["data"], "iso", float(g["noise_var"]), prior)
+        noise = orc.noise_of(g["noise_cov"]) if "noise_cov" in g.files else ("iso", float(g["noise_var"]))
+        level = orc.LinearGaussianLevel(g["A"], g["data"], *noise, prior)
     else:
         level = orc.RosenbrockLevel(prior, float(g["rosen_a"]), float(g["rosen_b"]))
     cfg = {k: g[k].item() for k in ("M0", "delta", "nCR", "adaptive", "period", "gamma", "b", "b_star")}
@@ -16,7 +17,7 @@ def dreamz_inputs(g):
     return level, cfg, var
 
 
-@pytest.mark.parametrize("name", ["g6_dreamz_linear", "g6_dreamz_rosen_adaptive", "g6_dreamz_empty_subspace"])
+@pytest.mark.parametrize("name", ["g6_dreamz_linear", "g6_dreamz_rosen_adaptive", "g6_dreamz_empty_subspace", "g6_dreamz_linear_dense"])
 def test_dreamz(golden, name):
     g = golden(name)
     level, cfg, var = dreamz_inputs(g)

@@ -62,11 +62,11 @@ def _device_plan(posteriors, proposal, diagonal_error_model=False):
             if low["A"] is None:  # callback / source-defined model: any sampler they run under, m <= 2048
                 if np.asarray(low["data"]).shape[0] > 2048:
                     return _no("a dense observation covariance beside a callback / source-defined model: at most 2048 outputs")
-            elif isinstance(proposal, DREAMZ) or low["A"].shape[0] > 1024 or (
+            elif low["A"].shape[0] > 1024 or (
                     len(posteriors) != 1 and type(proposal) not in (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis)):
-                # linear model: GRW / pCN / AM with m <= 1024 (MFMA quadratic form) -- single level, and since 0.4 any level of a
-                # Delayed Acceptance / MLDA hierarchy of linear levels
-                return _no("a dense observation covariance with a linear model is lowered for GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis with at most 1024 outputs (single level or a hierarchy of linear levels)")
+                # linear model, m <= 1024 (MFMA quadratic form): single level under GRW / pCN / AM / DREAM(Z), and since 0.4 any level
+                # of a Delayed Acceptance / MLDA hierarchy of linear levels under GRW / pCN / AM
+                return _no("a dense observation covariance with a linear model is lowered for at most 1024 outputs, single level (any proposal the engine knows) or a hierarchy of linear levels under GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis")
         lows.append(low)
     if diagonal_error_model and any(lw["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG) for lw in lows):
         return _no("the diagonal error model takes its Sigma_e from isotropic / diagonal level noise")

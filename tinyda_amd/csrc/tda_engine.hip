@@ -571,6 +571,15 @@ int launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st) {
   // and densities of the levels above through the step loop untouched -- in the three- and four-level instances that is 33 / 91
   // spilled registers whose reloads drain the prefetch of the per-chain precision matrices; the one-level instance leaves them
   // in memory
+  bool dense = false;  // a dense observation covariance on some level: the instances that carry the Sigma^-1 quadratic form
+  for (int k = 0; k < a.nlev; ++k) dense = dense || a.lv[k].noise_kind == TDA_NOISE_DENSE;
+  if (dense) {
+    switch (a.nlev) {
+      case 2: return go(&k_ml_steps<DPAD, 2, 4, true>);
+      case 3: return go(&k_ml_steps<DPAD, 3, 4, true>);
+      default: return go(&k_ml_steps<DPAD, 4, 4, true>);
+    }
+  }
   if (!a.cascade && !a.randomize) return go(&k_ml_steps<DPAD, 1>);
   switch (a.nlev) {
     case 2: return go(&k_ml_steps<DPAD, 2>);
@@ -597,7 +606,13 @@ void launch_dz_steps(const DreamStepArgs& a, size_t lds, hipStream_t st) {
     hipLaunchKernelGGL(k_dreamz_steps_wave<DPAD>, dim3((unsigned)(a.NP / CPW)), dim3(64), 0, st, a);
     return;
   }
-  hipLaunchKernelGGL(k_dreamz_steps<DPAD>, dim3((unsigned)(a.NP / 16)), dim3(256), lds, st, a);
+  if (a.model == MODEL_LINEAR && a.lv.noise_kind == TDA_NOISE_DENSE) {
+    if (lds > 64 * 1024)  // beyond the default dynamic-LDS window (the residual tile at several hundred outputs)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dreamz_steps<DPAD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_dreamz_steps<DPAD, true>), dim3((unsigned)(a.NP / 16)), dim3(256), lds, st, a);
+    return;
+  }
+  hipLaunchKernelGGL((k_dreamz_steps<DPAD, false>), dim3((unsigned)(a.NP / 16)), dim3(256), lds, st, a);
 }
 template <int DPAD>
 void launch_colsum(const double* m, int64_t row0, int64_t nrows, double* partial, int64_t nb, hipStream_t st) {

@@ -324,7 +324,9 @@ struct DreamStepArgs {
   int jump_ready;      // 1: `coef` holds the finished jumps (k_dreamz_draw gathered the shared archive), no gathers here
 };
 
-template <int DPAD>
+// DENSE: the instance for a dense observation covariance (a template parameter: as a run-time branch it cost the plain instances
+// 12 / 30 more spilled registers)
+template <int DPAD, bool DENSE = false>
 __global__ void __launch_bounds__(256, 2) k_dreamz_steps(const DreamStepArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int KS = DPAD / 4;
@@ -340,6 +342,8 @@ __global__ void __launch_bounds__(256, 2) k_dreamz_steps(const DreamStepArgs a) 
   double* s_y = s_redp + 64;
   double* s_w = s_y + (linear ? a.lv.m_pad : 0);
   double* s_py = s_w + ((linear && diag) ? a.lv.m_pad : 0);
+  // dense observation covariance (round 4): the tile's residuals [16][m_pad + 2] for the Sigma^-1 quadratic form on the matrix cores
+  double* s_R = s_py + (prior_dense ? a.pr.ncb * 16 : 0);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -448,7 +452,15 @@ __global__ void __launch_bounds__(256, 2) k_dreamz_steps(const DreamStepArgs a) 
     }
     // ---- likelihood ----
     double ll_n;
-    if (linear) {
+    if constexpr (DENSE) {  // DefaultGaussianLogLike (distributions.py:246-301) under DREAM(Z): as k_mh_steps / k_ml_steps evaluate it
+      const int RSd = a.lv.m_pad + 2;
+      (void)level_sse_partial<DPAD, 2>(a.lv.Apk, a.lv.ncb, s_y, s_R + lc * RSd, th, wave, lane, f0, f1);
+      __syncthreads();
+      double qs = sum_rows(dense_quadform<4>(a.lv.Ppk, a.lv.ncb, a.lv.m_pad, s_R, RSd, wave, lane));
+      if (lane < 16) s_red[wave * 16 + lane] = qs;
+      __syncthreads();
+      ll_n = -0.5 * (((s_red[lc] + s_red[16 + lc]) + s_red[32 + lc]) + s_red[48 + lc]);
+    } else if (linear) {
       double sse = diag ? level_sse_partial<DPAD, 1>(a.lv.Apk, a.lv.ncb, s_y, s_w, th, wave, lane, f0, f1)
                         : level_sse_partial<DPAD, 0>(a.lv.Apk, a.lv.ncb, s_y, nullptr, th, wave, lane, f0, f1);
       sse = sum_rows(sse);

@@ -77,7 +77,9 @@ __device__ __forceinline__ constexpr int pair_index(int j, int q) { return q * (
 // NW = waves sharing the tile: 4 (one per SIMD, up to 512 registers, pairs of observation blocks in flight) or 8 (two per
 // SIMD with 256 registers each, the single-block pipeline of the 8-wave single-level tile; 17-30 % faster at every m,
 // tools/waves_vs_m.py) where the level count leaves the registers for it.
-template <int DPAD, int NLEV, int NW = 4>
+// DENSE: the instance for hierarchies with a dense observation covariance on some level (a template parameter: as a run-time branch
+// of `evaluate` it cost the other instances 39-95 more spilled registers at 64 parameters)
+template <int DPAD, int NLEV, int NW = 4, bool DENSE = false>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
   constexpr int NT = 64 * NW;
   constexpr int TPC = 4 * NW;  // threads per chain in the thread-mapped phases
@@ -290,7 +292,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
       lp_n = -0.5 * (a.pr.logconst + maha);
       return;
     }
-    if (L.noise_kind == 2) {
+    if (DENSE && L.noise_kind == 2) {
       // dense observation covariance (DefaultGaussianLogLike, distributions.py:246-301) at any level of the hierarchy (round 4):
       // residual tile to LDS, then r^T Sigma^-1 r for the tile's 16 chains on the matrix cores, as the single-level kernel does
       const int RSd = L.m_pad + 2;
