@@ -42,7 +42,6 @@ HOT = {
 #   k_ml_steps<64,3|4,4,false> the generic level kernel with three / four levels in one launch (C5 runs k_da_steps);
 #   k_ml_steps<64,*,4,true>    its instances for hierarchies with a dense observation covariance on some level (round 4)
 #   k_da_steps<64,1,*,1|2,3> three-level lean kernel with diagonal noise / the diagonal error model on the coarse level
-#   k_rng<*>             2-3 registers, the generator is held to 64 registers so that it fits beside two step waves
 KNOWN_SPILLERS = {
     "_ZN3tda13k_aem_refreshILi8ELi1EEE": 40, "_ZN3tda13k_aem_refreshILi8ELi2EEE": 48, "_ZN3tda13k_aem_refreshILi8ELi3EEE": 96,
     "_ZN3tda14k_dreamz_stepsILi64ELb0EEE": 160, "_ZN3tda14k_dreamz_stepsILi64ELb1EEE": 176, "_ZN3tda14k_dreamz_stepsILi32ELb1EEE": 8,
@@ -50,7 +49,6 @@ KNOWN_SPILLERS = {
     "_ZN3tda10k_ml_stepsILi64ELi2ELi4ELb1EEE": 48, "_ZN3tda10k_ml_stepsILi64ELi3ELi4ELb1EEE": 136, "_ZN3tda10k_ml_stepsILi64ELi4ELi4ELb1EEE": 232,
     "_ZN3tda10k_da_stepsILi64ELi1ELb1ELi2ELi3EEE": 24, "_ZN3tda10k_da_stepsILi64ELi1ELb0ELi2ELi3EEE": 16,
     "_ZN3tda10k_da_stepsILi64ELi1ELb1ELi1ELi3EEE": 4, "_ZN3tda10k_da_stepsILi64ELi1ELb1ELi0ELi3EEE": 4,
-    "_ZN3tda5k_rngILi16EEE": 3, "_ZN3tda5k_rngILi32EEE": 3, "_ZN3tda5k_rngILi64EEE": 3,
 }
 
 

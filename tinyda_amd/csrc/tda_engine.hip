@@ -452,8 +452,9 @@ void launch_rng_direct(const RngArgs& a, double* inc, hipStream_t st) {
 }
 template <int DPAD>
 void launch_rng(const RngArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_rng<DPAD>, dim3((unsigned)a.NP, (unsigned)((a.S + 15) / 16)), dim3(64), 0, st, a);
+  // (the 5 us of uniforms first: the long kernel then ends the generator stream's work of a block, and nothing small queues behind it)
   hipLaunchKernelGGL(k_rng_uniforms, dim3((unsigned)(((int64_t)a.S * a.NP + 255) / 256)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_rng<DPAD>, dim3((unsigned)a.NP, (unsigned)((a.S + 15) / 16)), dim3(64), 0, st, a);
 }
 template <int DPAD>
 void launch_apply(const ApplyArgs& a, hipStream_t st) {
