@@ -531,14 +531,24 @@ inline bool da_lean_eligible(const MLArgs& a) {
   return !off;
 }
 
+// free_regs != nullptr: no launch; *free_regs = the vector registers per SIMD lane that one resident tile of the kernel this call
+// would launch leaves free (512 - waves per SIMD x allocated registers) -- run_multilevel puts the next block's draws on a second
+// stream when the generator's 64-register waves fit beside the tile
 template <int DPAD>
-int launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st) {
+int launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st, int* free_regs = nullptr) {
+  auto regs_left = [&](const void* kern, int waves_per_simd) -> int {
+    hipFuncAttributes fa{};
+    HIP_TRY(hipFuncGetAttributes(&fa, kern));
+    *free_regs = 512 - waves_per_simd * ((fa.numRegs + 7) / 8 * 8);
+    return TDA_OK;
+  };
   // (the lean kernel keeps 64 KB of model outputs per tile in LDS: with very long data vectors staged beside them it does not fit)
   const size_t lds8 = (size_t)da_lds_doubles<DPAD>(a.lds_total) * sizeof(double);
   if (da_lean_eligible(a) && lds8 <= 160 * 1024) {
     const bool pcn = a.prop_kind == TDA_PROP_PCN, dg0 = a.lv[0].noise_kind == 1, one = a.lv[0].ncb <= 8;
 #define TDA_DA_LAUNCH(RBV, PCNV, NZV, NLV)                                                                                         \
   do {                                                                                                                             \
+    if (free_regs) return regs_left(reinterpret_cast<const void*>(&k_da_steps<DPAD, RBV, PCNV, NZV, NLV>), 2);                     \
     if (lds8 > 64 * 1024)                                                                                                          \
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_da_steps<DPAD, RBV, PCNV, NZV, NLV>),                           \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));                                         \
@@ -563,6 +573,7 @@ int launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st) {
     return TDA_OK;
   }
   auto go = [&](auto kern) -> int {
+    if (free_regs) return regs_left(reinterpret_cast<const void*>(kern), 1);
     if (lds > 64 * 1024)  // beyond the default dynamic-LDS window (the residual tile of an error model at several hundred outputs)
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, st, a);

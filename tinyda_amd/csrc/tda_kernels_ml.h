@@ -590,7 +590,14 @@ __device__ long long g_da_trace[128 * 8 * 8];  // debug builds only: [step][wave
 // on the coarse level -- template parameters, because as run-time flags they cost a select per model output and step in the
 // vector section that decides when the SIMD's other wave may start its burst
 template <int DPAD, int RB, bool PCN, int NZ0, int NLEV = 2>
-__global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
+#ifndef TDA_DA_VGPR
+#define TDA_DA_VGPR 0
+#endif
+__global__ void __launch_bounds__(512, 2)
+#if TDA_DA_VGPR > 0
+    __attribute__((amdgpu_num_vgpr(TDA_DA_VGPR)))  // (gfx90a and later: the backend doubles the number -- 112 is a budget of 224)
+#endif
+    k_da_steps(const MLArgs a) {
   static_assert(NLEV == 2 || NLEV == 3, "two-level Delayed Acceptance or three-level MLDA");
   constexpr int NPAIR = NLEV * (NLEV - 1) / 2;
   constexpr int NW = 8, NT = 64 * NW, TPC = 4 * NW;
@@ -641,7 +648,11 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
 
   // level 0 in scalars of its own (the step loop below), the levels above in arrays indexed by level - 1
   double cur0[EPT], curU[NLEV - 1][EPT], prp[EPT];
-  double sxa[EPT], sxb[EPT], sxc[EPT], sxd[EPT];  // increments of steps s .. s + 3 as loaded (a load has a whole step to arrive)
+  // increments: sxa = the SCALED increment of the current step (this thread's elements, read back from the fragment-ordered tile it
+  // staged them into two steps earlier), sxl = the raw increment loaded for the step after next (a load has a whole step to arrive).
+  // (Until round 4 the raw increments of steps s .. s + 3 travelled through four register sets: 8 registers more, and the
+  // kernel has to leave 64 of a SIMD's 512 to the generator of the next block, see launch_ml.)
+  double sxa[EPT], sxl[EPT];
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
     cur0[e] = active ? a.theta[gct * DPAD + q_ * EPT + e] : 0.0;
@@ -705,6 +716,11 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
 #pragma unroll
       for (int e = 0; e < EPT; ++e) dst[st_dst[e]] = scal_t * sx[e];
     }
+  };
+  auto stage_own = [&](int s, double (&sx)[EPT]) {  // this thread's elements of the staged tile of step s (its own writes: no barrier)
+    const double* __restrict__ src = s_inc + (s & 1) * 64 * RSX;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) sx[e] = active ? src[st_dst[e]] : 0.0;
   };
   auto chainmm = [&](const double2 (&f)[K2], const double2 (&b)[K2]) {
     double4_t g = {0.0, 0.0, 0.0, 0.0};
@@ -782,12 +798,13 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
 
   // ---- pipeline prologue: increments of steps 0 and 1 staged, A (s inc_0) issued ----
 #pragma unroll
-  for (int e = 0; e < EPT; ++e) sxa[e] = sxb[e] = sxc[e] = sxd[e] = 0.0;
+  for (int e = 0; e < EPT; ++e) sxa[e] = sxl[e] = 0.0;
   if (a.S > 0) stage_load(0, sxa);
-  if (a.S > 1) stage_load(1, sxb);
-  if (a.S > 2) stage_load(2, sxc);
+  if (a.S > 1) stage_load(1, sxl);
   if (a.S > 0) stage_store(0, sxa);
-  if (a.S > 1) stage_store(1, sxb);
+  if (a.S > 1) stage_store(1, sxl);
+  if (a.S > 2) stage_load(2, sxl);
+  if (a.S > 0) stage_own(0, sxa);
   double unext = a.S > 0 ? a.u0[gcl] : 0.5, lunext = (has_logu && a.S > 0) ? a.logu0[gcl] : 0.0;
   __syncthreads();
   auto issue_products = [&](int s) {  // G = A (s inc_s) for this wave's blocks, from the staged tile of step s
@@ -841,7 +858,7 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
     if (active) {
 #pragma unroll
       for (int e = 0; e < EPT; ++e) {
-        const double sx = scal_t * sxa[e];
+        const double sx = sxa[e];
         prp[e] = is_pcn ? keep_t * cur0[e] + sx : cur0[e] + sx;
         if (prior_std) {
           pp += prp[e] * prp[e];
@@ -889,7 +906,7 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     DA_STAMP(2);
     flush_coarse_record();  // (step s - 1)
-    if (s + 3 < a.S) stage_load(s + 3, sxd);  // staged one step from now, a proposal three steps from now
+    if (s + 1 < a.S) stage_own(s + 1, sxa);  // (the next step's; staged by this thread before the previous barrier)
     double u_nx = 0.5, lu_nx = 0.0;
     if (s + 1 < a.S) {
       u_nx = a.u0[(size_t)(s + 1) * a.NP + gcl];
@@ -897,7 +914,8 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
     }
     pp = sum_half_wave(pp);
     if (q_ == 0) s_pri[(s & 1) * 16 + c] = pp;
-    if (s + 2 < a.S) stage_store(s + 2, sxc);  // loaded after the previous barrier; its buffer was last read for step s
+    if (s + 2 < a.S) stage_store(s + 2, sxl);  // loaded a step ago; its buffer was last read for step s (products: before the previous
+    if (s + 3 < a.S) stage_load(s + 3, sxl);   // barrier; this thread's own elements: at the top of this step)
     DA_STAMP(3);
     __syncthreads();
     DA_STAMP(4);
@@ -940,12 +958,6 @@ __global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
     rec_ring = ringidx;
     rec_pending = true;  // the record of this step is written behind the next step's products (or before the fine level acts)
     rec_acc0 = acc0;
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-      sxa[e] = sxb[e];
-      sxb[e] = sxc[e];
-      sxc[e] = sxd[e];
-    }
     ringidx = ringidx + 1 == a.ring_P ? 0 : ringidx + 1;
     nrec0 += 1;
     step0 += 1;

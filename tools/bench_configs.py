@@ -86,7 +86,7 @@ def _level_buffers(rows, N, d):
 
 def run_hierarchy(name, ms, sl, prop, n_fine, per_eval, kernel, N=4096, d=64):
     torch = _torch()
-    lv = levels(ms)
+    lv = levels(ms, d=d)
     e = _engine()(N, d, seed=9, n_levels=len(ms))
     e.set_prior(np.zeros(d), np.eye(d))
     for k, (A, y) in enumerate(lv):
@@ -110,6 +110,12 @@ def run_hierarchy(name, ms, sl, prop, n_fine, per_eval, kernel, N=4096, d=64):
 def run_c3(n_fine=200):
     return run_hierarchy("C3: 2-level DA, pCN(0.02), 256/2048 obs, subsampling_rate=10", (256, 2048), [10], dict(kind=1, scaling=0.02), n_fine,
                          2 * 256 * 64 + 2 * 2048 * 64 / 10, "k_da_steps<64,2,true,0,2>")
+
+
+def run_da_small(n_fine=200, d=64):
+    """a Delayed-Acceptance shape whose level kernel leaves room for the generator (TINYDA_ML_SPLIT A/B): 128 coarse outputs, GRW"""
+    return run_hierarchy("DA, GRW(0.02 I), 128/2048 obs, subsampling_rate=10", (128, 2048), [10], dict(kind=0, C_=np.eye(d), scaling=0.02), n_fine,
+                         2 * 128 * d + 2 * 2048 * d / 10, "k_da_steps<64,1,false,0,2>", d=d)
 
 
 def run_c5(n_fine=60):
@@ -305,6 +311,8 @@ if __name__ == "__main__":
         print(json.dumps(run_c5_aem(m=int(av[2]), n_fine=int(av[3]) if len(av) > 3 else 20, diagonal=av[1] == "c5aemd")))
     elif len(av) > 1 and av[1] == "c3":
         print(json.dumps(run_c3()))
+    elif len(av) > 1 and av[1] == "da_small":
+        print(json.dumps(run_da_small(d=int(av[2]) if len(av) > 2 else 64)))
     elif len(av) > 1 and av[1] in ("c4", "c4peer", "c4peerlag"):
         print(json.dumps(run_c4(K=int(av[2]) if len(av) > 2 else 16, peer=av[1] != "c4", lag=av[1] == "c4peerlag")))
     elif len(av) > 1 and av[1] == "c5":
