@@ -21,7 +21,8 @@ HOT = {
     "_ZN3tda7k_adaptILi64EEE": "C2a moment recursion",
     "_ZN3tda16k_chol_apply_blkILi64ELb1EEE": "C2a covariance swap + increments",
     "_ZN3tda7k_applyILi64EEE": "C2a increments",
-    "_ZN3tda10k_da_stepsILi64ELi2ELb1ELi0ELi2EEE": "C3 Delayed Acceptance",
+    "_ZN3tda10k_da_stepsILi64ELi2ELb1ELi0ELi2EEE": "C3 Delayed Acceptance (replay mode, non-identity proposal factors)",
+    "_ZN3tda15k_da_steps_r224ILi64ELi2ELb1ELi0ELi2EEE": "C3 Delayed Acceptance, 224-register entry point (draws of the next block beside it)",
     "_ZN3tda10k_da_stepsILi64ELi1ELb0ELi0ELi3EEE": "C5-literal MLDA",
     "_ZN3tda12k_rng_directILi64EEE": "C3 proposal normals",
     "_ZN3tda9k_proposeILi64EEE": "C5 proposal increments",
@@ -41,14 +42,11 @@ HOT = {
 #                        <32,true>: its instance for a dense observation covariance
 #   k_ml_steps<64,3|4,4,false> the generic level kernel with three / four levels in one launch (C5 runs k_da_steps);
 #   k_ml_steps<64,*,4,true>    its instances for hierarchies with a dense observation covariance on some level (round 4)
-#   k_da_steps<64,1,*,1|2,3> three-level lean kernel with diagonal noise / the diagonal error model on the coarse level
 KNOWN_SPILLERS = {
     "_ZN3tda13k_aem_refreshILi8ELi1EEE": 40, "_ZN3tda13k_aem_refreshILi8ELi2EEE": 48, "_ZN3tda13k_aem_refreshILi8ELi3EEE": 96,
     "_ZN3tda14k_dreamz_stepsILi64ELb0EEE": 160, "_ZN3tda14k_dreamz_stepsILi64ELb1EEE": 176, "_ZN3tda14k_dreamz_stepsILi32ELb1EEE": 8,
     "_ZN3tda10k_ml_stepsILi64ELi3ELi4ELb0EEE": 56, "_ZN3tda10k_ml_stepsILi64ELi4ELi4ELb0EEE": 128,
     "_ZN3tda10k_ml_stepsILi64ELi2ELi4ELb1EEE": 48, "_ZN3tda10k_ml_stepsILi64ELi3ELi4ELb1EEE": 136, "_ZN3tda10k_ml_stepsILi64ELi4ELi4ELb1EEE": 232,
-    "_ZN3tda10k_da_stepsILi64ELi1ELb1ELi2ELi3EEE": 24, "_ZN3tda10k_da_stepsILi64ELi1ELb0ELi2ELi3EEE": 16,
-    "_ZN3tda10k_da_stepsILi64ELi1ELb1ELi1ELi3EEE": 4, "_ZN3tda10k_da_stepsILi64ELi1ELb1ELi0ELi3EEE": 4,
 }
 
 
@@ -104,3 +102,19 @@ def test_rng_kernel_fits_beside_the_step_kernel(kernel_metadata):
     rng = [v for k, v in kernel_metadata.items() if k.startswith("_ZN3tda5k_rngILi64EEE")][0]
     gran = lambda n: (n + 7) // 8 * 8  # allocation granule
     assert 2 * gran(step["vgprs"]) + gran(rng["vgprs"]) <= 512, (step, rng)
+
+
+def test_generator_fits_beside_the_two_level_kernel(kernel_metadata):
+    """run_multilevel draws block b + 1 on the second stream under block b when k_rng_direct's waves fit beside a resident tile of the
+    level kernel (two waves per SIMD): the 224-register entry point of C3's instance and the one-block two-level instances as
+    compiled must leave 64 registers, without spilling"""
+    gran = lambda n: (n + 7) // 8 * 8
+    rng = [v for k, v in kernel_metadata.items() if k.startswith("_ZN3tda12k_rng_directILi64EEE")][0]
+    assert gran(rng["vgprs"]) <= 64 and rng["spilled"] == 0, rng
+    fit = ["_ZN3tda15k_da_steps_r224ILi64ELi2ELb1ELi0ELi2EEE", "_ZN3tda15k_da_steps_r224ILi64ELi2ELb0ELi0ELi2EEE",
+           "_ZN3tda10k_da_stepsILi64ELi1ELb1ELi0ELi2EEE", "_ZN3tda10k_da_stepsILi64ELi1ELb0ELi0ELi2EEE",
+           "_ZN3tda10k_da_stepsILi64ELi1ELb1ELi1ELi2EEE", "_ZN3tda10k_da_stepsILi64ELi1ELb0ELi1ELi2EEE"]
+    for pre in fit:
+        md = [v for k, v in kernel_metadata.items() if k.startswith(pre)]
+        assert md, pre
+        assert md[0]["spilled"] == 0 and 2 * gran(md[0]["vgprs"]) + 64 <= 512, (pre, md[0])

@@ -534,8 +534,11 @@ inline bool da_lean_eligible(const MLArgs& a) {
 // free_regs != nullptr: no launch; *free_regs = the vector registers per SIMD lane that one resident tile of the kernel this call
 // would launch leaves free (512 - waves per SIMD x allocated registers) -- run_multilevel puts the next block's draws on a second
 // stream when the generator's 64-register waves fit beside the tile
+// lean224: the caller can put the next block's draws beside this kernel (run_multilevel): where the 224-register entry point of the
+// two-level kernel exists it is launched instead of the plain one (TINYDA_DA_R224=0: never)
 template <int DPAD>
-int launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st, int* free_regs = nullptr) {
+int launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st, int* free_regs = nullptr, bool lean224 = false) {
+  static const bool r224_ok = !(getenv("TINYDA_DA_R224") && atoi(getenv("TINYDA_DA_R224")) == 0);
   auto regs_left = [&](const void* kern, int waves_per_simd) -> int {
     hipFuncAttributes fa{};
     HIP_TRY(hipFuncGetAttributes(&fa, kern));
@@ -566,6 +569,17 @@ int launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st, int* f
       if (pcn) { if (dg0) TDA_DA_LAUNCH(1, true, 1, 2); else TDA_DA_LAUNCH(1, true, 0, 2); }
       else { if (dg0) TDA_DA_LAUNCH(1, false, 1, 2); else TDA_DA_LAUNCH(1, false, 0, 2); }
     } else {
+      if constexpr (DPAD == 64) {  // (smaller paddings leave the room as they are; with diagonal noise the budget would spill 12)
+        if (lean224 && r224_ok && !dg0) {
+          auto go224 = [&](auto kern) -> int {
+            if (free_regs) return regs_left(reinterpret_cast<const void*>(kern), 2);
+            if (lds8 > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+            hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds8, st, a);
+            return TDA_OK;
+          };
+          return pcn ? go224(&k_da_steps_r224<DPAD, 2, true, 0, 2>) : go224(&k_da_steps_r224<DPAD, 2, false, 0, 2>);
+        }
+      }
       if (pcn) { if (dg0) TDA_DA_LAUNCH(2, true, 1, 2); else TDA_DA_LAUNCH(2, true, 0, 2); }
       else { if (dg0) TDA_DA_LAUNCH(2, false, 1, 2); else TDA_DA_LAUNCH(2, false, 0, 2); }
     }

@@ -573,7 +573,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
 // ------------------------------------------------------------------------------------------------
 template <int DPAD>
 __host__ __device__ constexpr int da_lds_doubles(int stage_total) {
-  return 16 * (DPAD + 2) + 2 * 64 * (DPAD / 4 + 2) + 2 * 16 * 8 + 2 * 16 + 2 * DPAD + 6 * 16 + 64 * (DPAD / 4 + 2) + 16 * 512 + stage_total;
+  return 16 * (DPAD + 2) + 2 * 64 * (DPAD / 4 + 2) + 2 * 16 * 8 + 2 * 16 + 4 * DPAD + 2 * 16 + 6 * 16 + 64 * (DPAD / 4 + 2) + 16 * 512 + stage_total;
 }
 
 #ifdef TDA_DA_TRACE
@@ -589,564 +589,19 @@ __device__ long long g_da_trace[128 * 8 * 8];  // debug builds only: [step][wave
 // launch is one base subchain, the host sequences the level actions, MLArgs::cascade == 0)
 // on the coarse level -- template parameters, because as run-time flags they cost a select per model output and step in the
 // vector section that decides when the SIMD's other wave may start its burst
+// The kernel proper (tda_kernels_da_body.inc), twice: as the compiler allocates it (up to 256 registers per wave, two waves per SIMD:
+// the tile owns the CU), and held to 224 registers so that one wave of the generator (64 registers) is co-resident on every SIMD and
+// the next block's draws run under this block's steps (run_multilevel).  amdgpu_num_vgpr takes a literal, hence two entry points
+// and not a template argument -- and a textual include and not a __device__ function: with the arguments behind a reference the
+// register allocation of every instance changes (C3's from 227 to 238).  On gfx90a and later the backend doubles the number
+// (112 -> a budget of 224).
 template <int DPAD, int RB, bool PCN, int NZ0, int NLEV = 2>
-#ifndef TDA_DA_VGPR
-#define TDA_DA_VGPR 0
-#endif
-__global__ void __launch_bounds__(512, 2)
-#if TDA_DA_VGPR > 0
-    __attribute__((amdgpu_num_vgpr(TDA_DA_VGPR)))  // (gfx90a and later: the backend doubles the number -- 112 is a budget of 224)
-#endif
-    k_da_steps(const MLArgs a) {
-  static_assert(NLEV == 2 || NLEV == 3, "two-level Delayed Acceptance or three-level MLDA");
-  constexpr int NPAIR = NLEV * (NLEV - 1) / 2;
-  constexpr int NW = 8, NT = 64 * NW, TPC = 4 * NW;
-  constexpr int KS = DPAD / 4, K2 = DPAD / 8, LDP = DPAD + 2, RSX = KS + 2;
-  constexpr int EPT = DPAD >= TPC ? DPAD / TPC : 1;
-  constexpr int QACT = DPAD / EPT;
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* s_prop = smem;                    // [16][LDP] states in natural order (direct evaluations)
-  double* s_inc = s_prop + 16 * LDP;        // [2][64][RSX] scaled increments in fragment order
-  double* s_red = s_inc + 2 * 64 * RSX;     // [2][NW][16]
-  double* s_pri = s_red + 2 * 16 * NW;      // [2][16] prior quadratic form of theta'
-  double* s_pm = s_pri + 2 * 16;
-  double* s_pinv = s_pm + DPAD;
-  double* s_S = s_pinv + DPAD;              // [2 NPAIR][16] densities of level j at the start of level q's step, between level actions
-  double* s_thf = s_S + 6 * 16;             // [64][RSX] the states a level action evaluates, in fragment order
-  double* s_Fs = s_thf + 64 * RSX;          // [NLEV RB 4][512] coarse model outputs at the states the upper levels hold, per thread;
-  double* s_stage = s_Fs + 16 * 512;        // the last RB 4 pieces: those of the coarse state itself while a level acts
-  static_assert(NLEV * RB * 4 <= 16, "s_Fs holds sixteen doubles per thread");
-  constexpr int FS_CUR = (NLEV - 1) * RB * 4;
-
-  __builtin_amdgcn_s_setprio(3);
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t tile = blockIdx.x;
-  const int c = tid / TPC, q_ = tid % TPC;
-  const int lc = lane & 15, hi = lane >> 4;
-  const int64_t gct = tile * 16 + c;
-  const int64_t gcl = tile * 16 + lc;
-  const bool active = q_ < QACT;
-  const uint32_t gchain = (uint32_t)(a.chain_offset + gcl);
-
-#pragma unroll
-  for (int k = 0; k < NLEV; ++k) {
-    if (k > 0 && !a.cascade) break;  // (host-sequenced level actions: only the base level is evaluated, and staged)
-    for (int i = tid; i < a.lv[k].m_pad; i += NT) {
-      s_stage[a.lds_y[k] + i] = a.lv[k].ytil[i];
-      if (a.lv[k].noise_kind == 1) s_stage[a.lds_w[k] + i] = a.lv[k].w[i];
-    }
-  }
-  for (int i = tid; i < DPAD; i += NT) {
-    s_pm[i] = a.pr.mean[i];
-    s_pinv[i] = a.pr.pinv[i];
-  }
-  const bool prior_std = a.pr.kind == PRIOR_STANDARD;
-  constexpr bool dg0 = NZ0 != 0;
-  constexpr bool aemd0 = NZ0 == 2;
-
-  // level 0 in scalars of its own (the step loop below), the levels above in arrays indexed by level - 1
-  double cur0[EPT], curU[NLEV - 1][EPT], prp[EPT];
-  // increments: sxa = the SCALED increment of the current step (this thread's elements, read back from the fragment-ordered tile it
-  // staged them into two steps earlier), sxl = the raw increment loaded for the step after next (a load has a whole step to arrive).
-  // (Until round 4 the raw increments of steps s .. s + 3 travelled through four register sets: 8 registers more, and the
-  // kernel has to leave 64 of a SIMD's 512 to the generator of the next block, see launch_ml.)
-  double sxa[EPT], sxl[EPT];
-#pragma unroll
-  for (int e = 0; e < EPT; ++e) {
-    cur0[e] = active ? a.theta[gct * DPAD + q_ * EPT + e] : 0.0;
-#pragma unroll
-    for (int q = 1; q < NLEV; ++q) curU[q - 1][e] = active ? a.theta[((size_t)q * a.NP + gct) * DPAD + q_ * EPT + e] : 0.0;
-  }
-  double lp0 = a.lp[gcl], ll0 = a.ll[gcl], lpU[NLEV - 1], llU[NLEV - 1];
-  int anyU[NLEV - 1], cntU[NLEV - 1], nrecU[NLEV - 1];
-  int64_t stepU[NLEV - 1];
-#pragma unroll
-  for (int q = 1; q < NLEV; ++q) {
-    lpU[q - 1] = a.lp[(size_t)q * a.NP + gcl];
-    llU[q - 1] = a.ll[(size_t)q * a.NP + gcl];
-    anyU[q - 1] = a.anyacc[(size_t)q * a.NP + gcl];  // (the finest level's is never read: carried unchanged)
-    cntU[q - 1] = a.cnt[q];
-    stepU[q - 1] = a.done[q];
-    nrecU[q - 1] = 0;
-  }
-  // level j at the start of level q's current step, pair_index(j, q): only the level actions touch these, so they wait in LDS
-  // (lane-mapped, every wave would hold the same copy: 4 NPAIR registers in the step loop for nothing)
-  if (wave == 0 && lane < 16) {
-#pragma unroll
-    for (int p = 0; p < NPAIR; ++p) {
-      s_S[(2 * p) * 16 + lc] = a.Sst[((size_t)p * 2 + 0) * a.NP + gcl];
-      s_S[(2 * p + 1) * 16 + lc] = a.Sst[((size_t)p * 2 + 1) * a.NP + gcl];
-    }
-  }
-  int anyacc0 = a.anyacc[gcl];
-  const double scal_t = a.scaling[gct];
-  constexpr bool is_pcn = PCN;
-  const double keep_t = is_pcn ? sqrt(1.0 - scal_t * scal_t) : 1.0;
-  const double scal_l = a.scaling[gcl];
-  const double keep_l = is_pcn ? sqrt(1.0 - scal_l * scal_l) : 1.0;  // the same factor for this lane's chain (model outputs)
-  const bool has_logu = a.logu0 != nullptr;
-  int cnt0 = a.cnt[0];
-  int64_t step0 = a.done[0];
-  int nrec0 = 0;
-  // slot of the next entry in the accept-flag ring, kept incrementally: the 64-bit remainder is ~150 instructions, and wave 0
-  // alone would pay them in every step while seven waves wait at the barrier
-  int ringidx = (int)(a.ring_pos % a.ring_P);
-  const int L0 = a.sl[0];
-  const int ncb0 = a.lv[0].ncb;
-  bool has_b[RB];
-#pragma unroll
-  for (int i = 0; i < RB; ++i) has_b[i] = wave + i * NW < ncb0;
-
-  // where this thread's elements of an increment go in the fragment-ordered tile: row = fragment lane (dim & 3) * 16 + chain
-  int st_dst[EPT];
-#pragma unroll
-  for (int e = 0; e < EPT; ++e) {
-    const int j = q_ * EPT + e;
-    st_dst[e] = ((j & 3) * 16 + c) * RSX + (j >> 2);
-  }
-  auto stage_load = [&](int s, double (&sx)[EPT]) {
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) sx[e] = active ? a.inc[((size_t)s * a.NP + gct) * DPAD + q_ * EPT + e] : 0.0;  // raw: no use here,
-  };                                                                                                              // so no wait here
-  auto stage_store = [&](int s, const double (&sx)[EPT]) {
-    double* __restrict__ dst = s_inc + (s & 1) * 64 * RSX;
-    if (active) {
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) dst[st_dst[e]] = scal_t * sx[e];
-    }
-  };
-  auto stage_own = [&](int s, double (&sx)[EPT]) {  // this thread's elements of the staged tile of step s (its own writes: no barrier)
-    const double* __restrict__ src = s_inc + (s & 1) * 64 * RSX;
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) sx[e] = active ? src[st_dst[e]] : 0.0;
-  };
-  auto chainmm = [&](const double2 (&f)[K2], const double2 (&b)[K2]) {
-    double4_t g = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int k = 0; k < K2; ++k) {
-      g = mfma_f64(f[k].x, b[k].x, g);
-      g = mfma_f64(f[k].y, b[k].y, g);
-    }
-    return g;
-  };
-
-  // ---- the coarse operator, data and weights of this wave's blocks: registers for the whole launch ----
-  const FragSrc src0 = frag_src(a.lv[0].Apk, lane);
-  double2 fA[RB][K2];
-  int ob[RB];  // first observation row of this lane in block i (data and weights are read from LDS at use)
-  auto load_coarse_operator = [&]() {
-#pragma unroll
-    for (int i = 0; i < RB; ++i) frag_load_buf<DPAD>(src0, has_b[i] ? wave + i * NW : (ncb0 - 1), fA[i]);
-  };
-  load_coarse_operator();
-  __syncthreads();  // staging region, prior constants
-#pragma unroll
-  for (int i = 0; i < RB; ++i) {
-    ob[i] = (has_b[i] ? wave + i * NW : 0) * 16 + hi;
-  }
-  double yc[aemd0 ? RB : 1][4], wc[aemd0 ? RB : 1][4];
-  if constexpr (aemd0) {
-    const int m0 = a.aem_ld;  // real output count = row stride of the [N][m] bias / inverse-variance arrays
-#pragma unroll
-    for (int i = 0; i < RB; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int o = ob[i] + 4 * r;
-        const bool in = has_b[i] && gcl < a.N && o < m0;
-        yc[i][r] = s_stage[a.lds_y[0] + o] - (in ? a.aem_bias[(size_t)gcl * m0 + o] : 0.0);
-        wc[i][r] = in ? a.aem_P[(size_t)gcl * m0 + o] : 0.0;
-      }
-  } else {
-    yc[0][0] = wc[0][0] = 0.0;
-  }
-
-  // ---- model outputs of a state by a direct product: the anchors of every launch (coarse state, and the states the upper levels hold) ----
-  double Fc[RB][4], G[RB][4];
-  auto direct_outputs = [&](const double (&state)[EPT], double (&F)[RB][4]) {
-    if (active) {
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) s_prop[c * LDP + q_ * EPT + e] = state[e];
-    }
-    __syncthreads();
-    double2 b[K2];
-#pragma unroll
-    for (int k = 0; k < K2; ++k) b[k] = double2{s_prop[lc * LDP + 8 * k + hi], s_prop[lc * LDP + 8 * k + 4 + hi]};
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      const double4_t g = chainmm(fA[i], b);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) F[i][r] = g[r];
-    }
-    __syncthreads();
-  };
-  direct_outputs(cur0, Fc);
-  double* __restrict__ const fs_slot = s_Fs + tid;  // this thread's piece (q - 1) RB 4 + 4 i + r of level q at stride 512
-  if (a.cascade) {
-#pragma unroll
-    for (int q = 1; q < NLEV; ++q) {
-      double Fq[RB][4];
-      direct_outputs(curU[q - 1], Fq);
-#pragma unroll
-      for (int i = 0; i < RB; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) fs_slot[((q - 1) * RB * 4 + 4 * i + r) * 512] = Fq[i][r];
-    }
-  }
-  const double llscale0 = dg0 ? -0.5 : -0.5 / a.lv[0].var;
-
-  // ---- pipeline prologue: increments of steps 0 and 1 staged, A (s inc_0) issued ----
-#pragma unroll
-  for (int e = 0; e < EPT; ++e) sxa[e] = sxl[e] = 0.0;
-  if (a.S > 0) stage_load(0, sxa);
-  if (a.S > 1) stage_load(1, sxl);
-  if (a.S > 0) stage_store(0, sxa);
-  if (a.S > 1) stage_store(1, sxl);
-  if (a.S > 2) stage_load(2, sxl);
-  if (a.S > 0) stage_own(0, sxa);
-  double unext = a.S > 0 ? a.u0[gcl] : 0.5, lunext = (has_logu && a.S > 0) ? a.logu0[gcl] : 0.0;
-  __syncthreads();
-  auto issue_products = [&](int s) {  // G = A (s inc_s) for this wave's blocks, from the staged tile of step s
-    const double2* __restrict__ row = reinterpret_cast<const double2*>(s_inc + (s & 1) * 64 * RSX + lane * RSX);
-    double2 b[K2];
-#pragma unroll
-    for (int k = 0; k < K2; ++k) b[k] = row[k];
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      const double4_t g = chainmm(fA[i], b);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) G[i][r] = g[r];
-    }
-  };
-  if (a.S > 0) issue_products(0);
-
-  // record of the last decided coarse step (state after the decision, its densities, the flag, the accept-flag window) and the
-  // loads of later steps: off the chain decision -> next proposal, issued while the matrix pipe works
-  bool rec_pending = false, rec_acc0 = false;
-  int rec_ring = 0;
-  auto flush_coarse_record = [&]() {
-    if (!rec_pending) return;
-    rec_pending = false;
-    const int row = nrec0 - 1;  // the step's record row; its ring slot is the one before the current position
-    if (active) {
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) {
-        const int j = q_ * EPT + e;
-        if (a.rec_params[0] && gct < a.N && j < a.d) a.rec_params[0][((size_t)row * a.N + gct) * a.d + j] = cur0[e];
-      }
-    }
-    if (wave == 0 && lane < 16) {
-      if (gcl < a.N) {
-        const size_t r = (size_t)row * a.N + gcl;
-        if (a.rec_stats[0]) {
-          a.rec_stats[0][r * 3 + 0] = lp0;
-          a.rec_stats[0][r * 3 + 1] = ll0;
-          a.rec_stats[0][r * 3 + 2] = lp0 + ll0;
-        }
-        if (a.rec_acc[0]) a.rec_acc[0][r] = rec_acc0 ? 1 : 0;
-      }
-      a.ring[(size_t)rec_ring * a.NP + gcl] = rec_acc0 ? 1 : 0;
-    }
-  };
-
-  for (int s = 0; s < a.S; ++s) {
-    // ================= coarse level: one Metropolis-Hastings step (chain.py:404-444) =================
-    // theta' and its prior (thread-mapped: the 32 threads of a chain are consecutive lanes of one wave)
-    DA_STAMP(0);
-    double pp = 0.0;
-    if (active) {
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) {
-        const double sx = sxa[e];
-        prp[e] = is_pcn ? keep_t * cur0[e] + sx : cur0[e] + sx;
-        if (prior_std) {
-          pp += prp[e] * prp[e];
-        } else {
-          const double dv = prp[e] - s_pm[q_ * EPT + e];
-          pp += dv * dv * s_pinv[q_ * EPT + e];
-          if (a.pr.lo && (prp[e] < a.pr.lo[q_ * EPT + e] || prp[e] > a.pr.hi[q_ * EPT + e])) pp = INFINITY;
-        }
-      }
-    }
-    // model outputs of theta' and this wave's share of the weighted residual sum (data and weights: all reads first, no branches)
-    double Fp[RB][4], yv[RB][4], wv[RB][4];
-#pragma unroll
-    for (int i = 0; i < RB; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if constexpr (aemd0) {  // this chain's corrected data y - b and inverse variances: registers for the whole subchain
-          yv[i][r] = yc[i][r];
-          wv[i][r] = wc[i][r];
-        } else {
-          yv[i][r] = s_stage[a.lds_y[0] + ob[i] + 4 * r];
-          wv[i][r] = dg0 ? s_stage[a.lds_w[0] + ob[i] + 4 * r] : 1.0;
-        }
-      }
-    double sse = 0.0;
-#pragma unroll
-    for (int i = 0; i < RB; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        Fp[i][r] = is_pcn ? keep_l * Fc[i][r] + G[i][r] : Fc[i][r] + G[i][r];
-        const double res = Fp[i][r] - yv[i][r];
-        const double sq = res * res;
-        const double sqw = dg0 ? sq * wv[i][r] : sq;
-        sse += has_b[i] ? sqw : 0.0;
-      }
-    sse = sum_rows(sse);
-    if (lane < 16) s_red[(s & 1) * 16 * NW + wave * 16 + lane] = sse;
-    // the next step's products do not depend on this step's decision: issued now, they run while it is reduced and taken
-    DA_STAMP(1);
-    __builtin_amdgcn_sched_barrier(0);
-    // (measured, tools/da_trace.py: while one wave of a SIMD streams fp64 MFMAs the vector instructions of the other make no
-    // progress at any s_setprio -- the fp64 matrix instruction occupies the fp64 vector lanes -- so the two waves' bursts and
-    // vector sections add up; what this ordering hides is the latency of the reduction, the barrier and the decision)
-    if (s + 1 < a.S) issue_products(s + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    DA_STAMP(2);
-    flush_coarse_record();  // (step s - 1)
-    if (s + 1 < a.S) stage_own(s + 1, sxa);  // (the next step's; staged by this thread before the previous barrier)
-    double u_nx = 0.5, lu_nx = 0.0;
-    if (s + 1 < a.S) {
-      u_nx = a.u0[(size_t)(s + 1) * a.NP + gcl];
-      if (has_logu) lu_nx = a.logu0[(size_t)(s + 1) * a.NP + gcl];
-    }
-    pp = sum_half_wave(pp);
-    if (q_ == 0) s_pri[(s & 1) * 16 + c] = pp;
-    if (s + 2 < a.S) stage_store(s + 2, sxl);  // loaded a step ago; its buffer was last read for step s (products: before the previous
-    if (s + 3 < a.S) stage_load(s + 3, sxl);   // barrier; this thread's own elements: at the top of this step)
-    DA_STAMP(3);
-    __syncthreads();
-    DA_STAMP(4);
-
-    double part[NW];  // all partial sums requested before the first is used: one LDS latency, not eight
-#pragma unroll
-    for (int w = 0; w < NW; ++w) part[w] = s_red[(s & 1) * 16 * NW + w * 16 + lc];
-    const double maha = s_pri[(s & 1) * 16 + lc];
-    __builtin_amdgcn_sched_barrier(0);
-    double tot = part[0];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) tot += part[w];
-    const double ll_n = llscale0 * tot;
-    const double lp_n = -0.5 * (a.pr.logconst + maha);
-    const double post_n = lp_n + ll_n;
-    const double delta = is_pcn ? ll_n - ll0 : post_n - (lp0 + ll0);
-    bool acc0;
-    if (has_logu && (fabs(lunext - delta) > 1e-9 || delta != delta)) acc0 = (post_n == post_n) && (lunext < delta);
-    else acc0 = accept_exact(unext, delta, post_n);
-    if (acc0) {
-      lp0 = lp_n;
-      ll0 = ll_n;
-#pragma unroll
-      for (int i = 0; i < RB; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Fc[i][r] = Fp[i][r];
-    }
-    anyacc0 |= acc0 ? 1 : 0;
-    DA_STAMP(5);
-    if (a.sid && acc0 && wave == 0 && lane < 16) a.sid[gcl] = step0 + 1;
-    {
-      const int accf = __shfl(acc0 ? 1 : 0, c);
-      if (active) {
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) cur0[e] = accf ? prp[e] : cur0[e];
-      }
-    }
-    unext = u_nx;
-    lunext = lu_nx;
-    rec_ring = ringidx;
-    rec_pending = true;  // the record of this step is written behind the next step's products (or before the fine level acts)
-    rec_acc0 = acc0;
-    ringidx = ringidx + 1 == a.ring_P ? 0 : ringidx + 1;
-    nrec0 += 1;
-    step0 += 1;
-    cnt0 += 1;
-    DA_STAMP(6);
-    if (!a.cascade || cnt0 != L0) continue;  // (host-sequenced level actions: the launch ends with the subchain)
-
-    // ================= upper levels whose subchain just completed (chain.py:354-402; MLDA: proposal.py:1441-1530) =========
-    // Level q = k + 1 is evaluated directly at y = the state of the levels below it (after an action of level q - 1 these all
-    // coincide with level 0's, so y is always cur0); the registers of the coarse operator serve as the fragment pipeline
-    // (the operator is fetched again afterwards).  One prior for all levels: log-prior(y) = lp0.
-    flush_coarse_record();  // an upper level may move the coarse state: its last step is recorded first
-    auto LP = [&](int j) -> double& { return j == 0 ? lp0 : lpU[j - 1]; };
-    auto LL = [&](int j) -> double& { return j == 0 ? ll0 : llU[j - 1]; };
-    // (the coarse state's model outputs wait in LDS while the level streams its fragments: this section is the register peak)
-#pragma unroll
-    for (int i = 0; i < RB; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) fs_slot[(FS_CUR + 4 * i + r) * 512] = Fc[i][r];
-    double Slp[NPAIR], Sll[NPAIR];
-#pragma unroll
-    for (int p = 0; p < NPAIR; ++p) {  // (written before the previous action's last barrier, or the kernel's first)
-      Slp[p] = s_S[(2 * p) * 16 + lc];
-      Sll[p] = s_S[(2 * p + 1) * 16 + lc];
-    }
-    bool more = true;
-#pragma unroll
-    for (int k = 0; k < NLEV - 1; ++k) {
-      if (!more) break;
-      const int q = k + 1;
-      if (active) {
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) s_thf[st_dst[e]] = cur0[e];
-      }
-      const LevelDev& L = a.lv[q];
-      frag_load_buf<DPAD>(frag_src(L.Apk, lane), wave < L.ncb ? wave : L.ncb - 1, fA[0]);
-      double uq;  // (independent of the residuals: formed while the first fragments travel)
-      if (a.u_rep[q]) uq = a.u_rep[q][(size_t)(stepU[q - 1] - a.done[q]) * a.N + (gcl < a.N ? gcl : 0)];
-      else {
-        uint32_t gc = gchain;
-        asm volatile("" : "+v"(gc));  // (the generator's chain-dependent words are formed here, not kept across the step loop)
-        uq = accept_uniform(a.seed, gc, (uint32_t)stepU[q - 1], (uint32_t)q);
-      }
-      const bool more_after = q < NLEV - 1 && cntU[q - 1] + 1 == a.sl[q];  // the level above acts right after this one
-      __syncthreads();
-      double llq;
-      {
-        // (this section is the register peak of the kernel: the second fragment buffer is the coarse operator's second block where
-        // there is one; with one block per wave the chains' parameters come from LDS block by block instead of 32 registers)
-        const double2* th_frag = reinterpret_cast<const double2*>(s_thf + lane * RSX);
-        const bool dg = L.noise_kind == 1;
-        double sq;
-        if constexpr (RB >= 2) {
-          sq = dg ? level_sse_frag<DPAD, 1, NW, false>(L.Apk, L.ncb, s_stage + a.lds_y[q], s_stage + a.lds_w[q], th_frag, wave, lane, fA[0], fA[1])
-                  : level_sse_frag<DPAD, 0, NW, false>(L.Apk, L.ncb, s_stage + a.lds_y[q], nullptr, th_frag, wave, lane, fA[0], fA[1]);
-        } else {
-          double2 fb[K2];
-          constexpr bool fresh = NLEV >= 3;  // (two levels leave the 32 registers: 2 us less per action at 2048 observations)
-          sq = dg ? level_sse_frag<DPAD, 1, NW, fresh>(L.Apk, L.ncb, s_stage + a.lds_y[q], s_stage + a.lds_w[q], th_frag, wave, lane, fA[0], fb)
-                  : level_sse_frag<DPAD, 0, NW, fresh>(L.Apk, L.ncb, s_stage + a.lds_y[q], nullptr, th_frag, wave, lane, fA[0], fb);
-        }
-        if (!more_after) load_coarse_operator();  // (the fragment registers are free: the operator returns under the decision)
-        sq = sum_rows(sq);
-        if (lane < 16) s_red[wave * 16 + lane] = sq;  // (both reduction slabs are free here: the step's was read above)
-        __syncthreads();
-        double t1 = s_red[lc];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) t1 += s_red[w * 16 + lc];
-        llq = dg ? -0.5 * t1 : -0.5 * t1 / L.var;
-      }
-      const double y_lp = LP(k), y_ll = LL(k);
-      const double lpq = y_lp;
-      const int pkq = pair_index(k, q);
-      const double alq = exp(((lpq + llq) - (lpU[q - 1] + llU[q - 1])) + (Slp[pkq] + Sll[pkq]) - (y_lp + y_ll));  // chain.py:475-483
-      const int any_below = k == 0 ? anyacc0 : anyU[k - 1];
-      const bool accq = (any_below != 0) && (uq < alq);  // skip rule: nothing accepted below -> a recorded rejection (:357-364)
-      {
-        const int accf = __shfl(accq ? 1 : 0, c);
-        if (active) {
-#pragma unroll
-          for (int e = 0; e < EPT; ++e) {
-            if (accf) {
-              curU[q - 1][e] = cur0[e];
-            } else {  // every level below q restarts from theta_q (:360-362, 394-396)
-              cur0[e] = curU[q - 1][e];
-#pragma unroll
-              for (int j = 1; j < q; ++j) curU[j - 1][e] = curU[q - 1][e];
-            }
-            const int j = q_ * EPT + e;
-            if (a.rec_params[q] && gct < a.N && j < a.d) a.rec_params[q][((size_t)nrecU[q - 1] * a.N + gct) * a.d + j] = curU[q - 1][e];
-          }
-        }
-      }
-      if (accq) {
-        lpU[q - 1] = lpq;
-        llU[q - 1] = llq;
-#pragma unroll
-        for (int i = 0; i < RB; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)  // the outputs follow the state
-            fs_slot[((q - 1) * RB * 4 + 4 * i + r) * 512] = fs_slot[(FS_CUR + 4 * i + r) * 512];
-      } else {
-#pragma unroll
-        for (int j = 0; j < q; ++j) {
-          LP(j) = Slp[pair_index(j, q)];
-          LL(j) = Sll[pair_index(j, q)];
-        }
-#pragma unroll
-        for (int i = 0; i < RB; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const double v = fs_slot[((q - 1) * RB * 4 + 4 * i + r) * 512];
-            fs_slot[(FS_CUR + 4 * i + r) * 512] = v;
-#pragma unroll
-            for (int j = 1; j < q; ++j) fs_slot[((j - 1) * RB * 4 + 4 * i + r) * 512] = v;
-          }
-      }
-#pragma unroll
-      for (int j = 0; j < q; ++j)
-#pragma unroll
-        for (int q2 = j + 1; q2 <= q; ++q2) {
-          Slp[pair_index(j, q2)] = LP(j);
-          Sll[pair_index(j, q2)] = LL(j);
-        }
-      if (k == 0) anyacc0 = 0;
-      else anyU[k - 1] = 0;
-      if (q < NLEV - 1) anyU[q - 1] |= accq ? 1 : 0;
-      if (wave == 0 && lane < 16) {
-        if (gcl < a.N) {
-          const size_t r = (size_t)nrecU[q - 1] * a.N + gcl;
-          if (a.rec_stats[q]) {
-            a.rec_stats[q][r * 3 + 0] = lpU[q - 1];
-            a.rec_stats[q][r * 3 + 1] = llU[q - 1];
-            a.rec_stats[q][r * 3 + 2] = lpU[q - 1] + llU[q - 1];
-          }
-          if (a.rec_acc[q]) a.rec_acc[q][r] = accq ? 1 : 0;
-        }
-        a.ring[(size_t)ringidx * a.NP + gcl] = accq ? 1 : 0;  // alignment entry of the coarse accept list (:363,389,397)
-      }
-      ringidx = ringidx + 1 == a.ring_P ? 0 : ringidx + 1;
-      nrecU[q - 1] += 1;
-      stepU[q - 1] += 1;
-      if (k == 0) cnt0 = 0;
-      else cntU[k - 1] = 0;
-      cntU[q - 1] += 1;
-      more = more_after;
-    }
-    if (wave == 0 && lane < 16) {
-#pragma unroll
-      for (int p = 0; p < NPAIR; ++p) {
-        s_S[(2 * p) * 16 + lc] = Slp[p];
-        s_S[(2 * p + 1) * 16 + lc] = Sll[p];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < RB; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Fc[i][r] = fs_slot[(FS_CUR + 4 * i + r) * 512];
-    __syncthreads();  // (the reduction slab and the state tile are the next step's / action's again)
-  }
-  flush_coarse_record();
-
-  if (active) {
-    int64_t gce = gct;
-    asm volatile("" : "+v"(gce));  // (addresses rebuilt here: as common subexpressions of the loads at the top they would occupy
-                                   // registers -- or scratch -- across the whole step loop)
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-      a.theta[gce * DPAD + q_ * EPT + e] = cur0[e];
-#pragma unroll
-      for (int q = 1; q < NLEV; ++q) a.theta[((size_t)q * a.NP + gce) * DPAD + q_ * EPT + e] = curU[q - 1][e];
-    }
-  }
-  if (wave == 0 && lane < 16) {
-    a.lp[gcl] = lp0;
-    a.ll[gcl] = ll0;
-    a.anyacc[gcl] = anyacc0;
-#pragma unroll
-    for (int q = 1; q < NLEV; ++q) {
-      a.lp[(size_t)q * a.NP + gcl] = lpU[q - 1];
-      a.ll[(size_t)q * a.NP + gcl] = llU[q - 1];
-      a.anyacc[(size_t)q * a.NP + gcl] = anyU[q - 1];
-    }
-#pragma unroll
-    for (int p = 0; p < NPAIR; ++p) {  // (this wave wrote the slots)
-      a.Sst[((size_t)p * 2 + 0) * a.NP + gcl] = s_S[(2 * p) * 16 + lc];
-      a.Sst[((size_t)p * 2 + 1) * a.NP + gcl] = s_S[(2 * p + 1) * 16 + lc];
-    }
-  }
+__global__ void __launch_bounds__(512, 2) k_da_steps(const MLArgs a) {
+#include "tda_kernels_da_body.inc"
+}
+template <int DPAD, int RB, bool PCN, int NZ0, int NLEV = 2>
+__global__ void __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(112))) k_da_steps_r224(const MLArgs a) {
+#include "tda_kernels_da_body.inc"
 }
 
 // ------------------------------------------------------------------------------------------------
