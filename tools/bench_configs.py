@@ -109,7 +109,7 @@ def run_hierarchy(name, ms, sl, prop, n_fine, per_eval, kernel, N=4096, d=64):
 
 def run_c3(n_fine=200):
     return run_hierarchy("C3: 2-level DA, pCN(0.02), 256/2048 obs, subsampling_rate=10", (256, 2048), [10], dict(kind=1, scaling=0.02), n_fine,
-                         2 * 256 * 64 + 2 * 2048 * 64 / 10, "k_da_steps<64,2,true,0,2>")
+                         2 * 256 * 64 + 2 * 2048 * 64 / 10, "k_da_steps_r224<64,2,true,0,2> (k_rng_direct of the next block beside it)")
 
 
 def run_da_small(n_fine=200, d=64):
