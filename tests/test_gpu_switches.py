@@ -17,7 +17,7 @@ def _probe(what, env_extra, tmp_path, tag):
     out = str(tmp_path / ("%s_%s.npz" % (what, tag)))
     env = dict(os.environ)
     for k in ("TINYDA_DA_LEAN", "TINYDA_DZ_WAVE", "TINYDA_DZ_PIPELINE", "TINYDA_AEMD_FUSED", "TINYDA_FUSE_CHOL_APPLY", "TINYDA_CHOL_BLOCKED",
-              "TINYDA_FUSE_ADAPT_CHOL", "TINYDA_AEM_BASE"):
+              "TINYDA_FUSE_ADAPT_CHOL", "TINYDA_AEM_BASE", "TINYDA_ML_SPLIT", "TINYDA_DA_R224"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "switch_probe.py"), what, out], cwd=ROOT, env=env,
@@ -36,6 +36,25 @@ def test_pipelined_level_kernel_equals_the_generic_one(what, tmp_path):
         else:
             np.testing.assert_allclose(lean[k], generic[k], rtol=1e-10, atol=1e-12, err_msg=k)
     assert 0.02 < lean["acc0"].mean() < 0.98
+
+
+@pytest.mark.parametrize("what", ["da2", "da2_ragged", "mlda3", "mlda3_ragged"])
+def test_draws_on_the_second_stream_change_nothing(what, tmp_path):
+    """run_multilevel draws block b + 1 under block b's level kernel when the generator fits beside it (the 224-register entry
+    points of k_da_steps) -- against TINYDA_ML_SPLIT=0: one stream, k_propose in front of every block, the kernel as compiled.
+    pCN with the identity factor (da2): the same arithmetic, so the same bits.  AdaptiveMetropolis (mlda3): increments by k_apply
+    / the swap launch instead of k_propose, the same products in the same order."""
+    on, off = _probe(what, {}, tmp_path, "split"), _probe(what, {"TINYDA_ML_SPLIT": "0"}, tmp_path, "one_stream")
+    for k in on:
+        if k.startswith("acc") or what.startswith("da2"):
+            assert np.array_equal(on[k], off[k]), "%s differs (%s)" % (k, what)
+        else:
+            np.testing.assert_allclose(on[k], off[k], rtol=1e-10, atol=1e-12, err_msg=k)
+    assert 0.02 < on["acc0"].mean() < 0.98
+    # the 224-register entry point against the kernel as compiled, both with the draws on the second stream
+    plain = _probe(what, {"TINYDA_DA_R224": "0", "TINYDA_ML_SPLIT": "1"}, tmp_path, "plain_kernel")
+    for k in on:
+        assert np.array_equal(on[k], plain[k]), "%s differs between the two entry points (%s)" % (k, what)
 
 
 @pytest.mark.parametrize("what", ["am", "am_ragged"])

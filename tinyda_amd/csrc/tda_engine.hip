@@ -557,12 +557,25 @@ int launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st, int* f
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));                                         \
     hipLaunchKernelGGL((k_da_steps<DPAD, RBV, PCNV, NZV, NLV>), dim3((unsigned)tiles), dim3(512), lds8, st, a);                    \
   } while (0)
+    auto go224 = [&](auto kern) -> int {  // (the 224-register entry points)
+      if (free_regs) return regs_left(reinterpret_cast<const void*>(kern), 2);
+      if (lds8 > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+      hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds8, st, a);
+      return TDA_OK;
+    };
+    (void)go224;
     if (a.aem_on == 2) {  // (instantiated for 33..64 parameters and one operator block per wave: da_lean_eligible)
       if constexpr (DPAD == 64) {
         if (a.nlev == 3) { if (pcn) TDA_DA_LAUNCH(1, true, 2, 3); else TDA_DA_LAUNCH(1, false, 2, 3); }
         else { if (pcn) TDA_DA_LAUNCH(1, true, 2, 2); else TDA_DA_LAUNCH(1, false, 2, 2); }
       }
     } else if (a.nlev == 3) {  // (one operator block per wave: da_lean_eligible)
+      if constexpr (DPAD == 64) {
+        if (lean224 && r224_ok) {
+          if (pcn) return dg0 ? go224(&k_da_steps_r224<DPAD, 1, true, 1, 3>) : go224(&k_da_steps_r224<DPAD, 1, true, 0, 3>);
+          return dg0 ? go224(&k_da_steps_r224<DPAD, 1, false, 1, 3>) : go224(&k_da_steps_r224<DPAD, 1, false, 0, 3>);
+        }
+      }
       if (pcn) { if (dg0) TDA_DA_LAUNCH(1, true, 1, 3); else TDA_DA_LAUNCH(1, true, 0, 3); }
       else { if (dg0) TDA_DA_LAUNCH(1, false, 1, 3); else TDA_DA_LAUNCH(1, false, 0, 3); }
     } else if (one) {
@@ -571,12 +584,6 @@ int launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st, int* f
     } else {
       if constexpr (DPAD == 64) {  // (smaller paddings leave the room as they are; with diagonal noise the budget would spill 12)
         if (lean224 && r224_ok && !dg0) {
-          auto go224 = [&](auto kern) -> int {
-            if (free_regs) return regs_left(reinterpret_cast<const void*>(kern), 2);
-            if (lds8 > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
-            hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds8, st, a);
-            return TDA_OK;
-          };
           return pcn ? go224(&k_da_steps_r224<DPAD, 2, true, 0, 2>) : go224(&k_da_steps_r224<DPAD, 2, false, 0, 2>);
         }
       }

@@ -573,7 +573,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
 // ------------------------------------------------------------------------------------------------
 template <int DPAD>
 __host__ __device__ constexpr int da_lds_doubles(int stage_total) {
-  return 16 * (DPAD + 2) + 2 * 64 * (DPAD / 4 + 2) + 2 * 16 * 8 + 2 * 16 + 4 * DPAD + 2 * 16 + 6 * 16 + 64 * (DPAD / 4 + 2) + 16 * 512 + stage_total;
+  return 16 * (DPAD + 2) + 2 * 64 * (DPAD / 4 + 2) + 2 * 16 * 8 + 2 * 16 + 4 * DPAD + 2 * 16 + 8 * 2 * 2 * 16 + 6 * 16 + 64 * (DPAD / 4 + 2) + 16 * 512 + stage_total;
 }
 
 #ifdef TDA_DA_TRACE
