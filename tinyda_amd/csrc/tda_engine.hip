@@ -112,7 +112,7 @@ void pack_fragments(const double* A, int rows, int cols, int dpad, std::vector<d
 // Device-memory pool: an engine holds ~1.2 GB of block buffers at BASELINE config 2, and tda.sample() creates and destroys
 // one engine per call.  hipMalloc / hipFree of that set cost 10-20 ms per call (hipFree synchronises the device), which is
 // as long as 1000 iterations of 4096 chains take.  Released buffers are therefore kept per (device, byte count) and handed
-// out again -- zeroed, as fresh allocations are -- up to TINYDA_POOL_GB (default 8) GiB; tda_release_cached_memory() returns
+// out again -- zeroed, as fresh allocations are -- up to TINYDA_POOL_GB GiB (default 8, at most an eighth of the free memory); tda_release_cached_memory() returns
 // them to the driver, as does an allocation failure before it is reported.
 struct DevPool {
   std::mutex mu;
@@ -123,6 +123,10 @@ struct DevPool {
     if (!cap_read) {
       const char* v = getenv("TINYDA_POOL_GB");
       cap = (size_t)((v ? atof(v) : 8.0) * 1073741824.0);
+      if (!v) {  // default: 8 GiB, but never more than an eighth of what the device has free when the pool is first used
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 8 < cap) cap = free_b / 8;
+      }
       cap_read = true;
     }
     return cap;

@@ -121,7 +121,7 @@ def run_da_small(n_fine=200, d=64):
 def run_c5(n_fine=60):
     return run_hierarchy("C5-literal: 3-level MLDA, AM, 128/512/2048 obs, subchains [5,3], no error model", (128, 512, 2048), [5, 3],
                          dict(kind=2, C_=1e-4 * np.eye(64), t0=100, period=100), n_fine,
-                         2 * 64 * (128 + 512 / 5 + 2048 / 15), "k_da_steps<64,1,false,0,3>")
+                         2 * 64 * (128 + 512 / 5 + 2048 / 15), "k_da_steps_r224<64,1,false,0,3> (k_rng of the next block beside it)")
 
 
 def run_c5_aem(N=4096, d=64, m=128, n_fine=20, diagonal=False):
@@ -160,7 +160,7 @@ def run_c5_aem(N=4096, d=64, m=128, n_fine=20, diagonal=False):
         return _roof(res, "mfma", per_eval, N * rows[0], p["ms_steps"] + p["ms_propose"] + p["ms_adapt"], dt, "k_ml_steps + k_aemd_*")
     per_eval = 2 * 64 * m * (1 + 1 / 5 + 1 / 15) + 2 * m * m * (1 + 2 / 15 + 4 / 15) + 4 * m ** 3 / 15
     bucket = p.get("ms_aem") or p["ms_adapt"]
-    return _roof(res, "mfma", per_eval, N * rows[0], bucket, dt, "error-model refresh (k_aem_action + k_aem_inverse)")
+    return _roof(res, "mfma", per_eval, N * rows[0], bucket, dt, "error-model refresh (k_aem_action + k_aem_refresh)")
 
 
 def run_mala(N=4096, d=64, m=1024, T=2000):
