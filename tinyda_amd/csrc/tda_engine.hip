@@ -309,6 +309,11 @@ struct tda_engine {
   hipStream_t rng_stream = nullptr;
   hipEvent_t ev_rng[2] = {nullptr, nullptr}, ev_apply[2] = {nullptr, nullptr}, ev_steps[2] = {nullptr, nullptr};
   DevBuf<double> zfrag[2], ublk2[2], lublk2[2];
+  // hierarchies under AdaptiveMetropolis whose blocks are shorter than the adaptation period (the error model cuts them at every
+  // base subchain): the states of the current period not yet folded into the moments (run_multilevel)
+  DevBuf<double> am_stage;
+  int64_t am_pending = 0, am_pending_t0 = 0;
+  const double* am_pending_rows = nullptr;
   DevBuf<uint8_t> rec_acc;
 
   // multi-level state (n_levels > 1)

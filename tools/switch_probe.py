@@ -1,6 +1,6 @@
 """One seeded run of a configuration whose kernel choice an environment switch changes; records to an .npz.  The switches are
 read once per process, so A/B comparisons start this script twice (tests/test_gpu_switches.py).
-    python tools/switch_probe.py {mlda3|da2|aemd|aemd_lean|aem_dense|aem_dense_da_pcn|dream|am}[_ragged] out.npz     (_ragged: a chain count that is not a multiple of the 16-chain tile)"""
+    python tools/switch_probe.py {mlda3|mlda3_short|da2|aemd|aemd_lean|aem_dense|aem_dense_da_pcn|dream|am}[_ragged] out.npz     (_ragged: a chain count that is not a multiple of the 16-chain tile)"""
 import os
 import sys
 
@@ -72,6 +72,8 @@ if __name__ == "__main__":
     cut = 7 if ragged else 0  # the last tile holds 9 chains
     if what == "mlda3":
         res = hierarchy((128, 256, 512), [5, 3], "am", 6, N=256 - cut)
+    elif what == "mlda3_short":  # run() calls that end inside an adaptation period (20 base steps): 15 base steps per finest iteration
+        res = hierarchy((128, 256, 512), [5, 3], "am", 5, N=64)
     elif what == "da2":
         res = hierarchy((256, 1024), [10], "pcn", 8, N=256 - cut)
     elif what == "aemd":
