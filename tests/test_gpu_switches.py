@@ -17,7 +17,7 @@ def _probe(what, env_extra, tmp_path, tag):
     out = str(tmp_path / ("%s_%s.npz" % (what, tag)))
     env = dict(os.environ)
     for k in ("TINYDA_DA_LEAN", "TINYDA_DZ_WAVE", "TINYDA_DZ_PIPELINE", "TINYDA_AEMD_FUSED", "TINYDA_FUSE_CHOL_APPLY", "TINYDA_CHOL_BLOCKED",
-              "TINYDA_FUSE_ADAPT_CHOL", "TINYDA_AEM_BASE", "TINYDA_ML_SPLIT", "TINYDA_DA_R224", "TINYDA_AM_DEFER"):
+              "TINYDA_FUSE_ADAPT_CHOL", "TINYDA_AEM_BASE", "TINYDA_ML_SPLIT", "TINYDA_DA_R224", "TINYDA_AM_DEFER", "TINYDA_ML_PREDRAW"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "switch_probe.py"), what, out], cwd=ROOT, env=env,
@@ -105,6 +105,16 @@ def test_deferred_moment_recursion_is_bitwise_the_per_block_one(what, tmp_path):
     states are folded into the moments in one launch at the boundary instead of block by block (TINYDA_AM_DEFER=0) -- the same
     recursion over the same states in the same order"""
     a, b = _probe(what, {}, tmp_path, "deferred"), _probe(what, {"TINYDA_AM_DEFER": "0"}, tmp_path, "per_block")
+    for k in a:
+        assert np.array_equal(a[k], b[k]), "%s differs (%s)" % (k, what)
+    assert 0.02 < a["acc0"].mean() < 0.98
+
+
+@pytest.mark.parametrize("what", ["aem_dense", "aemd_lean", "aem_dense_da_pcn", "aemd"])
+def test_window_of_draws_is_bitwise_the_per_block_draws(what, tmp_path):
+    """error-model hierarchies: proposal increments and uniforms of a whole window of steps in one launch, the blocks (one base
+    subchain each) walking through it -- against one k_propose per block (TINYDA_ML_PREDRAW=0): the same counters, the same draws"""
+    a, b = _probe(what, {}, tmp_path, "window"), _probe(what, {"TINYDA_ML_PREDRAW": "0"}, tmp_path, "per_block")
     for k in a:
         assert np.array_equal(a[k], b[k]), "%s differs (%s)" % (k, what)
     assert 0.02 < a["acc0"].mean() < 0.98
