@@ -326,8 +326,13 @@ struct DreamStepArgs {
 
 // DENSE: the instance for a dense observation covariance (a template parameter: as a run-time branch it cost the plain instances
 // 12 / 30 more spilled registers)
+// (waves per SIMD: at 64 parameters -- and at 32 with the dense quadratic form -- the tile's state needs up to ~400 registers per
+// wave; at two waves per SIMD those instances spilled 154 / 163 / 6 registers with reloads inside the step loop)
+#ifndef DZ_TILE_WAVES_PER_EU
+#define DZ_TILE_WAVES_PER_EU ((DPAD >= 64 || (DENSE && DPAD >= 32)) ? 1 : 2)
+#endif
 template <int DPAD, bool DENSE = false>
-__global__ void __launch_bounds__(256, 2) k_dreamz_steps(const DreamStepArgs a) {
+__global__ void __launch_bounds__(256, DZ_TILE_WAVES_PER_EU) k_dreamz_steps(const DreamStepArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int KS = DPAD / 4;
   constexpr int LDP = DPAD + 2;
