@@ -4,6 +4,7 @@ with the per-chain Python loop replaced by the HIP engine for every configuratio
 Extra keyword-only arguments (not in the reference): seed, backend, device, chain_offset.
 """
 import copy
+import gc
 import os
 import warnings
 from collections.abc import Mapping
@@ -318,14 +319,23 @@ def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None
     if thin > 1 and (plan is None or n_levels > 1 or isinstance(proposal, DREAMZ)):
         raise NotImplementedError("thin > 1 is a single-level device option (GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis / MALA ...)")
     if plan is not None:
-        if n_levels == 1:
-            return _sample_device(plan, posteriors[0], iterations, n_chains, initial_parameters, seed, device,
-                                  chain_offset, distributed, total if distributed else None, overlap_archive_exchange,
-                                  shared_archive == "distributed", thin, force_progress_bar)
-        return _sample_device_multilevel(plan, posteriors, iterations, n_chains, initial_parameters, subchain_length,
-                                         subchain_lengths, randomize_subchain_length, store_coarse_chain, seed, device,
-                                         chain_offset, "state-independent-diagonal" if diag_aem else adaptive_error_model,
-                                         force_progress_bar)
+        # The result holds one view object per chain and level; building thousands of them in one call is what trips the
+        # interpreter's generational collector into a full pass over every live object of the process (70 ms, a third of the calls
+        # at BASELINE config 5, whose whole run takes 11).  Nothing built here is cyclic garbage: the collector rests for the call.
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            if n_levels == 1:
+                return _sample_device(plan, posteriors[0], iterations, n_chains, initial_parameters, seed, device,
+                                      chain_offset, distributed, total if distributed else None, overlap_archive_exchange,
+                                      shared_archive == "distributed", thin, force_progress_bar)
+            return _sample_device_multilevel(plan, posteriors, iterations, n_chains, initial_parameters, subchain_length,
+                                             subchain_lengths, randomize_subchain_length, store_coarse_chain, seed, device,
+                                             chain_offset, "state-independent-diagonal" if diag_aem else adaptive_error_model,
+                                             force_progress_bar)
+        finally:
+            if gc_was_on:
+                gc.enable()
     if n_levels > 1:
         return _sample_host_multilevel(posteriors, proposal, iterations, n_chains, initial_parameters, subchain_length,
                                        subchain_lengths, randomize_subchain_length, adaptive_error_model, store_coarse_chain,

@@ -165,19 +165,28 @@ class DeviceChain(Sequence):
     is materialised only when indexed.  `get_samples` reads all chains of a result in one pass (DeviceRecords.all_chains_host).
 
     DeviceChain(records, chain_index, model) over DeviceRecords, or DeviceChain(parameters, stats, accepted, model) over host
-    arrays of one chain."""
+    arrays of one chain.
+
+    A result holds one of these per chain and level (12 288 at BASELINE config 5): no instance dictionary, no cache object until
+    something is fetched -- the interpreter's cyclic collector walks every tracked object, and a result three times the size
+    pushed a full collection (70 ms) into every third `sample()` call."""
+
+    __slots__ = ("_records", "_chain", "_rows", "_model", "_cache")
 
     def __init__(self, parameters, stats=None, accepted=None, model=None, rows=slice(None)):
         if isinstance(parameters, DeviceRecords):
             self._records, self._chain, self._rows = parameters, int(stats), rows
             self._model = accepted if model is None else model
-            self._cache = {}
+            self._cache = None
         else:
             self._records = None
+            self._rows = self._chain = None
             self._cache = {"parameters": parameters, "stats": stats, "accepted": accepted}
             self._model = model
 
     def _get(self, field):
+        if self._cache is None:
+            self._cache = {}
         if field not in self._cache:
             self._cache[field] = self._records.chain_host(field, self._chain, self._rows)
         return self._cache[field]
@@ -195,7 +204,7 @@ class DeviceChain(Sequence):
         return self._get("accepted")
 
     def __len__(self):
-        if self._records is not None and "parameters" not in self._cache:
+        if self._records is not None and (self._cache is None or "parameters" not in self._cache):
             return len(range(*self._rows.indices(self._records.n_rows)))
         return self.parameters.shape[0]
 
