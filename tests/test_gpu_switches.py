@@ -17,7 +17,7 @@ def _probe(what, env_extra, tmp_path, tag):
     out = str(tmp_path / ("%s_%s.npz" % (what, tag)))
     env = dict(os.environ)
     for k in ("TINYDA_DA_LEAN", "TINYDA_DZ_WAVE", "TINYDA_DZ_PIPELINE", "TINYDA_AEMD_FUSED", "TINYDA_FUSE_CHOL_APPLY", "TINYDA_CHOL_BLOCKED",
-              "TINYDA_FUSE_ADAPT_CHOL", "TINYDA_AEM_BASE", "TINYDA_ML_SPLIT", "TINYDA_DA_R224", "TINYDA_AM_DEFER", "TINYDA_ML_PREDRAW"):
+              "TINYDA_FUSE_ADAPT_CHOL", "TINYDA_AEM_BASE", "TINYDA_ML_SPLIT", "TINYDA_DA_R224", "TINYDA_AM_DEFER", "TINYDA_ML_PREDRAW", "TINYDA_AEM_PRE"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "switch_probe.py"), what, out], cwd=ROOT, env=env,
@@ -117,6 +117,20 @@ def test_window_of_draws_is_bitwise_the_per_block_draws(what, tmp_path):
     a, b = _probe(what, {}, tmp_path, "window"), _probe(what, {"TINYDA_ML_PREDRAW": "0"}, tmp_path, "per_block")
     for k in a:
         assert np.array_equal(a[k], b[k]), "%s differs (%s)" % (k, what)
+    assert 0.02 < a["acc0"].mean() < 0.98
+
+
+@pytest.mark.parametrize("what", ["aem_dense", "aem_dense_ragged", "aem_dense_da_pcn"])
+def test_error_model_outputs_on_the_matrix_cores_agree(what, tmp_path):
+    """dense error model over linear levels: the model outputs k_aem_action needs for all chains from one k_linear_outputs_multi launch
+    (an operator fragment serves a 16-chain tile) against three matrix-vector products per chain inside the kernel
+    (TINYDA_AEM_PRE=0): the same products summed in another order -- decisions equal, densities to rounding"""
+    a, b = _probe(what, {}, tmp_path, "pre"), _probe(what, {"TINYDA_AEM_PRE": "0"}, tmp_path, "gemv")
+    for k in a:
+        if k.startswith("acc"):
+            assert np.array_equal(a[k], b[k]), "%s: %d accept flips" % (k, int((a[k] != b[k]).sum()))
+        else:
+            np.testing.assert_allclose(a[k], b[k], rtol=1e-10, atol=1e-12, err_msg=k)
     assert 0.02 < a["acc0"].mean() < 0.98
 
 

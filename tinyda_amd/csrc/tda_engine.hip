@@ -344,6 +344,7 @@ struct tda_engine {
   DevBuf<double> aem_bias[tda::MAXLEV], aem_covinv[tda::MAXLEV], aem_bmu[tda::MAXLEV], aem_bsig[tda::MAXLEV], aem_mdiff[tda::MAXLEV];
   DevBuf<double> aem_rvec;  // [NP][aem_ld] bias-corrected residual the action kernels leave for k_aem_refresh's update_link
   DevBuf<double> aem_upd;   // [NP][3][aem_ld] vectors of the tracker covariance update they leave for it
+  DevBuf<double> aem_F;     // [4][NP][aem_ld] model outputs of levels q, q - 1 at the states of levels q - 1, q (k_linear_outputs_multi -> k_aem_action)
   int64_t aem_bt[tda::MAXLEV] = {1, 1, 1, 1};
   DevBuf<int64_t> ml_sid;
   DevBuf<double> prior_W_rm;

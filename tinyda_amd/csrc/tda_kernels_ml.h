@@ -613,14 +613,15 @@ __global__ void __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(112))) 
 // N m d 8 bytes through L2 per launch: 256 MB at 4096 chains, m = 128, 2 GB at m = 1024.)
 // ------------------------------------------------------------------------------------------------
 template <int DPAD>
-__global__ void __launch_bounds__(256) k_linear_outputs(long long N, int d, int m, const double* __restrict__ Apk, int ncb,
-                                                        const double* __restrict__ bvec, const double* __restrict__ prop, int ldp,
-                                                        double* __restrict__ F) {  // prop: rows of ldp doubles ([N][d] or a state array)
+__device__ __forceinline__ void linear_outputs_tile(long long N, int d, int m, const double* __restrict__ Apk, int ncb,
+                                                    const double* __restrict__ bvec, const double* __restrict__ prop, int ldp,
+                                                    double* __restrict__ F, int ldf, long long tile) {  // prop: rows of ldp doubles ([N][d] or a state array); bvec may be null
+
   constexpr int KS = DPAD / 4, K2 = DPAD / 8, NWV = 4;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lc = lane & 15, hi = lane >> 4;
-  const long long c = (long long)blockIdx.x * 16 + lc;
+  const long long c = tile * 16 + lc;
   double th[KS];
 #pragma unroll
   for (int kk = 0; kk < KS; ++kk) th[kk] = (c < N && 4 * kk + hi < d) ? prop[c * ldp + 4 * kk + hi] : 0.0;
@@ -641,7 +642,7 @@ __global__ void __launch_bounds__(256) k_linear_outputs(long long N, int d, int 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int o = cb * 16 + hi + 4 * r;
-        if (c < N && o < m) F[c * m + o] = acc[r] + bvec[o];
+        if (c < N && o < m) F[c * ldf + o] = acc[r] + (bvec ? bvec[o] : 0.0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -658,11 +659,34 @@ __global__ void __launch_bounds__(256) k_linear_outputs(long long N, int d, int 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int o = (cb + NWV) * 16 + hi + 4 * r;
-        if (c < N && o < m) F[c * m + o] = acc[r] + bvec[o];
+        if (c < N && o < m) F[c * ldf + o] = acc[r] + (bvec ? bvec[o] : 0.0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+template <int DPAD>
+__global__ void __launch_bounds__(256) k_linear_outputs(long long N, int d, int m, const double* __restrict__ Apk, int ncb,
+                                                        const double* __restrict__ bvec, const double* __restrict__ prop, int ldp,
+                                                        double* __restrict__ F) {
+  linear_outputs_tile<DPAD>(N, d, m, Apk, ncb, bvec, prop, ldp, F, m, (long long)blockIdx.x);
+}
+// several products in one launch (blockIdx.y picks the item): the model outputs k_aem_action needs -- levels q and q - 1 at the
+// states of levels q - 1 and q -- for every chain on the matrix cores, an operator fragment serving a 16-chain tile, instead of
+// three matrix-vector products per chain inside that kernel (each chain read the whole operator from L2: 0.8 GB per launch at
+// 4096 chains x 128 outputs, the larger part of the kernel's time)
+struct LinMultiArgs {
+  long long N;
+  int d, m, ldp, ldf, n;
+  const double* Apk[4];
+  int ncb[4];
+  const double* prop[4];
+  double* F[4];
+};
+template <int DPAD>
+__global__ void __launch_bounds__(256) k_linear_outputs_multi(const LinMultiArgs a) {
+  const int w = blockIdx.y;
+  linear_outputs_tile<DPAD>(a.N, a.d, a.m, a.Apk[w], a.ncb[w], nullptr, a.prop[w], a.ldp, a.F[w], a.ldf, (long long)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -679,6 +703,7 @@ struct AemArgs {
   int is_da, dependent, prop_kind;
   uint64_t seed;
   int64_t step;            // index of this level-q step (RNG / replay row)
+  const double* Fpre[4];       // [NP][MP] each, or null: A_q theta_{q-1}, A_q theta_q, A_{q-1} theta_{q-1}, A_{q-1} theta_q (k_linear_outputs_multi)
   const double* A[MAXLEV];     // row-major [m][d]
   const double* ytil[MAXLEV];  // y - b, [MP]   (residual r = A theta - ytil = F - y)
   const double* data[MAXLEV];  // y, [MP]       (model output F = r + y)
@@ -731,6 +756,10 @@ __global__ void __launch_bounds__(MPT) k_aem_action(const AemArgs a) {
     return v;
   };
   // F_lev(theta)[lane] - ytil_lev[lane]  (theta given through LDS vector s_v[0..d))
+  const bool pre = a.Fpre[0] != nullptr;
+  auto resid_pre = [&](int which, int lev) {  // the same from the products of k_linear_outputs_multi
+    return lo ? a.Fpre[which][c * MP + lane] - a.ytil[lev][lane] : 0.0;
+  };
   auto resid = [&](int lev) {
     double f = 0.0;
     if (lo) {
@@ -773,8 +802,8 @@ __global__ void __launch_bounds__(MPT) k_aem_action(const AemArgs a) {
   __syncthreads();
   s_v[lane] = yj;
   __syncthreads();
-  const double rq_y = resid(q);                   // F_q(y) - ytil_q
-  const double rk_y = a.dependent ? resid(k) : 0.0;  // F_k(y) - ytil_k
+  const double rq_y = pre ? resid_pre(0, q) : resid(q);                          // F_q(y) - ytil_q
+  const double rk_y = a.dependent ? (pre ? resid_pre(2, k) : resid(k)) : 0.0;  // F_k(y) - ytil_k
   const double lpn = y_lp;  // same prior, same parameters (posterior.py:92)
   const double lln = loglike_of(q, rq_y);
   double alpha;
@@ -784,7 +813,7 @@ __global__ void __launch_bounds__(MPT) k_aem_action(const AemArgs a) {
     __syncthreads();
     s_v[lane] = xj;  // subchain start = the fine state
     __syncthreads();
-    const double rk_x = resid(k);
+    const double rk_x = pre ? resid_pre(3, k) : resid(k);
     const double ll_b = quad(k, lo ? rk_x + bias_next : 0.0);
     double q_xy = 0.0, q_yx = 0.0;
     if (a.prop_kind == 1) {  // pCN transition densities (proposal.py:364-369) between the fine links
@@ -860,7 +889,9 @@ __global__ void __launch_bounds__(MPT) k_aem_action(const AemArgs a) {
   __syncthreads();
   s_v[lane] = cj;
   __syncthreads();
-  const double rq = resid(q), rk = resid(k);
+  // (the state is y = theta_k after an acceptance, x = theta_q after a rejection: both were multiplied out ahead of the decision)
+  const double rq = pre ? (acc ? rq_y : resid_pre(1, q)) : resid(q);
+  const double rk = pre ? resid_pre(acc ? 2 : 3, k) : resid(k);
   const double diff_new = lo ? (rq + a.data[q][lane]) - (rk + a.data[k][lane]) : 0.0;
   double* md = a.mdiff[q] + c * MP;
   const double t = (double)a.b_t;
