@@ -333,3 +333,18 @@ def test_record_buffers_fall_back_when_the_device_is_full(monkeypatch):
         warnings.simplefilter("always")
         bufs = api._record_buffers(fake, "cuda:0", shapes)
     assert [(b[2], b[3]) for b in bufs] == [("cpu", True), ("cpu", True)] and any(issubclass(x.category, ResourceWarning) for x in w)
+
+
+def test_result_views_carry_no_instance_dictionary_and_survive_pickle_and_copy():
+    """a device result holds one DeviceChain per chain and level (12 288 at BASELINE config 5): slots only -- the interpreter's
+    cyclic collector walks every tracked object -- and still picklable / copyable / sliceable like the list of links it stands for"""
+    import copy
+    import pickle
+
+    from tinyda_amd.records import DeviceChain
+
+    c = DeviceChain(np.arange(15.0).reshape(5, 3), np.zeros((5, 3)), np.ones(5, dtype=np.uint8), None)
+    assert not hasattr(c, "__dict__")
+    for other in (pickle.loads(pickle.dumps(c)), copy.deepcopy(c), copy.copy(c)):
+        assert len(other) == 5 and np.array_equal(other.parameters, c.parameters)
+    assert c[1:3].parameters.shape == (2, 3) and c[4].parameters.shape == (3,)
