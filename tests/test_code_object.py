@@ -38,12 +38,13 @@ HOT = {
 # they are known to have (a cap per instance, so that neither a new spiller nor a worse one goes unnoticed).
 #   k_aem_refresh<8, *>  one wave per SIMD with 512 registers by design (the 128 x 128 matrix lives in registers); what is spilled
 #                        is reloaded once, outside any loop (straight-line code)
-#   k_ml_steps<64,3|4,4,false> the generic level kernel with three / four levels in one launch (C5 runs k_da_steps);
+#   k_ml_steps<64,3|4,4,false> the generic level kernel with three / four levels in one launch (C5 runs k_da_steps): 10 / 7 since the
+#                              upper levels' state waits in LDS between level actions (46 / 117 before);
 #   k_ml_steps<64,*,4,true>    its instances for hierarchies with a dense observation covariance on some level (round 4)
 KNOWN_SPILLERS = {
     "_ZN3tda13k_aem_refreshILi8ELi1EEE": 40, "_ZN3tda13k_aem_refreshILi8ELi2EEE": 48, "_ZN3tda13k_aem_refreshILi8ELi3EEE": 96,
-    "_ZN3tda10k_ml_stepsILi64ELi3ELi4ELb0EEE": 56, "_ZN3tda10k_ml_stepsILi64ELi4ELi4ELb0EEE": 128,
-    "_ZN3tda10k_ml_stepsILi64ELi2ELi4ELb1EEE": 48, "_ZN3tda10k_ml_stepsILi64ELi3ELi4ELb1EEE": 136, "_ZN3tda10k_ml_stepsILi64ELi4ELi4ELb1EEE": 232,
+    "_ZN3tda10k_ml_stepsILi64ELi3ELi4ELb0EEE": 16, "_ZN3tda10k_ml_stepsILi64ELi4ELi4ELb0EEE": 16,
+    "_ZN3tda10k_ml_stepsILi64ELi2ELi4ELb1EEE": 32, "_ZN3tda10k_ml_stepsILi64ELi3ELi4ELb1EEE": 80, "_ZN3tda10k_ml_stepsILi64ELi4ELi4ELb1EEE": 112,
 }
 
 

@@ -91,7 +91,13 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
   constexpr int NPAIR = NLEV * (NLEV - 1) / 2;
 
   const bool prior_dense = a.pr.kind == PRIOR_DENSE;
-  double* s_prop = smem;
+  // what the levels above the base hold -- states (thread-mapped), densities and flags (lane-mapped, one copy per wave) -- waits in
+  // LDS between level actions: as registers across the base steps it is 60 of them at four levels, in a kernel that spills
+  constexpr int UP_T = (NLEV - 1) * EPT;                        // doubles per thread
+  constexpr int UP_L = 3 * (NLEV - 1) + 2 * NPAIR;              // doubles per lane-mapped chain and wave
+  double* s_upt = smem;                                          // [UP_T][NT]
+  double* s_upl = s_upt + UP_T * NT;                             // [NW][UP_L][16]
+  double* s_prop = s_upl + NW * UP_L * 16;
   double* s_red = s_prop + 16 * LDP;
   double* s_redp = s_red + 16 * NW;
   double* s_stage = s_redp + 16 * NW;      // ytil / w of every level
@@ -159,6 +165,47 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
   const double keep_t = is_pcn ? sqrt(1.0 - scal_t * scal_t) : 1.0;
   double unext = a.u0[gcl];
 
+  auto stash_upper = [&]() {
+    if constexpr (NLEV > 1) {
+#pragma unroll
+      for (int k = 1; k < NLEV; ++k)
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) s_upt[((k - 1) * EPT + e) * NT + tid] = cur[k][e];
+      double* __restrict__ ul = s_upl + wave * (UP_L * 16) + lc;
+#pragma unroll
+      for (int k = 1; k < NLEV; ++k) {
+        ul[(3 * (k - 1) + 0) * 16] = lp[k];
+        ul[(3 * (k - 1) + 1) * 16] = ll[k];
+        ul[(3 * (k - 1) + 2) * 16] = (double)anyacc[k];
+      }
+#pragma unroll
+      for (int p = 0; p < NPAIR; ++p) {
+        ul[(3 * (NLEV - 1) + 2 * p) * 16] = Slp[p];
+        ul[(3 * (NLEV - 1) + 2 * p + 1) * 16] = Sll[p];
+      }
+    }
+  };
+  auto fetch_upper = [&]() {
+    if constexpr (NLEV > 1) {
+#pragma unroll
+      for (int k = 1; k < NLEV; ++k)
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) cur[k][e] = s_upt[((k - 1) * EPT + e) * NT + tid];
+      const double* __restrict__ ul = s_upl + wave * (UP_L * 16) + lc;
+#pragma unroll
+      for (int k = 1; k < NLEV; ++k) {
+        lp[k] = ul[(3 * (k - 1) + 0) * 16];
+        ll[k] = ul[(3 * (k - 1) + 1) * 16];
+        anyacc[k] = (int)ul[(3 * (k - 1) + 2) * 16];
+      }
+#pragma unroll
+      for (int p = 0; p < NPAIR; ++p) {
+        Slp[p] = ul[(3 * (NLEV - 1) + 2 * p) * 16];
+        Sll[p] = ul[(3 * (NLEV - 1) + 2 * p + 1) * 16];
+      }
+    }
+  };
+  stash_upper();
   int cnt[NLEV];
   int64_t stepno[NLEV];  // local step index (global, for RNG) of the NEXT step of level k
   int nrec[NLEV];        // records written by this launch per level
@@ -424,9 +471,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
     cnt[0] += 1;
 
     // ================= upper levels whose subchain just completed =================
+    if (NLEV > 1 && a.cascade && cnt[0] == a.sl[0]) {
+    fetch_upper();
 #pragma unroll
     for (int k = 0; k < NLEV - 1; ++k) {
-      if (!a.cascade || cnt[k] != a.sl[k]) break;
+      if (cnt[k] != a.sl[k]) break;
       const int q = k + 1;
       const bool use_snap = (a.randomize != 0) && k == 0;
       // y -> LDS for the fragment gather
@@ -519,9 +568,12 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
       cnt[k] = 0;
       cnt[q] += 1;
     }
+    stash_upper();
+    }
   }
 
   // ---- write the state back ----
+  fetch_upper();
 #pragma unroll
   for (int k = 0; k < NLEV; ++k) {
     if (active) {

@@ -99,6 +99,12 @@ CASES = [
 ]
 
 if __name__ == "__main__":
+    if "--lib" in sys.argv:  # A/B against another build of the library:  --lib path/to/libtinyda_hip.so
+        from tinyda_amd import _lib
+
+        i = sys.argv.index("--lib")
+        _lib.LIB_PATH = os.path.abspath(sys.argv[i + 1])
+        del sys.argv[i:i + 2]
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
     for name, fn in CASES:
         if flt not in name:
