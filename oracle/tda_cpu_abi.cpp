@@ -16,6 +16,13 @@
  *   adapt      t += 1, scaling, RecursiveSampleMoments.update, C <- Sigma      proposal.py:228-245, :502-512; utils.py:113-124
  * The factor of C is cached between swaps (NumPy's multivariate_normal re-runs an SVD per draw), so this is faster than the
  * reference itself -- a reported baseline, not a target.
+ *
+ * Round 5 ("an honest CPU baseline"): the loops are written so that `-O3 -march=native` vectorises them WITHOUT
+ * changing one rounding (-ffp-contract=off stays): the forward model runs over a transposed copy of A, a block of outputs per
+ * vector register, each output's sum still taken in the order j = 0 .. d-1 (the scalar loop's order: results are bit-identical to
+ * the -O2 build, which a test holds); the proposal's L z likewise over a transposed factor; the moment recursion with its two
+ * loop-invariant quotients formed once per step.  Two builds exist: libtda_cpu.so (-O2, portable: the parity / sanitizer tests)
+ * and libtda_cpu_native.so (-O3 -march=native, built on the machine that runs it: bench.py's cpu_baseline).
  */
 #include <cmath>
 #include <cstdarg>
@@ -61,7 +68,13 @@ bool cholesky(const double* C, int d, std::vector<double>& L) {
 }
 
 struct ChainState {
-  std::vector<double> theta, L, mu, sigma;
+  std::vector<double> theta, L, Lt, mu, sigma;  // Lt[k][i] = L[i][k] (the draw runs over it)
+  void set_factor(const std::vector<double>& Ln, int d) {
+    L = Ln;
+    Lt.assign((size_t)d * d, 0.0);
+    for (int i = 0; i < d; ++i)
+      for (int k = 0; k <= i; ++k) Lt[(size_t)k * d + i] = Ln[(size_t)i * d + k];
+  }
   double lp = 0.0, ll = 0.0, scaling = 1.0;
   int flags = 0;
 };
@@ -76,6 +89,8 @@ struct tda_engine {
   std::vector<double> pmean, pcov, pL, pW;  // prior: mean, covariance, Cholesky factor, its inverse (whitening)
   double plogconst = 0.0;
   std::vector<double> A, b, data, w;
+  std::vector<double> At;  // [d][mpad]: A transposed, outputs contiguous (padding rows are zero)
+  int mpad = 0;
   int noise_kind = 0;
   double var = 1.0;
   tda_proposal_params pp{};
@@ -101,13 +116,25 @@ struct tda_engine {
       maha += s * s;
     }
     lp = -0.5 * (plogconst + maha);
+    // F = A theta: OB outputs at a time, each output's sum in the order j = 0 .. d-1 (what `f += a[j] * th[j]` per output does);
+    // the sum of squares in the order o = 0 .. m-1
+    constexpr int OB = 32;
     double ss = 0.0;
-    for (int o = 0; o < m; ++o) {
-      const double* a = A.data() + (size_t)o * d;
-      double f = 0.0;
-      for (int j = 0; j < d; ++j) f += a[j] * th[j];
-      const double r = (f + b[o]) - data[o];
-      ss += noise_kind == TDA_NOISE_DIAG ? r * r * w[o] : r * r;
+    const double* __restrict__ at = At.data();
+    for (int o0 = 0; o0 < m; o0 += OB) {
+      double f[OB];
+      for (int k = 0; k < OB; ++k) f[k] = 0.0;
+      for (int j = 0; j < d; ++j) {
+        const double tj = th[j];
+        const double* __restrict__ col = at + (size_t)j * mpad + o0;
+        for (int k = 0; k < OB; ++k) f[k] += col[k] * tj;
+      }
+      const int nk = m - o0 < OB ? m - o0 : OB;
+      for (int k = 0; k < nk; ++k) {
+        const int o = o0 + k;
+        const double r = (f[k] + b[o]) - data[o];
+        ss += noise_kind == TDA_NOISE_DIAG ? r * r * w[o] : r * r;
+      }
     }
     if (noise_kind == TDA_NOISE_DIAG) {
       ll = -0.5 * ss;
@@ -167,6 +194,10 @@ int tda_engine_set_level(tda_engine* e, int level, int m, const double* A, const
   if (noise_kind != TDA_NOISE_ISO && noise_kind != TDA_NOISE_DIAG) return fail(TDA_ERR_UNSUPPORTED, "the CPU twin knows isotropic and diagonal noise");
   e->m = m;
   e->A.assign(A, A + (size_t)m * e->d);
+  e->mpad = (m + 31) / 32 * 32;
+  e->At.assign((size_t)e->d * e->mpad, 0.0);
+  for (int o = 0; o < m; ++o)
+    for (int j = 0; j < e->d; ++j) e->At[(size_t)j * e->mpad + o] = A[(size_t)o * e->d + j];
   e->b.assign(m, 0.0);
   if (b) e->b.assign(b, b + m);
   e->data.assign(data, data + m);
@@ -220,7 +251,7 @@ int tda_engine_init(tda_engine* e, const double* theta0) {
         s.theta[i] = e->pmean[i] + acc;
       }
     }
-    s.L = L;
+    s.set_factor(L, d);
     s.scaling = e->pp.kind == TDA_PROP_AM ? 1.0 : e->pp.scaling;
     if (e->pp.kind == TDA_PROP_AM) {  // RecursiveSampleMoments(mu0 = theta0, sigma0 = 0) (proposal.py:495-500)
       s.mu = s.theta;
@@ -291,10 +322,14 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
         std::copy(z.begin(), z.begin() + d, e->z_exp + ((size_t)(e->exp_pos + it) * N + c) * d);
         e->u_exp[(size_t)(e->exp_pos + it) * N + c] = u;
       }
-      for (int i = 0; i < d; ++i) {
-        double acc = 0.0;
-        for (int k = 0; k <= i; ++k) acc += s.L[(size_t)i * d + k] * z[k];
-        inc[i] = acc;
+      // inc = L z, every element's sum in the order k = 0 .. i (Lt is zero above the diagonal of L: those terms are skipped by
+      // starting row k at i = k)
+      for (int i = 0; i < d; ++i) inc[i] = 0.0;
+      for (int k = 0; k < d; ++k) {
+        const double zk = z[k];
+        const double* __restrict__ lt = s.Lt.data() + (size_t)k * d;
+        double* __restrict__ ip = inc.data();
+        for (int i = k; i < d; ++i) ip[i] += lt[i] * zk;
       }
       const double keep = kind == TDA_PROP_PCN ? std::sqrt(1.0 - s.scaling * s.scaling) : 1.0;
       for (int i = 0; i < d; ++i) prop[i] = kind == TDA_PROP_PCN ? keep * s.theta[i] + s.scaling * inc[i] : s.theta[i] + s.scaling * inc[i];
@@ -334,16 +369,22 @@ int tda_engine_run(tda_engine* e, int64_t n_iter, const tda_outputs* out) {
       }
       if (boundary) win.clear();
       if (is_am) {  // RecursiveSampleMoments.update (utils.py:113-122): recursion counter = adapt calls + 1
-        const double tt = (double)tn;
-        for (int i = 0; i < d; ++i) mu_new[i] = (1.0 / (tt + 1.0)) * (tt * s.mu[i] + s.theta[i]);
-        for (int i = 0; i < d; ++i)
+        const double tt = (double)tn, t1 = tt + 1.0, ca = (tt - 1.0) / tt, cb = e->am_sd / tt, eps = e->pp.epsilon;
+        const double* __restrict__ mu = s.mu.data();
+        const double* __restrict__ th = s.theta.data();
+        double* __restrict__ mn = mu_new.data();
+        for (int i = 0; i < d; ++i) mn[i] = (1.0 / t1) * (tt * mu[i] + th[i]);
+        for (int i = 0; i < d; ++i) {
+          double* __restrict__ sg = s.sigma.data() + (size_t)i * d;
+          const double mi = mu[i], ni = mn[i], ti = th[i];
           for (int j = 0; j < d; ++j) {
-            const double M = ((tt * (s.mu[i] * s.mu[j]) - (tt + 1.0) * (mu_new[i] * mu_new[j])) + s.theta[i] * s.theta[j]) + (i == j ? e->pp.epsilon : 0.0);
-            s.sigma[(size_t)i * d + j] = (tt - 1.0) / tt * s.sigma[(size_t)i * d + j] + e->am_sd / tt * M;
+            const double M = ((tt * (mi * mu[j]) - t1 * (ni * mn[j])) + ti * th[j]) + (i == j ? eps : 0.0);
+            sg[j] = ca * sg[j] + cb * M;
           }
+        }
         s.mu = mu_new;
         if (tn >= e->pp.t0 && boundary) {
-          if (cholesky(s.sigma.data(), d, Lnew)) s.L = Lnew;
+          if (cholesky(s.sigma.data(), d, Lnew)) s.set_factor(Lnew, d);
           else {
             s.flags |= 1;
             bad |= 1;

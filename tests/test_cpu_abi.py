@@ -13,15 +13,25 @@ from oracle import tinyda_oracle as orc
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def cpu():
+_SANITIZED = "TINYDA_CPU_ABI_SO" in os.environ  # (one build, named by the parent test, under the sanitizers)
+
+
+@pytest.fixture(scope="module", params=["portable"] if _SANITIZED else ["portable", "native"])
+def cpu(request):
+    """both builds of oracle/tda_cpu_abi.cpp: libtda_cpu.so (-O2) and libtda_cpu_native.so (-O3 -march=native for this host:
+    what bench.py's cpu_baseline leg times, round 5)"""
     import __graft_entry__ as g
 
     g.build()
     from tinyda_amd import _lib
 
     # tests/test_cpu_twin_sanitized.py re-runs this module in a child process against an ASan + UBSan build of the same source
-    path = os.environ.get("TINYDA_CPU_ABI_SO", g.CPU_ABI_SO)
+    if _SANITIZED:
+        path = os.environ["TINYDA_CPU_ABI_SO"]
+    else:
+        path = g.CPU_ABI_SO if request.param == "portable" else g.build_cpu_native()
+        if path is None:
+            pytest.skip("no compiler for the -march=native build")
     return _lib.load_from(path), path
 
 
@@ -100,3 +110,48 @@ def test_cpu_twin_philox_stream_is_the_contract(cpu):
     e.close()
     with pytest.raises(Exception, match="CPU twin"):
         Engine(4, 3, n_levels=2, lib=lib)
+
+
+def test_native_build_rounds_like_the_portable_one():
+    """-O3 -march=native vectorises the forward model, the draw and the moment recursion over outputs / columns; every sum keeps
+    the scalar loop's order, so the two builds agree BITWISE on an engine-driven AdaptiveMetropolis run with a covariance swap"""
+    import __graft_entry__ as g
+
+    g.build()
+    from tinyda_amd import _lib
+    from tinyda_amd.engine import Engine
+
+    native = os.environ["TINYDA_CPU_ABI_SO"] if _SANITIZED else g.build_cpu_native()  # (sanitized: that build against the -O2 one)
+    if native is None:
+        pytest.skip("no compiler for the -march=native build")
+    rng = np.random.default_rng(4)
+    d, m, N, T = 13, 45, 6, 70
+    A = rng.standard_normal((m, d)) / 3
+    y = rng.standard_normal(m)
+    res = []
+    for path in (g.CPU_ABI_SO, native):
+        e = Engine(N, d, seed=99, lib=_lib.load_from(path))
+        e.set_prior(0.1 * np.ones(d), np.eye(d) + 0.1)
+        e.set_level(0, A, y, 1, 0.5 + rng.random(m) * 0 + 0.25)
+        e.set_proposal(2, 0.01 * np.eye(d), t0=20, period=20, adaptive=True)
+        e.init(None)
+        params, stats, acc = np.empty((T, N, d)), np.empty((T, N, 3)), np.empty((T, N), dtype=np.uint8)
+        e.run(T, params, stats, acc)
+        st = e.proposal_state(want_am=True)
+        res.append((params, stats, acc, st["am_sigma"], st["scaling"]))
+        e.close()
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+    assert 0.02 < res[0][2].mean() < 0.98
+
+
+def test_bench_counts_the_cores_it_may_use():
+    """bench.py's cpu_baseline reports `cores` = the threads it started = min(CPU count, affinity mask, cgroup quota), and per_core"""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("tda_bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n = bench.effective_cores()
+    assert 1 <= n <= (os.cpu_count() or 1) and n <= len(os.sched_getaffinity(0))
+    assert (bench.CPU_SAMPLE_CHAINS, bench.CPU_SAMPLE_ITERATIONS) == (4096, 1000)

@@ -40,6 +40,8 @@ def test_bench_with_the_drivers_arguments():
     assert 0.0 < rf["whole_pipeline_frac"] <= rf["frac"]
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    np.testing.assert_allclose(cb["per_core"], cb["value"] / cb["cores"], rtol=1e-12)  # round 5: the job's CPU share, not the host's thread count
+    assert "-march=native" in cb["flags"] and "4096 chains" in cb["sample"]
     assert cb["reference_shaped"].get("value", 0) > 0, cb["reference_shaped"]  # the reference's cost profile, one core
     assert "roofline_hbm_step_synchronous" not in out
     assert "ess" in out and "max_rhat" in out["ess"], out.get("ess_error")
@@ -57,7 +59,14 @@ def test_bench_with_the_drivers_arguments():
             assert key in c, (c["tag"], key)
         assert c["bound"] in ("mfma", "hbm") and 0.0 < c["pipeline_frac"] <= c["frac"] < 1.0, c
         assert c["chains"] == (8192 if c["tag"].startswith("C4") else 4096)
-    assert out["configs_seconds"] < 60.0
+        # round 5: median of >= 5 repetitions of a window of >= 0.1 s, spread reported
+        assert c["repetitions"] >= 5 and len(c["window_seconds"]) == c["repetitions"] and c["calls_per_window"] >= 1, c["tag"]
+        assert c["window_s"] >= 0.09 and 0.0 <= c["spread"] < 0.5, (c["tag"], c["window_s"], c["spread"])
+    c4 = [c for c in cfgs if c["tag"].startswith("C4")]
+    assert all("k_dreamz_draw" in c["dominant_kernel"] and "k_dreamz_steps_wave" in c["dominant_kernel"] for c in c4)  # priced on the SUM
+    assert out["configs_seconds"] < 120.0
+    # round 5 (item 2a): the matrix-core counters of the committed PMC pass ride beside the algorithmic frac, stale-stamped
+    assert "mfma_util_counter" in rf and "mfma_flops_counted" in rf and "mfma_counter_stale" in rf
 
 
 def test_bench_survives_a_hung_cpu_baseline_and_flags_stale_traffic():

@@ -209,6 +209,34 @@ def test_host_fallback_is_announced_with_the_rule_that_refused_the_problem():
         assert api._device_plan(posts, tda.CrankNicolson()) is None and "AdaptiveGaussianLogLike" in api._refusal[0]
 
 
+def test_dense_error_model_with_a_dense_fine_level_falls_back_with_the_warning():
+    """AdaptiveGaussianLogLike coarse level + dense observation covariance on the finest level under the dense error
+    model is a legal reference configuration the engine does not lower (its finest level must be isotropic): the lowering pass
+    refuses it, so backend='auto' runs the host protocol with ONE HostFallbackWarning instead of raising from tda_engine_init."""
+    from tinyda_amd import api
+
+    d, m = 3, 6
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((m, d))
+    y = A @ np.ones(d)
+    prior = stats.multivariate_normal(np.zeros(d), np.eye(d))
+    L = 0.3 * np.eye(m) + 0.05 * np.tril(rng.standard_normal((m, m)))
+    posts = [tda.Posterior(prior, tda.AdaptiveGaussianLogLike(y, 0.1 * np.eye(m)), tda.LinearModel(A + 0.05)),
+             tda.Posterior(prior, tda.GaussianLogLike(y, L @ L.T), tda.LinearModel(A))]
+    assert api._device_plan(posts, tda.CrankNicolson(scaling=0.2)) is not None  # without an error model: lowered (0.4)
+    for kind in ("state-independent", "state-dependent"):
+        assert api._device_plan(posts, tda.CrankNicolson(scaling=0.2), False, kind) is None
+        assert "finest level must have an isotropic likelihood" in api._refusal[0]
+    with pytest.warns(tda.HostFallbackWarning, match="finest level must have an isotropic likelihood") as rec:
+        res = tda.sample(posts, tda.CrankNicolson(scaling=0.2), 6, n_chains=1, subchain_length=2, adaptive_error_model="state-independent")
+    assert res["backend"] == "host" and res["sampler"] == "DA"
+    assert len([w for w in rec if issubclass(w.category, tda.HostFallbackWarning)]) == 1
+    with pytest.raises(tda.EngineError, match="finest level must have an isotropic likelihood"):
+        tda.sample(posts, tda.CrankNicolson(scaling=0.2), 6, n_chains=1, subchain_length=2, adaptive_error_model="state-independent", backend="hip")
+    iso = [posts[0], tda.Posterior(prior, tda.GaussianLogLike(y, 0.1 * np.eye(m)), tda.LinearModel(A))]
+    assert api._device_plan(iso, tda.CrankNicolson(scaling=0.2), False, "state-independent") is not None
+
+
 def test_multilevel_lowering_and_argument_checks():
     from tinyda_amd.api import _device_plan
 

@@ -6,6 +6,7 @@ Extra keyword-only arguments (not in the reference): seed, backend, device, chai
 import copy
 import gc
 import os
+import threading
 import warnings
 from collections.abc import Mapping
 
@@ -39,8 +40,9 @@ def _no(reason):
     return None
 
 
-def _device_plan(posteriors, proposal, diagonal_error_model=False):
-    """Lowering pass: returns (list of level descriptions, proposal description) or None (the reason is left in _refusal)."""
+def _device_plan(posteriors, proposal, diagonal_error_model=False, error_model=None):
+    """Lowering pass: returns (list of level descriptions, proposal description) or None (the reason is left in _refusal).
+    error_model: sample()'s adaptive_error_model after its own validation (None / 'state-independent' / 'state-dependent')."""
     del _refusal[:]
     if not 1 <= len(posteriors) <= MAX_LEVELS or type(proposal) not in _DEVICE_PROPOSALS:
         return _no("more than %d levels (or none), or a proposal class the engine has no kernel for (%s)" % (MAX_LEVELS, type(proposal).__name__))
@@ -71,6 +73,13 @@ def _device_plan(posteriors, proposal, diagonal_error_model=False):
         lows.append(low)
     if diagonal_error_model and any(lw["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG) for lw in lows):
         return _no("the diagonal error model takes its Sigma_e from isotropic / diagonal level noise")
+    if error_model is not None and not diagonal_error_model and len(lows) > 1:
+        # the dense error model (tda_host_init.inc, "adaptive error model set-up"): adaptive likelihoods below an ISOTROPIC finest
+        # level; refused here so that backend='auto' falls back with its warning instead of failing in tda_engine_init
+        if lows[-1]["noise_kind"] != _lib.NOISE_ISO or any(lw["noise_kind"] == _lib.NOISE_DENSE for lw in lows):
+            return _no("dense error model: the finest level must have an isotropic likelihood on the device (and no level a dense observation covariance)")
+        if any(lw["noise_kind"] != _lib.NOISE_ADAPTIVE for lw in lows[:-1]):
+            return _no("dense error model: every level below the finest needs an AdaptiveGaussianLogLike")
     if isinstance(proposal, DREAMZ) and len(posteriors) != 1 and proposal._shared:
         return _no("DREAM's shared archive is single-level on the device (below a hierarchy: DREAMZ's per-chain archives)")
     if any("rosenbrock" in low for low in lows) and not isinstance(proposal, DREAMZ):
@@ -112,6 +121,34 @@ def _device_plan(posteriors, proposal, diagonal_error_model=False):
     if prop is None:  # an option of a lowerable proposal class that the engine does not know: host protocol under 'auto'
         return _no("an option of %s the engine does not implement" % type(proposal).__name__)
     return lows, prop
+
+
+class _GcPaused:
+    """The result of a device run holds one view object per chain and level; building thousands of them in one go is what trips the
+    interpreter's generational collector into a full pass over every live object of the process (70 ms, a third of the calls at
+    BASELINE config 5, whose whole run takes 11).  Nothing built there is cyclic garbage, so the collector rests -- for the
+    construction of the views ONLY (the run itself, user callbacks and progress polling stay under the normal
+    collector), and behind a lock-protected count so that concurrent sample() calls in different threads neither re-enable it
+    under each other nor leave it off."""
+    _lock = threading.Lock()
+    _depth = 0
+    _was_on = False
+
+    def __enter__(self):
+        cls = _GcPaused
+        with cls._lock:
+            if cls._depth == 0:
+                cls._was_on = gc.isenabled()
+                gc.disable()
+            cls._depth += 1
+
+    def __exit__(self, *exc):
+        cls = _GcPaused
+        with cls._lock:
+            cls._depth -= 1
+            if cls._depth == 0 and cls._was_on:
+                gc.enable()
+        return False
 
 
 _TAG_THETA0, _TAG_ARCHIVE = 0x7468, 0x5a30  # sub-streams of the host generators below
@@ -292,7 +329,7 @@ def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None
     diag_aem = error_model_covariance == "diagonal" and n_levels > 1 and adaptive_error_model is not None
     if diag_aem and adaptive_error_model != "state-independent":
         raise ValueError("the diagonal error model is state-independent")
-    plan = None if backend == "host" else _device_plan(posteriors, proposal, diag_aem)
+    plan = None if backend == "host" else _device_plan(posteriors, proposal, diag_aem, adaptive_error_model if n_levels > 1 else None)
     why = list(_refusal)
     if plan is not None and isinstance(proposal, DREAMZ) and n_levels > 1 and diag_aem:
         plan = None  # (DREAMZ below a hierarchy runs with the reference's dense error model; the diagonal extension: host protocol)
@@ -304,7 +341,7 @@ def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None
         # proposals, level logic, error model, adaptation and records on the device
         wrapped = _wrap_opaque_models(posteriors)
         if wrapped is not None:
-            plan = _device_plan(wrapped, proposal, diag_aem)
+            plan = _device_plan(wrapped, proposal, diag_aem, adaptive_error_model)
             if plan is not None:
                 posteriors = wrapped
             else:
@@ -319,23 +356,14 @@ def sample(posteriors, proposal, iterations, n_chains=1, initial_parameters=None
     if thin > 1 and (plan is None or n_levels > 1 or isinstance(proposal, DREAMZ)):
         raise NotImplementedError("thin > 1 is a single-level device option (GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis / MALA ...)")
     if plan is not None:
-        # The result holds one view object per chain and level; building thousands of them in one call is what trips the
-        # interpreter's generational collector into a full pass over every live object of the process (70 ms, a third of the calls
-        # at BASELINE config 5, whose whole run takes 11).  Nothing built here is cyclic garbage: the collector rests for the call.
-        gc_was_on = gc.isenabled()
-        gc.disable()
-        try:
-            if n_levels == 1:
-                return _sample_device(plan, posteriors[0], iterations, n_chains, initial_parameters, seed, device,
-                                      chain_offset, distributed, total if distributed else None, overlap_archive_exchange,
-                                      shared_archive == "distributed", thin, force_progress_bar)
-            return _sample_device_multilevel(plan, posteriors, iterations, n_chains, initial_parameters, subchain_length,
-                                             subchain_lengths, randomize_subchain_length, store_coarse_chain, seed, device,
-                                             chain_offset, "state-independent-diagonal" if diag_aem else adaptive_error_model,
-                                             force_progress_bar)
-        finally:
-            if gc_was_on:
-                gc.enable()
+        if n_levels == 1:
+            return _sample_device(plan, posteriors[0], iterations, n_chains, initial_parameters, seed, device,
+                                  chain_offset, distributed, total if distributed else None, overlap_archive_exchange,
+                                  shared_archive == "distributed", thin, force_progress_bar)
+        return _sample_device_multilevel(plan, posteriors, iterations, n_chains, initial_parameters, subchain_length,
+                                         subchain_lengths, randomize_subchain_length, store_coarse_chain, seed, device,
+                                         chain_offset, "state-independent-diagonal" if diag_aem else adaptive_error_model,
+                                         force_progress_bar)
     if n_levels > 1:
         return _sample_host_multilevel(posteriors, proposal, iterations, n_chains, initial_parameters, subchain_length,
                                        subchain_lengths, randomize_subchain_length, adaptive_error_model, store_coarse_chain,
@@ -581,8 +609,9 @@ def _sample_device(plan, posterior, iterations, n_chains, initial_parameters, se
         result["thin"] = thin
     recs = DeviceRecords(params, stat, acc)
     model = posterior.model
-    for i in range(n_chains):
-        result["chain_%d" % i] = DeviceChain(recs, i, model)
+    with _GcPaused():
+        for i in range(n_chains):
+            result["chain_%d" % i] = DeviceChain(recs, i, model)
     return result
 
 
@@ -654,14 +683,16 @@ def _sample_device_multilevel(plan, posteriors, iterations, n_chains, initial_pa
     if nl == 2:
         result = {"sampler": "DA", "n_chains": n_chains, "iterations": iterations + 1, "subchain_length": subchain_length,
                   "backend": "hip", "seed": seed}
-        for i in range(n_chains):
-            result["chain_coarse_{}".format(i)] = chain_of(0, i)
-        for i in range(n_chains):
-            result["chain_fine_{}".format(i)] = chain_of(1, i)
+        with _GcPaused():
+            for i in range(n_chains):
+                result["chain_coarse_{}".format(i)] = chain_of(0, i)
+            for i in range(n_chains):
+                result["chain_fine_{}".format(i)] = chain_of(1, i)
         return result
     result = {"sampler": "MLDA", "n_chains": n_chains, "iterations": iterations + 1, "levels": nl,
               "subchain_lengths": subchain_lengths, "backend": "hip", "seed": seed}
-    for k in reversed(range(nl)):
-        for i in range(n_chains):
-            result["chain_l{}_{}".format(k, i)] = chain_of(k, i)
+    with _GcPaused():
+        for k in reversed(range(nl)):
+            for i in range(n_chains):
+                result["chain_l{}_{}".format(k, i)] = chain_of(k, i)
     return result

@@ -112,23 +112,29 @@ void pack_fragments(const double* A, int rows, int cols, int dpad, std::vector<d
 // Device-memory pool: an engine holds ~1.2 GB of block buffers at BASELINE config 2, and tda.sample() creates and destroys
 // one engine per call.  hipMalloc / hipFree of that set cost 10-20 ms per call (hipFree synchronises the device), which is
 // as long as 1000 iterations of 4096 chains take.  Released buffers are therefore kept per (device, byte count) and handed
-// out again -- zeroed, as fresh allocations are -- up to TINYDA_POOL_GB GiB (default 8, at most an eighth of the free memory); tda_release_cached_memory() returns
+// out again -- zeroed, as fresh allocations are -- up to TINYDA_POOL_GB GiB PER DEVICE (default 8, at most an eighth of the device's memory); tda_release_cached_memory() returns
 // them to the driver, as does an allocation failure before it is reported.
 struct DevPool {
   std::mutex mu;
   std::multimap<std::pair<int, size_t>, void*> idle;
-  size_t held = 0, cap = 0;
-  bool cap_read = false;
-  size_t capacity() {
-    if (!cap_read) {
-      const char* v = getenv("TINYDA_POOL_GB");
-      cap = (size_t)((v ? atof(v) : 8.0) * 1073741824.0);
-      if (!v) {  // default: 8 GiB, but never more than an eighth of what the device has free when the pool is first used
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 8 < cap) cap = free_b / 8;
-      }
-      cap_read = true;
+  size_t held = 0;                       // all devices (what trim() reports)
+  std::map<int, size_t> held_dev, cap_dev;  // per device: bytes parked, cap
+  // The cap is per DEVICE (one process-wide figure read on whichever device was current at first use could come from
+  // the wrong GPU, or from a moment when another engine's peak buffers were live): TINYDA_POOL_GB GiB if set, otherwise 8 GiB but
+  // never more than an eighth of that device's TOTAL memory -- a figure that does not depend on what happens to be allocated.
+  size_t capacity(int dev) {
+    auto it = cap_dev.find(dev);
+    if (it != cap_dev.end()) return it->second;
+    const char* v = getenv("TINYDA_POOL_GB");
+    size_t cap = (size_t)((v ? atof(v) : 8.0) * 1073741824.0);
+    if (!v) {
+      int cur = 0;
+      (void)hipGetDevice(&cur);
+      size_t free_b = 0, total_b = 0;
+      if (hipSetDevice(dev) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b / 8 < cap) cap = total_b / 8;
+      (void)hipSetDevice(cur);
     }
+    cap_dev[dev] = cap;
     return cap;
   }
   void* take(int dev, size_t bytes) {
@@ -138,13 +144,15 @@ struct DevPool {
     void* p = it->second;
     idle.erase(it);
     held -= bytes;
+    held_dev[dev] -= bytes;
     return p;
   }
   bool give(int dev, size_t bytes, void* p) {
     std::lock_guard<std::mutex> g(mu);
-    if (bytes < (64u << 10) || held + bytes > capacity()) return false;  // small buffers: the runtime's own sub-allocator is fast
+    if (bytes < (64u << 10) || held_dev[dev] + bytes > capacity(dev)) return false;  // small buffers: the runtime's own sub-allocator is fast
     idle.insert({{dev, bytes}, p});
     held += bytes;
+    held_dev[dev] += bytes;
     return true;
   }
   size_t trim() {
@@ -159,6 +167,7 @@ struct DevPool {
     (void)hipSetDevice(cur);
     idle.clear();
     held = 0;
+    held_dev.clear();
     return was;
   }
 };
