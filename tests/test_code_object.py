@@ -116,3 +116,59 @@ def test_generator_fits_beside_the_two_level_kernel(kernel_metadata):
         md = [v for k, v in kernel_metadata.items() if k.startswith(pre)]
         assert md, pre
         assert md[0]["spilled"] == 0 and 2 * gran(md[0]["vgprs"]) + 64 <= 512, (pre, md[0])
+
+
+# ---- loop-level gate (round 5): the STEP LOOP of each hot kernel, located in the disassembly ----
+# kernel instance -> (cap on `s_waitcnt vmcnt(0)` inside its step loop, what the ones that remain are).  The caps are the counts of
+# the shipped build (tools/loop_audit.py prints them); a new full wait in a step loop -- the signature of a spill reload, of an LDS
+# pointer demoted to a flat access, or of a load whose count the compiler lost -- fails here, on the CPU tier.
+STEP_LOOP_VMCNT0 = {
+    # 32 of the 39 sit in the dense-prior branch (two loads per parameter block, never taken with a diagonal prior: BASELINE);
+    # on the C2a path: the drain behind the last operator block of the step (2, either exit), the increments + uniform requested a
+    # whole step earlier in front of the step's barrier (1) -- true dependences -- and the alternatives of those for the other
+    # operator-block counts (4)
+    "_ZN3tda10k_mh_stepsILi64ELi8ELb0ELi0EEE": (39, "C2a"),
+    "_ZN3tda10k_mh_stepsILi64ELi4ELb0ELi0EEE": (41, "C2b (34 of them in the dense-prior branch)"),
+    # round 5: 72 -> 12.  Rounds 3-4 read the level action's states through a flat pointer (tda_kernels_mh.h block_sse_frag):
+    # eight full waits per observation block of every level action
+    "_ZN3tda15k_da_steps_r224ILi64ELi1ELb0ELi0ELi3EEE": (12, "C5-literal"),
+    "_ZN3tda15k_da_steps_r224ILi64ELi2ELb1ELi0ELi2EEE": (6, "C3"),
+    "_ZN3tda19k_dreamz_steps_waveILi32EEE": (10, "C4 steps"),
+    "_ZN3tda16k_aem_base_stepsILi8EEE": (2, "C5 + dense error model, base subchain"),
+}
+
+
+@pytest.fixture(scope="module")
+def loop_audit():
+    import importlib.util
+
+    if not os.path.exists(os.path.join(LLVM_BIN, "llvm-objdump")):
+        pytest.skip("ROCm LLVM tools not installed")
+    if not os.path.exists(LIB):
+        pytest.skip("libtinyda_hip.so not built")
+    spec = importlib.util.spec_from_file_location("tda_loop_audit", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "loop_audit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.audit(["k_mh_steps", "k_da_steps", "k_dreamz_steps_wave", "k_aem_base_steps", "k_ml_steps", "k_aem_action", "k_adapt"])
+
+
+@pytest.mark.parametrize("prefix", sorted(STEP_LOOP_VMCNT0))
+def test_step_loops_hold_their_full_wait_count(loop_audit, prefix):
+    cap, what = STEP_LOOP_VMCNT0[prefix]
+    hits = {k: v for k, v in loop_audit.items() if k.startswith(prefix)}
+    assert len(hits) == 1, (prefix, list(hits))
+    (name, r), = hits.items()
+    assert r["step"] is not None, "%s: no step loop found in the disassembly" % name
+    st = r["step"][2]
+    assert st["instructions"] > 200, (name, st)  # it IS the step loop, not a staging loop
+    assert st["scratch"] == 0, "%s (%s): %d scratch accesses inside the step loop" % (name, what, st["scratch"])
+    assert st["flat"] == 0, "%s (%s): %d flat accesses inside the step loop (an LDS / global pointer lost its address space)" % (name, what, st["flat"])
+    assert st["vmcnt0"] <= cap, "%s (%s): %d `s_waitcnt vmcnt(0)` inside the step loop, %d allowed" % (name, what, st["vmcnt0"], cap)
+
+
+def test_no_level_kernel_reads_memory_through_flat_pointers(loop_audit):
+    """every k_da_steps / k_ml_steps / k_mh_steps instance: no flat_load / flat_store anywhere (rounds 3-4 shipped 64 per three-level
+    k_da_steps instance: LDS reads behind `s_waitcnt vmcnt(0) lgkmcnt(0)`)"""
+    bad = ["%s: %d" % (k, v["whole"]["flat"]) for k, v in sorted(loop_audit.items())
+           if v["whole"].get("flat", 0) and ("k_da_steps" in k or "k_ml_steps" in k or "k_mh_steps" in k)]
+    assert not bad, "\n".join(bad)

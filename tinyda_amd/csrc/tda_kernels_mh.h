@@ -320,10 +320,18 @@ template <int DPAD, int MODE, bool FRESH>
 __device__ __forceinline__ double block_sse_frag(const double2 (&f)[DPAD / 8], const double2* th_frag, const double* __restrict__ s_y,
                                                  double* __restrict__ s_w, int cb, int hi) {
   double4_t a0 = {0.0, 0.0, 0.0, 0.0};
-  if (FRESH) asm volatile("" : "+v"(th_frag));  // (a new read per block: hoisted out of the block loop these are the 32 registers again)
+  // th_frag points into LDS.  FRESH: a new read per block (hoisted out of the block loop these are the 32 registers again), forced
+  // by passing the pointer through an empty asm -- as an LDS (address space 3, 32-bit) pointer.  Round 5: rounds 3-4 passed the
+  // GENERIC pointer through the asm; the compiler no longer knew it was LDS and read the states with flat_load_dwordx4, each
+  // followed by `s_waitcnt vmcnt(0) lgkmcnt(0)` (a flat access may resolve to either memory): eight full drains of the fragment
+  // prefetch per observation block in every level action of the three-level instances (tools/loop_audit.py found them).
+  typedef double lds_d2 __attribute__((ext_vector_type(2)));  // (a builtin vector: HIP's double2 is a class, whose copy cannot bind an LDS reference)
+  typedef const lds_d2 __attribute__((address_space(3)))* lds_frag_ptr;
+  lds_frag_ptr th_lds = (lds_frag_ptr)th_frag;
+  if (FRESH) asm volatile("" : "+v"(th_lds));
 #pragma unroll
   for (int k = 0; k < DPAD / 8; ++k) {
-    const double2 b = th_frag[k];
+    const lds_d2 b = th_lds[k];
     a0 = mfma_f64(f[k].x, b.x, a0);
     a0 = mfma_f64(f[k].y, b.y, a0);
   }
