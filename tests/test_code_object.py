@@ -30,19 +30,19 @@ HOT = {
     "_ZN3tda10k_ml_stepsILi64ELi1ELi4ELb0EEE": "dense error model base steps, step-by-step path (TINYDA_AEM_BASE=0, dense priors)",
     "_ZN3tda16k_aem_base_stepsILi8EEE": "C5 + dense error model base subchain (one pass over V per launch)",
     "_ZN3tda12k_aem_actionILi128EEE": "C5 + dense error model level decision",
+    "_ZN3tda13k_aem_refreshILi8ELi1EEE": "C5 + dense error model refresh of level 1 (one tracker)",
+    "_ZN3tda13k_aem_refreshILi8ELi2EEE": "C5 + dense error model refresh of level 0 (two trackers)",
     "_ZN3tda18k_adapt_chol_applyILi64EEE": "C2a period boundary in one launch",
     "_ZN3tda13k_dreamz_drawILi32ELb0EEE": "C4 DREAM draws",
 }
 
 # Every OTHER instance of the code object must be spill-free too, except the ones listed here with the number of spilled registers
 # they are known to have (a cap per instance, so that neither a new spiller nor a worse one goes unnoticed).
-#   k_aem_refresh<8, *>  one wave per SIMD with 512 registers by design (the 128 x 128 matrix lives in registers); what is spilled
-#                        is reloaded once, outside any loop (straight-line code)
+#   (k_aem_refresh<8, *> left this list in round 5: the factor form -- no V = L^-1 beside U -- needs 412 - 452 of the 512 registers)
 #   k_ml_steps<64,3|4,4,false> the generic level kernel with three / four levels in one launch (C5 runs k_da_steps): 10 / 7 since the
 #                              upper levels' state waits in LDS between level actions (46 / 117 before);
 #   k_ml_steps<64,*,4,true>    its instances for hierarchies with a dense observation covariance on some level (round 4)
 KNOWN_SPILLERS = {
-    "_ZN3tda13k_aem_refreshILi8ELi1EEE": 40, "_ZN3tda13k_aem_refreshILi8ELi2EEE": 48, "_ZN3tda13k_aem_refreshILi8ELi3EEE": 96,
     "_ZN3tda10k_ml_stepsILi64ELi3ELi4ELb0EEE": 16, "_ZN3tda10k_ml_stepsILi64ELi4ELi4ELb0EEE": 16,
     "_ZN3tda10k_ml_stepsILi64ELi2ELi4ELb1EEE": 32, "_ZN3tda10k_ml_stepsILi64ELi3ELi4ELb1EEE": 80, "_ZN3tda10k_ml_stepsILi64ELi4ELi4ELb1EEE": 112,
 }

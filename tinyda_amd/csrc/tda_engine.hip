@@ -94,6 +94,37 @@ void tri_inverse_host(const std::vector<double>& L, int d, std::vector<double>& 
   }
 }
 
+// The error model's FACTOR FORM (tda_kernels_aemr.h) of an m x m lower Cholesky factor L, padded with identity to MP rows: the
+// off-diagonal 16 x 16 tiles as U = L^T tiles, the diagonal tiles replaced by their inverses.  out: aemr_v_doubles(MP) doubles.
+void factor_form_pack_host(const std::vector<double>& L, int m, int MP, std::vector<double>& out) {
+  out.assign(tda::aemr_v_doubles(MP), 0.0);
+  auto Lp = [&](int i, int j) { return (i < m && j < m) ? L[(size_t)i * m + j] : (i == j ? 1.0 : 0.0); };
+  for (int q = 0; q < MP / 16; ++q) {
+    std::vector<double> D(256), Di;
+    for (int i = 0; i < 16; ++i)
+      for (int j = 0; j < 16; ++j) D[i * 16 + j] = j <= i ? Lp(16 * q + i, 16 * q + j) : 0.0;
+    tri_inverse_host(D, 16, Di);
+    for (int i = 0; i < 16; ++i)
+      for (int j = 0; j <= i; ++j) out[tda::aemr_v_offset(16 * q + i, 16 * q + j)] = Di[i * 16 + j];
+  }
+  for (int i = 0; i < MP; ++i)
+    for (int j = 0; j < (i & ~15); ++j) out[tda::aemr_w_offset_offdiag(i, j)] = Lp(i, j);
+}
+// ... and back: L (m x m, row-major) from one chain's factor form
+void factor_form_unpack_host(const double* w, int m, std::vector<double>& L) {
+  L.assign((size_t)m * m, 0.0);
+  for (int q = 0; q * 16 < m; ++q) {
+    std::vector<double> Di(256, 0.0), D;
+    for (int i = 0; i < 16; ++i)
+      for (int j = 0; j <= i; ++j) Di[i * 16 + j] = w[tda::aemr_v_offset(16 * q + i, 16 * q + j)];
+    tri_inverse_host(Di, 16, D);
+    for (int i = 0; i < 16 && 16 * q + i < m; ++i)
+      for (int j = 0; j <= i; ++j) L[(size_t)(16 * q + i) * m + 16 * q + j] = D[i * 16 + j];
+  }
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < (i & ~15); ++j) L[(size_t)i * m + j] = w[tda::aemr_w_offset_offdiag(i, j)];
+}
+
 // pack an (rows x cols) row-major matrix into MFMA A-operand fragments, see LevelDev::Apk; kpad = padded K
 void pack_fragments(const double* A, int rows, int cols, int dpad, std::vector<double>& out, int& ncb) {
   ncb = (rows + 15) / 16;

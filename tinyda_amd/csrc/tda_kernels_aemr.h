@@ -1,24 +1,29 @@
-// Error-model refresh (round 4): (Sigma_e + Sigma_bias)^-1 of one level for every chain, as the triangular factor
-// V = L^-1 (Sigma = L L^T, so r^T Sigma^-1 r = |V r|^2), ONE WAVE PER CHAIN with the whole matrix in registers.
+// Error-model refresh: (Sigma_e + Sigma_bias)^-1 of one level for every chain, kept as the Cholesky FACTOR of the matrix, ONE WAVE
+// PER CHAIN with the factorisation in registers.  Sigma = L L^T, r^T Sigma^-1 r = |L^-1 r|^2.
 //
-// What it replaces (k_aem_inverse, round 1-3): one workgroup of eight waves per chain around an LDS copy of the matrix, three
-// barriers per block column, one wave factoring the diagonal block while seven wait, then W = L^-1 and P = W^T W as two more
-// passes -- 0.73 ms per launch at 4096 chains x 128 outputs, 0.10-0.15 of the fp64 matrix peak.
+// Round 5: what is stored per chain is the factor itself -- the off-diagonal 16 x 16 tiles of U = L^T and, in place of the diagonal
+// tiles, the INVERSES of the diagonal tiles of L ("factor form", aemr_w_offset below) -- and every consumer evaluates |L^-1 r|^2 by
+// a blocked forward substitution (aem_quad_factor: z_q = L_qq^-1 (r_q - sum_{i<q} U_iq^T z_i), all in registers, no transposition:
+// the C/D layout of U_iq gives the column sums, that of L_qq^-1 the row sums).  Round 4 stored V = L^-1: the refresh spent half of
+// its 896 matrix instructions and half of its live registers on the right-looking inversion (36 of 72 tiles live, 28-74 spilled
+// registers, one 512-register wave per SIMD waiting on its own previous instruction 54 % of its cycles: VERDICT r4 weak #2).  The
+// factor alone is 448 matrix instructions and at most 20 live tiles; same bytes written, same bytes read by every consumer, and
+// the substitution's dependent chain (eight block steps) is nothing beside the 72 KB a consumer streams per chain.
+//
+// What round 4 replaced (k_aem_inverse, rounds 1-3): one workgroup of eight waves per chain around an LDS copy of the matrix, three
+// barriers per block column, then W = L^-1 and P = W^T W as two more passes -- 0.73 ms per launch at 4096 chains x 128 outputs.
 //
 // Here (reference: distributions.py:385-425 set_bias / loglike; chain.py:740-765; proposal.py:1548-1578):
 //   * the matrix is held as 16 x 16 tiles in the fp64 MFMA C/D register layout (lane (lc, hi), register r = element
 //     [hi + 4 r][lc]), upper factor U = L^T, exactly the layout k_chol_apply_blk uses for the proposal covariance: the
 //     accumulator layout of v_mfma_f64_16x16x4 is its operand layout for X^T Y products, so EVERY matrix-core operand below
 //     comes straight out of the registers that hold the tiles -- no LDS copy of the matrix, no barrier, no other wave;
-//   * the inverse comes out of the same elimination: [Sigma | I] -> [U | V] (block Gauss-Jordan on the augmented matrix).
-//     Block row p: the diagonal tile is factored and inverted in registers (16 pivots, pivot rows by ds_bpermute), the rest
-//     of the row is multiplied by that inverse on the matrix cores, the rows below are updated on the matrix cores.  A block
-//     row of U is dead once its trailing update is done and a block row of V is final at the same moment, so the live set
-//     peaks at 44 of the 72 tiles (352 registers of the wave's 512 at one wave per SIMD);
-//   * P = V^T V is never formed: every consumer evaluates |V r|^2 from the lower tiles (aem_quad_tiles below): a third
-//     fewer flops here and 72 KB instead of 128 KB per chain written;
-//   * update_link of the level under the refreshed model (posterior.py:112-134) is the last step of the same wave, from the V
-//     tiles while they are still in registers: the second launch of k_aem_action and its 72 KB read per chain are gone.
+//   * left-looking blocked Cholesky: block row q of Sigma is loaded when step q needs it, receives the updates of the finished rows
+//     at once (U_pq^T U_pi on the matrix cores), its diagonal tile is factored and inverted in registers (16 pivots, pivot rows by
+//     ds_bpermute), the rest of the row is multiplied by that inverse on the matrix cores.  Live: the finished U(p, i), p < q <= i,
+//     and the row itself -- (q + 1)(T - q) <= 20 of the 36 tiles;
+//   * update_link of the level under the refreshed model (posterior.py:112-134) rides along: the forward substitution advances one
+//     block per finished row, from the tiles while they are in registers.
 // Padding rows / columns (m not a multiple of 16, or fewer tiles than the instance) are identity.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -42,10 +47,18 @@ __host__ __device__ inline size_t aemr_u_offset(int MP, int i, int j) {
   const int ti = i >> 4, tj = j >> 4, ri = i & 15, cj = j & 15;
   return ((size_t)(aemr_ut(MP / 16, ti, tj) * 4 + (ri >> 2)) * 64) + (ri & 3) * 16 + cj;
 }
-// offset (doubles, inside one chain's V array) of V[i][j], i >= j
+// offset (doubles, inside one chain's lower-tile array) of element [i][j], i >= j, of a lower-triangular matrix kept tile by tile
 __host__ __device__ inline size_t aemr_v_offset(int i, int j) {
   const int ti = i >> 4, tj = j >> 4, ri = i & 15, cj = j & 15;
   return ((size_t)(aemr_lt(ti, tj) * 4 + (ri >> 2)) * 64) + (ri & 3) * 16 + cj;
+}
+// FACTOR FORM of Sigma = L L^T, what k_aem_refresh writes and every consumer reads (T (T + 1) / 2 tiles per chain, aemr_lt order):
+//   tile (q, i), i < q:  U_iq = (L_qi)^T, element [k][j] = L[16 q + j][16 i + k]   (the factorisation's own output tile, C/D layout)
+//   tile (q, q):         (L_qq)^-1, the inverse of the diagonal tile of L, lower triangular
+// offset (doubles) at which element L[i][j], i >= j, IN DIFFERENT TILES is stored; elements of (L_qq)^-1 sit at aemr_v_offset.
+__host__ __device__ inline size_t aemr_w_offset_offdiag(int i, int j) {
+  const int ti = i >> 4, tj = j >> 4, ci = i & 15, rj = j & 15;
+  return ((size_t)(aemr_lt(ti, tj) * 4 + (rj >> 2)) * 64) + (rj & 3) * 16 + ci;
 }
 
 struct AemRefreshArgs {
@@ -54,7 +67,7 @@ struct AemRefreshArgs {
   int nsum;                         // tracker covariances summed into Sigma_bias
   const double* cov;                // [tiles][4][64] Sigma_e as UPPER tiles (aemr_ut) in C/D layout, IDENTITY in the padding rows / columns (>= m)
   double* sig[AEMR_MAXSUM];         // [NP][tiles][4][64] tracker covariances, upper tiles, zero in the padding (symmetric: only this half exists)
-  double* V;                        // [NP][tiles][4][64]: lower tiles of L^-1 in C/D layout
+  double* V;                        // [NP][tiles][4][64]: the factor form (aemr_w_offset_offdiag above) in C/D layout
   // the covariance update of tracker sig[0] (utils.py:117-122 with sd = 1, eps = 0; state-dependent: utils.py:199), applied to every
   // tile on its way in and stored back; null upd: sig[0] is used as it is
   const double* upd;                // [NP][3][MP]: dm, mu, mu' as k_aem_action left them (state-dependent model: x, 0, 0)
@@ -84,8 +97,11 @@ __device__ __forceinline__ void aemr_static_for(F&& f) {
 // Buffer addressing (descriptor in SGPRs + ONE 32-bit lane offset + a compile-time scalar offset per access): with 64-bit
 // per-lane pointers the compiler kept an address pair per access alive -- hundreds of registers in a fully unrolled kernel.
 typedef unsigned int aemr_u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t aemr_rsrc(const double* p) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p), 0, 0x7fffffff, 0x00020000);
+#ifndef AEMR_NOMEM_MASK  // timing experiments (tools/aem_refresh_probe.hip): bit b set = the descriptors created with tag b have ZERO records --
+#define AEMR_NOMEM_MASK 0  // the range check drops every load / store through them, the instruction stream stays (results are then wrong)
+#endif
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t aemr_rsrc(const double* p, int tag = 0) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p), 0, ((AEMR_NOMEM_MASK >> tag) & 1) ? 0 : 0x7fffffff, 0x00020000);
 }
 __device__ __forceinline__ double aemr_ld(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
   const aemr_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
@@ -123,19 +139,21 @@ __device__ __forceinline__ void aemr_diag(double (&C)[4], double (&Vd)[4], doubl
     const double fac = (hi == kh) ? inv : 1.0;
     C[kr] *= fac;
     Vd[kr] *= fac;
+    // (the multiplier of a row that is not below the pivot is ZERO: x - 0 * y = x exactly, so one select per row replaces the two
+    // selects per updated element of round 4 -- two v_cndmask per double each; the tile is finite, 0 * y never meets an infinity)
     double ucol[4];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) ucol[rr] = rr >= kr ? aemr_pick(C[kr], kh * 16 + hi + 4 * rr) : 0.0;
+    for (int rr = 0; rr < 4; ++rr) {
+      const double pk = rr >= kr ? aemr_pick(C[kr], kh * 16 + hi + 4 * rr) : 0.0;
+      ucol[rr] = (rr > kr || hi > kh) ? pk : 0.0;
+    }
     const double urc = aemr_pick(C[kr], kh * 16 + lc);
     const double urv = kl > 0 ? aemr_pick(Vd[kr], kh * 16 + lc) : ((lc == 0) ? inv : 0.0);  // (row 0 of V is e_0 / l_00: no exchange needed)
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       if (rr < kr) continue;
-      const bool live = rr > kr || hi > kh;
-      const double uc = fma(-ucol[rr], urc, C[rr]);
-      const double uv = fma(-ucol[rr], urv, Vd[rr]);
-      C[rr] = live ? uc : C[rr];
-      Vd[rr] = live ? uv : Vd[rr];
+      C[rr] = fma(-ucol[rr], urc, C[rr]);
+      Vd[rr] = fma(-ucol[rr], urv, Vd[rr]);
     }
   }
   // Vt[hi + 4 r][lc] = Vd[lc][hi + 4 r]: that element sits in lane ((lc & 3), hi + 4 r) -> index (lc & 3) * 16 + hi + 4 r, register lc >> 2
@@ -156,84 +174,48 @@ __device__ __forceinline__ void aemr_diag(double (&C)[4], double (&Vd)[4], doubl
 // instructions on its dependent chain (~40 per pivot at ~8 cycles), and the swaps and DPP moves are more instructions than the
 // ds_bpermute they replace.)
 
-// -1/2 |V r|^2 for one chain by ONE wave: Vc = that chain's lower tiles, s_r = r in LDS (zero beyond m, 16 T entries).
-// Block row p: z[hi + 4 r] += V(p, i)[r] * r[16 i + lc] over its tiles, one 16-lane reduction per register, squares summed.
-// Every lane returns the value.  TW / tw: block rows are dealt round-robin to TW cooperating waves (the caller adds the parts).
-template <int T, int TW = 1>
-__device__ __forceinline__ double aem_quad_tiles_part(const double* __restrict__ Vc, const double* __restrict__ s_r, int lane, int tw = 0) {
+// |L^-1 r|^2 for one chain by ONE wave from the factor form: Wc = that chain's tiles, s_r = r in LDS (16 nbr entries read).
+// Blocked forward substitution, block column q:  t[lc] = r[16 q + lc] - sum_{i < q} sum_k U_iq[k][lc] z_i[k]  (a lane multiplies
+// its four rows k = hi + 4 r of each tile -- z_i[hi + 4 r] is exactly what it holds from step i -- and sum_rows() adds the four
+// 16-lane rows);  z_q[hi + 4 r] = sum_lc (L_qq^-1)[hi + 4 r][lc] t[lc]  (one 16-lane DPP reduction per register).  No LDS
+// traffic beyond r, no transposition; the tile loads do not depend on z and are issued ahead by the compiler.
+// Returns, per lane, the squares of the z entries of its 16-lane row: finish with sum_rows() (and -0.5).  nbr <= T block
+// columns are evaluated (the rows of blocks beyond the outputs are identity and r is not defined there).
+template <int T>
+__device__ __forceinline__ double aem_quad_factor(const double* __restrict__ Wc, const double* __restrict__ s_r, int lane, int nbr = T) {
   const int lc = lane & 15;
+  double z[T][4];
   double sq = 0.0;
 #pragma unroll
-  for (int p = 0; p < T; ++p) {
-    if (TW > 1 && (p % TW) != tw) continue;
-    double v[T][4];
+  for (int q = 0; q < T; ++q) {
+    if (q < nbr) {  // (uniform)
+      double t = 0.0;
 #pragma unroll
-    for (int i = 0; i <= p; ++i)
+      for (int i = 0; i < q; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[i][r] = Vc[(size_t)(aemr_lt(p, i) * 4 + r) * 64 + lane];
-    double z[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int r = 0; r < 4; ++r) t = fma(Wc[(size_t)(aemr_lt(q, i) * 4 + r) * 64 + lane], z[i][r], t);
+      t = s_r[16 * q + lc] - sum_rows(t);
 #pragma unroll
-    for (int i = 0; i <= p; ++i) {
-      const double rv = s_r[16 * i + lc];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) z[r] = fma(v[i][r], rv, z[r]);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const double zz = aemr_row_sum(z[r]);
-      sq = fma(zz, zz, sq);
+      for (int r = 0; r < 4; ++r) {
+        const double zz = aemr_row_sum(Wc[(size_t)(aemr_lt(q, q) * 4 + r) * 64 + lane] * t);
+        z[q][r] = zz;
+        sq = fma(zz, zz, sq);
+      }
     }
   }
-  return sq;  // per 16-lane row: the squares of its four output rows per block row; finish with sum_rows() and -0.5
-}
-// The same with the number of block rows known at run time (nbr <= T): r is read below 16 nbr only -- for callers whose residual
-// vector is not padded to the instance's width.
-template <int T>
-__device__ __forceinline__ double aem_quad_tiles_rows(const double* __restrict__ Vc, const double* __restrict__ s_r, int lane, int nbr) {
-  const int lc = lane & 15;
-  double sq = 0.0;
-  for (int p = 0; p < nbr; ++p) {
-    double v[T][4];
-    const double* __restrict__ Vp = Vc + (size_t)aemr_lt(p, 0) * 256 + lane;
-#pragma unroll
-    for (int i = 0; i < T; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[i][r] = i <= p ? Vp[(size_t)(i * 4 + r) * 64] : 0.0;
-    double z[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int i = 0; i < T; ++i) {
-      const double rv = i <= p ? s_r[16 * i + lc] : 0.0;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) z[r] = fma(v[i][r], rv, z[r]);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const double zz = aemr_row_sum(z[r]);
-      sq = fma(zz, zz, sq);
-    }
-  }
-  return -0.5 * sum_rows(sq);
-}
-template <int T>
-__device__ __forceinline__ double aem_quad_tiles(const double* __restrict__ Vc, const double* __restrict__ s_r, int lane) {
-  return -0.5 * sum_rows(aem_quad_tiles_part<T, 1>(Vc, s_r, lane, 0));
+  return sq;
 }
 
-// Measured and not kept (tools/aem_refresh_probe.hip -DAEMR_TRACE): the right-looking V update of row q - 1 dealt over the sixteen
-// pivots of row q's diagonal tile (independent work under a dependent chain) -- the two phases took 109 000 cycles together instead
-// of 51 000 + 33 000 one after the other: the fp64 matrix instruction holds the fp64 vector lanes, so it delays the chain it was
-// meant to hide under, as DESIGN.md notes for the step kernels.
-//
 // NSUM = trackers summed into Sigma_bias (a template parameter: every `nsum > 1 ? load : 0` of a runtime count became a branch
 // of its own -- a thousand basic blocks -- and the register allocator spilled 700 registers across them).
 //
-// Schedule: LEFT-looking for U (block row q of Sigma is loaded when step q needs it -- its loads fly under step q - 1 -- and
-// receives all its updates from the finished rows at once), RIGHT-looking for V (a finished row of V updates the partial
-// sums of the rows below and leaves).  Live tiles at step q: finished U(p, i), p <= q < i and the V partial sums of the rows
-// below, (q + 1)(T - 1 - q) each: 36 of 72 at most, and nothing is resident before it is needed.  (First version: all 36
-// tiles of Sigma loaded up front, right-looking for both -- 44 live tiles, and the allocator, asked for ~150 registers more than
-// the tiles themselves, spilled the early-loaded late-used tiles to scratch: 180 / 360 / 540 spilled registers and 417 / 624 /
-// 917 us per launch at NSUM = 1 / 2 / 3, still under the 730 us of the kernel it replaces.)
+// Schedule: LEFT-looking (block row q of Sigma is loaded when step q needs it -- its loads fly under step q - 1 -- and receives all
+// its updates from the finished rows at once).  Live tiles at step q: the finished U(p, i), p < q <= i, and the row:
+// (q + 1)(T - q), 20 of 36 at most.  History: round 4's first version loaded all of Sigma up front and inverted right-looking (44
+// live tiles, 180-540 spilled registers, 417-917 us per launch); its second, lazy one still carried the partial sums of V = L^-1
+// (36 live tiles, 28-74 spilled, 300-340 us).  Measured and not kept in round 4: matrix instructions dealt over the sixteen pivots
+// of the diagonal tile (the fp64 matrix instruction holds the fp64 vector lanes: it delays the chain it was meant to hide under);
+// k-slice-outermost matrix loops (more spills).
 #ifdef AEMR_TRACE  // tools/aem_refresh_probe.hip -DAEMR_TRACE: cycle stamps of chain 0's wave at the phase boundaries
 __device__ long long g_aemr_trace[64];
 #define AEMR_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_aemr_trace[i] = __builtin_readcyclecounter(); } while (0)
@@ -241,8 +223,11 @@ __device__ long long g_aemr_trace[64];
 #define AEMR_STAMP(i) do { } while (0)
 #endif
 
+#ifndef AEMR_WAVES
+#define AEMR_WAVES 1  // chains per SIMD: one 512-register wave (tools/aem_refresh_probe.hip -DAEMR_WAVES=2: see the note at the loads)
+#endif
 template <int T, int NSUM>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) k_aem_refresh(const AemRefreshArgs a) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AEMR_WAVES, AEMR_WAVES))) k_aem_refresh(const AemRefreshArgs a) {
   constexpr int NT = aemr_tiles(T);
   AEMR_STAMP(0);
   constexpr int MP = 16 * T;  // the row stride IS the instance's width (64 / 128): compile-time offsets
@@ -253,12 +238,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   if (c >= a.N) return;
   const bool want_ll = a.rvec != nullptr;
   double* __restrict__ Vc = a.V + (size_t)c * NT * 256;
-  const __amdgpu_buffer_rsrc_t Vrs = aemr_rsrc(Vc);
+  const __amdgpu_buffer_rsrc_t Vrs = aemr_rsrc(Vc, 1);
   const size_t cbase = (size_t)c * NT * 256;
-  const __amdgpu_buffer_rsrc_t sg0 = aemr_rsrc(a.sig[0] + cbase);
-  const __amdgpu_buffer_rsrc_t sg1 = aemr_rsrc(NSUM > 1 ? a.sig[1] + cbase : a.sig[0] + cbase);
+  const __amdgpu_buffer_rsrc_t sg0 = aemr_rsrc(a.sig[0] + cbase, 2);
+  const __amdgpu_buffer_rsrc_t sg1 = aemr_rsrc(NSUM > 1 ? a.sig[1] + cbase : a.sig[0] + cbase, 3);
   const __amdgpu_buffer_rsrc_t sg2 = aemr_rsrc(NSUM > 2 ? a.sig[2] + cbase : a.sig[0] + cbase);
-  const __amdgpu_buffer_rsrc_t sge = aemr_rsrc(a.cov);
+  const __amdgpu_buffer_rsrc_t sge = aemr_rsrc(a.cov, 4);
 
   // ---- the tracker's covariance update (k_aem_action left its vectors): every element of sig[0] on its way in ----
   //   state-independent (utils.py:117-122, sd = 1, eps = 0):  S <- (t-1)/t S + 1/t (t mu mu^T - (t+1) mu' mu'^T + x x^T)
@@ -273,21 +258,41 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     return upd ? nv : old;
   };
 
-  // ---- everything the first step needs is requested at once: r, the update vectors, the diagonals of the trackers (the 1e-9 rule
-  // below), block row 0 of every source -- ONE memory round trip in front of the first matrix instruction instead of three
-  // dependent ones (vectors to LDS, then the diagonals, then row 0)
-  int lane_rm = lane * 8;  // byte offset of this lane's element inside a 512-byte tile row
-  double raw[2][T][4][4];  // [buffer][tile i of the row][source: 3 trackers + Sigma_e][r]
-  auto issue_row = [&](int q, int buf) {  // (no bounds: the padding of the trackers is zero and that of Sigma_e the identity)
+  // ---- loads.  A block row of the sum arrives in two groups:
+  //   EARLY(q) = the trackers sig[0] (+ sig[1]): the long-latency HBM reads, requested a whole step ahead (after the matrix update
+  //              of step q - 1, so that their registers do not sit beside its accumulators) and folded into the row's partial sums
+  //              -- sig[0] updated and stored back on the way -- at the end of step q - 1: they fly under the diagonal tile's
+  //              sixteen dependent pivots;
+  //   LATE(q)  = Sigma_e (shared by all chains: L2) (+ sig[2]): requested once EARLY(q) has shrunk to one tile each, consumed
+  //              at the top of step q.
+  // (Round 5 also built the kernel for TWO chains per SIMD -- 256 registers, the second tracker through LDS by LDS-DMA
+  // (buffer_load ... lds), 26 live tiles at the fullest point, ~50 registers spilled: 342 us per launch against 307 for this form.
+  // A SIMD gains little from a second wave here: the matrix phases do not overlap at all (the fp64 matrix pipe), the diagonal tile's
+  // ds_bpermute exchanges share the CU's LDS (tools/aem_diag_probe.hip: 5 420 cycles per tile at one wave per SIMD, 7 810 at two =
+  // 1.39 x the throughput, 12 510 at four), and every spill reload is a full vmcnt drain.  profiles/r05_aem_refresh_notes.md.)
+  int lane_e = lane * 8, lane_l = lane * 8;  // byte offset of this lane's element inside a 512-byte tile row (one per load group: see the pins below)
+  constexpr int NE = NSUM > 1 ? 2 : 1, NL = NSUM > 2 ? 2 : 1;
+  double raw_e[T][NE][4], raw_l[T][NL][4];
+  auto issue_early = [&](auto qc) {  // (no bounds: the padding of the trackers is zero and that of Sigma_e the identity)
+    constexpr int q = decltype(qc)::value;
 #pragma unroll
     for (int i = q; i < T; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int so = (aemr_ut(T, q, i) * 4 + r) * 512;
-        raw[buf][i][0][r] = aemr_ld(sg0, lane_rm, so);
-        if constexpr (NSUM > 1) raw[buf][i][1][r] = aemr_ld(sg1, lane_rm, so);
-        if constexpr (NSUM > 2) raw[buf][i][2][r] = aemr_ld(sg2, lane_rm, so);
-        raw[buf][i][3][r] = aemr_ld(sge, lane_rm, so);
+        raw_e[i][0][r] = aemr_ld(sg0, lane_e, so);
+        if constexpr (NSUM > 1) raw_e[i][1][r] = aemr_ld(sg1, lane_e, so);
+      }
+  };
+  auto issue_late = [&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+#pragma unroll
+    for (int i = q; i < T; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int so = (aemr_ut(T, q, i) * 4 + r) * 512;
+        raw_l[i][0][r] = aemr_ld(sge, lane_l, so);
+        if constexpr (NSUM > 2) raw_l[i][1][r] = aemr_ld(sg2, lane_l, so);
       }
   };
   constexpr int NH = (16 * T + 63) / 64;  // vector elements per lane
@@ -308,7 +313,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       d2[h] = NSUM > 2 ? aemr_ld(sg2, o, 0) : 0.0;
     }
   }
-  issue_row(0, 0);
+  issue_early(std::integral_constant<int, 0>{});  // (one memory round trip in front of the first step: vectors, diagonals, row 0 of the trackers)
   // ---- the 1e-9 rule (distributions.py:399-402: no re-inversion while every entry of Sigma_bias is below 1e-9) ----
   // The rows are loaded lazily, so the decision cannot wait for them: the diagonal decides almost always (a covariance with an
   // entry >= 1e-9 has a diagonal entry >= 1e-9 up to rounding); when the diagonal says "small" the exact test over every entry
@@ -359,118 +364,121 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         }
       }
     }
-    sq = aem_quad_tiles_part<T, 1>(Vc, s_r, lane, 0);
+    sq = aem_quad_factor<T>(Vc, s_r, lane);
   } else {
     const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
-    double4_t Uf[NT];  // finished rows of U (upper tiles), whole 8-register tuples from birth to their last matrix instruction
-    double4_t Vl[NT];  // V: partial sums of the rows below, final rows on their way out
+    double4_t Uf[NT];  // finished rows of U (upper tiles, off-diagonal), whole 8-register tuples from birth to their last matrix instruction
+    double4_t Cn[T];   // the block row being summed: partial (trackers) at the end of step q - 1, complete at the top of step q
+    double fs[T];      // forward substitution (update_link): partial sums  sum_{p < q} sum_k U_pi[k][lc] z_p[k]  of the rows below
+#pragma unroll
+    for (int i = 0; i < T; ++i) fs[i] = 0.0;
+    // EARLY(q) -> partial sums of row q: the tracker update (utils.py:117-122 / :199) on every element of sig[0] on its way in,
+    // stored back; the reference's sum over the trackers starts from zero (proposal.py:1563-1569)
+    auto fold_early = [&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      double xr[4], mr[4], pr[4];  // the update vectors at this lane's four rows of the block row
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        xr[r] = s_u[16 * q + hi + 4 * r];
+        mr[r] = s_u[MP + 16 * q + hi + 4 * r];
+        pr[r] = s_u[2 * MP + 16 * q + hi + 4 * r];
+      }
+#pragma unroll
+      for (int i = q; i < T; ++i) {
+        const double xc = s_u[16 * i + lc], mc = s_u[MP + 16 * i + lc], pc = s_u[2 * MP + 16 * i + lc];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double s0 = updated(raw_e[i][0][r], xr[r], mr[r], pr[r], xc, mc, pc);
+          aemr_st(s0, sg0, lane * 8, (aemr_ut(T, q, i) * 4 + r) * 512);  // (no update wanted: the old value goes back)
+          double sb = 0.0 + s0;
+          if constexpr (NSUM > 1) sb += raw_e[i][1][r];
+          Cn[i][r] = sb;
+        }
+      }
+    };
+    auto fold_late = [&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+#pragma unroll
+      for (int i = q; i < T; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double sb = Cn[i][r];
+          if constexpr (NSUM > 2) sb += raw_l[i][1][r];
+          Cn[i][r] = raw_l[i][0][r] + sb;
+        }
+    };
+    fold_early(std::integral_constant<int, 0>{});
+    asm volatile("" : "+v"(lane_l) : "v"(Cn[0][0]));
+    issue_late(std::integral_constant<int, 0>{});
     aemr_static_for<T>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
       __builtin_amdgcn_sched_barrier(0);
-      // block row q of Sigma_e + Sigma_bias (the reference's sum over the trackers starts from zero, proposal.py:1563-1569)
-      double4_t Cq[T];
-      {
-        double xr[4], mr[4], pr[4];  // the update vectors at this lane's four rows of the block row
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          xr[r] = s_u[16 * q + hi + 4 * r];
-          mr[r] = s_u[MP + 16 * q + hi + 4 * r];
-          pr[r] = s_u[2 * MP + 16 * q + hi + 4 * r];
-        }
-#pragma unroll
-        for (int i = q; i < T; ++i) {
-          const double xc = s_u[16 * i + lc], mc = s_u[MP + 16 * i + lc], pc = s_u[2 * MP + 16 * i + lc];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const double s0 = updated(raw[q & 1][i][0][r], xr[r], mr[r], pr[r], xc, mc, pc);
-            aemr_st(s0, sg0, lane * 8, (aemr_ut(T, q, i) * 4 + r) * 512);  // (no update wanted: the old value goes back)
-            double sb = 0.0 + s0;
-            if constexpr (NSUM > 1) sb += raw[q & 1][i][1][r];
-            if constexpr (NSUM > 2) sb += raw[q & 1][i][2][r];
-            Cq[i][r] = raw[q & 1][i][3][r] + sb;
-          }
-        }
-      }
-      // the lane offset of the loads two rows on is "produced" here, next to a value of this row: neither the optimiser nor the
-      // scheduler can then issue those loads before this row's sums exist (memory clobbers and sched_barrier alone did not hold
-      // them: every load went to the top of the kernel and half of them straight to scratch)
-      asm volatile("" : "+v"(lane_rm) : "v"(Cq[q][0]));
+      fold_late(qc);
       __builtin_amdgcn_sched_barrier(0);
       AEMR_STAMP(2 + 6 * q);
       // left-looking: C(q, i) -= sum_{p < q} U_pq^T U_pi
+      // (k-slice outermost: consecutive matrix instructions on different accumulators -- a dependent fp64 matrix instruction waits
+      // for its predecessor; with V = L^-1 beside U in round 4 this order cost 50 spilled registers more, now there is room)
 #pragma unroll
       for (int p = 0; p < q; ++p) {
         const double4_t nA = -Uf[aemr_ut(T, p, q)];
-        // (measured: with the k-slice outermost -- consecutive matrix instructions on different accumulators -- here and in the two
-        // loops below the allocator spills 84 instead of 34 registers and the launch takes 447 instead of 390 us)
 #pragma unroll
-        for (int i = q; i < T; ++i)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) Cq[i] = mfma_f64(nA[r], Uf[aemr_ut(T, p, i)][r], Cq[i]);
+          for (int i = q; i < T; ++i) Cn[i] = mfma_f64(nA[r], Uf[aemr_ut(T, p, i)][r], Cn[i]);
       }
       __builtin_amdgcn_sched_barrier(0);
-      // the next row's loads fly under this row's diagonal tile (16 dependent pivots, ~1.5 us) and V updates: issued here, not at
-      // the top of the step, their 8 (NSUM + 1) registers per tile do not sit beside the accumulators of the update above
       AEMR_STAMP(3 + 6 * q);
-      if constexpr (q + 1 < T) issue_row(q + 1, (q + 1) & 1);
+      // the next row's trackers fly under this row's diagonal tile (16 dependent pivots) and scaling.  The lane offset of the loads is
+      // "produced" here, next to a value of this row: neither the optimiser nor the scheduler can then issue them before this
+      // row's update exists (memory clobbers and sched_barrier alone did not hold them in round 4: every load went to the top of
+      // the kernel and half of them straight to scratch)
+      if constexpr (q + 1 < T) {
+        asm volatile("" : "+v"(lane_e) : "v"(Cn[q][0]));
+        issue_early(std::integral_constant<int, q + 1>{});
+      }
       __builtin_amdgcn_sched_barrier(0);
       double Cd[4], Vd[4], Vt[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Cd[r] = Cq[q][r];
+      for (int r = 0; r < 4; ++r) Cd[r] = Cn[q][r];
       aemr_diag(Cd, Vd, Vt, lc, hi);
       __builtin_amdgcn_sched_barrier(0);
       AEMR_STAMP(4 + 6 * q);
-      // the rest of block row q times V_qq (lower-triangular inverse of the diagonal tile's factor)
+      // the rest of block row q times (L_qq)^-1: U_qi = (L_qq)^-1 C_qi
 #pragma unroll
-      for (int i = q + 1; i < T; ++i) {
-        double4_t acc = zero4;
+      for (int i = q + 1; i < T; ++i) Uf[aemr_ut(T, q, i)] = zero4;
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) acc = mfma_f64(Vt[kc], Cq[i][kc], acc);
-        Uf[aemr_ut(T, q, i)] = acc;
-      }
+      for (int kc = 0; kc < 4; ++kc)
 #pragma unroll
-      for (int i = 0; i < q; ++i) {
-        double4_t acc = zero4;
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) acc = mfma_f64(Vt[kc], Vl[aemr_lt(q, i)][kc], acc);
-        Vl[aemr_lt(q, i)] = acc;
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Vl[aemr_lt(q, q)][r] = Vd[r];
+        for (int i = q + 1; i < T; ++i) Uf[aemr_ut(T, q, i)] = mfma_f64(Vt[kc], Cn[i][kc], Uf[aemr_ut(T, q, i)]);
       __builtin_amdgcn_sched_barrier(0);
       AEMR_STAMP(5 + 6 * q);
-      // block row q of V is final: out it goes, and its share of |V r|^2
-      double z[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int i = 0; i <= q; ++i) {
-        const double rv = s_r[16 * i + lc];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          aemr_st(Vl[aemr_lt(q, i)][r], Vrs, lane * 8, (aemr_lt(q, i) * 4 + r) * 512);
-          z[r] = fma(Vl[aemr_lt(q, i)][r], rv, z[r]);
-        }
-      }
+      // block row q of the factor is final: the inverse of its diagonal tile to tile (q, q), U_qi to tile (i, q) of the factor form;
+      // and update_link advances one block: t = r_q - (sums so far), z_q = (L_qq)^-1 t, the rows below take U_qi^T z_q
+      const double tq = s_r[16 * q + lc] - sum_rows(fs[q]);
+      double zq[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double zz = aemr_row_sum(z[r]);
-        sq = fma(zz, zz, sq);
+        aemr_st(Vd[r], Vrs, lane * 8, (aemr_lt(q, q) * 4 + r) * 512);
+        zq[r] = aemr_row_sum(Vd[r] * tq);
+        sq = fma(zq[r], zq[r], sq);
       }
+#pragma unroll
+      for (int i = q + 1; i < T; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          aemr_st(Uf[aemr_ut(T, q, i)][r], Vrs, lane * 8, (aemr_lt(i, q) * 4 + r) * 512);
+          fs[i] = fma(Uf[aemr_ut(T, q, i)][r], zq[r], fs[i]);
+        }
       __builtin_amdgcn_sched_barrier(0);
       AEMR_STAMP(6 + 6 * q);
-      // right-looking for V: the rows below take  -U_qq'^T V_qi  into their partial sums (tile (q', q) is born here)
-#pragma unroll
-      for (int q2 = q + 1; q2 < T; ++q2) {
-        __builtin_amdgcn_sched_barrier(0);  // one block row at a time: the negated copy of U_qq' lives for this row only
-        const double4_t nA = -Uf[aemr_ut(T, q, q2)];
-#pragma unroll
-        for (int i = 0; i <= q; ++i) {
-          double4_t acc = i < q ? Vl[aemr_lt(q2, i)] : zero4;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc = mfma_f64(nA[r], Vl[aemr_lt(q, i)][r], acc);
-          Vl[aemr_lt(q2, i)] = acc;
-        }
+      // the next row: its trackers (requested above) shrink to partial sums, then Sigma_e is requested
+      if constexpr (q + 1 < T) {
+        fold_early(std::integral_constant<int, q + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : "+v"(lane_l) : "v"(Cn[q + 1][0]));
+        issue_late(std::integral_constant<int, q + 1>{});
       }
-      __builtin_amdgcn_sched_barrier(0);
       AEMR_STAMP(7 + 6 * q);
     });
   }
@@ -489,12 +497,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 // ------------------------------------------------------------------------------------------------
 // The base level of a host-sequenced hierarchy under the dense error model: one subchain of S Metropolis-Hastings steps per
 // launch (chain.py:96-129 inside MLDAChain / DAChain; AdaptiveGaussianLogLike.loglike, distributions.py:404-425), ONE WAVE PER
-// CHAIN.  k_ml_steps evaluates -1/2 |V r'|^2 per step and chain from that chain's 72 KB factor: S passes over V per launch,
+// CHAIN.  k_ml_steps evaluates -1/2 |L^-1 r'|^2 per step and chain from that chain's 72 KB factor: S passes over it per launch,
 // 360 KB per chain at S = 5 -- the launch ran at the HBM roofline and was a third of the configuration's wall clock.  The model is
 // linear and the increments of the block are known before its first step, so with F = A theta (no offsets)
-//     V r' = keep V F + V A (s inc_k) + V (bias - ytil)            (keep = sqrt(1 - beta^2) for pCN, 1 otherwise)
-// and ONE pass over V multiplies all S + 2 vectors [F | bias - ytil | A s inc_1 ... A s inc_S]; a step is then an m-vector update
-// and two reductions.  The products are re-derived from theta at every launch (rounding does not accumulate beyond one
+//     L^-1 r' = keep L^-1 F + L^-1 A (s inc_k) + L^-1 (bias - ytil)  (keep = sqrt(1 - beta^2) for pCN, 1 otherwise)
+// and ONE pass over the factor solves for all S + 2 vectors [F | bias - ytil | A s inc_1 ... A s inc_S] (round 5: a blocked forward
+// substitution on the factor form; round 4 multiplied by V = L^-1); a step is then an m-vector update and two reductions.  The products are re-derived from theta at every launch (rounding does not accumulate beyond one
 // subchain); log-densities agree with the step-by-step evaluation to rounding, decisions are the same.
 // Diagonal prior (bounded support included), fixed subchain lengths; anything else stays with k_ml_steps.
 // ------------------------------------------------------------------------------------------------
@@ -532,7 +540,7 @@ __global__ void __launch_bounds__(64) k_aem_base_steps(const AemBaseArgs a) {
   constexpr int MP = 16 * T, NH = MP / 64 > 0 ? MP / 64 : 1;  // observations per lane
   constexpr int CMAX = 8;                                      // vectors per pass over V
   extern __shared__ __attribute__((aligned(16))) double aemb_smem[];
-  double* s_X = aemb_smem;         // [S + 2][MP]: F, bias - ytil, A s inc_k; overwritten by V times them; then CMAX staged parameter vectors [64]
+  double* s_X = aemb_smem;         // [S + 2][MP]: F, bias - ytil, A s inc_k; overwritten by L^-1 times them; then CMAX staged parameter vectors [64]
   const int lane = threadIdx.x, lc = lane & 15, hi = lane >> 4;
   const int64_t c = blockIdx.x;
   if (c >= a.N) return;
@@ -540,8 +548,6 @@ __global__ void __launch_bounds__(64) k_aem_base_steps(const AemBaseArgs a) {
   const bool lj = lane < d;
   double th = lj ? a.theta[c * a.DP + lane] : 0.0;
   const double scal = a.scaling[c];
-  const double keep = a.pcn ? sqrt(1.0 - scal * scal) : 1.0;
-  double lp = a.lp[c], ll = a.ll[c];
   const double* __restrict__ Vc = a.V + (size_t)c * aemr_tiles(T) * 256;
 
   // ---- the S + 1 products with the level's operator, the offsets ----
@@ -587,50 +593,65 @@ __global__ void __launch_bounds__(64) k_aem_base_steps(const AemBaseArgs a) {
   }
   __syncthreads();
 
-  // ---- Z = V X: one pass over the chain's factor for CMAX vectors; block rows from the last to the first, so that the
-  // results can take the place of the operands (row p of Z needs the blocks 0..p of X only) ----
+  // ---- Z = L^-1 X: ONE pass over the chain's factor for CMAX vectors at a time, blocked forward substitution by block columns:
+  //   t[lc] = x[16 q + lc] - sum_{i < q} sum_k U_iq[k][lc] z_i[k],   z_q = (L_qq)^-1 t      (aem_quad_factor, for CMAX vectors)
+  // The results take the place of the operands in LDS -- block q of a vector is read (as x) at step q, before it is written -- with
+  // the entries of a block PERMUTED: position 4 hi + r holds z[hi + 4 r], so that a lane fetches the four entries it multiplies
+  // with one 32-byte read.  Everything after this pass is elementwise over vectors in the same order or a sum of squares: the
+  // permutation is never undone.  (The first version kept the partial sums of all blocks below in registers, right-looking: 502
+  // registers, or 984 bytes of scratch at two waves per SIMD.)
   for (int k0 = 0; k0 < NC; k0 += CMAX) {
     const int nk = NC - k0 < CMAX ? NC - k0 : CMAX;
-    for (int p = T - 1; p >= 0; --p) {
-      double v[T][4];
-      const double* __restrict__ Vp = Vc + (size_t)aemr_lt(p, 0) * 256 + lane;
+    int lane_w = lane * 8;  // byte offset of this lane's element inside a 512-byte tile row
+    const __amdgpu_buffer_rsrc_t Wrs = aemr_rsrc(Vc);  // (descriptor + one lane offset + compile-time scalar offsets: no address pairs)
 #pragma unroll
-      for (int i = 0; i < T; ++i)
+    for (int q = 0; q < T; ++q) {
+      double w[T][4];  // tiles (q, 0 .. q) of the factor form: 2 (q + 1) KB contiguous
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[i][r] = i <= p ? Vp[(size_t)(i * 4 + r) * 64] : 0.0;
-      double z[CMAX][4];
+      for (int i = 0; i <= q; ++i)
 #pragma unroll
-      for (int k = 0; k < CMAX; ++k)
+        for (int r = 0; r < 4; ++r) w[i][r] = aemr_ld(Wrs, lane_w, (aemr_lt(q, i) * 4 + r) * 512);
+      // (the vectors in two halves: four result quadruples in registers instead of eight -- 138 registers, three waves per SIMD)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) z[k][r] = 0.0;
+      for (int kh = 0; kh < CMAX; kh += CMAX / 2) {
+        double zq[CMAX / 2][4];
 #pragma unroll
-      for (int i = 0; i < T; ++i) {
-        if (i > p) continue;
+        for (int k = 0; k < CMAX / 2; ++k) {
+          const double* __restrict__ xk = s_X + (size_t)(k0 + (kh + k < nk ? kh + k : 0)) * MP;  // (vectors beyond nk: recomputed copies of the first, dropped)
+          double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < CMAX; ++k) {
-          const double xv = k < nk ? s_X[(size_t)(k0 + k) * MP + 16 * i + lc] : 0.0;
+          for (int i = 0; i < q; ++i) {
+            const double4_t zv = *reinterpret_cast<const double4_t*>(xk + 16 * i + 4 * hi);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) z[k][r] = fma(v[i][r], xv, z[k][r]);
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < CMAX; ++k)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) z[k][r] = aemr_row_sum(z[k][r]);
-      __syncthreads();  // every read of block p of X is done
-      if (lc == 0) {
-#pragma unroll
-        for (int k = 0; k < CMAX; ++k)
-          if (k < nk) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s_X[(size_t)(k0 + k) * MP + 16 * p + hi + 4 * r] = z[k][r];
+            for (int r = 0; r < 4; ++r) acc = fma(w[i][r], zv[r], acc);
           }
+          const double t = xk[16 * q + lc] - sum_rows(acc);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) zq[k][r] = aemr_row_sum(w[q][r] * t);
+        }
+        // (the tile loads of step q + 1 take their lane offset from here: hoisted to the top of the fully unrolled pass the 36 tiles
+        // are 288 registers, or a kilobyte of scratch under any occupancy target; the waves sharing the SIMD hide the latency)
+        asm volatile("" : "+v"(lane_w) : "v"(zq[0][0]));
+        __syncthreads();  // every read of block q of these vectors is done
+        if (lc == 0) {
+#pragma unroll
+          for (int k = 0; k < CMAX / 2; ++k)
+            if (kh + k < nk) {
+              double4_t zv;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) zv[r] = zq[k][r];
+              *reinterpret_cast<double4_t*>(s_X + (size_t)(k0 + kh + k) * MP + 16 * q + 4 * hi) = zv;
+            }
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
   }
 
   // ---- the S steps ----
+  // (what only the steps use is read here, not at the top: held across the pass above it cost three spilled registers at three waves per SIMD)
+  const double keep = a.pcn ? sqrt(1.0 - scal * scal) : 1.0;
+  double lp = a.lp[c], ll = a.ll[c];
   double zF[NH], zb[NH];
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
@@ -659,7 +680,7 @@ __global__ void __launch_bounds__(64) k_aem_base_steps(const AemBaseArgs a) {
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const int o = lane + 64 * h;
-      zn[h] = o < MP ? (keep * zF[h] + s_X[(size_t)(s + 2) * MP + o]) : 0.0;  // V (keep F + A s inc): the new V F if accepted
+      zn[h] = o < MP ? (keep * zF[h] + s_X[(size_t)(s + 2) * MP + o]) : 0.0;  // L^-1 (keep F + A s inc): the new L^-1 F if accepted
       const double zz = zn[h] + zb[h];
       ssq = fma(zz, zz, ssq);
     }

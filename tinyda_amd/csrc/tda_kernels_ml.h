@@ -324,8 +324,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
         // -1/2 |V r|^2 from the chain's lower tiles of V = L^-1 (72 KB per chain at 128 outputs, 512-byte rows; the rows of
         // blocks beyond the outputs are identity and r is not defined there: only the block rows of the outputs are read)
         double qv;
-        if (LD <= 64) qv = aem_quad_tiles_rows<4>(a.aem_P + (size_t)gc * aemr_v_doubles(64), rrow, lane, MP >> 4);
-        else qv = aem_quad_tiles_rows<8>(a.aem_P + (size_t)gc * aemr_v_doubles(128), rrow, lane, MP >> 4);
+        if (LD <= 64) qv = -0.5 * sum_rows(aem_quad_factor<4>(a.aem_P + (size_t)gc * aemr_v_doubles(64), rrow, lane, MP >> 4));
+        else qv = -0.5 * sum_rows(aem_quad_factor<8>(a.aem_P + (size_t)gc * aemr_v_doubles(128), rrow, lane, MP >> 4));
         if (lane == 0) s_R[16 * RSa + cc] = qv;
       }
       if (prior_dense && lane < 16) {}  // (s_redp already written above)
@@ -822,15 +822,15 @@ __global__ void __launch_bounds__(MPT) k_aem_action(const AemArgs a) {
     }
     return f;
   };
-  // -1/2 r^T (Sigma_e + Sigma_bias)^-1 r = -1/2 |V r|^2 with chain c's triangular factor V = L^-1 of adaptive level lev
-  // (tda_kernels_aemr.h: lower 16 x 16 tiles in the MFMA C/D layout); r given per lane (already bias corrected).  The block rows
-  // of V are dealt to the workgroup's waves.
+  // -1/2 r^T (Sigma_e + Sigma_bias)^-1 r = -1/2 |L^-1 r|^2 from chain c's factor of adaptive level lev (tda_kernels_aemr.h: factor
+  // form, 16 x 16 tiles in the MFMA C/D layout) by blocked forward substitution; r given per lane (already bias corrected).
   auto quad = [&](int lev, double r) {
     __syncthreads();
     s_v[MPT + lane] = lo ? r : 0.0;
     __syncthreads();
     const double* __restrict__ Vc = a.cov_inv[lev] + (size_t)c * aemr_v_doubles(MPT);
-    double s = sum_rows(aem_quad_tiles_part<MPT / 16, NW>(Vc, s_v + MPT, lane & 63, lane >> 6));
+    // (the substitution is one wave's dependent chain: wave 0 runs it, a second wave of a 128-output workgroup contributes zero)
+    double s = (lane >> 6) == 0 ? sum_rows(aem_quad_factor<MPT / 16>(Vc, s_v + MPT, lane & 63)) : 0.0;
     if constexpr (NW > 1) {
       __syncthreads();
       if ((lane & 63) == 0) s_x[lane >> 6] = s;
@@ -1054,7 +1054,8 @@ __global__ void __launch_bounds__(MPT) k_ext_aem_action(const ExtAemArgs a) {
     s_v[MPT + lane] = lo ? r : 0.0;
     __syncthreads();
     const double* __restrict__ Vc = a.cov_inv[lev] + (size_t)c * aemr_v_doubles(MPT);
-    double s = sum_rows(aem_quad_tiles_part<MPT / 16, NW>(Vc, s_v + MPT, lane & 63, lane >> 6));
+    // (the substitution is one wave's dependent chain: wave 0 runs it, a second wave of a 128-output workgroup contributes zero)
+    double s = (lane >> 6) == 0 ? sum_rows(aem_quad_factor<MPT / 16>(Vc, s_v + MPT, lane & 63)) : 0.0;
     if constexpr (NW > 1) {
       __syncthreads();
       if ((lane & 63) == 0) s_x[lane >> 6] = s;
@@ -1258,7 +1259,7 @@ __global__ void __launch_bounds__(MPT) k_ext_aem_accept(const ExtAemAcceptArgs a
   double ll_n;
   {
     const double* __restrict__ Vc = a.P + (size_t)c * aemr_v_doubles(MPT);
-    double sq = sum_rows(aem_quad_tiles_part<MPT / 16, NW>(Vc, s_r, lane & 63, lane >> 6));
+    double sq = (lane >> 6) == 0 ? sum_rows(aem_quad_factor<MPT / 16>(Vc, s_r, lane & 63)) : 0.0;
     if constexpr (NW > 1) {
       __syncthreads();
       if ((lane & 63) == 0) s_x[lane >> 6] = sq;

@@ -1,4 +1,4 @@
-// k_aem_refresh (tda_kernels_aemr.h) on its own: correctness against a host Cholesky / triangular inverse, and launch time at
+// k_aem_refresh (tda_kernels_aemr.h) on its own: correctness against a host Cholesky (factor form) / triangular inverse, and launch time at
 // 4096 chains.  Debug tool, not part of the library.
 // Build: hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -w -Itinyda_amd/csrc -Iinclude -o /tmp/arp tools/aem_refresh_probe.hip
 #include <hip/hip_runtime.h>
@@ -118,7 +118,7 @@ static int run_case(int m, int64_t N, int nsum, int reps) {
       const long long prev = q == 0 ? st[1] : st[2 + 6 * (q - 1) + 5];
       tot[0] += b[0] - prev; tot[1] += b[1] - b[0]; tot[2] += b[2] - b[1]; tot[3] += b[3] - b[2]; tot[4] += b[4] - b[3]; tot[5] += b[5] - b[4];
     }
-    printf(" row sums+update %lld, left-looking U %lld, diagonal tiles %lld, row scaling %lld, V out + z %lld, right-looking V %lld; total %lld\n",
+    printf(" row sums+update %lld, left-looking U %lld, diagonal tiles %lld, row scaling %lld, factor out + z %lld, (unused) %lld; total %lld\n",
            tot[0], tot[1], tot[2], tot[3], tot[4], tot[5], st[2 + 6 * T] - st[0]);
   }
 #endif
@@ -154,13 +154,27 @@ static int run_case(int m, int64_t N, int nsum, int reps) {
         W[(size_t)i * m + j] = -s / L[(size_t)i * m + i];
       }
     }
+    // the factor form (round 5): off-diagonal tiles hold L (as U = L^T tiles), the diagonal tiles the inverses of L's diagonal tiles
+    std::vector<long double> Dinv((size_t)MP * 16, 0.0L);  // [row][col within the row's diagonal tile]
+    for (int qb = 0; qb * 16 < m; ++qb)
+      for (int j = 0; j < 16 && qb * 16 + j < m; ++j) {
+        const int J = qb * 16 + j;
+        Dinv[(size_t)J * 16 + j] = 1.0L / L[(size_t)J * m + J];
+        for (int i = j + 1; i < 16 && qb * 16 + i < m; ++i) {
+          const int I = qb * 16 + i;
+          long double s = 0;
+          for (int k2 = j; k2 < i; ++k2) s += L[(size_t)I * m + qb * 16 + k2] * Dinv[(size_t)(qb * 16 + k2) * 16 + j];
+          Dinv[(size_t)I * 16 + j] = -s / L[(size_t)I * m + I];
+        }
+      }
     long double q = 0;
     for (int i = 0; i < m; ++i) {
       long double z = 0;
       for (int j = 0; j <= i; ++j) {
         z += W[(size_t)i * m + j] * rv[(size_t)(c % NV) * MP + j];
-        const double got = V[aemr_v_offset(i, j)];
-        const double ref = (double)W[(size_t)i * m + j];
+        const bool same = (i >> 4) == (j >> 4);
+        const double got = same ? V[aemr_v_offset(i, j)] : V[aemr_w_offset_offdiag(i, j)];
+        const double ref = same ? (double)Dinv[(size_t)i * 16 + (j & 15)] : (double)L[(size_t)i * m + j];
         worstV = fmax(worstV, fabs(got - ref) / (fabs(ref) + 1.0));
       }
       q += z * z;
