@@ -39,12 +39,13 @@ HOT = {
 # Every OTHER instance of the code object must be spill-free too, except the ones listed here with the number of spilled registers
 # they are known to have (a cap per instance, so that neither a new spiller nor a worse one goes unnoticed).
 #   (k_aem_refresh<8, *> left this list in round 5: the factor form -- no V = L^-1 beside U -- needs 412 - 452 of the 512 registers)
-#   k_ml_steps<64,3|4,4,false> the generic level kernel with three / four levels in one launch (C5 runs k_da_steps): 10 / 7 since the
-#                              upper levels' state waits in LDS between level actions (46 / 117 before);
+#   k_ml_steps<64,4,4,false>   the generic level kernel with four levels in one launch (C5 runs k_da_steps): 3 (round 4: 10 / 7 with three /
+#                              four levels, 46 / 117 before the upper levels' state waited in LDS; round 5: its error-model evaluation
+#                              solves in place in LDS, aem_quad_factor_inplace);
 #   k_ml_steps<64,*,4,true>    its instances for hierarchies with a dense observation covariance on some level (round 4)
 KNOWN_SPILLERS = {
-    "_ZN3tda10k_ml_stepsILi64ELi3ELi4ELb0EEE": 16, "_ZN3tda10k_ml_stepsILi64ELi4ELi4ELb0EEE": 16,
-    "_ZN3tda10k_ml_stepsILi64ELi2ELi4ELb1EEE": 32, "_ZN3tda10k_ml_stepsILi64ELi3ELi4ELb1EEE": 80, "_ZN3tda10k_ml_stepsILi64ELi4ELi4ELb1EEE": 112,
+    "_ZN3tda10k_ml_stepsILi64ELi4ELi4ELb0EEE": 8,
+    "_ZN3tda10k_ml_stepsILi64ELi2ELi4ELb1EEE": 24, "_ZN3tda10k_ml_stepsILi64ELi3ELi4ELb1EEE": 64, "_ZN3tda10k_ml_stepsILi64ELi4ELi4ELb1EEE": 104,
 }
 
 

@@ -206,6 +206,42 @@ __device__ __forceinline__ double aem_quad_factor(const double* __restrict__ Wc,
   return sq;
 }
 
+// The same substitution with the solved blocks kept in LDS instead of 8 T registers: s_r is OVERWRITTEN (block q of r by z_q, entries
+// permuted inside the block: position 4 hi + r holds z[hi + 4 r], one 32-byte read per tile for the lane that multiplies them), the
+// block loops are run-time loops.  For callers at their register peak (k_ml_steps evaluates every level through one inlined
+// function); the wave owns s_r.  Returns -1/2 |L^-1 r|^2 in every lane.
+template <int T>
+__device__ __forceinline__ double aem_quad_factor_inplace(const double* __restrict__ Wc, double* __restrict__ s_r, int lane, int nbr) {
+  const int lc = lane & 15, hi = lane >> 4;
+  double sq = 0.0;
+  for (int q = 0; q < nbr; ++q) {
+    const double* __restrict__ Wq = Wc + (size_t)aemr_lt(q, 0) * 256 + lane;
+    double acc = 0.0;
+    for (int i = 0; i < q; ++i) {
+      typedef double aemr_d2 __attribute__((ext_vector_type(2)));  // (16-byte pieces: the caller's row is 16-byte aligned, not 32)
+      const aemr_d2 z01 = *reinterpret_cast<const aemr_d2*>(s_r + 16 * i + 4 * hi), z23 = *reinterpret_cast<const aemr_d2*>(s_r + 16 * i + 4 * hi + 2);
+      acc = fma(Wq[(size_t)(i * 4 + 0) * 64], z01[0], acc);
+      acc = fma(Wq[(size_t)(i * 4 + 1) * 64], z01[1], acc);
+      acc = fma(Wq[(size_t)(i * 4 + 2) * 64], z23[0], acc);
+      acc = fma(Wq[(size_t)(i * 4 + 3) * 64], z23[1], acc);
+    }
+    const double t = s_r[16 * q + lc] - sum_rows(acc);
+    double zq[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      zq[r] = aemr_row_sum(Wq[(size_t)(q * 4 + r) * 64] * t);
+      sq = fma(zq[r], zq[r], sq);
+    }
+    __builtin_amdgcn_wave_barrier();  // (every lane has read block q of r)
+    if (lc == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_r[16 * q + 4 * hi + r] = zq[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  return -0.5 * sum_rows(sq);
+}
+
 // NSUM = trackers summed into Sigma_bias (a template parameter: every `nsum > 1 ? load : 0` of a runtime count became a branch
 // of its own -- a thousand basic blocks -- and the register allocator spilled 700 registers across them).
 //

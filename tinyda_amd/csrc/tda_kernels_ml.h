@@ -324,8 +324,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
         // -1/2 |V r|^2 from the chain's lower tiles of V = L^-1 (72 KB per chain at 128 outputs, 512-byte rows; the rows of
         // blocks beyond the outputs are identity and r is not defined there: only the block rows of the outputs are read)
         double qv;
-        if (LD <= 64) qv = -0.5 * sum_rows(aem_quad_factor<4>(a.aem_P + (size_t)gc * aemr_v_doubles(64), rrow, lane, MP >> 4));
-        else qv = -0.5 * sum_rows(aem_quad_factor<8>(a.aem_P + (size_t)gc * aemr_v_doubles(128), rrow, lane, MP >> 4));
+        if (LD <= 64) qv = aem_quad_factor_inplace<4>(a.aem_P + (size_t)gc * aemr_v_doubles(64), rrow, lane, MP >> 4);
+        else qv = aem_quad_factor_inplace<8>(a.aem_P + (size_t)gc * aemr_v_doubles(128), rrow, lane, MP >> 4);
         if (lane == 0) s_R[16 * RSa + cc] = qv;
       }
       if (prior_dense && lane < 16) {}  // (s_redp already written above)
