@@ -286,12 +286,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AEMR_WA
   //   state-dependent   (utils.py:199):                       S <- (t-1)/t S + 1/t x x^T
   // in the reference's order of operations; products commute, so the upper half kept here is the whole matrix bit for bit.
   const bool upd = a.upd != nullptr;
-  const double tt = (double)a.b_t, t1 = tt + 1.0, ca = (tt - 1.0) / tt, cb = 1.0 / tt;
+  // (no update wanted: coefficients 1 and 0 -- 1 * S + 0 * M is S itself, M being finite -- instead of a select per element: the
+  // select was two v_cndmask on each of a chain's 9 216 tracker elements, a tenth of the kernel's vector instructions)
+  const double tt = (double)a.b_t, t1 = tt + 1.0, ca = upd ? (tt - 1.0) / tt : 1.0, cb = upd ? 1.0 / tt : 0.0;
   // (the state-dependent model leaves mu = mu' = 0: (t 0 - (t+1) 0) + x x^T is x x^T exactly -- one formula, no branch per element)
   auto updated = [&](double old, double xr, double mr, double pr, double xc, double mc, double pc) {
     const double M = (tt * (mr * mc) - t1 * (pr * pc)) + xr * xc;
-    const double nv = ca * old + cb * M;
-    return upd ? nv : old;
+    return ca * old + cb * M;
   };
 
   // ---- loads.  A block row of the sum arrives in two groups:
@@ -305,7 +306,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AEMR_WA
   // (buffer_load ... lds), 26 live tiles at the fullest point, ~50 registers spilled: 342 us per launch against 307 for this form.
   // A SIMD gains little from a second wave here: the matrix phases do not overlap at all (the fp64 matrix pipe), the diagonal tile's
   // ds_bpermute exchanges share the CU's LDS (tools/aem_diag_probe.hip: 5 420 cycles per tile at one wave per SIMD, 7 810 at two =
-  // 1.39 x the throughput, 12 510 at four), and every spill reload is a full vmcnt drain.  profiles/r05_aem_refresh_notes.md.)
+  // 1.39 x the throughput, 12 510 at four), and every spill reload is a full vmcnt drain.  Also built and measured: the kernel
+  // PERSISTENT, one wave per SIMD working through four chains with the first rows of the next chain requested half a chain ahead
+  // (the 28 000 cycles a chain waits for its first round trip disappear from its trace; the launch stays at 300 - 312 us: what the
+  // memory system does not deliver at the start of a chain it does not deliver in the middle either -- the launch moves 1.18 GB at
+  // 3.9 TB/s in 2 - 16 KB pieces of 12 288 streams).  profiles/r05_aem_refresh_notes.md has the numbers.)
   int lane_e = lane * 8, lane_l = lane * 8;  // byte offset of this lane's element inside a 512-byte tile row (one per load group: see the pins below)
   constexpr int NE = NSUM > 1 ? 2 : 1, NL = NSUM > 2 ? 2 : 1;
   double raw_e[T][NE][4], raw_l[T][NL][4];
