@@ -1,0 +1,85 @@
+"""Single-level chains with 65 .. 128 parameters (round 5, tda_kernels_wide.h: k_mh_steps<128, 4>, k_rng<128>, k_wide_adapt, the error
+model's blocked Cholesky as the covariance swap, k_wide_apply) against the oracle on the engine's own Philox stream.  Same bar as
+test_gpu_parity.py: accept masks bit-exact, log-posterior within 1e-10 relative."""
+import numpy as np
+import pytest
+
+from oracle import tinyda_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _spd(rng, n, scale):
+    B = rng.standard_normal((n, n))
+    return scale * (np.eye(n) + 0.3 * B @ B.T / n)
+
+
+def _problem(d, m, N, seed, noise="iso"):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((m, d)) / np.sqrt(d)
+    truth = 0.7 * rng.standard_normal(d)
+    y = A @ truth + 0.1 * rng.standard_normal(m)
+    theta0 = truth + 0.05 * rng.standard_normal((N, d))
+    nz = 0.01 if noise == "iso" else 0.01 * (0.5 + rng.random(m))
+    return rng, A, y, theta0, nz
+
+
+CASES = [
+    # (d, m, N, T, proposal, noise, prior)
+    (96, 40, 17, 130, "am", "iso", "identity"),
+    (128, 64, 16, 90, "am_adaptive", "diag", "diag"),
+    (65, 17, 5, 75, "am", "iso", "diag"),
+    (100, 130, 33, 60, "grw_adaptive", "iso", "identity"),
+    (128, 33, 16, 50, "pcn_adaptive", "diag", "identity"),
+    (80, 257, 20, 45, "pcn", "iso", "identity"),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=["%d-%s" % (c[0], c[4]) for c in CASES])
+def test_wide_single_level_against_the_oracle(case):
+    from tinyda_amd.engine import Engine
+
+    d, m, N, T, kind, noise, prior = case
+    rng, A, y, theta0, nz = _problem(d, m, N, 100 + d + m, noise)
+    if prior == "identity":
+        pm, pc = np.zeros(d), np.eye(d)
+    else:
+        pm, pc = (np.zeros(d) if kind.startswith("pcn") else 0.1 * rng.standard_normal(d)), np.diag(0.5 + rng.random(d))
+    period = 20
+    C0 = _spd(rng, d, 8e-3 / d)
+    adaptive = kind.endswith("adaptive")
+    e = Engine(N, d, seed=77 + d, chain_offset=3, block_steps=33 if d == 100 else 0)
+    e.set_prior(pm, pc)
+    e.set_level(0, A, y, 0 if noise == "iso" else 1, nz)
+    if kind.startswith("am"):
+        e.set_proposal(2, C0, t0=period, period=period, adaptive=adaptive)
+        prop = dict(kind="am", C0=C0, t0=period, period=period, adaptive=adaptive)
+    elif kind.startswith("grw"):
+        e.set_proposal(0, C0, scaling=0.8, adaptive=adaptive, period=period, gamma=1.05)
+        prop = dict(kind="grw", C=C0, scaling=0.8, adaptive=adaptive, period=period, gamma=1.05)
+    else:
+        e.set_proposal(1, None, scaling=0.03, adaptive=adaptive, period=period)
+        prop = dict(kind="pcn", scaling=0.03, adaptive=adaptive, period=period)
+    e.init(theta0)
+    z, u = e.set_export(T)
+    k = T // 3  # two run() calls continue the same chains
+    p1, s1, a1 = e.run_host(k)
+    p2, s2, a2 = e.run_host(T - k)
+    params, stats, acc = np.concatenate([p1, p2]), np.concatenate([s1, s2]), np.concatenate([a1, a2])
+    st = e.proposal_state(want_am=kind.startswith("am"))
+    e.close()
+    lvl = orc.LinearGaussianLevel(A, y, noise, nz, orc.MVNPrior(pm, pc))
+    res = orc.run_mh(lvl, prop, theta0, np.swapaxes(z, 0, 1), np.swapaxes(u, 0, 1))
+    ref_acc = np.swapaxes(res["accepted"][:, 1:], 0, 1)
+    assert np.array_equal(acc, ref_acc), "%d accept flips" % int((acc != ref_acc).sum())
+    assert 0.02 < acc.mean() < 0.98
+    # (AdaptiveMetropolis with fewer states than 4 d behind a swap: the near-singular factor carries the recursion's last bits into the
+    # proposals -- the rule of tests/test_gpu_sweep.py)
+    rtol = 1e-9 if (kind.startswith("am") and T < 4 * d) else 1e-10
+    np.testing.assert_allclose(stats[:, :, 2], np.swapaxes(res["logpost"][:, 1:], 0, 1), rtol=rtol)
+    np.testing.assert_allclose(params, np.swapaxes(res["theta"][:, 1:], 0, 1), rtol=1e-8, atol=1e-10)
+    if kind.startswith("am"):
+        np.testing.assert_allclose(st["am_sigma"], res["am_sigma"], rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(st["am_mu"], res["am_mu"], rtol=1e-8, atol=1e-10)  # (means of states that agree to 1e-8 / 1e-10)
+    if adaptive:
+        np.testing.assert_allclose(st["scaling"], res["scaling"], rtol=1e-12)

@@ -61,7 +61,7 @@ bool is_pinned_host_ptr(const void* p) {
   return at.type == hipMemoryTypeHost;
 }
 
-int dpad_for(int d) { return d <= 8 ? 8 : d <= 16 ? 16 : d <= 32 ? 32 : 64; }
+int dpad_for(int d) { return d <= 8 ? 8 : d <= 16 ? 16 : d <= 32 ? 32 : d <= 64 ? 64 : 128; }
 
 // lower Cholesky of a d x d row-major SPD matrix; returns false if not positive definite
 bool cholesky_host(const double* C, int d, std::vector<double>& L) {
@@ -392,6 +392,12 @@ struct tda_engine {
   int64_t u_rep_lv_n[tda::MAXLEV] = {0, 0, 0, 0}, ridx_rep_n = 0;
   int64_t u_rep_lv_pos[tda::MAXLEV] = {0, 0, 0, 0}, ridx_rep_pos = 0;
 
+  // single-level chains with 65 .. 128 parameters (tda_kernels_wide.h): the proposal factor lives in e->Lk as two buffers of
+  // factor-form tiles; the diagonal tiles, the current-buffer selector, the padding "Sigma_e" of the swap
+  bool wide = false;
+  DevBuf<double> wide_ud, wide_cov;
+  DevBuf<int32_t> wide_sel;
+
   // replay / export
   DevBuf<double> z_rep, u_rep;
   int64_t rep_steps = 0, rep_pos = 0;
@@ -550,6 +556,97 @@ bool launch_adapt_chol_apply(const AdaptArgs& aa, const CholArgs& ca, const Appl
     }
   }
   return false;
+}
+
+// ---- 65 .. 128 parameters (tda_kernels_wide.h): the same launch points, other kernels ----
+template <>
+void launch_steps<128>(const StepArgs& a, int64_t tiles, size_t lds, hipStream_t st) {
+  auto kern = &k_mh_steps<128, 4, false>;  // one 512-register wave per SIMD (set_proposal admits GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis)
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, st, a);
+}
+static WideApplyArgs wide_apply_args(const ApplyArgs& a) {
+  WideApplyArgs w{};
+  w.NP = a.NP;
+  w.S = a.S;
+  w.fac = a.Lk;
+  w.ud = a.ud;
+  w.sel = a.sel;
+  w.chain_stride = a.L_stride ? 1 : 0;
+  w.NPf = a.NPf;
+  w.zf = a.zf;
+  w.inc = a.inc;
+  return w;
+}
+template <>
+void launch_apply<128>(const ApplyArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_wide_apply<WIDE_T>, dim3((unsigned)a.NP), dim3(64), 0, st, wide_apply_args(a));
+}
+// replay mode (and TINYDA_SPLIT_PROPOSE=0): uniforms, the normals as fragments (recorded ones converted, or k_rng<128>), the product
+template <>
+void launch_propose<128>(const ProposeArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_wide_uniforms, dim3((unsigned)(((int64_t)a.S * a.NP + 255) / 256)), dim3(256), 0, st, a);
+  const dim3 g((unsigned)a.NP, (unsigned)((a.S + 15) / 16));
+  if (a.z_replay) {
+    WideReplayArgs w{};
+    w.N = a.N;
+    w.NP = a.NP;
+    w.d = a.d;
+    w.S = a.S;
+    w.z = a.z_replay;
+    w.zf = a.zf_tmp;
+    hipLaunchKernelGGL(k_wide_replay_frags<WIDE_T>, g, dim3(64), 0, st, w);
+  } else {
+    RngArgs ra{};
+    ra.N = a.N;
+    ra.NP = a.NP;
+    ra.chain_offset = a.chain_offset;
+    ra.d = a.d;
+    ra.S = a.S;
+    ra.step0 = a.step0;
+    ra.seed = a.seed;
+    ra.zf = a.zf_tmp;
+    ra.z_export = a.z_export;
+    hipLaunchKernelGGL(k_rng<128>, g, dim3(64), 0, st, ra);
+  }
+  ApplyArgs ap{};
+  ap.NP = a.NP;
+  ap.S = a.S;
+  ap.Lk = a.Lk;
+  ap.L_stride = a.L_stride;
+  ap.zf = a.zf_tmp;
+  ap.inc = a.inc;
+  ap.ud = a.ud;
+  ap.sel = a.sel;
+  ap.NPf = a.NPf;
+  launch_apply<128>(ap, st);
+}
+template <>
+void launch_adapt<128>(const AdaptArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_wide_adapt<WIDE_T>, dim3((unsigned)a.N), dim3(64), 0, st, a);
+}
+template <>
+void launch_chol<128>(const CholArgs& a, hipStream_t st) {  // C <- Sigma: the error model's factorisation (AemRefreshArgs::wide)
+  AemRefreshArgs ra{};
+  ra.N = a.N;
+  ra.NP = a.NP;
+  ra.m = a.d;
+  ra.MP = 128;
+  ra.nsum = 1;
+  ra.cov = a.pad_cov;
+  ra.sig[0] = const_cast<double*>(a.am_sigma);
+  ra.V = a.Lk;
+  ra.b_t = 1;
+  ra.wide = 1;
+  ra.Ud = a.ud;
+  ra.sel = a.sel;
+  ra.flags = a.flags;
+  hipLaunchKernelGGL((k_aem_refresh<WIDE_T, 1>), dim3((unsigned)a.N), dim3(64), 0, st, ra);
+}
+template <>
+void launch_chol_apply<128>(const CholArgs& a, const ApplyArgs& ap, hipStream_t st) {
+  launch_chol<128>(a, st);
+  launch_apply<128>(ap, st);
 }
 
 // k_aem_refresh<T, NSUM> for the engine's row stride (64 / 128 -> 4 / 8 tile rows) and the number of trackers summed
@@ -716,6 +813,16 @@ void launch_dz_adapt(const DreamAdaptArgs& a, hipStream_t st) {
     case 16: { constexpr int DPAD = 16; CALL; } break; \
     case 32: { constexpr int DPAD = 32; CALL; } break; \
     default: { constexpr int DPAD = 64; CALL; } break; \
+  }
+
+// the single-level sites (run_single, evaluate): 65 .. 128 parameters too (launch_*<128>: tda_kernels_wide.h)
+#define DISPATCH_DPAD_W(dp, CALL)                    \
+  switch (dp) {                                      \
+    case 8: { constexpr int DPAD = 8; CALL; } break;     \
+    case 16: { constexpr int DPAD = 16; CALL; } break;   \
+    case 32: { constexpr int DPAD = 32; CALL; } break;   \
+    case 128: { constexpr int DPAD = 128; CALL; } break; \
+    default: { constexpr int DPAD = 64; CALL; } break;   \
   }
 
 struct ScopedTimer {
@@ -923,7 +1030,7 @@ int launch_eval(tda_engine* e, int level, double* theta, double* lp, double* ll)
   a.ll = ll;
   a.scaling = e->scaling.p;
   const size_t lds = steps_lds_bytes(e, e->levels[level]);
-  DISPATCH_DPAD(e->DP, launch_steps<DPAD>(a, e->NP / 16, lds, e->stream));
+  DISPATCH_DPAD_W(e->DP, launch_steps<DPAD>(a, e->NP / 16, lds, e->stream));
   HIP_TRY(hipGetLastError());
   return TDA_OK;
 }
@@ -1035,8 +1142,10 @@ const char* tda_version(void) { return "tinyda_amd 0.4 (gfx950)"; }
 int tda_engine_create(const tda_config* cfg, tda_engine** out) {
   if (!cfg || !out) return fail(TDA_ERR_INVALID, "null argument");
   if (cfg->struct_size != sizeof(tda_config)) return fail(TDA_ERR_INVALID, "tda_config.struct_size mismatch");
-  if (cfg->dim < 1 || cfg->dim > 64)
-    return fail(TDA_ERR_UNSUPPORTED, "dim=%d outside the device engine's range 1..64", cfg->dim);
+  if (cfg->dim < 1 || cfg->dim > 128)
+    return fail(TDA_ERR_UNSUPPORTED, "dim=%d outside the device engine's range 1..128", cfg->dim);
+  if (cfg->dim > 64 && cfg->n_levels != 1)
+    return fail(TDA_ERR_UNSUPPORTED, "dim=%d: more than 64 parameters are lowered for single-level chains", cfg->dim);
   if (cfg->n_chains < 1) return fail(TDA_ERR_INVALID, "n_chains must be >= 1");
   if (cfg->n_levels < 1 || cfg->n_levels > MAXLEV)
     return fail(TDA_ERR_UNSUPPORTED, "n_levels=%d outside 1..%d", cfg->n_levels, (int)MAXLEV);
@@ -1049,6 +1158,7 @@ int tda_engine_create(const tda_config* cfg, tda_engine** out) {
   e->cfg = *cfg;
   e->d = cfg->dim;
   e->DP = dpad_for(cfg->dim);
+  e->wide = cfg->dim > 64;
   e->N = cfg->n_chains;
   e->NP = (cfg->n_chains + 15) / 16 * 16;
   e->SMAX = cfg->block_steps > 0 ? cfg->block_steps : 128;

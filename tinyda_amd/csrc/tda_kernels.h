@@ -6,6 +6,8 @@
 //   tda_kernels_aemr.h    k_aem_refresh (dense error model: tracker update + factorisation + update_link, one wave per
 //                         chain), k_aem_base_steps (its base subchain with one pass over the factor)
 //   tda_kernels_aemd.h    k_aemd_* (diagonal error model, any output count)
+//   tda_kernels_wide.h    k_wide_adapt / k_wide_apply: single-level chains with 65 .. 128 parameters (with k_mh_steps<128, 4>, k_rng<128>
+//                         and k_aem_refresh<8, 1> as the covariance swap)
 //   tda_kernels_dreamz.h  k_dreamz_draw / steps / adapt, k_colsum_partial
 //   tda_kernels_pooled.h  k_moments_partial / final
 //   tda_kernels_ext.h     k_ext_propose / k_ext_accept (batched host-callback forward models)
@@ -16,3 +18,4 @@
 #include "tda_kernels_pooled.h"
 #include "tda_kernels_ext.h"
 #include "tda_kernels_aemd.h"
+#include "tda_kernels_wide.h"

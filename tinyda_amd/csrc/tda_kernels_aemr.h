@@ -78,6 +78,14 @@ struct AemRefreshArgs {
   double* Sst;                      // [npairs][2][NP]
   const int64_t* sid;               // [nlev][NP]
   int nlev, k;                      // the refreshed level; its log-likelihood also goes to S[k][q2] of every level q2 > k holding the same parameters
+  // AdaptiveMetropolis covariance swap of the 65 .. 128-parameter chains (tda_kernels_wide.h): the same factorisation with
+  //   no 1e-9 rule; the factor written into buffer 1 - sel[c] of two ([2][NP][tiles] behind V), the factors U_qq of the diagonal
+  //   tiles stored beside their inverses (Ud: [2][NP][T][4][64], zero below the diagonal); all pivots > 0: sel[c] flips to the
+  //   new buffer, otherwise flags[c] |= 1 and the previous factor stays current
+  int wide;
+  double* Ud;
+  int32_t* sel;
+  int32_t* flags;
 };
 
 __device__ __forceinline__ double aemr_pick(double v, int src) { return __shfl(v, src); }
@@ -126,13 +134,14 @@ __device__ __forceinline__ double aemr_row_sum(double v) {
 // factor: pivot row k lives in the lanes hi == k & 3, register k >> 2; it reaches the lanes of its column with one ds_bpermute
 // per tile, the multipliers of a lane's own rows with up to four more.  1 / sqrt(pivot) = v_rsq_f64 + one third-order correction
 // (error ~ e^3, e = 2^-26: full precision), no division.
-__device__ __forceinline__ void aemr_diag(double (&C)[4], double (&Vd)[4], double (&Vt)[4], int lc, int hi) {
+__device__ __forceinline__ void aemr_diag(double (&C)[4], double (&Vd)[4], double (&Vt)[4], int lc, int hi, bool* ok = nullptr) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) Vd[r] = (hi + 4 * r == lc) ? 1.0 : 0.0;
 #pragma unroll
   for (int kl = 0; kl < 16; ++kl) {
     const int kh = kl & 3, kr = kl >> 2;
     const double dkk = bcast_lane64(C[kr], kh * 16 + kl);
+    if (ok) *ok = *ok && (dkk > 0.0);  // (callers that do not ask: the test is dropped at compile time)
     const double y0 = __builtin_amdgcn_rsq(dkk);
     const double e0 = fma(-dkk * y0, y0, 1.0);
     const double inv = fma(y0 * e0, fma(0.375, e0, 0.5), y0);
@@ -273,7 +282,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AEMR_WA
   const int64_t c = blockIdx.x;
   if (c >= a.N) return;
   const bool want_ll = a.rvec != nullptr;
-  double* __restrict__ Vc = a.V + (size_t)c * NT * 256;
+  const int tb = a.wide ? 1 - a.sel[c] : 0;  // (wide chains: the factor goes into the buffer that is not current)
+  double* __restrict__ Vc = a.V + ((size_t)tb * a.NP + c) * NT * 256;
   const __amdgpu_buffer_rsrc_t Vrs = aemr_rsrc(Vc, 1);
   const size_t cbase = (size_t)c * NT * 256;
   const __amdgpu_buffer_rsrc_t sg0 = aemr_rsrc(a.sig[0] + cbase, 2);
@@ -374,6 +384,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AEMR_WA
     big = big || !(sb < 1e-9);
   }
   __syncthreads();  // s_u, s_r
+  if (a.wide) big = true;  // (a proposal covariance is factored whatever its size)
   if (__builtin_amdgcn_ballot_w64(big) == 0) {
     for (int t = 0; t < NT; ++t) {  // (padding entries are zero)
       int p = 0, rem = t;
@@ -390,6 +401,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AEMR_WA
   }
   AEMR_STAMP(1);
   double sq = 0.0;
+  bool wide_ok = true;
   if (__builtin_amdgcn_ballot_w64(big) == 0) {
     // set_bias keeps the previous inverse; update_link still runs under the new bias.  The tracker itself is still updated.
     if (upd) {
@@ -411,6 +423,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AEMR_WA
     double4_t Uf[NT];  // finished rows of U (upper tiles, off-diagonal), whole 8-register tuples from birth to their last matrix instruction
     double4_t Cn[T];   // the block row being summed: partial (trackers) at the end of step q - 1, complete at the top of step q
     double fs[T];      // forward substitution (update_link): partial sums  sum_{p < q} sum_k U_pi[k][lc] z_p[k]  of the rows below
+    bool pivots_ok = true;
 #pragma unroll
     for (int i = 0; i < T; ++i) fs[i] = 0.0;
     // EARLY(q) -> partial sums of row q: the tracker update (utils.py:117-122 / :199) on every element of sig[0] on its way in,
@@ -482,7 +495,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AEMR_WA
       double Cd[4], Vd[4], Vt[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) Cd[r] = Cn[q][r];
-      aemr_diag(Cd, Vd, Vt, lc, hi);
+      aemr_diag(Cd, Vd, Vt, lc, hi, &pivots_ok);
+      if (a.wide) {  // the factor U_qq of the diagonal tile itself: what the elimination left on and above the diagonal of C
+        double* __restrict__ ud = a.Ud + (((size_t)tb * a.NP + c) * T + q) * 256 + lane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ud[r * 64] = (hi + 4 * r <= lc) ? Cd[r] : 0.0;
+      }
       __builtin_amdgcn_sched_barrier(0);
       AEMR_STAMP(4 + 6 * q);
       // the rest of block row q times (L_qq)^-1: U_qi = (L_qq)^-1 C_qi
@@ -522,8 +540,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AEMR_WA
       }
       AEMR_STAMP(7 + 6 * q);
     });
+    wide_ok = pivots_ok;
   }
   AEMR_STAMP(2 + 6 * T);
+  if (a.wide && lane == 0) {
+    if (wide_ok) a.sel[c] = tb;
+    else atomicOr(&a.flags[c], 1);
+  }
   if (want_ll) {
     const double llk = -0.5 * sum_rows(sq);
     if (lane == 0) {
@@ -576,6 +599,9 @@ struct AemBaseArgs {
   uint8_t* rec_acc;
 };
 
+#ifndef AEMB_KG
+#define AEMB_KG 2
+#endif
 template <int T>
 __global__ void __launch_bounds__(64) k_aem_base_steps(const AemBaseArgs a) {
   constexpr int MP = 16 * T, NH = MP / 64 > 0 ? MP / 64 : 1;  // observations per lane
@@ -652,12 +678,13 @@ __global__ void __launch_bounds__(64) k_aem_base_steps(const AemBaseArgs a) {
       for (int i = 0; i <= q; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) w[i][r] = aemr_ld(Wrs, lane_w, (aemr_lt(q, i) * 4 + r) * 512);
-      // (the vectors in two halves: four result quadruples in registers instead of eight -- 138 registers, three waves per SIMD)
+      // (the vectors KG at a time: that many result quadruples in registers instead of eight)
+      constexpr int KG = AEMB_KG;
 #pragma unroll
-      for (int kh = 0; kh < CMAX; kh += CMAX / 2) {
-        double zq[CMAX / 2][4];
+      for (int kh = 0; kh < CMAX; kh += KG) {
+        double zq[KG][4];
 #pragma unroll
-        for (int k = 0; k < CMAX / 2; ++k) {
+        for (int k = 0; k < KG; ++k) {
           const double* __restrict__ xk = s_X + (size_t)(k0 + (kh + k < nk ? kh + k : 0)) * MP;  // (vectors beyond nk: recomputed copies of the first, dropped)
           double acc = 0.0;
 #pragma unroll
@@ -676,7 +703,7 @@ __global__ void __launch_bounds__(64) k_aem_base_steps(const AemBaseArgs a) {
         __syncthreads();  // every read of block q of these vectors is done
         if (lc == 0) {
 #pragma unroll
-          for (int k = 0; k < CMAX / 2; ++k)
+          for (int k = 0; k < KG; ++k)
             if (kh + k < nk) {
               double4_t zv;
 #pragma unroll

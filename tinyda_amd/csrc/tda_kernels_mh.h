@@ -108,6 +108,12 @@ struct ProposeArgs {
   const double* u_replay; // [.][N]
   double* z_export;       // same layout (may be null)
   double* u_export;
+  // 65 .. 128 parameters only (tda_kernels_wide.h: fragments of the normals, then k_wide_apply): a fragment buffer, the diagonal
+  // tiles, the current-buffer selector, chains per factor buffer
+  double* zf_tmp;
+  const double* ud;
+  const int32_t* sel;
+  int64_t NPf;
 };
 
 struct AdaptArgs {
@@ -1158,10 +1164,14 @@ __global__ void __launch_bounds__(256, 2) k_rng_uniforms(const RngArgs a) {
 struct ApplyArgs {
   int64_t NP;
   int S;
-  const double* Lk;   // [NP or 1][DPAD][DPAD] k-major
-  int64_t L_stride;
+  const double* Lk;   // [NP or 1][DPAD][DPAD] k-major (65 .. 128 parameters: the factor tiles of tda_kernels_wide.h, [2][NPf][36][4][64])
+  int64_t L_stride;   // doubles between the factors of two chains (0: one shared factor)
   const double* zf;   // [groups][NP][DPAD/4][64]
   double* inc;        // [S][NP][DPAD]
+  // 65 .. 128 parameters only (tda_kernels_wide.h): the diagonal tiles, the current-buffer selector, chains per factor buffer
+  const double* ud;
+  const int32_t* sel;
+  int64_t NPf;
 };
 
 template <int DPAD>
@@ -1503,6 +1513,12 @@ struct CholArgs {
   const double* am_sigma;  // [NP][am_tiles][4][64] (see k_adapt)
   double* Lk;              // [NP][DPAD][DPAD] k-major
   int32_t* flags;
+  // 65 .. 128 parameters only (tda_kernels_wide.h: the swap runs on k_aem_refresh): the diagonal tiles, the buffer selector, the
+  // "Sigma_e" of that kernel (zero inside the d parameters, identity in the padding), chains per buffer
+  double* ud;
+  int32_t* sel;
+  const double* pad_cov;
+  int64_t NP;
 };
 
 template <int DPAD>
