@@ -1007,6 +1007,8 @@ FIXTURES = {
                                  seed=204, noise="dense", prior_kind="general"),
     "g2_am_c2": lambda: g2_am("g2_am_c2", d=64, m=1024, n_chains=2, iters=300, t0=100, period=100,
                               seed=1, c0=1e-4),
+    # round 5: 96 parameters (the device's 65 .. 128-parameter path, tda_kernels_wide.h), two covariance swaps
+    "g2_am_d96": lambda: g2_am("g2_am_d96", d=96, m=256, n_chains=2, iters=300, t0=100, period=100, seed=96, c0=1e-4),
     "g2b_pcn": g2b_pcn,
     "g3_loglike_kats": g3_loglike_kats,
     "g4_da_pcn": lambda: g4_da("g4_da_pcn", "pcn"),

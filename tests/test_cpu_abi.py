@@ -44,7 +44,7 @@ def test_cpu_twin_exports_the_whole_abi(cpu):
     assert b"cpu twin" in lib.tda_version()
 
 
-@pytest.mark.parametrize("name", ["g1_basic_sampler", "g2_am_small", "g2_am_small_adaptive", "g2b_pcn", "g2_am_c2"])
+@pytest.mark.parametrize("name", ["g1_basic_sampler", "g2_am_small", "g2_am_small_adaptive", "g2b_pcn", "g2_am_c2", "g2_am_d96"])
 def test_cpu_twin_replays_reference_traces(cpu, golden, name):
     from tinyda_amd.engine import Engine
 

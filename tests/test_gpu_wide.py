@@ -83,3 +83,33 @@ def test_wide_single_level_against_the_oracle(case):
         np.testing.assert_allclose(st["am_mu"], res["am_mu"], rtol=1e-8, atol=1e-10)  # (means of states that agree to 1e-8 / 1e-10)
     if adaptive:
         np.testing.assert_allclose(st["scaling"], res["scaling"], rtol=1e-12)
+
+
+def test_sample_runs_100_parameters_on_the_device():
+    """tda.sample() at 100 parameters returns "backend": "hip" (0.4: the host protocol, with a HostFallbackWarning) and a chain that has
+    moved towards the data; a hierarchy at 100 parameters still falls back, announced"""
+    import warnings
+
+    import scipy.stats as stats
+
+    import tinyda_amd as tda
+
+    d, m, n_chains, T = 100, 300, 32, 400
+    rng = np.random.default_rng(9)
+    A = rng.standard_normal((m, d)) / np.sqrt(d)
+    truth = 0.5 * rng.standard_normal(d)
+    y = A @ truth + 0.05 * rng.standard_normal(m)
+    post = tda.Posterior(stats.multivariate_normal(np.zeros(d), np.eye(d)), tda.GaussianLogLike(y, 0.0025 * np.eye(m)), tda.LinearModel(A))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", tda.HostFallbackWarning)
+        res = tda.sample(post, tda.AdaptiveMetropolis(1e-4 * np.eye(d), t0=100, period=100), T, n_chains=n_chains, seed=5)
+    assert res["backend"] == "hip" and res["iterations"] == T + 1
+    par = tda.get_samples(res, burnin=T // 2)["chain_3"]
+    assert par.shape == (T + 1 - T // 2, d)
+    first, last = res["chain_0"][0], res["chain_0"][-1]
+    assert last.posterior > first.posterior + 100.0  # (theta0 ~ prior: far from the data)
+    st = res["proposal_state"]
+    assert np.asarray(st["C"]).shape == (n_chains, d, d) and np.all(np.isfinite(np.asarray(st["C"])))
+    coarse = tda.Posterior(post.prior, tda.GaussianLogLike(y[:50], 0.0025 * np.eye(50)), tda.LinearModel(A[:50]))
+    with pytest.warns(tda.HostFallbackWarning, match="more than 64 parameters are lowered for single-level chains"):
+        tda.sample([coarse, post], tda.CrankNicolson(scaling=0.05), 3, n_chains=1, subchain_length=2)

@@ -186,17 +186,17 @@ def test_host_fallback_is_announced_with_the_rule_that_refused_the_problem():
 
     from tinyda_amd import api
 
-    d = 65  # one parameter past the engine's limit
+    d = 129  # one parameter past the engine's limit (0.5: 128 for single-level chains)
     rng = np.random.default_rng(3)
     A = rng.standard_normal((8, d))
     post = tda.Posterior(stats.multivariate_normal(np.zeros(d), np.eye(d)), tda.GaussianLogLike(np.zeros(8), 0.1 * np.eye(8)), tda.LinearModel(A))
-    with pytest.warns(tda.HostFallbackWarning, match="more than 64 parameters") as rec:
+    with pytest.warns(tda.HostFallbackWarning, match="more than 128 parameters") as rec:
         res = tda.sample(post, tda.GaussianRandomWalk(np.eye(d), scaling=0.05), 5, n_chains=1)
     assert res["backend"] == "host" and len([w for w in rec if issubclass(w.category, tda.HostFallbackWarning)]) == 1
     with warnings.catch_warnings():
         warnings.simplefilter("error", tda.HostFallbackWarning)
         tda.sample(post, tda.GaussianRandomWalk(np.eye(d), scaling=0.05), 5, n_chains=1, backend="host")
-    with pytest.raises(tda.EngineError, match="more than 64 parameters"):
+    with pytest.raises(tda.EngineError, match="more than 128 parameters"):
         tda.sample(post, tda.GaussianRandomWalk(np.eye(d), scaling=0.05), 5, n_chains=1, backend="hip")
     # every refusal of the lowering pass leaves its reason
     prior4 = stats.multivariate_normal(np.zeros(4), np.eye(4))

@@ -42,7 +42,7 @@ def test_g1_basic_sampler_grw_adaptive(golden):
 
 
 @pytest.mark.parametrize("name", ["g2_am_small", "g2_am_small_adaptive", "g2_am_diag_genprior",
-                                  "g2_am_dense", "g2_am_c2"])
+                                  "g2_am_dense", "g2_am_c2", "g2_am_d96"])
 def test_g2_adaptive_metropolis(golden, name):
     g = golden(name)
     prop = dict(kind="am", C0=g["C0"], sd=float(g["sd"]), epsilon=float(g["epsilon"]), t0=int(g["t0"]),

@@ -24,6 +24,7 @@ _DEVICE_PROPOSALS = (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis, DREA
 
 
 MAX_LEVELS = 4
+MAX_PARAMETERS = 128  # (more than 64: single-level chains, see _device_plan)
 MAX_AEM_OUTPUTS = 128
 
 
@@ -49,8 +50,17 @@ def _device_plan(posteriors, proposal, diagonal_error_model=False, error_model=N
     lows = []
     for post in posteriors:
         low = getattr(post, "_lowering", lambda: None)()
-        if low is None or low["prior_mean"].shape[0] > 64:
-            return _no("a posterior the engine cannot lower (an opaque Python model, a prior other than scipy's multivariate normal / JointPrior of norm and uniform, a likelihood outside GaussianLogLike's classes)" if low is None else "more than 64 parameters")
+        if low is None or low["prior_mean"].shape[0] > MAX_PARAMETERS:
+            return _no("a posterior the engine cannot lower (an opaque Python model, a prior other than scipy's multivariate normal / JointPrior of norm and uniform, a likelihood outside GaussianLogLike's classes)" if low is None else "more than %d parameters" % MAX_PARAMETERS)
+        if low["prior_mean"].shape[0] > 64:
+            # 65 .. 128 parameters (0.5, tda_kernels_wide.h): single-level chains, a linear model with isotropic / diagonal noise, a Gaussian
+            # prior with a diagonal covariance, GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis
+            pc = np.asarray(low["prior_cov"])
+            if (len(posteriors) != 1 or type(proposal) not in (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis) or low.get("A") is None
+                    or any(k in low for k in ("source", "batched", "rosenbrock", "prior_joint"))
+                    or low["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG) or np.count_nonzero(pc - np.diag(np.diag(pc)))):
+                return _no("more than 64 parameters are lowered for single-level chains only: a linear model with isotropic / diagonal noise, "
+                           "a Gaussian prior with a diagonal covariance, GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis")
         if diagonal_error_model and low["noise_kind"] == _lib.NOISE_ADAPTIVE:
             # diagonal error model: the adaptive likelihood's covariance must be diagonal and travels as its diagonal
             cov = np.asarray(low["noise"], dtype=np.float64)
@@ -388,7 +398,7 @@ def _sample_host(posterior, proposal, iterations, n_chains, initial_parameters):
 def _sample_host_multilevel(posteriors, proposal, iterations, n_chains, initial_parameters, subchain_length, subchain_lengths,
                             randomize, error_model, store_coarse_chain, error_model_covariance="dense"):
     """Hierarchies the engine does not lower (models returning (output, qoi), proposals outside the engine's set below a
-    hierarchy, more than MAX_LEVELS levels, more than 64 parameters, per-level priors): the reference's protocol on the host,
+    hierarchy, more than MAX_LEVELS levels, more than 128 parameters (64 in a hierarchy), per-level priors): the reference's protocol on the host,
     one chain after the other (sampler.py:335-368, :441-473), with the reference's result layout (:406-439, :510-547).
     Every chain gets its own copies of the posteriors, so that the error model of one chain does not leak into the next
     (the reference's sequential sampler shares them: SURVEY.md Appendix A.14, not reproduced)."""

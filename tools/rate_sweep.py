@@ -82,6 +82,12 @@ CASES = [
     ("grw d32 m256", lambda: single("grw d32 m256", 32, 256, dict(kind=0, C_=np.eye(32), scaling=0.05))),
     ("grw d64 m256", lambda: single("grw d64 m256", 64, 256, dict(kind=0, C_=np.eye(64), scaling=0.03))),
     ("pcn d64 m1024 adaptive", lambda: single("pcn d64 m1024 adaptive", 64, 1024, dict(kind=1, scaling=0.03, adaptive=True))),
+    # round 5: 65 .. 128 parameters (tda_kernels_wide.h) next to the 64-parameter headline shape; flops per evaluation 2 m d
+    ("am d64 m1024", lambda: single("am d64 m1024", 64, 1024, dict(kind=2, C_=1e-4 * np.eye(64), t0=100, period=100))),
+    ("am d128 m1024", lambda: single("am d128 m1024", 128, 1024, dict(kind=2, C_=1e-4 * np.eye(128), t0=100, period=100))),
+    ("am d96 m1024", lambda: single("am d96 m1024", 96, 1024, dict(kind=2, C_=1e-4 * np.eye(96), t0=100, period=100))),
+    ("grw d128 m1024", lambda: single("grw d128 m1024", 128, 1024, dict(kind=0, C_=np.eye(128), scaling=0.02))),
+    ("pcn d128 m1024 adaptive", lambda: single("pcn d128 m1024 adaptive", 128, 1024, dict(kind=1, scaling=0.02, adaptive=True))),
     ("am d32 m256", lambda: single("am d32 m256", 32, 256, dict(kind=2, C_=1e-4 * np.eye(32), t0=100, period=100))),
     ("am d64 m1024 diag noise", lambda: single("am d64 m1024 diag noise", 64, 1024, dict(kind=2, C_=1e-4 * np.eye(64), t0=100, period=100), noise=1)),
     ("am d64 m1024 dense prior", lambda: single("am d64 m1024 dense prior", 64, 1024, dict(kind=2, C_=1e-4 * np.eye(64), t0=100, period=100), prior="dense")),
