@@ -623,7 +623,7 @@ void launch_propose<128>(const ProposeArgs& a, hipStream_t st) {
 }
 template <>
 void launch_adapt<128>(const AdaptArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_wide_adapt<WIDE_T>, dim3((unsigned)a.N), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(k_wide_adapt<WIDE_T>, dim3((unsigned)a.N), dim3(128), 0, st, a);  // two waves per chain
 }
 template <>
 void launch_chol<128>(const CholArgs& a, hipStream_t st) {  // C <- Sigma: the error model's factorisation (AemRefreshArgs::wide)

@@ -37,73 +37,89 @@ constexpr size_t WIDE_UD_DOUBLES = (size_t)WIDE_T * 256;       // its diagonal t
 //   Sigma' = (t - 1) / t Sigma + sd / t ((t (mu_i mu_j) - (t + 1) (mu'_i mu'_j)) + x_i x_j [+ eps on the diagonal])
 // (k_adapt carries (t + 1) mu' mu'^T over as the next state's t mu mu^T -- the same operands, the same rounding -- in 80 more
 // registers; at 36 tiles there is no room for a second matrix, so the products are formed again: the same values.)
+// Two waves per chain, 18 tiles each (tile rows {0, 3, 4, 7} and {1, 2, 5, 6}: 8 + 5 + 4 + 1 = 7 + 6 + 3 + 2): 144 registers of Sigma
+// per wave, two waves per SIMD.  (First version: one wave with all 36 tiles -- 288 registers plus operands, 240 bytes of scratch
+// at 512 registers, the single-wave issue rate: 2.2 ms per 100 states of 4096 chains.)
+template <int T, int R0, int R1, int R2, int R3>
+__device__ __forceinline__ void wide_adapt_rows(const AdaptArgs& a, const int64_t c, const int lane, const int tid, double* s_x, double* s_m,
+                                                double* s_p) {
+  constexpr int NT = aemr_tiles(T), W = 16 * T;
+  constexpr int ROWS[4] = {R0, R1, R2, R3};
+  constexpr int NMINE = (T - R0) + (T - R1) + (T - R2) + (T - R3);
+  const int lc = lane & 15, hi = lane >> 4;
+  // (descriptor + one lane offset + compile-time scalar offsets: 64-bit addresses per tile row would stay alive across the state loop)
+  const __amdgpu_buffer_rsrc_t srs = aemr_rsrc(a.am_sigma + (size_t)c * NT * 256);
+  double Sg[NMINE][4];
+  {
+    int k = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = ROWS[q]; i < T; ++i, ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Sg[k][r] = aemr_ld(srs, lane * 8, (aemr_ut(T, ROWS[q], i) * 4 + r) * 512);
+  }
+  double mu = a.am_mu[c * W + tid];  // thread tid of the 2 x 64 owns parameter tid
+  for (int s = 0; s < a.S; ++s) {
+    const double t = (double)(a.t_base + s + 1), t1 = t + 1.0;  // recursor.t before this update
+    const double c_inv = 1.0 / t1, ca = (t - 1.0) / t, cb = a.sd / t;
+    const double x = tid < a.d ? a.rec_params[((size_t)s * a.N + c) * a.d + tid] : 0.0;
+    const double mup = c_inv * (t * mu + x);
+    __syncthreads();  // the previous state's operand reads are done
+    s_x[tid] = x;
+    s_m[tid] = mu;
+    s_p[tid] = mup;
+    __syncthreads();
+    int k = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int p = ROWS[q];
+      double xr[4], mr[4], pr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        xr[r] = s_x[16 * p + hi + 4 * r];
+        mr[r] = s_m[16 * p + hi + 4 * r];
+        pr[r] = s_p[16 * p + hi + 4 * r];
+      }
+#pragma unroll
+      for (int i = p; i < T; ++i, ++k) {
+        const double xc = s_x[16 * i + lc], mc = s_m[16 * i + lc], pc = s_p[16 * i + lc];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double M = (t * (mr[r] * mc) - t1 * (pr[r] * pc)) + xr[r] * xc;
+          if (p == i) M += (hi + 4 * r == lc) ? a.eps : 0.0;  // + eps on the diagonal, + 0 beside it (padded dimensions collect eps too; nothing reads them)
+          Sg[k][r] = ca * Sg[k][r] + cb * M;
+        }
+        __builtin_amdgcn_sched_barrier(0);  // (a tile at a time: hoisted ahead, the operand reads of a whole state spill Sigma)
+      }
+    }
+    mu = mup;
+  }
+  a.am_mu[c * W + tid] = mu;  // (thread tid of the two waves owns parameter tid)
+  {
+    int k = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = ROWS[q]; i < T; ++i, ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) aemr_st(Sg[k][r], srs, lane * 8, (aemr_ut(T, ROWS[q], i) * 4 + r) * 512);
+  }
+}
+
 template <int T>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) k_wide_adapt(const AdaptArgs a) {
-  constexpr int NT = aemr_tiles(T), W = 16 * T, NH = W / 64;
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) k_wide_adapt(const AdaptArgs a) {
+  static_assert(T == 8, "the tile rows are dealt to the two waves for eight tile rows");
+  constexpr int W = 16 * T;
   __shared__ double s_x[W], s_m[W], s_p[W];
-  const int lane = threadIdx.x, lc = lane & 15, hi = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t c = blockIdx.x;
   if (c >= a.N) return;
   if (a.do_am) {
-    double* __restrict__ sig = a.am_sigma + (size_t)c * NT * 256;
-    double Sg[NT][4];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Sg[t][r] = sig[(t * 4 + r) * 64 + lane];
-    double mu[NH];
-#pragma unroll
-    for (int h = 0; h < NH; ++h) mu[h] = a.am_mu[c * W + lane + 64 * h];
-    for (int s = 0; s < a.S; ++s) {
-      const double t = (double)(a.t_base + s + 1), t1 = t + 1.0;  // recursor.t before this update
-      const double c_inv = 1.0 / t1, ca = (t - 1.0) / t, cb = a.sd / t;
-      double x[NH], mup[NH];
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        const int i = lane + 64 * h;
-        x[h] = i < a.d ? a.rec_params[((size_t)s * a.N + c) * a.d + i] : 0.0;
-        mup[h] = c_inv * (t * mu[h] + x[h]);
-      }
-      __syncthreads();  // the previous state's operand reads are done
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        s_x[lane + 64 * h] = x[h];
-        s_m[lane + 64 * h] = mu[h];
-        s_p[lane + 64 * h] = mup[h];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int p = 0; p < T; ++p) {
-        double xr[4], mr[4], pr[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          xr[r] = s_x[16 * p + hi + 4 * r];
-          mr[r] = s_m[16 * p + hi + 4 * r];
-          pr[r] = s_p[16 * p + hi + 4 * r];
-        }
-#pragma unroll
-        for (int i = p; i < T; ++i) {
-          const double xc = s_x[16 * i + lc], mc = s_m[16 * i + lc], pc = s_p[16 * i + lc];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            double M = (t * (mr[r] * mc) - t1 * (pr[r] * pc)) + xr[r] * xc;
-            if (p == i) M += (hi + 4 * r == lc) ? a.eps : 0.0;  // + eps on the diagonal, + 0 beside it (padded dimensions collect eps too; nothing reads them)
-            Sg[aemr_ut(T, p, i)][r] = ca * Sg[aemr_ut(T, p, i)][r] + cb * M;
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);  // (a tile row at a time: with the operand reads of all rows hoisted the 288 registers of Sigma spill)
-      }
-#pragma unroll
-      for (int h = 0; h < NH; ++h) mu[h] = mup[h];
-    }
-#pragma unroll
-    for (int h = 0; h < NH; ++h) a.am_mu[c * W + lane + 64 * h] = mu[h];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sig[(t * 4 + r) * 64 + lane] = Sg[t][r];
+    if (wave == 0) wide_adapt_rows<T, 0, 3, 4, 7>(a, c, lane, tid, s_x, s_m, s_p);
+    else wide_adapt_rows<T, 1, 2, 5, 6>(a, c, lane, tid, s_x, s_m, s_p);
   }
-  adapt_scaling(a, c, lane);
+  if (wave == 0) adapt_scaling(a, c, lane);
 }
 
 // ---- INC = Z L^T for a block of steps, one wave per chain ----
