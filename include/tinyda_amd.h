@@ -98,7 +98,9 @@ typedef struct tda_config {
   int32_t device;        /* HIP device ordinal */
   int64_t n_chains;      /* chains held by this engine (rows of the state matrix) */
   int64_t chain_offset;  /* global id of local chain 0 */
-  int32_t dim;           /* parameter dimension d (1..64) */
+  int32_t dim;           /* parameter dimension d: 1..64; 0.5: 65..128 for single-level chains (n_levels = 1) with a linear model, isotropic /
+                          * diagonal noise, a Gaussian prior with a diagonal covariance and TDA_PROP_GRW / TDA_PROP_PCN / TDA_PROP_AM --
+                          * anything else at more than 64 parameters is refused by tda_engine_init with TDA_ERR_UNSUPPORTED */
   int32_t n_levels;      /* 1 = MH (sampler.py:213), 2 = Delayed Acceptance (:231), 3..4 = MLDA (:260) */
   uint64_t seed;
   void* stream;          /* hipStream_t to run on, or NULL for an engine-owned stream */
@@ -181,7 +183,9 @@ const char* tda_last_error(void);
  * that passes 0 with non-NULL buffers is refused with TDA_ERR_INVALID); 0.3 tda_release_cached_memory, tda_engine_set_record_thinning,
  * tda_engine_set_progress / get_progress, tda_engine_detach_proposal_state + tda_proposal_snapshot_*,
  * tda_engine_set_proposal_spectrum; 0.4 tda_profile grew n_launch_aem / ms_aem (struct_size 48 is still accepted), checkpoint blobs
- * carry the ABI / RNG-contract version and older blobs are refused. */
+ * carry the ABI / RNG-contract version and older blobs are refused; 0.5 no entry point added or changed: tda_config.dim up to 128
+ * (single-level chains, see tda_config), the dense error model kept as the Cholesky factor instead of its triangular inverse (same
+ * results through tda_engine_get_error_model; checkpoint blobs are format 3 and format-2 blobs are refused). */
 const char* tda_version(void);
 
 /* Released engines park their large device buffers in a per-process pool (TINYDA_POOL_GB, default 8 GiB) so that the next
@@ -234,7 +238,8 @@ int tda_engine_set_level_rosenbrock(tda_engine* e, int level, double a, double b
 int tda_engine_set_subchains(tda_engine* e, const int32_t* lengths, int randomize);
 
 /* Adaptive error model (chain.py:268-305, 485-523; :643-678, 739-765): every level below the finest must have been set
- * with TDA_NOISE_ADAPTIVE (noise = m x m covariance), all levels share m <= 64.  State-dependent is two-level only. */
+ * with TDA_NOISE_ADAPTIVE (noise = m x m covariance), all levels share m <= 128 (dense model; the diagonal one: any m).  State-dependent
+ * is two-level only. */
 int tda_engine_set_error_model(tda_engine* e, int kind);
 /* Error-model state of adaptive level `level` (HOST, any may be NULL): bias [n_chains][m], cov_inverse [n_chains][m][m]
  * (the diagonal model fills the diagonal of each matrix). */

@@ -148,7 +148,7 @@ struct tda_engine {
 extern "C" {
 
 const char* tda_last_error(void) { return g_err.c_str(); }
-const char* tda_version(void) { return "tinyda_amd 0.4 (cpu twin of the C-ABI: test / baseline infrastructure)"; }
+const char* tda_version(void) { return "tinyda_amd 0.5 (cpu twin of the C-ABI: test / baseline infrastructure)"; }
 int64_t tda_release_cached_memory(void) { return 0; }
 
 int tda_engine_create(const tda_config* cfg, tda_engine** out) {

@@ -44,7 +44,7 @@ HOT = {
 #                              solves in place in LDS, aem_quad_factor_inplace);
 #   k_ml_steps<64,*,4,true>    its instances for hierarchies with a dense observation covariance on some level (round 4)
 KNOWN_SPILLERS = {
-    "_ZN3tda13k_aem_refreshILi8ELi3EEE": 2,  # (three trackers = four-level hierarchies: one register, no scratch)
+    "_ZN3tda13k_adapt_splitILi64EEE": 8,  # (TINYDA_ADAPT_SPLIT=1, an A/B switch: the moment recursion on two waves per chain at three waves per SIMD)
     "_ZN3tda10k_ml_stepsILi64ELi4ELi4ELb0EEE": 8,
     "_ZN3tda10k_ml_stepsILi64ELi2ELi4ELb1EEE": 24, "_ZN3tda10k_ml_stepsILi64ELi3ELi4ELb1EEE": 64, "_ZN3tda10k_ml_stepsILi64ELi4ELi4ELb1EEE": 104,
 }

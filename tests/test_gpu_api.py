@@ -210,7 +210,7 @@ def test_engine_buffers_are_pooled_and_come_back_zeroed(eng_mod):
     from tinyda_amd import _lib
 
     lib = _lib.load()
-    assert b"0.4" in lib.tda_version()
+    assert b"0.5" in lib.tda_version()
     A, y = _problem(d=33, m=70)  # padded to 64 parameters: pad lanes of recycled buffers must read as zero
     d = A.shape[1]
     post = tda.Posterior(st.multivariate_normal(np.zeros(d), np.eye(d)), tda.GaussianLogLike(y, 0.01 * np.eye(len(y))), tda.LinearModel(A))

@@ -94,8 +94,10 @@ def test_records_are_optional(eng_mod):
 def test_loud_failures(eng_mod):
     from tinyda_amd import EngineError
 
-    with pytest.raises(EngineError, match="dim=65"):
-        eng_mod.Engine(4, 65)
+    with pytest.raises(EngineError, match="dim=129"):  # (0.5: 128 parameters for single-level chains)
+        eng_mod.Engine(4, 129)
+    with pytest.raises(EngineError, match="more than 64 parameters are lowered for single-level chains"):
+        eng_mod.Engine(4, 65, n_levels=2)
     with pytest.raises(EngineError, match="n_levels"):
         eng_mod.Engine(4, 3, n_levels=5)
     e = eng_mod.Engine(4, 3)

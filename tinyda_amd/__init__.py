@@ -3,7 +3,7 @@
 Drop-in for the hot path tda.sample() -> Chain.sample -> Proposal / Posterior / GaussianLogLike
 (tinyDA/sampler.py, chain.py, proposal.py, posterior.py, distributions.py); see DESIGN.md for the scope.
 """
-__version__ = "0.4.0"
+__version__ = "0.5.0"
 
 from ._lib import EngineError  # noqa: F401
 from .hostloop import Chain  # noqa: F401

@@ -518,6 +518,13 @@ void launch_apply(const ApplyArgs& a, hipStream_t st) {
 }
 template <int DPAD>
 void launch_adapt(const AdaptArgs& a, hipStream_t st) {
+  if constexpr (DPAD == 64) {  // TINYDA_ADAPT_SPLIT=1 (A/B): the ten tiles of a chain dealt to two waves, three waves per SIMD (k_adapt_split)
+    static const bool split = getenv("TINYDA_ADAPT_SPLIT") && atoi(getenv("TINYDA_ADAPT_SPLIT")) == 1;
+    if (split && a.do_am && !a.block_moments) {
+      hipLaunchKernelGGL(k_adapt_split<DPAD>, dim3((unsigned)(2 * a.N)), dim3(64), 0, st, a);
+      return;
+    }
+  }
   if (a.do_am && a.block_moments) hipLaunchKernelGGL(k_adapt_block<DPAD>, dim3((unsigned)a.N), dim3(64), 0, st, a);
   else hipLaunchKernelGGL(k_adapt<DPAD>, dim3((unsigned)a.N), dim3(64), 0, st, a);
 }
@@ -1137,7 +1144,7 @@ int progress_mark(tda_engine* e, int64_t S, const uint8_t* blk_acc, int64_t n_fl
 extern "C" {
 
 const char* tda_last_error(void) { return g_err.c_str(); }
-const char* tda_version(void) { return "tinyda_amd 0.4 (gfx950)"; }
+const char* tda_version(void) { return "tinyda_amd 0.5 (gfx950)"; }
 
 int tda_engine_create(const tda_config* cfg, tda_engine** out) {
   if (!cfg || !out) return fail(TDA_ERR_INVALID, "null argument");

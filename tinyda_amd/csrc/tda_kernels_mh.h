@@ -1300,7 +1300,13 @@ __device__ __forceinline__ double bcast_lane64(double v, int src) {
 // dominate there), at DPAD = 32 nothing (150 us: four resident waves x 125 instructions, the vector unit 56 % busy); not
 // adopted, no benchmark configuration adapts in fewer than 64 dimensions.
 // the moment recursion of one chain by its wave; Sigma is left in Sg (and stored): k_adapt, and the first half of k_adapt_chol_apply
-template <int DPAD>
+// HALF: -1 = every tile row; 0 / 1 (64 parameters, k_adapt_split): the tile rows {0, 3} / {1, 2} -- five of the ten tiles each -- for two
+// waves that share a chain: 80 instead of 160 registers of Sigma and t mu mu^T, four waves per SIMD instead of two
+template <int HALF>
+__host__ __device__ constexpr bool am_row_mine(int ti) {
+  return HALF < 0 || (HALF == 0 ? (ti == 0 || ti == 3) : (ti == 1 || ti == 2));
+}
+template <int DPAD, int HALF = -1>
 __device__ __forceinline__ void adapt_am_chain(const AdaptArgs& a, const int64_t c, const int lane, double (&Sg)[am_tiles<DPAD>()][4]) {
   constexpr int T = am_tile_rows<DPAD>();
   constexpr int NTL = am_tiles<DPAD>();
@@ -1314,9 +1320,12 @@ __device__ __forceinline__ void adapt_am_chain(const AdaptArgs& a, const int64_t
     double* __restrict__ sig = a.am_sigma + (size_t)c * NTL * 256;
     double TM[NTL][4];  // t mu mu^T of the current mean, element (16 ti + hi + 4 r, 16 tj + lc), like Sigma in Sg
 #pragma unroll
-    for (int idx = 0; idx < NTL; ++idx)
+    for (int ti = 0; ti < T; ++ti)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Sg[idx][r] = sig[(idx * 4 + r) * 64 + lane];
+      for (int tj = 0; tj <= ti; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (am_row_mine<HALF>(ti)) Sg[ti * (ti + 1) / 2 + tj][r] = sig[((ti * (ti + 1) / 2 + tj) * 4 + r) * 64 + lane];
     double mu = lp ? a.am_mu[c * DPAD + lane] : 0.0;
     const int ppos = (lane & ~15) | ((lane & 3) << 2) | ((lane >> 2) & 3);
     // (t + 1) (mu'_s mu'_s^T) of step s IS t (mu_{s+1} mu_{s+1}^T) of step s + 1 (same operands, same rounding): it is
@@ -1332,6 +1341,7 @@ __device__ __forceinline__ void adapt_am_chain(const AdaptArgs& a, const int64_t
       for (int tj = 0; tj < T; ++tj) mc[tj] = s_nat[16 * tj + lc];
 #pragma unroll
       for (int ti = 0; ti < T; ++ti) {
+        if (!am_row_mine<HALF>(ti)) continue;
         const double2* __restrict__ q = reinterpret_cast<const double2*>(s_prm + 16 * ti + 4 * hi);
         const double2 m01 = q[0], m23 = q[1];
         const double mr[4] = {m01.x, m01.y, m23.x, m23.y};
@@ -1379,6 +1389,7 @@ __device__ __forceinline__ void adapt_am_chain(const AdaptArgs& a, const int64_t
       }
 #pragma unroll
       for (int ti = 0; ti < T; ++ti) {
+        if (!am_row_mine<HALF>(ti)) continue;
         double xr[4], pr[4];
         {
           const double2* __restrict__ q = reinterpret_cast<const double2*>(s_prm + 16 * ti + 4 * hi);
@@ -1401,11 +1412,14 @@ __device__ __forceinline__ void adapt_am_chain(const AdaptArgs& a, const int64_t
       }
       mu = mup;
     }
-    if (lp) a.am_mu[c * DPAD + lane] = mu;
+    if (lp && HALF <= 0) a.am_mu[c * DPAD + lane] = mu;  // (both halves carry the mean; one stores it)
 #pragma unroll
-    for (int idx = 0; idx < NTL; ++idx)
+    for (int ti = 0; ti < T; ++ti)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sig[(idx * 4 + r) * 64 + lane] = Sg[idx][r];
+      for (int tj = 0; tj <= ti; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (am_row_mine<HALF>(ti)) sig[((ti * (ti + 1) / 2 + tj) * 4 + r) * 64 + lane] = Sg[ti * (ti + 1) / 2 + tj][r];
   }
 }
 
@@ -1422,6 +1436,26 @@ __global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
 }
 
 // AdaptiveMetropolis(block_moments=True): the covariance as one rank-S update per block (see above)
+// The same recursion with the ten tiles of a 64-parameter chain dealt to TWO waves (workgroups 2 c and 2 c + 1: tile rows {0, 3} and
+// {1, 2}), each carrying the mean itself: 5 tiles of Sigma and of t mu mu^T per wave, at most 128 registers, FOUR waves per SIMD.  The
+// loop is bound by vector issue (434 vector instructions per state); tools/valu_rate_probe.hip prices that mix at 3.95
+// cycles per instruction with two waves per SIMD and 2.87 with four.  Same operations per element, same results bit for bit.
+template <int DPAD>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) k_adapt_split(const AdaptArgs a) {
+  static_assert(DPAD == 64, "four tile rows");
+  const int lane = threadIdx.x;
+  const int64_t c = blockIdx.x >> 1;
+  if (c >= a.N) return;
+  if (blockIdx.x & 1) {
+    double Sg[am_tiles<DPAD>()][4];
+    adapt_am_chain<DPAD, 1>(a, c, lane, Sg);
+  } else {
+    double Sg[am_tiles<DPAD>()][4];
+    adapt_am_chain<DPAD, 0>(a, c, lane, Sg);
+    adapt_scaling(a, c, lane);
+  }
+}
+
 template <int DPAD>
 __global__ void __launch_bounds__(64) k_adapt_block(const AdaptArgs a) {
   constexpr int T = am_tile_rows<DPAD>();
