@@ -121,11 +121,11 @@ def test_bench_launches_its_own_ranks():
 
 
 def test_scale_script_rehearsal_on_one_gpu(tmp_path):
-    """tools/r04_scale.sh -- the one command for an 8-GPU node (bench at 1/2/4/8 ranks, config 4 in the four archive modes, the peer
+    """tools/r05_scale.sh -- the one command for an 8-GPU node (bench at 1/2/4/8 ranks, config 4 in the four archive modes, the peer
     archive check) -- rehearsed with two ranks on this one GPU over gloo: every stage runs, every line carries its rank count."""
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         os.environ.pop(k, None)
-    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "r04_scale.sh"), str(tmp_path)], cwd=ROOT, env=dict(os.environ, REHEARSE="1"),
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "r05_scale.sh"), str(tmp_path)], cwd=ROOT, env=dict(os.environ, REHEARSE="1"),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-4000:]
     rep = json.load(open(tmp_path / "summary.json"))
