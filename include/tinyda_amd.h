@@ -98,8 +98,8 @@ typedef struct tda_config {
   int32_t device;        /* HIP device ordinal */
   int64_t n_chains;      /* chains held by this engine (rows of the state matrix) */
   int64_t chain_offset;  /* global id of local chain 0 */
-  int32_t dim;           /* parameter dimension d: 1..64; 0.5: 65..128 for single-level chains (n_levels = 1) with a linear model, isotropic /
-                          * diagonal noise, a Gaussian prior with a diagonal covariance and TDA_PROP_GRW / TDA_PROP_PCN / TDA_PROP_AM --
+  int32_t dim;           /* parameter dimension d: 1..64; 0.5: 65..128 for single-level chains and two-level Delayed Acceptance (n_levels <= 2, no error model)
+                          * with linear models, isotropic / diagonal noise, a Gaussian prior with a diagonal covariance and TDA_PROP_GRW / TDA_PROP_PCN / TDA_PROP_AM --
                           * anything else at more than 64 parameters is refused by tda_engine_init with TDA_ERR_UNSUPPORTED */
   int32_t n_levels;      /* 1 = MH (sampler.py:213), 2 = Delayed Acceptance (:231), 3..4 = MLDA (:260) */
   uint64_t seed;
@@ -184,7 +184,7 @@ const char* tda_last_error(void);
  * tda_engine_set_progress / get_progress, tda_engine_detach_proposal_state + tda_proposal_snapshot_*,
  * tda_engine_set_proposal_spectrum; 0.4 tda_profile grew n_launch_aem / ms_aem (struct_size 48 is still accepted), checkpoint blobs
  * carry the ABI / RNG-contract version and older blobs are refused; 0.5 no entry point added or changed: tda_config.dim up to 128
- * (single-level chains, see tda_config), the dense error model kept as the Cholesky factor instead of its triangular inverse (same
+ * (single-level chains and two-level hierarchies, see tda_config), the dense error model kept as the Cholesky factor instead of its triangular inverse (same
  * results through tda_engine_get_error_model; checkpoint blobs are format 3 and format-2 blobs are refused). */
 const char* tda_version(void);
 

@@ -111,8 +111,65 @@ def test_sample_runs_100_parameters_on_the_device():
     st = res["proposal_state"]
     assert np.asarray(st["C"]).shape == (n_chains, d, d) and np.all(np.isfinite(np.asarray(st["C"])))
     coarse = tda.Posterior(post.prior, tda.GaussianLogLike(y[:50], 0.0025 * np.eye(50)), tda.LinearModel(A[:50]))
-    with pytest.warns(tda.HostFallbackWarning, match="more than 64 parameters are lowered for single-level chains"):
-        tda.sample([coarse, post], tda.CrankNicolson(scaling=0.05), 3, n_chains=1, subchain_length=2)
+    da = tda.sample([coarse, post], tda.CrankNicolson(scaling=0.02), 40, n_chains=8, subchain_length=3, seed=3)  # Delayed Acceptance at 100 parameters
+    assert da["backend"] == "hip" and da["sampler"] == "DA" and len(da["chain_fine_0"]) == 41
+    mid = tda.Posterior(post.prior, tda.GaussianLogLike(y[:120], 0.0025 * np.eye(120)), tda.LinearModel(A[:120]))
+    with pytest.warns(tda.HostFallbackWarning, match="more than 64 parameters are lowered for single-level chains and two-level"):
+        tda.sample([coarse, mid, post], tda.CrankNicolson(scaling=0.05), 2, n_chains=1, subchain_length=[2, 2])
+
+
+DA_CASES = [(96, (24, 70), 3, 17, 12, "pcn"), (128, (33, 130), 4, 16, 9, "am"), (80, (16, 40), 2, 20, 15, "grw_adaptive"), (100, (20, 65), 3, 18, 10, "pcn_random")]
+
+
+@pytest.mark.parametrize("case", DA_CASES, ids=["%d-%s" % (c[0], c[5]) for c in DA_CASES])
+def test_wide_delayed_acceptance_against_the_oracle(case):
+    """two-level Delayed Acceptance at 80 .. 128 parameters (generic level kernel k_ml_steps<128, 2> + the wide proposal / adaptation
+    launches) on the engine's own Philox stream against the oracle: accept masks of both levels exact, log-posteriors to 1e-10"""
+    from tests.test_gpu_multilevel import _oracle_uniforms
+    from tinyda_amd.engine import Engine
+
+    d, ms, L, N, n_fine, kind = case
+    rng = np.random.default_rng(7000 + d)
+    truth = 0.5 * rng.standard_normal(d)
+    As = [rng.standard_normal((m, d)) / np.sqrt(d) for m in ms]
+    ys = [A @ truth + 0.1 * rng.standard_normal(len(A)) for A in As]
+    theta0 = truth + 0.05 * rng.standard_normal((N, d))
+    period = 8
+    C0 = _spd(rng, d, 4e-3 / d)
+    randomize = kind.endswith("random")
+    if kind.startswith("pcn"):
+        prop = dict(kind="pcn", scaling=0.04, adaptive=True, gamma=1.01, period=period)
+    elif kind.startswith("grw"):
+        prop = dict(kind="grw", C=C0, scaling=0.9, adaptive=True, gamma=1.02, period=period)
+    else:
+        prop = dict(kind="am", C0=C0, t0=period, period=period, adaptive=False)
+    seed = 900 + d
+    e = Engine(N, d, seed=seed, n_levels=2)
+    e.set_prior(np.zeros(d), np.eye(d))
+    for k in range(2):
+        e.set_level(k, As[k], ys[k], 0, 0.01)
+    if prop["kind"] == "pcn":
+        e.set_proposal(1, None, scaling=prop["scaling"], adaptive=True, gamma=prop["gamma"], period=period)
+    elif prop["kind"] == "grw":
+        e.set_proposal(0, C0, scaling=0.9, adaptive=True, gamma=1.02, period=period)
+    else:
+        e.set_proposal(2, C0, t0=period, period=period, adaptive=False)
+    e.set_subchains([L], randomize)
+    e.init(theta0)
+    rows = e.rows_per_level(n_fine)
+    z, _ = e.set_export(rows[0])
+    outs = e.run_levels_host(n_fine)
+    e.close()
+    us, ridx = _oracle_uniforms(seed, N, rows, [L], L if randomize else None)
+    prior = orc.MVNPrior(np.zeros(d), np.eye(d))
+    levels = [orc.LinearGaussianLevel(As[k], ys[k], "iso", 0.01, prior) for k in range(2)]
+    res, _ = orc.run_multilevel(levels, prop, [L], theta0, np.swapaxes(z, 0, 1), us, n_fine, ridx)
+    for k in range(2):
+        ref = res[k]
+        sk = slice(1, None) if k == 1 else slice(None)
+        assert np.array_equal(outs[k][2], ref["accepted"][:, sk].T), "level %d accept masks differ" % k
+        np.testing.assert_allclose(outs[k][1][:, :, 2], ref["logpost"][:, sk].T, rtol=1e-9 if kind == "am" else 1e-10)
+    assert 0.0 < outs[0][2].mean() < 1.0
 
 
 def test_wide_checkpoint_resume_is_bitwise():

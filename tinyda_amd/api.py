@@ -53,14 +53,17 @@ def _device_plan(posteriors, proposal, diagonal_error_model=False, error_model=N
         if low is None or low["prior_mean"].shape[0] > MAX_PARAMETERS:
             return _no("a posterior the engine cannot lower (an opaque Python model, a prior other than scipy's multivariate normal / JointPrior of norm and uniform, a likelihood outside GaussianLogLike's classes)" if low is None else "more than %d parameters" % MAX_PARAMETERS)
         if low["prior_mean"].shape[0] > 64:
-            # 65 .. 128 parameters (0.5, tda_kernels_wide.h): single-level chains, a linear model with isotropic / diagonal noise, a Gaussian
+            # 65 .. 128 parameters (0.5, tda_kernels_wide.h): single-level chains and two-level Delayed Acceptance, linear models with isotropic / diagonal noise, a Gaussian
             # prior with a diagonal covariance, GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis
             pc = np.asarray(low["prior_cov"])
-            if (len(posteriors) != 1 or type(proposal) not in (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis) or low.get("A") is None
+            if (len(posteriors) > 2 or (len(posteriors) == 2 and error_model is not None)
+                    or type(proposal) not in (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis) or low.get("A") is None
+                    or getattr(proposal, "block_moments", False)
                     or any(k in low for k in ("source", "batched", "rosenbrock", "prior_joint"))
                     or low["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG) or np.count_nonzero(pc - np.diag(np.diag(pc)))):
-                return _no("more than 64 parameters are lowered for single-level chains only: a linear model with isotropic / diagonal noise, "
-                           "a Gaussian prior with a diagonal covariance, GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis")
+                return _no("more than 64 parameters are lowered for single-level chains and two-level Delayed Acceptance only: linear models with "
+                           "isotropic / diagonal noise, a Gaussian prior with a diagonal covariance, GaussianRandomWalk / CrankNicolson / "
+                           "AdaptiveMetropolis, no error model")
         if diagonal_error_model and low["noise_kind"] == _lib.NOISE_ADAPTIVE:
             # diagonal error model: the adaptive likelihood's covariance must be diagonal and travels as its diagonal
             cov = np.asarray(low["noise"], dtype=np.float64)

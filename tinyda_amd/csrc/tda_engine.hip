@@ -774,6 +774,20 @@ int launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st, int* f
     default: return go(&k_ml_steps<DPAD, 4>);
   }
 }
+// 65 .. 128 parameters: Delayed Acceptance (two levels) on the generic level kernel, one 512-register wave per SIMD (tda_engine_init
+// refuses everything else above 64 parameters in a hierarchy)
+template <>
+int launch_ml<128>(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st, int* free_regs, bool) {
+  auto kern = &k_ml_steps<128, 2>;
+  if (free_regs) {
+    *free_regs = 0;  // (no room for the generator beside it)
+    return TDA_OK;
+  }
+  if (a.nlev != 2) return fail(TDA_ERR_UNSUPPORTED, "more than 64 parameters: two-level hierarchies only");
+  if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, st, a);
+  return TDA_OK;
+}
 
 template <int DPAD>
 void launch_dz_draw(const DreamDrawArgs& a, hipStream_t st) {
@@ -1151,8 +1165,8 @@ int tda_engine_create(const tda_config* cfg, tda_engine** out) {
   if (cfg->struct_size != sizeof(tda_config)) return fail(TDA_ERR_INVALID, "tda_config.struct_size mismatch");
   if (cfg->dim < 1 || cfg->dim > 128)
     return fail(TDA_ERR_UNSUPPORTED, "dim=%d outside the device engine's range 1..128", cfg->dim);
-  if (cfg->dim > 64 && cfg->n_levels != 1)
-    return fail(TDA_ERR_UNSUPPORTED, "dim=%d: more than 64 parameters are lowered for single-level chains", cfg->dim);
+  if (cfg->dim > 64 && cfg->n_levels > 2)
+    return fail(TDA_ERR_UNSUPPORTED, "dim=%d: more than 64 parameters are lowered for single-level chains and two-level Delayed Acceptance", cfg->dim);
   if (cfg->n_chains < 1) return fail(TDA_ERR_INVALID, "n_chains must be >= 1");
   if (cfg->n_levels < 1 || cfg->n_levels > MAXLEV)
     return fail(TDA_ERR_UNSUPPORTED, "n_levels=%d outside 1..%d", cfg->n_levels, (int)MAXLEV);
