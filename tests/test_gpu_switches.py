@@ -17,7 +17,7 @@ def _probe(what, env_extra, tmp_path, tag):
     out = str(tmp_path / ("%s_%s.npz" % (what, tag)))
     env = dict(os.environ)
     for k in ("TINYDA_DA_LEAN", "TINYDA_DZ_WAVE", "TINYDA_DZ_PIPELINE", "TINYDA_AEMD_FUSED", "TINYDA_FUSE_CHOL_APPLY", "TINYDA_CHOL_BLOCKED",
-              "TINYDA_FUSE_ADAPT_CHOL", "TINYDA_AEM_BASE", "TINYDA_ML_SPLIT", "TINYDA_DA_R224", "TINYDA_AM_DEFER", "TINYDA_ML_PREDRAW", "TINYDA_AEM_PRE"):
+              "TINYDA_FUSE_ADAPT_CHOL", "TINYDA_ADAPT_SPLIT", "TINYDA_AEM_BASE", "TINYDA_ML_SPLIT", "TINYDA_DA_R224", "TINYDA_AM_DEFER", "TINYDA_ML_PREDRAW", "TINYDA_AEM_PRE"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "switch_probe.py"), what, out], cwd=ROOT, env=env,
@@ -83,6 +83,11 @@ def test_fused_swap_and_increments_equal_the_two_launches(what, tmp_path):
     two = _probe(what, {"TINYDA_FUSE_ADAPT_CHOL": "0"}, tmp_path, "two_launches")
     for k in blk:
         assert np.array_equal(blk[k], two[k]), "one-launch boundary changed %s" % k
+    # round 5: the recursion's ten tiles dealt to two waves per chain (k_adapt_split, TINYDA_ADAPT_SPLIT=1): the same operations per
+    # element -- bitwise
+    spl = _probe(what, {"TINYDA_FUSE_ADAPT_CHOL": "0", "TINYDA_ADAPT_SPLIT": "1"}, tmp_path, "split_recursion")
+    for k in blk:
+        assert np.array_equal(blk[k], spl[k]), "k_adapt_split changed %s" % k
 
 
 @pytest.mark.parametrize("what", ["aem_dense", "aem_dense_ragged", "aem_dense_da_pcn"])
@@ -163,3 +168,14 @@ def test_fused_and_per_step_diagonal_error_model_agree(what, other, tmp_path):
         else:
             np.testing.assert_allclose(fused[k], steps[k], rtol=1e-9, atol=1e-11, err_msg=k)
     assert 0.02 < fused["acc0"].mean() < 0.98 and 0.02 < fused["acc2"].mean() <= 1.0
+
+
+def test_long_base_subchains_of_the_dense_error_model_take_the_step_by_step_kernel(tmp_path):
+    """k_aem_base_steps keeps its S + 2 product vectors in LDS; a base subchain whose set exceeds 64 KB (beyond ~58 steps at
+    128 outputs) runs on the level kernel instead of asking for more LDS than a workgroup may have -- and agrees with TINYDA_AEM_BASE=0"""
+    a, b = _probe("aem_dense_long", {}, tmp_path, "auto"), _probe("aem_dense_long", {"TINYDA_AEM_BASE": "0"}, tmp_path, "per_step")
+    for k in a:
+        if k.startswith("acc"):
+            assert np.array_equal(a[k], b[k]), k
+        else:
+            np.testing.assert_allclose(a[k], b[k], rtol=1e-10, atol=1e-12, err_msg=k)

@@ -84,6 +84,8 @@ if __name__ == "__main__":
         res = hierarchy((100, 100, 100), [5, 3], "am", 8, N=96 - cut, error_model="state-independent")
     elif what == "aem_dense_da_pcn":  # two levels, pCN (keep < 1 in the linear update), state-dependent model
         res = hierarchy((40, 40), [4], "pcn", 12, N=64, error_model="state-dependent")
+    elif what == "aem_dense_long":  # a base subchain whose product vectors do not fit 64 KB of LDS (128 outputs, 70 steps): level kernel
+        res = hierarchy((128, 128), [70], "pcn", 2, N=32, error_model="state-independent")
     elif what == "am":
         res = single_am(N=96 - cut)
     else:
