@@ -24,7 +24,7 @@ _DEVICE_PROPOSALS = (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis, DREA
 
 
 MAX_LEVELS = 4
-MAX_PARAMETERS = 128  # (more than 64: single-level chains, see _device_plan)
+MAX_PARAMETERS = 128  # (more than 64: single-level chains and two-level Delayed Acceptance, see _device_plan)
 MAX_AEM_OUTPUTS = 128
 
 
