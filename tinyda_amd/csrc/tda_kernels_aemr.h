@@ -215,6 +215,63 @@ __device__ __forceinline__ double aem_quad_factor(const double* __restrict__ Wc,
   return sq;
 }
 
+// aem_quad_factor with the factor's tiles as ONE stream of buffer loads in the order of use, AEMQ_WIN tiles requested ahead of the one
+// being multiplied (tile t + AEMQ_WIN is requested when tile t has arrived): the caller issues the first requests with
+// aem_quad_request() as early as it knows the chain -- before its own dependent loads, which would otherwise be a round trip the
+// 72 KB wait behind -- and passes the registers on.  Same arithmetic in the same order as aem_quad_factor: identical results.
+#ifndef AEMQ_WIN
+#define AEMQ_WIN 8
+#endif
+template <int T>
+struct AemQuadStream {
+  static constexpr int NT = aemr_tiles(T), WIN = AEMQ_WIN < NT ? AEMQ_WIN : NT;
+  __amdgpu_buffer_rsrc_t rs;
+  int lane_w;
+  double w[NT][4];
+};
+template <int T>
+__device__ __forceinline__ void aem_quad_request(AemQuadStream<T>& st, const double* __restrict__ Wc, int lane) {
+  st.rs = aemr_rsrc(Wc);
+  st.lane_w = lane * 8;
+#pragma unroll
+  for (int t = 0; t < AemQuadStream<T>::WIN; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st.w[t][r] = aemr_ld(st.rs, st.lane_w, (t * 4 + r) * 512);
+}
+template <int T>
+__device__ __forceinline__ double aem_quad_factor_stream(AemQuadStream<T>& st, const double* __restrict__ s_r, int lane) {
+  constexpr int NT = AemQuadStream<T>::NT, WIN = AemQuadStream<T>::WIN;
+  const int lc = lane & 15;
+  double z[T][4];
+  double sq = 0.0;
+#pragma unroll
+  for (int q = 0; q < T; ++q) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i <= q; ++i) {
+      const int ti = aemr_lt(q, i);
+      if (i < q) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t = fma(st.w[ti][r], z[i][r], t);
+      } else {
+        t = s_r[16 * q + lc] - sum_rows(t);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double zz = aemr_row_sum(st.w[ti][r] * t);
+          z[q][r] = zz;
+          sq = fma(zz, zz, sq);
+        }
+      }
+      asm volatile("" : "+v"(st.lane_w) : "v"(st.w[ti][3]));
+      if (ti + WIN < NT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st.w[ti + WIN][r] = aemr_ld(st.rs, st.lane_w, ((ti + WIN) * 4 + r) * 512);
+      }
+    }
+  }
+  return sq;
+}
+
 // The same substitution with the solved blocks kept in LDS instead of 8 T registers: s_r is OVERWRITTEN (block q of r by z_q, entries
 // permuted inside the block: position 4 hi + r holds z[hi + 4 r], one 32-byte read per tile for the lane that multiplies them), the
 // block loops are run-time loops.  For callers at their register peak (k_ml_steps evaluates every level through one inlined
@@ -566,14 +623,27 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AEMR_WA
 // linear and the increments of the block are known before its first step, so with F = A theta (no offsets)
 //     L^-1 r' = keep L^-1 F + L^-1 A (s inc_k) + L^-1 (bias - ytil)  (keep = sqrt(1 - beta^2) for pCN, 1 otherwise)
 // and ONE pass over the factor solves for all S + 2 vectors [F | bias - ytil | A s inc_1 ... A s inc_S] (round 5: a blocked forward
-// substitution on the factor form; round 4 multiplied by V = L^-1); a step is then an m-vector update and two reductions.  The products are re-derived from theta at every launch (rounding does not accumulate beyond one
-// subchain); log-densities agree with the step-by-step evaluation to rounding, decisions are the same.
+// substitution on the factor form, products and substitution on the matrix cores -- the vectors are the columns of the B operand;
+// round 4 multiplied by V = L^-1 on the vector unit); a step is then an m-vector update and two reductions.  The products are
+// re-derived from theta at every launch (rounding does not accumulate beyond one subchain); log-densities agree with the step-by-step evaluation to rounding, decisions are the same.
 // Diagonal prior (bounded support included), fixed subchain lengths; anything else stays with k_ml_steps.
 // ------------------------------------------------------------------------------------------------
+#define AEMB_ZS(MP) ((MP) + 2)  // (a vector's blocks are written 32 bytes per lane: 16-byte aligned, lanes of a row on different banks)
+#define AEMB_XS 17
+#ifndef AEMB_WIN
+#define AEMB_WIN 8  // tiles of the factor requested ahead (2 KB each; 8: 251 registers, two waves per SIMD)
+#endif
+#ifdef AEMB_TRACE  // timing experiments: cycle stamps of every chain's wave ([chain][16] of s_memtime) -- tools/trace_base_steps.py
+__device__ unsigned long long aemb_trace_buf[8192 * 16];
+#define AEMB_STAMP(i) do { if (lane == 0 && c < 8192) aemb_trace_buf[c * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define AEMB_STAMP(i) do { } while (0)
+#endif
 struct AemBaseArgs {
   int64_t N, NP;
   int d, DP, m, MP, S, pcn;
-  const double* A_cm;   // [d][MP] level-0 operator, column-major (lane = observation reads consecutive addresses)
+  const double* Apk;    // level 0's operator as packed matrix-core fragments (LevelDev::Apk, [ncb][DP / 8][64][2])
+  int ncb;              // its 16-row blocks (<= MP / 16)
   const double* ytil;   // [MP] y - b
   const double* bias;   // [NP][MP] total bias of level 0
   const double* V;      // [NP][tiles][4][64]
@@ -599,122 +669,149 @@ struct AemBaseArgs {
   uint8_t* rec_acc;
 };
 
-#ifndef AEMB_KG
-#define AEMB_KG 2
-#endif
 template <int T>
-__global__ void __launch_bounds__(64) k_aem_base_steps(const AemBaseArgs a) {
-  constexpr int MP = 16 * T, NH = MP / 64 > 0 ? MP / 64 : 1;  // observations per lane
-  constexpr int CMAX = 8;                                      // vectors per pass over V
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_aem_base_steps(const AemBaseArgs a) {
+  constexpr int MP = 16 * T, NH = MP / 64 > 0 ? MP / 64 : 1;  // observations per lane (the steps)
+  constexpr int ZS = AEMB_ZS(MP), XS = AEMB_XS;               // strides of a result vector / of a staged parameter row in LDS
   extern __shared__ __attribute__((aligned(16))) double aemb_smem[];
-  double* s_X = aemb_smem;         // [S + 2][MP]: F, bias - ytil, A s inc_k; overwritten by L^-1 times them; then CMAX staged parameter vectors [64]
   const int lane = threadIdx.x, lc = lane & 15, hi = lane >> 4;
   const int64_t c = blockIdx.x;
   if (c >= a.N) return;
   const int d = a.d, S = a.S, NC = S + 2;
+  double* s_X = aemb_smem;                 // [S + 2][ZS]: L^-1 times F, bias - ytil, A s inc_k (entries of a block permuted, see below)
+  double* s_xs = s_X + (size_t)NC * ZS;    // [64 parameters][XS]: the 16 parameter vectors of a column chunk, B operand of the products
+  double* s_T = s_xs + 64 * XS;            // [16][XS]: a diagonal tile on its way to its transpose
+  double* s_u = s_T + 16 * XS;             // [S]: the steps' uniforms
   const bool lj = lane < d;
   double th = lj ? a.theta[c * a.DP + lane] : 0.0;
   const double scal = a.scaling[c];
   const double* __restrict__ Vc = a.V + (size_t)c * aemr_tiles(T) * 256;
+  const int K2 = a.DP >> 3;
+  AEMB_STAMP(0);
+  for (int k = lane; k < S; k += 64) s_u[k] = a.u0[(size_t)k * a.NP + c];  // (read after the pass over the factor, barriers in between)
 
-  // ---- the S + 1 products with the level's operator, the offsets ----
-  for (int k0 = 0; k0 <= S; k0 += CMAX) {  // vectors theta (k = 0) and s inc_k (k >= 1), CMAX at a time
-    const int nk = S + 1 - k0 < CMAX ? S + 1 - k0 : CMAX;
-    __syncthreads();
-    for (int k = 0; k < nk; ++k) {  // the chunk's parameter vectors: rows of a [CMAX][64] block (s_th grows into a block here)
-      const int kk = k0 + k;
-      const double v = kk == 0 ? th : (lj ? scal * a.inc[((size_t)(kk - 1) * a.NP + c) * a.DP + lane] : 0.0);
-      s_X[(size_t)NC * MP + k * 64 + lane] = v;  // (staging rows beyond the S + 2 result vectors)
+  // The S + 2 vectors are the columns of ONE matrix X [MP][S + 2] -- F = A theta, the offsets bias - ytil, A (s inc_k) -- taken 16
+  // columns at a time (one chunk up to a 14-step subchain), and both halves of the work are matrix-core work in the accumulator
+  // layout (lane (lc, hi), register r of block q = X[16 q + hi + 4 r][column lc]):
+  //   products   X_q = A_q Theta: the level's packed operator fragments (LevelDev::Apk) are the A operand, the staged parameter
+  //              vectors the B operand: 16 matrix instructions per block;
+  //   solve      Z_q = L_qq^-1 (X_q - sum_{i < q} U_iq^T Z_i): tile (q, i) of the factor form and Z_i, register for register, ARE the
+  //              operands of the X^T Y product; the diagonal tile goes through LDS once to arrive transposed: 4 (q + 1) matrix
+  //              instructions per block row and ONE pass over the chain's 72 KB.
+  // ONE streaming pass: the factor's tiles are requested in the order they are used ((0,0), (1,0), (1,1), (2,0) ...), AEMB_WIN of them
+  // ahead of the one in use and the first ones before anything is waited for; block q of X is formed just before block row q needs
+  // it, from operator fragments requested a block ahead.
+  // History (4096 chains x 128 outputs, 5-step subchains, per launch; cycle stamps per wave: tools/trace_base_steps.py): both halves on
+  // the vector unit with the solved blocks going through LDS, 0.161 ms (products 53 us, pass 82, steps 26); the same two phases on the
+  // matrix cores one after the other, 0.161 ms STILL -- the launch is two rounds of waves that run their phases in step, so there was
+  // no memory traffic during the products and nothing else during the pass; products inside the pass, 0.107; the staging's loads
+  // requested ahead of the window's (loads return in order: behind 16 KB of tiles the increments took 16 us), the steps reading
+  // increments and uniforms from LDS instead of memory and summing with DPP / permlane instead of ds_bpermute, 0.093.  The pass
+  // itself runs at 6 TB/s while it runs (58 000 of a wave's 92 000 cycles); windows of 3 to 12 tiles time the same.
+  constexpr int NT = aemr_tiles(T), WIN = AEMB_WIN < NT ? AEMB_WIN : NT;
+  const __amdgpu_buffer_rsrc_t Wrs = aemr_rsrc(Vc);  // (descriptor + one lane offset + compile-time scalar offsets: no address pairs)
+  const FragSrc Asrc = frag_src(a.Apk, lane);
+  for (int k0 = 0; k0 < NC; k0 += 16) {
+    // (what the staging needs is requested FIRST: loads return in order, and behind the window's 16 KB the increments took 16 us to arrive)
+    double sv[16], sb[NH], sy[NH];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {  // column g: 0 = theta, 1 = nothing (the offsets enter below), g >= 2: s inc_{g-2}
+      const int g = k0 + v;
+      sv[v] = (g >= 2 && g < NC && lj) ? a.inc[((size_t)(g - 2) * a.NP + c) * a.DP + lane] : 0.0;
     }
-    __syncthreads();
-    double acc[NH][CMAX];
 #pragma unroll
-    for (int h = 0; h < NH; ++h)
-#pragma unroll
-      for (int k = 0; k < CMAX; ++k) acc[h][k] = 0.0;
-    const double* __restrict__ xs = s_X + (size_t)NC * MP;
-    for (int j = 0; j < d; ++j) {
-      double av[NH];
-#pragma unroll
-      for (int h = 0; h < NH; ++h) av[h] = a.A_cm[(size_t)j * MP + lane + 64 * h];
-#pragma unroll
-      for (int k = 0; k < CMAX; ++k) {
-        const double xv = k < nk ? xs[k * 64 + j] : 0.0;
-#pragma unroll
-        for (int h = 0; h < NH; ++h) acc[h][k] = fma(av[h], xv, acc[h][k]);
-      }
+    for (int h = 0; h < NH; ++h) {
+      const int o = lane + 64 * h;
+      const bool in = k0 == 0 && o < a.m;
+      sb[h] = in ? a.bias[c * MP + o] : 0.0;
+      sy[h] = in ? a.ytil[o] : 0.0;
     }
+    int lane_f = Asrc.lane_off;
+    double2 f[8];  // the operator fragments of one 16-row block (slices beyond DP / 8: copies of the last, multiplied by zeros)
+    auto load_fragments = [&](int cb) {
+      const int soff = (cb < a.ncb ? cb : a.ncb - 1) * K2 * 1024;
 #pragma unroll
-    for (int k = 0; k < CMAX; ++k)
-      if (k < nk) {
-        const int col = k0 + k == 0 ? 0 : k0 + k + 1;  // F first, then (after the offsets) the increments
-#pragma unroll
-        for (int h = 0; h < NH; ++h)
-          if (lane + 64 * h < MP) s_X[(size_t)col * MP + lane + 64 * h] = acc[h][k];
+      for (int k = 0; k < 8; ++k) {
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(Asrc.rsrc, lane_f, soff + (k < K2 ? k : K2 - 1) * 1024, 0);
+        f[k] = *reinterpret_cast<const double2*>(&v);
       }
-  }
-#pragma unroll
-  for (int h = 0; h < NH; ++h) {
-    const int o = lane + 64 * h;
-    if (o < MP) s_X[(size_t)MP + o] = o < a.m ? a.bias[c * MP + o] - a.ytil[o] : 0.0;
-  }
-  __syncthreads();
-
-  // ---- Z = L^-1 X: ONE pass over the chain's factor for CMAX vectors at a time, blocked forward substitution by block columns:
-  //   t[lc] = x[16 q + lc] - sum_{i < q} sum_k U_iq[k][lc] z_i[k],   z_q = (L_qq)^-1 t      (aem_quad_factor, for CMAX vectors)
-  // The results take the place of the operands in LDS -- block q of a vector is read (as x) at step q, before it is written -- with
-  // the entries of a block PERMUTED: position 4 hi + r holds z[hi + 4 r], so that a lane fetches the four entries it multiplies
-  // with one 32-byte read.  Everything after this pass is elementwise over vectors in the same order or a sum of squares: the
-  // permutation is never undone.  (The first version kept the partial sums of all blocks below in registers, right-looking: 502
-  // registers, or 984 bytes of scratch at two waves per SIMD.)
-  for (int k0 = 0; k0 < NC; k0 += CMAX) {
-    const int nk = NC - k0 < CMAX ? NC - k0 : CMAX;
+    };
+    load_fragments(0);
     int lane_w = lane * 8;  // byte offset of this lane's element inside a 512-byte tile row
-    const __amdgpu_buffer_rsrc_t Wrs = aemr_rsrc(Vc);  // (descriptor + one lane offset + compile-time scalar offsets: no address pairs)
+    double w[NT][4];
+#pragma unroll
+    for (int t = 0; t < WIN; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w[t][r] = aemr_ld(Wrs, lane_w, (t * 4 + r) * 512);
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < 16; ++v) s_xs[lane * XS + v] = k0 + v == 0 ? th : scal * sv[v];
+    if (k0 == 0) {  // (the offsets wait where the first chunk's results go at its end)
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+        if (lane + 64 * h < MP) s_X[lane + 64 * h] = sb[h] - sy[h];
+    }
+    __syncthreads();
+    AEMB_STAMP(1);
+    double4_t X[T];
 #pragma unroll
     for (int q = 0; q < T; ++q) {
-      double w[T][4];  // tiles (q, 0 .. q) of the factor form: 2 (q + 1) KB contiguous
+      // ---- X_q = A_q Theta (+ the offsets in column 1) ----
+      double4_t x0;
 #pragma unroll
-      for (int i = 0; i <= q; ++i)
+      for (int r = 0; r < 4; ++r) x0[r] = (k0 == 0 && lc == 1) ? s_X[16 * q + hi + 4 * r] : 0.0;
+      double4_t xq = x0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) w[i][r] = aemr_ld(Wrs, lane_w, (aemr_lt(q, i) * 4 + r) * 512);
-      // (the vectors KG at a time: that many result quadruples in registers instead of eight)
-      constexpr int KG = AEMB_KG;
-#pragma unroll
-      for (int kh = 0; kh < CMAX; kh += KG) {
-        double zq[KG][4];
-#pragma unroll
-        for (int k = 0; k < KG; ++k) {
-          const double* __restrict__ xk = s_X + (size_t)(k0 + (kh + k < nk ? kh + k : 0)) * MP;  // (vectors beyond nk: recomputed copies of the first, dropped)
-          double acc = 0.0;
-#pragma unroll
-          for (int i = 0; i < q; ++i) {
-            const double4_t zv = *reinterpret_cast<const double4_t*>(xk + 16 * i + 4 * hi);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc = fma(w[i][r], zv[r], acc);
-          }
-          const double t = xk[16 * q + lc] - sum_rows(acc);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) zq[k][r] = aemr_row_sum(w[q][r] * t);
-        }
-        // (the tile loads of step q + 1 take their lane offset from here: hoisted to the top of the fully unrolled pass the 36 tiles
-        // are 288 registers, or a kilobyte of scratch under any occupancy target; the waves sharing the SIMD hide the latency)
-        asm volatile("" : "+v"(lane_w) : "v"(zq[0][0]));
-        __syncthreads();  // every read of block q of these vectors is done
-        if (lc == 0) {
-#pragma unroll
-          for (int k = 0; k < KG; ++k)
-            if (kh + k < nk) {
-              double4_t zv;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) zv[r] = zq[k][r];
-              *reinterpret_cast<double4_t*>(s_X + (size_t)(k0 + kh + k) * MP + 16 * q + 4 * hi) = zv;
-            }
-        }
-        __syncthreads();
+      for (int k = 0; k < 8; ++k) {  // (B operand: parameter 4 j + hi of column lc; rows beyond d are zero)
+        xq = mfma_f64(f[k].x, s_xs[(8 * k + hi) * XS + lc], xq);
+        xq = mfma_f64(f[k].y, s_xs[(8 * k + 4 + hi) * XS + lc], xq);
       }
+      if (q >= a.ncb) xq = x0;  // (uniform: blocks beyond the level's outputs)
+      if (q + 1 < T) {
+        asm volatile("" : "+v"(lane_f) : "v"(f[7].y));
+        load_fragments(q + 1);
+      }
+      // ---- Z_q = L_qq^-1 (X_q - sum_{i < q} U_iq^T Z_i) ----
+      double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int i = 0; i <= q; ++i) {
+        const int t = aemr_lt(q, i);
+        if (i < q) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc = mfma_f64(w[t][r], X[i][r], acc);
+        } else {
+          // the diagonal tile holds (L_qq^-1)[hi + 4 r][lc]; as the A operand of slice r it has to be (L_qq^-1)[lc][hi + 4 r]
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s_T[(hi + 4 * r) * XS + lc] = w[t][r];
+        }
+        asm volatile("" : "+v"(lane_w) : "v"(w[t][3]));  // tile t has arrived: request tile t + WIN
+        if (t + WIN < NT) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) w[t + WIN][r] = aemr_ld(Wrs, lane_w, ((t + WIN) * 4 + r) * 512);
+        }
+      }
+      __syncthreads();
+      double vt[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vt[r] = s_T[lc * XS + hi + 4 * r];
+      __syncthreads();
+      const double4_t tq = xq - acc;
+      double4_t z = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) z = mfma_f64(vt[r], tq[r], z);
+      X[q] = z;
+      asm volatile("" ::"v"(z[0]));
+      AEMB_STAMP(2 + q);
+    }
+    __syncthreads();  // (the offsets have been read)
+    // the steps below are elementwise over vectors or sums of squares: ANY order of a vector's entries serves, as long as it is
+    // the same for all of them.  Position 16 q + 4 hi + r holds row 16 q + hi + 4 r: a lane stores its four entries of a block at once.
+    if (k0 + lc < NC) {
+#pragma unroll
+      for (int q = 0; q < T; ++q) *reinterpret_cast<double4_t*>(s_X + (size_t)(k0 + lc) * ZS + 16 * q + 4 * hi) = X[q];
     }
   }
+  __syncthreads();
 
   // ---- the S steps ----
   // (what only the steps use is read here, not at the top: held across the pass above it cost three spilled registers at three waves per SIMD)
@@ -725,19 +822,29 @@ __global__ void __launch_bounds__(64) k_aem_base_steps(const AemBaseArgs a) {
   for (int h = 0; h < NH; ++h) {
     const int o = lane + 64 * h;
     zF[h] = o < MP ? s_X[o] : 0.0;
-    zb[h] = o < MP ? s_X[(size_t)MP + o] : 0.0;
+    zb[h] = o < MP ? s_X[(size_t)ZS + o] : 0.0;
   }
   const double pm = lj ? a.pr_mean[lane] : 0.0, pinv = lj ? a.pr_pinv[lane] : 0.0;
   const double plo = (lj && a.pr_lo) ? a.pr_lo[lane] : -__builtin_inf(), phi = (lj && a.pr_lo) ? a.pr_hi[lane] : __builtin_inf();
   int any = a.anyacc[c];
   int ringidx = (int)(a.ring_pos % a.ring_P);
-  auto wsum = [&](double v) {
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-  };
+  auto wsum = [&](double v) { return sum_rows(aemr_row_sum(v)); };  // (DPP rotations inside a row, permlane swaps across: no LDS round trips)
+  AEMB_STAMP(10);
+  // A step reads nothing from memory when the subchain is one chunk of columns (S <= 14): its scaled increment is still in s_xs, its
+  // uniform in s_u (a step is ~100 instructions; under the pass's traffic a round trip to memory is thousands of cycles, and it was
+  // on every step's path).  Longer subchains request the next step's increment a step ahead.
+  const bool staged = NC <= 16;
+  double inc_next = (!staged && lj && S > 0) ? a.inc[(size_t)c * a.DP + lane] : 0.0;
   for (int s = 0; s < S; ++s) {
-    const double incv = lj ? a.inc[((size_t)s * a.NP + c) * a.DP + lane] : 0.0;
-    const double prp = lj ? keep * th + scal * incv : 0.0;
+    double sinc;
+    if (staged) {
+      sinc = s_xs[lane * XS + s + 2];
+    } else {
+      sinc = scal * inc_next;
+      if (s + 1 < S) inc_next = lj ? a.inc[((size_t)(s + 1) * a.NP + c) * a.DP + lane] : 0.0;
+    }
+    const double u_s = s_u[s];
+    const double prp = lj ? keep * th + sinc : 0.0;
     double pj = 0.0;
     if (lj) {
       const double dv = prp - pm;
@@ -748,7 +855,7 @@ __global__ void __launch_bounds__(64) k_aem_base_steps(const AemBaseArgs a) {
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const int o = lane + 64 * h;
-      zn[h] = o < MP ? (keep * zF[h] + s_X[(size_t)(s + 2) * MP + o]) : 0.0;  // L^-1 (keep F + A s inc): the new L^-1 F if accepted
+      zn[h] = o < MP ? (keep * zF[h] + s_X[(size_t)(s + 2) * ZS + o]) : 0.0;  // L^-1 (keep F + A s inc): the new L^-1 F if accepted
       const double zz = zn[h] + zb[h];
       ssq = fma(zz, zz, ssq);
     }
@@ -758,7 +865,7 @@ __global__ void __launch_bounds__(64) k_aem_base_steps(const AemBaseArgs a) {
     const double post_n = lp_n + ll_n;
     double alpha = a.pcn ? exp(ll_n - ll) : exp(post_n - (lp + ll));
     if (post_n != post_n) alpha = 0.0;
-    const bool acc = a.u0[(size_t)s * a.NP + c] < alpha;
+    const bool acc = u_s < alpha;
     if (acc) {
       lp = lp_n;
       ll = ll_n;
@@ -781,6 +888,7 @@ __global__ void __launch_bounds__(64) k_aem_base_steps(const AemBaseArgs a) {
     }
     ringidx = ringidx + 1 == a.ring_P ? 0 : ringidx + 1;
   }
+  AEMB_STAMP(11);
   if (lane < a.DP) a.theta[c * a.DP + lane] = th;
   if (lane == 0) {
     a.lp[c] = lp;
@@ -788,7 +896,7 @@ __global__ void __launch_bounds__(64) k_aem_base_steps(const AemBaseArgs a) {
     a.anyacc[c] = any;
   }
 }
-// dynamic LDS of k_aem_base_steps: (S + 2 result vectors) MP + CMAX staged parameter vectors of 64
-__host__ __device__ constexpr size_t aem_base_lds_bytes(int S, int MP) { return (size_t)((S + 2) * MP + 8 * 64) * sizeof(double); }
+// dynamic LDS of k_aem_base_steps: S + 2 result vectors of AEMB_ZS(MP), 64 staged parameter rows and one tile of AEMB_XS, S uniforms
+__host__ __device__ constexpr size_t aem_base_lds_bytes(int S, int MP) { return (size_t)((S + 2) * AEMB_ZS(MP) + (64 + 16) * AEMB_XS + ((S + 1) & ~1)) * sizeof(double); }
 
 }  // namespace tda

@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
   // alone would pay them in every step while seven waves wait at the barrier
   int ringidx = (int)(a.ring_pos % a.ring_P);
   const FragSrc fbase = frag_src(a.lv[0].Apk, lane);
-  constexpr bool PAIRS = NW == 4;
+  constexpr bool PAIRS = NW == 4 && DPAD <= 64;  // (128 parameters: two blocks of 16 fragments and the prior in registers would be 256 of them before any state)
   double2 f0[KS / 2], f1[PAIRS ? KS / 2 : 1];
   __syncthreads();
 
@@ -824,13 +824,20 @@ __global__ void __launch_bounds__(MPT) k_aem_action(const AemArgs a) {
   };
   // -1/2 r^T (Sigma_e + Sigma_bias)^-1 r = -1/2 |L^-1 r|^2 from chain c's factor of adaptive level lev (tda_kernels_aemr.h: factor
   // form, 16 x 16 tiles in the MFMA C/D layout) by blocked forward substitution; r given per lane (already bias corrected).
-  auto quad = [&](int lev, double r) {
+  // (the substitution is one wave's dependent chain: wave 0 runs it, a second wave of a 128-output workgroup contributes zero; the first
+  // tiles of the acting level's factor are requested HERE, ahead of the decision's own loads)
+  AemQuadStream<MPT / 16> qs;
+  const bool quad_q = a.q < a.nlev - 1, wave0 = (lane >> 6) == 0;
+  if (quad_q && wave0) aem_quad_request(qs, a.cov_inv[a.q] + (size_t)c * aemr_v_doubles(MPT), lane & 63);
+  auto quad = [&](int lev, double r, bool requested) {
     __syncthreads();
     s_v[MPT + lane] = lo ? r : 0.0;
     __syncthreads();
-    const double* __restrict__ Vc = a.cov_inv[lev] + (size_t)c * aemr_v_doubles(MPT);
-    // (the substitution is one wave's dependent chain: wave 0 runs it, a second wave of a 128-output workgroup contributes zero)
-    double s = (lane >> 6) == 0 ? sum_rows(aem_quad_factor<MPT / 16>(Vc, s_v + MPT, lane & 63)) : 0.0;
+    double s = 0.0;
+    if (wave0) {
+      if (!requested) aem_quad_request(qs, a.cov_inv[lev] + (size_t)c * aemr_v_doubles(MPT), lane & 63);
+      s = sum_rows(aem_quad_factor_stream(qs, s_v + MPT, lane & 63));
+    }
     if constexpr (NW > 1) {
       __syncthreads();
       if ((lane & 63) == 0) s_x[lane >> 6] = s;
@@ -841,7 +848,7 @@ __global__ void __launch_bounds__(MPT) k_aem_action(const AemArgs a) {
   };
   auto loglike_of = [&](int lev, double r0) {  // r0 = F - ytil without bias
     if (lev == nl - 1) return -0.5 * bsum(lo ? r0 * r0 : 0.0) / a.var_finest;
-    return quad(lev, lo ? r0 + a.bias_tot[lev][c * MP + lane] : 0.0);
+    return quad(lev, lo ? r0 + a.bias_tot[lev][c * MP + lane] : 0.0, lev == a.q);
   };
 
   // ---------------- the level-q decision ----------------
@@ -866,7 +873,7 @@ __global__ void __launch_bounds__(MPT) k_aem_action(const AemArgs a) {
     s_v[lane] = xj;  // subchain start = the fine state
     __syncthreads();
     const double rk_x = pre ? resid_pre(3, k) : resid(k);
-    const double ll_b = quad(k, lo ? rk_x + bias_next : 0.0);
+    const double ll_b = quad(k, lo ? rk_x + bias_next : 0.0, false);
     double q_xy = 0.0, q_yx = 0.0;
     if (a.prop_kind == 1) {  // pCN transition densities (proposal.py:364-369) between the fine links
       const double beta = a.scaling[c], kp = sqrt(1.0 - beta * beta);
