@@ -98,7 +98,7 @@ typedef struct tda_config {
   int32_t device;        /* HIP device ordinal */
   int64_t n_chains;      /* chains held by this engine (rows of the state matrix) */
   int64_t chain_offset;  /* global id of local chain 0 */
-  int32_t dim;           /* parameter dimension d: 1..64; 0.5: 65..128 for single-level chains and two-level Delayed Acceptance (n_levels <= 2, no error model)
+  int32_t dim;           /* parameter dimension d: 1..64; 0.5: 65..128 for single-level chains and hierarchies of two to four levels (no error model)
                           * with linear models, isotropic / diagonal noise, a Gaussian prior with a diagonal covariance and TDA_PROP_GRW / TDA_PROP_PCN / TDA_PROP_AM --
                           * anything else at more than 64 parameters is refused by tda_engine_init with TDA_ERR_UNSUPPORTED */
   int32_t n_levels;      /* 1 = MH (sampler.py:213), 2 = Delayed Acceptance (:231), 3..4 = MLDA (:260) */

@@ -1040,6 +1040,13 @@ FIXTURES = {
                                                 iters=24, n_chains=2, seed=822, beta=0.08),
     "g8_mlda_aem_m100": lambda: g8_mlda_aem("g8_mlda_aem_m100", d=5, m=100, sl=(3, 2), iters=10, n_chains=2, seed=823,
                                             prop_var=0.004),
+    # ... and beyond 128 (round 5: k_aem_refresh_big, k_aem_action<256>, k_aem_base_steps<16>): ragged 200 / 160 and the full 256
+    "g8_da_aem_indep_m200": lambda: g8_da_aem("g8_da_aem_indep_m200", "state-independent", d=6, m=200, L=3, iters=14, n_chains=2,
+                                              seed=831, prop_var=0.003),
+    "g8_da_aem_dep_pcn_m256": lambda: g8_da_aem("g8_da_aem_dep_pcn_m256", "state-dependent", proposal_kind="pcn", d=6, m=256, L=1,
+                                                iters=20, n_chains=2, seed=832, beta=0.06),
+    "g8_mlda_aem_m160": lambda: g8_mlda_aem("g8_mlda_aem_m160", d=5, m=160, sl=(3, 2), iters=8, n_chains=2, seed=833,
+                                            prop_var=0.003),
     "g5_mlda_am": lambda: g5_mlda("g5_mlda_am", "am", period=10),
     "g5_mlda_grw_adaptive": lambda: g5_mlda("g5_mlda_grw_adaptive", "grw", adaptive=True, period=7, seed=502),
     "g5_mlda_4level": lambda: g5_mlda("g5_mlda_4level", "am", ms=(6, 10, 16, 24), sl=(3, 2, 2), iters=20, period=10, seed=503),

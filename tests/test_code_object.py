@@ -42,10 +42,13 @@ HOT = {
 #   k_ml_steps<64,4,4,false>   the generic level kernel with four levels in one launch (C5 runs k_da_steps): 3 (round 4: 10 / 7 with three /
 #                              four levels, 46 / 117 before the upper levels' state waited in LDS; round 5: its error-model evaluation
 #                              solves in place in LDS, aem_quad_factor_inplace);
+#   k_ml_steps<128,3|4,4,false> the level kernel at 65 .. 128 parameters with three / four levels (one observation block in flight, no prior
+#                              in registers: with them the TWO-level instance spilled 385)
 #   k_ml_steps<64,*,4,true>    its instances for hierarchies with a dense observation covariance on some level (round 4)
 KNOWN_SPILLERS = {
     "_ZN3tda13k_adapt_splitILi64EEE": 8,  # (TINYDA_ADAPT_SPLIT=1, an A/B switch: the moment recursion on two waves per chain at three waves per SIMD)
     "_ZN3tda10k_ml_stepsILi64ELi4ELi4ELb0EEE": 8,
+    "_ZN3tda10k_ml_stepsILi128ELi3ELi4ELb0EEE": 4, "_ZN3tda10k_ml_stepsILi128ELi4ELi4ELb0EEE": 48,  # (MLDA above 64 parameters, round 5: 2 / 44; the two-level instance spills nothing)
     "_ZN3tda10k_ml_stepsILi64ELi2ELi4ELb1EEE": 24, "_ZN3tda10k_ml_stepsILi64ELi3ELi4ELb1EEE": 64, "_ZN3tda10k_ml_stepsILi64ELi4ELi4ELb1EEE": 104,
 }
 

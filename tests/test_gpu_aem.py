@@ -53,7 +53,8 @@ def _check(outs, g, nl, st_init):
             np.testing.assert_allclose(stats[:, :, 2], (ref_lp + ref_ll).T, rtol=RTOL)
 
 
-@pytest.mark.parametrize("name", ["g8_da_aem_indep", "g8_da_aem_dep", "g8_da_aem_dep_pcn", "g8_da_aem_indep_m72", "g8_da_aem_dep_pcn_m128"])
+@pytest.mark.parametrize("name", ["g8_da_aem_indep", "g8_da_aem_dep", "g8_da_aem_dep_pcn", "g8_da_aem_indep_m72", "g8_da_aem_dep_pcn_m128",
+                                  "g8_da_aem_indep_m200", "g8_da_aem_dep_pcn_m256"])
 def test_da_error_model_replay(eng_mod, golden, name):
     g = golden(name)
     L = int(g["subchain_length"])
@@ -71,7 +72,7 @@ def test_da_error_model_replay(eng_mod, golden, name):
     e.close()
 
 
-@pytest.mark.parametrize("name", ["g8_mlda_aem", "g8_mlda_aem_m100"])
+@pytest.mark.parametrize("name", ["g8_mlda_aem", "g8_mlda_aem_m100", "g8_mlda_aem_m160"])
 def test_mlda_error_model_replay(eng_mod, golden, name):
     g = golden(name)
     nl = int(g["n_levels"])

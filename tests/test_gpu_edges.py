@@ -94,10 +94,8 @@ def test_records_are_optional(eng_mod):
 def test_loud_failures(eng_mod):
     from tinyda_amd import EngineError
 
-    with pytest.raises(EngineError, match="dim=129"):  # (0.5: 128 parameters for single-level chains)
+    with pytest.raises(EngineError, match="dim=129"):  # (0.5: 128 parameters; hierarchies above 64: tests/test_gpu_wide.py)
         eng_mod.Engine(4, 129)
-    with pytest.raises(EngineError, match="more than 64 parameters are lowered for single-level chains"):
-        eng_mod.Engine(4, 65, n_levels=3)  # (two levels are lowered: tests/test_gpu_wide.py)
     with pytest.raises(EngineError, match="n_levels"):
         eng_mod.Engine(4, 3, n_levels=5)
     e = eng_mod.Engine(4, 3)

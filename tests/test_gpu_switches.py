@@ -90,7 +90,7 @@ def test_fused_swap_and_increments_equal_the_two_launches(what, tmp_path):
         assert np.array_equal(blk[k], spl[k]), "k_adapt_split changed %s" % k
 
 
-@pytest.mark.parametrize("what", ["aem_dense", "aem_dense_ragged", "aem_dense_da_pcn"])
+@pytest.mark.parametrize("what", ["aem_dense", "aem_dense_ragged", "aem_dense_da_pcn", "aem_dense_m200", "aem_dense_m200_ragged", "aem_dense_chunks"])
 def test_error_model_base_subchain_kernels_agree(what, tmp_path):
     """dense error model over linear levels: the base subchain on k_aem_base_steps (one pass over each chain's factor V per launch,
     linear update of V r) against k_ml_steps (TINYDA_AEM_BASE=0: -1/2 |V r'|^2 evaluated per step): same decisions, log-densities
@@ -125,7 +125,7 @@ def test_window_of_draws_is_bitwise_the_per_block_draws(what, tmp_path):
     assert 0.02 < a["acc0"].mean() < 0.98
 
 
-@pytest.mark.parametrize("what", ["aem_dense", "aem_dense_ragged", "aem_dense_da_pcn"])
+@pytest.mark.parametrize("what", ["aem_dense", "aem_dense_ragged", "aem_dense_da_pcn", "aem_dense_m200"])
 def test_error_model_outputs_on_the_matrix_cores_agree(what, tmp_path):
     """dense error model over linear levels: the model outputs k_aem_action needs for all chains from one k_linear_outputs_multi launch
     (an operator fragment serves a 16-chain tile) against three matrix-vector products per chain inside the kernel

@@ -87,7 +87,8 @@ def test_wide_single_level_against_the_oracle(case):
 
 def test_sample_runs_100_parameters_on_the_device():
     """tda.sample() at 100 parameters returns "backend": "hip" (0.4: the host protocol, with a HostFallbackWarning) and a chain that has
-    moved towards the data; a hierarchy at 100 parameters still falls back, announced"""
+    moved towards the data; Delayed Acceptance and three-level MLDA at 100 parameters run there too; an error model above 64 parameters
+    still falls back, announced"""
     import warnings
 
     import scipy.stats as stats
@@ -114,21 +115,28 @@ def test_sample_runs_100_parameters_on_the_device():
     da = tda.sample([coarse, post], tda.CrankNicolson(scaling=0.02), 40, n_chains=8, subchain_length=3, seed=3)  # Delayed Acceptance at 100 parameters
     assert da["backend"] == "hip" and da["sampler"] == "DA" and len(da["chain_fine_0"]) == 41
     mid = tda.Posterior(post.prior, tda.GaussianLogLike(y[:120], 0.0025 * np.eye(120)), tda.LinearModel(A[:120]))
-    with pytest.warns(tda.HostFallbackWarning, match="more than 64 parameters are lowered for single-level chains and two-level"):
-        tda.sample([coarse, mid, post], tda.CrankNicolson(scaling=0.05), 2, n_chains=1, subchain_length=[2, 2])
+    ml = tda.sample([coarse, mid, post], tda.CrankNicolson(scaling=0.02), 12, n_chains=8, subchain_length=[2, 2], seed=4)  # three-level MLDA
+    assert ml["backend"] == "hip" and ml["sampler"] == "MLDA"
+    acoarse = tda.Posterior(post.prior, tda.AdaptiveGaussianLogLike(y[:50], 0.0025 * np.eye(50)), tda.LinearModel(0.9 * A[:50]))  # (an error model: same outputs on both levels)
+    with pytest.warns(tda.HostFallbackWarning, match="more than 64 parameters are lowered for single-level chains, Delayed Acceptance and MLDA"):
+        tda.sample([acoarse, coarse], tda.CrankNicolson(scaling=0.05), 2, n_chains=1, subchain_length=2, adaptive_error_model="state-independent")
 
 
-DA_CASES = [(96, (24, 70), 3, 17, 12, "pcn"), (128, (33, 130), 4, 16, 9, "am"), (80, (16, 40), 2, 20, 15, "grw_adaptive"), (100, (20, 65), 3, 18, 10, "pcn_random")]
+DA_CASES = [(96, (24, 70), 3, 17, 12, "pcn"), (128, (33, 130), 4, 16, 9, "am"), (80, (16, 40), 2, 20, 15, "grw_adaptive"), (100, (20, 65), 3, 18, 10, "pcn_random"),
+            (112, (20, 48, 150), (3, 2), 16, 8, "am"), (128, (16, 40, 90, 200), (3, 2, 2), 16, 5, "pcn"), (72, (12, 30, 64), (4, 3), 18, 6, "grw_adaptive")]
 
 
-@pytest.mark.parametrize("case", DA_CASES, ids=["%d-%s" % (c[0], c[5]) for c in DA_CASES])
+@pytest.mark.parametrize("case", DA_CASES, ids=["%d-%dlev-%s" % (c[0], len(c[1]), c[5]) for c in DA_CASES])
 def test_wide_delayed_acceptance_against_the_oracle(case):
-    """two-level Delayed Acceptance at 80 .. 128 parameters (generic level kernel k_ml_steps<128, 2> + the wide proposal / adaptation
-    launches) on the engine's own Philox stream against the oracle: accept masks of both levels exact, log-posteriors to 1e-10"""
+    """Delayed Acceptance and three- / four-level MLDA at 72 .. 128 parameters (generic level kernel k_ml_steps<128, 2..4> + the wide
+    proposal / adaptation launches) on the engine's own Philox stream against the oracle: accept masks of every level exact,
+    log-posteriors to 1e-10"""
     from tests.test_gpu_multilevel import _oracle_uniforms
     from tinyda_amd.engine import Engine
 
     d, ms, L, N, n_fine, kind = case
+    sl = list(L) if isinstance(L, tuple) else [L]
+    nl = len(ms)
     rng = np.random.default_rng(7000 + d)
     truth = 0.5 * rng.standard_normal(d)
     As = [rng.standard_normal((m, d)) / np.sqrt(d) for m in ms]
@@ -144,9 +152,9 @@ def test_wide_delayed_acceptance_against_the_oracle(case):
     else:
         prop = dict(kind="am", C0=C0, t0=period, period=period, adaptive=False)
     seed = 900 + d
-    e = Engine(N, d, seed=seed, n_levels=2)
+    e = Engine(N, d, seed=seed, n_levels=nl)
     e.set_prior(np.zeros(d), np.eye(d))
-    for k in range(2):
+    for k in range(nl):
         e.set_level(k, As[k], ys[k], 0, 0.01)
     if prop["kind"] == "pcn":
         e.set_proposal(1, None, scaling=prop["scaling"], adaptive=True, gamma=prop["gamma"], period=period)
@@ -154,19 +162,19 @@ def test_wide_delayed_acceptance_against_the_oracle(case):
         e.set_proposal(0, C0, scaling=0.9, adaptive=True, gamma=1.02, period=period)
     else:
         e.set_proposal(2, C0, t0=period, period=period, adaptive=False)
-    e.set_subchains([L], randomize)
+    e.set_subchains(sl, randomize)
     e.init(theta0)
     rows = e.rows_per_level(n_fine)
     z, _ = e.set_export(rows[0])
     outs = e.run_levels_host(n_fine)
     e.close()
-    us, ridx = _oracle_uniforms(seed, N, rows, [L], L if randomize else None)
+    us, ridx = _oracle_uniforms(seed, N, rows, sl, sl[0] if randomize else None)
     prior = orc.MVNPrior(np.zeros(d), np.eye(d))
-    levels = [orc.LinearGaussianLevel(As[k], ys[k], "iso", 0.01, prior) for k in range(2)]
-    res, _ = orc.run_multilevel(levels, prop, [L], theta0, np.swapaxes(z, 0, 1), us, n_fine, ridx)
-    for k in range(2):
+    levels = [orc.LinearGaussianLevel(As[k], ys[k], "iso", 0.01, prior) for k in range(nl)]
+    res, _ = orc.run_multilevel(levels, prop, sl, theta0, np.swapaxes(z, 0, 1), us, n_fine, ridx)
+    for k in range(nl):
         ref = res[k]
-        sk = slice(1, None) if k == 1 else slice(None)
+        sk = slice(1, None) if k == nl - 1 else slice(None)
         assert np.array_equal(outs[k][2], ref["accepted"][:, sk].T), "level %d accept masks differ" % k
         np.testing.assert_allclose(outs[k][1][:, :, 2], ref["logpost"][:, sk].T, rtol=1e-9 if kind == "am" else 1e-10)
     assert 0.0 < outs[0][2].mean() < 1.0

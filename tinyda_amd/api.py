@@ -24,8 +24,9 @@ _DEVICE_PROPOSALS = (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis, DREA
 
 
 MAX_LEVELS = 4
-MAX_PARAMETERS = 128  # (more than 64: single-level chains and two-level Delayed Acceptance, see _device_plan)
-MAX_AEM_OUTPUTS = 128
+MAX_PARAMETERS = 128  # (more than 64: no error models, see _device_plan)
+MAX_AEM_OUTPUTS = 256  # dense error model (0.5: 129 .. 256 on k_aem_refresh_big); hierarchies sequenced by the host: MAX_AEM_OUTPUTS_HOST_SEQUENCED
+MAX_AEM_OUTPUTS_HOST_SEQUENCED = 128
 
 
 class HostFallbackWarning(UserWarning):
@@ -53,15 +54,15 @@ def _device_plan(posteriors, proposal, diagonal_error_model=False, error_model=N
         if low is None or low["prior_mean"].shape[0] > MAX_PARAMETERS:
             return _no("a posterior the engine cannot lower (an opaque Python model, a prior other than scipy's multivariate normal / JointPrior of norm and uniform, a likelihood outside GaussianLogLike's classes)" if low is None else "more than %d parameters" % MAX_PARAMETERS)
         if low["prior_mean"].shape[0] > 64:
-            # 65 .. 128 parameters (0.5, tda_kernels_wide.h): single-level chains and two-level Delayed Acceptance, linear models with isotropic / diagonal noise, a Gaussian
+            # 65 .. 128 parameters (0.5, tda_kernels_wide.h): single-level chains, Delayed Acceptance and MLDA (up to four levels), linear models with isotropic / diagonal noise, a Gaussian
             # prior with a diagonal covariance, GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis
             pc = np.asarray(low["prior_cov"])
-            if (len(posteriors) > 2 or (len(posteriors) == 2 and error_model is not None)
+            if ((len(posteriors) >= 2 and error_model is not None)
                     or type(proposal) not in (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis) or low.get("A") is None
                     or getattr(proposal, "block_moments", False)
                     or any(k in low for k in ("source", "batched", "rosenbrock", "prior_joint"))
                     or low["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG) or np.count_nonzero(pc - np.diag(np.diag(pc)))):
-                return _no("more than 64 parameters are lowered for single-level chains and two-level Delayed Acceptance only: linear models with "
+                return _no("more than 64 parameters are lowered for single-level chains, Delayed Acceptance and MLDA of linear models with "
                            "isotropic / diagonal noise, a Gaussian prior with a diagonal covariance, GaussianRandomWalk / CrankNicolson / "
                            "AdaptiveMetropolis, no error model")
         if diagonal_error_model and low["noise_kind"] == _lib.NOISE_ADAPTIVE:
@@ -93,6 +94,9 @@ def _device_plan(posteriors, proposal, diagonal_error_model=False, error_model=N
             return _no("dense error model: the finest level must have an isotropic likelihood on the device (and no level a dense observation covariance)")
         if any(lw["noise_kind"] != _lib.NOISE_ADAPTIVE for lw in lows[:-1]):
             return _no("dense error model: every level below the finest needs an AdaptiveGaussianLogLike")
+    if error_model is not None and not diagonal_error_model and len(lows) > 1 and np.asarray(lows[0]["data"]).shape[0] > MAX_AEM_OUTPUTS_HOST_SEQUENCED and (
+            isinstance(proposal, DREAMZ) or any("source" in lw or "batched" in lw for lw in lows)):
+        return _no("dense error model with more than %d outputs: hierarchies of linear levels under GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis" % MAX_AEM_OUTPUTS_HOST_SEQUENCED)
     if isinstance(proposal, DREAMZ) and len(posteriors) != 1 and proposal._shared:
         return _no("DREAM's shared archive is single-level on the device (below a hierarchy: DREAMZ's per-chain archives)")
     if any("rosenbrock" in low for low in lows) and not isinstance(proposal, DREAMZ):

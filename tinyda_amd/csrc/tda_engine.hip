@@ -281,7 +281,7 @@ struct Level {
   DevBuf<double> A_rm, ytil64, data64, cov64;  // error-model copies, row stride em_ld (cov64: Sigma_e as upper tiles, tda_kernels_aemr.h)
   DevBuf<double> Pd;                           // callback / source-defined level with dense noise: Sigma^-1 [m][m]
   DevBuf<double> A_dev, b_dev;                 // hierarchies: row-major [m][d] and offset [m] for k_ext_linear_eval (host-sequenced mode)
-  int em_ld = 0;                               // 64 (m <= 64) or 128 (m <= 128); 0: level too large for an error model
+  int em_ld = 0;                               // 64 (m <= 64), 128 (m <= 128) or 256 (m <= 256); 0: level too large for an error model
 };
 
 struct TimedLaunch {
@@ -656,12 +656,16 @@ void launch_chol_apply<128>(const CholArgs& a, const ApplyArgs& ap, hipStream_t 
   launch_apply<128>(ap, st);
 }
 
-// k_aem_refresh<T, NSUM> for the engine's row stride (64 / 128 -> 4 / 8 tile rows) and the number of trackers summed
+// k_aem_refresh<T, NSUM> for the engine's row stride (64 / 128 -> 4 / 8 tile rows; 256: k_aem_refresh_big<16, NSUM>) and the number of trackers summed
 static int launch_aem_refresh(const tda::AemRefreshArgs& ra, hipStream_t st) {
   using namespace tda;
   const dim3 g((unsigned)ra.N), b(64);
 #define TDA_AEMR(TT, NS) hipLaunchKernelGGL((k_aem_refresh<TT, NS>), g, b, 0, st, ra)
-  if (ra.MP == 64) {
+  if (ra.MP == 256) {  // 129 .. 256 outputs: the factorisation with the chain's factor buffer as its workspace
+    if (ra.nsum == 1) hipLaunchKernelGGL((k_aem_refresh_big<16, 1>), g, b, 0, st, ra);
+    else if (ra.nsum == 2) hipLaunchKernelGGL((k_aem_refresh_big<16, 2>), g, b, 0, st, ra);
+    else hipLaunchKernelGGL((k_aem_refresh_big<16, 3>), g, b, 0, st, ra);
+  } else if (ra.MP == 64) {
     if (ra.nsum == 1) TDA_AEMR(4, 1); else if (ra.nsum == 2) TDA_AEMR(4, 2); else TDA_AEMR(4, 3);
   } else {
     if (ra.nsum == 1) TDA_AEMR(8, 1); else if (ra.nsum == 2) TDA_AEMR(8, 2); else TDA_AEMR(8, 3);
@@ -774,19 +778,27 @@ int launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st, int* f
     default: return go(&k_ml_steps<DPAD, 4>);
   }
 }
-// 65 .. 128 parameters: Delayed Acceptance (two levels) on the generic level kernel, one 512-register wave per SIMD (tda_engine_init
-// refuses everything else above 64 parameters in a hierarchy)
+// 65 .. 128 parameters: Delayed Acceptance and MLDA on the generic level kernel, one 512-register wave per SIMD, ONE observation
+// block in flight per wave (k_ml_steps: paired blocks and the prior in registers are 256 registers at this width -- with them the
+// two-level instance spilled 385; without, two levels spill nothing, three 2 registers, four 44).  tda_engine_init refuses error
+// models and everything but linear levels above 64 parameters.
 template <>
 int launch_ml<128>(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st, int* free_regs, bool) {
-  auto kern = &k_ml_steps<128, 2>;
   if (free_regs) {
     *free_regs = 0;  // (no room for the generator beside it)
     return TDA_OK;
   }
-  if (a.nlev != 2) return fail(TDA_ERR_UNSUPPORTED, "more than 64 parameters: two-level hierarchies only");
-  if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, st, a);
-  return TDA_OK;
+  auto go = [&](auto kern) -> int {
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, st, a);
+    return TDA_OK;
+  };
+  switch (a.nlev) {
+    case 2: return go(&k_ml_steps<128, 2>);
+    case 3: return go(&k_ml_steps<128, 3>);
+    case 4: return go(&k_ml_steps<128, 4>);
+    default: return fail(TDA_ERR_UNSUPPORTED, "more than 64 parameters: hierarchies of two to four levels");
+  }
 }
 
 template <int DPAD>
@@ -941,7 +953,8 @@ void fill_ext_args(tda_engine* e, const Level& lv, ExtArgs& xa) {
 // AdaptiveGaussianLogLike on a callback / source-defined level: host and device copies of Sigma_e and the data vector in
 // the error-model layout (row stride 64 / 128), as tda_engine_set_level keeps them for linear levels
 int ext_level_adaptive(tda_engine* /*e*/, Level& lv, int m, const double* data, const double* cov) {
-  if (m > AEM_MP_MAX) return fail(TDA_ERR_UNSUPPORTED, "AdaptiveGaussianLogLike on the device is limited to m <= %d observations", (int)AEM_MP_MAX);
+  if (m > AEM_MP_MAX_EXT)
+    return fail(TDA_ERR_UNSUPPORTED, "AdaptiveGaussianLogLike on a callback / source-defined level is limited to m <= %d observations", (int)AEM_MP_MAX_EXT);
   std::vector<double> Lc;
   if (!cholesky_host(cov, m, Lc)) return fail(TDA_ERR_NUMERIC, "noise covariance is not positive definite");
   const int MP = m <= 64 ? 64 : 128;
@@ -1165,8 +1178,6 @@ int tda_engine_create(const tda_config* cfg, tda_engine** out) {
   if (cfg->struct_size != sizeof(tda_config)) return fail(TDA_ERR_INVALID, "tda_config.struct_size mismatch");
   if (cfg->dim < 1 || cfg->dim > 128)
     return fail(TDA_ERR_UNSUPPORTED, "dim=%d outside the device engine's range 1..128", cfg->dim);
-  if (cfg->dim > 64 && cfg->n_levels > 2)
-    return fail(TDA_ERR_UNSUPPORTED, "dim=%d: more than 64 parameters are lowered for single-level chains and two-level Delayed Acceptance", cfg->dim);
   if (cfg->n_chains < 1) return fail(TDA_ERR_INVALID, "n_chains must be >= 1");
   if (cfg->n_levels < 1 || cfg->n_levels > MAXLEV)
     return fail(TDA_ERR_UNSUPPORTED, "n_levels=%d outside 1..%d", cfg->n_levels, (int)MAXLEV);

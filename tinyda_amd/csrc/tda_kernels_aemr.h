@@ -616,6 +616,196 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AEMR_WA
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_aem_refresh for widths beyond the register-resident kernel (T = 16: 129 .. 256 outputs, 136 tiles = 272 KB per chain and matrix --
+// the left-looking live set of the kernel above would be 72 tiles).  Same contract, same arithmetic in the same order (at T = 8 the
+// two kernels write the same bits: tests/test_gpu_aem.py), ONE WAVE PER CHAIN, run-time loops, and the chain's factor buffer itself
+// as the workspace: a finished tile is stored at once and read back (past L1: glc) by the rows below,
+//     C(q, i) = Sigma(q, i) - sum_{p < q} U_pq^T U_pi,   U_qq^-1 by aemr_diag,   U_qi = (L_qq)^-1 C(q, i),
+// one tile of the block row at a time.  2 T (T + 1)(T + 2) / 3 matrix instructions per chain (3 264 at T = 16) and, per tile update,
+// two 2 KB tile reads from L2 / HBM: the launch is bound by that traffic (~ 2.7 MB per chain), not by the matrix cores -- ~ 10 x the
+// 128-output launch for 8 x its flops.  (Not built: the current block column U_pq parked in LDS, which would halve the reads.)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double aemr_ld_l2(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {  // glc: served by L2, never by a stale L1 line
+  const aemr_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 1);
+  return __hiloint2double((int)v.y, (int)v.x);
+}
+template <int T, int NSUM>
+__global__ void __launch_bounds__(64) k_aem_refresh_big(const AemRefreshArgs a) {
+  constexpr int NT = aemr_tiles(T), MP = 16 * T, NH = (MP + 63) / 64;
+  __shared__ __attribute__((aligned(16))) double s_r[MP];
+  __shared__ __attribute__((aligned(16))) double s_z[MP];  // update_link: solved blocks, position 16 q + 4 hi + r holds z[16 q + hi + 4 r]
+  __shared__ double s_u[3 * MP];                           // vectors of the tracker update: x (dm), mu, mu'
+  const int lane = threadIdx.x, lc = lane & 15, hi = lane >> 4;
+  const int64_t c = blockIdx.x;
+  if (c >= a.N) return;
+  const bool want_ll = a.rvec != nullptr;
+  double* __restrict__ Vc = a.V + (size_t)c * NT * 256;
+  const __amdgpu_buffer_rsrc_t Vrs = aemr_rsrc(Vc);
+  const size_t cbase = (size_t)c * NT * 256;
+  const __amdgpu_buffer_rsrc_t sg0 = aemr_rsrc(a.sig[0] + cbase);
+  const __amdgpu_buffer_rsrc_t sg1 = aemr_rsrc(NSUM > 1 ? a.sig[1] + cbase : a.sig[0] + cbase);
+  const __amdgpu_buffer_rsrc_t sg2 = aemr_rsrc(NSUM > 2 ? a.sig[2] + cbase : a.sig[0] + cbase);
+  const __amdgpu_buffer_rsrc_t sge = aemr_rsrc(a.cov);
+  const bool upd = a.upd != nullptr;
+  const double tt = (double)a.b_t, t1 = tt + 1.0, ca = upd ? (tt - 1.0) / tt : 1.0, cb = upd ? 1.0 / tt : 0.0;
+  auto updated = [&](double old, double xr, double mr, double pr, double xc, double mc, double pc) {
+    const double M = (tt * (mr * mc) - t1 * (pr * pc)) + xr * xc;
+    return ca * old + cb * M;
+  };
+  const int lane8 = lane * 8;
+  // ---- vectors, the diagonal's verdict on the 1e-9 rule (as in k_aem_refresh) ----
+  bool big = false;
+  {
+    const double* __restrict__ rsrc = want_ll ? a.rvec + c * MP : a.cov;
+    const double* __restrict__ usrc = upd ? a.upd + (size_t)c * 3 * MP : a.cov;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const int i = lane + 64 * h;
+      const int o = (int)aemr_u_offset(MP, i, i) * 8;
+      const double rv = rsrc[i], x = upd ? usrc[i] : 0.0, mo = upd ? usrc[MP + i] : 0.0, mn = upd ? usrc[2 * MP + i] : 0.0;
+      s_r[i] = rv;
+      s_u[i] = x;
+      s_u[MP + i] = mo;
+      s_u[2 * MP + i] = mn;
+      double sb = 0.0 + updated(aemr_ld(sg0, o, 0), x, mo, mn, x, mo, mn);
+      if constexpr (NSUM > 1) sb += aemr_ld(sg1, o, 0);
+      if constexpr (NSUM > 2) sb += aemr_ld(sg2, o, 0);
+      big = big || !(sb < 1e-9);
+    }
+  }
+  __syncthreads();
+  if (__builtin_amdgcn_ballot_w64(big) == 0) {
+    for (int t = 0; t < NT; ++t) {  // (padding entries are zero)
+      int p = 0, rem = t;
+      while (rem >= T - p) { rem -= T - p; ++p; }
+      const int i = p + rem;
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * p + hi + 4 * r, col = 16 * i + lc, o = ((t * 4 + r) * 64 + lane) * 8;
+        double sb = 0.0 + updated(aemr_ld(sg0, o, 0), s_u[row], s_u[MP + row], s_u[2 * MP + row], s_u[col], s_u[MP + col], s_u[2 * MP + col]);
+        if constexpr (NSUM > 1) sb += aemr_ld(sg1, o, 0);
+        if constexpr (NSUM > 2) sb += aemr_ld(sg2, o, 0);
+        big = big || !(sb < 1e-9);
+      }
+    }
+  }
+  double llk = 0.0;
+  if (__builtin_amdgcn_ballot_w64(big) == 0) {
+    // set_bias keeps the previous inverse; update_link still runs under the new bias.  The tracker itself is still updated.
+    if (upd) {
+      double* __restrict__ S0 = a.sig[0] + cbase;
+      for (int t = 0; t < NT; ++t) {
+        int p = 0, rem = t;
+        while (rem >= T - p) { rem -= T - p; ++p; }
+        const int i = p + rem;
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * p + hi + 4 * r, col = 16 * i + lc;
+          const size_t o = (size_t)(t * 4 + r) * 64 + lane;
+          S0[o] = updated(S0[o], s_u[row], s_u[MP + row], s_u[2 * MP + row], s_u[col], s_u[MP + col], s_u[2 * MP + col]);
+        }
+      }
+    }
+    llk = aem_quad_factor_inplace<T>(Vc, s_r, lane, T);
+  } else {
+    double sq = 0.0;
+    // the sum's tile (q, i), i >= q: the tracker update on every element of sig[0] on its way in, stored back
+    auto sum_tile = [&](int q, int i) {
+      const int so = aemr_ut(T, q, i) * 2048;
+      const double xc = s_u[16 * i + lc], mc = s_u[MP + 16 * i + lc], pc = s_u[2 * MP + 16 * i + lc];
+      double4_t C;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * q + hi + 4 * r;
+        const double s0 = updated(aemr_ld(sg0, lane8, so + r * 512), s_u[row], s_u[MP + row], s_u[2 * MP + row], xc, mc, pc);
+        aemr_st(s0, sg0, lane8, so + r * 512);
+        double sb = 0.0 + s0;
+        if constexpr (NSUM > 1) sb += aemr_ld(sg1, lane8, so + r * 512);
+        if constexpr (NSUM > 2) sb += aemr_ld(sg2, lane8, so + r * 512);
+        C[r] = aemr_ld(sge, lane8, so + r * 512) + sb;
+      }
+      return C;
+    };
+    for (int q = 0; q < T; ++q) {
+      // the rows above have left the wave before this row reads them back (its reads are glc: L2 is where they meet; no cache
+      // maintenance needed, which an agent-scope fence would add 16 times per chain)
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      // ---- the diagonal tile; update_link's partial sums ride on the same tile reads ----
+      double4_t C = sum_tile(q, q);
+      double fsum = 0.0;
+#pragma unroll 2
+      for (int p = 0; p < q; ++p) {
+        const int so = aemr_lt(q, p) * 2048;
+        double u[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[r] = aemr_ld_l2(Vrs, lane8, so + r * 512);
+        const double4_t zp = *reinterpret_cast<const double4_t*>(s_z + 16 * p + 4 * hi);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          C = mfma_f64(-u[r], u[r], C);
+          fsum = fma(u[r], zp[r], fsum);
+        }
+      }
+      double Cd[4], Vd[4], Vt[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cd[r] = C[r];
+      aemr_diag(Cd, Vd, Vt, lc, hi);
+      const double tq = s_r[16 * q + lc] - sum_rows(fsum);
+      double4_t zq;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        aemr_st(Vd[r], Vrs, lane8, (aemr_lt(q, q) * 4 + r) * 512);
+        zq[r] = aemr_row_sum(Vd[r] * tq);
+        sq = fma(zq[r], zq[r], sq);
+      }
+      if (lc == 0) *reinterpret_cast<double4_t*>(s_z + 16 * q + 4 * hi) = zq;
+      __builtin_amdgcn_wave_barrier();
+      // ---- the rest of block row q: U_qi = (L_qq)^-1 (Sigma(q, i) - sum_{p < q} U_pq^T U_pi) ----
+      // (two tiles of the row at a time: one read of U_pq serves both, and their matrix instructions alternate between two accumulators)
+      for (int i = q + 1; i < T; i += 2) {
+        const bool two = i + 1 < T;  // (uniform)
+        const int i1 = two ? i + 1 : i;
+        double4_t C0 = sum_tile(q, i), C1 = C0;
+        if (two) C1 = sum_tile(q, i1);
+#pragma unroll 2
+        for (int p = 0; p < q; ++p) {
+          const int sq_ = aemr_lt(q, p) * 2048, s0 = aemr_lt(i, p) * 2048, s1 = aemr_lt(i1, p) * 2048;
+          double uq[4], u0[4], u1[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            uq[r] = aemr_ld_l2(Vrs, lane8, sq_ + r * 512);
+            u0[r] = aemr_ld_l2(Vrs, lane8, s0 + r * 512);
+            u1[r] = aemr_ld_l2(Vrs, lane8, s1 + r * 512);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            C0 = mfma_f64(-uq[r], u0[r], C0);
+            C1 = mfma_f64(-uq[r], u1[r], C1);
+          }
+        }
+        double4_t U0 = {0.0, 0.0, 0.0, 0.0}, U1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+          U0 = mfma_f64(Vt[kc], C0[kc], U0);
+          U1 = mfma_f64(Vt[kc], C1[kc], U1);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) aemr_st(U0[r], Vrs, lane8, (aemr_lt(i, q) * 4 + r) * 512);
+        if (two) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) aemr_st(U1[r], Vrs, lane8, (aemr_lt(i1, q) * 4 + r) * 512);
+        }
+      }
+    }
+    llk = -0.5 * sum_rows(sq);
+  }
+  if (want_ll && lane == 0) {
+    a.ll[(size_t)a.k * a.NP + c] = llk;
+    const int64_t idk = a.sid[(size_t)a.k * a.NP + c];
+    for (int q2 = a.k + 1; q2 < a.nlev; ++q2)
+      if (a.sid[(size_t)q2 * a.NP + c] == idk) a.Sst[((size_t)(q2 * (q2 - 1) / 2 + a.k) * 2 + 1) * a.NP + c] = llk;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The base level of a host-sequenced hierarchy under the dense error model: one subchain of S Metropolis-Hastings steps per
 // launch (chain.py:96-129 inside MLDAChain / DAChain; AdaptiveGaussianLogLike.loglike, distributions.py:404-425), ONE WAVE PER
 // CHAIN.  k_ml_steps evaluates -1/2 |L^-1 r'|^2 per step and chain from that chain's 72 KB factor: S passes over it per launch,
@@ -670,7 +860,7 @@ struct AemBaseArgs {
 };
 
 template <int T>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_aem_base_steps(const AemBaseArgs a) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T <= 8 ? 2 : 1, T <= 8 ? 2 : 1))) k_aem_base_steps(const AemBaseArgs a) {
   constexpr int MP = 16 * T, NH = MP / 64 > 0 ? MP / 64 : 1;  // observations per lane (the steps)
   constexpr int ZS = AEMB_ZS(MP), XS = AEMB_XS;               // strides of a result vector / of a staged parameter row in LDS
   extern __shared__ __attribute__((aligned(16))) double aemb_smem[];

@@ -26,7 +26,8 @@ namespace tda {
 // (chain.py:363,389,397; proposal.py:1486), kept as a ring of the last `period` entries.
 // ------------------------------------------------------------------------------------------------
 constexpr int MAXLEV = 4;
-constexpr int AEM_MP_MAX = 128;  // error-model output dimension limit; per-chain vectors / matrices in HBM have row stride 64 or 128
+constexpr int AEM_MP_MAX = 256;  // error-model output dimension limit; per-chain vectors / matrices in HBM have row stride 64, 128 or 256
+constexpr int AEM_MP_MAX_EXT = 128;  // ... of hierarchies sequenced by the host (callback / source-defined levels, DREAM(Z) below a hierarchy)
 enum : uint32_t { STREAM_INDEX = 3 };
 
 struct MLArgs {
@@ -310,22 +311,23 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
         lp_n = -0.5 * (a.pr.logconst + maha);
         return;
       }
-      for (int cc = wave; cc < 16; cc += NW) {  // lane = observation (and observation + 64 beyond 64 outputs)
+      for (int cc = wave; cc < 16; cc += NW) {  // lane = observation (and observation + 64, + 128, + 192 beyond 64 outputs)
         const int64_t gc = tile * 16 + cc;
         double* rrow = s_R + cc * RSa;
-        const bool l0 = lane < MP, l1 = lane + 64 < MP;
-        double rb0 = 0.0, rb1 = 0.0;
-        if (l0) rb0 = rrow[lane] + a.aem_bias[gc * LD + lane];
-        if (l1) rb1 = rrow[lane + 64] + a.aem_bias[gc * LD + lane + 64];
+        double rb[AEM_MP_MAX / 64];
+#pragma unroll
+        for (int h = 0; h < AEM_MP_MAX / 64; ++h) rb[h] = lane + 64 * h < MP ? rrow[lane + 64 * h] + a.aem_bias[gc * LD + lane + 64 * h] : 0.0;
         __builtin_amdgcn_wave_barrier();
-        if (l0) rrow[lane] = rb0;
-        if (l1) rrow[lane + 64] = rb1;
+#pragma unroll
+        for (int h = 0; h < AEM_MP_MAX / 64; ++h)
+          if (lane + 64 * h < MP) rrow[lane + 64 * h] = rb[h];
         __builtin_amdgcn_wave_barrier();
         // -1/2 |V r|^2 from the chain's lower tiles of V = L^-1 (72 KB per chain at 128 outputs, 512-byte rows; the rows of
         // blocks beyond the outputs are identity and r is not defined there: only the block rows of the outputs are read)
         double qv;
         if (LD <= 64) qv = aem_quad_factor_inplace<4>(a.aem_P + (size_t)gc * aemr_v_doubles(64), rrow, lane, MP >> 4);
-        else qv = aem_quad_factor_inplace<8>(a.aem_P + (size_t)gc * aemr_v_doubles(128), rrow, lane, MP >> 4);
+        else if (LD <= 128) qv = aem_quad_factor_inplace<8>(a.aem_P + (size_t)gc * aemr_v_doubles(128), rrow, lane, MP >> 4);
+        else qv = aem_quad_factor_inplace<16>(a.aem_P + (size_t)gc * aemr_v_doubles(256), rrow, lane, MP >> 4);
         if (lane == 0) s_R[16 * RSa + cc] = qv;
       }
       if (prior_dense && lane < 16) {}  // (s_redp already written above)
@@ -788,7 +790,8 @@ struct AemArgs {
 
 template <int MPT>
 __global__ void __launch_bounds__(MPT) k_aem_action(const AemArgs a) {
-  constexpr int NW = MPT / 64;  // thread = observation: one wave up to 64 outputs, two up to 128
+  constexpr int NW = MPT / 64;  // thread = observation: one wave up to 64 outputs, two up to 128, four up to 256
+  static_assert(NW == 1 || NW == 2 || NW == 4, "k_aem_action: 64, 128 or 256 outputs");
   __shared__ double s_v[4 * MPT];
   __shared__ double s_x[8];  // exchange slots between the waves
   const int lane = threadIdx.x;
@@ -804,6 +807,7 @@ __global__ void __launch_bounds__(MPT) k_aem_action(const AemArgs a) {
       if ((lane & 63) == 0) s_x[lane >> 6] = v;
       __syncthreads();
       v = s_x[0] + s_x[1];
+      if constexpr (NW == 4) v += s_x[2] + s_x[3];
     }
     return v;
   };
@@ -843,6 +847,7 @@ __global__ void __launch_bounds__(MPT) k_aem_action(const AemArgs a) {
       if ((lane & 63) == 0) s_x[lane >> 6] = s;
       __syncthreads();
       s = s_x[0] + s_x[1];
+      if constexpr (NW == 4) s += s_x[2] + s_x[3];
     }
     return -0.5 * s;
   };

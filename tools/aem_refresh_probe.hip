@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <random>
 #include <vector>
+#include <string>
 #include "tinyda_amd.h"
 #include "tda_kernels_aemr.h"
 using namespace tda;
@@ -20,8 +21,16 @@ static void launch(const AemRefreshArgs& a) {
   else hipLaunchKernelGGL((k_aem_refresh<T, 3>), dim3((unsigned)a.N), dim3(64), 0, 0, a);
 }
 
+template <int T>
+static void launch_big(const AemRefreshArgs& a) {
+  if (a.nsum == 1) hipLaunchKernelGGL((k_aem_refresh_big<T, 1>), dim3((unsigned)a.N), dim3(64), 0, 0, a);
+  else if (a.nsum == 2) hipLaunchKernelGGL((k_aem_refresh_big<T, 2>), dim3((unsigned)a.N), dim3(64), 0, 0, a);
+  else hipLaunchKernelGGL((k_aem_refresh_big<T, 3>), dim3((unsigned)a.N), dim3(64), 0, 0, a);
+}
+static bool g_force_big = false;  // argv[2] = "big": the run-time-loop kernel at every width (at 64 / 128 it must write the register kernel's bits)
+
 static int run_case(int m, int64_t N, int nsum, int reps) {
-  const int MP = m <= 64 ? 64 : 128, T = MP / 16;
+  const int MP = m <= 64 ? 64 : (m <= 128 ? 128 : 256), T = MP / 16;
   const int nlev = 3, k = 0;
   std::mt19937_64 g(5 + m + nsum);
   std::normal_distribution<double> nd;
@@ -90,7 +99,12 @@ static int run_case(int m, int64_t N, int nsum, int reps) {
   for (int s = 0; s < nsum; ++s) a.sig[s] = dsig[s];
   a.V = dV; a.rvec = drv; a.ll = dll; a.Sst = dS; a.sid = dsid; a.nlev = nlev; a.k = k;
   a.upd = nullptr; a.b_t = (int64_t)tt;
-  auto go = [&]() { if (T == 4) launch<4>(a); else launch<8>(a); };
+  auto go = [&]() {
+    if (T == 16) launch_big<16>(a);
+    else if (g_force_big) { if (T == 4) launch_big<4>(a); else launch_big<8>(a); }
+    else if (T == 4) launch<4>(a);
+    else launch<8>(a);
+  };
   // timing: no update (the trackers stay what they are over the repetitions; the arithmetic of the update runs all the same)
   go();
   CK(hipDeviceSynchronize());
@@ -190,8 +204,16 @@ static int run_case(int m, int64_t N, int nsum, int reps) {
   }
   const double us = ms * 1000.0 / reps;
   const double flops = (double)N * (2.0 / 3.0) * pow((double)MP, 3);
-  printf("m=%3d MP=%3d nsum=%d N=%lld: %8.1f us / launch  (%.1f TFLOP/s at 2/3 m^3)   max rel err V %.2e, ll %.2e\n", m, MP, nsum, (long long)N, us,
-         flops / (us * 1e-6) / 1e12, worstV, worstL);
+  unsigned long long hsh = 1469598103934665603ull;  // FNV-1a over chain 0's factor and log-likelihood: equal bits <=> equal hash across builds / kernels
+  {
+    CK(hipMemcpy(V.data(), dV, VD * 8, hipMemcpyDeviceToHost));
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(V.data());
+    for (size_t i = 0; i < VD * 8; ++i) hsh = (hsh ^ b[i]) * 1099511628211ull;
+    b = reinterpret_cast<const unsigned char*>(ll.data());
+    for (size_t i = 0; i < 8; ++i) hsh = (hsh ^ b[i]) * 1099511628211ull;
+  }
+  printf("m=%3d MP=%3d nsum=%d N=%lld: %8.1f us / launch  (%.1f TFLOP/s at 2/3 m^3)   max rel err V %.2e, ll %.2e   bits %016llx\n", m, MP, nsum, (long long)N, us,
+         flops / (us * 1e-6) / 1e12, worstV, worstL, hsh);
   hipFree(dcov); for (int s = 0; s < nsum; ++s) hipFree(dsig[s]);
   hipFree(dV); hipFree(drv); hipFree(dll); hipFree(dS); hipFree(dsid); hipFree(dupd);
   return (worstV < 1e-10 && worstL < 1e-10) ? 0 : 2;
@@ -199,7 +221,11 @@ static int run_case(int m, int64_t N, int nsum, int reps) {
 
 int main(int argc, char** argv) {
   const int64_t N = argc > 1 ? atoll(argv[1]) : 4096;
+  g_force_big = argc > 2 && std::string(argv[2]) == "big";
   int rc = 0;
+  rc |= run_case(256, N, 2, 3);
+  rc |= run_case(200, N, 1, 3);
+  rc |= run_case(130, N, 3, 2);
   rc |= run_case(128, N, 2, 10);
   rc |= run_case(128, N, 1, 10);
   rc |= run_case(100, N, 3, 5);

@@ -101,6 +101,11 @@ CASES = [
     ("da d64 256/2048 pcn randomised", lambda: hier("da d64 256/2048 pcn randomised", 64, (256, 2048), [10], dict(kind=1, scaling=0.02), 100, randomize=True)),
     ("mlda3 d64 256/512/2048 am (generic kernel)", lambda: hier("mlda3 d64 256/512/2048 am (generic kernel)", 64, (256, 512, 2048), [5, 3], dict(kind=2, C_=1e-4 * np.eye(64), t0=100, period=100), 40)),
     ("mlda4 d64 128/256/512/2048 grw", lambda: hier("mlda4 d64 128/256/512/2048 grw", 64, (128, 256, 512, 2048), [4, 3, 2], dict(kind=0, C_=np.eye(64), scaling=0.02), 30)),
+    ("da d128 256/2048 pcn", lambda: hier("da d128 256/2048 pcn", 128, (256, 2048), [10], dict(kind=1, scaling=0.02), 60)),
+    ("da d128 256/2048 am", lambda: hier("da d128 256/2048 am", 128, (256, 2048), [10], dict(kind=2, C_=1e-4 * np.eye(128), t0=100, period=100), 60)),
+    ("da d64 256/2048 pcn (same harness)", lambda: hier("da d64 256/2048 pcn (same harness)", 64, (256, 2048), [10], dict(kind=1, scaling=0.02), 60)),
+    ("mlda3 d128 256/512/2048 am", lambda: hier("mlda3 d128 256/512/2048 am", 128, (256, 512, 2048), [5, 3], dict(kind=2, C_=1e-4 * np.eye(128), t0=100, period=100), 30)),
+    ("mlda4 d128 128/256/512/2048 grw", lambda: hier("mlda4 d128 128/256/512/2048 grw", 128, (128, 256, 512, 2048), [4, 3, 2], dict(kind=0, C_=np.eye(128), scaling=0.02), 20)),
     ("mlda3 d32 64/256/1024 am", lambda: hier("mlda3 d32 64/256/1024 am", 32, (64, 256, 1024), [5, 3], dict(kind=2, C_=1e-4 * np.eye(32), t0=100, period=100), 40)),
 ]
 

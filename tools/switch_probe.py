@@ -1,6 +1,6 @@
 """One seeded run of a configuration whose kernel choice an environment switch changes; records to an .npz.  The switches are
 read once per process, so A/B comparisons start this script twice (tests/test_gpu_switches.py).
-    python tools/switch_probe.py {mlda3|mlda3_short|da2|aemd|aemd_lean|aem_dense|aem_dense_da_pcn|dream|am}[_ragged] out.npz     (_ragged: a chain count that is not a multiple of the 16-chain tile)"""
+    python tools/switch_probe.py {mlda3|mlda3_short|da2|aemd|aemd_lean|aem_dense|aem_dense_da_pcn|aem_dense_m200|aem_dense_chunks|dream|am}[_ragged] out.npz     (_ragged: a chain count that is not a multiple of the 16-chain tile)"""
 import os
 import sys
 
@@ -84,6 +84,10 @@ if __name__ == "__main__":
         res = hierarchy((100, 100, 100), [5, 3], "am", 8, N=96 - cut, error_model="state-independent")
     elif what == "aem_dense_da_pcn":  # two levels, pCN (keep < 1 in the linear update), state-dependent model
         res = hierarchy((40, 40), [4], "pcn", 12, N=64, error_model="state-dependent")
+    elif what == "aem_dense_m200":  # 129 .. 256 outputs (round 5): k_aem_refresh_big, k_aem_action<256>, k_aem_base_steps<16> / aem_quad_factor_inplace<16>
+        res = hierarchy((200, 200, 200), [5, 3], "am", 6, N=48 - cut, error_model="state-independent")
+    elif what == "aem_dense_chunks":  # a 20-step base subchain: 22 vectors, two chunks of 16 columns in k_aem_base_steps
+        res = hierarchy((72, 72), [20], "pcn", 4, N=32, error_model="state-independent")
     elif what == "aem_dense_long":  # a base subchain whose product vectors do not fit 64 KB of LDS (128 outputs, 70 steps): level kernel
         res = hierarchy((128, 128), [70], "pcn", 2, N=32, error_model="state-independent")
     elif what == "am":
