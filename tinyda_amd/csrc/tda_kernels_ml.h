@@ -314,20 +314,12 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_ml_steps(const MLArgs a) {
       for (int cc = wave; cc < 16; cc += NW) {  // lane = observation (and observation + 64, + 128, + 192 beyond 64 outputs)
         const int64_t gc = tile * 16 + cc;
         double* rrow = s_R + cc * RSa;
-        double rb[AEM_MP_MAX / 64];
-#pragma unroll
-        for (int h = 0; h < AEM_MP_MAX / 64; ++h) rb[h] = lane + 64 * h < MP ? rrow[lane + 64 * h] + a.aem_bias[gc * LD + lane + 64 * h] : 0.0;
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int h = 0; h < AEM_MP_MAX / 64; ++h)
-          if (lane + 64 * h < MP) rrow[lane + 64 * h] = rb[h];
+        for (int o = lane; o < MP; o += 64) rrow[o] += a.aem_bias[gc * LD + o];  // (a lane's own entries: no exchange until the solve)
         __builtin_amdgcn_wave_barrier();
         // -1/2 |V r|^2 from the chain's lower tiles of V = L^-1 (72 KB per chain at 128 outputs, 512-byte rows; the rows of
         // blocks beyond the outputs are identity and r is not defined there: only the block rows of the outputs are read)
-        double qv;
-        if (LD <= 64) qv = aem_quad_factor_inplace<4>(a.aem_P + (size_t)gc * aemr_v_doubles(64), rrow, lane, MP >> 4);
-        else if (LD <= 128) qv = aem_quad_factor_inplace<8>(a.aem_P + (size_t)gc * aemr_v_doubles(128), rrow, lane, MP >> 4);
-        else qv = aem_quad_factor_inplace<16>(a.aem_P + (size_t)gc * aemr_v_doubles(256), rrow, lane, MP >> 4);
+        // (one instance for every row stride: the substitution's loops are run-time loops over the block rows of the outputs)
+        const double qv = aem_quad_factor_inplace<8>(a.aem_P + (size_t)gc * aemr_v_doubles(LD), rrow, lane, MP >> 4);
         if (lane == 0) s_R[16 * RSa + cc] = qv;
       }
       if (prior_dense && lane < 16) {}  // (s_redp already written above)
