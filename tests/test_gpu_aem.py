@@ -88,14 +88,15 @@ def test_mlda_error_model_replay(eng_mod, golden, name):
     e.close()
 
 
-def test_sample_api_with_error_model_beyond_64_outputs():
-    """tda.sample(..., adaptive_error_model=...) lowers AdaptiveGaussianLogLike levels with up to 128 outputs (two-wave
-    error-model kernels); the finest-level links carry the posterior of the finest model."""
+@pytest.mark.parametrize("m", [100, 200])
+def test_sample_api_with_error_model_beyond_64_outputs(m):
+    """tda.sample(..., adaptive_error_model=...) lowers AdaptiveGaussianLogLike levels with up to 256 outputs (two- and four-wave
+    error-model kernels; beyond 128: k_aem_refresh_big); the finest-level links carry the posterior of the finest model."""
     import scipy.stats as st
 
     import tinyda_amd as tda
 
-    d, m, N = 6, 100, 12
+    d, N = 6, 12
     rng = np.random.default_rng(5)
     Af = rng.standard_normal((m, d)) / np.sqrt(d)
     truth = rng.standard_normal(d)

@@ -128,12 +128,14 @@ def test_c4_dream_full_size(eng_mod):
     e.close()
 
 
-def test_c5_error_model_full_size(eng_mod):
+@pytest.mark.parametrize("N,m", [(4096, 128), (1024, 256)], ids=["4096x128", "1024x256"])
+def test_c5_error_model_full_size(eng_mod, N, m):
     """SURVEY's C5 with the state-independent error model: 4096 chains, d = 64, three linear levels with a common output
-    dimension of 128, AdaptiveMetropolis, subchains [5, 3].  Invariants: the finest records carry the finest posterior
+    dimension of 128, AdaptiveMetropolis, subchains [5, 3] -- and the same at 256 outputs (round 5: k_aem_refresh_big; 1024 chains,
+    the host forms every chain's 256 x 256 inverse for the check).  Invariants: the finest records carry the finest posterior
     (re-evaluated by the oracle), every chain's (Sigma_e + Sigma_bias)^-1 is finite, symmetric and positive on the
     diagonal, biases are finite, the levels move."""
-    N, d, m, n_fine = 4096, 64, 128, 4
+    d, n_fine = 64, 4
     rng = np.random.default_rng(6)
     truth = rng.standard_normal(d)
     Af = rng.standard_normal((m, d)) / 8

@@ -203,10 +203,15 @@ def test_host_fallback_is_announced_with_the_rule_that_refused_the_problem():
     like = tda.GaussianLogLike(np.zeros(10), 0.1 * np.eye(10))
     assert api._device_plan([tda.Posterior(prior4, like, lambda th: th)], tda.AdaptiveMetropolis(np.eye(4))) is None
     assert "opaque Python model" in api._refusal[0]
-    posts = [tda.Posterior(prior4, tda.AdaptiveGaussianLogLike(np.zeros(200), 0.1 * np.eye(200)), tda.LinearModel(rng.standard_normal((200, 4)))),
-             tda.Posterior(prior4, tda.GaussianLogLike(np.zeros(200), 0.1 * np.eye(200)), tda.LinearModel(rng.standard_normal((200, 4))))]
-    if api.MAX_AEM_OUTPUTS < 200:
-        assert api._device_plan(posts, tda.CrankNicolson()) is None and "AdaptiveGaussianLogLike" in api._refusal[0]
+    mo = api.MAX_AEM_OUTPUTS + 1  # (0.5: 256 outputs for the dense error model over linear levels)
+    posts = [tda.Posterior(prior4, tda.AdaptiveGaussianLogLike(np.zeros(mo), 0.1 * np.eye(mo)), tda.LinearModel(rng.standard_normal((mo, 4)))),
+             tda.Posterior(prior4, tda.GaussianLogLike(np.zeros(mo), 0.1 * np.eye(mo)), tda.LinearModel(rng.standard_normal((mo, 4))))]
+    assert api._device_plan(posts, tda.CrankNicolson(), error_model="state-independent") is None and "AdaptiveGaussianLogLike" in api._refusal[0]
+    mo = api.MAX_AEM_OUTPUTS_HOST_SEQUENCED + 1  # ... and 128 below DREAM(Z) or beside host-sequenced levels
+    posts = [tda.Posterior(prior4, tda.AdaptiveGaussianLogLike(np.zeros(mo), 0.1 * np.eye(mo)), tda.LinearModel(rng.standard_normal((mo, 4)))),
+             tda.Posterior(prior4, tda.GaussianLogLike(np.zeros(mo), 0.1 * np.eye(mo)), tda.LinearModel(rng.standard_normal((mo, 4))))]
+    assert api._device_plan(posts, tda.CrankNicolson(), error_model="state-independent") is not None
+    assert api._device_plan(posts, tda.DREAMZ(M0=20), error_model="state-independent") is None and "dense error model with more than 128" in api._refusal[0]
 
 
 def test_dense_error_model_with_a_dense_fine_level_falls_back_with_the_warning():

@@ -621,14 +621,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AEMR_WA
 // two kernels write the same bits: tests/test_gpu_aem.py), ONE WAVE PER CHAIN, run-time loops, and the chain's factor buffer itself
 // as the workspace: a finished tile is stored at once and read back (past L1: glc) by the rows below,
 //     C(q, i) = Sigma(q, i) - sum_{p < q} U_pq^T U_pi,   U_qq^-1 by aemr_diag,   U_qi = (L_qq)^-1 C(q, i),
-// one tile of the block row at a time.  2 T (T + 1)(T + 2) / 3 matrix instructions per chain (3 264 at T = 16) and, per tile update,
-// two 2 KB tile reads from L2 / HBM: the launch is bound by that traffic (~ 2.7 MB per chain), not by the matrix cores -- ~ 10 x the
-// 128-output launch for 8 x its flops.  (Not built: the current block column U_pq parked in LDS, which would halve the reads.)
+// up to AEMRB_NB tiles of the block row at a time.  2 T (T + 1)(T + 2) / 3 matrix instructions per chain (3 264 at T = 16) and, per tile
+// update, 1 + 1 / AEMRB_NB tile reads of 2 KB from L2 / HBM: the launch is bound by that traffic (~ 2 MB per chain), not by the matrix
+// cores -- 2.16 ms per launch of 4096 chains at 256 outputs, 7 x the 128-output launch for 8 x its flops.  (Not built: the current block
+// column U_pq parked in LDS: 30 KB per wave, five waves per CU.)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double aemr_ld_l2(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {  // glc: served by L2, never by a stale L1 line
   const aemr_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 1);
   return __hiloint2double((int)v.y, (int)v.x);
 }
+#ifndef AEMRB_NB
+#define AEMRB_NB 3  // tiles of a block row per pass (4096 chains x 256 outputs, two trackers: 2: 2.28 ms, 3: 2.16, 4: 2.28 -- 166 registers, two waves per SIMD)
+#endif
 template <int T, int NSUM>
 __global__ void __launch_bounds__(64) k_aem_refresh_big(const AemRefreshArgs a) {
   constexpr int NT = aemr_tiles(T), MP = 16 * T, NH = (MP + 63) / 64;
@@ -759,40 +763,46 @@ __global__ void __launch_bounds__(64) k_aem_refresh_big(const AemRefreshArgs a) 
       if (lc == 0) *reinterpret_cast<double4_t*>(s_z + 16 * q + 4 * hi) = zq;
       __builtin_amdgcn_wave_barrier();
       // ---- the rest of block row q: U_qi = (L_qq)^-1 (Sigma(q, i) - sum_{p < q} U_pq^T U_pi) ----
-      // (two tiles of the row at a time: one read of U_pq serves both, and their matrix instructions alternate between two accumulators)
-      for (int i = q + 1; i < T; i += 2) {
-        const bool two = i + 1 < T;  // (uniform)
-        const int i1 = two ? i + 1 : i;
-        double4_t C0 = sum_tile(q, i), C1 = C0;
-        if (two) C1 = sum_tile(q, i1);
+      // (AEMRB_NB tiles of the row at a time: one read of U_pq serves all of them -- the launch is bound by these tile reads --, and
+      // their matrix instructions alternate between independent accumulators; a tile index beyond the row repeats the last tile,
+      // whose result is stored once)
+      constexpr int NB = AEMRB_NB;
+      for (int i = q + 1; i < T; i += NB) {
+        int ib[NB];
+        double4_t C[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          ib[b] = i + b < T ? i + b : T - 1;
+          C[b] = (b == 0 || i + b < T) ? sum_tile(q, ib[b]) : C[0];  // (uniform)
+        }
 #pragma unroll 2
         for (int p = 0; p < q; ++p) {
-          const int sq_ = aemr_lt(q, p) * 2048, s0 = aemr_lt(i, p) * 2048, s1 = aemr_lt(i1, p) * 2048;
-          double uq[4], u0[4], u1[4];
+          const int sq_ = aemr_lt(q, p) * 2048;
+          double uq[4], ub[NB][4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             uq[r] = aemr_ld_l2(Vrs, lane8, sq_ + r * 512);
-            u0[r] = aemr_ld_l2(Vrs, lane8, s0 + r * 512);
-            u1[r] = aemr_ld_l2(Vrs, lane8, s1 + r * 512);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) ub[b][r] = aemr_ld_l2(Vrs, lane8, aemr_lt(ib[b], p) * 2048 + r * 512);
           }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            C0 = mfma_f64(-uq[r], u0[r], C0);
-            C1 = mfma_f64(-uq[r], u1[r], C1);
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) C[b] = mfma_f64(-uq[r], ub[b][r], C[b]);
+        }
+        double4_t U[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) U[b] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+          for (int b = 0; b < NB; ++b) U[b] = mfma_f64(Vt[kc], C[b][kc], U[b]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          if (i + b < T) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) aemr_st(U[b][r], Vrs, lane8, (aemr_lt(i + b, q) * 4 + r) * 512);
           }
-        }
-        double4_t U0 = {0.0, 0.0, 0.0, 0.0}, U1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
-          U0 = mfma_f64(Vt[kc], C0[kc], U0);
-          U1 = mfma_f64(Vt[kc], C1[kc], U1);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) aemr_st(U0[r], Vrs, lane8, (aemr_lt(i, q) * 4 + r) * 512);
-        if (two) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) aemr_st(U1[r], Vrs, lane8, (aemr_lt(i1, q) * 4 + r) * 512);
-        }
       }
     }
     llk = -0.5 * sum_rows(sq);
