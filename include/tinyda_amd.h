@@ -101,7 +101,8 @@ typedef struct tda_config {
   int32_t dim;           /* parameter dimension d: 1..64; 0.5: 65..128 for single-level chains and hierarchies of two to four levels (no error model)
                           * with linear models, isotropic / diagonal noise, a Gaussian prior with a diagonal covariance and TDA_PROP_GRW / TDA_PROP_PCN / TDA_PROP_AM --
                           * anything else at more than 64 parameters is refused by tda_engine_init with TDA_ERR_UNSUPPORTED */
-  int32_t n_levels;      /* 1 = MH (sampler.py:213), 2 = Delayed Acceptance (:231), 3..4 = MLDA (:260) */
+  int32_t n_levels;      /* 1 = MH (sampler.py:213), 2 = Delayed Acceptance (:231), 3..6 = MLDA (:260); 0.5: 5 and 6 for the engine's own models without error model,
+                          * dense observation covariance or DREAM(Z), dim <= 64 (0.4: at most 4) */
   uint64_t seed;
   void* stream;          /* hipStream_t to run on, or NULL for an engine-owned stream */
   int32_t block_steps;   /* max MH steps fused per launch group (0 = default 128) */
@@ -185,7 +186,7 @@ const char* tda_last_error(void);
  * tda_engine_set_proposal_spectrum; 0.4 tda_profile grew n_launch_aem / ms_aem (struct_size 48 is still accepted), checkpoint blobs
  * carry the ABI / RNG-contract version and older blobs are refused; 0.5 no entry point added or changed: tda_config.dim up to 128
  * (single-level chains and two-level hierarchies, see tda_config), the dense error model kept as the Cholesky factor instead of its triangular inverse (same
- * results through tda_engine_get_error_model; checkpoint blobs are format 3 and format-2 blobs are refused). */
+ * results through tda_engine_get_error_model; checkpoint blobs are format 4 -- six levels' counters -- and older blobs are refused). */
 const char* tda_version(void);
 
 /* Released engines park their large device buffers in a per-process pool (TINYDA_POOL_GB, default 8 GiB) so that the next

@@ -1050,6 +1050,9 @@ FIXTURES = {
     "g5_mlda_am": lambda: g5_mlda("g5_mlda_am", "am", period=10),
     "g5_mlda_grw_adaptive": lambda: g5_mlda("g5_mlda_grw_adaptive", "grw", adaptive=True, period=7, seed=502),
     "g5_mlda_4level": lambda: g5_mlda("g5_mlda_4level", "am", ms=(6, 10, 16, 24), sl=(3, 2, 2), iters=20, period=10, seed=503),
+    # five and six levels (round 5: MAXLEV = 6, the generic level kernel)
+    "g5_mlda_5level": lambda: g5_mlda("g5_mlda_5level", "grw", ms=(5, 8, 12, 16, 24), sl=(2, 2, 2, 2), iters=10, adaptive=True, period=8, seed=504),
+    "g5_mlda_6level": lambda: g5_mlda("g5_mlda_6level", "am", ms=(4, 6, 9, 12, 16, 24), sl=(2, 2, 2, 2, 2), iters=8, period=12, seed=505),
     "g15_da_dreamz": lambda: g15_hier_dreamz("g15_da_dreamz", ms=(10, 24), sl=(3,), seed=1501),
     "g15_mlda_dreamz": lambda: g15_hier_dreamz("g15_mlda_dreamz", ms=(8, 14, 24), sl=(3, 2), iters=20, seed=1502),
     "g15_da_dreamz_random": lambda: g15_hier_dreamz("g15_da_dreamz_random", ms=(10, 24), sl=(4,), seed=1503, randomize=True),

@@ -48,6 +48,7 @@ HOT = {
 KNOWN_SPILLERS = {
     "_ZN3tda13k_adapt_splitILi64EEE": 8,  # (TINYDA_ADAPT_SPLIT=1, an A/B switch: the moment recursion on two waves per chain at three waves per SIMD)
     "_ZN3tda10k_ml_stepsILi64ELi4ELi4ELb0EEE": 8,
+    "_ZN3tda10k_ml_stepsILi64ELi5ELi4ELb0EEE": 56, "_ZN3tda10k_ml_stepsILi64ELi6ELi4ELb0EEE": 100,  # (five / six levels, round 5: 51 / 95; no spill at 8 .. 32 parameters)
     "_ZN3tda10k_ml_stepsILi128ELi3ELi4ELb0EEE": 4, "_ZN3tda10k_ml_stepsILi128ELi4ELi4ELb0EEE": 48,  # (MLDA above 64 parameters, round 5: 2 / 44; the two-level instance spills nothing)
     "_ZN3tda10k_ml_stepsILi64ELi2ELi4ELb1EEE": 24, "_ZN3tda10k_ml_stepsILi64ELi3ELi4ELb1EEE": 64, "_ZN3tda10k_ml_stepsILi64ELi4ELi4ELb1EEE": 104,
 }

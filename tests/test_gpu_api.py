@@ -263,3 +263,31 @@ def test_sample_hierarchy_with_dense_observation_covariance(eng_mod):
         np.testing.assert_allclose([link.prior, link.likelihood], [ref.prior, ref.likelihood], rtol=1e-10)
     acc = np.mean([np.mean(res["chain_fine_%d" % i].accepted[1:]) for i in range(24)])
     assert 0.02 < acc < 0.98
+
+
+def test_sample_five_level_mlda_runs_on_the_device(eng_mod):
+    """tda.sample over FIVE levels (0.5: six at most; 0.4 fell back to the host protocol beyond four): backend hip, the finest links
+    carry the finest posterior; with an error model five levels still fall back, announced"""
+    import warnings
+
+    import tinyda_amd as tda
+
+    rng = np.random.default_rng(8)
+    d, ms = 5, (6, 9, 12, 18, 30)
+    base = rng.standard_normal((ms[-1], d)) / 2
+    truth = rng.standard_normal(d)
+    y = base @ truth + 0.2 * rng.standard_normal(ms[-1])
+    prior = st.multivariate_normal(np.zeros(d), np.eye(d))
+    posts = [tda.Posterior(prior, tda.GaussianLogLike(y[:m], 0.04 * np.eye(m)), tda.LinearModel(base[:m])) for m in ms]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", tda.HostFallbackWarning)
+        res = tda.sample(posts, tda.GaussianRandomWalk(0.01 * np.eye(d)), 12, n_chains=16, subchain_length=[2, 2, 2, 2], seed=5)
+    assert res["sampler"] == "MLDA" and res["backend"] == "hip" and res["levels"] == 5
+    for i in (0, 7, 15):
+        link = res["chain_l4_%d" % i][-1]
+        ref = posts[4].create_link(link.parameters)
+        np.testing.assert_allclose([link.prior, link.likelihood], [ref.prior, ref.likelihood], rtol=1e-10)
+    same = [tda.Posterior(prior, tda.AdaptiveGaussianLogLike(y[:6], 0.04 * np.eye(6)), tda.LinearModel(base[:6] * (1 + 0.01 * k))) for k in range(4)]
+    same.append(tda.Posterior(prior, tda.GaussianLogLike(y[:6], 0.04 * np.eye(6)), tda.LinearModel(base[:6])))
+    with pytest.warns(tda.HostFallbackWarning, match="more than 4 levels are lowered without error model"):
+        tda.sample(same, tda.GaussianRandomWalk(0.01 * np.eye(d)), 2, n_chains=1, subchain_length=[2, 2, 2, 2], adaptive_error_model="state-independent")

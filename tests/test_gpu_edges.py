@@ -97,7 +97,7 @@ def test_loud_failures(eng_mod):
     with pytest.raises(EngineError, match="dim=129"):  # (0.5: 128 parameters; hierarchies above 64: tests/test_gpu_wide.py)
         eng_mod.Engine(4, 129)
     with pytest.raises(EngineError, match="n_levels"):
-        eng_mod.Engine(4, 3, n_levels=5)
+        eng_mod.Engine(4, 3, n_levels=7)  # (0.5: six levels)
     e = eng_mod.Engine(4, 3)
     with pytest.raises(EngineError, match="not initialised"):
         e.run(1)

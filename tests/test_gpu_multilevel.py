@@ -84,7 +84,8 @@ def test_delayed_acceptance_replay(eng_mod, golden, name, block):
 
 
 @pytest.mark.parametrize("name,block", [("g5_mlda_am", 0), ("g5_mlda_am", 5), ("g5_mlda_grw_adaptive", 0),
-                                        ("g5_mlda_4level", 0), ("g5_mlda_am_dense", 0)])
+                                        ("g5_mlda_4level", 0), ("g5_mlda_am_dense", 0),
+                                        ("g5_mlda_5level", 0), ("g5_mlda_6level", 0)])
 def test_mlda_replay(eng_mod, golden, name, block):
     g = golden(name)
     nl = int(g["n_levels"])
@@ -114,7 +115,7 @@ def _oracle_uniforms(seed, N, rows, sl, randomize_L=None):
     return us, ridx
 
 
-@pytest.mark.parametrize("case", ["da_c3", "da_random", "mlda3", "da_long_data"])
+@pytest.mark.parametrize("case", ["da_c3", "da_random", "mlda3", "da_long_data", "mlda5", "mlda6"])
 def test_multilevel_philox_forward_vs_oracle(eng_mod, case):
     """Engine on its own Philox stream (normals exported, uniforms / promoted index regenerated bit-exactly by the
     oracle's Philox); BASELINE config-3 / config-5 shapes at reduced chain counts.  da_long_data: a fine level of 9 000
@@ -126,6 +127,12 @@ def test_multilevel_philox_forward_vs_oracle(eng_mod, case):
     elif case == "mlda3":
         d, ms, sl, n_fine, N = 64, (128, 512, 2048), [5, 3], 12, 32
         prop = dict(kind="am", C0=1e-4 * np.eye(d), t0=50, period=50)
+    elif case == "mlda5":  # five and six levels (round 5): the generic level kernel's k_ml_steps<., 5 | 6> instances
+        d, ms, sl, n_fine, N = 64, (64, 96, 160, 320, 640), [3, 2, 2, 2], 6, 32
+        prop = dict(kind="pcn", scaling=0.02, adaptive=True, gamma=1.01, period=40)
+    elif case == "mlda6":
+        d, ms, sl, n_fine, N = 24, (16, 32, 48, 64, 128, 256), [2, 2, 2, 2, 2], 5, 20
+        prop = dict(kind="am", C0=1e-3 * np.eye(d), t0=40, period=40)
     else:
         d, ms, sl, n_fine, N = 64, (256, 2048), [10], 20, 48
         prop = dict(kind="pcn", scaling=0.02, adaptive=True, gamma=1.01, period=40) if case == "da_c3" else \

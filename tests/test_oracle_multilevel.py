@@ -44,7 +44,7 @@ def test_delayed_acceptance(golden, name):
     np.testing.assert_allclose(prop.scaling, g["scaling"], rtol=1e-12)
 
 
-@pytest.mark.parametrize("name", ["g5_mlda_am", "g5_mlda_grw_adaptive", "g5_mlda_4level", "g5_mlda_am_dense"])
+@pytest.mark.parametrize("name", ["g5_mlda_am", "g5_mlda_grw_adaptive", "g5_mlda_4level", "g5_mlda_am_dense", "g5_mlda_5level", "g5_mlda_6level"])
 def test_mlda(golden, name):
     g = golden(name)
     nl = int(g["n_levels"])

@@ -23,7 +23,8 @@ _DEVICE_PROPOSALS = (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis, DREA
                      OperatorWeightedCrankNicolson, MALA)
 
 
-MAX_LEVELS = 4
+MAX_LEVELS = 6  # (0.5; five and six levels: no error model, no dense observation covariance, at most 64 parameters -- MAX_LEVELS_FULL otherwise)
+MAX_LEVELS_FULL = 4
 MAX_PARAMETERS = 128  # (more than 64: no error models, see _device_plan)
 MAX_AEM_OUTPUTS = 256  # dense error model (0.5: 129 .. 256 on k_aem_refresh_big); hierarchies sequenced by the host: MAX_AEM_OUTPUTS_HOST_SEQUENCED
 MAX_AEM_OUTPUTS_HOST_SEQUENCED = 128
@@ -48,6 +49,8 @@ def _device_plan(posteriors, proposal, diagonal_error_model=False, error_model=N
     del _refusal[:]
     if not 1 <= len(posteriors) <= MAX_LEVELS or type(proposal) not in _DEVICE_PROPOSALS:
         return _no("more than %d levels (or none), or a proposal class the engine has no kernel for (%s)" % (MAX_LEVELS, type(proposal).__name__))
+    if len(posteriors) > MAX_LEVELS_FULL and (error_model is not None or isinstance(proposal, DREAMZ)):
+        return _no("more than %d levels are lowered without error model, under GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis" % MAX_LEVELS_FULL)
     lows = []
     for post in posteriors:
         low = getattr(post, "_lowering", lambda: None)()
@@ -57,7 +60,7 @@ def _device_plan(posteriors, proposal, diagonal_error_model=False, error_model=N
             # 65 .. 128 parameters (0.5, tda_kernels_wide.h): single-level chains, Delayed Acceptance and MLDA (up to four levels), linear models with isotropic / diagonal noise, a Gaussian
             # prior with a diagonal covariance, GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis
             pc = np.asarray(low["prior_cov"])
-            if ((len(posteriors) >= 2 and error_model is not None)
+            if ((len(posteriors) >= 2 and error_model is not None) or len(posteriors) > MAX_LEVELS_FULL
                     or type(proposal) not in (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis) or low.get("A") is None
                     or getattr(proposal, "block_moments", False)
                     or any(k in low for k in ("source", "batched", "rosenbrock", "prior_joint"))
@@ -76,6 +79,8 @@ def _device_plan(posteriors, proposal, diagonal_error_model=False, error_model=N
         if low["noise_kind"] == _lib.NOISE_ADAPTIVE and (len(posteriors) < 2 or np.asarray(low["data"]).shape[0] > MAX_AEM_OUTPUTS):
             return _no("AdaptiveGaussianLogLike on the device: coarse levels of a hierarchy with at most %d outputs" % MAX_AEM_OUTPUTS)
         if low["noise_kind"] == _lib.NOISE_DENSE:
+            if len(posteriors) > MAX_LEVELS_FULL:
+                return _no("a dense observation covariance in a hierarchy: at most %d levels" % MAX_LEVELS_FULL)
             if low["A"] is None:  # callback / source-defined model: any sampler they run under, m <= 2048
                 if np.asarray(low["data"]).shape[0] > 2048:
                     return _no("a dense observation covariance beside a callback / source-defined model: at most 2048 outputs")
@@ -112,6 +117,8 @@ def _device_plan(posteriors, proposal, diagonal_error_model=False, error_model=N
     if any("source" in low or "batched" in low for low in lows):
         # source-defined and batched host models: single level, or a whole hierarchy of them (Delayed Acceptance / MLDA with
         # host-sequenced level actions: GRW / pCN / AM).  iso / diag noise, diagonal prior.
+        if len(posteriors) > MAX_LEVELS_FULL:
+            return _no("hierarchies of callback / source-defined models: at most %d levels" % MAX_LEVELS_FULL)
         if len(posteriors) > 1:
             if any("rosenbrock" in low for low in lows) or type(proposal) not in (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis, DREAMZ):
                 return _no("hierarchies of callback / source-defined models run under GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis / DREAMZ")

@@ -357,8 +357,9 @@ struct tda_engine {
   DevBuf<uint8_t> rec_acc;
 
   // multi-level state (n_levels > 1)
+  static_assert(tda::MAXLEV == 6, "the initialisers of sl / aem_bt below list MAXLEV ones");
   int nlev = 1;
-  int sl[tda::MAXLEV] = {1, 1, 1, 1};
+  int sl[tda::MAXLEV] = {1, 1, 1, 1, 1, 1};
   bool sub_set = false;
   int randomize = 0;
   int cnt[tda::MAXLEV] = {0, 0, 0, 0};
@@ -385,7 +386,7 @@ struct tda_engine {
   DevBuf<double> aem_rvec;  // [NP][aem_ld] bias-corrected residual the action kernels leave for k_aem_refresh's update_link
   DevBuf<double> aem_upd;   // [NP][3][aem_ld] vectors of the tracker covariance update they leave for it
   DevBuf<double> aem_F;     // [4][NP][aem_ld] model outputs of levels q, q - 1 at the states of levels q - 1, q (k_linear_outputs_multi -> k_aem_action)
-  int64_t aem_bt[tda::MAXLEV] = {1, 1, 1, 1};
+  int64_t aem_bt[tda::MAXLEV] = {1, 1, 1, 1, 1, 1};
   DevBuf<int64_t> ml_sid;
   DevBuf<double> prior_W_rm;
   DevBuf<double> u_rep_lv[tda::MAXLEV], ridx_rep;
@@ -768,14 +769,17 @@ int launch_ml(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st, int* f
     switch (a.nlev) {
       case 2: return go(&k_ml_steps<DPAD, 2, 4, true>);
       case 3: return go(&k_ml_steps<DPAD, 3, 4, true>);
-      default: return go(&k_ml_steps<DPAD, 4, 4, true>);
+      case 4: return go(&k_ml_steps<DPAD, 4, 4, true>);
+      default: return fail(TDA_ERR_UNSUPPORTED, "a dense observation covariance in a hierarchy: at most %d levels", (int)AEM_MAXLEV);
     }
   }
   if (!a.cascade && !a.randomize) return go(&k_ml_steps<DPAD, 1>);
   switch (a.nlev) {
     case 2: return go(&k_ml_steps<DPAD, 2>);
     case 3: return go(&k_ml_steps<DPAD, 3>);
-    default: return go(&k_ml_steps<DPAD, 4>);
+    case 4: return go(&k_ml_steps<DPAD, 4>);
+    case 5: return go(&k_ml_steps<DPAD, 5>);  // (0.5: five and six levels -- 51 / 95 spilled registers at 64 parameters, none at 32)
+    default: return go(&k_ml_steps<DPAD, 6>);
   }
 }
 // 65 .. 128 parameters: Delayed Acceptance and MLDA on the generic level kernel, one 512-register wave per SIMD, ONE observation

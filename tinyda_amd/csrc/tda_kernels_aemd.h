@@ -31,11 +31,11 @@ struct AemdArgs {
   const double* F;             // [N][m] fresh model outputs: level 0 at the proposals (accept) / level q at theta_{q-1} (action)
   const double* prop;          // [N][d] base-level proposals (accept)
   const double* u0;            // [S][NP] base-level uniforms (accept)
-  const double* data[MAXLEV];  // [m]
-  const double* sig2[MAXLEV];  // [m] diagonal of Sigma_e (adaptive levels)
+  const double* data[AEM_MAXLEV];  // [m]
+  const double* sig2[AEM_MAXLEV];  // [m] diagonal of Sigma_e (adaptive levels)
   const double* wfin;          // [m] 1 / diagonal of the finest level's noise, or null (isotropic: var_finest)
   double var_finest;
-  double* Fcur[MAXLEV];        // [N][m] model output of every level's current link
+  double* Fcur[AEM_MAXLEV];        // [N][m] model output of every level's current link
   double* Fst;                 // [npairs][N][m] output of level j at theta_q (companion of Sst)
   double* theta;               // [nlev][NP][DP]
   double* lp;                  // [nlev][NP]
@@ -44,11 +44,11 @@ struct AemdArgs {
   int* anyacc;                 // [nlev][NP]
   long long* sid;              // [nlev][NP]
   long long sid_value;
-  double* bias[MAXLEV];        // [N][m] total bias of adaptive level k
-  double* w[MAXLEV];           // [N][m] 1 / (sigma^2 + total bias variance) in use at level k
-  double* mu[MAXLEV];          // trackers of levels >= 1: running mean, diagonal variance, last difference fed
-  double* var[MAXLEV];
-  double* md[MAXLEV];
+  double* bias[AEM_MAXLEV];        // [N][m] total bias of adaptive level k
+  double* w[AEM_MAXLEV];           // [N][m] 1 / (sigma^2 + total bias variance) in use at level k
+  double* mu[AEM_MAXLEV];          // trackers of levels >= 1: running mean, diagonal variance, last difference fed
+  double* var[AEM_MAXLEV];
+  double* md[AEM_MAXLEV];
   long long b_t;               // recursion counter of level q's tracker before this update
   const double* pr_mean;
   const double* pr_pinv;
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_aemd_action(const AemdArgs a
   const double ca = (t - 1.0) / t, cb = 1.0 / t;
   bool small = true;  // every entry of the total bias variance below 1e-9: set_bias keeps the inverse (distributions.py:399-402)
   for (int o0 = lane; o0 < m; o0 += 128) {
-    double fnew[2], fq_old[2], fj_old[MAXLEV - 1][2], fs[MAXLEV - 1][2], md_old[2], mu_p[MAXLEV][2], var_p[MAXLEV][2];
+    double fnew[2], fq_old[2], fj_old[AEM_MAXLEV - 1][2], fs[AEM_MAXLEV - 1][2], md_old[2], mu_p[AEM_MAXLEV][2], var_p[AEM_MAXLEV][2];
     bool in[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_aemd_action(const AemdArgs a
       fq_old[u] = a.Fcur[q][i];
       md_old[u] = a.md[q][i];
 #pragma unroll
-      for (int j = 0; j < MAXLEV - 1; ++j)  // (constant trip counts + predicates: the per-level values stay in registers)
+      for (int j = 0; j < AEM_MAXLEV - 1; ++j)  // (constant trip counts + predicates: the per-level values stay in registers)
         if (j < q) {
           fj_old[j][u] = a.Fcur[j][i];
           fs[j][u] = FS(j, q)[in[u] ? o : o0];
@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_aemd_action(const AemdArgs a
           fj_old[j][u] = fs[j][u] = 0.0;
         }
 #pragma unroll
-      for (int p = 1; p < MAXLEV; ++p)
+      for (int p = 1; p < AEM_MAXLEV; ++p)
         if (p >= q && p < nl) {
           mu_p[p][u] = a.mu[p][i];
           var_p[p][u] = a.var[p][i];
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_aemd_action(const AemdArgs a
       double fk_cur = 0.0;  // acc ? Fcur[k] : FS(k, q): the aligned output of level k, picked up in the loop below
       if (acc) a.Fcur[q][i] = fnew[u];
 #pragma unroll
-      for (int j = 0; j < MAXLEV - 1; ++j)
+      for (int j = 0; j < AEM_MAXLEV - 1; ++j)
         if (j < q) {
           const double fj = acc ? fj_old[j][u] : fs[j][u];  // the output of level j's current link after the alignment
           if (j == k) fk_cur = fj;
@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_aemd_action(const AemdArgs a
       a.md[q][i] = dm;
       double mu_o = 0.0, var_o = 0.0;
 #pragma unroll
-      for (int p = 1; p < MAXLEV; ++p)
+      for (int p = 1; p < AEM_MAXLEV; ++p)
         if (p == q) {
           mu_o = mu_p[p][u];
           var_o = var_p[p][u];
@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_aemd_action(const AemdArgs a
       a.mu[q][i] = mu_n;
       double bt = 0.0, s2 = 0.0;
 #pragma unroll
-      for (int p = 1; p < MAXLEV; ++p)  // ascending p, as the reference sums the trackers (proposal.py:1563-1569)
+      for (int p = 1; p < AEM_MAXLEV; ++p)  // ascending p, as the reference sums the trackers (proposal.py:1563-1569)
         if (p >= q && p < nl) {
           bt += p == q ? mu_n : mu_p[p][u];
           s2 += p == q ? var_n : var_p[p][u];

@@ -35,7 +35,7 @@
 
 namespace tda {
 
-constexpr int AEMR_MAXSUM = 3;  // trackers summed into Sigma_bias (levels above the refreshed one: MAXLEV - 1)
+constexpr int AEMR_MAXSUM = 3;  // trackers summed into Sigma_bias (levels above the refreshed one: AEM_MAXLEV - 1)
 
 __host__ __device__ constexpr int aemr_ut(int T, int p, int i) { return p * T - p * (p - 1) / 2 + (i - p); }  // upper tile (p, i), p <= i
 __host__ __device__ constexpr int aemr_lt(int q, int i) { return q * (q + 1) / 2 + i; }                        // lower tile (q, i), i <= q

@@ -25,7 +25,12 @@ namespace tda {
 // The accept flag of every upper-level step is also appended to the base proposal's `accepted` window
 // (chain.py:363,389,397; proposal.py:1486), kept as a ring of the last `period` entries.
 // ------------------------------------------------------------------------------------------------
-constexpr int MAXLEV = 4;
+#ifndef TDA_MAXLEV
+#define TDA_MAXLEV 6
+#endif
+constexpr int MAXLEV = TDA_MAXLEV;  // levels of a hierarchy (0.5: six; the generic level kernel with five / six levels spills 51 / 95 registers at 64 parameters)
+constexpr int AEM_MAXLEV = 4;       // ... under an error model (dense: AEMR_MAXSUM trackers are summed; diagonal: per-level register arrays), with a dense
+                                    // observation covariance, and above 64 parameters
 constexpr int AEM_MP_MAX = 256;  // error-model output dimension limit; per-chain vectors / matrices in HBM have row stride 64, 128 or 256
 constexpr int AEM_MP_MAX_EXT = 128;  // ... of hierarchies sequenced by the host (callback / source-defined levels, DREAM(Z) below a hierarchy)
 enum : uint32_t { STREAM_INDEX = 3 };
