@@ -52,7 +52,7 @@ def test_bench_with_the_drivers_arguments():
     # the other BASELINE configurations ride in the same line, full chain counts, each with its own roofline
     cfgs = out.get("configs")
     assert cfgs, out.get("configs_error")
-    assert [c["tag"] for c in cfgs] == ["C2b", "C3", "C4/16", "C4/128", "C5-literal", "C5+AEM128"]
+    assert [c["tag"] for c in cfgs] == ["C2b", "C3", "C4/16", "C4/128", "C5-literal", "C5+AEM128", "C5+AEM256"]
     for c in cfgs:
         assert "error" not in c, c
         for key in ("name", "evals_per_s", "finest_it_per_s", "dominant_kernel", "bound", "flops_or_bytes_per_eval", "frac", "kernel_ms"):

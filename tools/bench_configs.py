@@ -339,7 +339,8 @@ def config_block(log=None):
     """Every BASELINE configuration besides the headline, full chain counts, one dict each (errors are reported in place: the
     headline line must survive a failing side run)."""
     runs = (("C2b", run_c2b), ("C3", run_c3), ("C4/16", lambda: run_c4(K=16)), ("C4/128", lambda: run_c4(K=128)),
-            ("C5-literal", run_c5), ("C5+AEM128", lambda: run_c5_aem(m=128)))
+            ("C5-literal", run_c5), ("C5+AEM128", lambda: run_c5_aem(m=128)),
+            ("C5+AEM256", lambda: run_c5_aem(m=256, n_fine=8)))  # (round 5: the dense error model beyond 128 outputs, k_aem_refresh_big)
     out = []
     for tag, fn in runs:
         t0 = time.perf_counter()

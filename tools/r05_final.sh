@@ -8,7 +8,7 @@ B)  # HBM traffic of the headline kernels; SQ / traffic counters of C4 and of C5
   bash tools/pmc_any.sh r05_pmc_c4.json python3 tools/bench_configs.py c4 16 > gpurun_out/r05_pmc_c4.log 2>&1; echo "c4 rc=$?"
   bash tools/pmc_any.sh r05_pmc_c5aem.json python3 tools/bench_configs.py c5aem 128 > gpurun_out/r05_pmc_c5aem.log 2>&1; echo "c5aem rc=$?" ;;
 C)  # rates: 65 .. 128 parameters (single level and hierarchies), C5 + dense error model at 128 / 256 outputs with kernel stats, the refresh probe
-  for f in "am d64 m1024" "am d128" "am d96" "grw d128" "pcn d128" "da d128" "da d64 256/2048 pcn (same" "mlda3 d128" "mlda4 d128" "mlda3 d64" "mlda4 d64"; do python tools/rate_sweep.py "$f"; done > gpurun_out/r05_rate_wide.jsonl 2> gpurun_out/r05_rate_wide.err; echo "rates rc=$?"
+  for f in "am d64 m1024" "am d128" "am d96" "grw d128" "pcn d128" "da d128" "da d64 256/2048 pcn (same" "mlda3 d128" "mlda4 d128" "mlda3 d64" "mlda4 d64" "mlda5 d64" "mlda6 d32"; do python tools/rate_sweep.py "$f"; done > gpurun_out/r05_rate_wide.jsonl 2> gpurun_out/r05_rate_wide.err; echo "rates rc=$?"
   python tools/bench_configs.py c5aem 128 > gpurun_out/r05_c5aem_m128.json 2> gpurun_out/r05_c5aem.err; echo "c5aem128 rc=$?"
   python tools/bench_configs.py c5aem 256 10 > gpurun_out/r05_c5aem_m256.json 2>> gpurun_out/r05_c5aem.err; echo "c5aem256 rc=$?"
   (cd /tmp && export TMPDIR=/tmp && TINYDA_CONFIGS_REPS=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c5aem -- python3 $GRAFT_REPO_ROOT/tools/bench_configs.py c5aem 128 > /tmp/prof_c5aem.log 2>&1; find /tmp/prof_c5aem -name "*kernel_stats.csv" -exec cp {} $GRAFT_REPO_ROOT/gpurun_out/r05_c5aem_kernel_stats.csv \; )

@@ -106,6 +106,8 @@ CASES = [
     ("da d64 256/2048 pcn (same harness)", lambda: hier("da d64 256/2048 pcn (same harness)", 64, (256, 2048), [10], dict(kind=1, scaling=0.02), 60)),
     ("mlda3 d128 256/512/2048 am", lambda: hier("mlda3 d128 256/512/2048 am", 128, (256, 512, 2048), [5, 3], dict(kind=2, C_=1e-4 * np.eye(128), t0=100, period=100), 30)),
     ("mlda4 d128 128/256/512/2048 grw", lambda: hier("mlda4 d128 128/256/512/2048 grw", 128, (128, 256, 512, 2048), [4, 3, 2], dict(kind=0, C_=np.eye(128), scaling=0.02), 20)),
+    ("mlda5 d64 64/128/256/512/2048 pcn", lambda: hier("mlda5 d64 64/128/256/512/2048 pcn", 64, (64, 128, 256, 512, 2048), [3, 2, 2, 2], dict(kind=1, scaling=0.02), 16)),
+    ("mlda6 d32 32/64/128/256/512/1024 am", lambda: hier("mlda6 d32 32/64/128/256/512/1024 am", 32, (32, 64, 128, 256, 512, 1024), [2, 2, 2, 2, 2], dict(kind=2, C_=1e-4 * np.eye(32), t0=100, period=100), 10)),
     ("mlda3 d32 64/256/1024 am", lambda: hier("mlda3 d32 64/256/1024 am", 32, (64, 256, 1024), [5, 3], dict(kind=2, C_=1e-4 * np.eye(32), t0=100, period=100), 40)),
 ]
 
