@@ -212,3 +212,81 @@ def test_wide_checkpoint_resume_is_bitwise():
     for k in range(3):
         assert np.array_equal(np.concatenate([first[k], rest[k]]), full[k])
     assert np.all(np.isfinite(st["C"])) and st["t"] == 95
+
+
+@pytest.mark.parametrize("kind", ["am", "pcn", "grw_diag"])
+def test_wide_batched_host_model_matches_the_oracle(kind):
+    """a batched host callback (tda.BatchedModel / tda_engine_set_level_callback) at 100 parameters, single level: the device draws,
+    proposes, decides and adapts, the model is evaluated on the host for all chains at once -- against the oracle running the same
+    NumPy model chain by chain on the exported stream"""
+    from tinyda_amd.engine import Engine
+
+    d, M, N, T = 100, 70, 19, 90
+    W = 0.02 + 0.003 * ((np.arange(M)[:, None] * 7 + np.arange(d)[None, :] * 3) % 11)
+
+    def np_model(theta):
+        theta = np.atleast_2d(theta)
+        return np.tanh(theta @ W.T) + 0.25 * theta[:, [0]] * theta[:, [-1]]
+
+    rng = np.random.default_rng(15)
+    truth = 0.3 * rng.standard_normal(d)
+    y = np_model(truth)[0] + 0.05 * rng.standard_normal(M)
+    theta0 = truth + 0.02 * rng.standard_normal((N, d))
+    pm, pv = np.zeros(d), (np.ones(d) if kind == "pcn" else 0.5 + 0.01 * np.arange(d))
+    calls = []
+
+    def fn(thetas):
+        calls.append(thetas.shape)
+        return np_model(thetas)
+
+    e = Engine(N, d, seed=92, chain_offset=1, block_steps=32)
+    e.set_prior(pm, np.diag(pv))
+    noise = 0.05 ** 2 * (1.0 + 0.1 * np.arange(M))
+    C0 = _spd(rng, d, 2e-4 / d)
+    if kind == "grw_diag":
+        e.set_level_callback(0, fn, y, 1, noise)
+        lvl = orc.CallableGaussianLevel(np_model, y, "diag", noise, orc.MVNPrior(pm, np.diag(pv)))
+        e.set_proposal(0, C0, scaling=1.0, adaptive=True, period=20)
+        prop = dict(kind="grw", C=C0, scaling=1.0, adaptive=True, period=20)
+    else:
+        e.set_level_callback(0, fn, y, 0, [0.05 ** 2])
+        lvl = orc.CallableGaussianLevel(np_model, y, "iso", 0.05 ** 2, orc.MVNPrior(pm, np.diag(pv)))
+        if kind == "am":
+            e.set_proposal(2, C0, t0=30, period=30)
+            prop = dict(kind="am", C0=C0, t0=30, period=30)
+        else:
+            e.set_proposal(1, None, scaling=0.01)
+            prop = dict(kind="pcn", scaling=0.01)
+    e.init(theta0)
+    z, u = e.set_export(T)
+    params, stats, acc = e.run_host(T)
+    e.close()
+    assert calls == [(N, d)] * (T + 1)
+    ref = orc.run_mh(lvl, prop, theta0, np.swapaxes(z, 0, 1), np.swapaxes(u, 0, 1))
+    assert np.array_equal(acc, np.swapaxes(ref["accepted"][:, 1:], 0, 1))
+    np.testing.assert_allclose(stats[:, :, 2], np.swapaxes(ref["logpost"][:, 1:], 0, 1), rtol=1e-9 if kind == "am" else 1e-10)
+    np.testing.assert_allclose(params, np.swapaxes(ref["theta"][:, 1:], 0, 1), rtol=1e-9, atol=1e-12)
+    assert 0.0 < acc.mean() < 1.0
+
+
+def test_wide_batched_model_through_sample():
+    """tda.sample with a BatchedModel at 80 parameters returns backend hip (0.4: the host protocol chain by chain)"""
+    import warnings
+
+    import scipy.stats as stats
+
+    import tinyda_amd as tda
+
+    d, m, n_chains = 80, 40, 12
+    rng = np.random.default_rng(2)
+    A = rng.standard_normal((m, d)) / np.sqrt(d)
+    y = np.tanh(A @ (0.3 * rng.standard_normal(d))) + 0.05 * rng.standard_normal(m)
+    model = tda.BatchedModel(lambda th: np.tanh(th @ A.T), m)
+    post = tda.Posterior(stats.multivariate_normal(np.zeros(d), np.eye(d)), tda.GaussianLogLike(y, 0.0025 * np.eye(m)), model)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", tda.HostFallbackWarning)
+        res = tda.sample(post, tda.CrankNicolson(scaling=0.05), 60, n_chains=n_chains, seed=1)
+    assert res["backend"] == "hip"
+    link = res["chain_5"][-1]
+    ref = post.create_link(link.parameters)
+    np.testing.assert_allclose([link.prior, link.likelihood], [ref.prior, ref.likelihood], rtol=1e-10)

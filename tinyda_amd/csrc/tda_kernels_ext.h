@@ -61,26 +61,30 @@ struct ExtArgs {
 constexpr int EXT_WAVES = 4;
 
 __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_propose(const ExtArgs a) {
-  const int lane = threadIdx.x & 63;
+  const int lane0 = threadIdx.x & 63;
   const long long c = (long long)blockIdx.x * EXT_WAVES + (threadIdx.x >> 6);
-  if (c >= a.N || lane >= a.d) return;
-  const double cur = a.theta[c * (a.theta_ld ? a.theta_ld : a.DP) + lane];
-  double prp = cur;
-  if (a.mode != 1) {  // proposal.py:249-251 / :351-355 / :113-115 / :592-598
-    const double scal = a.scaling[c];
-    const double inc = a.inc[((size_t)a.s * a.NP + c) * a.DP + lane];
-    const double sx = scal * inc;
-    if (a.prop_kind == 4) {
-      prp = a.q_mean[lane] + inc;
-    } else if (a.prop_kind == 5) {  // (S theta)[lane] = sum_j S^T[j][lane] theta[j] (the lanes >= d left above; the sources j < d are alive)
-      double st = 0.0;
-      for (int j = 0; j < a.d; ++j) st = fma(a.SopT[(size_t)j * a.DP + lane], __shfl(cur, j), st);
-      prp = st + inc;
-    } else {
-      prp = a.prop_kind == 1 ? sqrt(1.0 - scal * scal) * cur + sx : cur + sx;
+  if (c >= a.N) return;
+  // lane = parameter (and parameter + 64 at 65 .. 128 parameters: GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis only, whose
+  // proposals are elementwise -- tda_engine_init refuses the other kinds there)
+  for (int lane = lane0; lane < a.d; lane += 64) {
+    const double cur = a.theta[c * (a.theta_ld ? a.theta_ld : a.DP) + lane];
+    double prp = cur;
+    if (a.mode != 1) {  // proposal.py:249-251 / :351-355 / :113-115 / :592-598
+      const double scal = a.scaling[c];
+      const double inc = a.inc[((size_t)a.s * a.NP + c) * a.DP + lane];
+      const double sx = scal * inc;
+      if (a.prop_kind == 4) {
+        prp = a.q_mean[lane] + inc;
+      } else if (a.prop_kind == 5) {  // (S theta)[lane] = sum_j S^T[j][lane] theta[j] (d <= 64: every source j is a lane of this wave)
+        double st = 0.0;
+        for (int j = 0; j < a.d; ++j) st = fma(a.SopT[(size_t)j * a.DP + lane], __shfl(cur, j), st);
+        prp = st + inc;
+      } else {
+        prp = a.prop_kind == 1 ? sqrt(1.0 - scal * scal) * cur + sx : cur + sx;
+      }
     }
+    a.prop[c * a.d + lane] = prp;
   }
-  a.prop[c * a.d + lane] = prp;
 }
 
 __device__ __forceinline__ double ext_wave_sum(double v) {
@@ -117,8 +121,8 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_accept(const ExtArgs a) 
   const int lane = threadIdx.x & 63;
   const long long c = (long long)blockIdx.x * EXT_WAVES + (threadIdx.x >> 6);
   if (c >= a.N) return;  // whole waves leave together
-  const bool lj = lane < a.d, eval = a.mode == 1;
-  const double prp = lj ? a.prop[c * a.d + lane] : 0.0;
+  const bool lj = lane < a.d, lj2 = lane + 64 < a.d, eval = a.mode == 1;  // (lj2: 65 .. 128 parameters, a second parameter per lane)
+  const double prp = lj ? a.prop[c * a.d + lane] : 0.0, prp2 = lj2 ? a.prop[c * a.d + lane + 64] : 0.0;
   extern __shared__ double ext_dyn_lds[];  // dense noise only: [EXT_WAVES][m]
   const double sse = ext_weighted_sse(a.F + (size_t)c * a.m, a.data, a.w, a.Pd, a.m, lane, ext_dyn_lds + (size_t)(threadIdx.x >> 6) * a.m);  // distributions.py:295-326
   double pj = 0.0;
@@ -126,6 +130,11 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_accept(const ExtArgs a) 
     const double dv = prp - a.pr_mean[lane];
     pj = dv * dv * a.pr_pinv[lane];
     if (a.pr_lo && (prp < a.pr_lo[lane] || prp > a.pr_hi[lane])) pj = __builtin_inf();  // uniform prior components
+  }
+  if (lj2) {
+    const double dv = prp2 - a.pr_mean[lane + 64];
+    pj += dv * dv * a.pr_pinv[lane + 64];
+    if (a.pr_lo && (prp2 < a.pr_lo[lane + 64] || prp2 > a.pr_hi[lane + 64])) pj = __builtin_inf();
   }
   const double maha = ext_wave_sum(pj);
   const double ll_n = (a.w || a.Pd) ? -0.5 * sse : -0.5 * sse / a.var;
@@ -142,12 +151,14 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_accept(const ExtArgs a) 
     acc = a.u[(size_t)a.s * a.NP + c] < alpha;
     if (acc && a.prop_kind == 4 && lane == 0) a.lq[c] = qzs;
   }
-  double cur = lj ? a.theta[c * a.DP + lane] : 0.0;
+  double cur = lj ? a.theta[c * a.DP + lane] : 0.0, cur2 = lj2 ? a.theta[c * a.DP + lane + 64] : 0.0;
   if (acc) {
     lp = lp_n;
     ll = ll_n;
     cur = prp;
+    cur2 = prp2;
     if (lj) a.theta[c * a.DP + lane] = cur;
+    if (lj2) a.theta[c * a.DP + lane + 64] = cur2;
     if (lane == 0) {
       a.lp[c] = lp;
       a.ll[c] = ll;
@@ -167,7 +178,8 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_accept(const ExtArgs a) 
       if (a.rec_acc) a.rec_acc[r] = acc ? 1 : 0;
     }
     if (a.rec_params && lj) a.rec_params[r * a.d + lane] = cur;
-    if (a.pick && a.cnt == a.pick[c]) {  // the promoted state of this subchain
+    if (a.rec_params && lj2) a.rec_params[r * a.d + lane + 64] = cur2;
+    if (a.pick && a.cnt == a.pick[c]) {  // the promoted state of this subchain (hierarchies: at most 64 parameters)
       double* ys = a.ysnap + (size_t)c * (a.DP + 2);
       if (lane < a.DP) ys[lane] = lj ? cur : 0.0;
       if (lane == 0) {
