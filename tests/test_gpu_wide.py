@@ -270,7 +270,8 @@ def test_wide_batched_host_model_matches_the_oracle(kind):
 
 
 def test_wide_batched_model_through_sample():
-    """tda.sample with a BatchedModel at 80 parameters returns backend hip (0.4: the host protocol chain by chain)"""
+    """tda.sample with a BatchedModel at 80 parameters returns backend hip (0.4: the host protocol chain by chain), single level and as
+    a Delayed-Acceptance hierarchy of two batched models"""
     import warnings
 
     import scipy.stats as stats
@@ -290,3 +291,81 @@ def test_wide_batched_model_through_sample():
     link = res["chain_5"][-1]
     ref = post.create_link(link.parameters)
     np.testing.assert_allclose([link.prior, link.likelihood], [ref.prior, ref.likelihood], rtol=1e-10)
+    coarse = tda.Posterior(post.prior, tda.GaussianLogLike(y[:20], 0.0025 * np.eye(20)), tda.BatchedModel(lambda th: np.tanh(th @ A[:20].T), 20))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", tda.HostFallbackWarning)
+        da = tda.sample([coarse, post], tda.CrankNicolson(scaling=0.05), 20, n_chains=n_chains, subchain_length=3, seed=2)
+    assert da["backend"] == "hip" and da["sampler"] == "DA"
+    lk = da["chain_fine_3"][-1]
+    rf = post.create_link(lk.parameters)
+    np.testing.assert_allclose([lk.prior, lk.likelihood], [rf.prior, rf.likelihood], rtol=1e-10)
+
+
+@pytest.mark.parametrize("case", ["da_pcn", "da_grw_random", "mlda_am", "mlda_mixed"])
+def test_wide_callback_hierarchy_matches_the_oracle(case):
+    """Delayed Acceptance / MLDA at 90 parameters with the levels behind batched host callbacks (host-sequenced level actions:
+    k_ext_level_action with a second parameter per lane; mlda_mixed: a LINEAR coarse level beside two callback levels, its outputs
+    from k_linear_outputs<128>; da_grw_random: randomised subchain lengths, the promoted state through ysnap) against the oracle
+    running the same NumPy models"""
+    from tests.test_gpu_multilevel import _oracle_uniforms
+    from tinyda_amd.engine import Engine
+
+    d, M, N = 90, 40, 17
+    rng = np.random.default_rng(16)
+    truth = 0.3 * rng.standard_normal(d)
+    Wb = 0.02 + 0.003 * ((np.arange(M)[:, None] * 7 + np.arange(d)[None, :] * 3) % 11)
+
+    def level_model(k):
+        def fn(theta):
+            theta = np.atleast_2d(theta)
+            return np.tanh(theta @ (Wb + 0.001 * (2 - k)).T) + 0.25 * (0.6 + 0.2 * k) * theta[:, [0]] * theta[:, [-1]]
+        return fn
+
+    if case.startswith("mlda"):
+        nl, sl, n_fine = 3, [3, 2], 10
+    else:
+        nl, sl, n_fine = 2, [4], 18
+    models = [level_model(k + (3 - nl)) for k in range(nl)]
+    A0 = rng.standard_normal((M, d)) / np.sqrt(d)
+    if case == "mlda_mixed":
+        models[0] = lambda th: np.atleast_2d(th) @ A0.T
+    y = models[-1](truth)[0] + 0.05 * rng.standard_normal(M)
+    theta0 = truth + 0.02 * rng.standard_normal((N, d))
+    pm, pv = np.zeros(d), np.ones(d)
+    noise = 0.05 ** 2 if case != "mlda_mixed" else 0.3 ** 2
+    randomize = case == "da_grw_random"
+    seed = 4712
+    e = Engine(N, d, seed=seed, n_levels=nl)
+    e.set_prior(pm, np.diag(pv))
+    for k in range(nl):
+        if case == "mlda_mixed" and k == 0:
+            e.set_level(0, A0, y, 0, noise)
+        else:
+            e.set_level_callback(k, models[k], y, 0, [noise])
+    C0 = _spd(rng, d, 2e-4 / d)
+    if case == "da_pcn":
+        e.set_proposal(1, None, scaling=0.01)
+        prop = dict(kind="pcn", scaling=0.01)
+    elif case == "da_grw_random":
+        e.set_proposal(0, C0, scaling=1.0, adaptive=True, gamma=1.02, period=15)
+        prop = dict(kind="grw", C=C0, scaling=1.0, adaptive=True, gamma=1.02, period=15)
+    else:
+        e.set_proposal(2, C0, t0=20, period=10, adaptive=True, gamma=1.02)
+        prop = dict(kind="am", C0=C0, t0=20, period=10, adaptive=True, gamma=1.02)
+    e.set_subchains(sl, randomize)
+    e.init(theta0)
+    rows = e.rows_per_level(n_fine)
+    z, _ = e.set_export(rows[0])
+    outs = e.run_levels_host(n_fine)
+    e.close()
+    us, ridx = _oracle_uniforms(seed, N, rows, sl, sl[0] if randomize else None)
+    prior = orc.MVNPrior(pm, np.diag(pv))
+    levels = [orc.CallableGaussianLevel(models[k], y, "iso", noise, prior) for k in range(nl)]
+    res, _ = orc.run_multilevel(levels, prop, sl, theta0, np.swapaxes(z, 0, 1), us, n_fine, ridx)
+    for k in range(nl):
+        ref = res[k]
+        sk = slice(1, None) if k == nl - 1 else slice(None)
+        assert np.array_equal(outs[k][2], ref["accepted"][:, sk].T), "level %d accept masks differ" % k
+        np.testing.assert_allclose(outs[k][1][:, :, 2], ref["logpost"][:, sk].T, rtol=1e-9 if case.startswith("mlda") else 1e-10)
+        np.testing.assert_allclose(outs[k][0], np.swapaxes(ref["theta"][:, sk], 0, 1), rtol=1e-8, atol=1e-10)
+    assert 0.0 < outs[0][2].mean() < 1.0

@@ -62,11 +62,11 @@ def _device_plan(posteriors, proposal, diagonal_error_model=False, error_model=N
             pc = np.asarray(low["prior_cov"])
             if ((len(posteriors) >= 2 and error_model is not None) or len(posteriors) > MAX_LEVELS_FULL
                     or type(proposal) not in (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis)
-                    or (low.get("A") is None and not ("batched" in low and len(posteriors) == 1))  # (a batched host model: single level)
+                    or (low.get("A") is None and "batched" not in low)  # (linear models and batched host models)
                     or getattr(proposal, "block_moments", False)
-                    or any(k in low for k in ("source", "rosenbrock", "prior_joint")) or ("batched" in low and len(posteriors) > 1)
+                    or any(k in low for k in ("source", "rosenbrock", "prior_joint"))
                     or low["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG) or np.count_nonzero(pc - np.diag(np.diag(pc)))):
-                return _no("more than 64 parameters are lowered for single-level chains, Delayed Acceptance and MLDA of linear models (single level: batched host models too) with "
+                return _no("more than 64 parameters are lowered for single-level chains, Delayed Acceptance and MLDA of linear models and batched host models with "
                            "isotropic / diagonal noise, a Gaussian prior with a diagonal covariance, GaussianRandomWalk / CrankNicolson / "
                            "AdaptiveMetropolis, no error model")
         if diagonal_error_model and low["noise_kind"] == _lib.NOISE_ADAPTIVE:

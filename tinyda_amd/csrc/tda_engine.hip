@@ -1001,7 +1001,7 @@ int ext_model_outputs(tda_engine* e, const Level& lv) {
   if (lv.model == MODEL_USER) return launch_user_eval(lv.ufn_eval, e->N, e->d, lv.m, lv.cb_prop.p, lv.cb_F.p, e->stream);
   if (lv.model == MODEL_LINEAR) {
     if (lv.Apk.p) {  // on the matrix cores, every operator fragment serving a 16-chain tile
-      DISPATCH_DPAD(e->DP, hipLaunchKernelGGL((k_linear_outputs<DPAD>), dim3((unsigned)(e->NP / 16)), dim3(256), 0, e->stream, (long long)e->N,
+      DISPATCH_DPAD_W(e->DP, hipLaunchKernelGGL((k_linear_outputs<DPAD>), dim3((unsigned)(e->NP / 16)), dim3(256), 0, e->stream, (long long)e->N,
                                               e->d, lv.m, lv.Apk.p, lv.ncb, lv.b_dev.p, lv.cb_prop.p, e->d, lv.cb_F.p));
       return TDA_OK;
     }
@@ -1019,7 +1019,7 @@ int ext_model_outputs(tda_engine* e, const Level& lv) {
 
 // outputs of a linear level with a packed operator at the states theta[N][ld] (a level's slab of the state array), into out[N][m]
 void linear_outputs_at(tda_engine* e, const Level& lv, const double* theta, int ld, double* out) {
-  DISPATCH_DPAD(e->DP, hipLaunchKernelGGL((k_linear_outputs<DPAD>), dim3((unsigned)(e->NP / 16)), dim3(256), 0, e->stream, (long long)e->N,
+  DISPATCH_DPAD_W(e->DP, hipLaunchKernelGGL((k_linear_outputs<DPAD>), dim3((unsigned)(e->NP / 16)), dim3(256), 0, e->stream, (long long)e->N,
                                           e->d, lv.m, lv.Apk.p, lv.ncb, lv.b_dev.p, theta, ld, out));
 }
 

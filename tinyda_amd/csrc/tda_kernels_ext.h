@@ -179,9 +179,10 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_accept(const ExtArgs a) 
     }
     if (a.rec_params && lj) a.rec_params[r * a.d + lane] = cur;
     if (a.rec_params && lj2) a.rec_params[r * a.d + lane + 64] = cur2;
-    if (a.pick && a.cnt == a.pick[c]) {  // the promoted state of this subchain (hierarchies: at most 64 parameters)
+    if (a.pick && a.cnt == a.pick[c]) {  // the promoted state of this subchain
       double* ys = a.ysnap + (size_t)c * (a.DP + 2);
       if (lane < a.DP) ys[lane] = lj ? cur : 0.0;
+      if (lane + 64 < a.DP) ys[lane + 64] = lj2 ? cur2 : 0.0;
       if (lane == 0) {
         ys[a.DP] = lp;
         ys[a.DP + 1] = ll;
@@ -326,7 +327,9 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_level_action(const ExtLe
   const double sse = ext_weighted_sse(a.F + (size_t)c * a.m, a.data, a.w, a.Pd, a.m, lane, ext_dyn_lds + (size_t)(threadIdx.x >> 6) * a.m);
   const double lln = (a.w || a.Pd) ? -0.5 * sse : -0.5 * sse / a.var;
   const double* ys = a.ysnap ? a.ysnap + (size_t)c * (a.DP + 2) : nullptr;
+  const bool lj2 = lane + 64 < a.d;  // (65 .. 128 parameters: a second parameter per lane)
   const double yj = lj ? (ys ? ys[lane] : TH(k)[lane]) : 0.0, xj = lj ? TH(q)[lane] : 0.0;
+  const double yj2 = lj2 ? (ys ? ys[lane + 64] : TH(k)[lane + 64]) : 0.0, xj2 = lj2 ? TH(q)[lane + 64] : 0.0;
   const double y_lp = ys ? ys[a.DP] : a.lp[(size_t)k * a.NP + c], y_ll = ys ? ys[a.DP + 1] : a.ll[(size_t)k * a.NP + c];
   const double x_lp = a.lp[(size_t)q * a.NP + c], x_ll = a.ll[(size_t)q * a.NP + c];
   const int pkq = PI(k, q);
@@ -341,10 +344,14 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_level_action(const ExtLe
   // alignment (chain.py:357-398; proposal.py:1469-1493): accept -> level q takes y; reject -> the levels below return to theta_q
   if (acc) {  // level q takes y -- and level q - 1 too, if y is a promoted intermediate state
     if (lane < a.DP) TH(q)[lane] = lj ? yj : 0.0;
+    if (lane + 64 < a.DP) TH(q)[lane + 64] = lj2 ? yj2 : 0.0;
     if (ys && lane < a.DP) TH(k)[lane] = lj ? yj : 0.0;
+    if (ys && lane + 64 < a.DP) TH(k)[lane + 64] = lj2 ? yj2 : 0.0;
   } else {
-    for (int j = 0; j < q; ++j)
+    for (int j = 0; j < q; ++j) {
       if (lane < a.DP) TH(j)[lane] = lj ? xj : 0.0;
+      if (lane + 64 < a.DP) TH(j)[lane + 64] = lj2 ? xj2 : 0.0;
+    }
   }
   if (lane == 0) {
     if (acc) {
@@ -377,6 +384,7 @@ __global__ void __launch_bounds__(64 * EXT_WAVES) k_ext_level_action(const ExtLe
     if (a.ring) a.ring[(size_t)(a.ring_pos % a.ring_P) * a.NP + c] = acc ? 1 : 0;
   }
   if (a.rec_params && lj) a.rec_params[c * a.d + lane] = acc ? yj : xj;
+  if (a.rec_params && lj2) a.rec_params[c * a.d + lane + 64] = acc ? yj2 : xj2;
 }
 
 }  // namespace tda
