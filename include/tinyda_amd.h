@@ -239,7 +239,7 @@ int tda_engine_set_level_rosenbrock(tda_engine* e, int level, double a, double b
 int tda_engine_set_subchains(tda_engine* e, const int32_t* lengths, int randomize);
 
 /* Adaptive error model (chain.py:268-305, 485-523; :643-678, 739-765): every level below the finest must have been set
- * with TDA_NOISE_ADAPTIVE (noise = m x m covariance), all levels share m <= 256 (dense model; 0.4: 128, still the limit beside callback / source-defined levels and DREAM(Z); the diagonal one: any m).  State-dependent
+ * with TDA_NOISE_ADAPTIVE (noise = m x m covariance), all levels share m <= 256 (dense model; 0.4: 128; the diagonal one: any m).  State-dependent
  * is two-level only. */
 int tda_engine_set_error_model(tda_engine* e, int kind);
 /* Error-model state of adaptive level `level` (HOST, any may be NULL): bias [n_chains][m], cov_inverse [n_chains][m][m]

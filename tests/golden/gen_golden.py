@@ -1058,6 +1058,7 @@ FIXTURES = {
     "g15_da_dreamz_random": lambda: g15_hier_dreamz("g15_da_dreamz_random", ms=(10, 24), sl=(4,), seed=1503, randomize=True),
     "g15_da_dreamz_aem": lambda: g15_hier_dreamz("g15_da_dreamz_aem", ms=(8, 8), sl=(3,), seed=1504, aem="state-independent"),
     "g15_da_dreamz_aem_dep": lambda: g15_hier_dreamz("g15_da_dreamz_aem_dep", ms=(8, 8), sl=(2,), seed=1505, aem="state-dependent"),
+    "g15_da_dreamz_aem_m160": lambda: g15_hier_dreamz("g15_da_dreamz_aem_m160", ms=(160, 160), sl=(3,), iters=14, n_chains=2, seed=1507, aem="state-independent"),
     "g15_mlda_dreamz_aem": lambda: g15_hier_dreamz("g15_mlda_dreamz_aem", ms=(8, 8, 8), sl=(3, 2), iters=20, seed=1506, aem="state-independent"),
     "g7_moments": g7_moments,
     "g16_get_samples": g16_get_samples,

@@ -259,7 +259,7 @@ def test_sample_api_dreamz_with_uniform_prior_components():
 @pytest.mark.parametrize("name,block", [("g15_da_dreamz", 0), ("g15_da_dreamz", 5), ("g15_mlda_dreamz", 0), ("g15_mlda_dreamz", 7),
                                         ("g15_da_dreamz_random", 0), ("g15_da_dreamz_random", 6),
                                         ("g15_da_dreamz_aem", 0), ("g15_da_dreamz_aem", 5), ("g15_da_dreamz_aem_dep", 0), ("g15_mlda_dreamz_aem", 0),
-                                        ("g15_mlda_dreamz_aem", 7)])
+                                        ("g15_mlda_dreamz_aem", 7), ("g15_da_dreamz_aem_m160", 0)])
 def test_dreamz_below_a_hierarchy_replay(eng_mod, golden, name, block):
     """DREAMZ as the base proposal of Delayed Acceptance / MLDA (the reference's MLDA notebook configuration,
     examples/Multilevel Delayed Acceptance.ipynb cells 20-23; proposal.py:1583-1613, chain.py:404-444) on the device: traces

@@ -207,11 +207,11 @@ def test_host_fallback_is_announced_with_the_rule_that_refused_the_problem():
     posts = [tda.Posterior(prior4, tda.AdaptiveGaussianLogLike(np.zeros(mo), 0.1 * np.eye(mo)), tda.LinearModel(rng.standard_normal((mo, 4)))),
              tda.Posterior(prior4, tda.GaussianLogLike(np.zeros(mo), 0.1 * np.eye(mo)), tda.LinearModel(rng.standard_normal((mo, 4))))]
     assert api._device_plan(posts, tda.CrankNicolson(), error_model="state-independent") is None and "AdaptiveGaussianLogLike" in api._refusal[0]
-    mo = api.MAX_AEM_OUTPUTS_HOST_SEQUENCED + 1  # ... and 128 below DREAM(Z) or beside host-sequenced levels
+    mo = 200  # ... and inside the limit also below DREAM(Z) (host-sequenced level actions: k_ext_aem_*<256>)
     posts = [tda.Posterior(prior4, tda.AdaptiveGaussianLogLike(np.zeros(mo), 0.1 * np.eye(mo)), tda.LinearModel(rng.standard_normal((mo, 4)))),
              tda.Posterior(prior4, tda.GaussianLogLike(np.zeros(mo), 0.1 * np.eye(mo)), tda.LinearModel(rng.standard_normal((mo, 4))))]
     assert api._device_plan(posts, tda.CrankNicolson(), error_model="state-independent") is not None
-    assert api._device_plan(posts, tda.DREAMZ(M0=20), error_model="state-independent") is None and "dense error model with more than 128" in api._refusal[0]
+    assert api._device_plan(posts, tda.DREAMZ(M0=20), error_model="state-independent") is not None
 
 
 def test_dense_error_model_with_a_dense_fine_level_falls_back_with_the_warning():

@@ -188,7 +188,7 @@ class _DreamzTap:
 
 
 @pytest.mark.parametrize("name", ["g15_da_dreamz", "g15_mlda_dreamz", "g15_da_dreamz_random", "g15_da_dreamz_aem", "g15_da_dreamz_aem_dep",
-                                  "g15_mlda_dreamz_aem"])
+                                  "g15_mlda_dreamz_aem", "g15_da_dreamz_aem_m160"])
 def test_dreamz_below_a_hierarchy_replay(golden, name):
     """DREAMZ as the base proposal of Delayed Acceptance / MLDA (the reference's MLDA notebook configuration) on the host driver;
     round 3: also with randomised subchains and with the state-independent / state-dependent error model"""

@@ -27,7 +27,7 @@ MAX_LEVELS = 6  # (0.5; five and six levels: no error model, no dense observatio
 MAX_LEVELS_FULL = 4
 MAX_PARAMETERS = 128  # (more than 64: no error models, see _device_plan)
 MAX_AEM_OUTPUTS = 256  # dense error model (0.5: 129 .. 256 on k_aem_refresh_big); hierarchies sequenced by the host: MAX_AEM_OUTPUTS_HOST_SEQUENCED
-MAX_AEM_OUTPUTS_HOST_SEQUENCED = 128
+MAX_AEM_OUTPUTS_HOST_SEQUENCED = 256  # (the same since k_ext_aem_*<256>)
 
 
 class HostFallbackWarning(UserWarning):

@@ -961,7 +961,7 @@ int ext_level_adaptive(tda_engine* /*e*/, Level& lv, int m, const double* data, 
     return fail(TDA_ERR_UNSUPPORTED, "AdaptiveGaussianLogLike on a callback / source-defined level is limited to m <= %d observations", (int)AEM_MP_MAX_EXT);
   std::vector<double> Lc;
   if (!cholesky_host(cov, m, Lc)) return fail(TDA_ERR_NUMERIC, "noise covariance is not positive definite");
-  const int MP = m <= 64 ? 64 : 128;
+  const int MP = m <= 64 ? 64 : (m <= 128 ? 128 : 256);
   lv.em_ld = MP;
   lv.cov_h.assign(cov, cov + (size_t)m * m);
   lv.ytil_h.assign(MP, 0.0);

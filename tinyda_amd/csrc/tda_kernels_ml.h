@@ -32,7 +32,7 @@ constexpr int MAXLEV = TDA_MAXLEV;  // levels of a hierarchy (0.5: six; the gene
 constexpr int AEM_MAXLEV = 4;       // ... under an error model (dense: AEMR_MAXSUM trackers are summed; diagonal: per-level register arrays), with a dense
                                     // observation covariance, and above 64 parameters
 constexpr int AEM_MP_MAX = 256;  // error-model output dimension limit; per-chain vectors / matrices in HBM have row stride 64, 128 or 256
-constexpr int AEM_MP_MAX_EXT = 128;  // ... of hierarchies sequenced by the host (callback / source-defined levels, DREAM(Z) below a hierarchy)
+constexpr int AEM_MP_MAX_EXT = 256;  // ... of hierarchies sequenced by the host (callback / source-defined levels, DREAM(Z) below a hierarchy): the same since k_ext_aem_*<256>
 enum : uint32_t { STREAM_INDEX = 3 };
 
 struct MLArgs {
@@ -1055,6 +1055,7 @@ __global__ void __launch_bounds__(MPT) k_ext_aem_action(const ExtAemArgs a) {
       if ((lane & 63) == 0) s_x[lane >> 6] = v;
       __syncthreads();
       v = s_x[0] + s_x[1];
+      if constexpr (NW == 4) v += s_x[2] + s_x[3];
     }
     return v;
   };
@@ -1070,6 +1071,7 @@ __global__ void __launch_bounds__(MPT) k_ext_aem_action(const ExtAemArgs a) {
       if ((lane & 63) == 0) s_x[lane >> 6] = s;
       __syncthreads();
       s = s_x[0] + s_x[1];
+      if constexpr (NW == 4) s += s_x[2] + s_x[3];
     }
     return -0.5 * s;
   };
@@ -1258,6 +1260,7 @@ __global__ void __launch_bounds__(MPT) k_ext_aem_accept(const ExtAemAcceptArgs a
       if ((lane & 63) == 0) s_x[lane >> 6] = v;
       __syncthreads();
       v = s_x[0] + s_x[1];
+      if constexpr (NW == 4) v += s_x[2] + s_x[3];
     }
     return v;
   };
@@ -1274,6 +1277,7 @@ __global__ void __launch_bounds__(MPT) k_ext_aem_accept(const ExtAemAcceptArgs a
       if ((lane & 63) == 0) s_x[lane >> 6] = sq;
       __syncthreads();
       sq = s_x[0] + s_x[1];
+      if constexpr (NW == 4) sq += s_x[2] + s_x[3];
     }
     ll_n = -0.5 * sq;
   }
