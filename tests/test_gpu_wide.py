@@ -117,6 +117,15 @@ def test_sample_runs_100_parameters_on_the_device():
     mid = tda.Posterior(post.prior, tda.GaussianLogLike(y[:120], 0.0025 * np.eye(120)), tda.LinearModel(A[:120]))
     ml = tda.sample([coarse, mid, post], tda.CrankNicolson(scaling=0.02), 12, n_chains=8, subchain_length=[2, 2], seed=4)  # three-level MLDA
     assert ml["backend"] == "hip" and ml["sampler"] == "MLDA"
+    Lp = np.eye(d) + 0.05 * np.tril(rng.standard_normal((d, d)), -1)
+    dense = tda.Posterior(stats.multivariate_normal(np.zeros(d), Lp @ Lp.T), post.likelihood, post.model)  # a dense prior covariance
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", tda.HostFallbackWarning)
+        dn = tda.sample(dense, tda.GaussianRandomWalk(1e-4 * np.eye(d), adaptive=True, period=50), 60, n_chains=8, seed=6)
+    assert dn["backend"] == "hip"
+    lk = dn["chain_2"][-1]
+    rf = dense.create_link(lk.parameters)
+    np.testing.assert_allclose([lk.prior, lk.likelihood], [rf.prior, rf.likelihood], rtol=1e-10)
     acoarse = tda.Posterior(post.prior, tda.AdaptiveGaussianLogLike(y[:50], 0.0025 * np.eye(50)), tda.LinearModel(0.9 * A[:50]))  # (an error model: same outputs on both levels)
     with pytest.warns(tda.HostFallbackWarning, match="more than 64 parameters are lowered for single-level chains, Delayed Acceptance and MLDA"):
         tda.sample([acoarse, coarse], tda.CrankNicolson(scaling=0.05), 2, n_chains=1, subchain_length=2, adaptive_error_model="state-independent")
@@ -369,3 +378,75 @@ def test_wide_callback_hierarchy_matches_the_oracle(case):
         np.testing.assert_allclose(outs[k][1][:, :, 2], ref["logpost"][:, sk].T, rtol=1e-9 if case.startswith("mlda") else 1e-10)
         np.testing.assert_allclose(outs[k][0], np.swapaxes(ref["theta"][:, sk], 0, 1), rtol=1e-8, atol=1e-10)
     assert 0.0 < outs[0][2].mean() < 1.0
+
+
+@pytest.mark.parametrize("case", ["dense_am", "dense_da_pcn", "joint_grw", "joint_mlda_am"])
+def test_wide_dense_and_joint_priors_against_the_oracle(case):
+    """65 .. 128 parameters under a Gaussian prior with a DENSE covariance (whitening product on the matrix cores, 8 x 8 fragment blocks)
+    and under a JointPrior of normal and uniform components (support bounds tested per proposal): single level and hierarchies"""
+    from tests.test_gpu_multilevel import _oracle_uniforms
+    from tinyda_amd.engine import Engine
+
+    d, N = (100 if case.startswith("dense") else 90), 18
+    rng = np.random.default_rng(31)
+    truth = 0.3 * rng.standard_normal(d)
+    hier = "da" in case or "mlda" in case
+    ms = (30, 80) if "da" in case else ((24, 48, 96) if "mlda" in case else (120,))
+    sl = [3] if "da" in case else ([3, 2] if "mlda" in case else [])
+    nl = len(ms)
+    As = [rng.standard_normal((m, d)) / np.sqrt(d) for m in ms]
+    ys = [A @ truth + 0.1 * rng.standard_normal(len(A)) for A in As]
+    theta0 = truth + 0.02 * rng.standard_normal((N, d))
+    seed = 77
+    e = Engine(N, d, seed=seed, n_levels=nl)
+    if case.startswith("dense"):
+        pm = 0.05 * rng.standard_normal(d)
+        pc = _spd(rng, d, 1.0 / d) + 0.5 * np.eye(d)
+        e.set_prior(pm, pc)
+        prior = orc.MVNPrior(pm, pc)
+    else:
+        kinds = np.zeros(d, dtype=np.int32)
+        kinds[[0, 2, 70, 89]] = 1  # uniform components, two of them beyond lane 64
+        loc = np.where(kinds == 1, truth - 0.4, 0.0)
+        scale = np.where(kinds == 1, 0.8, 1.0)
+        e.set_prior_joint(kinds, loc, scale)
+        prior = orc.JointPriorOracle(kinds, loc, scale)
+    for k in range(nl):
+        e.set_level(k, As[k], ys[k], 0, 0.01)
+    C0 = _spd(rng, d, 4e-3 / d)
+    if case.endswith("am"):
+        e.set_proposal(2, C0, t0=16, period=8, adaptive=True, gamma=1.02)
+        prop = dict(kind="am", C0=C0, t0=16, period=8, adaptive=True, gamma=1.02)
+    elif case.endswith("pcn"):
+        e.set_proposal(1, None, scaling=0.03)
+        prop = dict(kind="pcn", scaling=0.03)
+    else:
+        e.set_proposal(0, C0, scaling=1.0, adaptive=True, gamma=1.02, period=8)
+        prop = dict(kind="grw", C=C0, scaling=1.0, adaptive=True, gamma=1.02, period=8)
+    if hier:
+        e.set_subchains(sl, False)
+        e.init(theta0)
+        n_fine = 12
+        rows = e.rows_per_level(n_fine)
+        z, _ = e.set_export(rows[0])
+        outs = e.run_levels_host(n_fine)
+        e.close()
+        us, _ = _oracle_uniforms(seed, N, rows, sl)
+        levels = [orc.LinearGaussianLevel(As[k], ys[k], "iso", 0.01, prior) for k in range(nl)]
+        res, _ = orc.run_multilevel(levels, prop, sl, theta0, np.swapaxes(z, 0, 1), us, n_fine, None)
+        for k in range(nl):
+            sk = slice(1, None) if k == nl - 1 else slice(None)
+            assert np.array_equal(outs[k][2], res[k]["accepted"][:, sk].T), "level %d accept masks differ" % k
+            np.testing.assert_allclose(outs[k][1][:, :, 2], res[k]["logpost"][:, sk].T, rtol=1e-9 if case.endswith("am") else 1e-10)
+        assert 0.0 < outs[0][2].mean() < 1.0
+    else:
+        T = 70
+        e.init(theta0)
+        z, u = e.set_export(T)
+        params, stats, acc = e.run_host(T)
+        e.close()
+        lvl = orc.LinearGaussianLevel(As[0], ys[0], "iso", 0.01, prior)
+        ref = orc.run_mh(lvl, prop, theta0, np.swapaxes(z, 0, 1), np.swapaxes(u, 0, 1))
+        assert np.array_equal(acc, np.swapaxes(ref["accepted"][:, 1:], 0, 1))
+        np.testing.assert_allclose(stats[:, :, 2], np.swapaxes(ref["logpost"][:, 1:], 0, 1), rtol=1e-9 if case.endswith("am") else 1e-10)
+        assert 0.0 < acc.mean() < 1.0

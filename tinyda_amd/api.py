@@ -57,18 +57,18 @@ def _device_plan(posteriors, proposal, diagonal_error_model=False, error_model=N
         if low is None or low["prior_mean"].shape[0] > MAX_PARAMETERS:
             return _no("a posterior the engine cannot lower (an opaque Python model, a prior other than scipy's multivariate normal / JointPrior of norm and uniform, a likelihood outside GaussianLogLike's classes)" if low is None else "more than %d parameters" % MAX_PARAMETERS)
         if low["prior_mean"].shape[0] > 64:
-            # 65 .. 128 parameters (0.5, tda_kernels_wide.h): single-level chains, Delayed Acceptance and MLDA (up to four levels), linear models with isotropic / diagonal noise, a Gaussian
-            # prior with a diagonal covariance, GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis
+            # 65 .. 128 parameters (0.5, tda_kernels_wide.h): single-level chains, Delayed Acceptance and MLDA (up to four levels), linear models with isotropic / diagonal noise, Gaussian priors (diagonal or dense covariance)
+            # and JointPrior, GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis
             pc = np.asarray(low["prior_cov"])
             if ((len(posteriors) >= 2 and error_model is not None) or len(posteriors) > MAX_LEVELS_FULL
                     or type(proposal) not in (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis)
                     or (low.get("A") is None and "batched" not in low)  # (linear models and batched host models)
                     or getattr(proposal, "block_moments", False)
-                    or any(k in low for k in ("source", "rosenbrock", "prior_joint"))
-                    or low["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG) or np.count_nonzero(pc - np.diag(np.diag(pc)))):
+                    or any(k in low for k in ("source", "rosenbrock"))
+                    or ("batched" in low and np.count_nonzero(pc - np.diag(np.diag(pc))))  # (callback models: diagonal prior covariance, as at any width)
+                    or low["noise_kind"] not in (_lib.NOISE_ISO, _lib.NOISE_DIAG)):
                 return _no("more than 64 parameters are lowered for single-level chains, Delayed Acceptance and MLDA of linear models and batched host models with "
-                           "isotropic / diagonal noise, a Gaussian prior with a diagonal covariance, GaussianRandomWalk / CrankNicolson / "
-                           "AdaptiveMetropolis, no error model")
+                           "isotropic / diagonal noise, GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis, no error model")
         if diagonal_error_model and low["noise_kind"] == _lib.NOISE_ADAPTIVE:
             # diagonal error model: the adaptive likelihood's covariance must be diagonal and travels as its diagonal
             cov = np.asarray(low["noise"], dtype=np.float64)
