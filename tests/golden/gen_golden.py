@@ -1047,6 +1047,13 @@ FIXTURES = {
                                                 iters=20, n_chains=2, seed=832, beta=0.06),
     "g8_mlda_aem_m160": lambda: g8_mlda_aem("g8_mlda_aem_m160", d=5, m=160, sl=(3, 2), iters=8, n_chains=2, seed=833,
                                             prop_var=0.003),
+    # error models at 65 .. 128 parameters (round 5: k_ml_steps<128, 1>, k_aem_action<128 | 256> with a parameter per thread)
+    "g8_da_aem_indep_d80": lambda: g8_da_aem("g8_da_aem_indep_d80", "state-independent", d=80, m=72, L=3, iters=14, n_chains=2,
+                                             seed=841, prop_var=0.0004),
+    "g8_da_aem_dep_pcn_d96": lambda: g8_da_aem("g8_da_aem_dep_pcn_d96", "state-dependent", proposal_kind="pcn", d=96, m=100, L=1,
+                                               iters=20, n_chains=2, seed=842, beta=0.05),
+    "g8_mlda_aem_d72": lambda: g8_mlda_aem("g8_mlda_aem_d72", d=72, m=40, sl=(3, 2), iters=8, n_chains=2, seed=843,
+                                           prop_var=0.0004),
     "g5_mlda_am": lambda: g5_mlda("g5_mlda_am", "am", period=10),
     "g5_mlda_grw_adaptive": lambda: g5_mlda("g5_mlda_grw_adaptive", "grw", adaptive=True, period=7, seed=502),
     "g5_mlda_4level": lambda: g5_mlda("g5_mlda_4level", "am", ms=(6, 10, 16, 24), sl=(3, 2, 2), iters=20, period=10, seed=503),

@@ -54,7 +54,8 @@ def _check(outs, g, nl, st_init):
 
 
 @pytest.mark.parametrize("name", ["g8_da_aem_indep", "g8_da_aem_dep", "g8_da_aem_dep_pcn", "g8_da_aem_indep_m72", "g8_da_aem_dep_pcn_m128",
-                                  "g8_da_aem_indep_m200", "g8_da_aem_dep_pcn_m256"])
+                                  "g8_da_aem_indep_m200", "g8_da_aem_dep_pcn_m256",
+                                  "g8_da_aem_indep_d80", "g8_da_aem_dep_pcn_d96"])
 def test_da_error_model_replay(eng_mod, golden, name):
     g = golden(name)
     L = int(g["subchain_length"])
@@ -72,7 +73,7 @@ def test_da_error_model_replay(eng_mod, golden, name):
     e.close()
 
 
-@pytest.mark.parametrize("name", ["g8_mlda_aem", "g8_mlda_aem_m100", "g8_mlda_aem_m160"])
+@pytest.mark.parametrize("name", ["g8_mlda_aem", "g8_mlda_aem_m100", "g8_mlda_aem_m160", "g8_mlda_aem_d72"])
 def test_mlda_error_model_replay(eng_mod, golden, name):
     g = golden(name)
     nl = int(g["n_levels"])

@@ -87,8 +87,8 @@ def test_wide_single_level_against_the_oracle(case):
 
 def test_sample_runs_100_parameters_on_the_device():
     """tda.sample() at 100 parameters returns "backend": "hip" (0.4: the host protocol, with a HostFallbackWarning) and a chain that has
-    moved towards the data; Delayed Acceptance and three-level MLDA at 100 parameters run there too; an error model above 64 parameters
-    still falls back, announced"""
+    moved towards the data; Delayed Acceptance and three-level MLDA at 100 parameters run there too; the dense error model too; the diagonal error model above 64
+    parameters still falls back, announced"""
     import warnings
 
     import scipy.stats as stats
@@ -127,8 +127,16 @@ def test_sample_runs_100_parameters_on_the_device():
     rf = dense.create_link(lk.parameters)
     np.testing.assert_allclose([lk.prior, lk.likelihood], [rf.prior, rf.likelihood], rtol=1e-10)
     acoarse = tda.Posterior(post.prior, tda.AdaptiveGaussianLogLike(y[:50], 0.0025 * np.eye(50)), tda.LinearModel(0.9 * A[:50]))  # (an error model: same outputs on both levels)
+    with warnings.catch_warnings():  # the dense error model at 100 parameters: on the device (k_ml_steps<128, 1> + k_aem_action<128>)
+        warnings.simplefilter("error", tda.HostFallbackWarning)
+        em = tda.sample([acoarse, coarse], tda.CrankNicolson(scaling=0.02), 10, n_chains=6, subchain_length=2, adaptive_error_model="state-independent", seed=7)
+    assert em["backend"] == "hip" and em["sampler"] == "DA"
+    lk = em["chain_fine_1"][-1]
+    rf = coarse.create_link(lk.parameters)
+    np.testing.assert_allclose([lk.prior, lk.likelihood], [rf.prior, rf.likelihood], rtol=1e-10)
     with pytest.warns(tda.HostFallbackWarning, match="more than 64 parameters are lowered for single-level chains, Delayed Acceptance and MLDA"):
-        tda.sample([acoarse, coarse], tda.CrankNicolson(scaling=0.05), 2, n_chains=1, subchain_length=2, adaptive_error_model="state-independent")
+        tda.sample([acoarse, coarse], tda.CrankNicolson(scaling=0.05), 2, n_chains=1, subchain_length=2, adaptive_error_model="state-independent",
+                   error_model_covariance="diagonal")
 
 
 DA_CASES = [(96, (24, 70), 3, 17, 12, "pcn"), (128, (33, 130), 4, 16, 9, "am"), (80, (16, 40), 2, 20, 15, "grw_adaptive"), (100, (20, 65), 3, 18, 10, "pcn_random"),

@@ -32,7 +32,8 @@ def _compare(res, g, nl, accepted_only=False):
 
 
 @pytest.mark.parametrize("name", ["g8_da_aem_indep", "g8_da_aem_dep", "g8_da_aem_dep_pcn", "g8_da_aem_indep_m72", "g8_da_aem_dep_pcn_m128",
-                                  "g8_da_aem_indep_m200", "g8_da_aem_dep_pcn_m256"])
+                                  "g8_da_aem_indep_m200", "g8_da_aem_dep_pcn_m256",
+                                  "g8_da_aem_indep_d80", "g8_da_aem_dep_pcn_d96"])
 def test_da_with_error_model(golden, name):
     g = golden(name)
     L = int(g["subchain_length"])
@@ -44,7 +45,7 @@ def test_da_with_error_model(golden, name):
     np.testing.assert_allclose(st[key][1], g["bias_sigma"], rtol=1e-8, atol=1e-12)
 
 
-@pytest.mark.parametrize("name", ["g8_mlda_aem", "g8_mlda_aem_m100", "g8_mlda_aem_m160"])
+@pytest.mark.parametrize("name", ["g8_mlda_aem", "g8_mlda_aem_m100", "g8_mlda_aem_m160", "g8_mlda_aem_d72"])
 def test_mlda_with_error_model(golden, name):
     g = golden(name)
     nl = int(g["n_levels"])

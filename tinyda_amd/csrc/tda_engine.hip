@@ -797,6 +797,7 @@ int launch_ml<128>(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st, i
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, st, a);
     return TDA_OK;
   };
+  if (!a.cascade && !a.randomize) return go(&k_ml_steps<128, 1>);  // (dense error model: the base level alone, level actions sequenced by the host)
   switch (a.nlev) {
     case 2: return go(&k_ml_steps<128, 2>);
     case 3: return go(&k_ml_steps<128, 3>);
