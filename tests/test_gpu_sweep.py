@@ -9,7 +9,8 @@ from oracle import tinyda_oracle as orc
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-10
-AM_LOOSE_RTOL = 3e-10  # AdaptiveMetropolis runs whose log-posterior leaves 1e-10 (see the big sweep below)
+AM_LOOSE_RTOL = 5e-10  # AdaptiveMetropolis runs whose log-posterior leaves 1e-10 (see the big sweep below): none above 2.2e-10 in the 1 480
+                       # configurations of TINYDA_SWEEP=740, three at 3.0 - 3.2e-10 in the 5 000 of TINYDA_SWEEP=2500 (profiles/r05_sweep_report_5000.json)
 
 
 def _spd(rng, n, scale):
