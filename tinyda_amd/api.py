@@ -25,7 +25,7 @@ _DEVICE_PROPOSALS = (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis, DREA
 
 MAX_LEVELS = 6  # (0.5; five and six levels: no error model, no dense observation covariance, at most 64 parameters -- MAX_LEVELS_FULL otherwise)
 MAX_LEVELS_FULL = 4
-MAX_PARAMETERS = 128  # (more than 64: no error models, see _device_plan)
+MAX_PARAMETERS = 128  # (more than 64: GRW / pCN / AdaptiveMetropolis, see _device_plan)
 MAX_AEM_OUTPUTS = 256  # dense error model (0.5: 129 .. 256 on k_aem_refresh_big); hierarchies sequenced by the host: MAX_AEM_OUTPUTS_HOST_SEQUENCED
 MAX_AEM_OUTPUTS_HOST_SEQUENCED = 256  # (the same since k_ext_aem_*<256>)
 
