@@ -238,3 +238,47 @@ def test_mlda_dreamz_full_size(eng_mod):
     assert not (A1 & ~A0.any(axis=2)).any()
     assert not (outs[2][2].astype(bool) & ~A1.any(axis=1)).any()
     assert 0.02 < outs[0][2].mean() < 0.98
+
+
+def test_128_parameters_full_size(eng_mod):
+    """round 5: 4096 chains at 128 parameters, 1024 observations, AdaptiveMetropolis across two covariance swaps, and Delayed
+    Acceptance 256 / 2048 under pCN -- the same invariants as at 64 parameters: finite records, posterior = prior + likelihood,
+    recorded states re-evaluated by the oracle to 1e-10, rejected steps leave the state alone, every chain's swapped-in covariance
+    symmetric and positive on the diagonal"""
+    d, N, T = 128, 4096, 220
+    (A, y), = _levels((1024,), d=d)
+    e = eng_mod.Engine(N, d, seed=5)
+    e.set_prior(np.zeros(d), np.eye(d))
+    e.set_level(0, A, y, 0, 0.01)
+    e.set_proposal(2, 1e-4 * np.eye(d), t0=100, period=100)
+    e.init(None)
+    th0, _ = e.current()
+    P, S, Acc = e.run_host(T)
+    st = e.proposal_state(want_am=True)
+    e.close()
+    lvl = orc.LinearGaussianLevel(A, y, "iso", 0.01, orc.MVNPrior(np.zeros(d), np.eye(d)))
+    _check_level_records(P, S, Acc, th0, lvl, 96, 3)
+    prev = np.concatenate([th0[None], P[:-1]])
+    assert np.array_equal(P[Acc == 0], prev[Acc == 0]), "a rejected step changed the state"
+    assert 0.02 < Acc.mean() < 0.98
+    C = np.asarray(st["C"])
+    assert C.shape == (N, d, d) and np.isfinite(C).all() and np.allclose(C, np.swapaxes(C, 1, 2), rtol=1e-9, atol=1e-14) and (np.einsum("cii->ci", C) > 0).all()
+    lv = _levels((256, 2048), d=d)
+    L, n_fine = 10, 12
+    e = eng_mod.Engine(N, d, seed=6, n_levels=2)
+    e.set_prior(np.zeros(d), np.eye(d))
+    for k, (Ak, yk) in enumerate(lv):
+        e.set_level(k, Ak, yk, 0, 0.01)
+    e.set_proposal(1, None, scaling=0.02)
+    e.set_subchains([L])
+    e.init(None)
+    th0, _ = e.level_state(1)
+    (Pc, Sc, Ac), (Pf, Sf, Af) = e.run_levels_host(n_fine)
+    e.close()
+    prior = orc.MVNPrior(np.zeros(d), np.eye(d))
+    levels = [orc.LinearGaussianLevel(Ak, yk, "iso", 0.01, prior) for Ak, yk in lv]
+    _check_level_records(Pc, Sc, Ac, th0, levels[0], 96, 4)
+    _check_level_records(Pf, Sf, Af, th0, levels[1], 96, 5)
+    any_coarse = Ac.reshape(n_fine, L, N).any(axis=1)
+    assert not (Af.astype(bool) & ~any_coarse).any()
+    assert 0.0 < Af.mean() <= 1.0
