@@ -458,3 +458,42 @@ def test_wide_dense_and_joint_priors_against_the_oracle(case):
         assert np.array_equal(acc, np.swapaxes(ref["accepted"][:, 1:], 0, 1))
         np.testing.assert_allclose(stats[:, :, 2], np.swapaxes(ref["logpost"][:, 1:], 0, 1), rtol=1e-9 if case.endswith("am") else 1e-10)
         assert 0.0 < acc.mean() < 1.0
+
+
+@pytest.mark.parametrize("hier", [False, True])
+def test_wide_results_do_not_depend_on_sharding(hier):
+    """chains keyed by global id at 100 parameters too: one engine with 35 chains == two engines with 16 and 19 (offsets 0 and 16), bit
+    for bit -- what `bench.py --gpus N` and sample(distributed=True) rely on (single level: AdaptiveMetropolis across swaps; hier:
+    three-level MLDA)"""
+    from tinyda_amd.engine import Engine
+
+    d, n_all, cut = 100, 35, 16
+    rng = np.random.default_rng(12)
+    truth = 0.3 * rng.standard_normal(d)
+    ms = (24, 60, 150) if hier else (150,)
+    As = [rng.standard_normal((m, d)) / np.sqrt(d) for m in ms]
+    ys = [A @ truth + 0.1 * rng.standard_normal(len(A)) for A in As]
+    theta0 = truth + 0.02 * rng.standard_normal((n_all, d))
+    C0 = _spd(rng, d, 4e-3 / d)
+
+    def run(n, off, th0):
+        e = Engine(n, d, seed=9, chain_offset=off, n_levels=len(ms))
+        e.set_prior(np.zeros(d), np.eye(d))
+        for k in range(len(ms)):
+            e.set_level(k, As[k], ys[k], 0, 0.01)
+        e.set_proposal(2, C0, t0=20, period=20, adaptive=True)
+        if hier:
+            e.set_subchains([3, 2])
+            e.init(th0)
+            outs = e.run_levels_host(10)
+            e.close()
+            return [a for o in outs for a in o]
+        e.init(th0)
+        out = e.run_host(90)
+        e.close()
+        return list(out)
+
+    full = run(n_all, 0, theta0)
+    lo, hi = run(cut, 0, theta0[:cut]), run(n_all - cut, cut, theta0[cut:])
+    for k in range(len(full)):
+        assert np.array_equal(full[k][:, :cut], lo[k]) and np.array_equal(full[k][:, cut:], hi[k]), k
