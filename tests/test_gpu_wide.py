@@ -497,3 +497,87 @@ def test_wide_results_do_not_depend_on_sharding(hier):
     lo, hi = run(cut, 0, theta0[:cut]), run(n_all - cut, cut, theta0[cut:])
     for k in range(len(full)):
         assert np.array_equal(full[k][:, :cut], lo[k]) and np.array_equal(full[k][:, cut:], hi[k]), k
+
+
+WIDE_SRC = """
+__device__ double tda_forward(const double* theta, int dim, int o) {
+  double s = 0.0;
+  for (int j = 0; j < dim; ++j) s += (0.02 + 0.003 * ((o * 7 + j * 3) %% 11) + %(shift).4f) * theta[j];
+  const double q = theta[o %% dim] * theta[(o + 70) %% dim];  // (a coupling that reaches parameters beyond lane 64)
+  return sin(s) + %(coup).4f * q;
+}
+"""
+
+
+def _wide_src_twin(shift, coup, m=23):
+    def fn(theta):
+        theta = np.atleast_2d(theta)
+        N, d = theta.shape
+        out = np.empty((N, m))
+        for o in range(m):
+            s = np.zeros(N)
+            for j in range(d):  # same summation order as the device code
+                s = s + (0.02 + 0.003 * ((o * 7 + j * 3) % 11) + float("%.4f" % shift)) * theta[:, j]
+            out[:, o] = np.sin(s) + float("%.4f" % coup) * (theta[:, o % d] * theta[:, (o + 70) % d])
+        return out
+    return fn
+
+
+@pytest.mark.parametrize("case", ["am", "pcn", "da_pcn", "mlda_am"])
+def test_wide_source_defined_models_match_the_oracle(case):
+    """source-defined (hiprtc-compiled) forward models at 96 parameters: the fused step kernel and the fused level action of the
+    compiled module hold two parameters per lane; single level and hierarchies against the oracle running the NumPy twins"""
+    from tests.test_gpu_multilevel import _oracle_uniforms
+    from tinyda_amd.engine import Engine
+
+    d, m, N = 96, 23, 17
+    rng = np.random.default_rng(21)
+    truth = 0.3 * rng.standard_normal(d)
+    hier = case.startswith("da") or case.startswith("mlda")
+    cfgs = [dict(shift=0.0, coup=0.5)] if not hier else ([dict(shift=0.002, coup=0.4), dict(shift=0.0, coup=0.5)] if case.startswith("da")
+                                                        else [dict(shift=0.004, coup=0.3), dict(shift=0.002, coup=0.4), dict(shift=0.0, coup=0.5)])
+    nl = len(cfgs)
+    twins = [_wide_src_twin(c["shift"], c["coup"]) for c in cfgs]
+    y = twins[-1](truth)[0] + 0.05 * rng.standard_normal(m)
+    theta0 = truth + 0.02 * rng.standard_normal((N, d))
+    pm, pv = np.zeros(d), np.ones(d)
+    seed = 993
+    e = Engine(N, d, seed=seed, n_levels=nl, block_steps=0 if hier else 33)
+    e.set_prior(pm, np.diag(pv))
+    for k in range(nl):
+        e.set_level_source(k, WIDE_SRC % cfgs[k], y, 0, [0.05 ** 2])
+    C0 = _spd(rng, d, 2e-4 / d)
+    if case.endswith("am"):
+        e.set_proposal(2, C0, t0=20, period=10, adaptive=True, gamma=1.02)
+        prop = dict(kind="am", C0=C0, t0=20, period=10, adaptive=True, gamma=1.02)
+    else:
+        e.set_proposal(1, None, scaling=0.01, adaptive=True, gamma=1.02, period=15)
+        prop = dict(kind="pcn", scaling=0.01, adaptive=True, gamma=1.02, period=15)
+    prior = orc.MVNPrior(pm, np.diag(pv))
+    levels = [orc.CallableGaussianLevel(twins[k], y, "iso", 0.05 ** 2, prior) for k in range(nl)]
+    if hier:
+        sl = [3] if nl == 2 else [3, 2]
+        e.set_subchains(sl, False)
+        e.init(theta0)
+        n_fine = 10
+        rows = e.rows_per_level(n_fine)
+        z, _ = e.set_export(rows[0])
+        outs = e.run_levels_host(n_fine)
+        e.close()
+        us, _ = _oracle_uniforms(seed, N, rows, sl)
+        res, _ = orc.run_multilevel(levels, prop, sl, theta0, np.swapaxes(z, 0, 1), us, n_fine, None)
+        for k in range(nl):
+            sk = slice(1, None) if k == nl - 1 else slice(None)
+            assert np.array_equal(outs[k][2], res[k]["accepted"][:, sk].T), "level %d accept masks differ" % k
+            np.testing.assert_allclose(outs[k][1][:, :, 2], res[k]["logpost"][:, sk].T, rtol=1e-9 if case.endswith("am") else 1e-10)
+        assert 0.0 < outs[0][2].mean() < 1.0
+    else:
+        T = 80
+        e.init(theta0)
+        z, u = e.set_export(T)
+        params, stats, acc = e.run_host(T)
+        e.close()
+        ref = orc.run_mh(levels[0], prop, theta0, np.swapaxes(z, 0, 1), np.swapaxes(u, 0, 1))
+        assert np.array_equal(acc, np.swapaxes(ref["accepted"][:, 1:], 0, 1))
+        np.testing.assert_allclose(stats[:, :, 2], np.swapaxes(ref["logpost"][:, 1:], 0, 1), rtol=1e-9 if case == "am" else 1e-10)
+        assert 0.0 < acc.mean() < 1.0

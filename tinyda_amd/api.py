@@ -60,15 +60,15 @@ def _device_plan(posteriors, proposal, diagonal_error_model=False, error_model=N
             # 65 .. 128 parameters (0.5, tda_kernels_wide.h): single-level chains, Delayed Acceptance and MLDA (up to four levels), linear models with isotropic / diagonal noise, Gaussian priors (diagonal or dense covariance)
             # and JointPrior, GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis
             pc = np.asarray(low["prior_cov"])
-            if ((len(posteriors) >= 2 and error_model is not None and (diagonal_error_model or "batched" in low)) or len(posteriors) > MAX_LEVELS_FULL
+            if ((len(posteriors) >= 2 and error_model is not None and (diagonal_error_model or "batched" in low or "source" in low)) or len(posteriors) > MAX_LEVELS_FULL
                     or type(proposal) not in (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis)
-                    or (low.get("A") is None and "batched" not in low)  # (linear models and batched host models)
+                    or (low.get("A") is None and "batched" not in low and "source" not in low)  # (linear, source-defined and batched host models)
                     or getattr(proposal, "block_moments", False)
-                    or any(k in low for k in ("source", "rosenbrock"))
-                    or ("batched" in low and np.count_nonzero(pc - np.diag(np.diag(pc))))  # (callback models: diagonal prior covariance, as at any width)
+                    or "rosenbrock" in low
+                    or (("batched" in low or "source" in low) and np.count_nonzero(pc - np.diag(np.diag(pc))))  # (external models: diagonal prior covariance, as at any width)
                     or low["noise_kind"] not in ((_lib.NOISE_ISO, _lib.NOISE_DIAG, _lib.NOISE_ADAPTIVE) if (error_model is not None and not diagonal_error_model)
                                                  else (_lib.NOISE_ISO, _lib.NOISE_DIAG))):
-                return _no("more than 64 parameters are lowered for single-level chains, Delayed Acceptance and MLDA of linear models and batched host models with "
+                return _no("more than 64 parameters are lowered for single-level chains, Delayed Acceptance and MLDA of linear, source-defined and batched host models with "
                            "isotropic / diagonal noise, GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis (error models: the dense one over linear levels)")
         if diagonal_error_model and low["noise_kind"] == _lib.NOISE_ADAPTIVE:
             # diagonal error model: the adaptive likelihood's covariance must be diagonal and travels as its diagonal
