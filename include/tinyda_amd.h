@@ -98,7 +98,7 @@ typedef struct tda_config {
   int32_t device;        /* HIP device ordinal */
   int64_t n_chains;      /* chains held by this engine (rows of the state matrix) */
   int64_t chain_offset;  /* global id of local chain 0 */
-  int32_t dim;           /* parameter dimension d: 1..64; 0.5: 65..128 for single-level chains and hierarchies of two to four levels (linear models, tda_engine_set_level_source and tda_engine_set_level_callback; error models: the dense one over linear levels)
+  int32_t dim;           /* parameter dimension d: 1..64; 0.5: 65..128 for single-level chains and hierarchies of two to four levels (linear models, tda_engine_set_level_source and tda_engine_set_level_callback; error models: the dense one)
                           * with linear models, source-defined models or host callbacks, isotropic / diagonal noise, any prior the engine knows and TDA_PROP_GRW / TDA_PROP_PCN / TDA_PROP_AM --
                           * anything else at more than 64 parameters is refused by tda_engine_init with TDA_ERR_UNSUPPORTED */
   int32_t n_levels;      /* 1 = MH (sampler.py:213), 2 = Delayed Acceptance (:231), 3..6 = MLDA (:260); 0.5: 5 and 6 for the engine's own models without error model,

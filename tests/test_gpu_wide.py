@@ -581,3 +581,69 @@ def test_wide_source_defined_models_match_the_oracle(case):
         assert np.array_equal(acc, np.swapaxes(ref["accepted"][:, 1:], 0, 1))
         np.testing.assert_allclose(stats[:, :, 2], np.swapaxes(ref["logpost"][:, 1:], 0, 1), rtol=1e-9 if case == "am" else 1e-10)
         assert 0.0 < acc.mean() < 1.0
+
+
+@pytest.mark.parametrize("case", ["da_source", "mlda_mixed", "da_dep_pcn"])
+def test_wide_hierarchy_with_error_model_over_external_models(case):
+    """the dense error model at 96 parameters over source-defined levels, and over a linear surrogate + a batched host callback + a
+    source-defined finest level (k_ext_aem_action / k_ext_aem_accept with the error-model row stride at least 128: a thread is an
+    output AND a parameter) -- against the oracle's restatement of the reference's error-model chains running the NumPy twins"""
+    from tests.test_gpu_multilevel import _oracle_uniforms
+    from tinyda_amd.engine import Engine
+
+    d, m, N = 96, 23, 15
+    rng = np.random.default_rng(23)
+    truth = 0.3 * rng.standard_normal(d)
+    if case == "mlda_mixed":
+        cfgs, sl, n_fine = [None, dict(shift=0.002, coup=0.4), dict(shift=0.0, coup=0.5)], [3, 2], 10
+    else:
+        cfgs, sl, n_fine = [dict(shift=0.002, coup=0.4), dict(shift=0.0, coup=0.5)], [1 if case == "da_dep_pcn" else 3], 24 if case == "da_dep_pcn" else 14
+    aem = "state-dependent" if case == "da_dep_pcn" else "state-independent"
+    nl = len(cfgs)
+    Alin = np.array([[(0.02 + 0.003 * ((o * 7 + j * 3) % 11)) for j in range(d)] for o in range(m)])
+    blin = 0.01 * np.arange(m)
+    twins = [(lambda th: np.atleast_2d(th) @ Alin.T + blin) if c is None else _wide_src_twin(c["shift"], c["coup"]) for c in cfgs]
+    y = twins[-1](truth)[0] + 0.05 * rng.standard_normal(m)
+    theta0 = truth + 0.02 * rng.standard_normal((N, d))
+    pm, pv = np.zeros(d), np.ones(d)
+    var = 0.05 ** 2
+    cov = var * np.eye(m)
+    seed = 314
+    e = Engine(N, d, seed=seed, n_levels=nl)
+    e.set_prior(pm, np.diag(pv))
+    for i, c in enumerate(cfgs):
+        last = i == nl - 1
+        if c is None:
+            e.set_level(0, Alin, y, 3, cov, b=blin)
+        elif case == "mlda_mixed" and i == 1:
+            e.set_level_callback(1, twins[1], y, 3, cov)
+        else:
+            e.set_level_source(i, WIDE_SRC % c, y, 0 if last else 3, [var] if last else cov)
+    C0 = _spd(rng, d, 2e-4 / d)
+    if case == "da_dep_pcn":
+        e.set_proposal(1, None, scaling=0.01)
+        prop = dict(kind="pcn", scaling=0.01)
+    else:
+        e.set_proposal(0, C0, scaling=1.0)
+        prop = dict(kind="grw", C=C0, scaling=1.0)
+    e.set_subchains(sl, False)
+    e.set_error_model(aem)
+    e.init(theta0)
+    rows = e.rows_per_level(n_fine)
+    z, _ = e.set_export(rows[0])
+    outs = e.run_levels_host(n_fine)
+    bias, P = e.error_model_state(0, m)
+    e.close()
+    us, _ = _oracle_uniforms(seed, N, rows, sl)
+    prior = orc.MVNPrior(pm, np.diag(pv))
+    levels = [dict(fn=twins[i], y=y, prior=prior, **(dict(var=var) if i == nl - 1 else dict(cov=cov))) for i in range(nl)]
+    res = orc.run_multilevel_aem(levels, prop, sl, theta0, np.swapaxes(z, 0, 1), us, n_fine, aem)
+    res = res[0] if isinstance(res, tuple) else res
+    for i in range(nl):
+        ref = res[i]
+        sk = slice(1, None) if i == nl - 1 else slice(None)
+        assert np.array_equal(outs[i][2], np.asarray(ref["accepted"])[:, sk].T), "level %d accept masks differ" % i
+        np.testing.assert_allclose(outs[i][0], np.swapaxes(np.asarray(ref["theta"])[:, sk], 0, 1), rtol=1e-9, atol=1e-11)
+        if i == nl - 1:
+            np.testing.assert_allclose(outs[i][1][:, :, 2], (np.asarray(ref["logprior"]) + np.asarray(ref["loglike"]))[:, sk].T, rtol=1e-10)
+    assert 0.0 < outs[nl - 1][2].mean() <= 1.0 and np.all(np.isfinite(bias)) and np.all(np.isfinite(P))

@@ -60,7 +60,7 @@ def _device_plan(posteriors, proposal, diagonal_error_model=False, error_model=N
             # 65 .. 128 parameters (0.5, tda_kernels_wide.h): single-level chains, Delayed Acceptance and MLDA (up to four levels), linear models with isotropic / diagonal noise, Gaussian priors (diagonal or dense covariance)
             # and JointPrior, GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis
             pc = np.asarray(low["prior_cov"])
-            if ((len(posteriors) >= 2 and error_model is not None and (diagonal_error_model or "batched" in low or "source" in low)) or len(posteriors) > MAX_LEVELS_FULL
+            if ((len(posteriors) >= 2 and error_model is not None and diagonal_error_model) or len(posteriors) > MAX_LEVELS_FULL
                     or type(proposal) not in (GaussianRandomWalk, CrankNicolson, AdaptiveMetropolis)
                     or (low.get("A") is None and "batched" not in low and "source" not in low)  # (linear, source-defined and batched host models)
                     or getattr(proposal, "block_moments", False)
@@ -69,7 +69,7 @@ def _device_plan(posteriors, proposal, diagonal_error_model=False, error_model=N
                     or low["noise_kind"] not in ((_lib.NOISE_ISO, _lib.NOISE_DIAG, _lib.NOISE_ADAPTIVE) if (error_model is not None and not diagonal_error_model)
                                                  else (_lib.NOISE_ISO, _lib.NOISE_DIAG))):
                 return _no("more than 64 parameters are lowered for single-level chains, Delayed Acceptance and MLDA of linear, source-defined and batched host models with "
-                           "isotropic / diagonal noise, GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis (error models: the dense one over linear levels)")
+                           "isotropic / diagonal noise, GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis (error models: the dense one)")
         if diagonal_error_model and low["noise_kind"] == _lib.NOISE_ADAPTIVE:
             # diagonal error model: the adaptive likelihood's covariance must be diagonal and travels as its diagonal
             cov = np.asarray(low["noise"], dtype=np.float64)

@@ -957,12 +957,12 @@ void fill_ext_args(tda_engine* e, const Level& lv, ExtArgs& xa) {
 
 // AdaptiveGaussianLogLike on a callback / source-defined level: host and device copies of Sigma_e and the data vector in
 // the error-model layout (row stride 64 / 128), as tda_engine_set_level keeps them for linear levels
-int ext_level_adaptive(tda_engine* /*e*/, Level& lv, int m, const double* data, const double* cov) {
+int ext_level_adaptive(tda_engine* e, Level& lv, int m, const double* data, const double* cov) {
   if (m > AEM_MP_MAX_EXT)
     return fail(TDA_ERR_UNSUPPORTED, "AdaptiveGaussianLogLike on a callback / source-defined level is limited to m <= %d observations", (int)AEM_MP_MAX_EXT);
   std::vector<double> Lc;
   if (!cholesky_host(cov, m, Lc)) return fail(TDA_ERR_NUMERIC, "noise covariance is not positive definite");
-  const int MP = m <= 64 ? 64 : (m <= 128 ? 128 : 256);
+  const int MP = (m <= 64 && e->DP <= 64) ? 64 : (m <= 128 ? 128 : 256);  // (65 .. 128 parameters: a thread of the error-model kernels is a parameter too)
   lv.em_ld = MP;
   lv.cov_h.assign(cov, cov + (size_t)m * m);
   lv.ytil_h.assign(MP, 0.0);
