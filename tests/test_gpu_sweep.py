@@ -25,7 +25,7 @@ def _case(i, wide=False):
     N = int(rng.choice([1, 2, 15, 16, 17, 33, 50]))
     T = int(rng.choice([1, 37, 90, 140]))
     kind = str(rng.choice(["grw", "grw_adaptive", "pcn", "pcn_adaptive", "am", "am_adaptive"]))
-    noise = str(rng.choice(["iso", "diag"] if wide else ["iso", "diag", "dense"]))  # (65 .. 128 parameters: no dense observation covariance)
+    noise = str(rng.choice(["iso", "diag", "dense"]))
     prior = str(rng.choice(["identity", "diag", "dense"])) if "pcn" not in kind else str(rng.choice(["identity", "dense0"]))
     block = int(rng.choice([0, 0, 7, 16, 33]))
     split = bool(rng.integers(0, 2))

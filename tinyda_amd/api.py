@@ -67,6 +67,7 @@ def _device_plan(posteriors, proposal, diagonal_error_model=False, error_model=N
                     or "rosenbrock" in low
                     or (("batched" in low or "source" in low) and np.count_nonzero(pc - np.diag(np.diag(pc))))  # (external models: diagonal prior covariance, as at any width)
                     or low["noise_kind"] not in ((_lib.NOISE_ISO, _lib.NOISE_DIAG, _lib.NOISE_ADAPTIVE) if (error_model is not None and not diagonal_error_model)
+                                                 else (_lib.NOISE_ISO, _lib.NOISE_DIAG, _lib.NOISE_DENSE) if (len(posteriors) == 1 and low.get("A") is not None)
                                                  else (_lib.NOISE_ISO, _lib.NOISE_DIAG))):
                 return _no("more than 64 parameters are lowered for single-level chains, Delayed Acceptance and MLDA of linear, source-defined and batched host models with "
                            "isotropic / diagonal noise, GaussianRandomWalk / CrankNicolson / AdaptiveMetropolis (error models: the dense one)")
