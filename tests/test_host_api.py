@@ -381,3 +381,45 @@ def test_result_views_carry_no_instance_dictionary_and_survive_pickle_and_copy()
     for other in (pickle.loads(pickle.dumps(c)), copy.deepcopy(c), copy.copy(c)):
         assert len(other) == 5 and np.array_equal(other.parameters, c.parameters)
     assert c[1:3].parameters.shape == (2, 3) and c[4].parameters.shape == (3,)
+
+
+def test_lowering_rules_of_round_5():
+    """what _device_plan admits since 0.5 (no GPU needed: the pass only inspects the problem): 65 .. 128 parameters for linear,
+    batched and source-defined models under GRW / pCN / AM with any prior kind and the dense error model; five and six levels without
+    error model; 256 outputs under the dense error model -- and what it still refuses, with the reason recorded"""
+    from tinyda_amd import api
+
+    rng = np.random.default_rng(0)
+    d = 100
+    prior = stats.multivariate_normal(np.zeros(d), np.eye(d))
+    Lp = np.eye(d) + 0.05 * np.tril(rng.standard_normal((d, d)), -1)
+    dense_prior = stats.multivariate_normal(np.zeros(d), Lp @ Lp.T)
+    A = rng.standard_normal((30, d))
+    like = tda.GaussianLogLike(np.zeros(30), 0.1 * np.eye(30))
+    lin = tda.Posterior(prior, like, tda.LinearModel(A))
+    bat = tda.Posterior(prior, like, tda.BatchedModel(lambda th: th @ A.T, 30))
+    am = tda.AdaptiveMetropolis(1e-3 * np.eye(d))
+    assert api._device_plan([lin], am) is not None
+    assert api._device_plan([tda.Posterior(dense_prior, like, tda.LinearModel(A))], am) is not None
+    assert api._device_plan([bat], tda.CrankNicolson()) is not None
+    assert api._device_plan([bat, lin], tda.CrankNicolson()) is not None  # a host-sequenced hierarchy at 100 parameters
+    dense_like = tda.GaussianLogLike(np.zeros(30), 0.1 * np.eye(30) + 0.01 * np.ones((30, 30)))
+    assert api._device_plan([tda.Posterior(prior, dense_like, tda.LinearModel(A))], am) is not None  # dense noise: single level
+    assert api._device_plan([lin, tda.Posterior(prior, dense_like, tda.LinearModel(A))], am) is None and "more than 64 parameters" in api._refusal[0]
+    ada = tda.Posterior(prior, tda.AdaptiveGaussianLogLike(np.zeros(30), 0.1 * np.eye(30)), tda.LinearModel(0.9 * A))
+    assert api._device_plan([ada, lin], tda.CrankNicolson(), error_model="state-independent") is not None
+    assert api._device_plan([ada, lin], tda.CrankNicolson(), diagonal_error_model=True, error_model="state-independent") is None
+    assert api._device_plan([lin], tda.DREAMZ(M0=200)) is None and "more than 64 parameters" in api._refusal[0]
+    assert api._device_plan([tda.Posterior(stats.multivariate_normal(np.zeros(129), np.eye(129)), like, tda.LinearModel(rng.standard_normal((30, 129))))], am) is None
+    # levels
+    d4 = 4
+    prior4 = stats.multivariate_normal(np.zeros(d4), np.eye(d4))
+    lv = [tda.Posterior(prior4, tda.GaussianLogLike(np.zeros(6 + k), 0.1 * np.eye(6 + k)), tda.LinearModel(rng.standard_normal((6 + k, d4)))) for k in range(7)]
+    grw = tda.GaussianRandomWalk(np.eye(d4))
+    assert api._device_plan(lv[:5], grw) is not None and api._device_plan(lv[:6], grw) is not None
+    assert api._device_plan(lv[:7], grw) is None and "more than 6 levels" in api._refusal[0]
+    same = [tda.Posterior(prior4, tda.AdaptiveGaussianLogLike(np.zeros(6), 0.1 * np.eye(6)), tda.LinearModel(rng.standard_normal((6, d4)))) for _ in range(4)]
+    same.append(tda.Posterior(prior4, tda.GaussianLogLike(np.zeros(6), 0.1 * np.eye(6)), tda.LinearModel(rng.standard_normal((6, d4)))))
+    assert api._device_plan(same, grw, error_model="state-independent") is None and "more than 4 levels" in api._refusal[0]
+    assert api._device_plan(same[1:], grw, error_model="state-independent") is not None
+    assert api._device_plan(lv[:5], tda.DREAMZ(M0=20)) is None
