@@ -836,8 +836,17 @@ template <int DPAD>
 void launch_colsum(const double* m, int64_t row0, int64_t nrows, double* partial, int64_t nb, hipStream_t st) {
   hipLaunchKernelGGL(k_colsum_partial<DPAD>, dim3((unsigned)nb), dim3(64), 0, st, m, row0, nrows, partial);
 }
+// `partial` holds nb chunk sums and has room for ceil(nb / COLSUM_FOLD) folded ones behind them (colsum_partial_doubles)
+inline size_t colsum_partial_doubles(int64_t nb, int DP) { return (size_t)(nb + (nb + COLSUM_FOLD - 1) / COLSUM_FOLD) * 2 * DP; }
 template <int DPAD>
-void launch_colsum_final(const double* partial, int64_t nb, double* zsum, double* zsq, hipStream_t st) {
+void launch_colsum_final(double* partial, int64_t nb, double* zsum, double* zsq, hipStream_t st) {
+  if (nb > 2 * COLSUM_FOLD) {  // many chunks: fold them over several workgroups first (a fixed order for a given count)
+    const int64_t nf = (nb + COLSUM_FOLD - 1) / COLSUM_FOLD;
+    double* folded = partial + (size_t)nb * 2 * DPAD;
+    hipLaunchKernelGGL(k_colsum_fold<DPAD>, dim3((unsigned)nf), dim3(64), 0, st, partial, nb, folded);
+    hipLaunchKernelGGL(k_colsum_final<DPAD>, dim3(1), dim3(64 * COLSUM_FINAL_WAVES), 0, st, folded, nf, zsum, zsq);
+    return;
+  }
   hipLaunchKernelGGL(k_colsum_final<DPAD>, dim3(1), dim3(64 * COLSUM_FINAL_WAVES), 0, st, partial, nb, zsum, zsq);
 }
 template <int DPAD>

@@ -789,7 +789,9 @@ __global__ void __launch_bounds__(64) k_colsum_partial(const double* __restrict_
   const int64_t b = blockIdx.x;
   const int64_t lo = b * COLSUM_CHUNK, hi = lo + COLSUM_CHUNK < nrows ? lo + COLSUM_CHUNK : nrows;
   double zs = 0.0, zq = 0.0;
-#pragma unroll 16
+  // (64 rows requested per batch: the loop is a chain of round trips to memory, 16 per batch made eight of them per chunk -- 65 us per
+  // boundary of C4 for 210 MB; the sums are formed in the same order whatever the batch)
+#pragma unroll 64
   for (int64_t r = lo + g; r < hi; r += G) {
     const double z = m[(size_t)(row0 + r) * DPAD + col];
     zs += z;
@@ -810,6 +812,32 @@ __global__ void __launch_bounds__(64) k_colsum_partial(const double* __restrict_
 // zsum / zsq += the chunk sums, in an order that depends on the number of chunks only: accumulator (w, g) adds chunks
 // w G + g, w G + g + 16 G, ... in ascending order, then the 16 G accumulators are added in ascending order (deterministic
 // for a given append)
+// chunk sums -> sums of COLSUM_FOLD consecutive chunks, in order (round 5: one workgroup adding 3 200 chunks of a C4 boundary was bound by ITS
+// compute unit's load path: 3.3 MB through one L1 = 24 us; folded over ~25 workgroups first it is two short launches)
+constexpr int COLSUM_FOLD = 128;
+template <int DPAD>
+__global__ void __launch_bounds__(64) k_colsum_fold(const double* __restrict__ partial, int64_t npart, double* __restrict__ folded) {
+  constexpr int G = 64 / DPAD;
+  const int lane = threadIdx.x;
+  const int col = lane % DPAD, g = lane / DPAD;
+  const int64_t lo = (int64_t)blockIdx.x * COLSUM_FOLD, hi = lo + COLSUM_FOLD < npart ? lo + COLSUM_FOLD : npart;
+  double zs = 0.0, zq = 0.0;
+#pragma unroll 32
+  for (int64_t b = lo + g; b < hi; b += G) {
+    zs += partial[((size_t)b * 2 + 0) * DPAD + col];
+    zq += partial[((size_t)b * 2 + 1) * DPAD + col];
+  }
+  double ts = 0.0, tq = 0.0;
+#pragma unroll
+  for (int k = 0; k < G; ++k) {
+    ts += __shfl(zs, col + DPAD * k);
+    tq += __shfl(zq, col + DPAD * k);
+  }
+  if (lane < DPAD) {
+    folded[((size_t)blockIdx.x * 2 + 0) * DPAD + lane] = ts;
+    folded[((size_t)blockIdx.x * 2 + 1) * DPAD + lane] = tq;
+  }
+}
 constexpr int COLSUM_FINAL_WAVES = 16;
 template <int DPAD>
 __global__ void __launch_bounds__(64 * COLSUM_FINAL_WAVES) k_colsum_final(const double* __restrict__ partial, int64_t npart,
@@ -820,7 +848,7 @@ __global__ void __launch_bounds__(64 * COLSUM_FINAL_WAVES) k_colsum_final(const 
   const int col = lane % DPAD, g = lane / DPAD;
   {
     double zs = 0.0, zq = 0.0;
-#pragma unroll 8
+#pragma unroll 32
     for (int64_t b = w * G + g; b < npart; b += COLSUM_FINAL_WAVES * G) {
       zs += partial[((size_t)b * 2 + 0) * DPAD + col];
       zq += partial[((size_t)b * 2 + 1) * DPAD + col];
