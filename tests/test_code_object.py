@@ -33,7 +33,8 @@ HOT = {
     "_ZN3tda13k_aem_refreshILi8ELi1EEE": "C5 + dense error model refresh of level 1 (one tracker)",
     "_ZN3tda13k_aem_refreshILi8ELi2EEE": "C5 + dense error model refresh of level 0 (two trackers)",
     "_ZN3tda18k_adapt_chol_applyILi64EEE": "C2a period boundary in one launch",
-    "_ZN3tda13k_dreamz_drawILi32ELb0EEE": "C4 DREAM draws",
+    "_ZN3tda13k_dreamz_drawILi32ELb0ELb0EEE": "C4 DREAM draws (two-kernel path, TINYDA_DZ_FUSED=0)",
+    "_ZN3tda13k_dreamz_drawILi32ELb0ELb1EEE": "C4 DREAM block, draws and steps in one launch (round 5)",
 }
 
 # Every OTHER instance of the code object must be spill-free too, except the ones listed here with the number of spilled registers

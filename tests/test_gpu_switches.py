@@ -17,7 +17,7 @@ def _probe(what, env_extra, tmp_path, tag):
     out = str(tmp_path / ("%s_%s.npz" % (what, tag)))
     env = dict(os.environ)
     for k in ("TINYDA_DA_LEAN", "TINYDA_DZ_WAVE", "TINYDA_DZ_PIPELINE", "TINYDA_AEMD_FUSED", "TINYDA_FUSE_CHOL_APPLY", "TINYDA_CHOL_BLOCKED",
-              "TINYDA_FUSE_ADAPT_CHOL", "TINYDA_ADAPT_SPLIT", "TINYDA_AEM_BASE", "TINYDA_ML_SPLIT", "TINYDA_DA_R224", "TINYDA_AM_DEFER", "TINYDA_ML_PREDRAW", "TINYDA_AEM_PRE"):
+              "TINYDA_FUSE_ADAPT_CHOL", "TINYDA_ADAPT_SPLIT", "TINYDA_AEM_BASE", "TINYDA_DZ_FUSED", "TINYDA_ML_SPLIT", "TINYDA_DA_R224", "TINYDA_AM_DEFER", "TINYDA_ML_PREDRAW", "TINYDA_AEM_PRE"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "switch_probe.py"), what, out], cwd=ROOT, env=env,
@@ -141,11 +141,15 @@ def test_error_model_outputs_on_the_matrix_cores_agree(what, tmp_path):
 
 @pytest.mark.parametrize("what", ["dream", "dream_ragged"])
 def test_dream_kernel_choices_agree(what, tmp_path):
-    """k_dreamz_steps_wave against the 16-chain tile kernel (TINYDA_DZ_WAVE=0), and the draw-ahead pipeline
+    """the fused block (draws + steps in one launch) against k_dreamz_draw -> k_dreamz_steps_wave (TINYDA_DZ_FUSED=0): bitwise;
+    k_dreamz_steps_wave against the 16-chain tile kernel (TINYDA_DZ_WAVE=0), and the draw-ahead pipeline
     (TINYDA_DZ_PIPELINE=1: same sums in the same order, bitwise)"""
-    wave = _probe(what, {}, tmp_path, "wave")
-    tile = _probe(what, {"TINYDA_DZ_WAVE": "0"}, tmp_path, "tile")
-    pipe = _probe(what, {"TINYDA_DZ_PIPELINE": "1"}, tmp_path, "pipe")
+    fused = _probe(what, {}, tmp_path, "fused")  # (512 chains: draws and steps of a block in ONE launch, k_dreamz_draw<32, false, true>)
+    wave = _probe(what, {"TINYDA_DZ_FUSED": "0"}, tmp_path, "wave")
+    tile = _probe(what, {"TINYDA_DZ_FUSED": "0", "TINYDA_DZ_WAVE": "0"}, tmp_path, "tile")
+    pipe = _probe(what, {"TINYDA_DZ_FUSED": "0", "TINYDA_DZ_PIPELINE": "1"}, tmp_path, "pipe")
+    for k in ("acc0", "stats0", "params0", "pCR"):
+        assert np.array_equal(fused[k], wave[k]), "the fused block changed %s" % k
     assert np.array_equal(wave["acc0"], tile["acc0"])
     np.testing.assert_allclose(wave["stats0"], tile["stats0"], rtol=1e-10)
     np.testing.assert_allclose(wave["params0"], tile["params0"], rtol=1e-12, atol=1e-14)

@@ -807,9 +807,17 @@ int launch_ml<128>(const MLArgs& a, int64_t tiles, size_t lds, hipStream_t st, i
 }
 
 template <int DPAD>
-void launch_dz_draw(const DreamDrawArgs& a, hipStream_t st) {
-  if (a.dist_ranks) hipLaunchKernelGGL((k_dreamz_draw<DPAD, true>), dim3((unsigned)(a.NP / dz_chains_per_wave<DPAD>())), dim3(64), 0, st, a);
-  else hipLaunchKernelGGL((k_dreamz_draw<DPAD, false>), dim3((unsigned)(a.NP / dz_chains_per_wave<DPAD>())), dim3(64), 0, st, a);
+void launch_dz_draw(const DreamDrawArgs& a, hipStream_t st, const DreamFuseArgs* fuse = nullptr) {
+  const dim3 g((unsigned)(a.NP / dz_chains_per_wave<DPAD>()));
+  if constexpr (DPAD == 32) {
+    if (fuse) {  // draws AND steps of the block in one launch (run_dreamz decides: shared archive, Rosenbrock, diagonal prior, own variates)
+      hipLaunchKernelGGL((k_dreamz_draw<32, false, true>), g, dim3(64), 0, st, a, *fuse);
+      return;
+    }
+  }
+  const DreamFuseArgs none{};
+  if (a.dist_ranks) hipLaunchKernelGGL((k_dreamz_draw<DPAD, true>), g, dim3(64), 0, st, a, none);
+  else hipLaunchKernelGGL((k_dreamz_draw<DPAD, false>), g, dim3(64), 0, st, a, none);
 }
 template <int DPAD>
 void launch_dz_steps(const DreamStepArgs& a, size_t lds, hipStream_t st) {

@@ -35,6 +35,7 @@ __device__ __attribute__((noinline)) double2 dz_normal_pair_call(uint64_t seed, 
   normal_pair(seed, chain, step2, STREAM_DREAM_EPS, block, z0, z1);
   return double2{z0, z1};
 }
+__device__ __attribute__((noinline)) double dz_log_call(double u) { return log(u); }  // (fused block: the accept uniforms' logarithms, out of line for the same reason)
 constexpr int MAX_NCR = 8;
 constexpr int MAX_DELTA = 4;
 constexpr int MAX_PEERS = 16;
@@ -78,6 +79,45 @@ struct DreamDrawArgs {
                                // the kernel arguments per lane would copy the whole argument block to scratch)
 };
 
+// The step half of a FUSED block (k_dreamz_draw<32, false, true>, round 5): shared archive, the built-in Rosenbrock model, diagonal
+// prior, engine-generated variates, 32 parameters -- BASELINE configs[3].  The draws of a step do not depend on the chain's state and
+// the step itself is ~100 instructions: done in the kernel that draws, the finished jumps never go to memory ([S][NP][32] doubles
+// written by one kernel and read by the next: a third of the configuration's traffic), and the step's memory-bound tail overlaps the
+// next step's generator arithmetic.  Same arithmetic in the same order as k_dreamz_draw -> k_dreamz_steps_wave (a parameter per
+// lane here, two per lane there: the pair is added first, then the same rotation tree), so the two paths give the same bits
+// (TINYDA_DZ_FUSED=0 is the A/B switch, tests/test_gpu_switches.py).
+struct DreamFuseArgs {
+  const double* pr_mean;
+  const double* pr_pinv;
+  const double* pr_lo;  // or null
+  const double* pr_hi;
+  double logconst, ros_a, ros_b, ros_data, var;
+  double* theta;        // [NP][32]
+  double* theta_prev;
+  double* lp;
+  double* ll;
+  int32_t* acc_count;
+  double* rec_params;   // [S][N][d] or null
+  double* rec_stats;
+  uint8_t* rec_acc;
+  double* blk_states;   // [S][NP][32]: the block's states (the archive's next rows)
+};
+// sum over the 32 lanes of a chain (two DPP rows) of one value per parameter, in the order k_dreamz_steps_wave adds them: the two
+// parameters a lane holds there first, then its 16-lane rotations 8, 4, 2, 1 = pairs 16 lanes apart, then rotations 8, 4, 2 here
+__device__ __forceinline__ double dz_sum_chain32(double v) {
+  v += dpp_move<0xB1>(v);  // quad_perm [1, 0, 3, 2]: the neighbouring parameter
+  {
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    const uint2_t a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const uint2_t b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = __hiloint2double(b.x, a.x) + __hiloint2double(b.y, a.y);  // lane l + lane l ^ 16
+  }
+  v += dpp_move<0x128>(v);  // row_ror:8
+  v += dpp_move<0x124>(v);  // row_ror:4
+  v += dpp_move<0x122>(v);  // row_ror:2
+  return v;
+}
+
 // 64 / DPAD chains share a wave (lane = chain-in-wave * DPAD + parameter), so small dimensions do not idle lanes
 template <int DPAD>
 constexpr int dz_chains_per_wave() {
@@ -85,8 +125,12 @@ constexpr int dz_chains_per_wave() {
 }
 
 // DIST: the shared archive is distributed over the ranks (a template parameter: the plain kernel stays as it was)
-template <int DPAD, bool DIST = false>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_dreamz_draw(const DreamDrawArgs a) {
+#ifndef DZ_FUSED_WAVES
+#define DZ_FUSED_WAVES 3  // (the fused block: 168 registers, 6 spilled at three waves per SIMD; 176 / none at two; 128 / 61 spilled at four)
+#endif
+template <int DPAD, bool DIST = false, bool FUSED = false>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FUSED ? DZ_FUSED_WAVES : 4, FUSED ? DZ_FUSED_WAVES : 4))) k_dreamz_draw(const DreamDrawArgs a, const DreamFuseArgs f) {
+  static_assert(!FUSED || (DPAD == 32 && !DIST), "the fused block is built for 32 parameters, one archive in this process");
   constexpr int CPW = dz_chains_per_wave<DPAD>();
   const int seg = threadIdx.x / DPAD;
   const int lane = threadIdx.x % DPAD;  // parameter index within the chain
@@ -100,6 +144,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
   __shared__ double s_CR[MAX_NCR];  // crossover probability of index k: (k + 1) / nCR (a table lookup per step instead of a division)
   __shared__ int s_rows[CPW][DPAD][2 * MAX_DELTA];  // archive row pairs of the chunk's steps (written by the step's owner lane)
   __shared__ int s_mf[CPW][DPAD];                    // crossover index | forced index << 8
+  __shared__ double s_uacc[FUSED ? CPW : 1][FUSED ? DPAD : 1];  // fused block: the accept uniform of the owner lane's step
+  __shared__ double s_lacc[FUSED ? CPW : 1][FUSED ? DPAD : 1];  // ... and its logarithm (taken once, by the owner lane: sixteen steps side by side)
   if (lane == 0) {
     double run = 0.0;
     for (int k = 0; k < MAX_NCR; ++k) {
@@ -121,6 +167,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
   // dimensions: a shuffle per step instead of a square root and a division
   const double gam_tab = scaling * 2.38 / sqrt((double)(2 * a.delta * (lane + 1)));
   const bool philox_normals = a.sub_rep == nullptr;  // wave-uniform
+  // fused block: the chain's state, a parameter per lane
+  // (what only one step or a rare prior needs stays in memory: the state before the block's last step is stored at that step, support
+  // bounds are read where they are tested -- as registers they were the six that did not fit three waves per SIMD)
+  double th = 0.0, lpc = 0.0, llc = 0.0, pm = 0.0, pinv = 0.0;
+  int nacc = 0;
+  if constexpr (FUSED) {
+    th = f.theta[c * DPAD + lane];
+    lpc = f.lp[c];
+    llc = f.ll[c];
+    pm = f.pr_mean[lane];
+    pinv = f.pr_pinv[lane];
+  }
   // per-parameter variates: one block each for the crossover uniforms, the e-uniforms and the eps normals of FOUR steps
   double2 q_z{0.0, 0.0};  // eps normals of the step pair in progress
   constexpr int GS = DPAD < 4 ? DPAD : 4;  // steps per group: their archive rows are requested together, one group ahead
@@ -166,8 +224,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
             r2 = (int)(((uint64_t)x.y * (uint64_t)(M - 1)) >> 32);
             r2 += r2 >= r1 ? 1 : 0;
           }
-          a.ridx[((size_t)s * a.NP + c) * (2 * MAX_DELTA) + 2 * i + 0] = r1;
-          a.ridx[((size_t)s * a.NP + c) * (2 * MAX_DELTA) + 2 * i + 1] = r2;
+          if constexpr (!FUSED) {  // (the fused block gathers the rows itself and nobody reads the indices)
+            a.ridx[((size_t)s * a.NP + c) * (2 * MAX_DELTA) + 2 * i + 0] = r1;
+            a.ridx[((size_t)s * a.NP + c) * (2 * MAX_DELTA) + 2 * i + 1] = r2;
+          }
           s_rows[seg][lane][2 * i + 0] = r1;
           s_rows[seg][lane][2 * i + 1] = r2;
         }
@@ -197,7 +257,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
           }
           if (a.u_export) a.u_export[row] = u;
         }
-        a.u[(size_t)s * a.NP + c] = u;
+        if constexpr (!FUSED) a.u[(size_t)s * a.NP + c] = u;
+        if constexpr (FUSED) {
+          s_uacc[seg][lane] = u;
+          s_lacc[seg][lane] = dz_log_call(u);
+        }
       }
     }
     __syncthreads();
@@ -241,6 +305,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
       for (int q = 0; q < GS; ++q) {
         const int s = s0 + q;
         if (s < c1) {  // (no `break`: the loop must unroll completely, or the group arrays are indexed dynamically and live in scratch)
+          if constexpr (FUSED) __builtin_amdgcn_sched_barrier(0);  // (one step's generator arithmetic at a time: hoisted across the four steps of a group it is 60 registers more)
           const uint32_t step = (uint32_t)(a.step0 + s);
           const size_t row = (size_t)s * a.N + c;
           const int mcr = cur.mf[q] & 255, forced = cur.mf[q] >> 8;
@@ -281,7 +346,51 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
           if (lane < DPAD) {
             const double cf = ind ? (1.0 + e) * gam : 0.0, em = ind ? eps : 0.0;
             const size_t o = ((size_t)s * a.NP + c) * DPAD + lane;
-            if (a.arch_shared) {
+            if constexpr (FUSED) {
+              // ---- the step (k_dreamz_steps_wave, jump_ready): proposal, prior, Rosenbrock chain, decision, records ----
+              const double prp = th + (cf * cur.zd[q] + em);  // proposal.py:850-852
+              const double dv = prp - pm;
+              double p = dv * dv * pinv;
+              if (f.pr_lo && (prp < f.pr_lo[lane] || prp > f.pr_hi[lane])) p = INFINITY;  // uniform components: zero density outside their support
+              const double maha = dz_sum_chain32(p);
+              const double xnb = __shfl_down(prp, 1, DPAD);
+              const double t0 = f.ros_a - prp, t1 = xnb - prp * prp;
+              const double fs = dz_sum_chain32(lane + 1 < a.d ? t0 * t0 + f.ros_b * (t1 * t1) : 0.0);
+              const double rr = fs - f.ros_data;
+              const double ll_n = -0.5 * (rr * rr) / f.var;
+              const double lp_n = -0.5 * (f.logconst + maha);
+              const double post_n = lp_n + ll_n;
+              // u < exp(delta), decided on the logarithms unless they are within 1e-9 of each other (then exactly as the step kernel
+              // does): the exponential is ~40 instructions that both chains of the wave would execute at every step
+              const double delta = post_n - (lpc + llc);
+              const int slot = (s - c0) & (DPAD - 1);  // the step's slot in the chunk's tables (read here: as registers of the look-ahead group they were 32 more)
+              const double lu = s_lacc[seg][slot];
+              bool acc;
+              if (fabs(lu - delta) > 1e-9 || delta != delta) {
+                acc = (post_n == post_n) && (lu < delta);
+              } else {
+                double alpha = exp(delta);
+                if (post_n != post_n) alpha = 0.0;
+                acc = s_uacc[seg][slot] < alpha;
+              }
+              if (acc) {
+                lpc = lp_n;
+                llc = ll_n;
+              }
+              nacc += acc ? 1 : 0;
+              if (lane == 0) {
+                if (f.rec_stats) {
+                  f.rec_stats[row * 3 + 0] = lpc;
+                  f.rec_stats[row * 3 + 1] = llc;
+                  f.rec_stats[row * 3 + 2] = lpc + llc;
+                }
+                if (f.rec_acc) f.rec_acc[row] = acc ? 1 : 0;
+              }
+              if (s == a.S - 1) f.theta_prev[c * DPAD + lane] = th;  // the state before the block's last step (jumping distance, proposal.py:800)
+              th = acc ? prp : th;
+              if (f.rec_params && lj) f.rec_params[row * a.d + lane] = th;
+              f.blk_states[o] = th;
+            } else if (a.arch_shared) {
               a.coef[o] = cf * cur.zd[q] + em;  // the jump itself (proposal.py:850-852)
             } else {
               a.coef[o] = cf;
@@ -291,6 +400,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
         }
       }
       cur = nxt;
+    }
+  }
+  if constexpr (FUSED) {
+    f.theta[c * DPAD + lane] = th;
+    if (lane == 0) {
+      f.lp[c] = lpc;
+      f.ll[c] = llc;
+      f.acc_count[c] += nacc;
     }
   }
 }
