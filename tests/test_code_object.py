@@ -18,7 +18,8 @@ LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 # kernel instance (mangled prefix) -> what launches it
 HOT = {
     "_ZN3tda10k_mh_stepsILi64ELi8ELb0ELi0EEE": "C2a step kernel",
-    "_ZN3tda7k_adaptILi64EEE": "C2a moment recursion",
+    "_ZN3tda7k_adaptILi64ELb1EEE": "C2a moment recursion (diagonal blocks as circulant slots, round 5)",
+    "_ZN3tda7k_adaptILi64ELb0EEE": "C2a moment recursion, full diagonal tiles (TINYDA_ADAPT_CIRC=0)",
     "_ZN3tda16k_chol_apply_blkILi64ELb1EEE": "C2a covariance swap + increments",
     "_ZN3tda7k_applyILi64EEE": "C2a increments",
     "_ZN3tda10k_da_stepsILi64ELi2ELb1ELi0ELi2EEE": "C3 Delayed Acceptance (replay mode, non-identity proposal factors)",
@@ -32,7 +33,8 @@ HOT = {
     "_ZN3tda12k_aem_actionILi128EEE": "C5 + dense error model level decision",
     "_ZN3tda13k_aem_refreshILi8ELi1EEE": "C5 + dense error model refresh of level 1 (one tracker)",
     "_ZN3tda13k_aem_refreshILi8ELi2EEE": "C5 + dense error model refresh of level 0 (two trackers)",
-    "_ZN3tda18k_adapt_chol_applyILi64EEE": "C2a period boundary in one launch",
+    "_ZN3tda18k_adapt_chol_applyILi64ELb1EEE": "C2a period boundary in one launch (diagonal blocks as circulant slots, round 5)",
+    "_ZN3tda18k_adapt_chol_applyILi64ELb0EEE": "C2a period boundary in one launch, full diagonal tiles (TINYDA_ADAPT_CIRC=0)",
     "_ZN3tda13k_dreamz_drawILi32ELb0ELb0EEE": "C4 DREAM draws (two-kernel path, TINYDA_DZ_FUSED=0)",
     "_ZN3tda13k_dreamz_drawILi32ELb0ELb1EEE": "C4 DREAM block, draws and steps in one launch (round 5)",
 }

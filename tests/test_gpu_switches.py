@@ -17,7 +17,7 @@ def _probe(what, env_extra, tmp_path, tag):
     out = str(tmp_path / ("%s_%s.npz" % (what, tag)))
     env = dict(os.environ)
     for k in ("TINYDA_DA_LEAN", "TINYDA_DZ_WAVE", "TINYDA_DZ_PIPELINE", "TINYDA_AEMD_FUSED", "TINYDA_FUSE_CHOL_APPLY", "TINYDA_CHOL_BLOCKED",
-              "TINYDA_FUSE_ADAPT_CHOL", "TINYDA_ADAPT_SPLIT", "TINYDA_AEM_BASE", "TINYDA_DZ_FUSED", "TINYDA_ML_SPLIT", "TINYDA_DA_R224", "TINYDA_AM_DEFER", "TINYDA_ML_PREDRAW", "TINYDA_AEM_PRE"):
+              "TINYDA_FUSE_ADAPT_CHOL", "TINYDA_ADAPT_SPLIT", "TINYDA_ADAPT_CIRC", "TINYDA_AEM_BASE", "TINYDA_DZ_FUSED", "TINYDA_ML_SPLIT", "TINYDA_DA_R224", "TINYDA_AM_DEFER", "TINYDA_ML_PREDRAW", "TINYDA_AEM_PRE"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "switch_probe.py"), what, out], cwd=ROOT, env=env,
@@ -88,6 +88,14 @@ def test_fused_swap_and_increments_equal_the_two_launches(what, tmp_path):
     spl = _probe(what, {"TINYDA_FUSE_ADAPT_CHOL": "0", "TINYDA_ADAPT_SPLIT": "1"}, tmp_path, "split_recursion")
     for k in blk:
         assert np.array_equal(blk[k], spl[k]), "k_adapt_split changed %s" % k
+    # round 5, late: the diagonal blocks of Sigma as circulant slots (adapt_am_chain_c64, the default at 64 parameters; 264 instead of
+    # 320 operations per state) against full diagonal tiles (TINYDA_ADAPT_CIRC=0), in the one-launch boundary and in k_adapt alone: the
+    # same operations per element -- bitwise
+    full = _probe(what, {"TINYDA_ADAPT_CIRC": "0"}, tmp_path, "full_diagonal_tiles")
+    full2 = _probe(what, {"TINYDA_ADAPT_CIRC": "0", "TINYDA_FUSE_ADAPT_CHOL": "0"}, tmp_path, "full_diagonal_tiles_two_launches")
+    for k in blk:
+        assert np.array_equal(blk[k], full[k]), "circulant diagonal blocks changed %s" % k
+        assert np.array_equal(two[k], full2[k]), "circulant diagonal blocks (k_adapt) changed %s" % k
 
 
 @pytest.mark.parametrize("what", ["aem_dense", "aem_dense_ragged", "aem_dense_da_pcn", "aem_dense_m200", "aem_dense_m200_ragged", "aem_dense_chunks"])

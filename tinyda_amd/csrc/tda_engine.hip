@@ -517,6 +517,10 @@ template <int DPAD>
 void launch_apply(const ApplyArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_apply<DPAD>, dim3((unsigned)a.NP), dim3(64), 0, st, a);
 }
+static bool adapt_circ() {
+  static const bool on = !(getenv("TINYDA_ADAPT_CIRC") && atoi(getenv("TINYDA_ADAPT_CIRC")) == 0);
+  return on;
+}
 template <int DPAD>
 void launch_adapt(const AdaptArgs& a, hipStream_t st) {
   if constexpr (DPAD == 64) {  // TINYDA_ADAPT_SPLIT=1 (A/B): the ten tiles of a chain dealt to two waves, three waves per SIMD (k_adapt_split)
@@ -526,8 +530,11 @@ void launch_adapt(const AdaptArgs& a, hipStream_t st) {
       return;
     }
   }
-  if (a.do_am && a.block_moments) hipLaunchKernelGGL(k_adapt_block<DPAD>, dim3((unsigned)a.N), dim3(64), 0, st, a);
-  else hipLaunchKernelGGL(k_adapt<DPAD>, dim3((unsigned)a.N), dim3(64), 0, st, a);
+  if (a.do_am && a.block_moments) { hipLaunchKernelGGL(k_adapt_block<DPAD>, dim3((unsigned)a.N), dim3(64), 0, st, a); return; }
+  if constexpr (DPAD == 64) {  // TINYDA_ADAPT_CIRC=0 (A/B): the diagonal blocks as full tiles (rounds 2-4)
+    if (adapt_circ() && a.do_am) { hipLaunchKernelGGL((k_adapt<DPAD, true>), dim3((unsigned)a.N), dim3(64), 0, st, a); return; }
+  }
+  hipLaunchKernelGGL(k_adapt<DPAD>, dim3((unsigned)a.N), dim3(64), 0, st, a);
 }
 template <int DPAD>
 void launch_chol(const CholArgs& a, hipStream_t st) {
@@ -559,7 +566,8 @@ bool launch_adapt_chol_apply(const AdaptArgs& aa, const CholArgs& ca, const Appl
     static const bool ok = !(getenv("TINYDA_FUSE_ADAPT_CHOL") && atoi(getenv("TINYDA_FUSE_ADAPT_CHOL")) == 0) &&  // A/B switches
                            !(getenv("TINYDA_CHOL_BLOCKED") && atoi(getenv("TINYDA_CHOL_BLOCKED")) == 0);
     if (ok && aa.do_am && !aa.block_moments) {
-      hipLaunchKernelGGL(k_adapt_chol_apply<DPAD>, dim3((unsigned)ap.NP), dim3(64), 0, st, aa, ca, ap);
+      if (adapt_circ()) hipLaunchKernelGGL((k_adapt_chol_apply<DPAD, true>), dim3((unsigned)ap.NP), dim3(64), 0, st, aa, ca, ap);
+      else hipLaunchKernelGGL((k_adapt_chol_apply<DPAD, false>), dim3((unsigned)ap.NP), dim3(64), 0, st, aa, ca, ap);
       return true;
     }
   }

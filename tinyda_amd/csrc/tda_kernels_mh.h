@@ -1423,14 +1423,202 @@ __device__ __forceinline__ void adapt_am_chain(const AdaptArgs& a, const int64_t
   }
 }
 
-template <int DPAD>
-__global__ void __launch_bounds__(64) k_adapt(const AdaptArgs a) {
+// The same recursion at 64 parameters with the four DIAGONAL tiles kept as circulant slots instead of full 16 x 16 tiles (round 5).
+// A diagonal tile is symmetric -- bitwise: x_i x_j = x_j x_i, and so for every product of the recursion --, so 120 of its 256
+// elements are computed twice.  Here lane l = 16 b + lc holds, of diagonal block b, the nine pairs {lc, (lc + k) mod 16}, k = 0 .. 8
+// (every unordered pair once, those at distance 8 twice): 9 instead of 16 registers of Sigma and of t mu mu^T, 72 instead of 128
+// operations per state; in all 264 instead of 320.  The column operand of a slot is the lane's own x / mu' (a register), its row
+// operand one of eight consecutive doubles of a block stored twice in LDS (four ds_read2_b64 per vector); the six tiles below the
+// diagonal keep the tile layout and their operand reads (the column operands now come from the same doubled array).  Memory layout
+// of Sigma unchanged; same operations per element in the same order: the same bits (the "+ 0" that the tile version adds to the
+// off-diagonal elements of a diagonal tile is not added: it can change the sign of a zero only).  NEED_TILES: leave the diagonal
+// tiles in Sg in the tile layout (k_adapt_chol_apply factorises from registers), converted through LDS once per block.
+#ifndef CIRC_SCHED_MASK
+#define CIRC_SCHED_MASK 0
+#endif
+template <bool NEED_TILES>
+__device__ __forceinline__ void adapt_am_chain_c64_store(const AdaptArgs& a, const int64_t c, const int lane, const double mu, double (&Sg)[10][4],
+                                                         const double (&Dg)[9]);
+template <bool NEED_TILES>
+__device__ __forceinline__ void adapt_am_chain_c64(const AdaptArgs& a, const int64_t c, const int lane, double (&Sg)[10][4]) {
+  constexpr int W = 64;
+  __shared__ __attribute__((aligned(16))) double s_dbl[2 * 128];  // x, mu': block b (16 dimensions) at 32 b .. 32 b + 15 and again at + 16
+  __shared__ __attribute__((aligned(16))) double s_prm[2 * W];    // x, mu': dimension 16 ti + h + 4 r at 16 ti + 4 h + r
+  const bool lj = lane < a.d;
+  const int lc = lane & 15, hi = lane >> 4;
+  double* __restrict__ sig = a.am_sigma + (size_t)c * 10 * 256;
+  // t mu mu^T of the current mean in TWO sets used alternately (the loop takes two states per pass): a state reads one and
+  // writes (t + 1) mu' mu'^T into the other, so that no register is copied (with one set: 34 v_mov_b64 of 316 instructions per state)
+  double TM[2][10][4];  // (only the six tiles below the diagonal are used)
+  double Dg[9], TD[2][9];
+  int doff[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int i = 16 * hi + ((lc + k) & 15), j = 16 * hi + lc;
+    doff[k] = i >= j ? am_sigma_offset(i, j) : am_sigma_offset(j, i);
+  }
+#pragma unroll
+  for (int ti = 1; ti < 4; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < ti; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Sg[ti * (ti + 1) / 2 + tj][r] = sig[((ti * (ti + 1) / 2 + tj) * 4 + r) * 64 + lane];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Dg[k] = sig[doff[k]];
+  double mu = a.am_mu[c * 64 + lane];
+  const int ppos = (lane & ~15) | ((lane & 3) << 2) | ((lane >> 2) & 3);
+  const int dpos = 32 * hi + lc;
+  s_dbl[dpos] = mu;
+  s_dbl[dpos + 16] = mu;
+  s_prm[ppos] = mu;
+  __syncthreads();
+  {
+    double mc[3];
+#pragma unroll
+    for (int tj = 0; tj < 3; ++tj) mc[tj] = s_dbl[32 * tj + lc];
+#pragma unroll
+    for (int ti = 1; ti < 4; ++ti) {
+      const double2* __restrict__ q = reinterpret_cast<const double2*>(s_prm + 16 * ti + 4 * hi);
+      const double2 m01 = q[0], m23 = q[1];
+      const double mr[4] = {m01.x, m01.y, m23.x, m23.y};
+#pragma unroll
+      for (int tj = 0; tj < ti; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) TM[0][ti * (ti + 1) / 2 + tj][r] = (double)(a.t_base + 1) * (mr[r] * mc[tj]);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) TD[0][k] = (double)(a.t_base + 1) * (s_dbl[dpos + k] * mu);
+  }
+  double c_inv = 0.0, c_a = 0.0, c_b = 0.0;
+  double xn = lj ? a.rec_params[(size_t)c * a.d + lane] : 0.0;
+  const double eps = a.eps;
+  auto state = [&](const int s, const double (&TMi)[10][4], double (&TMo)[10][4], const double (&TDi)[9], double (&TDo)[9]) {
+    if ((s & 63) == 0) {
+      const double tl = (double)(a.t_base + s + 1) + (double)lane;  // (integers below 2^53: the sum is exact)
+      c_inv = 1.0 / (tl + 1.0);
+      c_a = (tl - 1.0) / tl;
+      c_b = a.sd / tl;
+    }
+    const double x = xn;
+    if (s + 1 < a.S) xn = lj ? a.rec_params[((size_t)(s + 1) * a.N + c) * a.d + lane] : 0.0;
+    const double t = (double)(a.t_base + s + 1);  // recursor.t before this update
+    const double mup = bcast_lane64(c_inv, s & 63) * (t * mu + x);
+    const double ca = bcast_lane64(c_a, s & 63), cb = bcast_lane64(c_b, s & 63);
+    const double t1 = t + 1.0;
+    __syncthreads();  // previous step's operand reads are done
+    s_dbl[dpos] = x;
+    s_dbl[dpos + 16] = x;
+    s_dbl[128 + dpos] = mup;
+    s_dbl[128 + dpos + 16] = mup;
+    s_prm[ppos] = x;
+    s_prm[W + ppos] = mup;
+    __syncthreads();
+    // the diagonal blocks: slot k = the pair (16 b + (lc + k) mod 16, 16 b + lc)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const double xr = k == 0 ? x : s_dbl[dpos + k], pr = k == 0 ? mup : s_dbl[128 + dpos + k];
+      const double tp = t1 * (pr * mup);
+      double M = (TDi[k] - tp) + xr * x;
+      if (k == 0) M += eps;
+      Dg[k] = ca * Dg[k] + cb * M;
+      TDo[k] = tp;
+    }
+    __builtin_amdgcn_sched_barrier(CIRC_SCHED_MASK);
+    double xc[3], pc[3];
+#pragma unroll
+    for (int tj = 0; tj < 3; ++tj) {
+      xc[tj] = s_dbl[32 * tj + lc];
+      pc[tj] = s_dbl[128 + 32 * tj + lc];
+    }
+#pragma unroll
+    for (int ti = 1; ti < 4; ++ti) {
+      double xr[4], pr[4];
+      {
+        const double2* __restrict__ q = reinterpret_cast<const double2*>(s_prm + 16 * ti + 4 * hi);
+        const double2 x01 = q[0], x23 = q[1], p01 = q[W / 2], p23 = q[W / 2 + 1];
+        xr[0] = x01.x; xr[1] = x01.y; xr[2] = x23.x; xr[3] = x23.y;
+        pr[0] = p01.x; pr[1] = p01.y; pr[2] = p23.x; pr[3] = p23.y;
+      }
+#pragma unroll
+      for (int tj = 0; tj < ti; ++tj) {
+        const int idx = ti * (ti + 1) / 2 + tj;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double tp = t1 * (pr[r] * pc[tj]);
+          const double M = (TMi[idx][r] - tp) + xr[r] * xc[tj];
+          Sg[idx][r] = ca * Sg[idx][r] + cb * M;
+          TMo[idx][r] = tp;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(CIRC_SCHED_MASK);
+    }
+    mu = mup;
+  };
+  for (int s = 0; s < a.S; s += 2) {
+    state(s, TM[0], TM[1], TD[0], TD[1]);
+    if (s + 1 < a.S) state(s + 1, TM[1], TM[0], TD[1], TD[0]);
+  }
+  // what follows the loop derives its addresses from a lane index the compiler cannot identify with `lane`: kept live across the
+  // loop for these few stores they cost registers the loop does not have (7 / 15 spilled)
+  int lane2 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  asm volatile("" : "+v"(lane2));
+  __builtin_assume(lane2 >= 0 && lane2 < 64);
+  return adapt_am_chain_c64_store<NEED_TILES>(a, c, lane2, mu, Sg, Dg);
+}
+
+template <bool NEED_TILES>
+__device__ __forceinline__ void adapt_am_chain_c64_store(const AdaptArgs& a, const int64_t c, const int lane, const double mu, double (&Sg)[10][4],
+                                                         const double (&Dg)[9]) {
+  __shared__ __attribute__((aligned(16))) double s_cv[NEED_TILES ? 4 * 256 : 2];
+  const int lc = lane & 15, hi = lane >> 4;
+  double* __restrict__ sig = a.am_sigma + (size_t)c * 10 * 256;
+  a.am_mu[c * 64 + lane] = mu;
+#pragma unroll
+  for (int ti = 1; ti < 4; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < ti; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sig[((ti * (ti + 1) / 2 + tj) * 4 + r) * 64 + lane] = Sg[ti * (ti + 1) / 2 + tj][r];
+  if constexpr (NEED_TILES) {
+    // the diagonal tiles in the tile layout: both mirror images through LDS, [b][row][column]; stored from there
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int i = (lc + k) & 15;
+      s_cv[hi * 256 + i * 16 + lc] = Dg[k];
+      s_cv[hi * 256 + lc * 16 + i] = Dg[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double v = s_cv[p * 256 + (hi + 4 * r) * 16 + lc];
+        Sg[p * (p + 1) / 2 + p][r] = v;
+        sig[((p * (p + 1) / 2 + p) * 4 + r) * 64 + lane] = v;
+      }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {  // both mirror images of a diagonal tile (its readers take the whole tile); distance 8: two lanes store the same bits
+      const int i = (lc + k) & 15, tile = (hi * (hi + 1) / 2 + hi) * 256;
+      sig[tile + (i >> 2) * 64 + (i & 3) * 16 + lc] = Dg[k];
+      sig[tile + (lc >> 2) * 64 + (lc & 3) * 16 + i] = Dg[k];
+    }
+  }
+}
+
+template <int DPAD, bool CIRC = false>
+__global__ void __launch_bounds__(64, CIRC ? 2 : 1) k_adapt(const AdaptArgs a) {
   const int lane = threadIdx.x;
   const int64_t c = blockIdx.x;
   if (c >= a.N) return;
   if (a.do_am) {
     double Sg[am_tiles<DPAD>()][4];
-    adapt_am_chain<DPAD>(a, c, lane, Sg);
+    if constexpr (CIRC) {
+      static_assert(DPAD == 64, "circulant diagonal blocks: four tile rows");
+      adapt_am_chain_c64<false>(a, c, lane, Sg);
+    } else {
+      adapt_am_chain<DPAD>(a, c, lane, Sg);
+    }
   }
   adapt_scaling(a, c, lane);
 }
@@ -1657,8 +1845,8 @@ __device__ __forceinline__ double lane_pick(double v, int src) { return __shfl(v
 // whose Sigma is not positive definite take the factor in memory).  APPLY = false: the swap alone (multilevel drivers, whose
 // increments come from the fused k_propose).
 template <int DPAD, bool APPLY>
-__device__ __forceinline__ void chol_apply_tiles(const CholArgs& ca, const ApplyArgs& ap, const int64_t c, double (&G)[10][4]) {
-  const int lane = threadIdx.x, lc = lane & 15, hi = lane >> 4;
+__device__ __forceinline__ void chol_apply_tiles(const CholArgs& ca, const ApplyArgs& ap, const int64_t c, double (&G)[10][4], const int lane_in = -1) {
+  const int lane = lane_in < 0 ? (int)threadIdx.x : lane_in, lc = lane & 15, hi = lane >> 4;
   bool have = false;
   if (c < ca.N) {
     const int d = ca.d;
@@ -1811,15 +1999,24 @@ __global__ void __launch_bounds__(64, 2) k_chol_apply_blk(const CholArgs ca, con
 // factorisation wants the upper tiles, k_adapt keeps the lower ones), with a kernel boundary in between.  Here the upper tiles are
 // formed by a 16 x 16 register transpose of their mirror images (ds_bpermute; Sigma is bitwise symmetric), and Sigma is stored
 // once, for the next period's recursion.  Same arithmetic, same results bit for bit (tests/test_gpu_switches.py).
-template <int DPAD>
+template <int DPAD, bool CIRC = false>
 __global__ void __launch_bounds__(64, 2) k_adapt_chol_apply(const AdaptArgs a, const CholArgs ca, const ApplyArgs ap) {
   static_assert(DPAD == 64, "the blocked swap is written for four 16-column panels");
-  const int lane = threadIdx.x, lc = lane & 15, hi = lane >> 4;
+  int lane = threadIdx.x;
   const int64_t c = blockIdx.x;
   double G[10][4];
   if (c < a.N) {
     double Sg[am_tiles<DPAD>()][4];
-    adapt_am_chain<DPAD>(a, c, lane, Sg);
+    if constexpr (CIRC) {
+      adapt_am_chain_c64<true>(a, c, lane, Sg);
+      // (the lane index of everything behind the recursion: one the compiler cannot identify with threadIdx.x, see adapt_am_chain_c64)
+      lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      asm volatile("" : "+v"(lane));
+      __builtin_assume(lane >= 0 && lane < 64);
+    } else {
+      adapt_am_chain<DPAD>(a, c, lane, Sg);
+    }
+    const int lc = lane & 15, hi = lane >> 4;
     adapt_scaling(a, c, lane);
     const int d = ca.d;
 #pragma unroll
@@ -1849,7 +2046,7 @@ __global__ void __launch_bounds__(64, 2) k_adapt_chol_apply(const AdaptArgs a, c
         }
       }
   }
-  chol_apply_tiles<DPAD, true>(ca, ap, c, G);
+  chol_apply_tiles<DPAD, true>(ca, ap, c, G, lane);
 }
 
 }  // namespace tda
