@@ -1433,8 +1433,8 @@ __device__ __forceinline__ void adapt_am_chain(const AdaptArgs& a, const int64_t
 // of Sigma unchanged; same operations per element in the same order: the same bits (the "+ 0" that the tile version adds to the
 // off-diagonal elements of a diagonal tile is not added: it can change the sign of a zero only).  NEED_TILES: leave the diagonal
 // tiles in Sg in the tile layout (k_adapt_chol_apply factorises from registers), converted through LDS once per block.
-#ifndef CIRC_SCHED_MASK
-#define CIRC_SCHED_MASK 0
+#ifndef CIRC_SCHED
+#define CIRC_SCHED
 #endif
 template <bool NEED_TILES>
 __device__ __forceinline__ void adapt_am_chain_c64_store(const AdaptArgs& a, const int64_t c, const int lane, const double mu, double (&Sg)[10][4],
@@ -1514,16 +1514,37 @@ __device__ __forceinline__ void adapt_am_chain_c64(const AdaptArgs& a, const int
     s_prm[W + ppos] = mup;
     __syncthreads();
     // the diagonal blocks: slot k = the pair (16 b + (lc + k) mod 16, 16 b + lc)
+    {
+      double xd[9], pd[9], q[9], w[9], m[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const double xr = k == 0 ? x : s_dbl[dpos + k], pr = k == 0 ? mup : s_dbl[128 + dpos + k];
-      const double tp = t1 * (pr * mup);
-      double M = (TDi[k] - tp) + xr * x;
-      if (k == 0) M += eps;
-      Dg[k] = ca * Dg[k] + cb * M;
-      TDo[k] = tp;
+      for (int k = 0; k < 9; ++k) {
+        xd[k] = k == 0 ? x : s_dbl[dpos + k];
+        pd[k] = k == 0 ? mup : s_dbl[128 + dpos + k];
+      }
+#pragma unroll
+      for (int g = 0; g < 9; g += 3) {  // three slots operation by operation
+#pragma unroll
+        for (int k = g; k < g + 3; ++k) q[k] = pd[k] * mup;
+#pragma unroll
+        for (int k = g; k < g + 3; ++k) w[k] = xd[k] * x;
+#pragma unroll
+        for (int k = g; k < g + 3; ++k) q[k] = t1 * q[k];
+#pragma unroll
+        for (int k = g; k < g + 3; ++k) Dg[k] = ca * Dg[k];
+#pragma unroll
+        for (int k = g; k < g + 3; ++k) m[k] = TDi[k] - q[k];
+#pragma unroll
+        for (int k = g; k < g + 3; ++k) TDo[k] = q[k];
+#pragma unroll
+        for (int k = g; k < g + 3; ++k) m[k] = m[k] + w[k];
+        if (g == 0) m[0] += eps;
+#pragma unroll
+        for (int k = g; k < g + 3; ++k) m[k] = cb * m[k];
+#pragma unroll
+        for (int k = g; k < g + 3; ++k) Dg[k] = Dg[k] + m[k];
+      }
     }
-    __builtin_amdgcn_sched_barrier(CIRC_SCHED_MASK);
+    CIRC_SCHED;
     double xc[3], pc[3];
 #pragma unroll
     for (int tj = 0; tj < 3; ++tj) {
@@ -1542,15 +1563,28 @@ __device__ __forceinline__ void adapt_am_chain_c64(const AdaptArgs& a, const int
 #pragma unroll
       for (int tj = 0; tj < ti; ++tj) {
         const int idx = ti * (ti + 1) / 2 + tj;
+        // the four elements of a tile operation by operation (independent instructions back to back, not four dependent chains)
+        double q[4], m[4], w[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const double tp = t1 * (pr[r] * pc[tj]);
-          const double M = (TMi[idx][r] - tp) + xr[r] * xc[tj];
-          Sg[idx][r] = ca * Sg[idx][r] + cb * M;
-          TMo[idx][r] = tp;
-        }
+        for (int r = 0; r < 4; ++r) q[r] = pr[r] * pc[tj];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = xr[r] * xc[tj];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q[r] = t1 * q[r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Sg[idx][r] = ca * Sg[idx][r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[r] = TMi[idx][r] - q[r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) TMo[idx][r] = q[r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[r] = m[r] + w[r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[r] = cb * m[r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Sg[idx][r] = Sg[idx][r] + m[r];
       }
-      __builtin_amdgcn_sched_barrier(CIRC_SCHED_MASK);
+      CIRC_SCHED;
     }
     mu = mup;
   };
