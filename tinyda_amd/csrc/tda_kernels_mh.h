@@ -1519,14 +1519,45 @@ __device__ __forceinline__ void adapt_am_chain_c64(const AdaptArgs& a, const int
     s_prm[ppos] = x;
     s_prm[W + ppos] = mup;
     __syncthreads();
-    // the diagonal blocks: slot k = the pair (16 b + (lc + k) mod 16, 16 b + lc)
-    {
-      double xd[9], pd[9], q[9], w[9], m[9];
+    // every operand of the state requested first: the diagonal slots' (slot k = the pair (16 b + (lc + k) mod 16, 16 b + lc)), the
+    // column operands and the three tile rows'
+    double xd[9], pd[9], xc[3], pc[3], xr[4][4], pr[4][4];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        xd[k] = k == 0 ? x : lds_b64(s_dbl + dpos + k);
-        pd[k] = k == 0 ? mup : lds_b64(s_dbl + VS + dpos + k);
-      }
+    for (int k = 0; k < 9; ++k) {
+      xd[k] = k == 0 ? x : lds_b64(s_dbl + dpos + k);
+      pd[k] = k == 0 ? mup : lds_b64(s_dbl + VS + dpos + k);
+    }
+#pragma unroll
+    for (int tj = 0; tj < 3; ++tj) {
+      xc[tj] = lds_b64(s_dbl + BS * tj + lc);
+      pc[tj] = lds_b64(s_dbl + VS + BS * tj + lc);
+    }
+#pragma unroll
+    for (int ti = 1; ti < 4; ++ti) {
+      const double2* __restrict__ q = reinterpret_cast<const double2*>(s_prm + 16 * ti + 4 * hi);
+      const double2 x01 = q[0], x23 = q[1], p01 = q[W / 2], p23 = q[W / 2 + 1];
+      xr[ti][0] = x01.x; xr[ti][1] = x01.y; xr[ti][2] = x23.x; xr[ti][3] = x23.y;
+      pr[ti][0] = p01.x; pr[ti][1] = p01.y; pr[ti][2] = p23.x; pr[ti][3] = p23.y;
+    }
+    // (t - 1)/t Sigma needs no operand: its 33 multiplications stand between the requests and the first wait (the scheduling barrier
+    // keeps the compiler from sinking them to their uses)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      Dg[k] = ca * Dg[k];
+      asm volatile("" : "+v"(Dg[k]));  // (an ordered no-op: the product exists before the barrier below)
+    }
+#pragma unroll
+    for (int ti = 1; ti < 4; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < ti; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          Sg[ti * (ti + 1) / 2 + tj][r] = ca * Sg[ti * (ti + 1) / 2 + tj][r];
+          asm volatile("" : "+v"(Sg[ti * (ti + 1) / 2 + tj][r]));
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      double q[9], w[9], m[9];
 #pragma unroll
       for (int g = 0; g < 9; g += 3) {  // three slots operation by operation
 #pragma unroll
@@ -1535,8 +1566,6 @@ __device__ __forceinline__ void adapt_am_chain_c64(const AdaptArgs& a, const int
         for (int k = g; k < g + 3; ++k) w[k] = xd[k] * x;
 #pragma unroll
         for (int k = g; k < g + 3; ++k) q[k] = t1 * q[k];
-#pragma unroll
-        for (int k = g; k < g + 3; ++k) Dg[k] = ca * Dg[k];
 #pragma unroll
         for (int k = g; k < g + 3; ++k) m[k] = TDi[k] - q[k];
 #pragma unroll
@@ -1550,35 +1579,19 @@ __device__ __forceinline__ void adapt_am_chain_c64(const AdaptArgs& a, const int
         for (int k = g; k < g + 3; ++k) Dg[k] = Dg[k] + m[k];
       }
     }
-    CIRC_SCHED;
-    double xc[3], pc[3];
-#pragma unroll
-    for (int tj = 0; tj < 3; ++tj) {
-      xc[tj] = lds_b64(s_dbl + BS * tj + lc);
-      pc[tj] = lds_b64(s_dbl + VS + BS * tj + lc);
-    }
 #pragma unroll
     for (int ti = 1; ti < 4; ++ti) {
-      double xr[4], pr[4];
-      {
-        const double2* __restrict__ q = reinterpret_cast<const double2*>(s_prm + 16 * ti + 4 * hi);
-        const double2 x01 = q[0], x23 = q[1], p01 = q[W / 2], p23 = q[W / 2 + 1];
-        xr[0] = x01.x; xr[1] = x01.y; xr[2] = x23.x; xr[3] = x23.y;
-        pr[0] = p01.x; pr[1] = p01.y; pr[2] = p23.x; pr[3] = p23.y;
-      }
 #pragma unroll
       for (int tj = 0; tj < ti; ++tj) {
         const int idx = ti * (ti + 1) / 2 + tj;
         // the four elements of a tile operation by operation (independent instructions back to back, not four dependent chains)
         double q[4], m[4], w[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) q[r] = pr[r] * pc[tj];
+        for (int r = 0; r < 4; ++r) q[r] = pr[ti][r] * pc[tj];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) w[r] = xr[r] * xc[tj];
+        for (int r = 0; r < 4; ++r) w[r] = xr[ti][r] * xc[tj];
 #pragma unroll
         for (int r = 0; r < 4; ++r) q[r] = t1 * q[r];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Sg[idx][r] = ca * Sg[idx][r];
 #pragma unroll
         for (int r = 0; r < 4; ++r) m[r] = TMi[idx][r] - q[r];
 #pragma unroll
@@ -1590,7 +1603,6 @@ __device__ __forceinline__ void adapt_am_chain_c64(const AdaptArgs& a, const int
 #pragma unroll
         for (int r = 0; r < 4; ++r) Sg[idx][r] = Sg[idx][r] + m[r];
       }
-      CIRC_SCHED;
     }
     mu = mup;
   };
