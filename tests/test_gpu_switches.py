@@ -98,6 +98,19 @@ def test_fused_swap_and_increments_equal_the_two_launches(what, tmp_path):
         assert np.array_equal(two[k], full2[k]), "circulant diagonal blocks (k_adapt) changed %s" % k
 
 
+@pytest.mark.parametrize("what", ["am_d40", "am_d33_ragged"])
+def test_circulant_diagonal_blocks_with_padded_parameters(what, tmp_path):
+    """the moment recursion with the diagonal blocks of Sigma as circulant slots (the default at 33 .. 64 parameters) against
+    full diagonal tiles (TINYDA_ADAPT_CIRC=0) where the 64-parameter instance is padded: the same operations per element -- every
+    record, Sigma, C, the scaling bitwise; in the one-launch boundary and in k_adapt alone"""
+    for extra in ({}, {"TINYDA_FUSE_ADAPT_CHOL": "0"}):
+        circ = _probe(what, dict(extra), tmp_path, "circ%d" % len(extra))
+        full = _probe(what, dict(extra, TINYDA_ADAPT_CIRC="0"), tmp_path, "full%d" % len(extra))
+        for k in circ:
+            assert np.array_equal(circ[k], full[k]), "circulant diagonal blocks changed %s (%s, %s)" % (k, what, extra)
+        assert 0.02 < circ["acc0"].mean() < 0.98 and np.abs(circ["C"]).max() > 0
+
+
 @pytest.mark.parametrize("what", ["aem_dense", "aem_dense_ragged", "aem_dense_da_pcn", "aem_dense_m200", "aem_dense_m200_ragged", "aem_dense_chunks"])
 def test_error_model_base_subchain_kernels_agree(what, tmp_path):
     """dense error model over linear levels: the base subchain on k_aem_base_steps (one pass over each chain's factor V per launch,

@@ -92,6 +92,8 @@ if __name__ == "__main__":
         res = hierarchy((128, 128), [70], "pcn", 2, N=32, error_model="state-independent")
     elif what == "am":
         res = single_am(N=96 - cut)
+    elif what in ("am_d40", "am_d33"):  # fewer than 64 parameters on the 64-parameter instances: padded rows / columns of Sigma
+        res = single_am(N=96 - cut, d=int(what[4:]), m=120, T=250)
     else:
         res = dream(N=512 - cut)
     np.savez(out, **res)
