@@ -175,6 +175,22 @@ def test_step_loops_hold_their_full_wait_count(loop_audit, prefix):
     assert st["vmcnt0"] <= cap, "%s (%s): %d `s_waitcnt vmcnt(0)` inside the step loop, %d allowed" % (name, what, st["vmcnt0"], cap)
 
 
+@pytest.mark.parametrize("prefix", ["_ZN3tda7k_adaptILi64ELb1EEE", "_ZN3tda18k_adapt_chol_applyILi64ELb1EEE"])
+def test_moment_recursion_state_loop(loop_audit, prefix):
+    """the state loop of the AdaptiveMetropolis moment recursion (a third of C2a's period, the loop with the most vector
+    instructions of its kernel; it stores nothing, so step_loop() does not find it): two states per pass, 264 operations per state
+    with the diagonal blocks as circulant slots and no register copies -- at most 640 vector instructions per pass (605 shipped; the tile
+    version: 2 x 394), nothing spilled, no flat access, the full waits are the state prefetch (one per state) + the coefficient refresh"""
+    hits = {k: v for k, v in loop_audit.items() if k.startswith(prefix)}
+    assert len(hits) == 1, (prefix, list(hits))
+    (name, r), = hits.items()
+    lo, hi, depth, st = max(r["loops"], key=lambda l: (l[3]["valu"], -l[2]))
+    assert st["mfma"] == 0 and st["lds"] >= 40, (name, st)  # it IS the state loop (operand exchange through LDS, no matrix instruction)
+    assert st["valu"] <= 640, "%s: %d vector instructions per pass of two states" % (name, st["valu"])
+    assert st["scratch"] == 0 and st["flat"] == 0, (name, st)
+    assert st["vmcnt0"] <= 4, (name, st)
+
+
 def test_no_level_kernel_reads_memory_through_flat_pointers(loop_audit):
     """every k_da_steps / k_ml_steps / k_mh_steps instance: no flat_load / flat_store anywhere (rounds 3-4 shipped 64 per three-level
     k_da_steps instance: LDS reads behind `s_waitcnt vmcnt(0) lgkmcnt(0)`)"""
